@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py -- scored tile-nodes/s of the TilinGNN graph-conv scoring forward on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" = one full TilinGNN.forward (ML_Solver.predict's network call,
+/root/reference/solver/ml_solver/ml_solver.py:39-43) over one synthetic super-graph whose
+inputs are already resident in HBM; graph preparation (int64 COO -> CSR, edge-type de-dup) is
+INSIDE the timed step (every greedy round of the reference presents a new sub-layout).
+Workload at N=1: BASELINE.json's metric configuration -- 100 000 nodes / 1 000 000 adjacency
+edges / 1 250 000 collision edges, 30-60-90 tile set (tile_count 2 -> Fx 3), T = 13 edge types
+(Fe 15), network_width 32, depth 20, fp32, seeded (BASELINE.json
+north_star "100k-node/1M-edge 30-60-90 super-graph").  At N GPUs the graph has N x 100 000
+nodes, node-range sharded (weak scaling); value = all nodes scored / max-over-ranks time.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, measured with HIP events on the
+launch stream in a second instrumented pass) and `cpu_baseline` (the CPU oracle = a port of the
+reference's op sequence, timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np
+import torch
+
+NODES_PER_GPU = 100_000
+ADJ_PER_GPU = 1_000_000
+COL_PER_GPU = 1_250_000
+TILE_COUNT, N_TYPES, WIDTH, DEPTH = 2, 13, 32, 20
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak = fp32 vector peak
+
+
+def nnconv_bytes(n, ea, t, c=32, s=4):
+    """ALGORITHMIC bytes of one NNConv-mean launch:
+    rowptr + src idx + type id (int32 here) + read h once + write out once + weight table."""
+    return (n + 1) * 4 + ea * 4 + ea * 4 + n * c * s + n * c * s + (t + 1) * c * c * s
+
+
+def nnconv_flops(n, ea, c=32):
+    return 2.0 * c * c * (ea + n)      # per edge one [1,C]x[C,C] product, per node the root term
+
+
+def gin_bytes(n, ec, c=32, s=4):
+    return (n + 1) * 4 + ec * 4 + 2 * n * c * s
+
+
+def forward_bytes(n, ea, ec, t, fe=15, fx=3, c=32, d=20, s=4):
+    """B_fwd of SURVEY.md section 8d (compulsory traffic of the whole forward)."""
+    api = 2 * 8 * (ea + ec) + ea * fe * 4 + n * fx * 4
+    b_nn = (n + 1) * 4 + ea * 4 + ea * 1 + 2 * n * c * s + t * c * c * s
+    b_gin = gin_bytes(n, ec, c, s)
+    b_mrg = 4 * n * c * s
+    return api + d * (b_nn + b_gin + b_mrg + n * c * s) + n * (d + 1) * c * s + n * 4
+
+
+def cpu_baseline(seed=11):
+    """The reference's CPU op sequence (oracle = port, incl. the materialised [Ea, C*C] tensor),
+    fp32, no_grad, train-mode BN, all host cores; bounded sample of the same generator."""
+    from oracle import tilingnn_oracle as orc
+    from tilingnn_amd.synth import make_super_graph
+    from tilingnn_amd.weights import make_state_dict
+    # torch CPU ops stop scaling (and then slow down) well before a 256-thread host is full: measured on
+    # the MI355X box (2 x EPYC 9575F): 8 thr 1121, 32 thr 1129, 64 thr 830, 128 thr 448, 256 thr 65 nodes/s.
+    cores = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    n, ea, ec = 20_000, 200_000, 250_000
+    sg = make_super_graph(n, ea, ec, tile_count=TILE_COUNT, n_edge_types=N_TYPES, seed=seed)
+    sd = make_state_dict(2 + N_TYPES, DEPTH, WIDTH, 1, TILE_COUNT + 1, seed=0)
+    x, adj, adj_attr, col, _ = sg.to_torch("cpu")
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        probs, _ = orc.tilingnn_forward(sd, x, adj, adj_attr, col)
+        dt = time.perf_counter() - t0
+    assert bool(torch.isfinite(probs).all())
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
+    except OSError:
+        pass
+    return {"value": n / dt, "unit": "nodes/s", "cores": cores, "kind": "port",
+            "sample": f"1 forward, N={n} Ea={ea} Ec={ec} (same generator, 1/5 of the GPU workload; cost is linear in Ea), "
+                      f"{dt:.1f} s, torch {torch.__version__} CPU, {model}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nodes-per-gpu", type=int, default=NODES_PER_GPU)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run with N ranks")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from tilingnn_amd import TilinGNN
+    from tilingnn_amd._lib import ModelDims, check, lib, ptr
+    from tilingnn_amd.synth import make_super_graph
+    from tilingnn_amd.weights import make_state_dict
+
+    scale = args.nodes_per_gpu / NODES_PER_GPU
+    n_total = args.nodes_per_gpu * world
+    ea_total, ec_total = int(ADJ_PER_GPU * scale) * world, int(COL_PER_GPU * scale) * world
+    sg = make_super_graph(n_total, ea_total, ec_total, tile_count=TILE_COUNT, n_edge_types=N_TYPES, seed=2)
+    fe, fx = 2 + N_TYPES, TILE_COUNT + 1
+    net = TilinGNN(adj_edge_features_dim=fe, network_depth=DEPTH, network_width=WIDTH, node_features_dim=fx)
+    net.load_state_dict(make_state_dict(fe, DEPTH, WIDTH, 1, fx, seed=0), strict=True)
+    net = net.to(dev).train()               # inference in train mode, as ml_solver.py:131 leaves it
+    net.cache_graph = False                 # graph preparation is part of every timed step
+
+    if world == 1:
+        x, adj, adj_attr, col, col_attr = sg.to_torch(dev)
+
+        def step():
+            return net(x=x, adj_e_index=adj, adj_e_features=adj_attr, col_e_idx=col, col_e_features=col_attr)[0]
+        n_local, ea_local, ec_local = n_total, ea_total, ec_total
+    else:
+        from tilingnn_amd.dist import ShardedTilinGNN
+        sharded = ShardedTilinGNN(net, sg, rank, world, dev)
+        step = sharded.step
+        n_local, ea_local, ec_local = sharded.n_local, sharded.ea_local, sharded.ec_local
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert bool(torch.isfinite(out).all())
+    ms_per_step = dt / args.steps * 1e3
+    value = n_total * args.steps / dt
+
+    # ---- cached-layout variant (prep amortised, e.g. repeated predict on one BrickLayout)
+    cached_ms = None
+    if world == 1:
+        net.cache_graph = True
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        cached_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        net.cache_graph = False
+
+    # ---- roofline of the dominant kernel: second, instrumented pass (HIP events on the launch stream)
+    roofline, class_ms = None, None
+    if world == 1:
+        from tilingnn_amd import ops
+        graph = ops.prepare_graph(n_total, adj, adj_attr, col)
+        dims = net._dims()
+        table, _ = net._param_table()
+        ws_bytes = lib.tgnn_forward_workspace_bytes(C.byref(dims), n_total, graph.n_types)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        probs = torch.empty(n_total, 1, dtype=torch.float32, device=dev)
+        ms = (C.c_float * 8)()
+        cnt = (C.c_int32 * 8)()
+        g = graph.c_struct()
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        for _ in range(args.steps):
+            check(lib.tgnn_forward_profiled(C.byref(dims), table, ptr(x), ptr(adj_attr), C.byref(g), 1, 0, ptr(probs),
+                                            ptr(ws), ws_bytes, stream, ms, cnt))
+        names = ["edge_weights", "dense_init", "nnconv", "gin", "bn_finalize", "merge", "dense_final", "-"]
+        class_ms = {names[i]: {"ms_per_forward": ms[i] / args.steps, "launches_per_forward": cnt[i] // args.steps}
+                    for i in range(7)}
+        dom = max(("nnconv", "gin", "dense_final"), key=lambda k: class_ms[k]["ms_per_forward"])
+        per_launch_s = class_ms["nnconv"]["ms_per_forward"] / max(1, class_ms["nnconv"]["launches_per_forward"]) * 1e-3
+        b_alg = nnconv_bytes(n_total, ea_total, graph.n_types)
+        roofline = {"kernel": "nnconv32_lds_kernel (NNConv mean scatter-add, per layer)", "bound": "hbm",
+                    "achieved": b_alg / per_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": b_alg / per_launch_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                    "algorithmic_bytes_per_launch": b_alg, "avg_launch_us": per_launch_s * 1e6,
+                    "flops_per_launch": nnconv_flops(n_total, ea_total),
+                    "achieved_tflops": nnconv_flops(n_total, ea_total) / per_launch_s / 1e12,
+                    "frac_of_f32_peak": nnconv_flops(n_total, ea_total) / per_launch_s / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                    "slowest_class": dom}
+        gl = class_ms["gin"]["ms_per_forward"] / max(1, class_ms["gin"]["launches_per_forward"]) * 1e-3
+        roofline["gin_kernel"] = {"avg_launch_us": gl * 1e6, "algorithmic_bytes_per_launch": gin_bytes(n_total, ec_total),
+                                  "achieved_GBs": gin_bytes(n_total, ec_total) / gl / 1e9}
+        roofline["whole_forward"] = {"algorithmic_bytes": forward_bytes(n_total, ea_total, ec_total, graph.n_types),
+                                     "frac_of_hbm_peak": forward_bytes(n_total, ea_total, ec_total, graph.n_types)
+                                     / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+    if rank == 0:
+        line = {
+            "metric": "scored tile-nodes/sec (GNN forward)", "value": value, "unit": "nodes/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"TilinGNN.forward on a seeded banded super-graph: {args.nodes_per_gpu} nodes / "
+                                   f"{int(ADJ_PER_GPU * scale)} adjacency edges / {int(COL_PER_GPU * scale)} collision edges "
+                                   f"per GPU, 30-60-90 (tile_count 2), T=13 edge types, width 32, depth 20, "
+                                   f"train-mode BatchNorm, graph prep included",
+                       "n_nodes": n_total, "n_adj_edges": ea_total, "n_col_edges": ec_total,
+                       "parallelism": "single GPU" if world == 1 else f"node-range shards x{world}, halo exchange + BN all-reduce (RCCL)"},
+            "roofline": roofline,
+        }
+        if cached_ms is not None:
+            line["cached_layout"] = {"ms_per_step": cached_ms, "value": n_total / (cached_ms * 1e-3)}
+        if class_ms is not None:
+            line["kernel_classes"] = class_ms
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+            line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

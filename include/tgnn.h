@@ -1,0 +1,234 @@
+/*
+ * tgnn.h -- C ABI of libtgnn.so: the MI355X (gfx950) implementation of TilinGNN's
+ * graph-conv scoring forward.
+ *
+ * The reference (xuhaocuhk/TilinGNN) has no FFI layer: its boundary for this path is the
+ * Python call
+ *     probs, *_ = network(x=, adj_e_index=, adj_e_features=, col_e_idx=, col_e_features=)
+ *     (solver/ml_solver/ml_solver.py:39-43, graph_networks/network_utils.py:11-15)
+ * and, one level down, the two PyTorch-Geometric layer calls
+ *     self.nnConv(x, edge_index, edge_features)    (graph_networks/layers/edge_conv.py:25)
+ *     self.ginConv(x, edge_index)                  (graph_networks/layers/coll_conv.py:25)
+ * This header is what a maintainer binds (ctypes) to replace those calls.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - all matrices are row-major fp32, indices at the API are int64 [2,E] exactly as the
+ *     reference passes them (row 0 = source, row 1 = destination; util/data_util.py:110-117),
+ *     internal CSR arrays are int32;
+ *   - functions enqueue work on `stream` (a hipStream_t) and return without synchronising,
+ *     except where the comment says "synchronises";
+ *   - nothing is allocated that outlives a call: scratch comes from the caller as (ws, ws_bytes),
+ *     sized by the matching *_workspace_bytes(); caller memory is never freed or resized;
+ *   - return value: 0 = ok, <0 = error (TGNN_ERR_*); tgnn_last_error() returns a thread-local
+ *     message for the last failing call on this thread;
+ *   - functions are re-entrant and hold no global mutable state.
+ */
+#ifndef TGNN_H
+#define TGNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TGNN_VERSION 100 /* 0.1.0 */
+
+#define TGNN_OK 0
+#define TGNN_ERR_INVALID_ARG (-1)
+#define TGNN_ERR_WORKSPACE (-2)   /* workspace too small */
+#define TGNN_ERR_LAUNCH (-3)      /* HIP launch / runtime failure */
+#define TGNN_ERR_UNSUPPORTED (-4) /* shape outside what the kernels are built for */
+#define TGNN_ERR_BAD_GRAPH (-5)   /* edge index out of [0, N) */
+
+/* activation codes (torch.nn.LeakyReLU() slope 0.01 / torch.nn.Sigmoid()) */
+#define TGNN_ACT_NONE 0
+#define TGNN_ACT_LEAKY_RELU 1
+#define TGNN_ACT_SIGMOID 2
+
+/* BatchNorm statistics record produced by tgnn_bn_finalize and consumed by the kernels that
+ * apply the normalisation while loading:  y = ((v - mean_hi) - mean_lo) * ginv + beta,
+ * ginv = gamma / sqrt(var_biased + eps).  Layout: float [4][F] = mean_hi, mean_lo, ginv, beta. */
+#define TGNN_BN_STAT_ROWS 4
+/* per-block partial sums: double [P][2][F] = sum(v), sum(v*v);  P <= TGNN_BN_MAX_PARTIALS */
+#define TGNN_BN_MAX_PARTIALS 512
+
+typedef void *tgnn_stream_t; /* hipStream_t */
+
+int tgnn_version(void);
+const char *tgnn_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Graph preparation (once per layout; the graph is constant across the 20 layers of a forward)
+ * ------------------------------------------------------------------------------------------ */
+
+/* CSR-by-destination of an edge_index [2,E] (int64).  Rows keep the ORIGINAL edge order (the
+ * order torch's CPU index_add_ accumulates in), so sums are reproducible run to run.
+ *   rowptr   int32 [N+1]
+ *   col_src  int32 [E]   source node of each CSR slot
+ *   col_eid  int32 [E]   original edge number of each CSR slot
+ * drop_self_loops != 0 removes (v,v) edges (GINConv semantics, PyG gin_conv.py); the number of
+ * kept edges is rowptr[N].  err_flag (int32 device word, may be NULL) is set to 1 when an index
+ * is outside [0,N); such edges are skipped. */
+size_t tgnn_csr_workspace_bytes(int64_t n_nodes, int64_t n_edges);
+int tgnn_csr_build(const int64_t *edge_index, int64_t n_edges, int64_t n_nodes, int drop_self_loops,
+                   int32_t *rowptr, int32_t *col_src, int32_t *col_eid, int32_t *err_flag,
+                   void *ws, size_t ws_bytes, tgnn_stream_t stream);
+
+/* Exact de-duplication of edge-attribute rows (K1 of SURVEY.md: the per-edge NNConv weight depends
+ * only on the attribute row; real layouts carry a small codebook -- 13 rows on the labyrinth set).
+ *   edge_type      int32 [E]  type id of every edge, ids numbered by first occurrence
+ *   type_rep_edge  int32 [E]  first n_types entries: an edge carrying that type's row
+ *   n_types        int32 device word
+ * Rows are compared bit-exactly after mapping -0.0 to +0.0. */
+size_t tgnn_edge_dedup_workspace_bytes(int64_t n_edges, int32_t fe);
+int tgnn_edge_type_dedup(const float *edge_attr, int64_t n_edges, int32_t fe, int32_t *edge_type,
+                         int32_t *type_rep_edge, int32_t *n_types, void *ws, size_t ws_bytes,
+                         tgnn_stream_t stream);
+
+/* out[i] = src[idx[i]] for int32 arrays (used to bring edge types into CSR order); an index outside
+ * [0, n_src) yields 0 (CSR slots beyond rowptr[N] are unspecified when edges were skipped). */
+int tgnn_gather_i32(const int32_t *src, int64_t n_src, const int32_t *idx, int64_t n, int32_t *out,
+                    tgnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-op entry points (the layer seams of the reference)
+ * ------------------------------------------------------------------------------------------ */
+
+/* GraphConv's edge MLP on the T representative rows (edge_conv.py:17-18: Fe->32->64->C*C, Sigmoid
+ * on all three layers):  wtab[t] = sigmoid(L3(sigmoid(L2(sigmoid(L1(edge_attr[type_rep_edge[t]])))))),
+ * stored [T][C][C] with flat index i*C+o exactly as NNConv's .view(-1, C_in, C_out).
+ * w1 [32,Fe] b1 [32] w2 [64,32] b2 [64] w3 [C*C,64] b3 [C*C]  (nn.Linear layout [out,in]). */
+int tgnn_edge_weight_table(const float *edge_attr, const int32_t *type_rep_edge, int32_t n_types, int32_t fe,
+                           const float *w1, const float *b1, const float *w2, const float *b2,
+                           const float *w3, const float *b3, int32_t c, float *wtab, tgnn_stream_t stream);
+
+/* NNConv(aggr="mean") + optional LeakyReLU (edge_conv.py:25-27):
+ *   out[v] = act( (1/max(deg_v,1)) * sum_{e: dst_e = v} h[src_e] . wtab[type_e]  +  h[v] . root + bias )
+ * h [N, C] with row stride ldh (floats); root [C_in, C_out]; out [N, C] dense.
+ * bn_partial (may be NULL): per-block column sums of the OUTPUT for the train-mode BatchNorm that
+ * follows (edge_conv.py:28-29); *n_partials_host receives the number of partial rows written. */
+int tgnn_nnconv_mean_fwd(const float *h, int64_t ldh, const int32_t *rowptr, const int32_t *col_src,
+                         const int32_t *col_type, const float *wtab, int32_t n_types, const float *root,
+                         const float *bias, int64_t n_nodes, int32_t c, int32_t act, float *out,
+                         double *bn_partial, int32_t *n_partials_host, tgnn_stream_t stream);
+
+/* GINConv + optional LeakyReLU (coll_conv.py:25-27):
+ *   z[v]  = (1+eps) * f(a[v]) + sum_{e: dst_e = v} f(a[src_e]),   f = identity or the BatchNorm
+ *           described by in_stat (lets layer i+1 read layer i's pre-BN activations directly);
+ *   out[v] = act( sigmoid(L3(sigmoid(L2(sigmoid(L1(z[v])))))) )   L1 [32,C] L2 [64,32] L3 [C,64].
+ * eps is the device buffer ginConv.eps [1].  z_scratch: [N, C] floats of caller scratch (the
+ * aggregate z travels through it between the gather kernel and the MFMA MLP kernel). */
+int tgnn_gin_fwd(const float *a, int64_t lda, const float *in_stat, const int32_t *rowptr,
+                 const int32_t *col_src, const float *eps, const float *w1, const float *b1,
+                 const float *w2, const float *b2, const float *w3, const float *b3, int64_t n_nodes,
+                 int32_t c, int32_t act, float *out, float *z_scratch, double *bn_partial,
+                 int32_t *n_partials_host, tgnn_stream_t stream);
+
+/* Linear_trans (layers/util.py:31-37) without its BatchNorm:  out = act(f(A) . W^T + b).
+ * A is given as ceil(in_dim/32) column blocks of 32: element (r, k) lives at
+ * a[(k/32)*a_kblock_stride + r*lda + k%32]  (row-major A: lda = in_dim, a_kblock_stride = 32;
+ * the [D+1][N][C] skip-connection buffer: lda = C = 32, a_kblock_stride = N*C).
+ * in_stat (may be NULL): BatchNorm of the PREVIOUS Linear_trans applied to A while loading.
+ * w [out_dim, in_dim]; out [N, out_dim] with row stride ldo. */
+int tgnn_dense_act_fwd(const float *a, int64_t lda, int64_t a_kblock_stride, const float *in_stat,
+                       const float *w, const float *b, int64_t n_rows, int32_t in_dim, int32_t out_dim,
+                       int32_t act, float *out, int64_t ldo, double *bn_partial, int32_t *n_partials_host,
+                       tgnn_stream_t stream);
+
+/* Train-mode BatchNorm1d statistics (fact 2 of SURVEY.md: the reference never leaves train mode).
+ * mode 0: partials -> stat (+ running stats)      single GPU
+ * mode 1: partials -> sums  (double [2][F])        multi GPU, before the all-reduce
+ * mode 2: sums     -> stat (+ running stats)      multi GPU, after the all-reduce
+ * n_rows_total = number of rows the statistics cover (all ranks).  running_mean / running_var /
+ * num_batches_tracked (int64) may be NULL; otherwise they are updated as torch does (momentum,
+ * unbiased variance). */
+int tgnn_bn_finalize(int32_t mode, const double *partials, int32_t n_partials, double *sums, int32_t f,
+                     int64_t n_rows_total, const float *gamma, const float *beta, float eps, float momentum,
+                     float *running_mean, float *running_var, int64_t *num_batches_tracked, float *stat,
+                     tgnn_stream_t stream);
+
+/* y = BatchNorm(v) for a dense [N, F] matrix given its stat record (used by the per-layer modules
+ * and tests; the fused forward never materialises this). */
+int tgnn_bn_apply(const float *v, int64_t ldv, const float *stat, int64_t n_rows, int32_t f, float *out,
+                  int64_t ldo, tgnn_stream_t stream);
+
+/* Branch merge (TilinGNN.py:64-71):  out = BN1(a1) * BN2(a2) [+ resid];  optionally also writes
+ * h2 = BN2(a2) (NULL to skip).  All [N, C] dense. */
+int tgnn_merge_fwd(const float *a1, const float *stat1, const float *a2, const float *stat2,
+                   const float *resid, int64_t n_nodes, int32_t c, float *out, float *h2_out,
+                   tgnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole forward: TilinGNN.forward (graph_networks/networks/TilinGNN.py:51-78)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct tgnn_model_dims {
+    int32_t node_features_dim;     /* Fx = tile_count + 1            (TilinGNN.py:19) */
+    int32_t adj_edge_features_dim; /* Fe                             (TilinGNN.py:15) */
+    int32_t network_width;         /* C                              (inputs/config.py:38) */
+    int32_t network_depth;         /* D                              (inputs/config.py:37) */
+    int32_t output_dim;            /* 1                              (TilinGNN.py:18) */
+} tgnn_model_dims;
+
+/* Number of entries of the `params` pointer table for a model, and the key (state-dict name) of
+ * entry i.  The table is a HOST array of DEVICE pointers in exactly this order. */
+int32_t tgnn_param_count(const tgnn_model_dims *dims);
+int tgnn_param_name(const tgnn_model_dims *dims, int32_t index, char *buf, size_t buf_len);
+
+/* A prepared graph: device arrays owned by the caller (typically one torch buffer carved up). */
+typedef struct tgnn_graph {
+    int64_t n_nodes;
+    int64_t n_adj_edges;        /* CSR slots of the adjacency set (= Ea) */
+    int64_t n_col_edges;        /* CSR slots of the collision set after self-loop removal */
+    int32_t n_types;            /* T */
+    const int32_t *adj_rowptr;  /* [N+1] */
+    const int32_t *adj_src;     /* [Ea]  */
+    const int32_t *adj_type;    /* [Ea]  CSR order */
+    const int32_t *type_rep_edge; /* [T] original edge numbers */
+    const int32_t *col_rowptr;  /* [N+1] */
+    const int32_t *col_src;     /* [Ec'] */
+} tgnn_graph;
+
+size_t tgnn_forward_workspace_bytes(const tgnn_model_dims *dims, int64_t n_nodes, int32_t n_types);
+
+/* probs [N, output_dim].  BatchNorm runs with batch statistics and updates the running buffers
+ * in `params` when update_running != 0 (train mode); with use_running_stats != 0 it normalises
+ * with the running buffers instead (eval mode; never used by the reference's solver).
+ * The collision branch is enqueued on stream2 when stream2 != NULL (it does not depend on the
+ * adjacency branch, TilinGNN.py:63); the caller must have made stream2 wait for the inputs. */
+int tgnn_forward(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
+                 const float *adj_edge_attr, const tgnn_graph *graph, int32_t update_running,
+                 int32_t use_running_stats, float *probs, void *ws, size_t ws_bytes,
+                 tgnn_stream_t stream, tgnn_stream_t stream2);
+
+/* The same forward with a hipEvent pair around every launch (on `stream`, where the kernels run);
+ * synchronises, then ADDS the elapsed milliseconds and launch counts per kernel class into the
+ * two host arrays of TGNN_PROF_CLASSES entries.  Measurement aid for bench.py's roofline line. */
+#define TGNN_PROF_CLASSES 8
+#define TGNN_PROF_EDGE_WEIGHTS 0 /* edge MLP on T rows, all layers   */
+#define TGNN_PROF_DENSE_INIT 1   /* init MLP GEMMs + BN apply        */
+#define TGNN_PROF_NNCONV 2       /* NNConv mean (+LeakyReLU, BN sums) */
+#define TGNN_PROF_GIN 3          /* GIN aggregate + MLP              */
+#define TGNN_PROF_BN_FINALIZE 4
+#define TGNN_PROF_MERGE 5
+#define TGNN_PROF_DENSE_FINAL 6  /* final MLP GEMMs                  */
+int tgnn_forward_profiled(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
+                          const float *adj_edge_attr, const tgnn_graph *graph, int32_t update_running,
+                          int32_t use_running_stats, float *probs, void *ws, size_t ws_bytes,
+                          tgnn_stream_t stream, float *class_ms_host, int32_t *class_launches_host);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU helpers: node-range shards exchange boundary rows each layer (RCCL does the moving)
+ * ------------------------------------------------------------------------------------------ */
+/* out[i, :] = src[idx[i], :]  and  dst[idx[i], :] = in[i, :]   for [*, C] fp32 rows */
+int tgnn_rows_gather(const float *src, int64_t ld_src, const int32_t *idx, int64_t n_idx, int32_t c,
+                     float *out, tgnn_stream_t stream);
+int tgnn_rows_scatter(const float *in, const int32_t *idx, int64_t n_idx, int32_t c, float *dst,
+                      int64_t ld_dst, tgnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TGNN_H */

@@ -1,0 +1,112 @@
+"""ctypes binding of libtgnn.so (the C ABI declared in include/tgnn.h).
+
+The library is the product: there is NO CPU or eager-PyTorch fallback anywhere in this package.
+If the shared object has not been built, importing this module raises with the build command.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("TGNN_LIB_PATH") or os.path.join(_HERE, "libtgnn.so")   # override: kernel experiments only
+
+ACT_NONE, ACT_LEAKY_RELU, ACT_SIGMOID = 0, 1, 2
+BN_MAX_PARTIALS = 512
+BN_STAT_ROWS = 4
+
+
+class TgnnError(RuntimeError):
+    pass
+
+
+class ModelDims(C.Structure):
+    """tgnn_model_dims"""
+    _fields_ = [("node_features_dim", C.c_int32), ("adj_edge_features_dim", C.c_int32),
+                ("network_width", C.c_int32), ("network_depth", C.c_int32), ("output_dim", C.c_int32)]
+
+
+class Graph(C.Structure):
+    """tgnn_graph"""
+    _fields_ = [("n_nodes", C.c_int64), ("n_adj_edges", C.c_int64), ("n_col_edges", C.c_int64),
+                ("n_types", C.c_int32),
+                ("adj_rowptr", C.c_void_p), ("adj_src", C.c_void_p), ("adj_type", C.c_void_p),
+                ("type_rep_edge", C.c_void_p), ("col_rowptr", C.c_void_p), ("col_src", C.c_void_p)]
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Build it with\n"
+            f"    python -c 'import __graft_entry__ as g; g.build()'    (or: make -C tilingnn_amd/csrc)\n"
+            "tilingnn_amd has no CPU fallback by design.")
+    lib = C.CDLL(LIB_PATH)
+    p, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+    pi32 = C.POINTER(C.c_int32)
+    sigs = {
+        "tgnn_version": (C.c_int, []),
+        "tgnn_last_error": (C.c_char_p, []),
+        "tgnn_csr_workspace_bytes": (sz, [i64, i64]),
+        "tgnn_csr_build": (C.c_int, [p, i64, i64, C.c_int, p, p, p, p, p, sz, p]),
+        "tgnn_edge_dedup_workspace_bytes": (sz, [i64, i32]),
+        "tgnn_edge_type_dedup": (C.c_int, [p, i64, i32, p, p, p, p, sz, p]),
+        "tgnn_gather_i32": (C.c_int, [p, i64, p, i64, p, p]),
+        "tgnn_edge_weight_table": (C.c_int, [p, p, i32, i32, p, p, p, p, p, p, i32, p, p]),
+        "tgnn_nnconv_mean_fwd": (C.c_int, [p, i64, p, p, p, p, i32, p, p, i64, i32, i32, p, p, pi32, p]),
+        "tgnn_gin_fwd": (C.c_int, [p, i64, p, p, p, p, p, p, p, p, p, p, i64, i32, i32, p, p, p, pi32, p]),
+        "tgnn_dense_act_fwd": (C.c_int, [p, i64, i64, p, p, p, i64, i32, i32, i32, p, i64, p, pi32, p]),
+        "tgnn_bn_finalize": (C.c_int, [i32, p, i32, p, i32, i64, p, p, f32, f32, p, p, p, p, p]),
+        "tgnn_bn_apply": (C.c_int, [p, i64, p, i64, i32, p, i64, p]),
+        "tgnn_merge_fwd": (C.c_int, [p, p, p, p, p, i64, i32, p, p, p]),
+        "tgnn_param_count": (i32, [C.POINTER(ModelDims)]),
+        "tgnn_param_name": (C.c_int, [C.POINTER(ModelDims), i32, C.c_char_p, sz]),
+        "tgnn_forward_workspace_bytes": (sz, [C.POINTER(ModelDims), i64, i32]),
+        "tgnn_forward": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), p, p, C.POINTER(Graph), i32, i32,
+                                   p, p, sz, p, p]),
+        "tgnn_forward_profiled": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), p, p, C.POINTER(Graph), i32,
+                                            i32, p, p, sz, p, C.POINTER(C.c_float), pi32]),
+        "tgnn_rows_gather": (C.c_int, [p, i64, p, i64, i32, p, p]),
+        "tgnn_rows_scatter": (C.c_int, [p, p, i64, i32, p, i64, p]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)      # AttributeError here = header / library mismatch
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+EXPORTED_SYMBOLS = (
+    "tgnn_version", "tgnn_last_error", "tgnn_csr_workspace_bytes", "tgnn_csr_build",
+    "tgnn_edge_dedup_workspace_bytes", "tgnn_edge_type_dedup", "tgnn_gather_i32", "tgnn_edge_weight_table",
+    "tgnn_nnconv_mean_fwd", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
+    "tgnn_merge_fwd", "tgnn_param_count", "tgnn_param_name", "tgnn_forward_workspace_bytes", "tgnn_forward",
+    "tgnn_forward_profiled",
+    "tgnn_rows_gather", "tgnn_rows_scatter")
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = lib.tgnn_last_error()
+        raise TgnnError(f"libtgnn error {rc}: {msg.decode() if msg else '?'}")
+
+
+def ptr(t) -> C.c_void_p:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream(device) -> C.c_void_p:
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def param_names(dims: ModelDims):
+    n = lib.tgnn_param_count(C.byref(dims))
+    if n < 0:
+        raise TgnnError("invalid model dims")
+    buf = C.create_string_buffer(256)
+    out = []
+    for i in range(n):
+        check(lib.tgnn_param_name(C.byref(dims), i, buf, 256))
+        out.append(buf.value.decode())
+    return out

@@ -1,0 +1,219 @@
+// Train-mode BatchNorm1d statistics, BN apply, branch merge and row gather/scatter on gfx950.
+//
+// Reference: nn.BatchNorm1d instances inside Linear_trans (layers/util.py:28,35-36), GraphConv
+// (edge_conv.py:22,28-29) and CollConv (coll_conv.py:22,28-29) -- 46 per forward, ALL in train
+// mode because ML_Solver.load_saved_network ends with network.train() (ml_solver.py:129-131):
+// batch statistics over all N rows, running stats updated with momentum 0.1 / unbiased variance.
+// Branch merge: TilinGNN.forward, graph_networks/networks/TilinGNN.py:64-71.
+//
+// The producing kernels emit per-block fp64 column sums; tgnn_bn_finalize turns them into the
+// 4-row stat record consumed while loading (mean split hi/lo so that v - mean stays exact for the
+// near-constant columns the collision branch produces).  Deterministic: fixed reduction tree.
+#include "tgnn_common.h"
+
+namespace tgnn {
+
+// mode 0: partials->stat, 1: partials->sums, 2: sums->stat, 3: running stats->stat (eval mode)
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(BnJobs jobs, int mode, int f, int64_t n_total, float eps,
+                                                           float momentum) {
+    __shared__ double red[1024];
+    __shared__ double tot[512];
+    const BnJob jb = jobs.job[blockIdx.x];
+    const int tid = threadIdx.x, two_f = 2 * f;
+    if (mode == 3) {
+        if (tid < f) {
+            const double mean = (double)jb.running_mean[tid];
+            const double var = (double)jb.running_var[tid];
+            const float mh = (float)mean;
+            jb.stat[tid] = mh;
+            jb.stat[f + tid] = (float)(mean - (double)mh);
+            jb.stat[2 * f + tid] = (float)((double)jb.gamma[tid] / sqrt(var + (double)eps));
+            jb.stat[3 * f + tid] = jb.beta[tid];
+        }
+        return;
+    }
+    if (mode == 2) {
+        if (tid < two_f) tot[tid] = jb.sums[tid];
+    } else {
+        const int groups = 1024 / two_f;                     // >= 2 since F <= 256
+        const int j = tid % two_f, g = tid / two_f;
+        double acc = 0.0;
+        if (g < groups) {
+            // 8 independent loads in flight per thread (a plain loop pays one L2 round trip per partial)
+            const double *src = jb.partials + j;
+            int p = g;
+            for (; p + 7 * groups < jb.n_partials; p += 8 * groups) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(p + u * groups) * two_f];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+            for (; p < jb.n_partials; p += groups) acc += src[(int64_t)p * two_f];
+        }
+        red[tid] = acc;
+        __syncthreads();
+        if (tid < two_f) {
+            double t = 0.0;
+            for (int gg = 0; gg < groups; ++gg) t += red[gg * two_f + tid];
+            tot[tid] = t;
+            if (mode == 1) jb.sums[tid] = t;
+        }
+        if (mode == 1) return;
+    }
+    __syncthreads();
+    if (tid < f) {
+        const double inv_n = 1.0 / (double)n_total;
+        const double mean = tot[tid] * inv_n;
+        double var = tot[f + tid] * inv_n - mean * mean;     // biased; fp64 sums of fp32 data
+        if (var < 0.0) var = 0.0;
+        const float mh = (float)mean;
+        jb.stat[tid] = mh;
+        jb.stat[f + tid] = (float)(mean - (double)mh);
+        jb.stat[2 * f + tid] = (float)((double)jb.gamma[tid] / sqrt(var + (double)eps));
+        jb.stat[3 * f + tid] = jb.beta[tid];
+        if (jb.running_mean) {
+            const double unbiased = n_total > 1 ? var * ((double)n_total / (double)(n_total - 1)) : var;
+            jb.running_mean[tid] = (float)((1.0 - (double)momentum) * (double)jb.running_mean[tid] + (double)momentum * mean);
+            jb.running_var[tid] = (float)((1.0 - (double)momentum) * (double)jb.running_var[tid] + (double)momentum * unbiased);
+        }
+    }
+    if (tid == 0 && jb.num_batches_tracked) *jb.num_batches_tracked += 1;
+}
+
+__global__ void bn_apply_kernel(const float *__restrict__ v, int64_t ldv, const float *__restrict__ stat, int64_t n,
+                                int f, float *__restrict__ out, int64_t ldo) {
+    const int64_t total = n * f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / f;
+        const int c = (int)(i - r * f);
+        out[r * ldo + c] = bn_apply1(v[r * ldv + c], stat[c], stat[f + c], stat[2 * f + c], stat[3 * f + c]);
+    }
+}
+
+// out = BN1(a1) * BN2(a2) (+ resid); h2_out = BN2(a2) (optional).  float4 per thread, C % 4 == 0.
+__global__ __launch_bounds__(256) void merge_kernel(const float *__restrict__ a1, const float *__restrict__ st1,
+                                                    const float *__restrict__ a2, const float *__restrict__ st2,
+                                                    const float *__restrict__ resid, int64_t n4, int c,
+                                                    float *__restrict__ out, float *__restrict__ h2_out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)((i * 4) % c);
+        const float4 x1 = reinterpret_cast<const float4 *>(a1)[i];
+        const float4 x2 = reinterpret_cast<const float4 *>(a2)[i];
+        const float4 m1h = *reinterpret_cast<const float4 *>(st1 + col), m1l = *reinterpret_cast<const float4 *>(st1 + c + col);
+        const float4 g1 = *reinterpret_cast<const float4 *>(st1 + 2 * c + col), b1 = *reinterpret_cast<const float4 *>(st1 + 3 * c + col);
+        const float4 m2h = *reinterpret_cast<const float4 *>(st2 + col), m2l = *reinterpret_cast<const float4 *>(st2 + c + col);
+        const float4 g2 = *reinterpret_cast<const float4 *>(st2 + 2 * c + col), b2 = *reinterpret_cast<const float4 *>(st2 + 3 * c + col);
+        float4 y2, o;
+        y2.x = bn_apply1(x2.x, m2h.x, m2l.x, g2.x, b2.x);
+        y2.y = bn_apply1(x2.y, m2h.y, m2l.y, g2.y, b2.y);
+        y2.z = bn_apply1(x2.z, m2h.z, m2l.z, g2.z, b2.z);
+        y2.w = bn_apply1(x2.w, m2h.w, m2l.w, g2.w, b2.w);
+        o.x = bn_apply1(x1.x, m1h.x, m1l.x, g1.x, b1.x) * y2.x;
+        o.y = bn_apply1(x1.y, m1h.y, m1l.y, g1.y, b1.y) * y2.y;
+        o.z = bn_apply1(x1.z, m1h.z, m1l.z, g1.z, b1.z) * y2.z;
+        o.w = bn_apply1(x1.w, m1h.w, m1l.w, g1.w, b1.w) * y2.w;
+        if (resid) {
+            const float4 r = reinterpret_cast<const float4 *>(resid)[i];
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        reinterpret_cast<float4 *>(out)[i] = o;
+        if (h2_out) reinterpret_cast<float4 *>(h2_out)[i] = y2;
+    }
+}
+
+__global__ void rows_gather_kernel(const float *__restrict__ src, int64_t ld, const int *__restrict__ idx, int64_t n_idx,
+                                   int c, float *__restrict__ out) {
+    const int64_t total = n_idx * c;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / c;
+        const int k = (int)(i - r * c);
+        out[i] = src[(int64_t)idx[r] * ld + k];
+    }
+}
+
+__global__ void rows_scatter_kernel(const float *__restrict__ in, const int *__restrict__ idx, int64_t n_idx, int c,
+                                    float *__restrict__ dst, int64_t ld) {
+    const int64_t total = n_idx * c;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / c;
+        const int k = (int)(i - r * c);
+        dst[(int64_t)idx[r] * ld + k] = in[i];
+    }
+}
+
+static inline unsigned ew_grid(int64_t n, int cap = 256 * 8) {
+    int64_t g = (n + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+void launch_bn_finalize(const BnJobs &jobs, int n_jobs, int mode, int f, int64_t n_total, float eps, float momentum,
+                        hipStream_t s) {
+    bn_finalize_kernel<<<n_jobs, 1024, 0, s>>>(jobs, mode, f, n_total, eps, momentum);
+}
+
+}  // namespace tgnn
+
+using namespace tgnn;
+
+extern "C" int tgnn_bn_finalize(int32_t mode, const double *partials, int32_t n_partials, double *sums, int32_t f,
+                                int64_t n_rows_total, const float *gamma, const float *beta, float eps, float momentum,
+                                float *running_mean, float *running_var, int64_t *num_batches_tracked, float *stat,
+                                tgnn_stream_t stream) {
+    TGNN_CHECK_ARG(mode >= 0 && mode <= 3, "mode");
+    TGNN_CHECK_ARG(f >= 1 && f <= 256, "feature count must be in [1,256]");
+    TGNN_CHECK_ARG(mode == 3 || n_rows_total >= 1, "n_rows_total");
+    TGNN_CHECK_ARG(mode == 1 || (gamma && beta && stat), "null pointer");
+    TGNN_CHECK_ARG(!(mode == 0 || mode == 1) || (partials && n_partials >= 1 && n_partials <= TGNN_BN_MAX_PARTIALS), "partials");
+    TGNN_CHECK_ARG(!(mode == 1 || mode == 2) || sums, "sums");
+    TGNN_CHECK_ARG(mode != 3 || (running_mean && running_var), "running stats");
+    TGNN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running stats come in pairs");
+    BnJobs jobs{};
+    jobs.job[0] = BnJob{partials, n_partials, sums, gamma, beta, running_mean, running_var, num_batches_tracked, stat};
+    bn_finalize_kernel<<<1, 1024, 0, static_cast<hipStream_t>(stream)>>>(jobs, mode, f, n_rows_total, eps, momentum);
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}
+
+extern "C" int tgnn_bn_apply(const float *v, int64_t ldv, const float *stat, int64_t n_rows, int32_t f, float *out,
+                             int64_t ldo, tgnn_stream_t stream) {
+    if (n_rows <= 0) return TGNN_OK;
+    TGNN_CHECK_ARG(v && stat && out && f >= 1 && ldv >= f && ldo >= f, "arguments");
+    bn_apply_kernel<<<ew_grid(n_rows * f), 256, 0, static_cast<hipStream_t>(stream)>>>(v, ldv, stat, n_rows, f, out, ldo);
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}
+
+extern "C" int tgnn_merge_fwd(const float *a1, const float *stat1, const float *a2, const float *stat2,
+                              const float *resid, int64_t n_nodes, int32_t c, float *out, float *h2_out,
+                              tgnn_stream_t stream) {
+    if (n_nodes <= 0) return TGNN_OK;
+    TGNN_CHECK_ARG(a1 && stat1 && a2 && stat2 && out, "null pointer");
+    TGNN_CHECK_ARG(c >= 4 && c % 4 == 0, "width must be a multiple of 4");
+    TGNN_CHECK_ARG(((uintptr_t)a1 | (uintptr_t)a2 | (uintptr_t)out | (uintptr_t)resid | (uintptr_t)h2_out |
+                    (uintptr_t)stat1 | (uintptr_t)stat2) % 16 == 0, "pointers must be 16-byte aligned");
+    const int64_t n4 = n_nodes * c / 4;
+    merge_kernel<<<ew_grid(n4), 256, 0, static_cast<hipStream_t>(stream)>>>(a1, stat1, a2, stat2, resid, n4, c, out, h2_out);
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}
+
+extern "C" int tgnn_rows_gather(const float *src, int64_t ld_src, const int32_t *idx, int64_t n_idx, int32_t c,
+                                float *out, tgnn_stream_t stream) {
+    if (n_idx <= 0) return TGNN_OK;
+    TGNN_CHECK_ARG(src && idx && out && c >= 1 && ld_src >= c, "arguments");
+    rows_gather_kernel<<<ew_grid(n_idx * c), 256, 0, static_cast<hipStream_t>(stream)>>>(src, ld_src, idx, n_idx, c, out);
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}
+
+extern "C" int tgnn_rows_scatter(const float *in, const int32_t *idx, int64_t n_idx, int32_t c, float *dst,
+                                 int64_t ld_dst, tgnn_stream_t stream) {
+    if (n_idx <= 0) return TGNN_OK;
+    TGNN_CHECK_ARG(in && idx && dst && c >= 1 && ld_dst >= c, "arguments");
+    rows_scatter_kernel<<<ew_grid(n_idx * c), 256, 0, static_cast<hipStream_t>(stream)>>>(in, idx, n_idx, c, dst, ld_dst);
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}

@@ -1,0 +1,189 @@
+// Dense Linear_trans blocks of TilinGNN on gfx950 matrix cores (K10 / K11 of SURVEY.md section 2b).
+//
+// Reference: Linear_trans.forward (/root/reference/graph_networks/layers/util.py:31-37) is
+// Linear -> activation -> BatchNorm1d(train); MLP (util.py:4-17) stacks them.  On the hot path
+// these are the init MLP [Fx->32->32] (TilinGNN.py:31), and the final MLP
+// [672->256->128->64->32] + Linear_trans(32->1, Sigmoid) (TilinGNN.py:45-48) -- the only
+// genuinely dense GEMMs of the forward (N x 0.43 MFLOP), hence MFMA.
+//
+// out = act( f(A) . W^T + b )   with f = the previous layer's BatchNorm applied while the A tile is
+// staged into LDS (so normalised activations are never written to HBM), and fp64 column sums of
+// `out` emitted for the BatchNorm that follows.  fp32 in / fp32 accumulate on
+// v_mfma_f32_32x32x2_f32: exact f32 (a k-ordered fma chain), 1e-5 parity needs no split tricks.
+//
+// Tiling: block = 4 waves, tile 128 rows x (32*NT) cols x 32 k; wave w owns rows [32w, 32w+32).
+// LDS rows are padded to 33 floats: the A/B fragment reads (lane&31 -> row, lane>>5 -> k) are
+// conflict free.  Blocks are persistent over row tiles so that one block = one BN partial row.
+#include "tgnn_common.h"
+
+namespace tgnn {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kBM = 128, kBK = 32, kLD = 33;
+
+template <int NT>
+__global__ __launch_bounds__(256) void dense_mfma_kernel(
+    const float *__restrict__ a, int64_t lda, int64_t a_kb_stride, const float *__restrict__ in_stat,
+    const float *__restrict__ w, const float *__restrict__ bias, int64_t n, int in_dim, int out_dim, int act,
+    float *__restrict__ out, int64_t ldo, double *__restrict__ bn_partial, int vec_a, int vec_w) {
+    constexpr int BN = 32 * NT;
+    __shared__ float As[kBM * kLD];
+    __shared__ float Bs[BN * kLD];
+    __shared__ double red[4 * 2 * BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.y * BN;
+    const int ktiles = (in_dim + kBK - 1) / kBK;
+    const int64_t row_tiles = (n + kBM - 1) / kBM;
+    const int frag_r = lane & 31, frag_k = lane >> 5;
+
+    double csum[NT], csq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) csum[nt] = csq[nt] = 0.0;
+
+    for (int64_t rt = blockIdx.x; rt < row_tiles; rt += gridDim.x) {
+        const int64_t m0 = rt * kBM;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+        for (int kt = 0; kt < ktiles; ++kt) {
+            // ---- stage A tile [128][32] (BatchNorm of the producer applied on the fly)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = tid + 256 * j, r = idx >> 3, q = idx & 7;
+                const int64_t row = m0 + r;
+                const int k = kt * kBK + 4 * q;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (row < n) {
+                    const float *src = a + (int64_t)kt * a_kb_stride + row * lda + 4 * q;
+                    if (vec_a && k + 3 < in_dim) {
+                        const float4 t4 = *reinterpret_cast<const float4 *>(src);
+                        v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (k + e < in_dim) v[e] = src[e];
+                    }
+                    if (in_stat) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (k + e < in_dim)
+                                v[e] = bn_apply1(v[e], in_stat[k + e], in_stat[in_dim + k + e],
+                                                 in_stat[2 * in_dim + k + e], in_stat[3 * in_dim + k + e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) As[r * kLD + 4 * q + e] = v[e];
+            }
+            // ---- stage W tile [BN][32]  (nn.Linear weight is [out, in]: k contiguous)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int idx = tid + 256 * j, r = idx >> 3, q = idx & 7;
+                const int col = n0 + r, k = kt * kBK + 4 * q;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (col < out_dim) {
+                    const float *src = w + (int64_t)col * in_dim + k;
+                    if (vec_w && k + 3 < in_dim) {
+                        const float4 t4 = *reinterpret_cast<const float4 *>(src);
+                        v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (k + e < in_dim) v[e] = src[e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Bs[r * kLD + 4 * q + e] = v[e];
+            }
+            __syncthreads();
+            const float *ap = As + (wave * 32 + frag_r) * kLD + frag_k;
+            const float *bp = Bs + frag_r * kLD + frag_k;
+#pragma unroll
+            for (int kk = 0; kk < kBK; kk += 2) {
+                const float av = ap[kk];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[nt * 32 * kLD + kk], acc[nt], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+        // ---- epilogue: bias, activation, store, BN partial sums.
+        // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = n0 + nt * 32 + frag_r;
+            const bool col_ok = col < out_dim;
+            const float b = col_ok ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * frag_k;
+                if (col_ok && row < n) {
+                    const float v = act_apply(acc[nt][r] + b, act);
+                    out[row * ldo + col] = v;
+                    csum[nt] += (double)v;
+                    csq[nt] += (double)v * (double)v;
+                }
+            }
+        }
+    }
+
+    if (bn_partial) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const double s = csum[nt] + __shfl_xor(csum[nt], 32, 64);
+            const double q = csq[nt] + __shfl_xor(csq[nt], 32, 64);
+            if (lane < 32) {
+                red[(wave * 2 + 0) * BN + nt * 32 + lane] = s;
+                red[(wave * 2 + 1) * BN + nt * 32 + lane] = q;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, cl = tid % BN;
+            const int col = n0 + cl;
+            if (col < out_dim) {
+                const double tot = red[(0 * 2 + which) * BN + cl] + red[(1 * 2 + which) * BN + cl] +
+                                   red[(2 * 2 + which) * BN + cl] + red[(3 * 2 + which) * BN + cl];
+                bn_partial[(int64_t)blockIdx.x * 2 * out_dim + (int64_t)which * out_dim + col] = tot;
+            }
+        }
+    }
+}
+
+}  // namespace tgnn
+
+using namespace tgnn;
+
+extern "C" int tgnn_dense_act_fwd(const float *a, int64_t lda, int64_t a_kblock_stride, const float *in_stat,
+                                  const float *w, const float *b, int64_t n_rows, int32_t in_dim, int32_t out_dim,
+                                  int32_t act, float *out, int64_t ldo, double *bn_partial,
+                                  int32_t *n_partials_host, tgnn_stream_t stream) {
+    TGNN_CHECK_ARG(n_rows >= 0 && in_dim >= 1 && out_dim >= 1, "shape");
+    TGNN_CHECK_ARG(act >= TGNN_ACT_NONE && act <= TGNN_ACT_SIGMOID, "activation");
+    if (n_rows == 0) {
+        if (n_partials_host) *n_partials_host = 0;
+        return TGNN_OK;
+    }
+    TGNN_CHECK_ARG(a && w && b && out, "null pointer");
+    TGNN_CHECK_ARG(ldo >= out_dim, "ldo");
+    TGNN_CHECK_ARG(in_dim <= kBK || lda >= kBK || a_kblock_stride == kBK, "A layout");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int vec_a = (lda % 4 == 0) && (a_kblock_stride % 4 == 0) && ((uintptr_t)a % 16 == 0);
+    const int vec_w = (in_dim % 4 == 0) && ((uintptr_t)w % 16 == 0);
+    const int blocks_x = producer_blocks(n_rows, kBM);
+    if (out_dim > 32) {
+        dim3 grid(blocks_x, (out_dim + 63) / 64);
+        dense_mfma_kernel<2><<<grid, 256, 0, s>>>(a, lda, a_kblock_stride, in_stat, w, b, n_rows, in_dim, out_dim, act,
+                                                  out, ldo, bn_partial, vec_a, vec_w);
+    } else {
+        dim3 grid(blocks_x, 1);
+        dense_mfma_kernel<1><<<grid, 256, 0, s>>>(a, lda, a_kblock_stride, in_stat, w, b, n_rows, in_dim, out_dim, act,
+                                                  out, ldo, bn_partial, vec_a, vec_w);
+    }
+    if (n_partials_host) *n_partials_host = blocks_x;
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}

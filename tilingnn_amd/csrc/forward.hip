@@ -1,0 +1,357 @@
+// Whole-network orchestration and C-ABI glue of libtgnn.so.
+//
+// tgnn_forward == TilinGNN.forward (/root/reference/graph_networks/networks/TilinGNN.py:51-78):
+//   :54     init MLP (2 x Linear -> LeakyReLU -> BN)                     dense_mfma + bn_finalize
+//   :59-71  D x { GraphConv(h1) || CollConv(h2); h1 = g1*h2 (+ middle[i-2]) }
+//                                                                       nnconv32 / gin32 / bn_finalize(x2) / merge
+//   :74-76  cat(middle) -> final MLP -> sigmoid                          dense_mfma reading the slot-major
+//                                                                       [D+1][N][C] buffer as K blocks
+// Data layout in HBM (all fp32, caller-provided workspace):
+//   mid   [D+1][N][C]   skip-connection maps; slot i+1 is written by merge_i, gathered by NNConv_{i+1}
+//                       and read as K-block i+1 by the final GEMM -- torch.cat never happens;
+//   a1    [N][C]        pre-BN GraphConv output of the current layer;
+//   a2    2 x [N][C]    pre-BN CollConv outputs, ping-pong: GIN_{i+1} reads a2[i] + stat2[i] and applies
+//                       the BatchNorm inside its neighbourhood sum (affine => commutes with the sum);
+//   wtab  [D][T][C*C]   per-layer per-edge-type NNConv matrices;
+//   BN partials (fp64) and stat records.
+#include <stdarg.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "tgnn_common.h"
+
+namespace tgnn {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- parameter table ---------------------------------------------------------------------
+// Order = registration order of the reference modules, minus the aliased
+// '<p>.nnConv.nn.*' entries (same tensors as '<p>.mlp.*', edge_conv.py:17-18).
+static void bn_names(std::vector<std::string> &v, const std::string &p) {
+    v.push_back(p + ".weight");
+    v.push_back(p + ".bias");
+    v.push_back(p + ".running_mean");
+    v.push_back(p + ".running_var");
+    v.push_back(p + ".num_batches_tracked");
+}
+static void lt_names(std::vector<std::string> &v, const std::string &p, bool bn) {
+    v.push_back(p + ".linear.weight");
+    v.push_back(p + ".linear.bias");
+    if (bn) bn_names(v, p + ".batch_norm");
+}
+
+static std::vector<std::string> param_names(const tgnn_model_dims &d) {
+    std::vector<std::string> v;
+    for (int l = 0; l < 2; ++l) lt_names(v, "init_node_feature_trans.mlp." + std::to_string(l), true);
+    for (int i = 0; i < d.network_depth; ++i) {
+        const std::string p1 = "brch_1_graph_conv_layers." + std::to_string(i);
+        for (int l = 0; l < 3; ++l) lt_names(v, p1 + ".mlp.mlp." + std::to_string(l), false);
+        v.push_back(p1 + ".nnConv.root");
+        v.push_back(p1 + ".nnConv.bias");
+        bn_names(v, p1 + ".batch_norm");
+        const std::string p2 = "brch_2_coll_conv_layers." + std::to_string(i);
+        v.push_back(p2 + ".ginConv.eps");
+        for (int l = 0; l < 3; ++l) lt_names(v, p2 + ".ginConv.nn.mlp." + std::to_string(l), false);
+        bn_names(v, p2 + ".batch_norm");
+    }
+    for (int l = 0; l < 4; ++l) lt_names(v, "final_mlp.0.mlp." + std::to_string(l), true);
+    lt_names(v, "final_mlp.1", false);
+    return v;
+}
+
+constexpr int kInitStride = 7, kLayerStride = 25, kFinalStride = 7;
+struct BnPtrs {
+    const float *gamma, *beta;
+    float *rm, *rv;
+    int64_t *nbt;
+};
+struct Params {
+    const void *const *p;
+    int depth;
+    const float *f(int i) const { return static_cast<const float *>(p[i]); }
+    BnPtrs bn(int i) const {
+        return BnPtrs{f(i), f(i + 1), const_cast<float *>(f(i + 2)), const_cast<float *>(f(i + 3)),
+                      const_cast<int64_t *>(static_cast<const int64_t *>(p[i + 4]))};
+    }
+    int init(int l) const { return l * kInitStride; }                // w, b, bn x5
+    int layer(int i) const { return 2 * kInitStride + i * kLayerStride; }
+    // layer block: 0-5 edge mlp (w1 b1 w2 b2 w3 b3), 6 root, 7 bias, 8-12 bn1, 13 eps, 14-19 gin mlp, 20-24 bn2
+    int fin(int l) const { return 2 * kInitStride + depth * kLayerStride + l * kFinalStride; }
+    int last() const { return fin(4); }
+};
+
+static bool dims_ok(const tgnn_model_dims *d) {
+    return d && d->node_features_dim >= 1 && d->adj_edge_features_dim >= 1 && d->adj_edge_features_dim <= 256 &&
+           d->network_width >= 4 && d->network_width % 4 == 0 && d->network_width <= 256 && d->network_depth >= 1 &&
+           d->network_depth <= kMaxDepth && d->output_dim >= 1 && d->output_dim <= 256;
+}
+
+struct Workspace {
+    float *mid, *a1, *a2[2], *t0, *f1, *f2, *f3, *f4, *wtab;
+    double *part1, *part2, *partf;
+    float *stat1, *stat2[2], *stat_i[2], *stat_f[4];
+    size_t bytes;
+};
+
+// ---- optional per-kernel-class timing (tgnn_forward_profiled) -----------------------------
+struct Prof {
+    hipStream_t s;
+    std::vector<hipEvent_t> ev;      // pairs
+    std::vector<int> slot;
+    bool on = false;
+    void begin(int sl) {
+        if (!on) return;
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        (void)hipEventRecord(a, s);
+        ev.push_back(a);
+        ev.push_back(b);
+        slot.push_back(sl);
+    }
+    void end() {
+        if (!on) return;
+        (void)hipEventRecord(ev.back(), s);
+    }
+    void collect(float *ms_out, int32_t *count_out) {
+        if (!on) return;
+        (void)hipStreamSynchronize(s);
+        for (size_t i = 0; i < slot.size(); ++i) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
+            ms_out[slot[i]] += ms;
+            count_out[slot[i]] += 1;
+            (void)hipEventDestroy(ev[2 * i]);
+            (void)hipEventDestroy(ev[2 * i + 1]);
+        }
+    }
+};
+
+static const int kFinalDims[4] = {256, 128, 64, 0};  // TilinGNN.py:46 hidden_layer_dims; [3] = C
+
+static Workspace carve(const tgnn_model_dims &d, int64_t n, int32_t n_types, void *ws, size_t ws_bytes) {
+    Carver cv(ws, ws_bytes);
+    const int c = d.network_width, D = d.network_depth;
+    Workspace w{};
+    w.mid = cv.take<float>((size_t)(D + 1) * n * c);
+    w.a1 = cv.take<float>((size_t)n * c);
+    w.a2[0] = cv.take<float>((size_t)n * c);
+    w.a2[1] = cv.take<float>((size_t)n * c);
+    w.t0 = cv.take<float>((size_t)n * c);
+    w.f1 = cv.take<float>((size_t)n * 256);
+    w.f2 = cv.take<float>((size_t)n * 128);
+    w.f3 = cv.take<float>((size_t)n * 64);
+    w.f4 = cv.take<float>((size_t)n * c);
+    w.wtab = cv.take<float>((size_t)D * (n_types > 0 ? n_types : 1) * c * c);
+    w.part1 = cv.take<double>((size_t)TGNN_BN_MAX_PARTIALS * 2 * c);
+    w.part2 = cv.take<double>((size_t)TGNN_BN_MAX_PARTIALS * 2 * c);
+    w.partf = cv.take<double>((size_t)TGNN_BN_MAX_PARTIALS * 2 * 256);
+    w.stat1 = cv.take<float>(4 * c);
+    w.stat2[0] = cv.take<float>(4 * c);
+    w.stat2[1] = cv.take<float>(4 * c);
+    w.stat_i[0] = cv.take<float>(4 * c);
+    w.stat_i[1] = cv.take<float>(4 * c);
+    for (int l = 0; l < 4; ++l) w.stat_f[l] = cv.take<float>(4 * 256);
+    w.bytes = cv.off + 256;
+    return w;
+}
+
+}  // namespace tgnn
+
+using namespace tgnn;
+
+extern "C" int tgnn_version(void) { return TGNN_VERSION; }
+extern "C" const char *tgnn_last_error(void) { return g_err; }
+
+extern "C" int32_t tgnn_param_count(const tgnn_model_dims *dims) {
+    if (!dims_ok(dims)) return -1;
+    return 2 * kInitStride + dims->network_depth * kLayerStride + 4 * kFinalStride + 2;
+}
+
+extern "C" int tgnn_param_name(const tgnn_model_dims *dims, int32_t index, char *buf, size_t buf_len) {
+    TGNN_CHECK_ARG(dims_ok(dims), "model dims");
+    TGNN_CHECK_ARG(buf && buf_len > 0, "buffer");
+    const std::vector<std::string> names = param_names(*dims);
+    TGNN_CHECK_ARG(index >= 0 && index < (int)names.size(), "index");
+    TGNN_CHECK_ARG(names[index].size() + 1 <= buf_len, "buffer too small");
+    memcpy(buf, names[index].c_str(), names[index].size() + 1);
+    return TGNN_OK;
+}
+
+extern "C" size_t tgnn_forward_workspace_bytes(const tgnn_model_dims *dims, int64_t n_nodes, int32_t n_types) {
+    if (!dims_ok(dims) || n_nodes < 0) return 0;
+    return carve(*dims, n_nodes, n_types, nullptr, 0).bytes;
+}
+
+#define TGNN_TRY(expr)               \
+    do {                             \
+        int rc__ = (expr);           \
+        if (rc__ != TGNN_OK) return rc__; \
+    } while (0)
+
+static int forward_impl(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
+                        const float *adj_edge_attr, const tgnn_graph *graph, int32_t update_running,
+                        int32_t use_running_stats, float *probs, void *ws, size_t ws_bytes, tgnn_stream_t stream,
+                        tgnn_stream_t stream2, Prof &prof) {
+    TGNN_CHECK_ARG(dims_ok(dims), "model dims");
+    TGNN_CHECK_ARG(params_host && graph && probs && x, "null pointer");
+    const int64_t n = graph->n_nodes;
+    TGNN_CHECK_ARG(n >= 1, "empty graph");
+    TGNN_CHECK_ARG(use_running_stats || n >= 2, "train-mode BatchNorm needs more than one row");
+    TGNN_CHECK_ARG(graph->adj_rowptr && graph->col_rowptr, "graph pointers");
+    TGNN_CHECK_ARG(graph->n_types == 0 || (adj_edge_attr && graph->type_rep_edge && graph->adj_src && graph->adj_type),
+                   "adjacency pointers");
+    const int np = tgnn_param_count(dims);
+    for (int i = 0; i < np; ++i)
+        if (!params_host[i]) {
+            set_error("tgnn_forward: params_host[%d] is null", i);
+            return TGNN_ERR_INVALID_ARG;
+        }
+    Workspace w = carve(*dims, n, graph->n_types, ws, ws_bytes);
+    if (!ws || w.bytes > ws_bytes) {
+        set_error("tgnn_forward: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
+        return TGNN_ERR_WORKSPACE;
+    }
+    (void)stream2;  // single-stream schedule in this version; see DESIGN.md
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    prof.s = s;
+    const int c = dims->network_width, D = dims->network_depth, fx = dims->node_features_dim,
+              fe = dims->adj_edge_features_dim, T = graph->n_types;
+    const Params P{params_host, D};
+    const float eps = 1e-5f, momentum = 0.1f;  // torch.nn.BatchNorm1d defaults
+    const int fin_mode = use_running_stats ? 3 : 0;
+    int32_t np1 = 0, np2 = 0;
+
+    auto finalize1 = [&](double *part, int nparts, int f, const BnPtrs &b, float *stat) {
+        BnJobs jobs{};
+        jobs.job[0] = BnJob{part, nparts, nullptr, b.gamma, b.beta, (update_running || use_running_stats) ? b.rm : nullptr,
+                            (update_running || use_running_stats) ? b.rv : nullptr,
+                            (update_running && !use_running_stats) ? b.nbt : nullptr, stat};
+        prof.begin(4);
+        launch_bn_finalize(jobs, 1, fin_mode, f, n, eps, momentum, s);
+        prof.end();
+    };
+
+    // ---- K1: per-type NNConv matrices of all layers, one launch
+    if (T > 0) {
+        EdgeMlpLayers layers{};
+        for (int i = 0; i < D; ++i) {
+            const int b = P.layer(i);
+            layers.l[i] = EdgeMlpLayer{P.f(b), P.f(b + 1), P.f(b + 2), P.f(b + 3), P.f(b + 4), P.f(b + 5)};
+        }
+        prof.begin(0);
+        launch_edge_weight_table_batched(adj_edge_attr, graph->type_rep_edge, T, fe, layers, D, c, w.wtab, s);
+        prof.end();
+    }
+
+    // ---- K10: init MLP  (TilinGNN.py:54)
+    prof.begin(1);
+    TGNN_TRY(tgnn_dense_act_fwd(x, fx, 32, nullptr, P.f(P.init(0)), P.f(P.init(0) + 1), n, fx, c, TGNN_ACT_LEAKY_RELU,
+                                w.t0, c, w.partf, &np1, s));
+    prof.end();
+    finalize1(w.partf, np1, c, P.bn(P.init(0) + 2), w.stat_i[0]);
+    prof.begin(1);
+    TGNN_TRY(tgnn_dense_act_fwd(w.t0, c, 32, w.stat_i[0], P.f(P.init(1)), P.f(P.init(1) + 1), n, c, c,
+                                TGNN_ACT_LEAKY_RELU, w.a1, c, w.partf, &np1, s));
+    prof.end();
+    finalize1(w.partf, np1, c, P.bn(P.init(1) + 2), w.stat_i[1]);
+    prof.begin(1);
+    TGNN_TRY(tgnn_bn_apply(w.a1, c, w.stat_i[1], n, c, w.mid, c, s));  // middle[0] = brch_1 = brch_2 (:55,58)
+    prof.end();
+
+    // ---- main loop (TilinGNN.py:59-71)
+    for (int i = 0; i < D; ++i) {
+        const int b = P.layer(i);
+        const float *h1 = w.mid + (size_t)i * n * c;
+        // GraphConv (:62): NNConv mean + LeakyReLU; BN statistics emitted as partials
+        prof.begin(2);
+        TGNN_TRY(tgnn_nnconv_mean_fwd(h1, c, graph->adj_rowptr, graph->adj_src, graph->adj_type,
+                                      w.wtab + (size_t)i * T * c * c, T, P.f(b + 6), P.f(b + 7), n, c,
+                                      TGNN_ACT_LEAKY_RELU, w.a1, w.part1, &np1, s));
+        prof.end();
+        // CollConv (:63): input = BN_{i-1}(a2_{i-1}) folded into the gather; layer 0 reads middle[0]
+        const float *gin_in = i == 0 ? w.mid : w.a2[(i - 1) & 1];
+        const float *gin_stat = i == 0 ? nullptr : w.stat2[(i - 1) & 1];
+        prof.begin(3);
+        TGNN_TRY(tgnn_gin_fwd(gin_in, c, gin_stat, graph->col_rowptr, graph->col_src, P.f(b + 13), P.f(b + 14),
+                              P.f(b + 15), P.f(b + 16), P.f(b + 17), P.f(b + 18), P.f(b + 19), n, c,
+                              TGNN_ACT_LEAKY_RELU, w.a2[i & 1], w.t0, w.part2, &np2, s));
+        prof.end();
+        {
+            const BnPtrs b1 = P.bn(b + 8), b2 = P.bn(b + 20);
+            const bool run = update_running || use_running_stats;
+            BnJobs jobs{};
+            jobs.job[0] = BnJob{w.part1, np1, nullptr, b1.gamma, b1.beta, run ? b1.rm : nullptr, run ? b1.rv : nullptr,
+                                (update_running && !use_running_stats) ? b1.nbt : nullptr, w.stat1};
+            jobs.job[1] = BnJob{w.part2, np2, nullptr, b2.gamma, b2.beta, run ? b2.rm : nullptr, run ? b2.rv : nullptr,
+                                (update_running && !use_running_stats) ? b2.nbt : nullptr, w.stat2[i & 1]};
+            prof.begin(4);
+            launch_bn_finalize(jobs, 2, fin_mode, c, n, eps, momentum, s);
+            prof.end();
+        }
+        // merge (:64-71): middle[i+1] = BN1(a1) * BN2(a2) (+ middle[i-2])
+        const float *resid = i >= 2 ? w.mid + (size_t)(i - 2) * n * c : nullptr;
+        prof.begin(5);
+        TGNN_TRY(tgnn_merge_fwd(w.a1, w.stat1, w.a2[i & 1], w.stat2[i & 1], resid, n, c,
+                                w.mid + (size_t)(i + 1) * n * c, nullptr, s));
+        prof.end();
+    }
+
+    // ---- K11: final MLP over the concatenation (TilinGNN.py:74-76); K block kb = middle[kb]
+    const int cat_dim = c * (D + 1);
+    float *fbuf[4] = {w.f1, w.f2, w.f3, w.f4};
+    int fdim[5] = {cat_dim, kFinalDims[0], kFinalDims[1], kFinalDims[2], c};
+    for (int l = 0; l < 4; ++l) {
+        const int pi = P.fin(l);
+        if (l == 0) {
+            TGNN_CHECK_ARG(c == 32, "final MLP over the slot-major buffer needs network_width == 32");
+            prof.begin(6);
+            TGNN_TRY(tgnn_dense_act_fwd(w.mid, c, (int64_t)n * c, nullptr, P.f(pi), P.f(pi + 1), n, cat_dim, fdim[1],
+                                        TGNN_ACT_LEAKY_RELU, fbuf[0], fdim[1], w.partf, &np1, s));
+            prof.end();
+        } else {
+            prof.begin(6);
+            TGNN_TRY(tgnn_dense_act_fwd(fbuf[l - 1], fdim[l], 32, w.stat_f[l - 1], P.f(pi), P.f(pi + 1), n, fdim[l],
+                                        fdim[l + 1], TGNN_ACT_LEAKY_RELU, fbuf[l], fdim[l + 1], w.partf, &np1, s));
+            prof.end();
+        }
+        finalize1(w.partf, np1, fdim[l + 1], P.bn(pi + 2), w.stat_f[l]);
+    }
+    prof.begin(6);
+    TGNN_TRY(tgnn_dense_act_fwd(fbuf[3], c, 32, w.stat_f[3], P.f(P.last()), P.f(P.last() + 1), n, c, dims->output_dim,
+                                TGNN_ACT_SIGMOID, probs, dims->output_dim, nullptr, nullptr, s));
+    prof.end();
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}
+
+extern "C" int tgnn_forward(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
+                            const float *adj_edge_attr, const tgnn_graph *graph, int32_t update_running,
+                            int32_t use_running_stats, float *probs, void *ws, size_t ws_bytes, tgnn_stream_t stream,
+                            tgnn_stream_t stream2) {
+    Prof prof;
+    return forward_impl(dims, params_host, x, adj_edge_attr, graph, update_running, use_running_stats, probs, ws,
+                        ws_bytes, stream, stream2, prof);
+}
+
+extern "C" int tgnn_forward_profiled(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
+                                     const float *adj_edge_attr, const tgnn_graph *graph, int32_t update_running,
+                                     int32_t use_running_stats, float *probs, void *ws, size_t ws_bytes,
+                                     tgnn_stream_t stream, float *class_ms_host, int32_t *class_launches_host) {
+    TGNN_CHECK_ARG(class_ms_host && class_launches_host, "null profile arrays");
+    Prof prof;
+    prof.on = true;
+    const int rc = forward_impl(dims, params_host, x, adj_edge_attr, graph, update_running, use_running_stats, probs,
+                                ws, ws_bytes, stream, nullptr, prof);
+    prof.collect(class_ms_host, class_launches_host);
+    return rc;
+}

@@ -1,0 +1,407 @@
+// NNConv(aggr="mean") for TilinGNN's adjacency branch on gfx950 (K1-K4 of SURVEY.md section 2b).
+//
+// Reference semantics (GraphConv.forward, /root/reference/graph_networks/layers/edge_conv.py:24-27,
+// calling PyG 1.3.2 NNConv): every edge e carries a [C,C] matrix W_e = edge_mlp(edge_attr_e);
+//   out[v] = mean_{e: dst_e = v} h[src_e] . W_e  +  h[v] . root + bias          (+ LeakyReLU)
+// The reference materialises all E matrices (4 KB each, ~83 % of its forward time).  Edge
+// attributes come from a small codebook, so W_e = wtab[type_e] with T types (13 on real data):
+//   * tgnn_edge_weight_table evaluates the edge MLP on the T representative rows only;
+//   * tgnn_nnconv_mean_fwd keeps the T matrices (+ root as type T) resident in LDS and walks a
+//     destination-sorted CSR: one wavefront per destination row, no atomics, sums in the original
+//     edge order.
+//
+// nnconv_lds_kernel<32> lane mapping (wave64 = 4 DPP rows of 16 lanes):
+//     lane = 32*p + 16*s + c      p: which of two in-flight items (edges) of the row
+//                                 s: which half of the input channels, i in [16s, 16s+16)
+//                                 c: output channels c and c+16
+//   each lane loads ONE float of h[src] (h[src][16s+c]: the two rows of a pair read one 128-B line)
+//   and gets the 16 inputs of its half by DPP row broadcast (no LDS traffic for activations);
+//   the weights come from LDS as 8 x ds_read_b128 per item pair.  LDS image per type:
+//   [s][o][20] floats (16 used): bank(20*o) hits 16 distinct 4-bank slots, so every ds_read_b128
+//   lane group is conflict free.
+#include "tgnn_common.h"
+
+namespace tgnn {
+
+// ------------------------------------------------------------------------------------------
+// K1 on the T representative rows
+// ------------------------------------------------------------------------------------------
+constexpr int kEH1 = 32, kEH2 = 64;  // edge-MLP hidden sizes (edge_conv.py:9)
+
+// grid = (T, depth): blockIdx.y selects the layer
+__global__ __launch_bounds__(256) void edge_weight_table_kernel(
+    const float *__restrict__ edge_attr, const int *__restrict__ type_rep_edge, int fe, EdgeMlpLayers layers, int cc,
+    float *__restrict__ wtab_all) {
+    const EdgeMlpLayer L = layers.l[blockIdx.y];
+    const float *__restrict__ w1 = L.w1, *__restrict__ b1 = L.b1, *__restrict__ w2 = L.w2, *__restrict__ b2 = L.b2,
+                *__restrict__ w3 = L.w3, *__restrict__ b3 = L.b3;
+    float *__restrict__ wtab = wtab_all + (int64_t)blockIdx.y * gridDim.x * cc;
+    __shared__ float e_s[256];
+    __shared__ float h1_s[kEH1];
+    __shared__ float h2_s[kEH2];
+    const int t = blockIdx.x;
+    const int64_t row = type_rep_edge[t];
+    for (int k = threadIdx.x; k < fe; k += blockDim.x) e_s[k] = edge_attr[row * fe + k];
+    __syncthreads();
+    if (threadIdx.x < kEH1) {
+        float acc = b1[threadIdx.x];
+        for (int k = 0; k < fe; ++k) acc = fmaf(e_s[k], w1[threadIdx.x * fe + k], acc);
+        h1_s[threadIdx.x] = sigmoidf_(acc);
+    }
+    __syncthreads();
+    if (threadIdx.x < kEH2) {
+        float acc = b2[threadIdx.x];
+#pragma unroll
+        for (int k = 0; k < kEH1; ++k) acc = fmaf(h1_s[k], w2[threadIdx.x * kEH1 + k], acc);
+        h2_s[threadIdx.x] = sigmoidf_(acc);
+    }
+    __syncthreads();
+    // L3: [cc, 64] row-major.  One wave per output row chunk: lane = k, shuffle-reduce would cost
+    // more than it saves at T ~ 13; each thread owns outputs j, j+256, ... and reads its row as
+    // 16 x float4 (rows are 256-B aligned).
+    for (int j = threadIdx.x; j < cc; j += blockDim.x) {
+        const float4 *wr = reinterpret_cast<const float4 *>(w3 + (int64_t)j * kEH2);
+        float acc = b3[j];
+#pragma unroll
+        for (int q = 0; q < kEH2 / 4; ++q) {
+            const float4 w = wr[q];
+            acc = fmaf(h2_s[4 * q + 0], w.x, acc);
+            acc = fmaf(h2_s[4 * q + 1], w.y, acc);
+            acc = fmaf(h2_s[4 * q + 2], w.z, acc);
+            acc = fmaf(h2_s[4 * q + 3], w.w, acc);
+        }
+        wtab[(int64_t)t * cc + j] = sigmoidf_(acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// NNConv mean, C = 32, weight table in LDS
+// ------------------------------------------------------------------------------------------
+constexpr int kNNThreads = 1024;           // 16 waves = 4 per SIMD; one block per CU, one LDS image per CU
+constexpr int kNNWaves = kNNThreads / 64;
+constexpr int kTypeStride = 2 * 32 * 20;   // floats per type in LDS
+
+template <int K>
+__device__ __forceinline__ float row_bcast(float x) {  // lane K of every 16-lane DPP row -> whole row
+#ifdef TGNN_ABLATE_NO_DPP
+    return x;
+#else
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + K, 0xf, 0xf, true));
+#endif
+}
+
+#ifdef TGNN_ABLATE_NO_LDSW
+#define TGNN_LOADW(Q) const float4 wa = make_float4(bias0, bias1, bias0, bias1), wb = make_float4(bias1, bias0, bias1, bias0);
+#else
+#define TGNN_LOADW(Q) const float4 wa = wlo[Q], wb = whi[Q];
+#endif
+#define TGNN_FMA4(Q, XA, XB, XC, XD)                          \
+    {                                                         \
+        TGNN_LOADW(Q)                                         \
+        m0 = fmaf(XA, wa.x, m0); m1 = fmaf(XA, wb.x, m1);     \
+        m0 = fmaf(XB, wa.y, m0); m1 = fmaf(XB, wb.y, m1);     \
+        m0 = fmaf(XC, wa.z, m0); m1 = fmaf(XC, wb.z, m1);     \
+        m0 = fmaf(XD, wa.w, m0); m1 = fmaf(XD, wb.w, m1);     \
+    }
+
+// One item = one in-edge (or the root pseudo-edge) of the current row, for this lane's stream p.
+#ifdef TGNN_ABLATE_NO_FMA
+#define TGNN_ITEM(X, T, SCALE) { acc0 = fmaf((SCALE), (X), acc0); acc1 += (float)(T); }
+#else
+#define TGNN_ITEM(X, T, SCALE)                                                                        \
+    {                                                                                                 \
+        const float4 *wlo = reinterpret_cast<const float4 *>(lds + (T) * kTypeStride + lane_w_off);   \
+        const float4 *whi = wlo + 80; /* +16 outputs * 20 floats */                                   \
+        float m0 = 0.f, m1 = 0.f;                                                                     \
+        const float x_ = (X);                                                                         \
+        TGNN_FMA4(0, row_bcast<0>(x_), row_bcast<1>(x_), row_bcast<2>(x_), row_bcast<3>(x_))          \
+        TGNN_FMA4(1, row_bcast<4>(x_), row_bcast<5>(x_), row_bcast<6>(x_), row_bcast<7>(x_))          \
+        TGNN_FMA4(2, row_bcast<8>(x_), row_bcast<9>(x_), row_bcast<10>(x_), row_bcast<11>(x_))        \
+        TGNN_FMA4(3, row_bcast<12>(x_), row_bcast<13>(x_), row_bcast<14>(x_), row_bcast<15>(x_))      \
+        acc0 = fmaf((SCALE), m0, acc0);                                                               \
+        acc1 = fmaf((SCALE), m1, acc1);                                                               \
+    }
+#endif
+
+constexpr int kSlots = 8;  // items per stream held in registers: rows with in-degree <= 15 are fully pipelined
+
+__global__ __launch_bounds__(kNNThreads) void nnconv32_lds_kernel(
+    const float *__restrict__ h, int64_t ldh, const int *__restrict__ rowptr, const int *__restrict__ col_src,
+    const int *__restrict__ col_type, const float *__restrict__ wtab, int n_types, const float *__restrict__ root,
+    const float *__restrict__ bias, int64_t n, int act, float *__restrict__ out, double *__restrict__ bn_partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // ---- weight table (+ root as pseudo-type T) into LDS, transposed to [t][s][o][20]
+    // kNNThreads == 1024: thread r owns element r = i*32+o of every type; types are independent
+    // loads, issued 4 at a time.
+    {
+        const int r = threadIdx.x & 1023, i = r >> 5, o = r & 31;
+        const int dst = (i >> 4) * 640 + o * 20 + (i & 15);
+        int t = 0;
+        for (; t + 4 <= n_types; t += 4) {
+            const float v0 = wtab[(t + 0) * 1024 + r], v1 = wtab[(t + 1) * 1024 + r];
+            const float v2 = wtab[(t + 2) * 1024 + r], v3 = wtab[(t + 3) * 1024 + r];
+            lds[(t + 0) * kTypeStride + dst] = v0;
+            lds[(t + 1) * kTypeStride + dst] = v1;
+            lds[(t + 2) * kTypeStride + dst] = v2;
+            lds[(t + 3) * kTypeStride + dst] = v3;
+        }
+        for (; t < n_types; ++t) lds[t * kTypeStride + dst] = wtab[t * 1024 + r];
+        lds[n_types * kTypeStride + dst] = root[r];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = lane >> 5, s = (lane >> 4) & 1, c = lane & 15;
+    const float bias0 = bias[c], bias1 = bias[c + 16];
+    const int lane_w_off = s * 640 + c * 20;  // + t*kTypeStride; second accumulator: + 16*20
+    const int lane_x_off = 16 * s + c;
+
+    // XCD-aware row ownership: block b runs on XCD b % 8 (observed placement, speed only): give
+    // every XCD one contiguous node range so that its private L2 holds that range's activations.
+    const int nblk = gridDim.x, xcd = blockIdx.x & 7, bl = blockIdx.x >> 3;
+    int64_t r_beg = 0, r_end = n;
+    int wl = blockIdx.x * kNNWaves + wave, wcount = nblk * kNNWaves;
+    if (nblk >= 8) {
+        r_beg = n * xcd / 8;
+        r_end = n * (xcd + 1) / 8;
+        wl = bl * kNNWaves + wave;
+        wcount = (nblk >> 3) * kNNWaves;
+    }
+
+    double s0 = 0.0, s1 = 0.0, q0 = 0.0, q1 = 0.0;  // BN partials of this lane's two columns
+
+    // Software pipeline over this wave's rows (each stage one dependent-load level ahead):
+    //   A: rowptr of row v+3   B: col_src/col_type of row v+2   C: h[src] of row v+1   D: FMAs of row v
+    int beg_a = 0, deg_a = -1;                         // stage A result (row v+3 -> consumed by B)
+    int src_b[kSlots], typ_b[kSlots], deg_b = -1, beg_b = 0;      // stage B result (row v+2 -> consumed by C)
+    float x_c[kSlots]; int typ_c[kSlots], deg_c = -1, beg_c = 0;  // stage C result (row v+1 -> consumed by D)
+#pragma unroll
+    for (int k = 0; k < kSlots; ++k) { src_b[k] = -1; typ_b[k] = n_types; x_c[k] = 0.f; typ_c[k] = n_types; }
+
+    const int64_t v0 = r_beg + wl;
+    for (int64_t v = v0 - 3 * (int64_t)wcount; v < r_end; v += wcount) {
+        // ---------------- stage D operands are the registers filled by stage C one iteration ago
+        float x_d[kSlots]; int typ_d[kSlots];
+        const int deg_d = deg_c, beg_d = beg_c;
+#pragma unroll
+        for (int k = 0; k < kSlots; ++k) { x_d[k] = x_c[k]; typ_d[k] = typ_c[k]; }
+        // ---------------- stage C: gathers of row v+1 (indices loaded by stage B one iteration ago).
+        // Loads are unconditional (invalid slots read row 0 and are zeroed by a select): no branches,
+        // so all of a stage's loads issue back to back and stay in flight across the FMA block.
+        deg_c = deg_b; beg_c = beg_b;
+#pragma unroll
+        for (int k = 0; k < kSlots; ++k) {
+            typ_c[k] = typ_b[k];
+            const int sidx = src_b[k] >= 0 ? src_b[k] : 0;
+            const float xv = h[(int64_t)sidx * ldh + lane_x_off];
+            x_c[k] = src_b[k] >= 0 ? xv : 0.f;
+        }
+        // ---------------- stage B: edge indices of row v+2 (rowptr loaded by stage A one iteration ago)
+        const int64_t vb = v + 2 * (int64_t)wcount;
+        deg_b = deg_a; beg_b = beg_a;
+#pragma unroll
+        for (int k = 0; k < kSlots; ++k) {
+            const int j = p + 2 * k;
+            const bool is_edge = j < deg_b;
+            const int eidx = is_edge ? beg_b + j : 0;          // slot 0 of the CSR arrays always exists
+            const int sv = col_src[eidx], tv = col_type[eidx];
+            src_b[k] = is_edge ? sv : (j == deg_b ? (int)vb : -1);   // j == deg: root pseudo-edge reads h[v]
+            typ_b[k] = is_edge ? tv : n_types;
+        }
+        // ---------------- stage A: rowptr of row v+3
+        const int64_t va = v + 3 * (int64_t)wcount;
+        {
+            const bool ok = va >= v0 && va < r_end;
+            const int64_t vv = ok ? va : 0;
+            const int b0 = rowptr[vv], b1 = rowptr[vv + 1];
+            beg_a = b0;
+            deg_a = ok ? b1 - b0 : -1;
+        }
+        // ---------------- stage D: compute row v
+        if (deg_d < 0) continue;                        // pipeline fill / drain (wave-uniform)
+        const float inv_deg = 1.0f / (float)(deg_d > 0 ? deg_d : 1);
+        float acc0 = 0.f, acc1 = 0.f;
+        const int n_items = deg_d + 1;
+        const int n_iter = (n_items + 1) >> 1;          // iterations of the widest stream
+#pragma unroll
+        for (int k = 0; k < kSlots; ++k) {
+            if (k < n_iter) {                           // wave-uniform
+                const int j = p + 2 * k;
+                const float scale = j < deg_d ? inv_deg : (j == deg_d ? 1.0f : 0.0f);
+                TGNN_ITEM(x_d[k], typ_d[k], scale)
+            }
+        }
+        // rows with more than 2*kSlots-1 in-edges: remaining items, not pipelined (rare on tile graphs)
+        for (int j = p + 2 * kSlots; j <= deg_d; j += 2) {
+            const bool is_edge = j < deg_d;
+            const int src = is_edge ? col_src[beg_d + j] : (int)v;
+            const int t = is_edge ? col_type[beg_d + j] : n_types;
+            const float scale = is_edge ? inv_deg : 1.0f;
+            TGNN_ITEM(h[(int64_t)src * ldh + lane_x_off], t, scale)
+        }
+        // combine the two input halves (lanes ^16) and the two item streams (lanes ^32)
+        acc0 += __shfl_xor(acc0, 16, 64);
+        acc1 += __shfl_xor(acc1, 16, 64);
+        acc0 += __shfl_xor(acc0, 32, 64);
+        acc1 += __shfl_xor(acc1, 32, 64);
+        float o0 = acc0 + bias0, o1 = acc1 + bias1;
+        if (act == TGNN_ACT_LEAKY_RELU) {
+            o0 = leakyf_(o0);
+            o1 = leakyf_(o1);
+        }
+        if (lane < 16) {
+            out[v * 32 + c] = o0;
+            out[v * 32 + 16 + c] = o1;
+            s0 += (double)o0; q0 += (double)o0 * (double)o0;
+            s1 += (double)o1; q1 += (double)o1 * (double)o1;
+        }
+    }
+
+    if (bn_partial) {
+        __syncthreads();  // every wave is done with the weight image: reuse the front of LDS
+        double *red = reinterpret_cast<double *>(lds);
+        if (lane < 16) {
+            double *r = red + (wave * 16 + c) * 4;
+            r[0] = s0; r[1] = s1; r[2] = q0; r[3] = q1;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int q = threadIdx.x >> 4, cc = threadIdx.x & 15;
+            double tot = 0.0;
+            for (int w = 0; w < kNNWaves; ++w) tot += red[(w * 16 + cc) * 4 + q];
+            // partial row layout [2][32]: sum then sumsq; q = 0: sum col c, 1: sum col c+16, 2/3: sumsq
+            bn_partial[(int64_t)blockIdx.x * 64 + (q >> 1) * 32 + (q & 1) * 16 + cc] = tot;
+        }
+    }
+}
+#undef TGNN_ITEM
+#undef TGNN_FMA4
+
+// ------------------------------------------------------------------------------------------
+// Generic fallback (any C, any T): one thread per (row, output); weights read through L2.
+// Used when the table does not fit LDS or C != 32.  Correct, not fast.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nnconv_generic_kernel(
+    const float *__restrict__ h, int64_t ldh, const int *__restrict__ rowptr, const int *__restrict__ col_src,
+    const int *__restrict__ col_type, const float *__restrict__ wtab, const float *__restrict__ root,
+    const float *__restrict__ bias, int64_t n, int c, int act, float *__restrict__ out,
+    double *__restrict__ bn_partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [rows_per_block][c] staging of h rows
+    double *red = reinterpret_cast<double *>(lds);
+    const int rows_per_block = blockDim.x / c;
+    const int r_local = threadIdx.x / c, o = threadIdx.x % c;
+    const bool active_thread = r_local < rows_per_block;
+    double s = 0.0, q = 0.0;
+    for (int64_t base = (int64_t)blockIdx.x * rows_per_block; base < n; base += (int64_t)gridDim.x * rows_per_block) {
+        const int64_t v = base + r_local;
+        if (active_thread && v < n) {
+            const int beg = rowptr[v], deg = rowptr[v + 1] - beg;
+            float acc = 0.f;
+            for (int j = 0; j < deg; ++j) {
+                const float *x = h + (int64_t)col_src[beg + j] * ldh;
+                const float *w = wtab + (int64_t)col_type[beg + j] * c * c + o;
+                float m = 0.f;
+                for (int i = 0; i < c; ++i) m = fmaf(x[i], w[(int64_t)i * c], m);
+                acc += m;
+            }
+            acc *= 1.0f / (float)(deg > 0 ? deg : 1);
+            const float *x = h + v * ldh;
+            float m = 0.f;
+            for (int i = 0; i < c; ++i) m = fmaf(x[i], root[(int64_t)i * c + o], m);
+            float r = acc + m + bias[o];
+            if (act == TGNN_ACT_LEAKY_RELU) r = leakyf_(r);
+            out[v * c + o] = r;
+            s += (double)r;
+            q += (double)r * (double)r;
+        }
+    }
+    if (bn_partial) {
+        __syncthreads();
+        if (active_thread) {
+            red[threadIdx.x * 2] = s;
+            red[threadIdx.x * 2 + 1] = q;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < c) {
+            double ts = 0.0, tq = 0.0;
+            for (int r = 0; r < rows_per_block; ++r) {
+                ts += red[(r * c + threadIdx.x) * 2];
+                tq += red[(r * c + threadIdx.x) * 2 + 1];
+            }
+            bn_partial[(int64_t)blockIdx.x * 2 * c + threadIdx.x] = ts;
+            bn_partial[(int64_t)blockIdx.x * 2 * c + c + threadIdx.x] = tq;
+        }
+    }
+}
+
+constexpr size_t kMaxDynLds = 160 * 1024 - 256;
+
+void launch_edge_weight_table_batched(const float *edge_attr, const int *type_rep_edge, int n_types, int fe,
+                                      const EdgeMlpLayers &layers, int depth, int c, float *wtab, hipStream_t s) {
+    edge_weight_table_kernel<<<dim3(n_types, depth), 256, 0, s>>>(edge_attr, type_rep_edge, fe, layers, c * c, wtab);
+}
+
+}  // namespace tgnn
+
+using namespace tgnn;
+
+extern "C" int tgnn_edge_weight_table(const float *edge_attr, const int32_t *type_rep_edge, int32_t n_types,
+                                      int32_t fe, const float *w1, const float *b1, const float *w2,
+                                      const float *b2, const float *w3, const float *b3, int32_t c, float *wtab,
+                                      tgnn_stream_t stream) {
+    if (n_types <= 0) return TGNN_OK;
+    TGNN_CHECK_ARG(edge_attr && type_rep_edge && w1 && b1 && w2 && b2 && w3 && b3 && wtab, "null pointer");
+    TGNN_CHECK_ARG(fe >= 1 && fe <= 256, "edge feature dim must be in [1,256]");
+    TGNN_CHECK_ARG(c >= 1, "width");
+    TGNN_CHECK_ARG((uintptr_t)w3 % 16 == 0, "w3 must be 16-byte aligned");
+    EdgeMlpLayers layers{};
+    layers.l[0] = EdgeMlpLayer{w1, b1, w2, b2, w3, b3};
+    launch_edge_weight_table_batched(edge_attr, type_rep_edge, n_types, fe, layers, 1, c, wtab,
+                                     static_cast<hipStream_t>(stream));
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}
+
+extern "C" int tgnn_nnconv_mean_fwd(const float *h, int64_t ldh, const int32_t *rowptr, const int32_t *col_src,
+                                    const int32_t *col_type, const float *wtab, int32_t n_types,
+                                    const float *root, const float *bias, int64_t n_nodes, int32_t c, int32_t act,
+                                    float *out, double *bn_partial, int32_t *n_partials_host,
+                                    tgnn_stream_t stream) {
+    TGNN_CHECK_ARG(n_nodes >= 0 && c >= 1, "shape");
+    TGNN_CHECK_ARG(act == TGNN_ACT_NONE || act == TGNN_ACT_LEAKY_RELU, "activation");
+    if (n_nodes == 0) {
+        if (n_partials_host) *n_partials_host = 0;
+        return TGNN_OK;
+    }
+    TGNN_CHECK_ARG(h && rowptr && root && bias && out, "null pointer");
+    TGNN_CHECK_ARG(n_types == 0 || (col_src && col_type && wtab), "null graph pointer");
+    TGNN_CHECK_ARG(ldh >= c, "ldh");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t lds_bytes = (size_t)(n_types + 1) * kTypeStride * sizeof(float);
+    if (c == 32 && lds_bytes <= kMaxDynLds) {
+        static bool attr_set = false;  // idempotent, racing setters write the same value
+        if (!attr_set) {
+            TGNN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nnconv32_lds_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
+            attr_set = true;
+        }
+        // one wave per row; at least one row per wave; a multiple of 8 blocks for the XCD split;
+        // at most one block per CU (the LDS image is per block)
+        int blocks = producer_blocks(n_nodes, kNNWaves);
+        if (blocks > 256) blocks = 256;
+        if (blocks >= 8) blocks &= ~7;
+        nnconv32_lds_kernel<<<blocks, kNNThreads, lds_bytes, s>>>(h, ldh, rowptr, col_src, col_type, wtab, n_types,
+                                                                 root, bias, n_nodes, act, out, bn_partial);
+        if (n_partials_host) *n_partials_host = blocks;
+    } else {
+        TGNN_CHECK_ARG(c <= 256, "width must be <= 256");
+        const int rows_per_block = 256 / c;
+        const int blocks = producer_blocks(n_nodes, rows_per_block);
+        nnconv_generic_kernel<<<blocks, 256, 256 * 2 * sizeof(double), s>>>(h, ldh, rowptr, col_src, col_type, wtab,
+                                                                            root, bias, n_nodes, c, act, out,
+                                                                            bn_partial);
+        if (n_partials_host) *n_partials_host = blocks;
+    }
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}

@@ -1,0 +1,108 @@
+// Shared helpers for the gfx950 kernels of libtgnn.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/tgnn.h"
+
+namespace tgnn {
+
+constexpr int kWave = 64;                 // CDNA wavefront
+constexpr float kLeakySlope = 0.01f;      // torch.nn.LeakyReLU() default (TilinGNN.py:31)
+
+void set_error(const char *fmt, ...);     // thread-local message, api.hip
+
+#define TGNN_CHECK_ARG(cond, msg)                                                     \
+    do {                                                                              \
+        if (!(cond)) {                                                                \
+            ::tgnn::set_error("%s: invalid argument: %s (%s)", __func__, msg, #cond); \
+            return TGNN_ERR_INVALID_ARG;                                              \
+        }                                                                             \
+    } while (0)
+
+#define TGNN_CHECK_LAUNCH()                                                                 \
+    do {                                                                                    \
+        hipError_t e__ = hipGetLastError();                                                 \
+        if (e__ != hipSuccess) {                                                            \
+            ::tgnn::set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__));   \
+            return TGNN_ERR_LAUNCH;                                                         \
+        }                                                                                   \
+    } while (0)
+
+#define TGNN_CHECK_HIP(expr)                                                                \
+    do {                                                                                    \
+        hipError_t e__ = (expr);                                                            \
+        if (e__ != hipSuccess) {                                                            \
+            ::tgnn::set_error("%s: %s failed: %s", __func__, #expr, hipGetErrorString(e__)); \
+            return TGNN_ERR_LAUNCH;                                                         \
+        }                                                                                   \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Carves aligned sub-buffers out of a caller-provided workspace.
+struct Carver {
+    char *base;
+    size_t off = 0, cap;
+    Carver(void *p, size_t bytes) : base(static_cast<char *>(p)), cap(bytes) {}
+    template <typename T>
+    T *take(size_t count) {
+        off = align_up(off, 256);
+        T *p = reinterpret_cast<T *>(base + off);
+        off += count * sizeof(T);
+        return p;
+    }
+    bool ok() const { return off <= cap; }
+};
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == TGNN_ACT_LEAKY_RELU) return v >= 0.f ? v : v * kLeakySlope;
+    if (act == TGNN_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    return v;
+}
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+__device__ __forceinline__ float leakyf_(float v) { return v >= 0.f ? v : v * kLeakySlope; }
+
+// BatchNorm apply from a stat record [4][F] (mean_hi, mean_lo, ginv, beta) -- see tgnn.h
+__device__ __forceinline__ float bn_apply1(float v, float mhi, float mlo, float g, float b) {
+    return ((v - mhi) - mlo) * g + b;
+}
+
+// Number of persistent blocks for a row-parallel producer: also the number of BN partial rows.
+static inline int producer_blocks(int64_t n_rows, int rows_per_block) {
+    int64_t nb = (n_rows + rows_per_block - 1) / rows_per_block;
+    if (nb < 1) nb = 1;
+    if (nb > TGNN_BN_MAX_PARTIALS) nb = TGNN_BN_MAX_PARTIALS;
+    return static_cast<int>(nb);
+}
+
+// ---- internal launchers shared between translation units -------------------------------
+struct BnJob {
+    const double *partials;
+    int n_partials;
+    double *sums;  // mode 1 output / mode 2 input, [2][F]
+    const float *gamma, *beta;
+    float *running_mean, *running_var;
+    int64_t *num_batches_tracked;
+    float *stat;  // [4][F]
+};
+struct BnJobs {
+    BnJob job[2];
+};
+// one block per job (1 or 2 BatchNorms of the same width finalised by one launch); bn_merge.hip
+void launch_bn_finalize(const BnJobs &jobs, int n_jobs, int mode, int f, int64_t n_total, float eps, float momentum,
+                        hipStream_t s);
+
+// GraphConv edge-MLP parameters of up to 64 layers, passed by value to one batched launch; nnconv.hip
+struct EdgeMlpLayer {
+    const float *w1, *b1, *w2, *b2, *w3, *b3;
+};
+constexpr int kMaxDepth = 64;
+struct EdgeMlpLayers {
+    EdgeMlpLayer l[kMaxDepth];
+};
+// wtab [depth][T][C*C]
+void launch_edge_weight_table_batched(const float *edge_attr, const int *type_rep_edge, int n_types, int fe,
+                                      const EdgeMlpLayers &layers, int depth, int c, float *wtab, hipStream_t s);
+}  // namespace tgnn

@@ -1,0 +1,60 @@
+"""Identity-keyed cache of prepared graphs.
+
+A layout's graph is constant across the 20 layers of a forward and usually across several
+forwards (ML_Solver.solve calls predict on the same BrickLayout repeatedly), so the CSR /
+edge-type preparation is cached.  Entries are keyed by the IDENTITY and `_version` of the input
+tensors and hold references to them, so a recycled device address can never alias a stale entry."""
+from collections import OrderedDict
+
+from .. import ops
+
+_MAX = 4
+_entries = OrderedDict()
+enabled = True
+
+
+def _key(*tensors):
+    return tuple((id(t), t._version, tuple(t.shape)) for t in tensors)
+
+
+def _lookup(key, tensors, build):
+    if not enabled:
+        return build()
+    hit = _entries.get(key)
+    if hit is not None and all(a is b for a, b in zip(hit[0], tensors)):
+        _entries.move_to_end(key)
+        return hit[1]
+    val = build()
+    _entries[key] = (tensors, val)
+    while len(_entries) > _MAX:
+        _entries.popitem(last=False)
+    return val
+
+
+def clear():
+    _entries.clear()
+
+
+def get_full(n_nodes, adj_e_index, adj_e_features, col_e_idx):
+    ts = (adj_e_index, adj_e_features, col_e_idx)
+    return _lookup(("full", n_nodes) + _key(*ts), ts,
+                   lambda: ops.prepare_graph(n_nodes, adj_e_index, adj_e_features, col_e_idx))
+
+
+def get_adj(n_nodes, adj_e_index, adj_e_features):
+    """Graph with only the adjacency set prepared (stand-alone NNConv / GraphConv calls)."""
+    import torch
+    ts = (adj_e_index, adj_e_features)
+    empty = torch.empty(2, 0, dtype=torch.int64, device=adj_e_index.device)
+    return _lookup(("adj", n_nodes) + _key(*ts), ts,
+                   lambda: ops.prepare_graph(n_nodes, adj_e_index, adj_e_features, empty))
+
+
+def get_col(n_nodes, col_e_idx):
+    """Graph with only the collision set prepared (stand-alone GINConv / CollConv calls)."""
+    import torch
+    ts = (col_e_idx,)
+    empty_i = torch.empty(2, 0, dtype=torch.int64, device=col_e_idx.device)
+    empty_f = torch.empty(0, 1, dtype=torch.float32, device=col_e_idx.device)
+    return _lookup(("col", n_nodes) + _key(*ts), ts,
+                   lambda: ops.prepare_graph(n_nodes, empty_i, empty_f, col_e_idx))

@@ -1,0 +1,137 @@
+"""`TilinGNN` -- the scoring network, same constructor / forward / state-dict as the reference
+(/root/reference/graph_networks/networks/TilinGNN.py:13-78), executed by ONE C-ABI call
+(`tgnn_forward`, csrc/forward.hip) into hand-written gfx950 kernels.
+
+    network = TilinGNN(adj_edge_features_dim=..., network_depth=20, network_width=32).to("cuda")
+    probs, *_ = network(x=x, adj_e_index=ei, adj_e_features=ea, col_e_idx=ci, col_e_features=cf)
+
+drops into ML_Solver.predict (solver/ml_solver/ml_solver.py:39-43) unchanged.  Differences a
+caller can observe: outputs carry no autograd graph (forward only -- training is out of scope,
+SURVEY.md section 8f-4), and a CPU module raises instead of computing (no fallback by design).
+BatchNorm follows module.training exactly like torch: batch statistics + running-stat updates in
+train mode (which is how the reference runs inference, ml_solver.py:129-131), running statistics
+in eval mode.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from ... import _lib, ops
+from ..._lib import check, lib, ptr
+from .. import _graph_cache, _tracking
+from .._tracking import Tracked
+from ..layers.coll_conv import CollConv
+from ..layers.edge_conv import GraphConv
+from ..layers.util import MLP, Linear_trans
+
+
+def _default_node_features_dim():
+    """The reference evaluates `environment.tile_count + 1` at import (TilinGNN.py:19).  When this
+    module is dropped into the reference tree the same global is honoured."""
+    try:
+        from inputs.config import environment          # type: ignore
+        return environment.tile_count + 1
+    except Exception as exc:                            # noqa: BLE001
+        raise ValueError("node_features_dim not given and inputs.config.environment is not importable; "
+                         "pass node_features_dim=tile_count+1") from exc
+
+
+class TilinGNN(Tracked, nn.Module):
+    def __init__(self, adj_edge_features_dim, network_depth, network_width, output_dim=1, node_features_dim=None):
+        super().__init__()
+        if node_features_dim is None:
+            node_features_dim = _default_node_features_dim()
+        self.network_depth = network_depth
+        self.network_width = network_width
+        self.residual_skip_num = 2                                           # TilinGNN.py:25
+        self.adj_edge_features_dim = adj_edge_features_dim
+        self.node_features_dim = node_features_dim
+        self.output_dim = output_dim
+        self.brch_1_layer_feature_dims = [network_width] * (network_depth + 1)
+        self.brch_2_layer_feature_dims = [network_width] * (network_depth + 1)
+
+        self.init_node_feature_trans = MLP(in_dim=node_features_dim, out_dim=network_width,
+                                           hidden_layer_dims=[network_width], activation=torch.nn.LeakyReLU(),
+                                           batch_norm=True)
+        self.brch_1_graph_conv_layers = nn.ModuleList(
+            [GraphConv(edge_feature_dim=adj_edge_features_dim, node_feature_in_dim=network_width,
+                       node_feature_out_dim=network_width) for _ in range(network_depth)])
+        self.brch_2_coll_conv_layers = nn.ModuleList(
+            [CollConv(node_feature_in_dim=network_width, node_feature_out_dim=network_width)
+             for _ in range(network_depth)])
+        self.final_mlp = nn.Sequential(
+            MLP(in_dim=network_width * (network_depth + 1), out_dim=network_width, hidden_layer_dims=[256, 128, 64],
+                activation=torch.nn.LeakyReLU()),
+            Linear_trans(network_width, output_dim, activation=torch.nn.Sigmoid(), batch_norm=False))
+        self.cache_graph = True          # reuse the prepared CSR / edge types while the edge tensors are unchanged
+
+    # ---- host-side table of device pointers -------------------------------------------------
+    def _dims(self):
+        return _lib.ModelDims(self.node_features_dim, self.adj_edge_features_dim, self.network_width,
+                              self.network_depth, self.output_dim)
+
+    def _param_table(self):
+        cache = self.__dict__.get("_tgnn_table")
+        if cache is not None and cache[0] == _tracking.epoch():
+            return cache[1], cache[2]
+        dims = self._dims()
+        sd = dict(self.named_parameters())
+        sd.update(dict(self.named_buffers()))
+        names = _lib.param_names(dims)
+        table = (C.c_void_p * len(names))()
+        keep = []
+        dev = None
+        for i, name in enumerate(names):
+            t = sd[name]
+            if not t.is_cuda:
+                raise RuntimeError(f"tilingnn_amd.TilinGNN: parameter `{name}` is on {t.device}; call .to('cuda') "
+                                   "(there is no CPU path)")
+            want = torch.int64 if name.endswith("num_batches_tracked") else torch.float32
+            if t.dtype != want:
+                raise ValueError(f"parameter `{name}` must be {want}, got {t.dtype}")
+            if not t.is_contiguous():
+                raise ValueError(f"parameter `{name}` must be contiguous")
+            dev = dev or t.device
+            if t.device != dev:
+                raise ValueError("all parameters must live on one device")
+            table[i] = t.data_ptr()
+            keep.append(t)
+        self.__dict__["_tgnn_table"] = (_tracking.epoch(), table, dev, keep)
+        return table, dev
+
+    def __getstate__(self):                      # copy.deepcopy(network) (ml_solver.py:26) and pickling
+        state = self.__dict__.copy()
+        state.pop("_tgnn_table", None)
+        return state
+
+    # ---- forward ----------------------------------------------------------------------------
+    def forward(self, x, adj_e_index, adj_e_features, col_e_idx, col_e_features=None):
+        table, dev = self._param_table()
+        for name, t in (("x", x), ("adj_e_index", adj_e_index), ("adj_e_features", adj_e_features),
+                        ("col_e_idx", col_e_idx)):
+            if t.device != dev:
+                raise ValueError(f"`{name}` is on {t.device} but the network is on {dev}")
+        if x.dim() != 2 or x.shape[1] != self.node_features_dim:
+            raise ValueError(f"x must be [N, {self.node_features_dim}], got {tuple(x.shape)}")     # util.py:16
+        if adj_e_features.dim() != 2 or adj_e_features.shape[1] != self.adj_edge_features_dim:
+            raise ValueError(f"adj_e_features must be [Ea, {self.adj_edge_features_dim}], "
+                             f"got {tuple(adj_e_features.shape)}")
+        n = int(x.shape[0])
+        bn_train = self.training
+        if bn_train and n < 2:
+            raise ValueError("Expected more than 1 value per channel when training")
+        xf = ops._f32c(x, "x")
+        ea = ops._f32c(adj_e_features, "adj_e_features")
+        if self.cache_graph:
+            graph = _graph_cache.get_full(n, adj_e_index, adj_e_features, col_e_idx)
+        else:
+            graph = ops.prepare_graph(n, adj_e_index, adj_e_features, col_e_idx)
+        dims = self._dims()
+        ws_bytes = lib.tgnn_forward_workspace_bytes(C.byref(dims), n, graph.n_types)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        probs = torch.empty(n, self.output_dim, dtype=torch.float32, device=dev)
+        g = graph.c_struct()
+        check(lib.tgnn_forward(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), int(bn_train), int(not bn_train),
+                               ptr(probs), ptr(ws), ws_bytes, _lib.current_stream(dev), None))
+        return probs, adj_e_features                                          # TilinGNN.py:78

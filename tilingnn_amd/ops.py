@@ -1,0 +1,257 @@
+"""Torch-tensor front end of the libtgnn C ABI: validation, workspace allocation, stream plumbing.
+
+PyTorch is used here for device memory and streams only; every function below ends in exactly
+one (or a few) C-ABI calls into the hand-written gfx950 kernels -- there is no torch compute and
+no CPU path.  Shape / dtype / device errors raise ValueError before anything is launched
+(the reference's `assert x.shape[-1] == in_dim`, layers/util.py:16, becomes a ValueError).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LEAKY_RELU, ACT_NONE, ACT_SIGMOID, BN_MAX_PARTIALS, check, lib, ptr
+
+Tensor = torch.Tensor
+
+
+def _need_gpu(t: Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"tilingnn_amd: `{name}` lives on {t.device}; this package only runs on an AMD GPU "
+            "(no CPU fallback exists by design -- move the module and its inputs to 'cuda').")
+
+
+def _f32c(t: Tensor, name: str) -> Tensor:
+    _need_gpu(t, name)
+    if t.dtype != torch.float32:
+        raise ValueError(f"`{name}` must be float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _stream(t: Tensor) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def act_code(activation) -> int:
+    """Map the reference's activation modules (torch.nn.LeakyReLU() / torch.nn.Sigmoid() / None)."""
+    if activation is None:
+        return ACT_NONE
+    if isinstance(activation, torch.nn.LeakyReLU):
+        if abs(activation.negative_slope - 0.01) > 1e-12:
+            raise ValueError("only the default LeakyReLU slope 0.01 is built into the kernels")
+        return ACT_LEAKY_RELU
+    if isinstance(activation, torch.nn.Sigmoid):
+        return ACT_SIGMOID
+    raise ValueError(f"unsupported activation {activation!r} (kernels provide None / LeakyReLU() / Sigmoid())")
+
+
+# ----------------------------------------------------------------------------------------------
+# graph preparation
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class PreparedGraph:
+    """CSR-by-destination of both edge sets + edge-type ids; device int32 tensors."""
+    n_nodes: int
+    n_adj_edges: int
+    n_col_edges: int          # after GINConv's self-loop removal
+    n_types: int
+    adj_rowptr: Tensor
+    adj_src: Tensor
+    adj_eid: Tensor
+    adj_type: Tensor          # CSR order
+    edge_type: Tensor         # original edge order
+    type_rep_edge: Tensor
+    col_rowptr: Tensor
+    col_src: Tensor
+    col_eid: Tensor
+
+    def c_struct(self) -> _lib.Graph:
+        return _lib.Graph(self.n_nodes, self.n_adj_edges, self.n_col_edges, self.n_types,
+                          self.adj_rowptr.data_ptr(), self.adj_src.data_ptr(), self.adj_type.data_ptr(),
+                          self.type_rep_edge.data_ptr(), self.col_rowptr.data_ptr(), self.col_src.data_ptr())
+
+
+def _check_edge_index(ei: Tensor, name: str) -> Tensor:
+    _need_gpu(ei, name)
+    if ei.dtype != torch.int64:
+        raise ValueError(f"`{name}` must be int64 (torch .long()), got {ei.dtype}")
+    if ei.numel() == 0:
+        return ei.reshape(2, 0)
+    if ei.dim() != 2 or ei.shape[0] != 2:
+        raise ValueError(f"`{name}` must have shape [2, E], got {tuple(ei.shape)}")
+    return ei if ei.is_contiguous() else ei.contiguous()
+
+
+def build_csr(edge_index: Tensor, n_nodes: int, drop_self_loops: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """-> (rowptr [N+1], col_src [E], col_eid [E], err_flag [1]) int32; asynchronous."""
+    ei = _check_edge_index(edge_index, "edge_index")
+    dev, e = ei.device, int(ei.shape[1])
+    rowptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
+    col_src = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+    col_eid = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws_bytes = lib.tgnn_csr_workspace_bytes(n_nodes, e)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    check(lib.tgnn_csr_build(ptr(ei), e, n_nodes, int(drop_self_loops), ptr(rowptr), ptr(col_src), ptr(col_eid),
+                             ptr(err), ptr(ws), ws_bytes, _stream(ei)))
+    return rowptr, col_src, col_eid, err
+
+
+def dedup_edge_types(edge_attr: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """-> (edge_type [E], type_rep_edge [E] (first T valid), n_types [1]) int32; asynchronous."""
+    ea = _f32c(edge_attr, "edge_attr")
+    if ea.dim() != 2:
+        raise ValueError(f"`edge_attr` must be [E, Fe], got {tuple(ea.shape)}")
+    e, fe = int(ea.shape[0]), int(ea.shape[1])
+    dev = ea.device
+    edge_type = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+    rep = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+    n_types = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws_bytes = lib.tgnn_edge_dedup_workspace_bytes(e, fe)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    check(lib.tgnn_edge_type_dedup(ptr(ea), e, fe, ptr(edge_type), ptr(rep), ptr(n_types), ptr(ws), ws_bytes,
+                                   _stream(ea)))
+    return edge_type, rep, n_types
+
+
+def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col_e_idx: Tensor) -> PreparedGraph:
+    """Everything the 20 layers share: CSR of both edge sets, edge-type ids in CSR order.
+    Synchronises once (the type count and the self-loop-free collision edge count are read back)."""
+    adj = _check_edge_index(adj_e_index, "adj_e_index")
+    col = _check_edge_index(col_e_idx, "col_e_idx")
+    ea, ec = int(adj.shape[1]), int(col.shape[1])
+    if adj_e_features.shape[0] != ea:
+        raise ValueError(f"adj_e_features has {adj_e_features.shape[0]} rows for {ea} edges")
+    a_rowptr, a_src, a_eid, a_err = build_csr(adj, n_nodes, drop_self_loops=False)
+    c_rowptr, c_src, c_eid, c_err = build_csr(col, n_nodes, drop_self_loops=True)     # GINConv strips self loops
+    edge_type, rep, n_types = dedup_edge_types(adj_e_features)
+    adj_type = torch.empty(max(ea, 1), dtype=torch.int32, device=adj.device)
+    check(lib.tgnn_gather_i32(ptr(edge_type), ea, ptr(a_eid), ea, ptr(adj_type), _stream(adj)))
+    host = torch.cat([n_types, a_err, c_err, c_rowptr[n_nodes:n_nodes + 1]]).cpu().tolist()   # the one sync
+    if host[1] or host[2]:
+        raise IndexError(f"edge index out of range [0, {n_nodes}) in "
+                         f"{'adj_e_index' if host[1] else 'col_e_idx'}")
+    return PreparedGraph(n_nodes, ea, int(host[3]), int(host[0]), a_rowptr, a_src, a_eid, adj_type, edge_type, rep,
+                         c_rowptr, c_src, c_eid)
+
+
+# ----------------------------------------------------------------------------------------------
+# per-op wrappers (layer seams of the reference)
+# ----------------------------------------------------------------------------------------------
+def new_partials(f: int, device) -> Tensor:
+    return torch.empty(BN_MAX_PARTIALS * 2 * f, dtype=torch.float64, device=device)
+
+
+def edge_weight_table(edge_attr: Tensor, graph: PreparedGraph, w1, b1, w2, b2, w3, b3, c: int) -> Tensor:
+    """[T, C, C] NNConv matrices: GraphConv's edge MLP on the T distinct attribute rows."""
+    ea = _f32c(edge_attr, "edge_attr")
+    t, fe = graph.n_types, int(ea.shape[1])
+    if tuple(w1.shape) != (32, fe) or tuple(w2.shape) != (64, 32) or tuple(w3.shape) != (c * c, 64):
+        raise ValueError(f"edge-MLP shapes {tuple(w1.shape)} {tuple(w2.shape)} {tuple(w3.shape)} do not match "
+                         f"Fe={fe}, C={c}")
+    wtab = torch.empty(max(t, 1), c, c, dtype=torch.float32, device=ea.device)
+    ws = [_f32c(p, "edge mlp parameter") for p in (w1, b1, w2, b2, w3, b3)]
+    check(lib.tgnn_edge_weight_table(ptr(ea), ptr(graph.type_rep_edge), t, fe, *[ptr(p) for p in ws], c, ptr(wtab),
+                                     _stream(ea)))
+    return wtab[:t]
+
+
+def nnconv_mean(h: Tensor, graph: PreparedGraph, wtab: Tensor, root: Tensor, bias: Tensor, act: int = ACT_NONE,
+                partials: Optional[Tensor] = None) -> Tuple[Tensor, int]:
+    h = _f32c(h, "x")
+    n, c = int(h.shape[0]), int(h.shape[1])
+    if n != graph.n_nodes:
+        raise ValueError(f"x has {n} rows, the graph {graph.n_nodes} nodes")
+    if tuple(root.shape) != (c, c) or tuple(bias.shape) != (c,):
+        raise ValueError("NNConv root/bias shape mismatch")
+    out = torch.empty(n, c, dtype=torch.float32, device=h.device)
+    npart = C.c_int32(0)
+    wt = _f32c(wtab, "wtab")
+    check(lib.tgnn_nnconv_mean_fwd(ptr(h), c, ptr(graph.adj_rowptr), ptr(graph.adj_src), ptr(graph.adj_type), ptr(wt),
+                                   graph.n_types, ptr(_f32c(root, "root")), ptr(_f32c(bias, "bias")), n, c, act,
+                                   ptr(out), ptr(partials), C.byref(npart), _stream(h)))
+    return out, npart.value
+
+
+def gin(a: Tensor, graph: PreparedGraph, eps: Tensor, w1, b1, w2, b2, w3, b3, act: int = ACT_NONE,
+        in_stat: Optional[Tensor] = None, partials: Optional[Tensor] = None) -> Tuple[Tensor, int]:
+    a = _f32c(a, "x")
+    n, c = int(a.shape[0]), int(a.shape[1])
+    if n != graph.n_nodes:
+        raise ValueError(f"x has {n} rows, the graph {graph.n_nodes} nodes")
+    if tuple(w1.shape) != (32, c) or tuple(w2.shape) != (64, 32) or tuple(w3.shape) != (c, 64):
+        raise ValueError("GIN MLP shape mismatch")
+    out = torch.empty(n, c, dtype=torch.float32, device=a.device)
+    z_scratch = torch.empty(n, c, dtype=torch.float32, device=a.device)
+    npart = C.c_int32(0)
+    ps = [_f32c(p, "gin parameter") for p in (eps, w1, b1, w2, b2, w3, b3)]
+    check(lib.tgnn_gin_fwd(ptr(a), c, ptr(in_stat), ptr(graph.col_rowptr), ptr(graph.col_src), *[ptr(p) for p in ps],
+                           n, c, act, ptr(out), ptr(z_scratch), ptr(partials), C.byref(npart), _stream(a)))
+    return out, npart.value
+
+
+def dense_act(a: Tensor, weight: Tensor, bias: Tensor, act: int, in_stat: Optional[Tensor] = None,
+              partials: Optional[Tensor] = None) -> Tuple[Tensor, int]:
+    """act(BN_in(a) @ weight.T + bias) for a row-major [N, in] matrix."""
+    a = _f32c(a, "x")
+    if a.dim() != 2:
+        raise ValueError(f"expected a [N, F] matrix, got {tuple(a.shape)}")
+    n, k = int(a.shape[0]), int(a.shape[1])
+    m = int(weight.shape[0])
+    if int(weight.shape[1]) != k:
+        raise ValueError(f"Linear expects in_dim {int(weight.shape[1])}, got {k}")      # layers/util.py:16
+    out = torch.empty(n, m, dtype=torch.float32, device=a.device)
+    npart = C.c_int32(0)
+    check(lib.tgnn_dense_act_fwd(ptr(a), k, 32, ptr(in_stat), ptr(_f32c(weight, "weight")), ptr(_f32c(bias, "bias")),
+                                 n, k, m, act, ptr(out), m, ptr(partials), C.byref(npart), _stream(a)))
+    return out, npart.value
+
+
+def bn_finalize(partials: Tensor, n_partials: int, n_rows: int, bn: torch.nn.BatchNorm1d, update_running: bool,
+                mode: int = 0, sums: Optional[Tensor] = None) -> Optional[Tensor]:
+    """Train-mode statistics -> stat record [4, F]  (mode 1 returns None and fills `sums`)."""
+    f = bn.num_features
+    dev = bn.weight.device
+    stat = torch.empty(4, f, dtype=torch.float32, device=dev) if mode != 1 else None
+    upd = update_running and bn.track_running_stats and mode != 1
+    check(lib.tgnn_bn_finalize(mode, ptr(partials), n_partials, ptr(sums), f, n_rows, ptr(bn.weight), ptr(bn.bias),
+                               float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.1),
+                               ptr(bn.running_mean if upd or mode == 3 else None),
+                               ptr(bn.running_var if upd or mode == 3 else None),
+                               ptr(bn.num_batches_tracked if upd else None), ptr(stat), _stream(bn.weight)))
+    return stat
+
+
+def bn_apply(v: Tensor, stat: Tensor) -> Tensor:
+    v = _f32c(v, "x")
+    n, f = int(v.shape[0]), int(v.shape[1])
+    out = torch.empty_like(v)
+    check(lib.tgnn_bn_apply(ptr(v), f, ptr(stat), n, f, ptr(out), f, _stream(v)))
+    return out
+
+
+def batch_norm(v: Tensor, partials: Tensor, n_partials: int, bn: torch.nn.BatchNorm1d) -> Tensor:
+    """nn.BatchNorm1d forward on a [N, F] activation whose column sums are in `partials`:
+    batch statistics (and running-stat update) in train mode, running statistics in eval mode."""
+    n = int(v.shape[0])
+    if bn.training or not bn.track_running_stats:
+        if n < 2:
+            raise ValueError("Expected more than 1 value per channel when training")     # torch's own message
+        stat = bn_finalize(partials, n_partials, n, bn, update_running=True, mode=0)
+    else:
+        stat = bn_finalize(partials, max(n_partials, 1), max(n, 1), bn, update_running=False, mode=3)
+    return bn_apply(v, stat)
+
+
+def merge(a1: Tensor, stat1: Tensor, a2: Tensor, stat2: Tensor, resid: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
+    n, c = int(a1.shape[0]), int(a1.shape[1])
+    out = torch.empty_like(a1)
+    h2 = torch.empty_like(a1)
+    check(lib.tgnn_merge_fwd(ptr(a1), ptr(stat1), ptr(a2), ptr(stat2), ptr(resid), n, c, ptr(out), ptr(h2),
+                             _stream(a1)))
+    return out, h2

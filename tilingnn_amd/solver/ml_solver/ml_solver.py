@@ -1,0 +1,94 @@
+"""`ML_Solver` -- the boundary caller of the scoring path, mirroring the part of
+/root/reference/solver/ml_solver/ml_solver.py that sits on it:
+
+    predict(brick_layout)            ml_solver.py:29-49   (empty-edge early-out, forward, best-map pick)
+    get_predict_probs(brick_layout)  ml_solver.py:69-81
+    load_saved_network(path)         ml_solver.py:129-131 (load_state_dict + network.train())
+
+`solve` (the greedy assembly loop, util/algorithms.py:18-62) and the debug dumps stay with the
+reference: when this class is used inside the reference tree, pass `greedy_solver=` the
+reference's `algorithms.solve_by_probablistic_greedy`; SURVEY.md section 8f-1 ranks a device-side
+loop as the next row after the forward.
+
+`brick_layout` is duck-typed exactly as the reference uses it: `.node_feature`,
+`.align_edge_index`, `.collide_edge_index` (numpy) and `.get_data_as_torch_tensor(device)`.
+"""
+from copy import deepcopy
+
+import numpy as np
+import torch
+
+from ...graph_networks.network_utils import get_network_prediction
+
+
+class LayoutArrays:
+    """Minimal stand-in for tiling.brick_layout.BrickLayout's data side (brick_layout.py:242-246):
+    the five numpy arrays and the float32/int64 conversion of util/data_util.py:110-117."""
+
+    def __init__(self, node_feature, align_edge_index, align_edge_features, collide_edge_index,
+                 collide_edge_features):
+        self.node_feature = node_feature
+        self.align_edge_index = align_edge_index
+        self.align_edge_features = align_edge_features
+        self.collide_edge_index = collide_edge_index
+        self.collide_edge_features = collide_edge_features
+
+    def get_data_as_torch_tensor(self, device):
+        return (torch.from_numpy(self.node_feature).float().to(device),
+                torch.from_numpy(self.align_edge_index).long().to(device),
+                torch.from_numpy(self.align_edge_features).float().to(device),
+                torch.from_numpy(self.collide_edge_index).long().to(device),
+                torch.from_numpy(self.collide_edge_features).float().to(device))
+
+
+class ML_Solver:
+    def __init__(self, debugger, device, complete_graph, network, num_prob_maps, greedy_solver=None):
+        self.debugger = debugger
+        self.device = device
+        self.complete_graph = complete_graph
+        self.network = network
+        self.random_network = deepcopy(self.network)            # ml_solver.py:26
+        self.num_prob_maps = num_prob_maps
+        self._greedy_solver = greedy_solver
+
+    def predict(self, brick_layout):
+        if len(brick_layout.collide_edge_index) == 0 or len(brick_layout.align_edge_index) == 0:
+            # only one edge set left: select every remaining tile (ml_solver.py:31-32)
+            predictions = torch.ones((brick_layout.node_feature.shape[0], self.num_prob_maps)).float().to(self.device)
+        else:
+            x, adj_edge_index, adj_edge_features, collide_edge_index, collide_edge_features = \
+                brick_layout.get_data_as_torch_tensor(self.device)
+            predictions, *_ = self.network(x=x, adj_e_index=adj_edge_index, adj_e_features=adj_edge_features,
+                                           col_e_idx=collide_edge_index, col_e_features=collide_edge_features)
+        best_map_index = self._best_prob_map(predictions, brick_layout)
+        return predictions[:, best_map_index].detach().cpu().numpy()
+
+    def _best_prob_map(self, predictions, brick_layout):
+        """get_best_prob_map (ml_solver.py:133-136): argsort of the per-map unsupervised loss.
+        With one probability map -- the only configuration the reference ever constructs
+        (Tiling-Shape.py:37, Tiling-GUI.py:570) -- the answer is 0 without evaluating the loss."""
+        if predictions.shape[1] == 1:
+            return 0
+        raise NotImplementedError("num_prob_maps > 1 needs the loss kernel (SURVEY.md section 8f-2)")
+
+    def get_predict_probs(self, brick_layout):
+        x, adj_edge_index, adj_edge_features, collide_edge_index, collide_edge_features = \
+            brick_layout.get_data_as_torch_tensor(self.device)
+        return get_network_prediction(network=self.network, x=x, adj_e_index=adj_edge_index,
+                                      adj_e_features=adj_edge_features, col_e_idx=collide_edge_index,
+                                      col_e_features=collide_edge_features)
+
+    def solve(self, brick_layout):
+        if self._greedy_solver is None:
+            raise NotImplementedError("pass greedy_solver=util.algorithms.solve_by_probablistic_greedy "
+                                      "(reference code) to use solve(); the forward is what this package replaces")
+        output_solution, score, predict_order = self._greedy_solver(self, brick_layout)
+        output_layout = deepcopy(brick_layout)
+        output_layout.predict_order = predict_order
+        output_layout.predict = output_solution
+        output_layout.predict_probs = self.predict(brick_layout)
+        return output_layout, score
+
+    def load_saved_network(self, net_path):
+        self.network.load_state_dict(torch.load(net_path, map_location=self.device))
+        self.network.train()                                     # ml_solver.py:131: inference stays in train mode
