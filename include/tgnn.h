@@ -115,6 +115,33 @@ int tgnn_nnconv_mean_fwd(const float *h, int64_t ldh, const int32_t *rowptr, con
                          const float *bias, int64_t n_nodes, int32_t c, int32_t act, float *out,
                          double *bn_partial, int32_t *n_partials_host, tgnn_stream_t stream);
 
+/* The same NNConv on matrix cores, over the tile structure built by tgnn_nnconv_tiles_build
+ * (network_width 32 and at most tgnn_nnconv_tiled_max_types() edge types; otherwise use
+ * tgnn_nnconv_mean_fwd, which handles any width / type count).  Production path of tgnn_forward.
+ *
+ * Tile structure (adjacency set, once per layout): every 64 destination rows form a tile whose
+ * in-edges are grouped by edge type and padded to 16-slot chunks, followed by 4 chunks of
+ * pseudo-type T carrying the rows themselves (the root term):
+ *   tile_chunk_ptr int32 [ceil(N/64)+1]   chunk range of every tile
+ *   chunk_type     int32 [n_chunks]       edge type of the chunk, T for root chunks
+ *   slot_src       int32 [16*n_chunks]    source row, -1 = padding
+ *   slot_row       int32 [16*n_chunks]    destination row inside the tile, 0..63 (64 = padding)
+ *   slot_mul       float [16*n_chunks]    0 padding, 1 edge, max(deg,1) root
+ * n_chunks <= tgnn_nnconv_tiles_max_chunks(N, E, T) (allocate for that); the exact count is
+ * tile_chunk_ptr[ceil(N/64)]. */
+int64_t tgnn_nnconv_tiles_max_chunks(int64_t n_nodes, int64_t n_edges, int32_t n_types);
+size_t tgnn_nnconv_tiles_workspace_bytes(int64_t n_nodes);
+int tgnn_nnconv_tiles_build(const int32_t *rowptr, const int32_t *col_src, const int32_t *col_type,
+                            int64_t n_nodes, int32_t n_types, int32_t *tile_chunk_ptr, int32_t *chunk_type,
+                            int32_t *slot_src, int32_t *slot_row, float *slot_mul, void *ws, size_t ws_bytes,
+                            tgnn_stream_t stream);
+int32_t tgnn_nnconv_tiled_max_types(void);
+int tgnn_nnconv_mean_tiled_fwd(const float *h, int64_t ldh, const int32_t *rowptr, const int32_t *tile_chunk_ptr,
+                               const int32_t *chunk_type, const int32_t *slot_src, const int32_t *slot_row,
+                               const float *slot_mul, const float *wtab, int32_t n_types, const float *root,
+                               const float *bias, int64_t n_nodes, int32_t c, int32_t act, float *out,
+                               double *bn_partial, int32_t *n_partials_host, tgnn_stream_t stream);
+
 /* GINConv + optional LeakyReLU (coll_conv.py:25-27):
  *   z[v]  = (1+eps) * f(a[v]) + sum_{e: dst_e = v} f(a[src_e]),   f = identity or the BatchNorm
  *           described by in_stat (lets layer i+1 read layer i's pre-BN activations directly);
@@ -189,6 +216,12 @@ typedef struct tgnn_graph {
     const int32_t *type_rep_edge; /* [T] original edge numbers */
     const int32_t *col_rowptr;  /* [N+1] */
     const int32_t *col_src;     /* [Ec'] */
+    /* NNConv tile structure (all NULL => tgnn_forward uses the CSR kernel) */
+    const int32_t *tile_chunk_ptr;
+    const int32_t *chunk_type;
+    const int32_t *slot_src;
+    const int32_t *slot_row;
+    const float *slot_mul;
 } tgnn_graph;
 
 size_t tgnn_forward_workspace_bytes(const tgnn_model_dims *dims, int64_t n_nodes, int32_t n_types);

@@ -21,3 +21,10 @@ def timeit(fn, n=20):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
 print("nnconv us:", timeit(lambda: ops.nnconv_mean(h, g, wtab, l1.nnConv.root, l1.nnConv.bias, act=1, partials=parts)))
+print("nnconv csr us:", timeit(lambda: ops.nnconv_mean(h, g, wtab, l1.nnConv.root, l1.nnConv.bias, act=1, partials=parts, force_csr_kernel=True)))
+l2 = net.brch_2_coll_conv_layers[0]
+print("gin us:", timeit(lambda: ops.gin(h, g, l2.ginConv.eps, *l2.ginConv._mlp_params(), act=1, partials=parts)))
+import time
+torch.cuda.synchronize(); t0=time.perf_counter()
+for _ in range(10): ops.prepare_graph(100_000, adj, adj_attr, col)
+torch.cuda.synchronize(); print("prepare_graph ms:", (time.perf_counter()-t0)/10*1e3)

@@ -99,6 +99,96 @@ def test_labyrinth_graph_has_13_edge_types(dev):
     assert len(pairs) == 13
 
 
+@pytest.mark.parametrize("n,e,t,seed", [(5, 12, 3, 0), (64, 700, 13, 1), (1254, 8502, 13, 2), (20001, 260000, 19, 3)])
+def test_nnconv_tile_structure(dev, n, e, t, seed):
+    """Tiles = per 64 destination rows the in-edges grouped by type (CSR order inside a group), padded to
+    16-slot chunks, followed by 4 root chunks of pseudo-type T."""
+    from tilingnn_amd import ops
+    rng = np.random.default_rng(seed)
+    ei = rng.integers(0, n, size=(2, e), dtype=np.int64)
+    etype = rng.integers(0, t, size=e).astype(np.int32)
+    rowptr, src, eid, _ = ops.build_csr(torch.from_numpy(ei).to(dev), n, False)
+    col_type = torch.from_numpy(etype).to(dev)[eid.long()[:e]].contiguous()
+    tiles = ops.build_nnconv_tiles(n, e, t, rowptr, src, col_type)
+    rp, srcs, ctype = rowptr.cpu().numpy(), src.cpu().numpy()[:e], col_type.cpu().numpy()
+    tcp = tiles.tile_chunk_ptr.cpu().numpy()
+    chunk_type = tiles.chunk_type.cpu().numpy(); s_src = tiles.slot_src.cpu().numpy()
+    s_row = tiles.slot_row.cpu().numpy(); s_mul = tiles.slot_mul.cpu().numpy()
+    ntiles = (n + 63) // 64
+    assert tcp[0] == 0 and tcp.shape[0] == ntiles + 1
+    for b in range(ntiles):
+        r0, r1 = 64 * b, min(64 * b + 64, n)
+        e0, e1 = rp[r0], rp[r1]
+        rows_of = np.repeat(np.arange(r0, r1), np.diff(rp[r0:r1 + 1])) - r0
+        c0, c1 = tcp[b], tcp[b + 1]
+        ct = chunk_type[c0:c1]
+        assert list(ct) == sorted(ct) and list(ct[-4:]) == [t] * 4 and (ct[:-4] < t).all()
+        want_chunks = sum((np.count_nonzero(ctype[e0:e1] == k) + 15) // 16 for k in range(t)) + 4
+        assert c1 - c0 == want_chunks
+        sl = slice(16 * c0, 16 * c1)
+        slot_t = np.repeat(ct, 16)
+        for k in range(t):
+            sel = (slot_t == k) & (s_src[sl] >= 0)
+            want = ctype[e0:e1] == k
+            np.testing.assert_array_equal(s_src[sl][sel], srcs[e0:e1][want])
+            np.testing.assert_array_equal(s_row[sl][sel], rows_of[want])
+            assert (s_mul[sl][sel] == 1.0).all()
+        pad = (slot_t < t) & (s_src[sl] < 0)
+        assert (s_mul[sl][pad] == 0).all() and (s_row[sl][pad] == 64).all()
+        root = slot_t == t
+        deg = np.diff(rp[r0:r1 + 1])
+        np.testing.assert_array_equal(s_row[sl][root], np.arange(64))
+        np.testing.assert_array_equal(s_src[sl][root][: r1 - r0], np.arange(r0, r1))
+        assert (s_src[sl][root][r1 - r0:] == -1).all()
+        np.testing.assert_array_equal(s_mul[sl][root][: r1 - r0], np.maximum(deg, 1).astype(np.float32))
+
+
+def test_nnconv_csr_kernel_and_tile_kernel_agree_with_oracle(dev):
+    """Both NNConv implementations (MFMA tile kernel = production; CSR / LDS-weight-table kernel = fallback
+    for many edge types) against the fp64 oracle, incl. the fused LeakyReLU and the BN partial sums."""
+    from tilingnn_amd import ops
+    g = load_labyrinth_graph()
+    net, sd = make_net(dev)
+    sd64 = orc.cast_sd(sd, torch.float64)
+    x, adj, adj_attr, col, _ = graph_tensors(g, torch.float32, dev)
+    gen = torch.Generator().manual_seed(5)
+    h = torch.randn(1254, 32, generator=gen)
+    with torch.no_grad():
+        want = orc.nnconv_mean(h.double(), adj.cpu(), adj_attr.cpu().double(), sd64, "brch_1_graph_conv_layers.4")
+    pg = ops.prepare_graph(1254, adj, adj_attr, col)
+    assert pg.tiles is not None
+    l1 = net.brch_1_graph_conv_layers[4]
+    wtab = ops.edge_weight_table(adj_attr, pg, *l1.nnConv._edge_mlp_params(), 32)
+    for force_csr in (False, True):
+        parts = ops.new_partials(32, dev)
+        got, n_parts = ops.nnconv_mean(h.to(dev), pg, wtab, l1.nnConv.root, l1.nnConv.bias, act=ops.ACT_NONE,
+                                       partials=parts, force_csr_kernel=force_csr)
+        assert orc.rel_max_err(got.cpu(), want) < TOL, force_csr
+        p = parts[: n_parts * 64].view(n_parts, 2, 32).sum(0).cpu()
+        np.testing.assert_allclose(p[0].numpy(), got.double().sum(0).cpu().numpy(), rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(p[1].numpy(), (got.double() ** 2).sum(0).cpu().numpy(), rtol=1e-9, atol=1e-9)
+        got_act, _ = ops.nnconv_mean(h.to(dev), pg, wtab, l1.nnConv.root, l1.nnConv.bias, act=ops.ACT_LEAKY_RELU,
+                                     force_csr_kernel=force_csr)
+        assert orc.rel_max_err(got_act.cpu(), orc.leaky_relu(want)) < TOL
+
+
+def test_many_edge_types_fall_back_to_csr_kernels(dev):
+    """T = 25 (> the tile kernel's LDS budget) -> LDS-weight-table CSR kernel; T = 300 -> generic kernel."""
+    from tilingnn_amd.synth import make_super_graph
+    for t_count in (25, 300):
+        sg = make_super_graph(3000, 24000, 30000, tile_count=2, n_edge_types=t_count, seed=9)
+        net, sd = make_net(dev, fe=2 + t_count)
+        sd64 = orc.cast_sd(sd, torch.float64)
+        x, adj, adj_attr, col, _ = sg.to_torch(dev)
+        h = torch.randn(3000, 32, generator=torch.Generator().manual_seed(1))
+        with torch.no_grad():
+            want = orc.nnconv_mean(h.double(), adj.cpu(), adj_attr.cpu().double(), sd64, "brch_1_graph_conv_layers.0")
+        got = net.brch_1_graph_conv_layers[0].nnConv(h.to(dev), adj, adj_attr)
+        assert orc.rel_max_err(got.cpu(), want) < TOL, t_count
+        probs, _ = net(x=x, adj_e_index=adj, adj_e_features=adj_attr, col_e_idx=col)
+        assert bool(torch.isfinite(probs).all())
+
+
 # ------------------------------------------------------------------------------------------ per op vs golden
 def test_per_op_against_reference_golden_small_graph(dev):
     """Teacher-forced pairs produced by the REFERENCE (tests/golden/ref_ops_small.npz)."""

@@ -11,9 +11,12 @@
 // `out` emitted for the BatchNorm that follows.  fp32 in / fp32 accumulate on
 // v_mfma_f32_32x32x2_f32: exact f32 (a k-ordered fma chain), 1e-5 parity needs no split tricks.
 //
-// Tiling: block = 4 waves, tile 128 rows x (32*NT) cols x 32 k; wave w owns rows [32w, 32w+32).
-// LDS rows are padded to 33 floats: the A/B fragment reads (lane&31 -> row, lane>>5 -> k) are
-// conflict free.  Blocks are persistent over row tiles so that one block = one BN partial row.
+// Tiling: block = 4 waves, tile 128 rows x (32*NT) cols x 32 k, NT in {1,2,4,8} chosen so that one
+// block covers the whole output width up to 256 (A is then read from HBM exactly once); wave w owns
+// rows [32w, 32w+32) x all columns = NT accumulators.  The next k-tile is prefetched into registers
+// while the current one feeds the MFMAs.  LDS rows are padded to 33 floats: the A/B fragment reads
+// (lane&31 -> row, lane>>5 -> k) are conflict free.  Blocks are persistent over row tiles so that
+// one block = one BN partial row.
 #include "tgnn_common.h"
 
 namespace tgnn {
@@ -22,24 +25,88 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kBM = 128, kBK = 32, kLD = 33;
 
+struct Frag4 {
+    float v[4];
+};
+
 template <int NT>
 __global__ __launch_bounds__(256) void dense_mfma_kernel(
     const float *__restrict__ a, int64_t lda, int64_t a_kb_stride, const float *__restrict__ in_stat,
     const float *__restrict__ w, const float *__restrict__ bias, int64_t n, int in_dim, int out_dim, int act,
     float *__restrict__ out, int64_t ldo, double *__restrict__ bn_partial, int vec_a, int vec_w) {
     constexpr int BN = 32 * NT;
-    __shared__ float As[kBM * kLD];
-    __shared__ float Bs[BN * kLD];
-    __shared__ double red[4 * 2 * BN];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                  // [128][33]
+    float *Bs = smem + kBM * kLD;      // [BN][33]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.y * BN;
     const int ktiles = (in_dim + kBK - 1) / kBK;
     const int64_t row_tiles = (n + kBM - 1) / kBM;
     const int frag_r = lane & 31, frag_k = lane >> 5;
+    const int ld_r = tid >> 3, ld_q = tid & 7;   // staging: thread -> (row ld_r + 32 j, float4 column ld_q)
 
     double csum[NT], csq[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) csum[nt] = csq[nt] = 0.0;
+
+    auto load_a = [&](int64_t m0, int kt, Frag4 (&ra)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t row = m0 + ld_r + 32 * j;
+            const int k = kt * kBK + 4 * ld_q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ra[j].v[e] = 0.f;
+            if (row < n) {
+                const float *src = a + (int64_t)kt * a_kb_stride + row * lda + 4 * ld_q;
+                if (vec_a && k + 3 < in_dim) {
+                    const float4 t4 = *reinterpret_cast<const float4 *>(src);
+                    ra[j].v[0] = t4.x; ra[j].v[1] = t4.y; ra[j].v[2] = t4.z; ra[j].v[3] = t4.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k + e < in_dim) ra[j].v[e] = src[e];
+                }
+            }
+        }
+    };
+    auto load_b = [&](int kt, Frag4 (&rb)[NT]) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = n0 + ld_r + 32 * j, k = kt * kBK + 4 * ld_q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rb[j].v[e] = 0.f;
+            if (col < out_dim) {
+                const float *src = w + (int64_t)col * in_dim + k;
+                if (vec_w && k + 3 < in_dim) {
+                    const float4 t4 = *reinterpret_cast<const float4 *>(src);
+                    rb[j].v[0] = t4.x; rb[j].v[1] = t4.y; rb[j].v[2] = t4.z; rb[j].v[3] = t4.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k + e < in_dim) rb[j].v[e] = src[e];
+                }
+            }
+        }
+    };
+    auto stage = [&](int64_t m0, int kt, const Frag4 (&ra)[4], const Frag4 (&rb)[NT]) {
+        const int k = kt * kBK + 4 * ld_q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool row_ok = m0 + ld_r + 32 * j < n;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = ra[j].v[e];
+                if (in_stat && row_ok && k + e < in_dim)     // BatchNorm of the producer, applied on the fly
+                    v = bn_apply1(v, in_stat[k + e], in_stat[in_dim + k + e], in_stat[2 * in_dim + k + e],
+                                  in_stat[3 * in_dim + k + e]);
+                As[(ld_r + 32 * j) * kLD + 4 * ld_q + e] = v;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Bs[(ld_r + 32 * j) * kLD + 4 * ld_q + e] = rb[j].v[e];
+    };
 
     for (int64_t rt = blockIdx.x; rt < row_tiles; rt += gridDim.x) {
         const int64_t m0 = rt * kBM;
@@ -49,56 +116,17 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
+        Frag4 ra[4], rb[NT];
+        load_a(m0, 0, ra);
+        load_b(0, rb);
+        __syncthreads();                       // previous row tile's fragment reads are done
+        stage(m0, 0, ra, rb);
+        __syncthreads();
         for (int kt = 0; kt < ktiles; ++kt) {
-            // ---- stage A tile [128][32] (BatchNorm of the producer applied on the fly)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int idx = tid + 256 * j, r = idx >> 3, q = idx & 7;
-                const int64_t row = m0 + r;
-                const int k = kt * kBK + 4 * q;
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
-                if (row < n) {
-                    const float *src = a + (int64_t)kt * a_kb_stride + row * lda + 4 * q;
-                    if (vec_a && k + 3 < in_dim) {
-                        const float4 t4 = *reinterpret_cast<const float4 *>(src);
-                        v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (k + e < in_dim) v[e] = src[e];
-                    }
-                    if (in_stat) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (k + e < in_dim)
-                                v[e] = bn_apply1(v[e], in_stat[k + e], in_stat[in_dim + k + e],
-                                                 in_stat[2 * in_dim + k + e], in_stat[3 * in_dim + k + e]);
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) As[r * kLD + 4 * q + e] = v[e];
+            if (kt + 1 < ktiles) {             // prefetch the next k-tile; it lands while the MFMAs run
+                load_a(m0, kt + 1, ra);
+                load_b(kt + 1, rb);
             }
-            // ---- stage W tile [BN][32]  (nn.Linear weight is [out, in]: k contiguous)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int idx = tid + 256 * j, r = idx >> 3, q = idx & 7;
-                const int col = n0 + r, k = kt * kBK + 4 * q;
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
-                if (col < out_dim) {
-                    const float *src = w + (int64_t)col * in_dim + k;
-                    if (vec_w && k + 3 < in_dim) {
-                        const float4 t4 = *reinterpret_cast<const float4 *>(src);
-                        v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (k + e < in_dim) v[e] = src[e];
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) Bs[r * kLD + 4 * q + e] = v[e];
-            }
-            __syncthreads();
             const float *ap = As + (wave * 32 + frag_r) * kLD + frag_k;
             const float *bp = Bs + frag_r * kLD + frag_k;
 #pragma unroll
@@ -108,7 +136,11 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(
                 for (int nt = 0; nt < NT; ++nt)
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[nt * 32 * kLD + kk], acc[nt], 0, 0, 0);
             }
-            __syncthreads();
+            if (kt + 1 < ktiles) {
+                __syncthreads();
+                stage(m0, kt + 1, ra, rb);
+                __syncthreads();
+            }
         }
         // ---- epilogue: bias, activation, store, BN partial sums.
         // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -131,6 +163,8 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(
     }
 
     if (bn_partial) {
+        __syncthreads();                       // LDS tiles are dead: reuse them for the cross-wave reduction
+        double *red = reinterpret_cast<double *>(smem);     // [4 waves][2][BN]
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const double s = csum[nt] + __shfl_xor(csum[nt], 32, 64);
@@ -141,8 +175,8 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(
             }
         }
         __syncthreads();
-        if (tid < 2 * BN) {
-            const int which = tid / BN, cl = tid % BN;
+        for (int i = tid; i < 2 * BN; i += 256) {
+            const int which = i / BN, cl = i % BN;
             const int col = n0 + cl;
             if (col < out_dim) {
                 const double tot = red[(0 * 2 + which) * BN + cl] + red[(1 * 2 + which) * BN + cl] +
@@ -151,6 +185,18 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(
             }
         }
     }
+}
+
+template <int NT>
+static void launch_dense(dim3 grid, hipStream_t s, const float *a, int64_t lda, int64_t akb, const float *in_stat,
+                         const float *w, const float *b, int64_t n, int in_dim, int out_dim, int act, float *out,
+                         int64_t ldo, double *bn_partial, int vec_a, int vec_w) {
+    constexpr int BN = 32 * NT;
+    size_t lds = (size_t)(kBM + BN) * kLD * sizeof(float);
+    const size_t red = (size_t)4 * 2 * BN * sizeof(double);
+    if (red > lds) lds = red;
+    dense_mfma_kernel<NT><<<grid, 256, lds, s>>>(a, lda, akb, in_stat, w, b, n, in_dim, out_dim, act, out, ldo,
+                                                 bn_partial, vec_a, vec_w);
 }
 
 }  // namespace tgnn
@@ -174,15 +220,19 @@ extern "C" int tgnn_dense_act_fwd(const float *a, int64_t lda, int64_t a_kblock_
     const int vec_a = (lda % 4 == 0) && (a_kblock_stride % 4 == 0) && ((uintptr_t)a % 16 == 0);
     const int vec_w = (in_dim % 4 == 0) && ((uintptr_t)w % 16 == 0);
     const int blocks_x = producer_blocks(n_rows, kBM);
-    if (out_dim > 32) {
-        dim3 grid(blocks_x, (out_dim + 63) / 64);
-        dense_mfma_kernel<2><<<grid, 256, 0, s>>>(a, lda, a_kblock_stride, in_stat, w, b, n_rows, in_dim, out_dim, act,
-                                                  out, ldo, bn_partial, vec_a, vec_w);
+#define TGNN_DENSE(NT_)                                                                                          \
+    launch_dense<NT_>(dim3(blocks_x, (out_dim + 32 * NT_ - 1) / (32 * NT_)), s, a, lda, a_kblock_stride, in_stat, w, \
+                      b, n_rows, in_dim, out_dim, act, out, ldo, bn_partial, vec_a, vec_w)
+    if (out_dim > 128) {
+        TGNN_DENSE(8);
+    } else if (out_dim > 64) {
+        TGNN_DENSE(4);
+    } else if (out_dim > 32) {
+        TGNN_DENSE(2);
     } else {
-        dim3 grid(blocks_x, 1);
-        dense_mfma_kernel<1><<<grid, 256, 0, s>>>(a, lda, a_kblock_stride, in_stat, w, b, n_rows, in_dim, out_dim, act,
-                                                  out, ldo, bn_partial, vec_a, vec_w);
+        TGNN_DENSE(1);
     }
+#undef TGNN_DENSE
     if (n_partials_host) *n_partials_host = blocks_x;
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;

@@ -90,7 +90,7 @@ struct Params {
 };
 
 static bool dims_ok(const tgnn_model_dims *d) {
-    return d && d->node_features_dim >= 1 && d->adj_edge_features_dim >= 1 && d->adj_edge_features_dim <= 256 &&
+    return d && d->node_features_dim >= 1 && d->adj_edge_features_dim >= 1 && d->adj_edge_features_dim <= 1024 &&
            d->network_width >= 4 && d->network_width % 4 == 0 && d->network_width <= 256 && d->network_depth >= 1 &&
            d->network_depth <= kMaxDepth && d->output_dim >= 1 && d->output_dim <= 256;
 }
@@ -274,9 +274,16 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         const float *h1 = w.mid + (size_t)i * n * c;
         // GraphConv (:62): NNConv mean + LeakyReLU; BN statistics emitted as partials
         prof.begin(2);
-        TGNN_TRY(tgnn_nnconv_mean_fwd(h1, c, graph->adj_rowptr, graph->adj_src, graph->adj_type,
+        if (graph->tile_chunk_ptr && c == 32) {
+            TGNN_TRY(tgnn_nnconv_mean_tiled_fwd(h1, c, graph->adj_rowptr, graph->tile_chunk_ptr, graph->chunk_type,
+                                                graph->slot_src, graph->slot_row, graph->slot_mul,
+                                                w.wtab + (size_t)i * T * c * c, T, P.f(b + 6), P.f(b + 7), n, c,
+                                                TGNN_ACT_LEAKY_RELU, w.a1, w.part1, &np1, s));
+        } else {
+            TGNN_TRY(tgnn_nnconv_mean_fwd(h1, c, graph->adj_rowptr, graph->adj_src, graph->adj_type,
                                       w.wtab + (size_t)i * T * c * c, T, P.f(b + 6), P.f(b + 7), n, c,
                                       TGNN_ACT_LEAKY_RELU, w.a1, w.part1, &np1, s));
+        }
         prof.end();
         // CollConv (:63): input = BN_{i-1}(a2_{i-1}) folded into the gather; layer 0 reads middle[0]
         const float *gin_in = i == 0 ? w.mid : w.a2[(i - 1) & 1];

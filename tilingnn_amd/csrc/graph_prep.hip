@@ -210,6 +210,121 @@ __global__ void gather_i32_kernel(const int *__restrict__ src, int64_t n_src, co
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// NNConv tiles: per 64 destination rows, the in-edges grouped by edge type and padded to 16-slot
+// chunks (one chunk = one 16x16x4 MFMA operand block), plus 4 "root" chunks (type T) that carry the
+// rows themselves.  Built once per layout, reused by all 20 layers.  One wavefront per tile.
+// ------------------------------------------------------------------------------------------
+constexpr int kTileRows = 64;
+constexpr int kMaxTileTypes = 64;
+
+// chunks of tile b = sum_t ceil(cnt_t / 16) + 4
+__global__ __launch_bounds__(64) void nnconv_tile_count_kernel(const int *__restrict__ rowptr,
+                                                               const int *__restrict__ col_type, int64_t n,
+                                                               int n_types, int *__restrict__ tile_chunks) {
+    __shared__ int cnt[kMaxTileTypes];
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.x, r0 = b * kTileRows, r1 = (r0 + kTileRows < n) ? r0 + kTileRows : n;
+    cnt[lane] = 0;
+    __syncthreads();
+    const int e0 = rowptr[r0], e1 = rowptr[r1];
+    for (int e = e0 + lane; e < e1; e += 64) atomicAdd(&cnt[col_type[e]], 1);
+    __syncthreads();
+    int c = lane < n_types ? (cnt[lane] + 15) >> 4 : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if (lane == 0) tile_chunks[b] = c + kTileRows / 16;
+}
+
+__global__ __launch_bounds__(64) void nnconv_tile_fill_kernel(
+    const int *__restrict__ rowptr, const int *__restrict__ col_src, const int *__restrict__ col_type, int64_t n,
+    int n_types, const int *__restrict__ tile_chunk_ptr, int *__restrict__ chunk_type, int *__restrict__ slot_src,
+    int *__restrict__ slot_row, float *__restrict__ slot_mul) {
+    __shared__ int cnt[kMaxTileTypes];
+    __shared__ int base[kMaxTileTypes + 1];   // first slot (tile-relative) of every type group; [T] = root group
+    __shared__ int run[kMaxTileTypes];
+    __shared__ int rp[kTileRows + 1];
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.x, r0 = b * kTileRows, r1 = (r0 + kTileRows < n) ? r0 + kTileRows : n;
+    const int rows = (int)(r1 - r0);
+    cnt[lane] = 0;
+    run[lane] = 0;
+    if (lane <= rows) rp[lane] = rowptr[r0 + lane];
+    if (lane == 0 && rows == kTileRows) rp[kTileRows] = rowptr[r1];
+    __syncthreads();
+    const int e0 = rp[0], e1 = rp[rows];
+    for (int e = e0 + lane; e < e1; e += 64) atomicAdd(&cnt[col_type[e]], 1);
+    __syncthreads();
+    {   // exclusive scan of the padded group sizes over the type axis (lane = type)
+        const int padded = lane < n_types ? ((cnt[lane] + 15) >> 4) << 4 : 0;
+        int incl = padded;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        base[lane] = incl - padded;
+        if (lane == 63) base[64] = incl;
+    }
+    __syncthreads();
+    const int root_base = base[n_types < 64 ? n_types : 64];   // == total padded edge slots (groups beyond T are empty)
+    const int64_t chunk0 = tile_chunk_ptr[b];
+    const int64_t slot0 = chunk0 * 16;
+    const int n_slots = root_base + kTileRows;
+    // chunk types + padding defaults
+    for (int k = lane; k < n_slots / 16; k += 64) {
+        int t = n_types;                                       // root
+        if (k * 16 < root_base) {
+            t = 0;
+            while (t + 1 < n_types && base[t + 1] <= k * 16) ++t;
+        }
+        chunk_type[chunk0 + k] = t;
+    }
+    for (int i = lane; i < root_base; i += 64) {
+        slot_src[slot0 + i] = -1;
+        slot_row[slot0 + i] = kTileRows;                       // scratch accumulator row: never read back
+        slot_mul[slot0 + i] = 0.f;
+    }
+    // root group: the rows themselves, pre-multiplied by max(deg,1) so that the common 1/deg scale cancels
+    {
+        const bool ok = lane < rows;
+        const int deg = ok ? rp[lane + 1] - rp[lane] : 0;
+        slot_src[slot0 + root_base + lane] = ok ? (int)(r0 + lane) : -1;
+        slot_row[slot0 + root_base + lane] = lane;
+        slot_mul[slot0 + root_base + lane] = ok ? (float)(deg > 0 ? deg : 1) : 0.f;
+    }
+    __syncthreads();
+    // stable placement: edges in CSR (= original) order inside every type group
+    for (int eb = e0; eb < e1; eb += 64) {
+        const int e = eb + lane;
+        const bool ok = e < e1;
+        const int t = ok ? col_type[e] : -1;
+        int row = 0;
+        if (ok) {   // destination row of CSR slot e: last r with rp[r] <= e
+            int lo = 0, hi = rows;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (rp[mid] <= e) lo = mid; else hi = mid;
+            }
+            row = lo;
+        }
+        for (int tt = 0; tt < n_types; ++tt) {
+            const unsigned long long m = __ballot(t == tt);
+            if (m == 0ull) continue;                           // wave-uniform
+            if (t == tt) {
+                const int rank = __popcll(m & ((1ull << lane) - 1ull));
+                const int64_t s_ = slot0 + base[tt] + run[tt] + rank;
+                slot_src[s_] = col_src[e];
+                slot_row[s_] = row;
+                slot_mul[s_] = 1.0f;
+            }
+            __syncthreads();
+            if (lane == 0) run[tt] += __popcll(m);
+            __syncthreads();
+        }
+    }
+}
+
 static inline unsigned grid_for(int64_t n, int threads = 256, int cap = 256 * 16) {
     int64_t g = (n + threads - 1) / threads;
     if (g < 1) g = 1;
@@ -305,6 +420,41 @@ extern "C" int tgnn_gather_i32(const int32_t *src, int64_t n_src, const int32_t 
     if (n <= 0) return TGNN_OK;
     TGNN_CHECK_ARG(src && idx && out, "null pointer");
     gather_i32_kernel<<<grid_for(n), 256, 0, static_cast<hipStream_t>(stream)>>>(src, n_src, idx, n, out);
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}
+
+extern "C" int64_t tgnn_nnconv_tiles_max_chunks(int64_t n_nodes, int64_t n_edges, int32_t n_types) {
+    const int64_t ntiles = (n_nodes + kTileRows - 1) / kTileRows;
+    return n_edges / 16 + ntiles * ((int64_t)n_types + kTileRows / 16) + 1;
+}
+
+extern "C" size_t tgnn_nnconv_tiles_workspace_bytes(int64_t n_nodes) {
+    const int64_t ntiles = (n_nodes + kTileRows - 1) / kTileRows;
+    return align_up((size_t)(ntiles + 1) * 4, 256) + scan_ws_ints(ntiles + 1) * 4 + 1024;
+}
+
+extern "C" int tgnn_nnconv_tiles_build(const int32_t *rowptr, const int32_t *col_src, const int32_t *col_type,
+                                       int64_t n_nodes, int32_t n_types, int32_t *tile_chunk_ptr,
+                                       int32_t *chunk_type, int32_t *slot_src, int32_t *slot_row, float *slot_mul,
+                                       void *ws, size_t ws_bytes, tgnn_stream_t stream) {
+    TGNN_CHECK_ARG(n_nodes >= 1, "n_nodes");
+    TGNN_CHECK_ARG(n_types >= 0 && n_types <= kMaxTileTypes - 1, "tiled NNConv supports at most 63 edge types");
+    TGNN_CHECK_ARG(rowptr && tile_chunk_ptr && chunk_type && slot_src && slot_row && slot_mul, "null pointer");
+    if (!ws || ws_bytes < tgnn_nnconv_tiles_workspace_bytes(n_nodes)) {
+        set_error("tgnn_nnconv_tiles_build: workspace too small");
+        return TGNN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t ntiles = (n_nodes + kTileRows - 1) / kTileRows;
+    Carver cv(ws, ws_bytes);
+    int *tile_chunks = cv.take<int>(ntiles + 1);
+    int *scan_ws = cv.take<int>(scan_ws_ints(ntiles + 1));
+    TGNN_CHECK_HIP(hipMemsetAsync(tile_chunks + ntiles, 0, 4, s));
+    nnconv_tile_count_kernel<<<(unsigned)ntiles, 64, 0, s>>>(rowptr, col_type, n_nodes, n_types, tile_chunks);
+    exclusive_scan_i32(tile_chunks, tile_chunk_ptr, ntiles + 1, scan_ws, s);
+    nnconv_tile_fill_kernel<<<(unsigned)ntiles, 64, 0, s>>>(rowptr, col_src, col_type, n_nodes, n_types, tile_chunk_ptr,
+                                                           chunk_type, slot_src, slot_row, slot_mul);
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
 }

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void edge_weight_table_kernel(
     const float *__restrict__ w1 = L.w1, *__restrict__ b1 = L.b1, *__restrict__ w2 = L.w2, *__restrict__ b2 = L.b2,
                 *__restrict__ w3 = L.w3, *__restrict__ b3 = L.b3;
     float *__restrict__ wtab = wtab_all + (int64_t)blockIdx.y * gridDim.x * cc;
-    __shared__ float e_s[256];
+    __shared__ float e_s[1024];
     __shared__ float h1_s[kEH1];
     __shared__ float h2_s[kEH2];
     const int t = blockIdx.x;
@@ -278,6 +278,249 @@ __global__ __launch_bounds__(kNNThreads) void nnconv32_lds_kernel(
 #undef TGNN_FMA4
 
 // ------------------------------------------------------------------------------------------
+// NNConv mean on matrix cores (C = 32, T + 1 <= 20): the production kernel.
+//
+// A tile = 64 destination rows.  Its in-edges arrive grouped by edge type in 16-slot chunks
+// (tgnn_nnconv_tiles_build): one chunk = 16 gathered source rows x one [32,32] type matrix
+//     M[16 x 32] = X[src(16) x 32] . W_t            = 2 column tiles x 8 x v_mfma_f32_16x16x4_f32
+// (exact fp32).  The block's 8 waves split the tile's chunks into contiguous ranges (type changes
+// ~3x per wave), keep the next two chunks' gathers in flight (8 VGPRs per chunk), and scatter-add
+// each M row into a WAVE-PRIVATE [64 x 32] LDS accumulator with ds_add_f32 -- wave-private means the
+// order of the adds is program order, so results are bit-reproducible.  The root term h[v].root
+// rides along as 4 extra chunks of pseudo-type T whose rows are pre-multiplied by max(deg,1), so one
+// common 1/deg scale applies at the end.  After a barrier 512 threads fold the 8 accumulators in
+// fixed order: (sum)/deg + bias -> LeakyReLU -> store, fp64 BN column sums on the side.
+//
+// LDS: (T+1) x 4.5 KB weight image (B-operand order, padded) + 8 x 8 KB accumulators = 128 KB @T=13.
+// ------------------------------------------------------------------------------------------
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kMfThreads = 512, kMfWaves = 8;
+constexpr int kWtNt = 16 * 36;             // floats per (type, column tile): [j=16][q=4][ks=8], row stride 36
+constexpr int kWtType = 2 * kWtNt;         // floats per type
+constexpr int kAccFloats = 65 * 32;        // per-wave accumulator: 64 tile rows + 1 scratch row
+constexpr int kBatch = 4;                  // chunks per pipeline stage
+
+struct ChunkIdx {                          // per-lane view of one 16-slot chunk
+    int type;                              // edge type of the chunk (wave-uniform)
+    int src;                               // source row of slot (lane & 15)
+    float mul;                             // its multiplier (0 pad, 1 edge, max(deg,1) root)
+    int4 rows;                             // destination rows (tile-local) of slots 4q .. 4q+3, q = lane >> 4
+};
+
+__global__ __launch_bounds__(kMfThreads) void nnconv32_mfma_kernel(
+    const float *__restrict__ h, int64_t ldh, const int *__restrict__ rowptr, const int *__restrict__ tile_chunk_ptr,
+    const int *__restrict__ chunk_type, const int *__restrict__ slot_src, const int *__restrict__ slot_row,
+    const float *__restrict__ slot_mul, const float *__restrict__ wtab, int n_types, const float *__restrict__ root,
+    const float *__restrict__ bias, int64_t n, int act, float *__restrict__ out, double *__restrict__ bn_partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *wl = lds;                                        // [(T+1)][2][16][36]
+    float *accs = lds + (n_types + 1) * kWtType;            // [8][64][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fj = lane & 15, fq = lane >> 4;
+
+    // ---- weight image: element (i, o) of type t -> wl[t][o >> 4][o & 15][i >> 3][i & 7]
+    for (int idx = tid; idx < (n_types + 1) * 1024; idx += kMfThreads) {
+        const int t = idx >> 10, r = idx & 1023, i = r >> 5, o = r & 31;
+        const float v = t < n_types ? wtab[idx] : root[r];
+        wl[t * kWtType + (o >> 4) * kWtNt + (o & 15) * 36 + (i >> 3) * 8 + (i & 7)] = v;
+    }
+    float *acc_w = accs + wave * kAccFloats;
+    for (int i = lane; i < kAccFloats / 4; i += 64) reinterpret_cast<float4 *>(acc_w)[i] = make_float4(0, 0, 0, 0);
+    __syncthreads();
+
+    const int64_t n_tiles = (n + 63) / 64;
+    // final-phase mapping: thread -> (row fr, columns 4*fc .. 4*fc+3)
+    const int fr = tid >> 3, fc = tid & 7;
+    const float4 bias4 = reinterpret_cast<const float4 *>(bias)[fc];
+    double cs[4] = {0, 0, 0, 0}, cq[4] = {0, 0, 0, 0};
+
+    // XCD-contiguous tile ranges (block b runs on XCD b % 8; speed only)
+    const int nblk = gridDim.x;
+    int64_t t_beg = blockIdx.x, t_end = n_tiles, t_step = nblk;
+    if (nblk >= 8 && (nblk & 7) == 0) {
+        const int xcd = blockIdx.x & 7;
+        t_beg = n_tiles * xcd / 8 + (blockIdx.x >> 3);
+        t_end = n_tiles * (xcd + 1) / 8;
+        t_step = nblk >> 3;
+    }
+
+    auto load_idx = [&](int c, bool ok) {
+        ChunkIdx ci;
+        const int cc = ok ? c : 0;
+        // unconditional loads + selects: a predicated load becomes a branch, and hipcc drains vmcnt(0)
+        // at the join, which would serialise the whole chunk pipeline
+        const int ty = chunk_type[cc], sr = slot_src[cc * 16 + fj];
+        const float mu = slot_mul[cc * 16 + fj];
+        ci.rows = reinterpret_cast<const int4 *>(slot_row + cc * 16)[fq];
+        ci.type = ty;
+        ci.src = ok ? sr : -1;
+        ci.mul = ok ? mu : 0.f;
+        return ci;
+    };
+
+    auto gather = [&](const ChunkIdx &ci, float4 (&x)[2]) {   // 8 k-values (32 B) of source row ci.src
+        const int sidx = ci.src >= 0 ? ci.src : 0;
+        const float4 *px = reinterpret_cast<const float4 *>(h + (int64_t)sidx * ldh + fq * 8);
+#ifdef TGNN_ABLATE_MF_NOGATHER
+        x[0] = make_float4(ci.mul, 1.f, 2.f, 3.f); x[1] = x[0]; (void)px;
+#else
+        x[0] = px[0];
+        x[1] = px[1];
+#endif
+    };
+
+    for (int64_t tile = t_beg; tile < t_end; tile += t_step) {
+        const int c_lo = tile_chunk_ptr[tile], c_hi = tile_chunk_ptr[tile + 1];
+        const int n_ch = c_hi - c_lo;
+        const int c0 = c_lo + (int)((int64_t)n_ch * wave / kMfWaves), c1 = c_lo + (int)((int64_t)n_ch * (wave + 1) / kMfWaves);
+
+        // Software pipeline at BATCH granularity (4 chunks): indices two batches ahead, gathers one batch
+        // ahead, so that every dependent-load level has a whole batch of MFMAs (2048 cycles) to land.
+        // All loads are unconditional (clamped) and straight-line: hipcc keeps counted vmcnt waits.
+        ChunkIdx ia[kBatch], ib[kBatch];                  // batch b+1 (gathers in flight), batch b+2
+        float4 xs[kBatch][2];                             // gathered A fragments of batch b+1
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) ia[u] = load_idx(c0 + u, c0 + u < c1);
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) ib[u] = load_idx(c0 + kBatch + u, c0 + kBatch + u < c1);
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) gather(ia[u], xs[u]);
+        int cur_type = -1;
+        float bw0[8], bw1[8];
+        for (int cb = c0; cb < c1; cb += kBatch) {
+            // ---- rotate: current batch = (ia, xs); start the next batch's gathers and the one after's indices
+            ChunkIdx ic[kBatch];
+            float av[kBatch][8];
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                ic[u] = ia[u];
+                av[u][0] = xs[u][0].x; av[u][1] = xs[u][0].y; av[u][2] = xs[u][0].z; av[u][3] = xs[u][0].w;
+                av[u][4] = xs[u][1].x; av[u][5] = xs[u][1].y; av[u][6] = xs[u][1].z; av[u][7] = xs[u][1].w;
+                ia[u] = ib[u];
+            }
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) gather(ia[u], xs[u]);
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) ib[u] = load_idx(cb + 2 * kBatch + u, cb + 2 * kBatch + u < c1);
+            // ---- compute the batch
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                if (cb + u >= c1) break;                 // wave-uniform tail
+                // B fragments only when the type changes (chunks are type-sorted); the type came with the
+                // prefetched indices -- a load issued here would queue behind the prefetches (in-order vmcnt)
+                const int t = __builtin_amdgcn_readfirstlane(ic[u].type);
+                if (t != cur_type) {                     // wave-uniform
+                    cur_type = t;
+                    const float *wp = wl + t * kWtType + fj * 36 + fq * 8;
+                    const float4 p0 = *reinterpret_cast<const float4 *>(wp), p1 = *reinterpret_cast<const float4 *>(wp + 4);
+                    const float4 p2 = *reinterpret_cast<const float4 *>(wp + kWtNt), p3 = *reinterpret_cast<const float4 *>(wp + kWtNt + 4);
+                    bw0[0] = p0.x; bw0[1] = p0.y; bw0[2] = p0.z; bw0[3] = p0.w; bw0[4] = p1.x; bw0[5] = p1.y; bw0[6] = p1.z; bw0[7] = p1.w;
+                    bw1[0] = p2.x; bw1[1] = p2.y; bw1[2] = p2.z; bw1[3] = p2.w; bw1[4] = p3.x; bw1[5] = p3.y; bw1[6] = p3.z; bw1[7] = p3.w;
+                }
+                // A fragments: zero padding slots, apply the root pre-scale
+                const bool valid = ic[u].src >= 0;
+                float a8[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a8[k] = valid ? av[u][k] * ic[u].mul : 0.f;
+                f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+#ifdef TGNN_ABLATE_MF_NOMFMA
+                    d0[k & 3] += a8[k] * bw0[k]; d1[k & 3] += a8[k] * bw1[k];
+#else
+                    d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a8[k], bw0[k], d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a8[k], bw1[k], d1, 0, 0, 0);
+#endif
+                }
+                // ---- scatter: D row (4q + r) belongs to destination row rows[r]; col = fj (+16).
+                // LDS float atomics run ~2 cycles PER LANE on gfx950 (ds_add_f32: 148 cycles / instruction
+                // measured), so equal-row slots -- adjacent, the group is in CSR order -- are first summed in
+                // registers (segmented scan: in-lane over r, then a 3-step carry across the four 16-lane
+                // groups); the last slot of every run then owns its accumulator row: plain read-add-write.
+                const int r0 = ic[u].rows.x, r1 = ic[u].rows.y, r2 = ic[u].rows.z, r3 = ic[u].rows.w;
+                const bool e1 = r1 == r0, e2 = r2 == r1, e3 = r3 == r2;
+                float s0[4], s1[4];
+                s0[0] = d0[0]; s1[0] = d1[0];
+                s0[1] = e1 ? s0[0] + d0[1] : d0[1]; s1[1] = e1 ? s1[0] + d1[1] : d1[1];
+                s0[2] = e2 ? s0[1] + d0[2] : d0[2]; s1[2] = e2 ? s1[1] + d1[2] : d1[2];
+                s0[3] = e3 ? s0[2] + d0[3] : d0[3]; s1[3] = e3 ? s1[2] + d1[3] : d1[3];
+                const bool lead[4] = {true, e1, e1 && e2, e1 && e2 && e3};     // slots still in the lane's first run
+                const int prev_r3 = __shfl_up(r3, 16, 64), next_r0 = __shfl_down(r0, 16, 64);
+                const bool joins_prev = fq > 0 && prev_r3 == r0;
+#pragma unroll
+                for (int step = 1; step <= 3; ++step) {
+                    const float t0 = __shfl_up(s0[3], 16, 64), t1 = __shfl_up(s1[3], 16, 64);
+                    if (fq == step && joins_prev) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (lead[r]) { s0[r] += t0; s1[r] += t1; }
+                    }
+                }
+                const bool last[4] = {!e1, !e2, !e3, fq == 3 || next_r0 != r3};
+                const int rr[4] = {r0, r1, r2, r3};
+                float *dst[4];
+                float o0[4], o1[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {            // non-final slots are parked on the scratch row 64
+                    dst[r] = acc_w + (last[r] ? rr[r] : 64) * 32 + fj;
+                    o0[r] = dst[r][0];
+                    o1[r] = dst[r][16];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dst[r][0] = o0[r] + s0[r];
+                    dst[r][16] = o1[r] + s1[r];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- fold the 8 accumulators (fixed order), finish the row, re-zero for the next tile
+        {
+            const int64_t v = tile * 64 + fr;
+            float4 sum = make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int w = 0; w < kMfWaves; ++w) {
+                float4 *pa = reinterpret_cast<float4 *>(accs + w * kAccFloats + fr * 32 + fc * 4);
+                const float4 a4 = *pa;
+                sum.x += a4.x; sum.y += a4.y; sum.z += a4.z; sum.w += a4.w;
+                *pa = make_float4(0, 0, 0, 0);
+            }
+            if (v < n) {
+                const int deg = rowptr[v + 1] - rowptr[v];
+                const float inv = 1.0f / (float)(deg > 0 ? deg : 1);
+                float4 o;
+                o.x = fmaf(sum.x, inv, bias4.x); o.y = fmaf(sum.y, inv, bias4.y);
+                o.z = fmaf(sum.z, inv, bias4.z); o.w = fmaf(sum.w, inv, bias4.w);
+                if (act == TGNN_ACT_LEAKY_RELU) { o.x = leakyf_(o.x); o.y = leakyf_(o.y); o.z = leakyf_(o.z); o.w = leakyf_(o.w); }
+                *reinterpret_cast<float4 *>(out + v * 32 + fc * 4) = o;
+                cs[0] += (double)o.x; cq[0] += (double)o.x * (double)o.x;
+                cs[1] += (double)o.y; cq[1] += (double)o.y * (double)o.y;
+                cs[2] += (double)o.z; cq[2] += (double)o.z * (double)o.z;
+                cs[3] += (double)o.w; cq[3] += (double)o.w * (double)o.w;
+            }
+        }
+        __syncthreads();
+    }
+
+    if (bn_partial) {
+        // 64 row-threads per column group: fold in fixed order through LDS ([64][64] doubles = 32 KB, aliases accs)
+        double *red = reinterpret_cast<double *>(accs);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            red[fr * 64 + fc * 4 + k] = cs[k];
+            red[fr * 64 + 32 + fc * 4 + k] = cq[k];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            double tot = 0.0;
+            for (int r = 0; r < 64; ++r) tot += red[r * 64 + tid];
+            bn_partial[(int64_t)blockIdx.x * 64 + tid] = tot;   // [2][32]: sums then sums of squares
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Generic fallback (any C, any T): one thread per (row, output); weights read through L2.
 // Used when the table does not fit LDS or C != 32.  Correct, not fast.
 // ------------------------------------------------------------------------------------------
@@ -351,7 +594,7 @@ extern "C" int tgnn_edge_weight_table(const float *edge_attr, const int32_t *typ
                                       tgnn_stream_t stream) {
     if (n_types <= 0) return TGNN_OK;
     TGNN_CHECK_ARG(edge_attr && type_rep_edge && w1 && b1 && w2 && b2 && w3 && b3 && wtab, "null pointer");
-    TGNN_CHECK_ARG(fe >= 1 && fe <= 256, "edge feature dim must be in [1,256]");
+    TGNN_CHECK_ARG(fe >= 1 && fe <= 1024, "edge feature dim must be in [1,1024]");
     TGNN_CHECK_ARG(c >= 1, "width");
     TGNN_CHECK_ARG((uintptr_t)w3 % 16 == 0, "w3 must be 16-byte aligned");
     EdgeMlpLayers layers{};
@@ -404,4 +647,45 @@ extern "C" int tgnn_nnconv_mean_fwd(const float *h, int64_t ldh, const int32_t *
     }
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
+}
+
+extern "C" int tgnn_nnconv_mean_tiled_fwd(const float *h, int64_t ldh, const int32_t *rowptr,
+                                          const int32_t *tile_chunk_ptr, const int32_t *chunk_type,
+                                          const int32_t *slot_src, const int32_t *slot_row, const float *slot_mul,
+                                          const float *wtab, int32_t n_types, const float *root, const float *bias,
+                                          int64_t n_nodes, int32_t c, int32_t act, float *out, double *bn_partial,
+                                          int32_t *n_partials_host, tgnn_stream_t stream) {
+    TGNN_CHECK_ARG(n_nodes >= 1 && c == 32, "tiled NNConv is built for network_width 32");
+    TGNN_CHECK_ARG(act == TGNN_ACT_NONE || act == TGNN_ACT_LEAKY_RELU, "activation");
+    TGNN_CHECK_ARG(h && rowptr && tile_chunk_ptr && chunk_type && slot_src && slot_row && slot_mul && root && bias && out,
+                   "null pointer");
+    TGNN_CHECK_ARG(n_types == 0 || wtab, "null weight table");
+    TGNN_CHECK_ARG(ldh >= 32 && ldh % 4 == 0 && ((uintptr_t)h % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
+                       ((uintptr_t)bias % 16) == 0, "alignment");
+    const size_t lds_bytes = ((size_t)(n_types + 1) * kWtType + (size_t)kMfWaves * kAccFloats) * sizeof(float);
+    if (lds_bytes > kMaxDynLds) {
+        set_error("tgnn_nnconv_mean_tiled_fwd: %d edge types do not fit the LDS weight image (max %d)", n_types,
+                  (int)((kMaxDynLds / sizeof(float) - kMfWaves * kAccFloats) / kWtType) - 1);
+        return TGNN_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    static bool attr_set = false;
+    if (!attr_set) {
+        TGNN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nnconv32_mfma_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
+        attr_set = true;
+    }
+    int blocks = producer_blocks(n_nodes, 64);
+    if (blocks > 256) blocks = 256;            // one block per CU (LDS), persistent over tiles
+    if (blocks >= 8) blocks &= ~7;
+    nnconv32_mfma_kernel<<<blocks, kMfThreads, lds_bytes, s>>>(h, ldh, rowptr, tile_chunk_ptr, chunk_type, slot_src,
+                                                               slot_row, slot_mul, wtab, n_types, root, bias, n_nodes,
+                                                               act, out, bn_partial);
+    if (n_partials_host) *n_partials_host = blocks;
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}
+
+extern "C" int32_t tgnn_nnconv_tiled_max_types(void) {
+    return (int32_t)((kMaxDynLds / sizeof(float) - kMfWaves * kAccFloats) / kWtType) - 1;
 }

@@ -56,12 +56,16 @@ struct Carver {
     bool ok() const { return off <= cap; }
 };
 
+// sigmoid on the hardware transcendentals: v_exp_f32 (via exp2(x * log2 e)) and v_rcp_f32, both
+// ~1 ulp; worst-case relative error ~6e-7 at |x| = 10 (argument rounding), two orders below the
+// 1e-5 parity bar.  The IEEE expf + division sequence cost as many VALU cycles as the GIN MLP's
+// MFMAs (64 sigmoids per lane per 32-row tile).
+__device__ __forceinline__ float sigmoidf_(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == TGNN_ACT_LEAKY_RELU) return v >= 0.f ? v : v * kLeakySlope;
-    if (act == TGNN_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    if (act == TGNN_ACT_SIGMOID) return sigmoidf_(v);
     return v;
 }
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 __device__ __forceinline__ float leakyf_(float v) { return v >= 0.f ? v : v * kLeakySlope; }
 
 // BatchNorm apply from a stat record [4][F] (mean_hi, mean_lo, ginv, beta) -- see tgnn.h

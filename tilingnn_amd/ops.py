@@ -69,11 +69,46 @@ class PreparedGraph:
     col_rowptr: Tensor
     col_src: Tensor
     col_eid: Tensor
+    tiles: Optional["NNConvTiles"] = None      # MFMA NNConv tile structure (None: CSR kernel is used)
 
     def c_struct(self) -> _lib.Graph:
+        t = self.tiles
         return _lib.Graph(self.n_nodes, self.n_adj_edges, self.n_col_edges, self.n_types,
                           self.adj_rowptr.data_ptr(), self.adj_src.data_ptr(), self.adj_type.data_ptr(),
-                          self.type_rep_edge.data_ptr(), self.col_rowptr.data_ptr(), self.col_src.data_ptr())
+                          self.type_rep_edge.data_ptr(), self.col_rowptr.data_ptr(), self.col_src.data_ptr(),
+                          *( (t.tile_chunk_ptr.data_ptr(), t.chunk_type.data_ptr(), t.slot_src.data_ptr(),
+                              t.slot_row.data_ptr(), t.slot_mul.data_ptr()) if t is not None else (None,) * 5))
+
+
+@dataclass
+class NNConvTiles:
+    """Per-64-row tiles of type-grouped, 16-padded in-edges (tgnn_nnconv_tiles_build)."""
+    tile_chunk_ptr: Tensor
+    chunk_type: Tensor
+    slot_src: Tensor
+    slot_row: Tensor
+    slot_mul: Tensor
+
+
+def build_nnconv_tiles(n_nodes: int, n_edges: int, n_types: int, rowptr: Tensor, col_src: Tensor,
+                       col_type: Tensor) -> Optional[NNConvTiles]:
+    """None when the layout has more edge types than the MFMA kernel's LDS weight image holds."""
+    if n_types > lib.tgnn_nnconv_tiled_max_types():
+        return None
+    dev = rowptr.device
+    cap = int(lib.tgnn_nnconv_tiles_max_chunks(n_nodes, n_edges, n_types))
+    ntiles = (n_nodes + 63) // 64
+    tiles = NNConvTiles(torch.empty(ntiles + 1, dtype=torch.int32, device=dev),
+                        torch.empty(cap, dtype=torch.int32, device=dev),
+                        torch.empty(cap * 16, dtype=torch.int32, device=dev),
+                        torch.empty(cap * 16, dtype=torch.int32, device=dev),
+                        torch.empty(cap * 16, dtype=torch.float32, device=dev))
+    ws_bytes = lib.tgnn_nnconv_tiles_workspace_bytes(n_nodes)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    check(lib.tgnn_nnconv_tiles_build(ptr(rowptr), ptr(col_src), ptr(col_type), n_nodes, n_types,
+                                      ptr(tiles.tile_chunk_ptr), ptr(tiles.chunk_type), ptr(tiles.slot_src),
+                                      ptr(tiles.slot_row), ptr(tiles.slot_mul), ptr(ws), ws_bytes, _stream(rowptr)))
+    return tiles
 
 
 def _check_edge_index(ei: Tensor, name: str) -> Tensor:
@@ -119,7 +154,8 @@ def dedup_edge_types(edge_attr: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
     return edge_type, rep, n_types
 
 
-def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col_e_idx: Tensor) -> PreparedGraph:
+def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col_e_idx: Tensor,
+                  tile_width: int = 32) -> PreparedGraph:
     """Everything the 20 layers share: CSR of both edge sets, edge-type ids in CSR order.
     Synchronises once (the type count and the self-loop-free collision edge count are read back)."""
     adj = _check_edge_index(adj_e_index, "adj_e_index")
@@ -136,8 +172,10 @@ def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col
     if host[1] or host[2]:
         raise IndexError(f"edge index out of range [0, {n_nodes}) in "
                          f"{'adj_e_index' if host[1] else 'col_e_idx'}")
-    return PreparedGraph(n_nodes, ea, int(host[3]), int(host[0]), a_rowptr, a_src, a_eid, adj_type, edge_type, rep,
-                         c_rowptr, c_src, c_eid)
+    n_types = int(host[0])
+    tiles = build_nnconv_tiles(n_nodes, ea, n_types, a_rowptr, a_src, adj_type) if tile_width == 32 else None
+    return PreparedGraph(n_nodes, ea, int(host[3]), n_types, a_rowptr, a_src, a_eid, adj_type, edge_type, rep,
+                         c_rowptr, c_src, c_eid, tiles)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -162,7 +200,9 @@ def edge_weight_table(edge_attr: Tensor, graph: PreparedGraph, w1, b1, w2, b2, w
 
 
 def nnconv_mean(h: Tensor, graph: PreparedGraph, wtab: Tensor, root: Tensor, bias: Tensor, act: int = ACT_NONE,
-                partials: Optional[Tensor] = None) -> Tuple[Tensor, int]:
+                partials: Optional[Tensor] = None, force_csr_kernel: bool = False) -> Tuple[Tensor, int]:
+    """NNConv mean: the MFMA tile kernel when the graph carries tiles (width 32, few edge types),
+    else the CSR / LDS-weight-table kernel (any type count that fits LDS) or the generic one."""
     h = _f32c(h, "x")
     n, c = int(h.shape[0]), int(h.shape[1])
     if n != graph.n_nodes:
@@ -172,9 +212,16 @@ def nnconv_mean(h: Tensor, graph: PreparedGraph, wtab: Tensor, root: Tensor, bia
     out = torch.empty(n, c, dtype=torch.float32, device=h.device)
     npart = C.c_int32(0)
     wt = _f32c(wtab, "wtab")
-    check(lib.tgnn_nnconv_mean_fwd(ptr(h), c, ptr(graph.adj_rowptr), ptr(graph.adj_src), ptr(graph.adj_type), ptr(wt),
-                                   graph.n_types, ptr(_f32c(root, "root")), ptr(_f32c(bias, "bias")), n, c, act,
-                                   ptr(out), ptr(partials), C.byref(npart), _stream(h)))
+    tl = graph.tiles
+    if tl is not None and c == 32 and not force_csr_kernel:
+        check(lib.tgnn_nnconv_mean_tiled_fwd(ptr(h), c, ptr(graph.adj_rowptr), ptr(tl.tile_chunk_ptr), ptr(tl.chunk_type),
+                                             ptr(tl.slot_src), ptr(tl.slot_row), ptr(tl.slot_mul), ptr(wt), graph.n_types,
+                                             ptr(_f32c(root, "root")), ptr(_f32c(bias, "bias")), n, c, act, ptr(out),
+                                             ptr(partials), C.byref(npart), _stream(h)))
+    else:
+        check(lib.tgnn_nnconv_mean_fwd(ptr(h), c, ptr(graph.adj_rowptr), ptr(graph.adj_src), ptr(graph.adj_type), ptr(wt),
+                                       graph.n_types, ptr(_f32c(root, "root")), ptr(_f32c(bias, "bias")), n, c, act,
+                                       ptr(out), ptr(partials), C.byref(npart), _stream(h)))
     return out, npart.value
 
 
