@@ -121,26 +121,30 @@ int tgnn_nnconv_mean_fwd(const float *h, int64_t ldh, const int32_t *rowptr, con
  *
  * Tile structure (adjacency set, once per layout): every 64 destination rows form a tile whose
  * in-edges are grouped by edge type and padded to 16-slot chunks, followed by 4 chunks of
- * pseudo-type T carrying the rows themselves (the root term):
+ * pseudo-type T carrying the rows themselves (the root term h[v] . root):
  *   tile_chunk_ptr int32 [ceil(N/64)+1]   chunk range of every tile
- *   chunk_type     int32 [n_chunks]       edge type of the chunk, T for root chunks
+ *   chunk_meta     int32 [8*n_chunks]     32-byte record per chunk (must be 32-byte aligned):
+ *                                         word 0 = edge type (T = root chunk), words 1-3 = 0,
+ *                                         words 4-7 = destination rows inside the tile, one byte per
+ *                                         slot (0..63; 64 = padding): word 4+q holds slots 4q..4q+3
  *   slot_src       int32 [16*n_chunks]    source row, -1 = padding
- *   slot_row       int32 [16*n_chunks]    destination row inside the tile, 0..63 (64 = padding)
- *   slot_mul       float [16*n_chunks]    0 padding, 1 edge, max(deg,1) root
  * n_chunks <= tgnn_nnconv_tiles_max_chunks(N, E, T) (allocate for that); the exact count is
  * tile_chunk_ptr[ceil(N/64)]. */
 int64_t tgnn_nnconv_tiles_max_chunks(int64_t n_nodes, int64_t n_edges, int32_t n_types);
 size_t tgnn_nnconv_tiles_workspace_bytes(int64_t n_nodes);
 int tgnn_nnconv_tiles_build(const int32_t *rowptr, const int32_t *col_src, const int32_t *col_type,
-                            int64_t n_nodes, int32_t n_types, int32_t *tile_chunk_ptr, int32_t *chunk_type,
-                            int32_t *slot_src, int32_t *slot_row, float *slot_mul, void *ws, size_t ws_bytes,
-                            tgnn_stream_t stream);
+                            int64_t n_nodes, int32_t n_types, int32_t *tile_chunk_ptr, int32_t *chunk_meta,
+                            int32_t *slot_src, void *ws, size_t ws_bytes, tgnn_stream_t stream);
 int32_t tgnn_nnconv_tiled_max_types(void);
+/* wimg_scratch: tgnn_nnconv_weight_image_floats(T) floats of caller scratch (the [T][C][C] table and
+ * the root matrix are re-laid out into MFMA B-operand order there before the main kernel runs). */
+size_t tgnn_nnconv_weight_image_floats(int32_t n_types);
 int tgnn_nnconv_mean_tiled_fwd(const float *h, int64_t ldh, const int32_t *rowptr, const int32_t *tile_chunk_ptr,
-                               const int32_t *chunk_type, const int32_t *slot_src, const int32_t *slot_row,
-                               const float *slot_mul, const float *wtab, int32_t n_types, const float *root,
+                               const int32_t *chunk_meta, const int32_t *slot_src,
+                               const float *wtab, int32_t n_types, const float *root,
                                const float *bias, int64_t n_nodes, int32_t c, int32_t act, float *out,
-                               double *bn_partial, int32_t *n_partials_host, tgnn_stream_t stream);
+                               float *wimg_scratch, double *bn_partial, int32_t *n_partials_host,
+                               tgnn_stream_t stream);
 
 /* GINConv + optional LeakyReLU (coll_conv.py:25-27):
  *   z[v]  = (1+eps) * f(a[v]) + sum_{e: dst_e = v} f(a[src_e]),   f = identity or the BatchNorm
@@ -218,10 +222,8 @@ typedef struct tgnn_graph {
     const int32_t *col_src;     /* [Ec'] */
     /* NNConv tile structure (all NULL => tgnn_forward uses the CSR kernel) */
     const int32_t *tile_chunk_ptr;
-    const int32_t *chunk_type;
+    const int32_t *chunk_meta;
     const int32_t *slot_src;
-    const int32_t *slot_row;
-    const float *slot_mul;
 } tgnn_graph;
 
 size_t tgnn_forward_workspace_bytes(const tgnn_model_dims *dims, int64_t n_nodes, int32_t n_types);

@@ -99,7 +99,7 @@ def test_labyrinth_graph_has_13_edge_types(dev):
     assert len(pairs) == 13
 
 
-@pytest.mark.parametrize("n,e,t,seed", [(5, 12, 3, 0), (64, 700, 13, 1), (1254, 8502, 13, 2), (20001, 260000, 19, 3)])
+@pytest.mark.parametrize("n,e,t,seed", [(5, 12, 3, 0), (64, 700, 13, 1), (1254, 8502, 13, 2), (20001, 260000, 17, 3)])
 def test_nnconv_tile_structure(dev, n, e, t, seed):
     """Tiles = per 64 destination rows the in-edges grouped by type (CSR order inside a group), padded to
     16-slot chunks, followed by 4 root chunks of pseudo-type T."""
@@ -112,8 +112,11 @@ def test_nnconv_tile_structure(dev, n, e, t, seed):
     tiles = ops.build_nnconv_tiles(n, e, t, rowptr, src, col_type)
     rp, srcs, ctype = rowptr.cpu().numpy(), src.cpu().numpy()[:e], col_type.cpu().numpy()
     tcp = tiles.tile_chunk_ptr.cpu().numpy()
-    chunk_type = tiles.chunk_type.cpu().numpy(); s_src = tiles.slot_src.cpu().numpy()
-    s_row = tiles.slot_row.cpu().numpy(); s_mul = tiles.slot_mul.cpu().numpy()
+    tcp = tiles.tile_chunk_ptr.cpu().numpy()
+    meta = tiles.chunk_meta.cpu().numpy().reshape(-1, 8)
+    chunk_type = meta[:, 0]; s_src = tiles.slot_src.cpu().numpy()
+    s_row = np.ascontiguousarray(meta[:, 4:8]).view(np.uint8).reshape(-1).astype(np.int64)
+    assert (meta[: tcp[-1], 1:4] == 0).all()
     ntiles = (n + 63) // 64
     assert tcp[0] == 0 and tcp.shape[0] == ntiles + 1
     for b in range(ntiles):
@@ -132,15 +135,13 @@ def test_nnconv_tile_structure(dev, n, e, t, seed):
             want = ctype[e0:e1] == k
             np.testing.assert_array_equal(s_src[sl][sel], srcs[e0:e1][want])
             np.testing.assert_array_equal(s_row[sl][sel], rows_of[want])
-            assert (s_mul[sl][sel] == 1.0).all()
         pad = (slot_t < t) & (s_src[sl] < 0)
-        assert (s_mul[sl][pad] == 0).all() and (s_row[sl][pad] == 64).all()
+        assert (s_row[sl][pad] == 64).all()
         root = slot_t == t
         deg = np.diff(rp[r0:r1 + 1])
         np.testing.assert_array_equal(s_row[sl][root], np.arange(64))
         np.testing.assert_array_equal(s_src[sl][root][: r1 - r0], np.arange(r0, r1))
         assert (s_src[sl][root][r1 - r0:] == -1).all()
-        np.testing.assert_array_equal(s_mul[sl][root][: r1 - r0], np.maximum(deg, 1).astype(np.float32))
 
 
 def test_nnconv_csr_kernel_and_tile_kernel_agree_with_oracle(dev):

@@ -32,8 +32,7 @@ class Graph(C.Structure):
                 ("n_types", C.c_int32),
                 ("adj_rowptr", C.c_void_p), ("adj_src", C.c_void_p), ("adj_type", C.c_void_p),
                 ("type_rep_edge", C.c_void_p), ("col_rowptr", C.c_void_p), ("col_src", C.c_void_p),
-                ("tile_chunk_ptr", C.c_void_p), ("chunk_type", C.c_void_p), ("slot_src", C.c_void_p),
-                ("slot_row", C.c_void_p), ("slot_mul", C.c_void_p)]
+                ("tile_chunk_ptr", C.c_void_p), ("chunk_meta", C.c_void_p), ("slot_src", C.c_void_p)]
 
 
 def _load() -> C.CDLL:
@@ -57,9 +56,10 @@ def _load() -> C.CDLL:
         "tgnn_nnconv_mean_fwd": (C.c_int, [p, i64, p, p, p, p, i32, p, p, i64, i32, i32, p, p, pi32, p]),
         "tgnn_nnconv_tiles_max_chunks": (i64, [i64, i64, i32]),
         "tgnn_nnconv_tiles_workspace_bytes": (sz, [i64]),
-        "tgnn_nnconv_tiles_build": (C.c_int, [p, p, p, i64, i32, p, p, p, p, p, p, sz, p]),
+        "tgnn_nnconv_tiles_build": (C.c_int, [p, p, p, i64, i32, p, p, p, p, sz, p]),
         "tgnn_nnconv_tiled_max_types": (i32, []),
-        "tgnn_nnconv_mean_tiled_fwd": (C.c_int, [p, i64, p, p, p, p, p, p, p, i32, p, p, i64, i32, i32, p, p, pi32, p]),
+        "tgnn_nnconv_weight_image_floats": (sz, [i32]),
+        "tgnn_nnconv_mean_tiled_fwd": (C.c_int, [p, i64, p, p, p, p, p, i32, p, p, i64, i32, i32, p, p, p, pi32, p]),
         "tgnn_gin_fwd": (C.c_int, [p, i64, p, p, p, p, p, p, p, p, p, p, i64, i32, i32, p, p, p, pi32, p]),
         "tgnn_dense_act_fwd": (C.c_int, [p, i64, i64, p, p, p, i64, i32, i32, i32, p, i64, p, pi32, p]),
         "tgnn_bn_finalize": (C.c_int, [i32, p, i32, p, i32, i64, p, p, f32, f32, p, p, p, p, p]),
@@ -86,7 +86,7 @@ EXPORTED_SYMBOLS = (
     "tgnn_version", "tgnn_last_error", "tgnn_csr_workspace_bytes", "tgnn_csr_build",
     "tgnn_edge_dedup_workspace_bytes", "tgnn_edge_type_dedup", "tgnn_gather_i32", "tgnn_edge_weight_table",
     "tgnn_nnconv_mean_fwd", "tgnn_nnconv_tiles_max_chunks", "tgnn_nnconv_tiles_workspace_bytes",
-    "tgnn_nnconv_tiles_build", "tgnn_nnconv_tiled_max_types", "tgnn_nnconv_mean_tiled_fwd", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
+    "tgnn_nnconv_tiles_build", "tgnn_nnconv_tiled_max_types", "tgnn_nnconv_weight_image_floats", "tgnn_nnconv_mean_tiled_fwd", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
     "tgnn_merge_fwd", "tgnn_param_count", "tgnn_param_name", "tgnn_forward_workspace_bytes", "tgnn_forward",
     "tgnn_forward_profiled",
     "tgnn_rows_gather", "tgnn_rows_scatter")

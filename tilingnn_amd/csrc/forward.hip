@@ -96,7 +96,7 @@ static bool dims_ok(const tgnn_model_dims *d) {
 }
 
 struct Workspace {
-    float *mid, *a1, *a2[2], *t0, *f1, *f2, *f3, *f4, *wtab;
+    float *mid, *a1, *a2[2], *t0, *f1, *f2, *f3, *f4, *wtab, *wimg;
     double *part1, *part2, *partf;
     float *stat1, *stat2[2], *stat_i[2], *stat_f[4];
     size_t bytes;
@@ -152,6 +152,7 @@ static Workspace carve(const tgnn_model_dims &d, int64_t n, int32_t n_types, voi
     w.f3 = cv.take<float>((size_t)n * 64);
     w.f4 = cv.take<float>((size_t)n * c);
     w.wtab = cv.take<float>((size_t)D * (n_types > 0 ? n_types : 1) * c * c);
+    w.wimg = cv.take<float>((size_t)D * (n_types + 1) * 1152);     // MFMA B-operand images (tiled NNConv)
     w.part1 = cv.take<double>((size_t)TGNN_BN_MAX_PARTIALS * 2 * c);
     w.part2 = cv.take<double>((size_t)TGNN_BN_MAX_PARTIALS * 2 * c);
     w.partf = cv.take<double>((size_t)TGNN_BN_MAX_PARTIALS * 2 * 256);
@@ -252,6 +253,14 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         launch_edge_weight_table_batched(adj_edge_attr, graph->type_rep_edge, T, fe, layers, D, c, w.wtab, s);
         prof.end();
     }
+    const bool tiled = graph->tile_chunk_ptr && c == 32;
+    if (tiled) {
+        const float *roots[kMaxDepth];
+        for (int i = 0; i < D; ++i) roots[i] = P.f(P.layer(i) + 6);
+        prof.begin(0);
+        launch_nnconv_weight_image(w.wtab, roots, T, D, w.wimg, s);
+        prof.end();
+    }
 
     // ---- K10: init MLP  (TilinGNN.py:54)
     prof.begin(1);
@@ -274,11 +283,10 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         const float *h1 = w.mid + (size_t)i * n * c;
         // GraphConv (:62): NNConv mean + LeakyReLU; BN statistics emitted as partials
         prof.begin(2);
-        if (graph->tile_chunk_ptr && c == 32) {
-            TGNN_TRY(tgnn_nnconv_mean_tiled_fwd(h1, c, graph->adj_rowptr, graph->tile_chunk_ptr, graph->chunk_type,
-                                                graph->slot_src, graph->slot_row, graph->slot_mul,
-                                                w.wtab + (size_t)i * T * c * c, T, P.f(b + 6), P.f(b + 7), n, c,
-                                                TGNN_ACT_LEAKY_RELU, w.a1, w.part1, &np1, s));
+        if (tiled) {
+            TGNN_TRY(launch_nnconv_tiled(h1, c, graph->adj_rowptr, graph->tile_chunk_ptr, graph->chunk_meta,
+                                         graph->slot_src, w.wimg + (size_t)i * (T + 1) * 1152, T, P.f(b + 7), n, TGNN_ACT_LEAKY_RELU, w.a1,
+                                         w.part1, &np1, s));
         } else {
             TGNN_TRY(tgnn_nnconv_mean_fwd(h1, c, graph->adj_rowptr, graph->adj_src, graph->adj_type,
                                       w.wtab + (size_t)i * T * c * c, T, P.f(b + 6), P.f(b + 7), n, c,

@@ -121,8 +121,9 @@ __global__ __launch_bounds__(kMlpThreads) void gin32_mlp_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int idx = j * 64 + lane, r = idx >> 3, qq = idx & 7;
-            float4 v4 = make_float4(0, 0, 0, 0);
-            if (row0 + r < n) v4 = *reinterpret_cast<const float4 *>(z + (row0 + r) * 32 + 4 * qq);
+            int64_t zr = row0 + r;                       // clamped, unconditional: rows >= n are masked at the store
+            zr = zr < n ? zr : n - 1;
+            const float4 v4 = *reinterpret_cast<const float4 *>(z + zr * 32 + 4 * qq);
             float *d = A + r * kBufALd + 4 * qq;
             d[0] = v4.x; d[1] = v4.y; d[2] = v4.z; d[3] = v4.w;
         }

@@ -236,10 +236,11 @@ __global__ __launch_bounds__(64) void nnconv_tile_count_kernel(const int *__rest
     if (lane == 0) tile_chunks[b] = c + kTileRows / 16;
 }
 
+// chunk_meta: 8 int32 per chunk = {type, 0, 0, 0, rows[0..3]}: rows[q] packs the destination rows (tile-local,
+// 64 = padding) of slots 4q..4q+3, one byte each.  32 bytes, wave-uniform -> fetched with scalar loads.
 __global__ __launch_bounds__(64) void nnconv_tile_fill_kernel(
     const int *__restrict__ rowptr, const int *__restrict__ col_src, const int *__restrict__ col_type, int64_t n,
-    int n_types, const int *__restrict__ tile_chunk_ptr, int *__restrict__ chunk_type, int *__restrict__ slot_src,
-    int *__restrict__ slot_row, float *__restrict__ slot_mul) {
+    int n_types, const int *__restrict__ tile_chunk_ptr, int *__restrict__ chunk_meta, int *__restrict__ slot_src) {
     __shared__ int cnt[kMaxTileTypes];
     __shared__ int base[kMaxTileTypes + 1];   // first slot (tile-relative) of every type group; [T] = root group
     __shared__ int run[kMaxTileTypes];
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(64) void nnconv_tile_fill_kernel(
     const int64_t chunk0 = tile_chunk_ptr[b];
     const int64_t slot0 = chunk0 * 16;
     const int n_slots = root_base + kTileRows;
+    unsigned char *rows_b = reinterpret_cast<unsigned char *>(chunk_meta);   // byte view: row of slot s of chunk c at c*32+16+s
     // chunk types + padding defaults
     for (int k = lane; k < n_slots / 16; k += 64) {
         int t = n_types;                                       // root
@@ -278,20 +280,19 @@ __global__ __launch_bounds__(64) void nnconv_tile_fill_kernel(
             t = 0;
             while (t + 1 < n_types && base[t + 1] <= k * 16) ++t;
         }
-        chunk_type[chunk0 + k] = t;
+        int *m = chunk_meta + (chunk0 + k) * 8;
+        m[0] = t; m[1] = 0; m[2] = 0; m[3] = 0;
     }
     for (int i = lane; i < root_base; i += 64) {
         slot_src[slot0 + i] = -1;
-        slot_row[slot0 + i] = kTileRows;                       // scratch accumulator row: never read back
-        slot_mul[slot0 + i] = 0.f;
+        rows_b[(chunk0 + (i >> 4)) * 32 + 16 + (i & 15)] = (unsigned char)kTileRows;   // scratch row: never read back
     }
-    // root group: the rows themselves, pre-multiplied by max(deg,1) so that the common 1/deg scale cancels
+    // root group: the rows themselves (chunk k of the group covers tile rows 16k .. 16k+15)
     {
         const bool ok = lane < rows;
-        const int deg = ok ? rp[lane + 1] - rp[lane] : 0;
-        slot_src[slot0 + root_base + lane] = ok ? (int)(r0 + lane) : -1;
-        slot_row[slot0 + root_base + lane] = lane;
-        slot_mul[slot0 + root_base + lane] = ok ? (float)(deg > 0 ? deg : 1) : 0.f;
+        const int i = root_base + lane;
+        slot_src[slot0 + i] = ok ? (int)(r0 + lane) : -1;
+        rows_b[(chunk0 + (i >> 4)) * 32 + 16 + (i & 15)] = (unsigned char)lane;
     }
     __syncthreads();
     // stable placement: edges in CSR (= original) order inside every type group
@@ -313,10 +314,9 @@ __global__ __launch_bounds__(64) void nnconv_tile_fill_kernel(
             if (m == 0ull) continue;                           // wave-uniform
             if (t == tt) {
                 const int rank = __popcll(m & ((1ull << lane) - 1ull));
-                const int64_t s_ = slot0 + base[tt] + run[tt] + rank;
-                slot_src[s_] = col_src[e];
-                slot_row[s_] = row;
-                slot_mul[s_] = 1.0f;
+                const int i = base[tt] + run[tt] + rank;
+                slot_src[slot0 + i] = col_src[e];
+                rows_b[(chunk0 + (i >> 4)) * 32 + 16 + (i & 15)] = (unsigned char)row;
             }
             __syncthreads();
             if (lane == 0) run[tt] += __popcll(m);
@@ -436,11 +436,12 @@ extern "C" size_t tgnn_nnconv_tiles_workspace_bytes(int64_t n_nodes) {
 
 extern "C" int tgnn_nnconv_tiles_build(const int32_t *rowptr, const int32_t *col_src, const int32_t *col_type,
                                        int64_t n_nodes, int32_t n_types, int32_t *tile_chunk_ptr,
-                                       int32_t *chunk_type, int32_t *slot_src, int32_t *slot_row, float *slot_mul,
-                                       void *ws, size_t ws_bytes, tgnn_stream_t stream) {
+                                       int32_t *chunk_meta, int32_t *slot_src, void *ws, size_t ws_bytes,
+                                       tgnn_stream_t stream) {
     TGNN_CHECK_ARG(n_nodes >= 1, "n_nodes");
     TGNN_CHECK_ARG(n_types >= 0 && n_types <= kMaxTileTypes - 1, "tiled NNConv supports at most 63 edge types");
-    TGNN_CHECK_ARG(rowptr && tile_chunk_ptr && chunk_type && slot_src && slot_row && slot_mul, "null pointer");
+    TGNN_CHECK_ARG(rowptr && tile_chunk_ptr && chunk_meta && slot_src, "null pointer");
+    TGNN_CHECK_ARG((uintptr_t)chunk_meta % 32 == 0, "chunk_meta must be 32-byte aligned");
     if (!ws || ws_bytes < tgnn_nnconv_tiles_workspace_bytes(n_nodes)) {
         set_error("tgnn_nnconv_tiles_build: workspace too small");
         return TGNN_ERR_WORKSPACE;
@@ -454,7 +455,7 @@ extern "C" int tgnn_nnconv_tiles_build(const int32_t *rowptr, const int32_t *col
     nnconv_tile_count_kernel<<<(unsigned)ntiles, 64, 0, s>>>(rowptr, col_type, n_nodes, n_types, tile_chunks);
     exclusive_scan_i32(tile_chunks, tile_chunk_ptr, ntiles + 1, scan_ws, s);
     nnconv_tile_fill_kernel<<<(unsigned)ntiles, 64, 0, s>>>(rowptr, col_src, col_type, n_nodes, n_types, tile_chunk_ptr,
-                                                           chunk_type, slot_src, slot_row, slot_mul);
+                                                           chunk_meta, slot_src);
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
 }

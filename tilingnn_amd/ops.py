@@ -76,18 +76,16 @@ class PreparedGraph:
         return _lib.Graph(self.n_nodes, self.n_adj_edges, self.n_col_edges, self.n_types,
                           self.adj_rowptr.data_ptr(), self.adj_src.data_ptr(), self.adj_type.data_ptr(),
                           self.type_rep_edge.data_ptr(), self.col_rowptr.data_ptr(), self.col_src.data_ptr(),
-                          *( (t.tile_chunk_ptr.data_ptr(), t.chunk_type.data_ptr(), t.slot_src.data_ptr(),
-                              t.slot_row.data_ptr(), t.slot_mul.data_ptr()) if t is not None else (None,) * 5))
+                          *((t.tile_chunk_ptr.data_ptr(), t.chunk_meta.data_ptr(), t.slot_src.data_ptr())
+                            if t is not None else (None,) * 3))
 
 
 @dataclass
 class NNConvTiles:
     """Per-64-row tiles of type-grouped, 16-padded in-edges (tgnn_nnconv_tiles_build)."""
     tile_chunk_ptr: Tensor
-    chunk_type: Tensor
+    chunk_meta: Tensor        # int32 [8 * n_chunks]: {type, 0, 0, 0, 16 destination-row bytes}
     slot_src: Tensor
-    slot_row: Tensor
-    slot_mul: Tensor
 
 
 def build_nnconv_tiles(n_nodes: int, n_edges: int, n_types: int, rowptr: Tensor, col_src: Tensor,
@@ -99,15 +97,13 @@ def build_nnconv_tiles(n_nodes: int, n_edges: int, n_types: int, rowptr: Tensor,
     cap = int(lib.tgnn_nnconv_tiles_max_chunks(n_nodes, n_edges, n_types))
     ntiles = (n_nodes + 63) // 64
     tiles = NNConvTiles(torch.empty(ntiles + 1, dtype=torch.int32, device=dev),
-                        torch.empty(cap, dtype=torch.int32, device=dev),
-                        torch.empty(cap * 16, dtype=torch.int32, device=dev),
-                        torch.empty(cap * 16, dtype=torch.int32, device=dev),
-                        torch.empty(cap * 16, dtype=torch.float32, device=dev))
+                        torch.empty(cap * 8, dtype=torch.int32, device=dev),
+                        torch.empty(cap * 16, dtype=torch.int32, device=dev))
     ws_bytes = lib.tgnn_nnconv_tiles_workspace_bytes(n_nodes)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     check(lib.tgnn_nnconv_tiles_build(ptr(rowptr), ptr(col_src), ptr(col_type), n_nodes, n_types,
-                                      ptr(tiles.tile_chunk_ptr), ptr(tiles.chunk_type), ptr(tiles.slot_src),
-                                      ptr(tiles.slot_row), ptr(tiles.slot_mul), ptr(ws), ws_bytes, _stream(rowptr)))
+                                      ptr(tiles.tile_chunk_ptr), ptr(tiles.chunk_meta), ptr(tiles.slot_src),
+                                      ptr(ws), ws_bytes, _stream(rowptr)))
     return tiles
 
 
@@ -214,10 +210,11 @@ def nnconv_mean(h: Tensor, graph: PreparedGraph, wtab: Tensor, root: Tensor, bia
     wt = _f32c(wtab, "wtab")
     tl = graph.tiles
     if tl is not None and c == 32 and not force_csr_kernel:
-        check(lib.tgnn_nnconv_mean_tiled_fwd(ptr(h), c, ptr(graph.adj_rowptr), ptr(tl.tile_chunk_ptr), ptr(tl.chunk_type),
-                                             ptr(tl.slot_src), ptr(tl.slot_row), ptr(tl.slot_mul), ptr(wt), graph.n_types,
+        wimg = torch.empty(lib.tgnn_nnconv_weight_image_floats(graph.n_types), dtype=torch.float32, device=h.device)
+        check(lib.tgnn_nnconv_mean_tiled_fwd(ptr(h), c, ptr(graph.adj_rowptr), ptr(tl.tile_chunk_ptr), ptr(tl.chunk_meta),
+                                             ptr(tl.slot_src), ptr(wt), graph.n_types,
                                              ptr(_f32c(root, "root")), ptr(_f32c(bias, "bias")), n, c, act, ptr(out),
-                                             ptr(partials), C.byref(npart), _stream(h)))
+                                             ptr(wimg), ptr(partials), C.byref(npart), _stream(h)))
     else:
         check(lib.tgnn_nnconv_mean_fwd(ptr(h), c, ptr(graph.adj_rowptr), ptr(graph.adj_src), ptr(graph.adj_type), ptr(wt),
                                        graph.n_types, ptr(_f32c(root, "root")), ptr(_f32c(bias, "bias")), n, c, act,
