@@ -70,11 +70,13 @@ const char *tgnn_last_error(void);
  *   col_src  int32 [E]   source node of each CSR slot
  *   col_eid  int32 [E]   original edge number of each CSR slot
  * drop_self_loops != 0 removes (v,v) edges (GINConv semantics, PyG gin_conv.py); the number of
- * kept edges is rowptr[N].  err_flag (int32 device word, may be NULL) is set to 1 when an index
- * is outside [0,N); such edges are skipped. */
+ * kept edges is rowptr[N].  Destinations must lie in [0, n_nodes), sources in [0, n_src_nodes)
+ * (n_src_nodes = n_nodes for a whole graph; a node-range shard also gathers from halo rows stored
+ * behind its own, so n_src_nodes = own + halo).  err_flag (int32 device word, may be NULL) is set
+ * to 1 when an index is out of range; such edges are skipped. */
 size_t tgnn_csr_workspace_bytes(int64_t n_nodes, int64_t n_edges);
-int tgnn_csr_build(const int64_t *edge_index, int64_t n_edges, int64_t n_nodes, int drop_self_loops,
-                   int32_t *rowptr, int32_t *col_src, int32_t *col_eid, int32_t *err_flag,
+int tgnn_csr_build(const int64_t *edge_index, int64_t n_edges, int64_t n_nodes, int64_t n_src_nodes,
+                   int drop_self_loops, int32_t *rowptr, int32_t *col_src, int32_t *col_eid, int32_t *err_flag,
                    void *ws, size_t ws_bytes, tgnn_stream_t stream);
 
 /* Exact de-duplication of edge-attribute rows (K1 of SURVEY.md: the per-edge NNConv weight depends
@@ -259,7 +261,7 @@ int tgnn_forward_profiled(const tgnn_model_dims *dims, const void *const *params
  * ------------------------------------------------------------------------------------------ */
 /* out[i, :] = src[idx[i], :]  and  dst[idx[i], :] = in[i, :]   for [*, C] fp32 rows */
 int tgnn_rows_gather(const float *src, int64_t ld_src, const int32_t *idx, int64_t n_idx, int32_t c,
-                     float *out, tgnn_stream_t stream);
+                     float *out, int64_t ld_out, tgnn_stream_t stream);
 int tgnn_rows_scatter(const float *in, const int32_t *idx, int64_t n_idx, int32_t c, float *dst,
                       int64_t ld_dst, tgnn_stream_t stream);
 

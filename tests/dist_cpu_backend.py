@@ -1,0 +1,89 @@
+"""CPU compute backend for tilingnn_amd.dist.ShardProgram, built on the ORACLE -- test infrastructure only.
+It lets the partition / halo-exchange / BatchNorm-all-reduce schedule run under gloo (or LocalSimComm)
+without a GPU; the product backend is dist.HipBackend."""
+import numpy as np
+import torch
+
+from oracle import tilingnn_oracle as orc
+
+
+def _sums(v):
+    v = v.double()
+    return torch.cat([v.sum(0), (v * v).sum(0)])
+
+
+class OracleBackend:
+    def __init__(self, dtype=torch.float64):
+        self.dtype, self.device = dtype, torch.device("cpu")
+
+    def tensor(self, a, dtype):
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        return t.to(self.dtype if dtype == torch.float32 else dtype)
+
+    def zeros(self, *shape):
+        return torch.zeros(*shape, dtype=self.dtype)
+
+    def prepare(self, shard):
+        return shard, self.tensor(shard.adj_attr, torch.float32)
+
+    def edge_tables(self, graph, attr, net):
+        return [None] * net.network_depth
+
+    @staticmethod
+    def _act(v, act):
+        return {0: lambda t: t, 1: orc.leaky_relu, 2: orc.sigmoid}[act](v)
+
+    def _bn_in(self, a, in_stat):
+        return a if in_stat is None else (a - in_stat[0]) * in_stat[1] + in_stat[2]
+
+    def dense(self, a, lin, act, in_stat=None, slot_major=False):
+        if slot_major:
+            a = torch.cat(list(a), dim=1)
+        w, b = lin.weight.detach().to(self.dtype), lin.bias.detach().to(self.dtype)
+        out = self._act(self._bn_in(a, in_stat) @ w.t() + b, act)
+        return out, _sums(out)
+
+    def nnconv(self, h_rows, shard, wtab, conv, act):
+        adj = torch.from_numpy(shard.adj)
+        attr = self.tensor(shard.adj_attr, torch.float32)
+        layers = list(conv.nn.mlp)
+        w = attr
+        for l in layers:
+            w = orc.sigmoid(w @ l.linear.weight.detach().to(self.dtype).t() + l.linear.bias.detach().to(self.dtype))
+        c = conv.in_channels
+        msg = torch.matmul(h_rows[adj[0]].unsqueeze(1), w.view(-1, c, c)).squeeze(1)
+        agg = torch.zeros(shard.n_own, c, dtype=self.dtype).index_add_(0, adj[1], msg)
+        cnt = torch.bincount(adj[1], minlength=shard.n_own).clamp(min=1).to(self.dtype)
+        out = agg / cnt[:, None] + h_rows[: shard.n_own] @ conv.root.detach().to(self.dtype) + conv.bias.detach().to(self.dtype)
+        out = self._act(out, act)
+        return out, _sums(out)
+
+    def gin(self, a_rows, shard, conv, act, in_stat):
+        col = torch.from_numpy(shard.col)
+        keep = col[0] != col[1]
+        src, dst = col[0][keep], col[1][keep]
+        x = self._bn_in(a_rows, in_stat)
+        z = (1 + conv.eps.detach().to(self.dtype)) * x[: shard.n_own] + \
+            torch.zeros(shard.n_own, x.shape[1], dtype=self.dtype).index_add_(0, dst, x[src])
+        for l in conv.nn.mlp:
+            z = orc.sigmoid(z @ l.linear.weight.detach().to(self.dtype).t() + l.linear.bias.detach().to(self.dtype))
+        out = self._act(z, act)
+        return out, _sums(out)
+
+    def bn_stat(self, sums, n_total, bn, update_running):
+        f = bn.num_features
+        mean = sums[:f] / n_total
+        var = (sums[f:] / n_total - mean * mean).clamp(min=0)
+        g = bn.weight.detach().double() / torch.sqrt(var + bn.eps)
+        return (mean.to(self.dtype), g.to(self.dtype), bn.bias.detach().to(self.dtype))
+
+    def bn_apply(self, v, stat):
+        return self._bn_in(v, stat)
+
+    def merge(self, a1, stat1, a2, stat2, resid, out):
+        r = self._bn_in(a1, stat1) * self._bn_in(a2, stat2)
+        out.copy_(r if resid is None else r + resid)
+
+    def pack_rows(self, src, idx, out, col_offset):
+        if idx.numel():
+            out[: idx.shape[0], col_offset:col_offset + src.shape[1]] = src[idx.long()]

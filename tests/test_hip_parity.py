@@ -460,3 +460,34 @@ def test_errors_are_loud(dev):
     bad = adj.clone(); bad[0, 0] = 99999
     with pytest.raises(IndexError):
         net(x=x, adj_e_index=bad, adj_e_features=adj_attr, col_e_idx=col)
+
+
+# ------------------------------------------------------------------------------------------ sharded path on one GPU
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_hip_path_matches_unsharded(dev, world):
+    """tilingnn_amd.dist with the HIP backend, P virtual ranks stepped in lock-step on this one GPU
+    (LocalSimComm): same ShardProgram, kernels, halo layout and BN-sum exchange as the RCCL path.
+    A shallow network keeps the comparison out of the chaotic regime; depth 20 is sanity-checked."""
+    from tilingnn_amd import dist as tdist
+    from tilingnn_amd.synth import make_super_graph
+    sg = make_super_graph(6000, 60000, 75000, tile_count=2, n_edge_types=13, seed=8)
+    for depth, tol in ((3, 2e-5), (20, 5e-2)):
+        net, sd = make_net(dev, depth=depth)
+        x, adj, adj_attr, col, col_attr = sg.to_torch(dev)
+        want = net(x=x, adj_e_index=adj, adj_e_features=adj_attr, col_e_idx=col)[0]
+        shards = [tdist.make_shard(sg.node_feature, sg.align_edge_index, sg.align_edge_features,
+                                   sg.collide_edge_index, r, world) for r in range(world)]
+        tdist.LocalSimComm.setup(shards)
+        nets = [make_net(dev, depth=depth)[0] for _ in range(world)]      # every rank holds its own replica
+        net2 = nets[0]
+        be = tdist.HipBackend(dev)
+        parts = tdist.LocalSimComm.run([tdist.ShardProgram(nets[r], s, be) for r, s in enumerate(shards)])
+        got = torch.cat(parts)
+        err = float((got - want).abs().max())
+        print(f"world {world} depth {depth}: max |sharded - unsharded| = {err:.2e}")
+        assert got.shape == want.shape and err < tol
+        if depth == 3:      # running statistics were updated once per BN, from the GLOBAL sums
+            a, b = net.state_dict(), net2.state_dict()
+            k = "brch_2_coll_conv_layers.2.batch_norm"
+            assert int(b[k + ".num_batches_tracked"]) == 1
+            assert float((a[k + ".running_var"] - b[k + ".running_var"]).abs().max()) < 1e-5

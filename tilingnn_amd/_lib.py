@@ -48,7 +48,7 @@ def _load() -> C.CDLL:
         "tgnn_version": (C.c_int, []),
         "tgnn_last_error": (C.c_char_p, []),
         "tgnn_csr_workspace_bytes": (sz, [i64, i64]),
-        "tgnn_csr_build": (C.c_int, [p, i64, i64, C.c_int, p, p, p, p, p, sz, p]),
+        "tgnn_csr_build": (C.c_int, [p, i64, i64, i64, C.c_int, p, p, p, p, p, sz, p]),
         "tgnn_edge_dedup_workspace_bytes": (sz, [i64, i32]),
         "tgnn_edge_type_dedup": (C.c_int, [p, i64, i32, p, p, p, p, sz, p]),
         "tgnn_gather_i32": (C.c_int, [p, i64, p, i64, p, p]),
@@ -72,7 +72,7 @@ def _load() -> C.CDLL:
                                    p, p, sz, p, p]),
         "tgnn_forward_profiled": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), p, p, C.POINTER(Graph), i32,
                                             i32, p, p, sz, p, C.POINTER(C.c_float), pi32]),
-        "tgnn_rows_gather": (C.c_int, [p, i64, p, i64, i32, p, p]),
+        "tgnn_rows_gather": (C.c_int, [p, i64, p, i64, i32, p, i64, p]),
         "tgnn_rows_scatter": (C.c_int, [p, p, i64, i32, p, i64, p]),
     }
     for name, (res, args) in sigs.items():

@@ -123,12 +123,12 @@ __global__ __launch_bounds__(256) void merge_kernel(const float *__restrict__ a1
 }
 
 __global__ void rows_gather_kernel(const float *__restrict__ src, int64_t ld, const int *__restrict__ idx, int64_t n_idx,
-                                   int c, float *__restrict__ out) {
+                                   int c, float *__restrict__ out, int64_t ld_out) {
     const int64_t total = n_idx * c;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / c;
         const int k = (int)(i - r * c);
-        out[i] = src[(int64_t)idx[r] * ld + k];
+        out[r * ld_out + k] = src[(int64_t)idx[r] * ld + k];
     }
 }
 
@@ -201,10 +201,11 @@ extern "C" int tgnn_merge_fwd(const float *a1, const float *stat1, const float *
 }
 
 extern "C" int tgnn_rows_gather(const float *src, int64_t ld_src, const int32_t *idx, int64_t n_idx, int32_t c,
-                                float *out, tgnn_stream_t stream) {
+                                float *out, int64_t ld_out, tgnn_stream_t stream) {
     if (n_idx <= 0) return TGNN_OK;
-    TGNN_CHECK_ARG(src && idx && out && c >= 1 && ld_src >= c, "arguments");
-    rows_gather_kernel<<<ew_grid(n_idx * c), 256, 0, static_cast<hipStream_t>(stream)>>>(src, ld_src, idx, n_idx, c, out);
+    TGNN_CHECK_ARG(src && idx && out && c >= 1 && ld_src >= c && ld_out >= c, "arguments");
+    rows_gather_kernel<<<ew_grid(n_idx * c), 256, 0, static_cast<hipStream_t>(stream)>>>(src, ld_src, idx, n_idx, c, out,
+                                                                                         ld_out);
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
 }

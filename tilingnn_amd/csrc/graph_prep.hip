@@ -90,11 +90,11 @@ static void exclusive_scan_i32(const int *in, int *out, int64_t n, int *ws, hipS
 // ------------------------------------------------------------------------------------------
 // CSR by destination
 // ------------------------------------------------------------------------------------------
-__global__ void csr_count_kernel(const int64_t *__restrict__ ei, int64_t e, int64_t n, int drop_self,
+__global__ void csr_count_kernel(const int64_t *__restrict__ ei, int64_t e, int64_t n, int64_t n_src, int drop_self,
                                  int *__restrict__ cnt, int *__restrict__ err_flag) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t s = ei[i], d = ei[e + i];
-        if (s < 0 || s >= n || d < 0 || d >= n) {
+        if (s < 0 || s >= n_src || d < 0 || d >= n) {
             if (err_flag) *err_flag = 1;
             continue;
         }
@@ -103,12 +103,12 @@ __global__ void csr_count_kernel(const int64_t *__restrict__ ei, int64_t e, int6
     }
 }
 
-__global__ void csr_fill_kernel(const int64_t *__restrict__ ei, int64_t e, int64_t n, int drop_self,
+__global__ void csr_fill_kernel(const int64_t *__restrict__ ei, int64_t e, int64_t n, int64_t n_src, int drop_self,
                                 const int *__restrict__ rowptr, int *__restrict__ cursor,
                                 int *__restrict__ col_src, int *__restrict__ col_eid) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t s = ei[i], d = ei[e + i];
-        if (s < 0 || s >= n || d < 0 || d >= n) continue;
+        if (s < 0 || s >= n_src || d < 0 || d >= n) continue;
         if (drop_self && s == d) continue;
         const int pos = rowptr[d] + atomicAdd(&cursor[d], 1);
         col_src[pos] = (int)s;
@@ -348,10 +348,11 @@ extern "C" size_t tgnn_csr_workspace_bytes(int64_t n_nodes, int64_t n_edges) {
     return align_up((size_t)(n_nodes + 1) * 4, 256) * 2 + scan_ws_ints(n_nodes + 1) * 4 + 1024;
 }
 
-extern "C" int tgnn_csr_build(const int64_t *edge_index, int64_t n_edges, int64_t n_nodes, int drop_self_loops,
-                              int32_t *rowptr, int32_t *col_src, int32_t *col_eid, int32_t *err_flag, void *ws,
+extern "C" int tgnn_csr_build(const int64_t *edge_index, int64_t n_edges, int64_t n_nodes, int64_t n_src_nodes,
+                              int drop_self_loops, int32_t *rowptr, int32_t *col_src, int32_t *col_eid, int32_t *err_flag, void *ws,
                               size_t ws_bytes, tgnn_stream_t stream) {
     TGNN_CHECK_ARG(n_nodes >= 0 && n_nodes < (1ll << 31) - 1, "n_nodes must fit int32");
+    TGNN_CHECK_ARG(n_src_nodes >= n_nodes && n_src_nodes < (1ll << 31) - 1, "n_src_nodes must be >= n_nodes and fit int32");
     TGNN_CHECK_ARG(n_edges >= 0 && n_edges < (1ll << 31) - 1, "n_edges must fit int32");
     TGNN_CHECK_ARG(rowptr && (n_edges == 0 || (edge_index && col_src && col_eid)), "null pointer");
     if (ws_bytes < tgnn_csr_workspace_bytes(n_nodes, n_edges) || !ws) {
@@ -366,11 +367,12 @@ extern "C" int tgnn_csr_build(const int64_t *edge_index, int64_t n_edges, int64_
     TGNN_CHECK_HIP(hipMemsetAsync(cnt, 0, (size_t)(n_nodes + 1) * 4, s));
     TGNN_CHECK_HIP(hipMemsetAsync(cursor, 0, (size_t)(n_nodes + 1) * 4, s));
     if (n_edges > 0)
-        csr_count_kernel<<<grid_for(n_edges), 256, 0, s>>>(edge_index, n_edges, n_nodes, drop_self_loops, cnt, err_flag);
+        csr_count_kernel<<<grid_for(n_edges), 256, 0, s>>>(edge_index, n_edges, n_nodes, n_src_nodes, drop_self_loops, cnt,
+                                                           err_flag);
     exclusive_scan_i32(cnt, rowptr, n_nodes + 1, scan_ws, s);
     if (n_edges > 0) {
-        csr_fill_kernel<<<grid_for(n_edges), 256, 0, s>>>(edge_index, n_edges, n_nodes, drop_self_loops, rowptr,
-                                                          cursor, col_src, col_eid);
+        csr_fill_kernel<<<grid_for(n_edges), 256, 0, s>>>(edge_index, n_edges, n_nodes, n_src_nodes, drop_self_loops,
+                                                          rowptr, cursor, col_src, col_eid);
         csr_sort_rows_kernel<<<grid_for(n_nodes), 256, 0, s>>>(rowptr, n_nodes, col_src, col_eid);
     }
     TGNN_CHECK_LAUNCH();

@@ -1,0 +1,357 @@
+"""Node-range sharding of the TilinGNN forward over the GPUs of one node.
+
+The reference is single-device (no distributed code at all); this is the build's own
+multi-GPU design for the same forward, one process per GPU:
+
+  * rank r owns the contiguous node range [N r / P, N (r+1) / P) and ALL in-edges of those nodes
+    (CSR-by-destination is local); remote sources form the HALO, stored behind the owned rows of
+    every feature buffer, grouped by owner rank and sorted by global id -- so an
+    `all_to_all_single` lands directly in the halo rows, no unpack kernel;
+  * per message-passing layer ONE halo exchange (the new adjacency-branch rows and the new pre-BN
+    collision-branch rows travel together, 64 floats per halo row; RCCL all-to-all over xGMI) and ONE
+    all-reduce of the fp64 BatchNorm column sums of both branches (train-mode BN = statistics over
+    all N nodes, ml_solver.py:129-131) -- 20 + 20 + 6 collectives per forward, every one latency
+    bound (<= 1 MB / 1 KB), which is why they are fused this way;
+  * dense per-node work (GIN MLP, merge, init / final MLP) never leaves the rank.
+
+The schedule is written ONCE as a generator that yields collective requests; three drivers run it:
+  `TorchDistComm`   real ranks, torch.distributed (backend "nccl" == RCCL on ROCm, "gloo" in CPU tests)
+  `LocalSimComm`    P virtual ranks in one process on one device: lets a 1-GPU box (and the test
+                    suite) execute the exact sharded HIP path and compare it with the unsharded one.
+Compute goes through a backend object; the product backend is `HipBackend` (the libtgnn kernels via
+tilingnn_amd.ops).  Tests pass a CPU backend built on the oracle to check the partition / halo / BN
+logic under gloo without a GPU; nothing in this package provides or falls back to a CPU path.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+Tensor = torch.Tensor
+
+
+# ----------------------------------------------------------------------------------------------
+# partitioning (host, numpy)
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class Shard:
+    rank: int
+    world: int
+    n_total: int
+    lo: int                        # first owned global node id
+    n_own: int
+    halo_ids: np.ndarray           # global ids of halo rows, grouped by owner rank, sorted inside a group
+    recv_counts: List[int]         # halo rows received from every rank (sum == len(halo_ids))
+    x: np.ndarray                  # node features of the owned rows
+    adj: np.ndarray                # [2, Ea_loc] int64, LOCAL ids (owned 0..n_own-1, halo n_own..)
+    adj_attr: np.ndarray
+    col: np.ndarray                # [2, Ec_loc] int64, local ids
+    send_ids: Optional[List[np.ndarray]] = None   # owned LOCAL row ids every peer needs (filled by setup)
+
+    @property
+    def n_rows(self) -> int:
+        return self.n_own + int(self.halo_ids.shape[0])
+
+
+def node_range(n_total: int, rank: int, world: int):
+    return n_total * rank // world, n_total * (rank + 1) // world
+
+
+def owner_of(ids: np.ndarray, n_total: int, world: int) -> np.ndarray:
+    """Rank owning each global node id (inverse of node_range)."""
+    bounds = np.array([n_total * r // world for r in range(1, world + 1)], dtype=np.int64)
+    return np.searchsorted(bounds, ids, side="right")
+
+
+def make_shard(node_feature: np.ndarray, adj: np.ndarray, adj_attr: np.ndarray, col: np.ndarray, rank: int,
+               world: int) -> Shard:
+    """Cut rank `rank`'s shard out of a global graph given in the reference's array layout
+    (util/data_util.py:164-205).  Edge order inside the shard = global edge order (sums stay reproducible)."""
+    n_total = int(node_feature.shape[0])
+    lo, hi = node_range(n_total, rank, world)
+    adj = adj.reshape(2, -1)
+    col = col.reshape(2, -1)
+    keep_a = (adj[1] >= lo) & (adj[1] < hi)
+    keep_c = (col[1] >= lo) & (col[1] < hi)
+    a, c = adj[:, keep_a], col[:, keep_c]
+    srcs = np.concatenate([a[0], c[0]])
+    remote = np.unique(srcs[(srcs < lo) | (srcs >= hi)])          # sorted global ids == grouped by owner
+    owners = owner_of(remote, n_total, world)
+    recv_counts = [int(np.count_nonzero(owners == r)) for r in range(world)]
+
+    def localise(e):
+        out = np.empty_like(e)
+        out[1] = e[1] - lo
+        own = (e[0] >= lo) & (e[0] < hi)
+        out[0] = np.where(own, e[0] - lo, (hi - lo) + np.searchsorted(remote, e[0]))
+        return out
+    return Shard(rank, world, n_total, lo, hi - lo, remote, recv_counts, node_feature[lo:hi], localise(a),
+                 adj_attr[keep_a], localise(c))
+
+
+def exchange_send_lists(shards_halo_ids: Sequence[np.ndarray], n_total: int, world: int) -> List[List[np.ndarray]]:
+    """send_ids[r][p] = LOCAL owned row ids of rank r that rank p holds in its halo (what the setup
+    all-to-all of id lists produces on real ranks)."""
+    out = [[np.empty(0, dtype=np.int64) for _ in range(world)] for _ in range(world)]
+    for p, ids in enumerate(shards_halo_ids):
+        owners = owner_of(ids, n_total, world)
+        for r in range(world):
+            sel = ids[owners == r]
+            out[r][p] = sel - node_range(n_total, r, world)[0]
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# compute backends
+# ----------------------------------------------------------------------------------------------
+class HipBackend:
+    """The product backend: libtgnn kernels through tilingnn_amd.ops.  Needs a GPU."""
+
+    def __init__(self, device):
+        from . import ops
+        self.ops, self.device = ops, torch.device(device)
+
+    def tensor(self, a: np.ndarray, dtype) -> Tensor:
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).to(self.device)
+
+    def prepare(self, shard: Shard):
+        adj, col = self.tensor(shard.adj, torch.int64), self.tensor(shard.col, torch.int64)
+        attr = self.tensor(shard.adj_attr, torch.float32)
+        g = self.ops.prepare_graph(shard.n_own, adj, attr, col, n_src_nodes=shard.n_rows)
+        return g, attr
+
+    def zeros(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float32, device=self.device)
+
+    def edge_tables(self, graph, attr, net) -> list:
+        return [self.ops.edge_weight_table(attr, graph, *l.nnConv._edge_mlp_params(), net.network_width)
+                for l in net.brch_1_graph_conv_layers]
+
+    def dense(self, a, lin, act, in_stat=None, slot_major=False):
+        f = lin.out_features
+        parts = self.ops.new_partials(f, self.device)
+        out, n_parts = self.ops.dense_act(a, lin.weight, lin.bias, act, in_stat=in_stat, partials=parts,
+                                          slot_major=slot_major)
+        return out, self.ops.bn_sums(parts, n_parts, f)
+
+    def nnconv(self, h_rows, graph, wtab, conv, act):
+        parts = self.ops.new_partials(conv.out_channels, self.device)
+        out, n_parts = self.ops.nnconv_mean(h_rows, graph, wtab, conv.root, conv.bias, act=act, partials=parts)
+        return out, self.ops.bn_sums(parts, n_parts, conv.out_channels)
+
+    def gin(self, a_rows, graph, conv, act, in_stat):
+        c = int(a_rows.shape[1])
+        parts = self.ops.new_partials(c, self.device)
+        out, n_parts = self.ops.gin(a_rows, graph, conv.eps, *conv._mlp_params(), act=act, in_stat=in_stat,
+                                    partials=parts)
+        return out, self.ops.bn_sums(parts, n_parts, c)
+
+    def bn_stat(self, sums, n_total, bn, update_running):
+        return self.ops.bn_stat_from_sums(sums, n_total, bn, update_running)
+
+    def bn_apply(self, v, stat):
+        return self.ops.bn_apply(v, stat)
+
+    def merge(self, a1, stat1, a2, stat2, resid, out):
+        self.ops.merge(a1, stat1, a2, stat2, resid, out=out, want_h2=False)
+
+    def pack_rows(self, src, idx, out, col_offset):
+        self.ops.rows_gather(src, idx, out, col_offset)
+
+
+# ----------------------------------------------------------------------------------------------
+# the sharded forward, written once
+# ----------------------------------------------------------------------------------------------
+class ShardProgram:
+    """One rank's share of TilinGNN.forward (graph_networks/networks/TilinGNN.py:51-78).
+    `run()` is a generator: it yields ("allreduce", fp64 tensor) / ("alltoall", send, send_splits,
+    recv_view, recv_splits) requests and is resumed once the collective has completed."""
+
+    def __init__(self, net, shard: Shard, backend, update_running: bool = True):
+        self.net, self.shard, self.be, self.update_running = net, shard, backend, update_running
+        self.graph, self.attr = backend.prepare(shard)
+        self.x = backend.tensor(shard.x, torch.float32)
+        send = shard.send_ids
+        assert send is not None, "shard.send_ids not set: run setup (exchange_send_lists / TorchDistComm.setup)"
+        self.send_splits = [int(s.shape[0]) for s in send]
+        self.send_idx = backend.tensor(np.concatenate(send) if send else np.empty(0), torch.int32)
+        self.recv_splits = list(shard.recv_counts)
+        c = net.network_width
+        n_rows, n_send = shard.n_rows, int(self.send_idx.shape[0])
+        self.h1 = backend.zeros(n_rows, c)                 # adjacency-branch features: owned rows then halo
+        self.a2 = backend.zeros(n_rows, c)                 # pre-BN collision-branch activations, same layout
+        self.sendbuf = backend.zeros(max(n_send, 1), 2 * c)
+        self.recvbuf = backend.zeros(max(n_rows - shard.n_own, 1), 2 * c)
+
+    def _exchange(self, with_a2: bool):
+        """Halo rows of h1 (and a2): pack the rows every peer needs, one all-to-all, drop into the halo rows."""
+        c, n_own = self.net.network_width, self.shard.n_own
+        n_halo, n_send = self.shard.n_rows - n_own, int(self.send_idx.shape[0])
+        self.be.pack_rows(self.h1, self.send_idx, self.sendbuf, 0)
+        if with_a2:
+            self.be.pack_rows(self.a2, self.send_idx, self.sendbuf, c)
+        send, recv = self.sendbuf[:n_send], self.recvbuf[:n_halo]
+        yield ("alltoall", send, self.send_splits, recv, self.recv_splits)
+        if n_halo:
+            self.h1[n_own:] = recv[:, :c]
+            if with_a2:
+                self.a2[n_own:] = recv[:, c:]
+
+    def run(self):
+        net, be, sh = self.net, self.be, self.shard
+        ACT_LEAKY, ACT_SIGMOID = 1, 2
+        n_own, n_total, c, depth = sh.n_own, sh.n_total, net.network_width, net.network_depth
+
+        def bn(sums, module):
+            return be.bn_stat(sums, n_total, module, self.update_running)
+
+        # ---- init MLP (TilinGNN.py:54): two Linear -> LeakyReLU -> BN, statistics over ALL nodes
+        l0, l1 = net.init_node_feature_trans.mlp[0], net.init_node_feature_trans.mlp[1]
+        t0, s = be.dense(self.x, l0.linear, ACT_LEAKY)
+        yield ("allreduce", s)
+        st0 = bn(s, l0.batch_norm)
+        t1, s = be.dense(t0, l1.linear, ACT_LEAKY, in_stat=st0)
+        yield ("allreduce", s)
+        st1 = bn(s, l1.batch_norm)
+        mid = be.zeros(depth + 1, n_own, c)                # slot-major skip buffer (TilinGNN.py:58,71,74)
+        mid[0] = be.bn_apply(t1, st1)
+        self.h1[:n_own] = mid[0]
+        yield from self._exchange(with_a2=False)
+        tables = be.edge_tables(self.graph, self.attr, net)
+
+        # ---- message passing layers (TilinGNN.py:59-71)
+        stat2 = None
+        for i in range(depth):
+            l1m, l2m = net.brch_1_graph_conv_layers[i], net.brch_2_coll_conv_layers[i]
+            a1, s1 = be.nnconv(self.h1, self.graph, tables[i], l1m.nnConv, ACT_LEAKY)
+            gin_in = self.h1 if i == 0 else self.a2          # layer 0: both branches start from middle[0] (:55)
+            a2, s2 = be.gin(gin_in, self.graph, l2m.ginConv, ACT_LEAKY, stat2)
+            both = torch.cat([s1, s2])
+            yield ("allreduce", both)                       # one message for both BatchNorms of the layer
+            stat1 = bn(both[: 2 * c], l1m.batch_norm)
+            stat2 = bn(both[2 * c:], l2m.batch_norm)
+            resid = mid[i - 2] if i >= 2 else None           # residual_skip_num = 2 (:25,67-69)
+            be.merge(a1, stat1, a2, stat2, resid, mid[i + 1])
+            if i + 1 < depth:
+                self.h1[:n_own] = mid[i + 1]
+                self.a2[:n_own] = a2
+                yield from self._exchange(with_a2=True)
+
+        # ---- final MLP over the concatenation (TilinGNN.py:74-76); K block k = middle[k]
+        fm = net.final_mlp[0].mlp
+        v, s = be.dense(mid, fm[0].linear, ACT_LEAKY, slot_major=True)
+        yield ("allreduce", s)
+        stat = bn(s, fm[0].batch_norm)
+        for layer in list(fm)[1:]:
+            v, s = be.dense(v, layer.linear, ACT_LEAKY, in_stat=stat)
+            yield ("allreduce", s)
+            stat = bn(s, layer.batch_norm)
+        probs, _ = be.dense(v, net.final_mlp[1].linear, ACT_SIGMOID, in_stat=stat)
+        return probs
+
+
+# ----------------------------------------------------------------------------------------------
+# drivers
+# ----------------------------------------------------------------------------------------------
+class TorchDistComm:
+    """Real ranks: one process per GPU, torch.distributed ("nccl" is RCCL on ROCm; "gloo" in CPU tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+
+    def setup(self, shard: Shard) -> None:
+        """Tell every owner which of its rows this rank keeps as halo (ids travel once per layout)."""
+        dist, world = self.dist, shard.world
+        dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        counts_out = torch.tensor(shard.recv_counts, dtype=torch.int64, device=dev)
+        counts_in = torch.empty(world, dtype=torch.int64, device=dev)
+        dist.all_to_all_single(counts_in, counts_out, group=self.group)
+        counts_in = counts_in.cpu().tolist()
+        ids_out = torch.from_numpy(shard.halo_ids.astype(np.int64)).to(dev)
+        ids_in = torch.empty(int(sum(counts_in)), dtype=torch.int64, device=dev)
+        dist.all_to_all_single(ids_in, ids_out, output_split_sizes=counts_in, input_split_sizes=shard.recv_counts,
+                               group=self.group)
+        ids_in = ids_in.cpu().numpy() - shard.lo
+        offs = np.concatenate([[0], np.cumsum(counts_in)]).astype(np.int64)
+        shard.send_ids = [ids_in[offs[p]:offs[p + 1]] for p in range(world)]
+
+    def run(self, program: ShardProgram) -> Tensor:
+        gen = program.run()
+        try:
+            req = next(gen)
+            while True:
+                if req[0] == "allreduce":
+                    self.dist.all_reduce(req[1], group=self.group)
+                else:
+                    _, send, send_splits, recv, recv_splits = req
+                    self.dist.all_to_all_single(recv, send, output_split_sizes=recv_splits,
+                                                input_split_sizes=send_splits, group=self.group)
+                req = gen.send(None)
+        except StopIteration as stop:
+            return stop.value
+
+
+class LocalSimComm:
+    """P virtual ranks in ONE process / on ONE device, stepped in lock-step: every collective is carried out
+    with plain tensor copies.  Same ShardProgram, same kernels, same halo layout as the real thing."""
+
+    @staticmethod
+    def setup(shards: Sequence[Shard]) -> None:
+        lists = exchange_send_lists([s.halo_ids for s in shards], shards[0].n_total, shards[0].world)
+        for r, s in enumerate(shards):
+            s.send_ids = lists[r]
+
+    @staticmethod
+    def run(programs: Sequence[ShardProgram]) -> List[Tensor]:
+        gens = [p.run() for p in programs]
+        world = len(gens)
+        reqs, results = [None] * world, [None] * world
+        for r, g in enumerate(gens):
+            reqs[r] = next(g)
+        while any(q is not None for q in reqs):
+            kinds = {q[0] for q in reqs if q is not None}
+            assert len(kinds) == 1 and all(q is not None for q in reqs), "ranks diverged"
+            if kinds == {"allreduce"}:
+                total = torch.stack([q[1] for q in reqs]).sum(0)
+                for q in reqs:
+                    q[1].copy_(total)
+            else:
+                for dst in range(world):
+                    _, _, _, recv, recv_splits = reqs[dst]
+                    off = 0
+                    for src in range(world):
+                        k = recv_splits[src]
+                        if k:
+                            _, send, send_splits, _, _ = reqs[src]
+                            s0 = sum(send_splits[:dst])
+                            assert send_splits[dst] == k
+                            recv[off:off + k].copy_(send[s0:s0 + k])
+                        off += k
+            for r, g in enumerate(gens):
+                try:
+                    reqs[r] = g.send(None)
+                except StopIteration as stop:
+                    reqs[r], results[r] = None, stop.value
+        return results
+
+
+class ShardedTilinGNN:
+    """bench.py's handle on the multi-GPU path: rank `rank` of `world`, RCCL collectives."""
+
+    def __init__(self, net, super_graph, rank: int, world: int, device, group=None):
+        shard = make_shard(super_graph.node_feature, super_graph.align_edge_index, super_graph.align_edge_features,
+                           super_graph.collide_edge_index, rank, world)
+        self.comm = TorchDistComm(group)
+        self.comm.setup(shard)
+        self.shard, self.net, self.backend = shard, net, HipBackend(device)
+        self.n_local, self.ea_local, self.ec_local = shard.n_own, int(shard.adj.shape[1]), int(shard.col.shape[1])
+        self.program = None
+
+    def step(self) -> Tensor:
+        """One forward of this rank's shard, graph preparation included (as in the 1-GPU benchmark)."""
+        self.program = ShardProgram(self.net, self.shard, self.backend)
+        return self.comm.run(self.program)

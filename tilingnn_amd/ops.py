@@ -118,8 +118,10 @@ def _check_edge_index(ei: Tensor, name: str) -> Tensor:
     return ei if ei.is_contiguous() else ei.contiguous()
 
 
-def build_csr(edge_index: Tensor, n_nodes: int, drop_self_loops: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
-    """-> (rowptr [N+1], col_src [E], col_eid [E], err_flag [1]) int32; asynchronous."""
+def build_csr(edge_index: Tensor, n_nodes: int, drop_self_loops: bool,
+              n_src_nodes: Optional[int] = None) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """-> (rowptr [N+1], col_src [E], col_eid [E], err_flag [1]) int32; asynchronous.
+    n_src_nodes (default n_nodes): sources may index halo rows stored behind the N destination rows."""
     ei = _check_edge_index(edge_index, "edge_index")
     dev, e = ei.device, int(ei.shape[1])
     rowptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
@@ -128,8 +130,9 @@ def build_csr(edge_index: Tensor, n_nodes: int, drop_self_loops: bool) -> Tuple[
     err = torch.zeros(1, dtype=torch.int32, device=dev)
     ws_bytes = lib.tgnn_csr_workspace_bytes(n_nodes, e)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    check(lib.tgnn_csr_build(ptr(ei), e, n_nodes, int(drop_self_loops), ptr(rowptr), ptr(col_src), ptr(col_eid),
-                             ptr(err), ptr(ws), ws_bytes, _stream(ei)))
+    check(lib.tgnn_csr_build(ptr(ei), e, n_nodes, n_nodes if n_src_nodes is None else n_src_nodes,
+                             int(drop_self_loops), ptr(rowptr), ptr(col_src), ptr(col_eid), ptr(err), ptr(ws), ws_bytes,
+                             _stream(ei)))
     return rowptr, col_src, col_eid, err
 
 
@@ -151,7 +154,7 @@ def dedup_edge_types(edge_attr: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
 
 
 def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col_e_idx: Tensor,
-                  tile_width: int = 32) -> PreparedGraph:
+                  tile_width: int = 32, n_src_nodes: Optional[int] = None) -> PreparedGraph:
     """Everything the 20 layers share: CSR of both edge sets, edge-type ids in CSR order.
     Synchronises once (the type count and the self-loop-free collision edge count are read back)."""
     adj = _check_edge_index(adj_e_index, "adj_e_index")
@@ -159,8 +162,8 @@ def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col
     ea, ec = int(adj.shape[1]), int(col.shape[1])
     if adj_e_features.shape[0] != ea:
         raise ValueError(f"adj_e_features has {adj_e_features.shape[0]} rows for {ea} edges")
-    a_rowptr, a_src, a_eid, a_err = build_csr(adj, n_nodes, drop_self_loops=False)
-    c_rowptr, c_src, c_eid, c_err = build_csr(col, n_nodes, drop_self_loops=True)     # GINConv strips self loops
+    a_rowptr, a_src, a_eid, a_err = build_csr(adj, n_nodes, False, n_src_nodes)
+    c_rowptr, c_src, c_eid, c_err = build_csr(col, n_nodes, True, n_src_nodes)        # GINConv strips self loops
     edge_type, rep, n_types = dedup_edge_types(adj_e_features)
     adj_type = torch.empty(max(ea, 1), dtype=torch.int32, device=adj.device)
     check(lib.tgnn_gather_i32(ptr(edge_type), ea, ptr(a_eid), ea, ptr(adj_type), _stream(adj)))
@@ -200,9 +203,10 @@ def nnconv_mean(h: Tensor, graph: PreparedGraph, wtab: Tensor, root: Tensor, bia
     """NNConv mean: the MFMA tile kernel when the graph carries tiles (width 32, few edge types),
     else the CSR / LDS-weight-table kernel (any type count that fits LDS) or the generic one."""
     h = _f32c(h, "x")
-    n, c = int(h.shape[0]), int(h.shape[1])
-    if n != graph.n_nodes:
-        raise ValueError(f"x has {n} rows, the graph {graph.n_nodes} nodes")
+    c = int(h.shape[1])
+    n = graph.n_nodes                      # destination rows; x may carry extra (halo) rows behind them
+    if int(h.shape[0]) < n:
+        raise ValueError(f"x has {int(h.shape[0])} rows, the graph {graph.n_nodes} nodes")
     if tuple(root.shape) != (c, c) or tuple(bias.shape) != (c,):
         raise ValueError("NNConv root/bias shape mismatch")
     out = torch.empty(n, c, dtype=torch.float32, device=h.device)
@@ -225,9 +229,10 @@ def nnconv_mean(h: Tensor, graph: PreparedGraph, wtab: Tensor, root: Tensor, bia
 def gin(a: Tensor, graph: PreparedGraph, eps: Tensor, w1, b1, w2, b2, w3, b3, act: int = ACT_NONE,
         in_stat: Optional[Tensor] = None, partials: Optional[Tensor] = None) -> Tuple[Tensor, int]:
     a = _f32c(a, "x")
-    n, c = int(a.shape[0]), int(a.shape[1])
-    if n != graph.n_nodes:
-        raise ValueError(f"x has {n} rows, the graph {graph.n_nodes} nodes")
+    c = int(a.shape[1])
+    n = graph.n_nodes                      # destination rows; x may carry extra (halo) rows behind them
+    if int(a.shape[0]) < n:
+        raise ValueError(f"x has {int(a.shape[0])} rows, the graph {graph.n_nodes} nodes")
     if tuple(w1.shape) != (32, c) or tuple(w2.shape) != (64, 32) or tuple(w3.shape) != (c, 64):
         raise ValueError("GIN MLP shape mismatch")
     out = torch.empty(n, c, dtype=torch.float32, device=a.device)
@@ -240,18 +245,25 @@ def gin(a: Tensor, graph: PreparedGraph, eps: Tensor, w1, b1, w2, b2, w3, b3, ac
 
 
 def dense_act(a: Tensor, weight: Tensor, bias: Tensor, act: int, in_stat: Optional[Tensor] = None,
-              partials: Optional[Tensor] = None) -> Tuple[Tensor, int]:
-    """act(BN_in(a) @ weight.T + bias) for a row-major [N, in] matrix."""
+              partials: Optional[Tensor] = None, slot_major: bool = False) -> Tuple[Tensor, int]:
+    """act(BN_in(a) @ weight.T + bias) for a row-major [N, in] matrix, or (slot_major) for the
+    [in/32, N, 32] skip-connection buffer read as 32-wide K blocks (torch.cat never happens)."""
     a = _f32c(a, "x")
-    if a.dim() != 2:
-        raise ValueError(f"expected a [N, F] matrix, got {tuple(a.shape)}")
-    n, k = int(a.shape[0]), int(a.shape[1])
+    if slot_major:
+        if a.dim() != 3 or a.shape[2] != 32:
+            raise ValueError(f"slot-major input must be [K/32, N, 32], got {tuple(a.shape)}")
+        n, k, lda, kb = int(a.shape[1]), 32 * int(a.shape[0]), 32, int(a.shape[1]) * 32
+    else:
+        if a.dim() != 2:
+            raise ValueError(f"expected a [N, F] matrix, got {tuple(a.shape)}")
+        n, k = int(a.shape[0]), int(a.shape[1])
+        lda, kb = k, 32
     m = int(weight.shape[0])
     if int(weight.shape[1]) != k:
         raise ValueError(f"Linear expects in_dim {int(weight.shape[1])}, got {k}")      # layers/util.py:16
     out = torch.empty(n, m, dtype=torch.float32, device=a.device)
     npart = C.c_int32(0)
-    check(lib.tgnn_dense_act_fwd(ptr(a), k, 32, ptr(in_stat), ptr(_f32c(weight, "weight")), ptr(_f32c(bias, "bias")),
+    check(lib.tgnn_dense_act_fwd(ptr(a), lda, kb, ptr(in_stat), ptr(_f32c(weight, "weight")), ptr(_f32c(bias, "bias")),
                                  n, k, m, act, ptr(out), m, ptr(partials), C.byref(npart), _stream(a)))
     return out, npart.value
 
@@ -292,10 +304,42 @@ def batch_norm(v: Tensor, partials: Tensor, n_partials: int, bn: torch.nn.BatchN
     return bn_apply(v, stat)
 
 
-def merge(a1: Tensor, stat1: Tensor, a2: Tensor, stat2: Tensor, resid: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
+def merge(a1: Tensor, stat1: Tensor, a2: Tensor, stat2: Tensor, resid: Optional[Tensor],
+          out: Optional[Tensor] = None, want_h2: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
+    """BN1(a1) * BN2(a2) (+ resid) -> out (a dense [N, C] tensor, e.g. a slot of the skip buffer)."""
     n, c = int(a1.shape[0]), int(a1.shape[1])
-    out = torch.empty_like(a1)
-    h2 = torch.empty_like(a1)
+    if out is None:
+        out = torch.empty_like(a1)
+    elif not out.is_contiguous() or tuple(out.shape) != (n, c):
+        raise ValueError("merge: `out` must be a contiguous [N, C] tensor")
+    h2 = torch.empty_like(a1) if want_h2 else None
     check(lib.tgnn_merge_fwd(ptr(a1), ptr(stat1), ptr(a2), ptr(stat2), ptr(resid), n, c, ptr(out), ptr(h2),
                              _stream(a1)))
     return out, h2
+
+
+def rows_gather(src: Tensor, idx: Tensor, out: Tensor, col_offset: int = 0) -> None:
+    """out[i, col_offset : col_offset + C] = src[idx[i], :C]  (halo send packing)."""
+    c = int(src.shape[1])
+    check(lib.tgnn_rows_gather(ptr(src), int(src.stride(0)), ptr(idx), int(idx.shape[0]), c,
+                               C.c_void_p(out.data_ptr() + 4 * col_offset), int(out.stride(0)), _stream(src)))
+
+
+def bn_sums(partials: Tensor, n_partials: int, f: int) -> Tensor:
+    """Per-block partial rows -> [2, F] fp64 column sums (the quantity ranks all-reduce)."""
+    sums = torch.empty(2 * f, dtype=torch.float64, device=partials.device)
+    check(lib.tgnn_bn_finalize(1, ptr(partials), n_partials, ptr(sums), f, 1, None, None, 1e-5, 0.1, None, None, None,
+                               None, _stream(partials)))
+    return sums
+
+
+def bn_stat_from_sums(sums: Tensor, n_rows_total: int, bn: torch.nn.BatchNorm1d, update_running: bool) -> Tensor:
+    """[2, F] global column sums -> stat record [4, F] (+ running-stat update)."""
+    f = bn.num_features
+    stat = torch.empty(4, f, dtype=torch.float32, device=sums.device)
+    upd = update_running and bn.track_running_stats
+    check(lib.tgnn_bn_finalize(2, None, 0, ptr(sums), f, n_rows_total, ptr(bn.weight), ptr(bn.bias), float(bn.eps),
+                               float(bn.momentum if bn.momentum is not None else 0.1),
+                               ptr(bn.running_mean if upd else None), ptr(bn.running_var if upd else None),
+                               ptr(bn.num_batches_tracked if upd else None), ptr(stat), _stream(sums)))
+    return stat
