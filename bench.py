@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nodes-per-gpu", type=int, default=NODES_PER_GPU)
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the sharded (RCCL) schedule even at world size 1 (exercises the multi-GPU code path)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,9 +114,18 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    saved_stdout_fd = None
+    if sharded:
+        # RCCL prints a version banner to fd 1 when the communicator is created; keep stdout = the one JSON line
+        sys.stdout.flush()
+        saved_stdout_fd = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29547")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from tilingnn_amd import TilinGNN
@@ -132,7 +143,7 @@ def main():
     net = net.to(dev).train()               # inference in train mode, as ml_solver.py:131 leaves it
     net.cache_graph = False                 # graph preparation is part of every timed step
 
-    if world == 1:
+    if not sharded:
         x, adj, adj_attr, col, col_attr = sg.to_torch(dev)
 
         def step():
@@ -145,7 +156,7 @@ def main():
         n_local, ea_local, ec_local = sharded.n_local, sharded.ea_local, sharded.ec_local
 
     def barrier():
-        if world > 1:
+        if sharded:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -158,7 +169,7 @@ def main():
         out = step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         import torch.distributed as dist
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -169,7 +180,7 @@ def main():
 
     # ---- cached-layout variant (prep amortised, e.g. repeated predict on one BrickLayout)
     cached_ms = None
-    if world == 1:
+    if not sharded:
         net.cache_graph = True
         for _ in range(2):
             step()
@@ -183,7 +194,7 @@ def main():
 
     # ---- roofline of the dominant kernel: second, instrumented pass (HIP events on the launch stream)
     roofline, class_ms = None, None
-    if world == 1:
+    if not sharded:
         from tilingnn_amd import ops
         graph = ops.prepare_graph(n_total, adj, adj_attr, col)
         dims = net._dims()
@@ -204,7 +215,7 @@ def main():
         dom = max(("nnconv", "gin", "dense_final"), key=lambda k: class_ms[k]["ms_per_forward"])
         per_launch_s = class_ms["nnconv"]["ms_per_forward"] / max(1, class_ms["nnconv"]["launches_per_forward"]) * 1e-3
         b_alg = nnconv_bytes(n_total, ea_total, graph.n_types)
-        roofline = {"kernel": "nnconv32_lds_kernel (NNConv mean scatter-add, per layer)", "bound": "hbm",
+        roofline = {"kernel": "nnconv32_mfma_kernel (NNConv mean scatter-add, per layer)", "bound": "hbm",
                     "achieved": b_alg / per_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": b_alg / per_launch_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
                     "algorithmic_bytes_per_launch": b_alg, "avg_launch_us": per_launch_s * 1e6,
@@ -219,6 +230,10 @@ def main():
                                      "frac_of_hbm_peak": forward_bytes(n_total, ea_total, ec_total, graph.n_types)
                                      / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
+    if saved_stdout_fd is not None:
+        sys.stdout.flush()
+        os.dup2(saved_stdout_fd, 1)
+        os.close(saved_stdout_fd)
     if rank == 0:
         line = {
             "metric": "scored tile-nodes/sec (GNN forward)", "value": value, "unit": "nodes/s", "n_gpus": world,
@@ -229,7 +244,7 @@ def main():
                                    f"per GPU, 30-60-90 (tile_count 2), T=13 edge types, width 32, depth 20, "
                                    f"train-mode BatchNorm, graph prep included",
                        "n_nodes": n_total, "n_adj_edges": ea_total, "n_col_edges": ec_total,
-                       "parallelism": "single GPU" if world == 1 else f"node-range shards x{world}, halo exchange + BN all-reduce (RCCL)"},
+                       "parallelism": "single GPU" if not sharded else f"node-range shards x{world}, halo exchange + BN all-reduce (RCCL)"},
             "roofline": roofline,
         }
         if cached_ms is not None:
@@ -239,8 +254,9 @@ def main():
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
-        print(json.dumps(line))
-    if world > 1:
+        print(json.dumps(line), flush=True)
+    if sharded:
+        os.dup2(2, 1)                      # teardown chatter, if any, goes to stderr
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -23,7 +23,12 @@ class OracleBackend:
     def zeros(self, *shape):
         return torch.zeros(*shape, dtype=self.dtype)
 
-    def prepare(self, shard):
+    def upload(self, shard):
+        send = shard.send_ids if shard.send_ids is not None else []
+        return {"x": self.tensor(shard.x, torch.float32),
+                "send_idx": self.tensor(np.concatenate(send) if len(send) else np.empty(0), torch.int32)}
+
+    def prepare(self, shard, inputs):
         return shard, self.tensor(shard.adj_attr, torch.float32)
 
     def edge_tables(self, graph, attr, net):
