@@ -39,9 +39,18 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(BnJobs jobs, int mode
         const int j = tid % two_f, g = tid / two_f;
         double acc = 0.0;
         if (g < groups) {
-            // 8 independent loads in flight per thread (a plain loop pays one L2 round trip per partial)
+            // all of a thread's partial rows are fetched before the first add: with <= 512 partial rows and
+            // >= 16 row groups that is one batch of <= 32 independent loads, i.e. ONE L2 round trip instead of
+            // one per row (the plain loop made this 1-block kernel cost 17 us, 8-deep batches 9.4 us)
             const double *src = jb.partials + j;
             int p = g;
+            for (; p + 31 * groups < jb.n_partials; p += 32 * groups) {
+                double v[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) v[u] = src[(int64_t)(p + u * groups) * two_f];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) acc += v[u];
+            }
             for (; p + 7 * groups < jb.n_partials; p += 8 * groups) {
                 double v[8];
 #pragma unroll

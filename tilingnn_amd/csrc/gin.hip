@@ -16,7 +16,11 @@
 //   gin32_mlp_kernel (MFMA-bound): 32 -> 32 -> 64 -> 32 with sigmoids on v_mfma_f32_32x32x2_f32,
 //            hidden activations wave-private in LDS, LeakyReLU + fp64 BN column sums in the epilogue.
 // (A first version kept the MLP per-thread with wave-uniform weights through the scalar cache:
-//  297 us per layer at N = 100k -- every s_load batch paid an L2 round trip; see DESIGN.md.)
+//  297 us per layer at N = 100k -- every s_load batch paid an L2 round trip.  A later variant kept the
+//  activations in the MFMA accumulator registers via the transposed product H^T = W . Z^T, no LDS
+//  round trips at all: correct, but 29 us vs 23.7 us for this one -- 64 VGPRs of per-lane fp64 BN sums
+//  cap occupancy, the 16-B-strided row loads/stores are TA-expensive and the final 32-lane fp64
+//  butterfly is serial.  See DESIGN.md section 5.)
 #include "tgnn_common.h"
 
 namespace tgnn {
