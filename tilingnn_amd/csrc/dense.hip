@@ -17,6 +17,8 @@
 // while the current one feeds the MFMAs.  LDS rows are padded to 33 floats: the A/B fragment reads
 // (lane&31 -> row, lane>>5 -> k) are conflict free.  Blocks are persistent over row tiles so that
 // one block = one BN partial row.
+#include <stdlib.h>
+
 #include "tgnn_common.h"
 
 namespace tgnn {
@@ -231,6 +233,222 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16 x 3 split-precision variant for the big Linear blocks (in_dim % 32 == 0, out_dim >= 64).
+//
+// gfx950 runs bf16 MFMA at 16x the fp32 MFMA rate.  Every fp32 operand is split exactly into three bf16
+// pieces x = hi + mid + lo (|x - (hi+mid+lo)| <= 2^-25 |x|) while its tile is staged into LDS, and the product
+// is accumulated in fp32 from the six leading cross terms
+//        hi.hi + hi.mid + mid.hi + mid.mid + hi.lo + lo.hi          (dropped terms <= 2^-24 |a||b|)
+// on v_mfma_f32_32x32x16_bf16: 6 x 32 cycles per 32x32x16 block instead of 8 x 64 for the fp32 MFMA --
+// 2.67x fewer matrix-pipe cycles at fp32-class accuracy (measured max-norm error vs the fp64 oracle
+// ~2e-7, same as the exact-fp32 kernel; tolerance 1e-5).  Tile 128 x (64*WN) x 32, 4 waves as (4/WN) x WN,
+// wave tile (32*TM) x 64; LDS rows are 32 bf16 + 8 pad = 80 B so that the 16-B fragment reads of a
+// 16-lane group hit 16 distinct slots.
+// ------------------------------------------------------------------------------------------
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+constexpr int kSplitLd = 40;   // bf16 elements per LDS row (32 used)
+
+__device__ __forceinline__ void split3(const float (&x)[8], bf16x8 &hi, bf16x8 &mid, bf16x8 &lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)x[i];
+        const float r1 = x[i] - (float)h;       // exact
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;         // exact
+        hi[i] = h;
+        mid[i] = m;
+        lo[i] = (__bf16)r2;
+    }
+}
+
+template <int TM, int WN>
+__global__ __launch_bounds__(256, 2) void dense_split_kernel(
+    const float *__restrict__ a, int64_t lda, int64_t a_kb_stride, const float *__restrict__ in_stat,
+    const float *__restrict__ w, const float *__restrict__ bias, int64_t n, int in_dim, int out_dim, int act,
+    float *__restrict__ out, int64_t ldo, double *__restrict__ bn_partial) {
+    constexpr int WM = 4 / WN;                 // waves along M
+    constexpr int BM = WM * TM * 32, BN = WN * 64;
+    constexpr int RA = BM * 4 / 256, RB = BN * 4 / 256;   // (row, k-octet) items per thread when staging
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    __bf16 *As = reinterpret_cast<__bf16 *>(smem_b);                 // [3][BM][40]
+    __bf16 *Bs = As + 3 * BM * kSplitLd;                            // [3][BN][40]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int fi = lane & 31, fg = lane >> 5;
+    const int n0 = blockIdx.y * BN;
+    const int ktiles = in_dim / kBK;
+    const int64_t row_tiles = (n + BM - 1) / BM;
+
+    double csum[2], csq[2];
+    csum[0] = csum[1] = csq[0] = csq[1] = 0.0;
+
+    float4 ra[RA][2], rb[RB][2];
+    auto load_tiles = [&](int64_t m0, int kt) {
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int item = tid + 256 * j, r = item >> 2, o = item & 3;       // row r, k-octet o
+            int64_t row = m0 + r;
+            row = row < n ? row : n - 1;
+            const float4 *p = reinterpret_cast<const float4 *>(a + (int64_t)kt * a_kb_stride + row * lda + 8 * o);
+            ra[j][0] = p[0];
+            ra[j][1] = p[1];
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            const int item = tid + 256 * j, r = item >> 2, o = item & 3;
+            int col = n0 + r;
+            col = col < out_dim ? col : out_dim - 1;
+            const float4 *p = reinterpret_cast<const float4 *>(w + (int64_t)col * in_dim + kt * kBK + 8 * o);
+            rb[j][0] = p[0];
+            rb[j][1] = p[1];
+        }
+    };
+    auto stage = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int item = tid + 256 * j, r = item >> 2, o = item & 3;
+            float x[8] = {ra[j][0].x, ra[j][0].y, ra[j][0].z, ra[j][0].w, ra[j][1].x, ra[j][1].y, ra[j][1].z, ra[j][1].w};
+            if (in_stat) {                           // BatchNorm of the producer, applied on the fly (uniform branch)
+                const int k = kt * kBK + 8 * o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    x[e] = bn_apply1(x[e], in_stat[k + e], in_stat[in_dim + k + e], in_stat[2 * in_dim + k + e],
+                                     in_stat[3 * in_dim + k + e]);
+            }
+            bf16x8 hi, mid, lo;
+            split3(x, hi, mid, lo);
+            *reinterpret_cast<bf16x8 *>(As + (0 * BM + r) * kSplitLd + 8 * o) = hi;
+            *reinterpret_cast<bf16x8 *>(As + (1 * BM + r) * kSplitLd + 8 * o) = mid;
+            *reinterpret_cast<bf16x8 *>(As + (2 * BM + r) * kSplitLd + 8 * o) = lo;
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            const int item = tid + 256 * j, r = item >> 2, o = item & 3;
+            const float x[8] = {rb[j][0].x, rb[j][0].y, rb[j][0].z, rb[j][0].w, rb[j][1].x, rb[j][1].y, rb[j][1].z, rb[j][1].w};
+            bf16x8 hi, mid, lo;
+            split3(x, hi, mid, lo);
+            *reinterpret_cast<bf16x8 *>(Bs + (0 * BN + r) * kSplitLd + 8 * o) = hi;
+            *reinterpret_cast<bf16x8 *>(Bs + (1 * BN + r) * kSplitLd + 8 * o) = mid;
+            *reinterpret_cast<bf16x8 *>(Bs + (2 * BN + r) * kSplitLd + 8 * o) = lo;
+        }
+    };
+
+    for (int64_t rt = blockIdx.x; rt < row_tiles; rt += gridDim.x) {
+        const int64_t m0 = rt * BM;
+        f32x16 acc[TM][2];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+        load_tiles(m0, 0);
+        __syncthreads();
+        stage(0);
+        __syncthreads();
+        for (int kt = 0; kt < ktiles; ++kt) {
+            if (kt + 1 < ktiles) load_tiles(m0, kt + 1);          // lands while the MFMAs run
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {                      // two 16-wide k blocks per tile
+                bf16x8 af[TM][3], bfr[2][3];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        af[tm][pl] = *reinterpret_cast<const bf16x8 *>(
+                            As + (pl * BM + (wm * TM + tm) * 32 + fi) * kSplitLd + kb * 16 + 8 * fg);
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        bfr[tn][pl] = *reinterpret_cast<const bf16x8 *>(
+                            Bs + (pl * BN + wn * 64 + tn * 32 + fi) * kSplitLd + kb * 16 + 8 * fg);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) {
+                        f32x16 c = acc[tm][tn];
+                        // smallest terms first
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][2], bfr[tn][0], c, 0, 0, 0);   // lo . hi
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][0], bfr[tn][2], c, 0, 0, 0);   // hi . lo
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][1], bfr[tn][1], c, 0, 0, 0);   // mid . mid
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][1], bfr[tn][0], c, 0, 0, 0);   // mid . hi
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][0], bfr[tn][1], c, 0, 0, 0);   // hi . mid
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][0], bfr[tn][0], c, 0, 0, 0);   // hi . hi
+                        acc[tm][tn] = c;
+                    }
+            }
+            if (kt + 1 < ktiles) {
+                __syncthreads();
+                stage(kt + 1);
+                __syncthreads();
+            }
+        }
+        // ---- epilogue (C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5))
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int col = n0 + wn * 64 + tn * 32 + fi;
+            const bool col_ok = col < out_dim;
+            const float b = col_ok ? bias[col] : 0.f;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg;
+                    if (col_ok && row < n) {
+                        const float v = act_apply(acc[tm][tn][r] + b, act);
+                        out[row * ldo + col] = v;
+                        csum[tn] += (double)v;
+                        csq[tn] += (double)v * (double)v;
+                    }
+                }
+        }
+    }
+
+    if (bn_partial) {
+        __syncthreads();
+        double *red = reinterpret_cast<double *>(smem_b);   // [WM][2][BN]
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const double s_ = csum[tn] + __shfl_xor(csum[tn], 32, 64);
+            const double q_ = csq[tn] + __shfl_xor(csq[tn], 32, 64);
+            if (lane < 32) {
+                red[(wm * 2 + 0) * BN + wn * 64 + tn * 32 + lane] = s_;
+                red[(wm * 2 + 1) * BN + wn * 64 + tn * 32 + lane] = q_;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * BN; i += 256) {
+            const int which = i / BN, cl = i % BN, col = n0 + cl;
+            if (col < out_dim) {
+                double tot = 0.0;
+#pragma unroll
+                for (int m = 0; m < WM; ++m) tot += red[(m * 2 + which) * BN + cl];
+                bn_partial[(int64_t)blockIdx.x * 2 * out_dim + (int64_t)which * out_dim + col] = tot;
+            }
+        }
+    }
+}
+
+template <int TM, int WN>
+static void launch_dense_split(int blocks_x, hipStream_t s, const float *a, int64_t lda, int64_t akb, const float *in_stat,
+                               const float *w, const float *b, int64_t n, int in_dim, int out_dim, int act, float *out,
+                               int64_t ldo, double *bn_partial) {
+    constexpr int BM = (4 / WN) * TM * 32, BN = WN * 64;
+    size_t lds = (size_t)3 * (BM + BN) * kSplitLd * 2;
+    const size_t red = (size_t)(4 / WN) * 2 * BN * sizeof(double);
+    if (red > lds) lds = red;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dense_split_kernel<TM, WN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        attr_set = true;
+    }
+    dense_split_kernel<TM, WN><<<dim3(blocks_x, (out_dim + BN - 1) / BN), 256, lds, s>>>(
+        a, lda, akb, in_stat, w, b, n, in_dim, out_dim, act, out, ldo, bn_partial);
+}
+
 template <int NT, bool FAST>
 static void launch_dense(dim3 grid, hipStream_t s, const float *a, int64_t lda, int64_t akb, const float *in_stat,
                          const float *w, const float *b, int64_t n, int in_dim, int out_dim, int act, float *out,
@@ -265,6 +483,23 @@ extern "C" int tgnn_dense_act_fwd(const float *a, int64_t lda, int64_t a_kblock_
     const int vec_w = (in_dim % 4 == 0) && ((uintptr_t)w % 16 == 0);
     const int blocks_x = producer_blocks(n_rows, kBM);
     const bool fast = vec_a && vec_w && in_dim % kBK == 0;
+    static const int exact_only = getenv("TGNN_DENSE_EXACT_FP32") ? atoi(getenv("TGNN_DENSE_EXACT_FP32")) : 0;
+    if (fast && out_dim >= 64 && !exact_only && lda % 8 == 0 && a_kblock_stride % 8 == 0 && in_dim % 8 == 0) {
+        // bf16 x 3 split-precision path (see dense_split_kernel)
+        if (out_dim > 64) {
+            const int bx = producer_blocks(n_rows, 128);
+            launch_dense_split<2, 2>(bx, s, a, lda, a_kblock_stride, in_stat, w, b, n_rows, in_dim, out_dim, act, out, ldo,
+                                     bn_partial);
+            if (n_partials_host) *n_partials_host = bx;
+        } else {
+            const int bx = producer_blocks(n_rows, 128);
+            launch_dense_split<1, 1>(bx, s, a, lda, a_kblock_stride, in_stat, w, b, n_rows, in_dim, out_dim, act, out, ldo,
+                                     bn_partial);
+            if (n_partials_host) *n_partials_host = bx;
+        }
+        TGNN_CHECK_LAUNCH();
+        return TGNN_OK;
+    }
 #define TGNN_DENSE(NT_)                                                                                            \
     do {                                                                                                           \
         const dim3 grid_(blocks_x, (out_dim + 32 * NT_ - 1) / (32 * NT_));                                         \
@@ -275,7 +510,12 @@ extern "C" int tgnn_dense_act_fwd(const float *a, int64_t lda, int64_t a_kblock_
             launch_dense<NT_, false>(grid_, s, a, lda, a_kblock_stride, in_stat, w, b, n_rows, in_dim, out_dim, act, \
                                      out, ldo, bn_partial, vec_a, vec_w);                                          \
     } while (0)
-    if (out_dim > 128) {
+    static const int force_nt = getenv("TGNN_DENSE_NT") ? atoi(getenv("TGNN_DENSE_NT")) : 0;   // tuning knob (experiments)
+    if (force_nt == 4 && out_dim > 32) {
+        TGNN_DENSE(4);
+    } else if (force_nt == 2 && out_dim > 32) {
+        TGNN_DENSE(2);
+    } else if (out_dim > 128) {
         TGNN_DENSE(8);
     } else if (out_dim > 64) {
         TGNN_DENSE(4);

@@ -157,9 +157,98 @@ __device__ __forceinline__ bool rows_equal(const float *__restrict__ attr, int f
     return true;
 }
 
-// table[slot] = smallest edge number carrying the row content that hashed/probed to the slot
-__global__ void dedup_insert_kernel(const float *__restrict__ attr, int64_t e, int fe, int *__restrict__ table,
-                                    uint32_t mask, int *__restrict__ slot_of_edge) {
+// table[slot] = smallest edge number carrying the row content that hashed/probed to the slot.
+// Two levels: a block first de-duplicates its own 256 rows in LDS (rows staged with coalesced loads, an LDS
+// hash table keyed by content, representative = smallest thread index); only the block representatives --
+// a dozen per block on real layouts -- then probe the global table.  A flat version in which all 1e6 edges
+// probed the global table spent 220-280 us hammering 13 hot slots.
+constexpr int kDedupRows = 256;
+constexpr int kDedupLocal = 512;                       // LDS table slots (>= 2 x rows: never full)
+__global__ __launch_bounds__(kDedupRows) void dedup_insert_kernel(const float *__restrict__ attr, int64_t e, int fe,
+                                                                  int *__restrict__ table, uint32_t mask,
+                                                                  int *__restrict__ slot_of_edge) {
+    extern __shared__ uint32_t rows_s[];                 // [256][ld], ld = fe | 1 (odd: conflict-free per-thread rows)
+    __shared__ int ltab[kDedupLocal];
+    __shared__ int lslot[kDedupRows];                    // global slot found by each block representative
+    const int ld = fe | 1, tid = threadIdx.x;
+    for (int64_t base = (int64_t)blockIdx.x * kDedupRows; base < e; base += (int64_t)gridDim.x * kDedupRows) {
+        const int64_t n_here = e - base < kDedupRows ? e - base : kDedupRows;
+        const int64_t total = n_here * fe;
+        __syncthreads();
+        for (int64_t k = tid; k < total; k += kDedupRows) {
+            const int r = (int)(k / fe), c = (int)(k - (int64_t)r * fe);
+            rows_s[r * ld + c] = canon_bits(attr[base * fe + k]);
+        }
+        ltab[tid] = -1;
+        ltab[tid + kDedupRows] = -1;
+        __syncthreads();
+        const int64_t i = base + tid;
+        const bool ok = i < e;
+        const uint32_t *mine = rows_s + tid * ld;
+        uint64_t h = 0xCBF29CE484222325ull;
+        if (ok)
+            for (int k = 0; k < fe; ++k) h = mix64(h, mine[k]);
+        const uint32_t h32 = (uint32_t)(h ^ (h >> 32));
+        // ---- level 1: representative inside the block
+        int my_l = 0;
+        if (ok) {
+            uint32_t sl = h32 & (kDedupLocal - 1);
+            while (true) {
+                int cur = ltab[sl];
+                if (cur < 0) {
+                    const int prev = atomicCAS(&ltab[sl], -1, tid);
+                    if (prev < 0) break;
+                    cur = prev;
+                }
+                bool same = cur == tid;
+                if (!same) {
+                    same = true;
+                    const uint32_t *other = rows_s + cur * ld;
+                    for (int k = 0; k < fe; ++k)
+                        if (other[k] != mine[k]) { same = false; break; }
+                }
+                if (same) {
+                    if (tid < cur) atomicMin(&ltab[sl], tid);
+                    break;
+                }
+                sl = (sl + 1) & (kDedupLocal - 1);
+            }
+            my_l = (int)sl;
+        }
+        __syncthreads();
+        // ---- level 2: block representatives probe the global table
+        if (ok && ltab[my_l] == tid) {
+            uint32_t slot = h32 & mask;
+            while (true) {
+                int cur = __hip_atomic_load(&table[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur < 0) {
+                    const int prev = atomicCAS(&table[slot], -1, (int)i);
+                    if (prev < 0) break;  // claimed the slot
+                    cur = prev;
+                }
+                bool same = cur == (int)i;
+                if (!same) {
+                    same = true;
+                    const float *other = attr + (int64_t)cur * fe;        // a handful of hot rows: L1 / L2 hits
+                    for (int k = 0; k < fe; ++k)
+                        if (canon_bits(other[k]) != mine[k]) { same = false; break; }
+                }
+                if (same) {
+                    if ((int)i < cur) atomicMin(&table[slot], (int)i);     // the representative only ever decreases
+                    break;
+                }
+                slot = (slot + 1) & mask;  // table is at most half full: terminates
+            }
+            lslot[tid] = (int)slot;
+        }
+        __syncthreads();
+        if (ok) slot_of_edge[i] = lslot[ltab[my_l]];
+    }
+}
+
+// Wide rows (Fe > 60: the staged tile would not fit 64 KB of LDS): every thread reads its row from HBM.
+__global__ void dedup_insert_direct_kernel(const float *__restrict__ attr, int64_t e, int fe, int *__restrict__ table,
+                                           uint32_t mask, int *__restrict__ slot_of_edge) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) {
         uint64_t h = 0xCBF29CE484222325ull;
         for (int k = 0; k < fe; ++k) h = mix64(h, canon_bits(attr[i * fe + k]));
@@ -168,16 +257,14 @@ __global__ void dedup_insert_kernel(const float *__restrict__ attr, int64_t e, i
             int cur = __hip_atomic_load(&table[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (cur < 0) {
                 const int prev = atomicCAS(&table[slot], -1, (int)i);
-                if (prev < 0) break;  // claimed the slot
+                if (prev < 0) break;
                 cur = prev;
             }
             if (cur == (int)i || rows_equal(attr, fe, cur, i)) {
-                // the slot's representative only ever decreases: with T ~ 13 distinct rows and 1e6
-                // edges an unconditional atomicMin serialises the whole kernel on 13 addresses
                 if ((int)i < cur) atomicMin(&table[slot], (int)i);
                 break;
             }
-            slot = (slot + 1) & mask;  // table is at most half full: terminates
+            slot = (slot + 1) & mask;
         }
         slot_of_edge[i] = (int)slot;
     }
@@ -408,7 +495,11 @@ extern "C" int tgnn_edge_type_dedup(const float *edge_attr, int64_t n_edges, int
     int *is_first = cv.take<int>(n_edges);
     int *scan_ws = cv.take<int>(scan_ws_ints(n_edges));
     TGNN_CHECK_HIP(hipMemsetAsync(table, 0xFF, (size_t)cap * 4, s));
-    dedup_insert_kernel<<<grid_for(n_edges), 256, 0, s>>>(edge_attr, n_edges, fe, table, cap - 1, slot_of_edge);
+    if (fe <= 60)
+        dedup_insert_kernel<<<grid_for(n_edges, kDedupRows), kDedupRows, (size_t)kDedupRows * (fe | 1) * 4, s>>>(
+            edge_attr, n_edges, fe, table, cap - 1, slot_of_edge);
+    else
+        dedup_insert_direct_kernel<<<grid_for(n_edges), 256, 0, s>>>(edge_attr, n_edges, fe, table, cap - 1, slot_of_edge);
     dedup_mark_first_kernel<<<grid_for(n_edges), 256, 0, s>>>(table, slot_of_edge, n_edges, is_first);
     exclusive_scan_i32(is_first, is_first, n_edges, scan_ws, s);
     dedup_assign_kernel<<<grid_for(n_edges), 256, 0, s>>>(table, slot_of_edge, is_first, n_edges, edge_type,
@@ -428,7 +519,7 @@ extern "C" int tgnn_gather_i32(const int32_t *src, int64_t n_src, const int32_t 
 
 extern "C" int64_t tgnn_nnconv_tiles_max_chunks(int64_t n_nodes, int64_t n_edges, int32_t n_types) {
     const int64_t ntiles = (n_nodes + kTileRows - 1) / kTileRows;
-    return n_edges / 16 + ntiles * ((int64_t)n_types + kTileRows / 16) + 1;
+    return n_edges / 16 + ntiles * ((int64_t)n_types + kTileRows / 16) + 16;   // + slack: the kernel reads whole 8-chunk units
 }
 
 extern "C" size_t tgnn_nnconv_tiles_workspace_bytes(int64_t n_nodes) {
