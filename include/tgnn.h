@@ -117,36 +117,37 @@ int tgnn_nnconv_mean_fwd(const float *h, int64_t ldh, const int32_t *rowptr, con
                          const float *bias, int64_t n_nodes, int32_t c, int32_t act, float *out,
                          double *bn_partial, int32_t *n_partials_host, tgnn_stream_t stream);
 
-/* The same NNConv on matrix cores, over the tile structure built by tgnn_nnconv_tiles_build
- * (network_width 32 and at most tgnn_nnconv_tiled_max_types() edge types; otherwise use
+/* The same NNConv on matrix cores, over the type-column structure built by tgnn_nnconv_cols_build
+ * (network_width 32 and at most tgnn_nnconv_cols_max_types() edge types; otherwise use
  * tgnn_nnconv_mean_fwd, which handles any width / type count).  Production path of tgnn_forward.
  *
- * Tile structure (adjacency set, once per layout): every 64 destination rows form a tile whose
- * in-edges are grouped by edge type and padded to 16-slot chunks, followed by 4 chunks of
- * pseudo-type T carrying the rows themselves (the root term h[v] . root):
- *   tile_chunk_ptr int32 [ceil(N/64)+1]   chunk range of every tile
- *   chunk_meta     int32 [8*n_chunks]     32-byte record per chunk (must be 32-byte aligned):
- *                                         word 0 = edge type (T = root chunk), words 1-3 = 0,
- *                                         words 4-7 = destination rows inside the tile, one byte per
- *                                         slot (0..63; 64 = padding): word 4+q holds slots 4q..4q+3
- *   slot_src       int32 [16*n_chunks]    source row, -1 = padding
- * n_chunks <= tgnn_nnconv_tiles_max_chunks(N, E, T) (allocate for that); the exact count is
- * tile_chunk_ptr[ceil(N/64)]. */
-int64_t tgnn_nnconv_tiles_max_chunks(int64_t n_nodes, int64_t n_edges, int32_t n_types);
-size_t tgnn_nnconv_tiles_workspace_bytes(int64_t n_nodes);
-int tgnn_nnconv_tiles_build(const int32_t *rowptr, const int32_t *col_src, const int32_t *col_type,
-                            int64_t n_nodes, int32_t n_types, int32_t *tile_chunk_ptr, int32_t *chunk_meta,
-                            int32_t *slot_src, void *ws, size_t ws_bytes, tgnn_stream_t stream);
-int32_t tgnn_nnconv_tiled_max_types(void);
+ * The sum over edges moves inside the product: sum_e h[src_e] . W_type(e) = sum_t (sum_{e of type t} h[src_e]) . W_t,
+ * one dense [16 x 32(T+1)] x [32(T+1) x 32] product per 16 destination rows whose accumulator is the output tile.
+ *
+ * Column structure (adjacency set, once per layout): every 16 destination rows form a tile with a list of
+ * columns sorted by edge type; column (t, r) holds, for each of the 16 rows, the source of the row's r-th
+ * in-edge of type t in original edge order, or -1.  The last column of a tile is the root column (type T):
+ *   tile_col_ptr int32 [ceil(N/16)+1]   column range of every tile
+ *   col_meta     int32 [n_cols]         type | first-of-type << 8 | last-of-type << 9 | end-of-tile << 10
+ *   col_src      int32 [16*n_cols]      source row per tile row, -1 = none; in a root column the float bits of
+ *                                       1 / max(in-degree, 1), or -1 for rows >= N
+ * n_cols <= tgnn_nnconv_cols_max_columns(N, E) (allocate col_meta / col_src for that many: the kernel reads
+ * index words a few columns past the end); the exact count is tile_col_ptr[ceil(N/16)].
+ * Source rows must lie within 2 GB of h (buffer addressing): N_src * ldh * 4 < 2^31. */
+int64_t tgnn_nnconv_cols_max_columns(int64_t n_nodes, int64_t n_edges);
+size_t tgnn_nnconv_cols_workspace_bytes(int64_t n_nodes);
+int tgnn_nnconv_cols_build(const int32_t *rowptr, const int32_t *col_src, const int32_t *col_type,
+                           int64_t n_nodes, int32_t n_types, int32_t *tile_col_ptr, int32_t *col_meta,
+                           int32_t *col_slot_src, void *ws, size_t ws_bytes, tgnn_stream_t stream);
+int32_t tgnn_nnconv_cols_max_types(void);
 /* wimg_scratch: tgnn_nnconv_weight_image_floats(T) floats of caller scratch (the [T][C][C] table and
- * the root matrix are re-laid out into MFMA B-operand order there before the main kernel runs). */
+ * the root matrix are re-laid out into MFMA operand order there before the main kernel runs). */
 size_t tgnn_nnconv_weight_image_floats(int32_t n_types);
-int tgnn_nnconv_mean_tiled_fwd(const float *h, int64_t ldh, const int32_t *rowptr, const int32_t *tile_chunk_ptr,
-                               const int32_t *chunk_meta, const int32_t *slot_src,
-                               const float *wtab, int32_t n_types, const float *root,
-                               const float *bias, int64_t n_nodes, int32_t c, int32_t act, float *out,
-                               float *wimg_scratch, double *bn_partial, int32_t *n_partials_host,
-                               tgnn_stream_t stream);
+int tgnn_nnconv_mean_cols_fwd(const float *h, int64_t ldh, const int32_t *tile_col_ptr, const int32_t *col_meta,
+                              const int32_t *col_src, const float *wtab, int32_t n_types, const float *root,
+                              const float *bias, int64_t n_nodes, int32_t c, int32_t act, float *out,
+                              float *wimg_scratch, double *bn_partial, int32_t *n_partials_host,
+                              tgnn_stream_t stream);
 
 /* GINConv + optional LeakyReLU (coll_conv.py:25-27):
  *   z[v]  = (1+eps) * f(a[v]) + sum_{e: dst_e = v} f(a[src_e]),   f = identity or the BatchNorm
@@ -222,10 +223,10 @@ typedef struct tgnn_graph {
     const int32_t *type_rep_edge; /* [T] original edge numbers */
     const int32_t *col_rowptr;  /* [N+1] */
     const int32_t *col_src;     /* [Ec'] */
-    /* NNConv tile structure (all NULL => tgnn_forward uses the CSR kernel) */
-    const int32_t *tile_chunk_ptr;
-    const int32_t *chunk_meta;
-    const int32_t *slot_src;
+    /* NNConv type-column structure (all NULL => tgnn_forward uses the CSR kernel) */
+    const int32_t *nn_tile_col_ptr;
+    const int32_t *nn_col_meta;
+    const int32_t *nn_col_src;
 } tgnn_graph;
 
 size_t tgnn_forward_workspace_bytes(const tgnn_model_dims *dims, int64_t n_nodes, int32_t n_types);
@@ -233,8 +234,9 @@ size_t tgnn_forward_workspace_bytes(const tgnn_model_dims *dims, int64_t n_nodes
 /* probs [N, output_dim].  BatchNorm runs with batch statistics and updates the running buffers
  * in `params` when update_running != 0 (train mode); with use_running_stats != 0 it normalises
  * with the running buffers instead (eval mode; never used by the reference's solver).
- * The collision branch is enqueued on stream2 when stream2 != NULL (it does not depend on the
- * adjacency branch, TilinGNN.py:63); the caller must have made stream2 wait for the inputs. */
+ * With stream2 != NULL (and != stream) the collision branch of every layer (TilinGNN.py:63) is enqueued on
+ * stream2 beside the adjacency branch (:62) it does not depend on; the library forks and joins with events, so
+ * on return all work is ordered on `stream` and the caller needs no synchronisation of its own with stream2. */
 int tgnn_forward(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
                  const float *adj_edge_attr, const tgnn_graph *graph, int32_t update_running,
                  int32_t use_running_stats, float *probs, void *ws, size_t ws_bytes,

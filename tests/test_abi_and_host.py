@@ -47,8 +47,8 @@ def test_workspace_size_queries_and_argument_validation_without_gpu():
     big = lib.tgnn_forward_workspace_bytes(C.byref(dims), 100000, 13)
     assert 0 < small < big < 2 ** 33
     assert lib.tgnn_csr_workspace_bytes(1000, 10000) > 0 and lib.tgnn_edge_dedup_workspace_bytes(10000, 15) > 0
-    assert lib.tgnn_nnconv_tiles_max_chunks(1000, 10000, 13) >= 10000 // 16
-    assert lib.tgnn_nnconv_tiled_max_types() >= 13
+    assert lib.tgnn_nnconv_cols_max_columns(1000, 10000) >= 10000 + 63
+    assert lib.tgnn_nnconv_cols_max_types() >= 13
     bad = _lib.ModelDims(3, 15, 30, 20, 1)                               # width must be a multiple of 4
     assert lib.tgnn_param_count(C.byref(bad)) == -1
     # invalid arguments are rejected before any launch (no GPU needed) with a message

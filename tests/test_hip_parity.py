@@ -99,53 +99,55 @@ def test_labyrinth_graph_has_13_edge_types(dev):
     assert len(pairs) == 13
 
 
-@pytest.mark.parametrize("n,e,t,seed", [(5, 12, 3, 0), (64, 700, 13, 1), (1254, 8502, 13, 2), (20001, 260000, 17, 3)])
-def test_nnconv_tile_structure(dev, n, e, t, seed):
-    """Tiles = per 64 destination rows the in-edges grouped by type (CSR order inside a group), padded to
-    16-slot chunks, followed by 4 root chunks of pseudo-type T."""
+@pytest.mark.parametrize("n,e,t,seed", [(5, 12, 3, 0), (64, 700, 13, 1), (1254, 8502, 13, 2), (20001, 260000, 31, 3),
+                                        (33, 900, 2, 4)])
+def test_nnconv_column_structure(dev, n, e, t, seed):
+    """Columns = per 16 destination rows, sorted by type: column (type k, rank r) holds every row's r-th in-edge
+    of type k in CSR (= original) order or -1; as many columns per type as the tile's largest multiplicity; the
+    root column (type T, all three flags) closes the tile with 1/max(deg,1) as float bits, -1 beyond N."""
     from tilingnn_amd import ops
     rng = np.random.default_rng(seed)
     ei = rng.integers(0, n, size=(2, e), dtype=np.int64)
     etype = rng.integers(0, t, size=e).astype(np.int32)
     rowptr, src, eid, _ = ops.build_csr(torch.from_numpy(ei).to(dev), n, False)
     col_type = torch.from_numpy(etype).to(dev)[eid.long()[:e]].contiguous()
-    tiles = ops.build_nnconv_tiles(n, e, t, rowptr, src, col_type)
+    cols = ops.build_nnconv_columns(n, e, t, rowptr, src, col_type)
     rp, srcs, ctype = rowptr.cpu().numpy(), src.cpu().numpy()[:e], col_type.cpu().numpy()
-    tcp = tiles.tile_chunk_ptr.cpu().numpy()
-    tcp = tiles.tile_chunk_ptr.cpu().numpy()
-    meta = tiles.chunk_meta.cpu().numpy().reshape(-1, 8)
-    chunk_type = meta[:, 0]; s_src = tiles.slot_src.cpu().numpy()
-    s_row = np.ascontiguousarray(meta[:, 4:8]).view(np.uint8).reshape(-1).astype(np.int64)
-    assert (meta[: tcp[-1], 1:4] == 0).all()
-    ntiles = (n + 63) // 64
+    tcp = cols.tile_col_ptr.cpu().numpy()
+    meta = cols.col_meta.cpu().numpy()
+    csrc = cols.col_src.cpu().numpy().reshape(-1, 16)
+    ntiles = (n + 15) // 16
     assert tcp[0] == 0 and tcp.shape[0] == ntiles + 1
+    assert tcp[-1] <= ops.lib.tgnn_nnconv_cols_max_columns(n, e) - 32
+    FIRST, LAST, END = 1 << 8, 1 << 9, 1 << 10
     for b in range(ntiles):
-        r0, r1 = 64 * b, min(64 * b + 64, n)
-        e0, e1 = rp[r0], rp[r1]
-        rows_of = np.repeat(np.arange(r0, r1), np.diff(rp[r0:r1 + 1])) - r0
+        r0, r1 = 16 * b, min(16 * b + 16, n)
         c0, c1 = tcp[b], tcp[b + 1]
-        ct = chunk_type[c0:c1]
-        assert list(ct) == sorted(ct) and list(ct[-4:]) == [t] * 4 and (ct[:-4] < t).all()
-        want_chunks = sum((np.count_nonzero(ctype[e0:e1] == k) + 15) // 16 for k in range(t)) + 4
-        assert c1 - c0 == want_chunks
-        sl = slice(16 * c0, 16 * c1)
-        slot_t = np.repeat(ct, 16)
+        want_cols, want_meta = [], []
         for k in range(t):
-            sel = (slot_t == k) & (s_src[sl] >= 0)
-            want = ctype[e0:e1] == k
-            np.testing.assert_array_equal(s_src[sl][sel], srcs[e0:e1][want])
-            np.testing.assert_array_equal(s_row[sl][sel], rows_of[want])
-        pad = (slot_t < t) & (s_src[sl] < 0)
-        assert (s_row[sl][pad] == 64).all()
-        root = slot_t == t
+            per_row = [srcs[rp[r]:rp[r + 1]][ctype[rp[r]:rp[r + 1]] == k] for r in range(r0, r1)]
+            m = max((len(p) for p in per_row), default=0)
+            for r in range(m):
+                col = np.full(16, -1, dtype=np.int64)
+                for j, pr in enumerate(per_row):
+                    if r < len(pr):
+                        col[j] = pr[r]
+                want_cols.append(col)
+                want_meta.append(k | (FIRST if r == 0 else 0) | (LAST if r == m - 1 else 0))
+        assert c1 - c0 == len(want_cols) + 1
+        if want_cols:
+            np.testing.assert_array_equal(csrc[c0:c1 - 1], np.stack(want_cols))
+            np.testing.assert_array_equal(meta[c0:c1 - 1], np.array(want_meta))
+        assert meta[c1 - 1] == (t | FIRST | LAST | END)
         deg = np.diff(rp[r0:r1 + 1])
-        np.testing.assert_array_equal(s_row[sl][root], np.arange(64))
-        np.testing.assert_array_equal(s_src[sl][root][: r1 - r0], np.arange(r0, r1))
-        assert (s_src[sl][root][r1 - r0:] == -1).all()
+        inv = (1.0 / np.maximum(deg, 1)).astype(np.float32)
+        root = csrc[c1 - 1]
+        np.testing.assert_array_equal(root[: r1 - r0].astype(np.int32).view(np.float32), inv)
+        assert (root[r1 - r0:] == -1).all()
 
 
 def test_nnconv_csr_kernel_and_tile_kernel_agree_with_oracle(dev):
-    """Both NNConv implementations (MFMA tile kernel = production; CSR / LDS-weight-table kernel = fallback
+    """Both NNConv implementations (matrix-core column kernel = production; CSR / LDS-weight-table kernel = fallback
     for many edge types) against the fp64 oracle, incl. the fused LeakyReLU and the BN partial sums."""
     from tilingnn_amd import ops
     g = load_labyrinth_graph()
@@ -157,7 +159,7 @@ def test_nnconv_csr_kernel_and_tile_kernel_agree_with_oracle(dev):
     with torch.no_grad():
         want = orc.nnconv_mean(h.double(), adj.cpu(), adj_attr.cpu().double(), sd64, "brch_1_graph_conv_layers.4")
     pg = ops.prepare_graph(1254, adj, adj_attr, col)
-    assert pg.tiles is not None
+    assert pg.cols is not None
     l1 = net.brch_1_graph_conv_layers[4]
     wtab = ops.edge_weight_table(adj_attr, pg, *l1.nnConv._edge_mlp_params(), 32)
     for force_csr in (False, True):
@@ -173,8 +175,9 @@ def test_nnconv_csr_kernel_and_tile_kernel_agree_with_oracle(dev):
         assert orc.rel_max_err(got_act.cpu(), orc.leaky_relu(want)) < TOL
 
 
-def test_many_edge_types_fall_back_to_csr_kernels(dev):
-    """T = 25 (> the tile kernel's LDS budget) -> LDS-weight-table CSR kernel; T = 300 -> generic kernel."""
+def test_many_edge_types(dev):
+    """T = 25: the column kernel with one block per CU (its LDS weight image holds up to 32 types);
+    T = 300: no LDS image fits -> generic CSR kernel."""
     from tilingnn_amd.synth import make_super_graph
     for t_count in (25, 300):
         sg = make_super_graph(3000, 24000, 30000, tile_count=2, n_edge_types=t_count, seed=9)

@@ -32,7 +32,7 @@ class Graph(C.Structure):
                 ("n_types", C.c_int32),
                 ("adj_rowptr", C.c_void_p), ("adj_src", C.c_void_p), ("adj_type", C.c_void_p),
                 ("type_rep_edge", C.c_void_p), ("col_rowptr", C.c_void_p), ("col_src", C.c_void_p),
-                ("tile_chunk_ptr", C.c_void_p), ("chunk_meta", C.c_void_p), ("slot_src", C.c_void_p)]
+                ("nn_tile_col_ptr", C.c_void_p), ("nn_col_meta", C.c_void_p), ("nn_col_src", C.c_void_p)]
 
 
 def _load() -> C.CDLL:
@@ -54,12 +54,12 @@ def _load() -> C.CDLL:
         "tgnn_gather_i32": (C.c_int, [p, i64, p, i64, p, p]),
         "tgnn_edge_weight_table": (C.c_int, [p, p, i32, i32, p, p, p, p, p, p, i32, p, p]),
         "tgnn_nnconv_mean_fwd": (C.c_int, [p, i64, p, p, p, p, i32, p, p, i64, i32, i32, p, p, pi32, p]),
-        "tgnn_nnconv_tiles_max_chunks": (i64, [i64, i64, i32]),
-        "tgnn_nnconv_tiles_workspace_bytes": (sz, [i64]),
-        "tgnn_nnconv_tiles_build": (C.c_int, [p, p, p, i64, i32, p, p, p, p, sz, p]),
-        "tgnn_nnconv_tiled_max_types": (i32, []),
+        "tgnn_nnconv_cols_max_columns": (i64, [i64, i64]),
+        "tgnn_nnconv_cols_workspace_bytes": (sz, [i64]),
+        "tgnn_nnconv_cols_build": (C.c_int, [p, p, p, i64, i32, p, p, p, p, sz, p]),
+        "tgnn_nnconv_cols_max_types": (i32, []),
         "tgnn_nnconv_weight_image_floats": (sz, [i32]),
-        "tgnn_nnconv_mean_tiled_fwd": (C.c_int, [p, i64, p, p, p, p, p, i32, p, p, i64, i32, i32, p, p, p, pi32, p]),
+        "tgnn_nnconv_mean_cols_fwd": (C.c_int, [p, i64, p, p, p, p, i32, p, p, i64, i32, i32, p, p, p, pi32, p]),
         "tgnn_gin_fwd": (C.c_int, [p, i64, p, p, p, p, p, p, p, p, p, p, i64, i32, i32, p, p, p, pi32, p]),
         "tgnn_dense_act_fwd": (C.c_int, [p, i64, i64, p, p, p, i64, i32, i32, i32, p, i64, p, pi32, p]),
         "tgnn_bn_finalize": (C.c_int, [i32, p, i32, p, i32, i64, p, p, f32, f32, p, p, p, p, p]),
@@ -85,8 +85,8 @@ lib = _load()
 EXPORTED_SYMBOLS = (
     "tgnn_version", "tgnn_last_error", "tgnn_csr_workspace_bytes", "tgnn_csr_build",
     "tgnn_edge_dedup_workspace_bytes", "tgnn_edge_type_dedup", "tgnn_gather_i32", "tgnn_edge_weight_table",
-    "tgnn_nnconv_mean_fwd", "tgnn_nnconv_tiles_max_chunks", "tgnn_nnconv_tiles_workspace_bytes",
-    "tgnn_nnconv_tiles_build", "tgnn_nnconv_tiled_max_types", "tgnn_nnconv_weight_image_floats", "tgnn_nnconv_mean_tiled_fwd", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
+    "tgnn_nnconv_mean_fwd", "tgnn_nnconv_cols_max_columns", "tgnn_nnconv_cols_workspace_bytes",
+    "tgnn_nnconv_cols_build", "tgnn_nnconv_cols_max_types", "tgnn_nnconv_weight_image_floats", "tgnn_nnconv_mean_cols_fwd", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
     "tgnn_merge_fwd", "tgnn_param_count", "tgnn_param_name", "tgnn_forward_workspace_bytes", "tgnn_forward",
     "tgnn_forward_profiled",
     "tgnn_rows_gather", "tgnn_rows_scatter")
@@ -106,6 +106,24 @@ def ptr(t) -> C.c_void_p:
 def current_stream(device) -> C.c_void_p:
     import torch
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+_side_streams = {}
+
+
+def side_stream(device) -> C.c_void_p:
+    """Second stream of the forward's two-stream schedule (collision branch beside the adjacency branch); one per
+    device, created on first use.  Off unless TGNN_TWO_STREAMS=1 (measured: no gain with the column NNConv kernel, which fills the CUs by itself): NULL = everything on the current stream."""
+    import torch
+    if os.environ.get("TGNN_TWO_STREAMS", "0") != "1":
+        return C.c_void_p(None)
+    key = torch.device(device).index
+    if key is None:
+        key = torch.cuda.current_device()
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=key)
+    return C.c_void_p(st.cuda_stream)
 
 
 def param_names(dims: ModelDims):

@@ -152,7 +152,7 @@ static Workspace carve(const tgnn_model_dims &d, int64_t n, int32_t n_types, voi
     w.f3 = cv.take<float>((size_t)n * 64);
     w.f4 = cv.take<float>((size_t)n * c);
     w.wtab = cv.take<float>((size_t)D * (n_types > 0 ? n_types : 1) * c * c);
-    w.wimg = cv.take<float>((size_t)D * (n_types + 1) * 1152);     // MFMA B-operand images (tiled NNConv)
+    w.wimg = cv.take<float>((size_t)D * (n_types + 1) * kWtType);  // MFMA operand images of the column NNConv
     w.part1 = cv.take<double>((size_t)TGNN_BN_MAX_PARTIALS * 2 * c);
     w.part2 = cv.take<double>((size_t)TGNN_BN_MAX_PARTIALS * 2 * c);
     w.partf = cv.take<double>((size_t)TGNN_BN_MAX_PARTIALS * 2 * 256);
@@ -222,8 +222,25 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         set_error("tgnn_forward: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
         return TGNN_ERR_WORKSPACE;
     }
-    (void)stream2;  // single-stream schedule in this version; see DESIGN.md
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // Two-stream schedule: the collision branch of layer i (GINConv, TilinGNN.py:63) does not depend on the
+    // adjacency branch (:62); with a side stream it runs beside NNConv, whose gather-latency-bound waves leave
+    // issue slots and whole CUs (tail) idle.  Fork after merge_{i-1}, join before the BN finalize of layer i.
+    hipStream_t s2 = prof.on ? nullptr : static_cast<hipStream_t>(stream2);
+    if (s2 == s) s2 = nullptr;
+    static thread_local hipEvent_t ev_cache[64][2] = {};   // per calling thread and device; never destroyed
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    if (s2) {
+        int dev = 0;
+        TGNN_CHECK_HIP(hipGetDevice(&dev));
+        TGNN_CHECK_ARG(dev >= 0 && dev < 64, "device index");
+        if (!ev_cache[dev][0]) {
+            TGNN_CHECK_HIP(hipEventCreateWithFlags(&ev_cache[dev][0], hipEventDisableTiming));
+            TGNN_CHECK_HIP(hipEventCreateWithFlags(&ev_cache[dev][1], hipEventDisableTiming));
+        }
+        ev_fork = ev_cache[dev][0];
+        ev_join = ev_cache[dev][1];
+    }
     prof.s = s;
     const int c = dims->network_width, D = dims->network_depth, fx = dims->node_features_dim,
               fe = dims->adj_edge_features_dim, T = graph->n_types;
@@ -253,7 +270,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         launch_edge_weight_table_batched(adj_edge_attr, graph->type_rep_edge, T, fe, layers, D, c, w.wtab, s);
         prof.end();
     }
-    const bool tiled = graph->tile_chunk_ptr && c == 32;
+    const bool tiled = graph->nn_tile_col_ptr && c == 32 && (int64_t)n * c * 4 < (int64_t(1) << 31);   // buffer-addressed gathers
     if (tiled) {
         const float *roots[kMaxDepth];
         for (int i = 0; i < D; ++i) roots[i] = P.f(P.layer(i) + 6);
@@ -281,12 +298,16 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     for (int i = 0; i < D; ++i) {
         const int b = P.layer(i);
         const float *h1 = w.mid + (size_t)i * n * c;
+        if (s2) {   // everything layer i reads (middle[i], a2_{i-1}, its BN record) is complete on `s` here
+            TGNN_CHECK_HIP(hipEventRecord(ev_fork, s));
+            TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev_fork, 0));
+        }
         // GraphConv (:62): NNConv mean + LeakyReLU; BN statistics emitted as partials
         prof.begin(2);
         if (tiled) {
-            TGNN_TRY(launch_nnconv_tiled(h1, c, graph->adj_rowptr, graph->tile_chunk_ptr, graph->chunk_meta,
-                                         graph->slot_src, w.wimg + (size_t)i * (T + 1) * 1152, T, P.f(b + 7), n, TGNN_ACT_LEAKY_RELU, w.a1,
-                                         w.part1, &np1, s));
+            TGNN_TRY(launch_nnconv_cols(h1, c, graph->nn_tile_col_ptr, graph->nn_col_meta, graph->nn_col_src,
+                                        w.wimg + (size_t)i * (T + 1) * kWtType, T, P.f(b + 7), n, TGNN_ACT_LEAKY_RELU,
+                                        w.a1, w.part1, &np1, s));
         } else {
             TGNN_TRY(tgnn_nnconv_mean_fwd(h1, c, graph->adj_rowptr, graph->adj_src, graph->adj_type,
                                       w.wtab + (size_t)i * T * c * c, T, P.f(b + 6), P.f(b + 7), n, c,
@@ -299,8 +320,12 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         prof.begin(3);
         TGNN_TRY(tgnn_gin_fwd(gin_in, c, gin_stat, graph->col_rowptr, graph->col_src, P.f(b + 13), P.f(b + 14),
                               P.f(b + 15), P.f(b + 16), P.f(b + 17), P.f(b + 18), P.f(b + 19), n, c,
-                              TGNN_ACT_LEAKY_RELU, w.a2[i & 1], w.t0, w.part2, &np2, s));
+                              TGNN_ACT_LEAKY_RELU, w.a2[i & 1], w.t0, w.part2, &np2, s2 ? s2 : s));
         prof.end();
+        if (s2) {
+            TGNN_CHECK_HIP(hipEventRecord(ev_join, s2));
+            TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev_join, 0));
+        }
         {
             const BnPtrs b1 = P.bn(b + 8), b2 = P.bn(b + 20);
             const bool run = update_running || use_running_stats;

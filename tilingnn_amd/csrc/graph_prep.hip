@@ -298,117 +298,68 @@ __global__ void gather_i32_kernel(const int *__restrict__ src, int64_t n_src, co
 }
 
 // ------------------------------------------------------------------------------------------
-// NNConv tiles: per 64 destination rows, the in-edges grouped by edge type and padded to 16-slot
-// chunks (one chunk = one 16x16x4 MFMA operand block), plus 4 "root" chunks (type T) that carry the
-// rows themselves.  Built once per layout, reused by all 20 layers.  One wavefront per tile.
+// NNConv type columns (nnconv_cols.hip): per 16 destination rows a list of columns sorted by edge type;
+// column (t, r) holds the source of every row's r-th in-edge of type t (CSR = original order) or -1.
+// The last column of a tile is the root column (type T): 1/max(deg,1) as float bits, -1 for rows >= n.
+// col_meta = type | first-of-type << 8 | last-of-type << 9 | end-of-tile << 10.
+// One block = 64 rows = 4 tiles, one thread per row.
 // ------------------------------------------------------------------------------------------
-constexpr int kTileRows = 64;
-constexpr int kMaxTileTypes = 64;
+constexpr int kColTileRows = 16;
+constexpr int kMaxColTypes = 40;
 
-// chunks of tile b = sum_t ceil(cnt_t / 16) + 4
-__global__ __launch_bounds__(64) void nnconv_tile_count_kernel(const int *__restrict__ rowptr,
-                                                               const int *__restrict__ col_type, int64_t n,
-                                                               int n_types, int *__restrict__ tile_chunks) {
-    __shared__ int cnt[kMaxTileTypes];
-    const int lane = threadIdx.x;
-    const int64_t b = blockIdx.x, r0 = b * kTileRows, r1 = (r0 + kTileRows < n) ? r0 + kTileRows : n;
-    cnt[lane] = 0;
+template <bool FILL>
+__global__ __launch_bounds__(64) void nnconv_col_kernel(const int *__restrict__ rowptr, const int *__restrict__ col_src,
+                                                        const int *__restrict__ col_type, int64_t n, int n_types,
+                                                        int *__restrict__ tile_cols,            // !FILL: out, columns per tile
+                                                        const int *__restrict__ tile_col_ptr,   // FILL
+                                                        int *__restrict__ col_meta, int *__restrict__ col_slot_src) {
+    __shared__ int cnt[64][kMaxColTypes + 1];    // +1: odd stride, the per-row walks hit distinct banks
+    __shared__ int maxm[4][kMaxColTypes];
+    __shared__ int base[4][kMaxColTypes + 1];
+    const int tid = threadIdx.x, k = tid >> 4, i = tid & 15;
+    const int64_t row = (int64_t)blockIdx.x * 64 + tid;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + k;
+    const int64_t n_tiles = (n + kColTileRows - 1) / kColTileRows;
+    for (int t = 0; t < n_types; ++t) cnt[tid][t] = 0;
+    int e0 = 0, e1 = 0;
+    if (row < n) { e0 = rowptr[row]; e1 = rowptr[row + 1]; }
+    for (int e = e0; e < e1; ++e) cnt[tid][col_type[e]]++;
     __syncthreads();
-    const int e0 = rowptr[r0], e1 = rowptr[r1];
-    for (int e = e0 + lane; e < e1; e += 64) atomicAdd(&cnt[col_type[e]], 1);
-    __syncthreads();
-    int c = lane < n_types ? (cnt[lane] + 15) >> 4 : 0;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
-    if (lane == 0) tile_chunks[b] = c + kTileRows / 16;
-}
-
-// chunk_meta: 8 int32 per chunk = {type, 0, 0, 0, rows[0..3]}: rows[q] packs the destination rows (tile-local,
-// 64 = padding) of slots 4q..4q+3, one byte each.  32 bytes, wave-uniform -> fetched with scalar loads.
-__global__ __launch_bounds__(64) void nnconv_tile_fill_kernel(
-    const int *__restrict__ rowptr, const int *__restrict__ col_src, const int *__restrict__ col_type, int64_t n,
-    int n_types, const int *__restrict__ tile_chunk_ptr, int *__restrict__ chunk_meta, int *__restrict__ slot_src) {
-    __shared__ int cnt[kMaxTileTypes];
-    __shared__ int base[kMaxTileTypes + 1];   // first slot (tile-relative) of every type group; [T] = root group
-    __shared__ int run[kMaxTileTypes];
-    __shared__ int rp[kTileRows + 1];
-    const int lane = threadIdx.x;
-    const int64_t b = blockIdx.x, r0 = b * kTileRows, r1 = (r0 + kTileRows < n) ? r0 + kTileRows : n;
-    const int rows = (int)(r1 - r0);
-    cnt[lane] = 0;
-    run[lane] = 0;
-    if (lane <= rows) rp[lane] = rowptr[r0 + lane];
-    if (lane == 0 && rows == kTileRows) rp[kTileRows] = rowptr[r1];
-    __syncthreads();
-    const int e0 = rp[0], e1 = rp[rows];
-    for (int e = e0 + lane; e < e1; e += 64) atomicAdd(&cnt[col_type[e]], 1);
-    __syncthreads();
-    {   // exclusive scan of the padded group sizes over the type axis (lane = type)
-        const int padded = lane < n_types ? ((cnt[lane] + 15) >> 4) << 4 : 0;
-        int incl = padded;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += t;
-        }
-        base[lane] = incl - padded;
-        if (lane == 63) base[64] = incl;
+    for (int t = i; t < n_types; t += 16) {
+        int m = 0;
+        for (int r = 0; r < 16; ++r) m = max(m, cnt[k * 16 + r][t]);
+        maxm[k][t] = m;
     }
     __syncthreads();
-    const int root_base = base[n_types < 64 ? n_types : 64];   // == total padded edge slots (groups beyond T are empty)
-    const int64_t chunk0 = tile_chunk_ptr[b];
-    const int64_t slot0 = chunk0 * 16;
-    const int n_slots = root_base + kTileRows;
-    unsigned char *rows_b = reinterpret_cast<unsigned char *>(chunk_meta);   // byte view: row of slot s of chunk c at c*32+16+s
-    // chunk types + padding defaults
-    for (int k = lane; k < n_slots / 16; k += 64) {
-        int t = n_types;                                       // root
-        if (k * 16 < root_base) {
-            t = 0;
-            while (t + 1 < n_types && base[t + 1] <= k * 16) ++t;
-        }
-        int *m = chunk_meta + (chunk0 + k) * 8;
-        m[0] = t; m[1] = 0; m[2] = 0; m[3] = 0;
+    if (i == 0) {
+        int acc = 0;
+        for (int t = 0; t < n_types; ++t) { base[k][t] = acc; acc += maxm[k][t]; }
+        base[k][n_types] = acc;
+        if (!FILL && tile < n_tiles) tile_cols[tile] = acc + 1;
     }
-    for (int i = lane; i < root_base; i += 64) {
-        slot_src[slot0 + i] = -1;
-        rows_b[(chunk0 + (i >> 4)) * 32 + 16 + (i & 15)] = (unsigned char)kTileRows;   // scratch row: never read back
-    }
-    // root group: the rows themselves (chunk k of the group covers tile rows 16k .. 16k+15)
-    {
-        const bool ok = lane < rows;
-        const int i = root_base + lane;
-        slot_src[slot0 + i] = ok ? (int)(r0 + lane) : -1;
-        rows_b[(chunk0 + (i >> 4)) * 32 + 16 + (i & 15)] = (unsigned char)lane;
-    }
+    if (!FILL) return;
     __syncthreads();
-    // stable placement: edges in CSR (= original) order inside every type group
-    for (int eb = e0; eb < e1; eb += 64) {
-        const int e = eb + lane;
-        const bool ok = e < e1;
-        const int t = ok ? col_type[e] : -1;
-        int row = 0;
-        if (ok) {   // destination row of CSR slot e: last r with rp[r] <= e
-            int lo = 0, hi = rows;
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (rp[mid] <= e) lo = mid; else hi = mid;
-            }
-            row = lo;
-        }
-        for (int tt = 0; tt < n_types; ++tt) {
-            const unsigned long long m = __ballot(t == tt);
-            if (m == 0ull) continue;                           // wave-uniform
-            if (t == tt) {
-                const int rank = __popcll(m & ((1ull << lane) - 1ull));
-                const int i = base[tt] + run[tt] + rank;
-                slot_src[slot0 + i] = col_src[e];
-                rows_b[(chunk0 + (i >> 4)) * 32 + 16 + (i & 15)] = (unsigned char)row;
-            }
-            __syncthreads();
-            if (lane == 0) run[tt] += __popcll(m);
-            __syncthreads();
-        }
+    if (tile >= n_tiles) return;                 // whole 16-thread group: no barrier below
+    const int64_t c0 = tile_col_ptr[tile];
+    const int n_edge_cols = base[k][n_types];
+    for (int c = 0; c < n_edge_cols; ++c) col_slot_src[(c0 + c) * 16 + i] = -1;
+    for (int t = i; t < n_types; t += 16) {
+        const int m = maxm[k][t];
+        for (int r = 0; r < m; ++r)
+            col_meta[c0 + base[k][t] + r] = t | (r == 0 ? 1 << 8 : 0) | (r == m - 1 ? 1 << 9 : 0);
+    }
+    // root column
+    const int deg = e1 - e0;
+    col_slot_src[(c0 + n_edge_cols) * 16 + i] = row < n ? __float_as_int(1.0f / (float)(deg > 0 ? deg : 1)) : -1;
+    if (i == 0) col_meta[c0 + n_edge_cols] = n_types | (1 << 8) | (1 << 9) | (1 << 10);
+    // the 16 threads of a tile are lanes of one wavefront: their -1 stores above are ordered before these
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int t = 0; t < n_types; ++t) cnt[tid][t] = 0;
+    for (int e = e0; e < e1; ++e) {
+        const int t = col_type[e];
+        const int r = cnt[tid][t]++;
+        col_slot_src[(c0 + base[k][t] + r) * 16 + i] = col_src[e];
     }
 }
 
@@ -517,38 +468,40 @@ extern "C" int tgnn_gather_i32(const int32_t *src, int64_t n_src, const int32_t 
     return TGNN_OK;
 }
 
-extern "C" int64_t tgnn_nnconv_tiles_max_chunks(int64_t n_nodes, int64_t n_edges, int32_t n_types) {
-    const int64_t ntiles = (n_nodes + kTileRows - 1) / kTileRows;
-    return n_edges / 16 + ntiles * ((int64_t)n_types + kTileRows / 16) + 16;   // + slack: the kernel reads whole 8-chunk units
+extern "C" int64_t tgnn_nnconv_cols_max_columns(int64_t n_nodes, int64_t n_edges) {
+    // every edge column holds at least one edge; one root column per tile; slack: the kernel fetches index words in
+    // groups of 4 columns and up to 3 groups ahead
+    return n_edges + (n_nodes + kColTileRows - 1) / kColTileRows + 32;
 }
 
-extern "C" size_t tgnn_nnconv_tiles_workspace_bytes(int64_t n_nodes) {
-    const int64_t ntiles = (n_nodes + kTileRows - 1) / kTileRows;
+extern "C" size_t tgnn_nnconv_cols_workspace_bytes(int64_t n_nodes) {
+    const int64_t ntiles = (n_nodes + kColTileRows - 1) / kColTileRows;
     return align_up((size_t)(ntiles + 1) * 4, 256) + scan_ws_ints(ntiles + 1) * 4 + 1024;
 }
 
-extern "C" int tgnn_nnconv_tiles_build(const int32_t *rowptr, const int32_t *col_src, const int32_t *col_type,
-                                       int64_t n_nodes, int32_t n_types, int32_t *tile_chunk_ptr,
-                                       int32_t *chunk_meta, int32_t *slot_src, void *ws, size_t ws_bytes,
-                                       tgnn_stream_t stream) {
+extern "C" int tgnn_nnconv_cols_build(const int32_t *rowptr, const int32_t *col_src, const int32_t *col_type,
+                                      int64_t n_nodes, int32_t n_types, int32_t *tile_col_ptr, int32_t *col_meta,
+                                      int32_t *col_slot_src, void *ws, size_t ws_bytes, tgnn_stream_t stream) {
     TGNN_CHECK_ARG(n_nodes >= 1, "n_nodes");
-    TGNN_CHECK_ARG(n_types >= 0 && n_types <= kMaxTileTypes - 1, "tiled NNConv supports at most 63 edge types");
-    TGNN_CHECK_ARG(rowptr && tile_chunk_ptr && chunk_meta && slot_src, "null pointer");
-    TGNN_CHECK_ARG((uintptr_t)chunk_meta % 32 == 0, "chunk_meta must be 32-byte aligned");
-    if (!ws || ws_bytes < tgnn_nnconv_tiles_workspace_bytes(n_nodes)) {
-        set_error("tgnn_nnconv_tiles_build: workspace too small");
+    TGNN_CHECK_ARG(n_types >= 0 && n_types <= kMaxColTypes, "the column NNConv structure supports at most 40 edge types");
+    TGNN_CHECK_ARG(rowptr && tile_col_ptr && col_meta && col_slot_src, "null pointer");
+    TGNN_CHECK_ARG(n_types == 0 || (col_src && col_type), "null CSR pointer");
+    if (!ws || ws_bytes < tgnn_nnconv_cols_workspace_bytes(n_nodes)) {
+        set_error("tgnn_nnconv_cols_build: workspace too small");
         return TGNN_ERR_WORKSPACE;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int64_t ntiles = (n_nodes + kTileRows - 1) / kTileRows;
+    const int64_t nt16 = (n_nodes + kColTileRows - 1) / kColTileRows;
     Carver cv(ws, ws_bytes);
-    int *tile_chunks = cv.take<int>(ntiles + 1);
-    int *scan_ws = cv.take<int>(scan_ws_ints(ntiles + 1));
-    TGNN_CHECK_HIP(hipMemsetAsync(tile_chunks + ntiles, 0, 4, s));
-    nnconv_tile_count_kernel<<<(unsigned)ntiles, 64, 0, s>>>(rowptr, col_type, n_nodes, n_types, tile_chunks);
-    exclusive_scan_i32(tile_chunks, tile_chunk_ptr, ntiles + 1, scan_ws, s);
-    nnconv_tile_fill_kernel<<<(unsigned)ntiles, 64, 0, s>>>(rowptr, col_src, col_type, n_nodes, n_types, tile_chunk_ptr,
-                                                           chunk_meta, slot_src);
+    int *tile_cols = cv.take<int>(nt16 + 1);
+    int *scan_ws = cv.take<int>(scan_ws_ints(nt16 + 1));
+    TGNN_CHECK_HIP(hipMemsetAsync(tile_cols + nt16, 0, 4, s));
+    const unsigned blocks = (unsigned)((n_nodes + 63) / 64);
+    nnconv_col_kernel<false><<<blocks, 64, 0, s>>>(rowptr, col_src, col_type, n_nodes, n_types, tile_cols, nullptr,
+                                                   nullptr, nullptr);
+    exclusive_scan_i32(tile_cols, tile_col_ptr, nt16 + 1, scan_ws, s);
+    nnconv_col_kernel<true><<<blocks, 64, 0, s>>>(rowptr, col_src, col_type, n_nodes, n_types, nullptr, tile_col_ptr,
+                                                  col_meta, col_slot_src);
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
 }

@@ -278,31 +278,9 @@ __global__ __launch_bounds__(kNNThreads) void nnconv32_lds_kernel(
 #undef TGNN_FMA4
 
 // ------------------------------------------------------------------------------------------
-// NNConv mean on matrix cores (C = 32, T + 1 <= 20): the production kernel.
-//
-// A tile = 64 destination rows.  Its in-edges arrive grouped by edge type in 16-slot chunks
-// (tgnn_nnconv_tiles_build): one chunk = 16 gathered source rows x one [32,32] type matrix
-//     M[16 x 32] = X[src(16) x 32] . W_t            = 2 column tiles x 8 x v_mfma_f32_16x16x4_f32
-// (exact fp32).  The block's 8 waves split the tile's chunks into contiguous ranges (type changes
-// ~3x per wave), keep the next two chunks' gathers in flight (8 VGPRs per chunk), and scatter-add
-// each M row into a WAVE-PRIVATE [64 x 32] LDS accumulator with ds_add_f32 -- wave-private means the
-// order of the adds is program order, so results are bit-reproducible.  The root term h[v].root
-// rides along as 4 extra chunks of pseudo-type T whose rows are pre-multiplied by max(deg,1), so one
-// common 1/deg scale applies at the end.  After a barrier 512 threads fold the 8 accumulators in
-// fixed order: (sum)/deg + bias -> LeakyReLU -> store, fp64 BN column sums on the side.
-//
-// LDS: (T+1) x 4.5 KB weight image (B-operand order, padded) + 8 x 8 KB accumulators = 128 KB @T=13.
+// Weight image of the matrix-core kernel (nnconv_cols.hip), built once per forward for all layers.
 // ------------------------------------------------------------------------------------------
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-constexpr int kMfThreads = 512, kMfWaves = 8;
-constexpr int kWtNt = 16 * 36;             // floats per (type, column tile): [j=16][q=4][ks=8], row stride 36
-constexpr int kWtType = 2 * kWtNt;         // floats per type
-constexpr int kAccFloats = 65 * 32;        // per-wave accumulator: 64 tile rows + 1 scratch row
-constexpr int kHalf = 4;                   // chunks per gather stage
-constexpr int kCap = 2 * kHalf;            // chunks per pipeline unit (indices of one unit live in registers)
-
-// wtab [T][32][32] (+ root [32][32] as pseudo-type T) -> B-operand image [(T+1)][2][16][36]:
+// wtab [T][32][32] (+ root [32][32] as pseudo-type T) -> MFMA operand image [(T+1)][2][16][36]:
 // element (i, o) of type t -> wimg[t][o >> 4][o & 15][(i >> 3) * 8 + (i & 7)]  (row padded 32 -> 36 floats).
 // grid = (T+1, layers); done once per layer so that every NNConv block fills its LDS with a straight
 // coalesced float4 copy instead of a 28-trip scatter.
@@ -320,306 +298,6 @@ __global__ __launch_bounds__(256) void nnconv_weight_image_kernel(const float *_
     }
     for (int k = threadIdx.x; k < 2 * 16 * 4; k += 256)      // zero the 4 padding floats of every row
         dst[(k >> 6) * kWtNt + ((k >> 2) & 15) * 36 + 32 + (k & 3)] = 0.f;
-}
-
-#ifdef TGNN_TIMING
-__device__ unsigned long long g_nn_timing[256 * 8 * 8];
-#define TGNN_T(slot) { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[slot] += now_ - tlast; tlast = now_; }
-#else
-#define TGNN_T(slot)
-#endif
-
-struct UnitIdx {                           // per-lane view of one pipeline unit (<= kCap chunks of one tile)
-    int type[kCap];                        // edge type of the chunk (wave-uniform; T = root chunk)
-    int src[kCap];                         // source row of slot (lane & 15); -1 = padding / no chunk
-    int rows4[kCap];                       // destination rows of slots 4q..4q+3 (q = lane >> 4), one byte each
-};
-
-// Vector-memory instructions are a scarce resource of this kernel: on gfx950 every wave-level load costs the
-// CU's texture-address / L1 path ~40 cycles (dword) to ~70 cycles (the 16-rows x 4 x 16-B gather) no matter
-// how few bytes it moves (scratch/ubench/vmem.hip), i.e. ~16 B/clk/CU.  The two gather instructions of a
-// chunk (2 KB) are compulsory; the per-chunk index data is kept to three dword loads (type, 4 row bytes, src).
-__global__ __launch_bounds__(kMfThreads) void nnconv32_mfma_kernel(
-    const float *__restrict__ h, int64_t ldh, const int *__restrict__ rowptr, const int *__restrict__ tile_chunk_ptr,
-    const int *__restrict__ chunk_meta, const int *__restrict__ slot_src, const float *__restrict__ wimg, int n_types,
-    const float *__restrict__ bias, int64_t n, int act, float *__restrict__ out, double *__restrict__ bn_partial) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *wl = lds;                                        // [(T+1)][2][16][36]
-    float *accs = lds + (n_types + 1) * kWtType;            // [8 waves + 1 root][65][32]
-    float *root_acc = accs + kMfWaves * kAccFloats;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fj = lane & 15, fq = lane >> 4;
-
-    {   // weight image: straight copy, all loads of a thread issued before the first LDS store
-        const int n4 = (n_types + 1) * kWtType / 4;
-        for (int i = tid; i < n4; i += 4 * kMfThreads) {
-            float4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int ii = i + u * kMfThreads < n4 ? i + u * kMfThreads : n4 - 1;
-                v[u] = reinterpret_cast<const float4 *>(wimg)[ii];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (i + u * kMfThreads < n4) reinterpret_cast<float4 *>(wl)[i + u * kMfThreads] = v[u];
-        }
-    }
-    float *acc_w = accs + wave * kAccFloats;
-    for (int i = tid; i < (kMfWaves + 1) * kAccFloats / 4; i += kMfThreads)
-        reinterpret_cast<float4 *>(accs)[i] = make_float4(0, 0, 0, 0);
-    __syncthreads();
-
-    const int64_t n_tiles = (n + 63) / 64;
-    // final-phase mapping: thread -> (row fr, columns 4*fc .. 4*fc+3)
-    const int fr = tid >> 3, fc = tid & 7;
-    const float4 bias4 = reinterpret_cast<const float4 *>(bias)[fc];
-    double cs[4] = {0, 0, 0, 0}, cq[4] = {0, 0, 0, 0};
-
-    // XCD-contiguous tile ranges (block b runs on XCD b % 8; speed only)
-    const int nblk = gridDim.x;
-    int64_t t_beg = blockIdx.x, t_end = n_tiles, t_step = nblk;
-    if (nblk >= 8 && (nblk & 7) == 0) {
-        const int xcd = blockIdx.x & 7;
-        t_beg = n_tiles * xcd / 8 + (blockIdx.x >> 3);
-        t_end = n_tiles * (xcd + 1) / 8;
-        t_step = nblk >> 3;
-    }
-
-    // ---- helpers (all loads unconditional + selects: a predicated load becomes a branch, and hipcc drains
-    //      vmcnt(0) at the join, which would serialise the pipeline)
-    auto tile_range = [&](int64_t tile, int &c_lo, int &c_hi) {       // chunk range of a tile, empty past the end
-        const int64_t tt = tile < t_end ? tile : 0;
-        const int lo = tile_chunk_ptr[tt], hi = tile_chunk_ptr[tt + 1];
-        c_lo = lo;
-        c_hi = tile < t_end ? hi : lo;
-    };
-    auto wave_share = [&](int c_lo, int c_hi, int &c0, int &cnt) {    // contiguous share of this wave
-        const int n_ch = c_hi - c_lo;
-        c0 = c_lo + n_ch * wave / kMfWaves;
-        cnt = c_lo + n_ch * (wave + 1) / kMfWaves - c0;
-    };
-    auto load_unit = [&](int c0, int cnt, UnitIdx &ui) {
-        // NB: fetching the wave-uniform record through the scalar cache (s_load_dwordx8) was tried and is
-        // SLOWER (76.7 vs 69.5 us): SMEM shares lgkmcnt with the LDS traffic of the scatter and returns out
-        // of order, so every use forces lgkmcnt(0).  Three dword vector loads per chunk it is.
-#pragma unroll
-        for (int u = 0; u < kCap; ++u) {
-            const bool ok = u < cnt;
-            const int cc = ok ? c0 + u : 0;
-            const int ty = chunk_meta[cc * 8], r4 = chunk_meta[cc * 8 + 4 + fq], sr = slot_src[cc * 16 + fj];
-            ui.type[u] = ty;
-            ui.src[u] = ok ? sr : -1;
-            ui.rows4[u] = r4;
-        }
-    };
-    auto gather = [&](int src, float4 (&x)[2]) {          // 8 k-values (32 B) of one source row
-        const int sidx = src >= 0 ? src : 0;
-        const float4 *px = reinterpret_cast<const float4 *>(h + (int64_t)sidx * ldh + fq * 8);
-        x[0] = px[0];
-        x[1] = px[1];
-    };
-
-    int cur_type = -1;
-    float bw0[8], bw1[8];
-    // ---- scatter of one chunk's D tiles into an accumulator that only this wave writes.
-    // D row (4q + r) belongs to destination row byte r of rows4; col = fj (+16).  LDS float atomics run
-    // ~2 cycles PER LANE on gfx950 (ds_add_f32: 148 cycles / instruction measured), so equal-row slots --
-    // adjacent, the group is in CSR order -- are first summed in registers (segmented scan: in-lane over r,
-    // then a 3-step carry across the four 16-lane groups); the last slot of every run then owns its
-    // accumulator row: plain read-add-write.
-    auto scatter = [&](float *accb, const f32x4 &d0, const f32x4 &d1, int rows4) {
-        const int r0 = rows4 & 0xff, r1 = (rows4 >> 8) & 0xff, r2 = (rows4 >> 16) & 0xff, r3 = (rows4 >> 24) & 0xff;
-        const bool e1 = r1 == r0, e2 = r2 == r1, e3 = r3 == r2;
-        float s0[4], s1[4];
-        s0[0] = d0[0]; s1[0] = d1[0];
-        s0[1] = e1 ? s0[0] + d0[1] : d0[1]; s1[1] = e1 ? s1[0] + d1[1] : d1[1];
-        s0[2] = e2 ? s0[1] + d0[2] : d0[2]; s1[2] = e2 ? s1[1] + d1[2] : d1[2];
-        s0[3] = e3 ? s0[2] + d0[3] : d0[3]; s1[3] = e3 ? s1[2] + d1[3] : d1[3];
-        const bool lead[4] = {true, e1, e1 && e2, e1 && e2 && e3};     // slots still in the lane's first run
-        const int prev_r3 = __shfl_up(r3, 16, 64), next_r0 = __shfl_down(r0, 16, 64);
-        const bool joins_prev = fq > 0 && prev_r3 == r0;
-        if (__any(joins_prev)) {                          // wave-uniform: some run crosses a 16-lane group
-#pragma unroll
-            for (int step = 1; step <= 3; ++step) {
-                const float t0 = __shfl_up(s0[3], 16, 64), t1 = __shfl_up(s1[3], 16, 64);
-                if (fq == step && joins_prev) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (lead[r]) { s0[r] += t0; s1[r] += t1; }
-                }
-            }
-        }
-        const bool last[4] = {!e1, !e2, !e3, fq == 3 || next_r0 != r3};
-        const int rr[4] = {r0, r1, r2, r3};
-        float *dst[4];
-        float o0[4], o1[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {                    // non-final slots are parked on the scratch row 64
-            dst[r] = accb + (last[r] ? rr[r] : 64) * 32 + fj;
-            o0[r] = dst[r][0];
-            o1[r] = dst[r][16];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            dst[r][0] = o0[r] + s0[r];
-            dst[r][16] = o1[r] + s1[r];
-        }
-    };
-    // The scatter of chunk k is issued AFTER the MFMAs of chunk k+1 (its D tiles wait in 8 VGPRs), so that its
-    // shuffle / LDS round trips run in the shadow of the matrix pipe instead of between two MFMA bursts.
-    f32x4 pend0 = {0.f, 0.f, 0.f, 0.f}, pend1 = {0.f, 0.f, 0.f, 0.f};
-    int pend_rows = 0;
-    float *pend_acc = acc_w;
-    bool pending = false;
-    auto flush = [&]() {
-        if (pending) scatter(pend_acc, pend0, pend1, pend_rows);
-        pending = false;
-    };
-    auto compute = [&](int type_v, int src, int rows4, const float4 (&x)[2]) {
-        // B fragments only when the type changes (chunks are type-sorted).  The type came with the prefetched
-        // indices: a load issued here would queue behind the prefetches (vmcnt is in-order).
-        const int t = __builtin_amdgcn_readfirstlane(type_v);
-        if (t != cur_type) {                             // wave-uniform
-            cur_type = t;
-            const float *wp = wl + t * kWtType + fj * 36 + fq * 8;
-            const float4 p0 = *reinterpret_cast<const float4 *>(wp), p1 = *reinterpret_cast<const float4 *>(wp + 4);
-            const float4 p2 = *reinterpret_cast<const float4 *>(wp + kWtNt), p3 = *reinterpret_cast<const float4 *>(wp + kWtNt + 4);
-            bw0[0] = p0.x; bw0[1] = p0.y; bw0[2] = p0.z; bw0[3] = p0.w; bw0[4] = p1.x; bw0[5] = p1.y; bw0[6] = p1.z; bw0[7] = p1.w;
-            bw1[0] = p2.x; bw1[1] = p2.y; bw1[2] = p2.z; bw1[3] = p2.w; bw1[4] = p3.x; bw1[5] = p3.y; bw1[6] = p3.z; bw1[7] = p3.w;
-        }
-        const bool valid = src >= 0;                     // padding slots multiply zeros
-        const float xv[8] = {x[0].x, x[0].y, x[0].z, x[0].w, x[1].x, x[1].y, x[1].z, x[1].w};
-        float a8[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) a8[k] = valid ? xv[k] : 0.f;
-        f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a8[k], bw0[k], d0, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a8[k], bw1[k], d1, 0, 0, 0);
-        }
-        if (pending) scatter(pend_acc, pend0, pend1, pend_rows);   // previous chunk, in this chunk's MFMA shadow
-        // root chunks (type T) carry h[v] . root, which is NOT divided by the in-degree: they go to their own
-        // accumulator (each root chunk owns 16 distinct rows, so the waves holding them never collide)
-        pend0 = d0; pend1 = d1; pend_rows = rows4; pend_acc = t == n_types ? root_acc : acc_w; pending = true;
-    };
-
-    // ---- pipeline over UNITS (<= 8 chunks of one tile; a tile is 1+ units per wave):
-    //   unit u+1's indices load while unit u computes; its first-half gathers are issued before unit u's second
-    //   half runs, its second-half gathers before its own first half.  Tile ranges are fetched one tile ahead.
-    //   Every dependent-load level (range -> indices -> gathers) therefore has >= 4 chunks of MFMAs to land,
-    //   also ACROSS the tile boundary (barrier + fold), where a per-tile pipeline would restart cold.
-    int64_t tile = t_beg;
-    int lo, hi, c0, rem;                                 // current tile: range, next chunk of this wave, chunks left
-    tile_range(tile, lo, hi);
-    wave_share(lo, hi, c0, rem);
-    int nlo, nhi;                                        // range of the next tile (prefetched)
-    tile_range(tile + t_step, nlo, nhi);
-    UnitIdx ua;
-    load_unit(c0, rem, ua);
-    float4 xa[kHalf][2], xb[kHalf][2];
-#pragma unroll
-    for (int u = 0; u < kHalf; ++u) gather(ua.src[u], xa[u]);
-
-#ifdef TGNN_TIMING
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
-#endif
-    while (tile < t_end) {
-        const bool last_unit = rem <= kCap;
-        TGNN_T(7)
-        // ---- next unit
-        // (no load may sit inside a branch: hipcc drains vmcnt(0) at the join -- everything here is
-        //  loaded unconditionally and selected)
-        const int64_t vtile = last_unit ? tile + t_step : tile;
-        int sc0, srem;
-        wave_share(nlo, nhi, sc0, srem);
-        const int vc0 = last_unit ? sc0 : c0 + kCap, vrem = last_unit ? srem : rem - kCap;
-        int qlo, qhi;
-        tile_range(tile + 2 * t_step, qlo, qhi);         // range after the next tile (used once we cross over)
-        const int plo = last_unit ? qlo : nlo, phi = last_unit ? qhi : nhi;
-        // in-degree of this thread's fold row, fetched a whole unit before the fold needs it
-        const int64_t frow = tile * 64 + fr;
-        const int64_t frc = frow < n ? frow : n - 1;
-        const int fdeg = rowptr[frc + 1] - rowptr[frc];
-        UnitIdx ub;
-        load_unit(vc0, vrem, ub);
-#pragma unroll
-        for (int u = 0; u < kHalf; ++u) gather(ua.src[kHalf + u], xb[u]);
-        TGNN_T(0)
-#pragma unroll
-        for (int u = 0; u < kHalf; ++u)
-            if (u < rem) compute(ua.type[u], ua.src[u], ua.rows4[u], xa[u]);
-        TGNN_T(1)
-#pragma unroll
-        for (int u = 0; u < kHalf; ++u) gather(ub.src[u], xa[u]);
-#pragma unroll
-        for (int u = 0; u < kHalf; ++u)
-            if (kHalf + u < rem) compute(ua.type[kHalf + u], ua.src[kHalf + u], ua.rows4[kHalf + u], xb[u]);
-        TGNN_T(2)
-
-#ifdef TGNN_ABLATE_MF_NOFOLD
-        if (last_unit && tile + t_step >= t_end) {
-#else
-        if (last_unit) {
-#endif
-            flush();
-            TGNN_T(3)
-            __syncthreads();
-            TGNN_T(4)
-            // ---- fold the 8 accumulators (fixed order), finish the row, re-zero for the next tile
-            const int64_t v = tile * 64 + fr;
-            float4 sum = make_float4(0, 0, 0, 0);
-#pragma unroll
-            for (int w = 0; w < kMfWaves; ++w) {
-                float4 *pa = reinterpret_cast<float4 *>(accs + w * kAccFloats + fr * 32 + fc * 4);
-                const float4 a4 = *pa;
-                sum.x += a4.x; sum.y += a4.y; sum.z += a4.z; sum.w += a4.w;
-                *pa = make_float4(0, 0, 0, 0);
-            }
-            float4 *pr = reinterpret_cast<float4 *>(root_acc + fr * 32 + fc * 4);
-            const float4 rt = *pr;
-            *pr = make_float4(0, 0, 0, 0);
-            if (v < n) {
-                const float inv = 1.0f / (float)(fdeg > 0 ? fdeg : 1);
-                float4 o;
-                o.x = fmaf(sum.x, inv, rt.x) + bias4.x; o.y = fmaf(sum.y, inv, rt.y) + bias4.y;
-                o.z = fmaf(sum.z, inv, rt.z) + bias4.z; o.w = fmaf(sum.w, inv, rt.w) + bias4.w;
-                if (act == TGNN_ACT_LEAKY_RELU) { o.x = leakyf_(o.x); o.y = leakyf_(o.y); o.z = leakyf_(o.z); o.w = leakyf_(o.w); }
-                *reinterpret_cast<float4 *>(out + v * 32 + fc * 4) = o;
-                cs[0] += (double)o.x; cq[0] += (double)o.x * (double)o.x;
-                cs[1] += (double)o.y; cq[1] += (double)o.y * (double)o.y;
-                cs[2] += (double)o.z; cq[2] += (double)o.z * (double)o.z;
-                cs[3] += (double)o.w; cq[3] += (double)o.w * (double)o.w;
-            }
-            TGNN_T(5)
-            __syncthreads();
-            TGNN_T(6)
-        }
-        // ---- rotate
-        tile = vtile; c0 = vc0; rem = vrem; nlo = plo; nhi = phi;
-        ua = ub;
-    }
-
-#ifdef TGNN_TIMING
-    if (lane == 0)
-        for (int k = 0; k < 8; ++k) g_nn_timing[(blockIdx.x * 8 + wave) * 8 + k] = tacc[k];
-#endif
-    if (bn_partial) {
-        // 64 row-threads per column group: fold in fixed order through LDS ([64][64] doubles = 32 KB, aliases accs)
-        __syncthreads();
-        double *red = reinterpret_cast<double *>(accs);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            red[fr * 64 + fc * 4 + k] = cs[k];
-            red[fr * 64 + 32 + fc * 4 + k] = cq[k];
-        }
-        __syncthreads();
-        if (tid < 64) {
-            double tot = 0.0;
-            for (int r = 0; r < 64; ++r) tot += red[r * 64 + tid];
-            bn_partial[(int64_t)blockIdx.x * 64 + tid] = tot;   // [2][32]: sums then sums of squares
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -758,65 +436,6 @@ void launch_nnconv_weight_image(const float *wtab_all, const float *const *roots
     for (int i = 0; i < depth; ++i) rp.p[i] = roots[i];
     nnconv_weight_image_kernel<<<dim3(n_types + 1, depth), 256, 0, s>>>(wtab_all, rp, n_types, wimg_all);
 }
-
-static size_t tiled_lds_bytes(int n_types) {
-    return ((size_t)(n_types + 1) * kWtType + (size_t)(kMfWaves + 1) * kAccFloats) * sizeof(float);
-}
-
-int launch_nnconv_tiled(const float *h, int64_t ldh, const int32_t *rowptr, const int32_t *tile_chunk_ptr,
-                        const int32_t *chunk_meta, const int32_t *slot_src, const float *wimg, int32_t n_types,
-                        const float *bias, int64_t n_nodes, int32_t act, float *out, double *bn_partial,
-                        int32_t *n_partials_host, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        TGNN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nnconv32_mfma_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
-        attr_set = true;
-    }
-    int blocks = producer_blocks(n_nodes, 64);
-    if (blocks > 256) blocks = 256;            // one block per CU (LDS), persistent over tiles
-    if (blocks >= 8) blocks &= ~7;
-    nnconv32_mfma_kernel<<<blocks, kMfThreads, tiled_lds_bytes(n_types), s>>>(
-        h, ldh, rowptr, tile_chunk_ptr, chunk_meta, slot_src, wimg, n_types, bias, n_nodes, act, out, bn_partial);
-    if (n_partials_host) *n_partials_host = blocks;
-    TGNN_CHECK_LAUNCH();
-    return TGNN_OK;
-}
-
 }  // namespace tgnn
-using namespace tgnn;
-
-#ifdef TGNN_TIMING
-extern "C" int tgnn_debug_nn_timing(unsigned long long *host_out) {
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_nn_timing), sizeof(unsigned long long) * 256 * 8 * 8);
-}
-#endif
 
 extern "C" size_t tgnn_nnconv_weight_image_floats(int32_t n_types) { return (size_t)(n_types + 1) * kWtType; }
-
-extern "C" int tgnn_nnconv_mean_tiled_fwd(const float *h, int64_t ldh, const int32_t *rowptr,
-                                          const int32_t *tile_chunk_ptr, const int32_t *chunk_meta,
-                                          const int32_t *slot_src, const float *wtab, int32_t n_types, const float *root, const float *bias,
-                                          int64_t n_nodes, int32_t c, int32_t act, float *out, float *wimg_scratch,
-                                          double *bn_partial, int32_t *n_partials_host, tgnn_stream_t stream) {
-    TGNN_CHECK_ARG(n_nodes >= 1 && c == 32, "tiled NNConv is built for network_width 32");
-    TGNN_CHECK_ARG(act == TGNN_ACT_NONE || act == TGNN_ACT_LEAKY_RELU, "activation");
-    TGNN_CHECK_ARG(h && rowptr && tile_chunk_ptr && chunk_meta && slot_src && root && bias && out && wimg_scratch,
-                   "null pointer");
-    TGNN_CHECK_ARG(n_types == 0 || wtab, "null weight table");
-    TGNN_CHECK_ARG(ldh >= 32 && ldh % 4 == 0 && ((uintptr_t)h % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
-                       ((uintptr_t)bias % 16) == 0 && ((uintptr_t)wimg_scratch % 16) == 0, "alignment");
-    if (tiled_lds_bytes(n_types) > kMaxDynLds) {
-        set_error("tgnn_nnconv_mean_tiled_fwd: %d edge types do not fit the LDS weight image (max %d)", n_types,
-                  tgnn_nnconv_tiled_max_types());
-        return TGNN_ERR_UNSUPPORTED;
-    }
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    launch_nnconv_weight_image(wtab, &root, n_types, 1, wimg_scratch, s);
-    return launch_nnconv_tiled(h, ldh, rowptr, tile_chunk_ptr, chunk_meta, slot_src, wimg_scratch, n_types, bias,
-                               n_nodes, act, out, bn_partial, n_partials_host, s);
-}
-
-extern "C" int32_t tgnn_nnconv_tiled_max_types(void) {
-    return (int32_t)((kMaxDynLds / sizeof(float) - (kMfWaves + 1) * kAccFloats) / kWtType) - 1;
-}

@@ -1,0 +1,347 @@
+// NNConv(aggr="mean"), network_width 32, "type column" formulation for the MFMA pipe of gfx950.
+//
+// Reference semantics: GraphConv.forward (/root/reference/graph_networks/layers/edge_conv.py:24-27) over
+// PyG 1.3.2 NNConv:   out[v] = mean_{e: dst_e = v} h[src_e] . W_{type_e}  +  h[v] . root + bias  (+ LeakyReLU)
+//
+// Linearity in the source row lets the sum over edges move INSIDE the matrix product:
+//     sum_e h[src_e] . W_{type_e}  =  sum_t ( sum_{e of type t} h[src_e] ) . W_t  =  [S_0 | S_1 | .. | S_{T-1}] . [W_0; ..; W_{T-1}]
+// i.e. one dense [16 rows x 32 T] x [32 T x 32] product per 16-row destination tile whose accumulator IS the
+// output tile: no scatter, no segmented reduction, no LDS accumulators, no block barrier.  On real layouts a
+// row has ~7-10 in-edges over 13 types, almost all of distinct type, so about half of the K-blocks of a row are
+// zero -- MFMA work that costs less than the reduction machinery it replaces.
+//
+// Layout built once per graph (graph_prep.hip: nnconv_col_*_kernel): for every 16-row tile a list of COLUMNS,
+// sorted by type; column (t, r) holds for each of the 16 rows the source of its r-th in-edge of type t or -1.
+// Columns of the same type are summed in registers (A-operand pre-add, CSR order), the last one of the run
+// triggers the 16 MFMAs against W_t.  The last column of a tile is the root column (type T): the row itself,
+// with 1/deg in the slot where the others keep the source row.
+//
+// One wavefront owns a contiguous run of tiles and walks its columns as ONE stream through a DEPTH-deep
+// register pipeline (index load -> gather -> consume), across tile boundaries.  D^T = W^T . S^T is computed
+// (operands swapped) so that a lane ends up with 4 consecutive output channels of ONE row: float4 stores.
+#include "tgnn_common.h"
+
+namespace tgnn {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+#ifdef TGNN_TIMING
+__device__ unsigned long long g_col_timing[512 * 8 * 8];
+#define TGNN_CT(slot) { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[slot] += now_ - tlast; tlast = now_; }
+#else
+#define TGNN_CT(slot)
+#endif
+
+constexpr int kColMetaFirst = 1 << 8, kColMetaLast = 1 << 9, kColMetaEnd = 1 << 10, kColMetaSkip = 1 << 11;
+constexpr int kColStage = 16 * 20;         // floats of the per-wave BN staging tile: [16 rows][16 cols], row stride 20
+
+template <int DEPTH, int WAVES, int OCC>
+__global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
+    const float *__restrict__ h, int64_t ldh, const int *__restrict__ tile_col_ptr, const int *__restrict__ col_meta,
+    const int *__restrict__ col_src, const float *__restrict__ wimg, int n_types, const float *__restrict__ bias,
+    int64_t n, int act, float *__restrict__ out, double *__restrict__ bn_partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *wl = lds;                                        // [(T+1)][2][16][36]
+    float *stage = lds + (n_types + 1) * kWtType;           // [WAVES][16][20]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fj = lane & 15, fq = lane >> 4;
+    constexpr int kThreads = WAVES * 64;
+
+#ifdef TGNN_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
+    {   // weight image: straight copy, all loads of a thread issued before the first LDS store
+        const int n4 = (n_types + 1) * kWtType / 4;
+        for (int i = tid; i < n4; i += 4 * kThreads) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ii = i + u * kThreads < n4 ? i + u * kThreads : n4 - 1;
+                v[u] = reinterpret_cast<const float4 *>(wimg)[ii];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i + u * kThreads < n4) reinterpret_cast<float4 *>(wl)[i + u * kThreads] = v[u];
+        }
+    }
+    float *stg = stage + wave * kColStage;
+
+    // ---- this wave's run of 16-row tiles: XCD-contiguous (block b runs on XCD b % 8), then block, then wave
+    const int64_t n_tiles = (n + 15) / 16;
+    const int nblk = gridDim.x;
+    int64_t wave_id = (int64_t)blockIdx.x * WAVES + wave;
+    if (nblk >= 8 && (nblk & 7) == 0) wave_id = ((int64_t)(blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3)) * WAVES + wave;
+    const int64_t n_waves = (int64_t)nblk * WAVES;
+    const int64_t t0 = n_tiles * wave_id / n_waves, t1 = n_tiles * (wave_id + 1) / n_waves;
+    const int cbeg = __builtin_amdgcn_readfirstlane(tile_col_ptr[t0]);
+    const int cend = __builtin_amdgcn_readfirstlane(tile_col_ptr[t1]);
+
+    // bias of this lane's 8 output channels: 16 m + 4 q + r
+    const float4 bias0 = *reinterpret_cast<const float4 *>(bias + 4 * fq);
+    const float4 bias1 = *reinterpret_cast<const float4 *>(bias + 16 + 4 * fq);
+    // BN partial sums of this lane: channel 16 m + fj over the rows 4 fq .. 4 fq + 3 of every tile
+    double bs[2] = {0, 0}, bq[2] = {0, 0};   // (indexed with constants only)
+    __syncthreads();
+
+    // ---- pipeline helpers.  Vector-memory INSTRUCTIONS are the scarce resource (scratch/ubench/vmem2.hip: the
+    // CU's L1 path moves ~16 B/clk and charges every wave-level load a floor of ~20 cycles, dummy lanes included):
+    //   * index data comes per GROUP of 4 columns: one dword load fetches the 64 sources (lane (fj, fq) <- column
+    //     fq, row fj), one the 4 meta words; ds_bpermute / v_readlane hand them out (LDS crossbar, scalar pipe: idle)
+    //   * the gathers are BUFFER loads: a lane with an out-of-range offset returns 0 without touching memory, so
+    //     empty slots cost nothing and need no select; and for this 16-rows x 64-B shape a buffer load costs the
+    //     L1 path half of what a global load does (66 vs 129 cycles).
+    // Nothing is loaded inside a branch (hipcc would drain vmcnt(0) at the join).
+    const __amdgpu_buffer_rsrc_t h_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(h), 0, (int)0x80000000u, 0x00020000);   // 2 GB window
+    const uint32_t row_bytes = (uint32_t)ldh * 4u;
+    auto load_group = [&](int p, int &s4, int &m4) {        // columns p .. p+3 (reads past cend stay inside the slack)
+#ifdef TGNN_ABL_SAMEIDX
+        const int pc = cbeg + (p & 0);
+#else
+        const int pc = p < cend ? p : cbeg;
+#endif
+        s4 = col_src[(int64_t)pc * 16 + lane];
+        m4 = col_meta[pc + (lane & 3)];
+    };
+    auto unpack = [&](int p, int u, int s4, int m4, int &s, int &m) {
+        const bool ok = p + u < cend;                        // wave-uniform
+        const int sv = __shfl(s4, u * 16 + fj, 64);
+        const int mv = __builtin_amdgcn_readlane(m4, u);
+        s = ok ? sv : -1;
+        m = ok ? mv : kColMetaSkip;
+    };
+    int64_t gtile = t0;                                     // tile of the column the gather stage is at
+    auto issue_gather = [&](int s, int mu, float4 (&x)[2]) {
+        const bool root = (mu & 0xff) == n_types && !(mu & kColMetaSkip);
+        const uint32_t row = root ? (uint32_t)(gtile * 16 + fj) : (uint32_t)s;
+#ifdef TGNN_ABL_NOGATHER
+        const uint32_t off = 0x80000000u + (row & 0);
+#else
+        const uint32_t off = s >= 0 ? row * row_bytes + (uint32_t)fq * 32u : 0x80000000u;   // s < 0: empty slot / row >= n
+#endif
+        x[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, off, 0, 0));
+        x[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, off + 16u, 0, 0));
+        if (root) ++gtile;                                   // wave-uniform
+    };
+
+    f32x4 de0 = {0.f, 0.f, 0.f, 0.f}, de1 = de0, dr0 = de0, dr1 = de0;   // D^T tiles: edge sum / root term
+    float af[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t ctile = t0;
+    auto consume = [&](int s, int mu, const float4 (&x)[2]) {
+        if (mu & kColMetaSkip) return;                       // wave-uniform
+        const int t = mu & 0xff;
+        const bool valid = s >= 0;                           // (empty slots were loaded as zeros)
+        const float xv[8] = {x[0].x, x[0].y, x[0].z, x[0].w, x[1].x, x[1].y, x[1].z, x[1].w};
+        if (mu & kColMetaFirst) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) af[k] = xv[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) af[k] += xv[k];
+        }
+        TGNN_CT(1)
+        if (mu & kColMetaLast) {
+            const float *wp = wl + t * kWtType + fj * 36 + fq * 8;
+            const float4 p0 = *reinterpret_cast<const float4 *>(wp), p1 = *reinterpret_cast<const float4 *>(wp + 4);
+            const float4 p2 = *reinterpret_cast<const float4 *>(wp + kWtNt), p3 = *reinterpret_cast<const float4 *>(wp + kWtNt + 4);
+            const float bw0[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+            const float bw1[8] = {p2.x, p2.y, p2.z, p2.w, p3.x, p3.y, p3.z, p3.w};
+#ifdef TGNN_ABL_NOMFMA
+            if (true) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { de0[k & 3] += bw0[k] * af[k]; de1[k & 3] += bw1[k] * af[k]; }
+            } else
+#endif
+            if (t == n_types) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    dr0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw0[k], af[k], dr0, 0, 0, 0);
+                    dr1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw1[k], af[k], dr1, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    de0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw0[k], af[k], de0, 0, 0, 0);
+                    de1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw1[k], af[k], de1, 0, 0, 0);
+                }
+            }
+        }
+        TGNN_CT(2)
+        if (mu & kColMetaEnd) {
+            // lane (fj, fq): row fj of the tile, channels 4 fq .. 4 fq + 3 (de0/dr0) and 16 + the same (de1/dr1)
+            const float inv = valid ? __int_as_float(s) : 0.f;   // root column: 1/deg in the source slot
+            const int64_t v = ctile * 16 + fj;
+            float4 o0, o1;
+            o0.x = fmaf(de0[0], inv, dr0[0]) + bias0.x; o0.y = fmaf(de0[1], inv, dr0[1]) + bias0.y;
+            o0.z = fmaf(de0[2], inv, dr0[2]) + bias0.z; o0.w = fmaf(de0[3], inv, dr0[3]) + bias0.w;
+            o1.x = fmaf(de1[0], inv, dr1[0]) + bias1.x; o1.y = fmaf(de1[1], inv, dr1[1]) + bias1.y;
+            o1.z = fmaf(de1[2], inv, dr1[2]) + bias1.z; o1.w = fmaf(de1[3], inv, dr1[3]) + bias1.w;
+            if (act == TGNN_ACT_LEAKY_RELU) {
+                o0.x = leakyf_(o0.x); o0.y = leakyf_(o0.y); o0.z = leakyf_(o0.z); o0.w = leakyf_(o0.w);
+                o1.x = leakyf_(o1.x); o1.y = leakyf_(o1.y); o1.z = leakyf_(o1.z); o1.w = leakyf_(o1.w);
+            }
+            if (valid) {
+                *reinterpret_cast<float4 *>(out + v * 32 + 4 * fq) = o0;
+                *reinterpret_cast<float4 *>(out + v * 32 + 16 + 4 * fq) = o1;
+            }
+            if (bn_partial) {
+                // column sums in fp64: transpose through the wave's own LDS tile, one 16-channel half at a time
+                // (written out twice: indexing {o0, o1} with the loop variable would put them in scratch memory,
+                //  and a scratch access drains the whole gather pipeline with vmcnt(0))
+                auto half_sums = [&](float4 o, double &sum, double &sq) {
+                    o.x = valid ? o.x : 0.f; o.y = valid ? o.y : 0.f;   // (component selects: `valid ? o : z` on
+                    o.z = valid ? o.z : 0.f; o.w = valid ? o.w : 0.f;   //  float4 lvalues becomes a POINTER select)
+                    *reinterpret_cast<float4 *>(stg + fj * 20 + 4 * fq) = o;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double val = (double)stg[(4 * fq + r) * 20 + fj];
+                        sum += val;
+                        sq += val * val;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                };
+                half_sums(o0, bs[0], bq[0]);
+                half_sums(o1, bs[1], bq[1]);
+            }
+            de0 = f32x4{0.f, 0.f, 0.f, 0.f}; de1 = de0; dr0 = de0; dr1 = de0;
+            ++ctile;
+        }
+        TGNN_CT(3)
+    };
+
+    // ---- the column stream, in groups of 4: group g+2's index words are in flight, group g+1's gathers are issued
+    //      column by column as group g's columns are consumed (each into the registers just freed)
+    static_assert(DEPTH == 4, "the pipeline is written for groups of 4 columns");
+    int s4a, m4a, s4b, m4b;
+    load_group(cbeg, s4a, m4a);
+    load_group(cbeg + 4, s4b, m4b);
+    int xs[4], xm[4];
+    float4 x[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        unpack(cbeg, u, s4a, m4a, xs[u], xm[u]);
+        issue_gather(xs[u], xm[u], x[u]);
+    }
+    TGNN_CT(0)
+    for (int base = cbeg; base < cend; base += 4) {
+        int s4c, m4c;
+        load_group(base + 8, s4c, m4c);
+        TGNN_CT(6)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            consume(xs[u], xm[u], x[u]);
+            unpack(base + 4, u, s4b, m4b, xs[u], xm[u]);
+            TGNN_CT(4)
+            issue_gather(xs[u], xm[u], x[u]);
+            TGNN_CT(5)
+        }
+        s4b = s4c;
+        m4b = m4c;
+    }
+
+    // ---- BN partials of the block: lanes (fj, fq) -> channel 16 m + fj; fold fq, then the waves, in fixed order
+    if (bn_partial) {
+        __syncthreads();                                     // everybody is done with the weight image
+        double *red = reinterpret_cast<double *>(lds);       // [WAVES][64 lanes][4]
+        double *mine = red + ((int64_t)wave * 64 + lane) * 4;
+        mine[0] = bs[0]; mine[1] = bs[1]; mine[2] = bq[0]; mine[3] = bq[1];
+        __syncthreads();
+        if (tid < 64) {                                      // tid = which * 32 + channel
+            const int which = tid >> 5, ch = tid & 31, m2 = ch >> 4, j = ch & 15;
+            double acc = 0;
+            for (int w = 0; w < WAVES; ++w)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc += red[((int64_t)w * 64 + q * 16 + j) * 4 + which * 2 + m2];
+            bn_partial[(int64_t)blockIdx.x * 64 + tid] = acc;
+        }
+    }
+#ifdef TGNN_TIMING
+    TGNN_CT(7)
+    if (lane == 0 && blockIdx.x < 512 && wave < 8)
+        for (int k = 0; k < 8; ++k) g_col_timing[(blockIdx.x * 8 + wave) * 8 + k] = tacc[k];
+#endif
+}
+
+static size_t cols_lds_bytes(int n_types, int waves) {
+    size_t a = ((size_t)(n_types + 1) * kWtType + (size_t)waves * kColStage) * sizeof(float);
+    const size_t b = (size_t)waves * 64 * 4 * sizeof(double);
+    return a > b ? a : b;
+}
+
+constexpr size_t kColsMaxLds = 160 * 1024 - 256;
+
+template <int DEPTH, int WAVES, int OCC>
+static int launch_cols_t(const float *h, int64_t ldh, const int32_t *tile_col_ptr, const int32_t *col_meta,
+                         const int32_t *col_src, const float *wimg, int32_t n_types, const float *bias,
+                         int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
+                         int blocks_per_cu, hipStream_t s) {
+    static bool attr_set = false;
+    auto kern = nnconv32_cols_kernel<DEPTH, WAVES, OCC>;
+    if (!attr_set) {
+        TGNN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kColsMaxLds));
+        attr_set = true;
+    }
+    const int64_t n_tiles = (n_nodes + 15) / 16;
+    int64_t blocks = (n_tiles + WAVES - 1) / WAVES;      // at least one tile per wave
+    const int64_t cap = 256 * (int64_t)blocks_per_cu;
+    if (blocks > cap) blocks = cap;
+    if (blocks >= 8) blocks &= ~7;
+    if (blocks < 1) blocks = 1;
+    kern<<<(unsigned)blocks, WAVES * 64, cols_lds_bytes(n_types, WAVES), s>>>(
+        h, ldh, tile_col_ptr, col_meta, col_src, wimg, n_types, bias, n_nodes, act, out, bn_partial);
+    if (n_partials_host) *n_partials_host = (int32_t)blocks;
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}
+
+int launch_nnconv_cols(const float *h, int64_t ldh, const int32_t *tile_col_ptr, const int32_t *col_meta,
+                       const int32_t *col_src, const float *wimg, int32_t n_types, const float *bias,
+                       int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
+                       hipStream_t s) {
+    // blocks per CU by what the LDS weight image leaves room for (2 at T <= 16)
+    const size_t per_block = cols_lds_bytes(n_types, 8);
+    const int bpc = per_block * 2 <= 160 * 1024 ? 2 : 1;
+    return launch_cols_t<4, 8, 4>(h, ldh, tile_col_ptr, col_meta, col_src, wimg, n_types, bias, n_nodes, act, out,
+                                  bn_partial, n_partials_host, bpc, s);
+}
+
+}  // namespace tgnn
+#ifdef TGNN_TIMING
+extern "C" int tgnn_debug_col_timing(unsigned long long *host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tgnn::g_col_timing), sizeof(unsigned long long) * 512 * 8 * 8);
+}
+#endif
+
+using namespace tgnn;
+
+extern "C" int32_t tgnn_nnconv_cols_max_types(void) {
+    return (int32_t)((kColsMaxLds / sizeof(float) - 8 * kColStage) / kWtType) - 1;
+}
+
+extern "C" int tgnn_nnconv_mean_cols_fwd(const float *h, int64_t ldh, const int32_t *tile_col_ptr,
+                                         const int32_t *col_meta, const int32_t *col_src, const float *wtab,
+                                         int32_t n_types, const float *root, const float *bias, int64_t n_nodes,
+                                         int32_t c, int32_t act, float *out, float *wimg_scratch, double *bn_partial,
+                                         int32_t *n_partials_host, tgnn_stream_t stream) {
+    TGNN_CHECK_ARG(n_nodes >= 1 && c == 32, "the column NNConv kernel is built for network_width 32");
+    TGNN_CHECK_ARG(act == TGNN_ACT_NONE || act == TGNN_ACT_LEAKY_RELU, "activation");
+    TGNN_CHECK_ARG(h && tile_col_ptr && col_meta && col_src && root && bias && out && wimg_scratch, "null pointer");
+    TGNN_CHECK_ARG(n_types == 0 || wtab, "null weight table");
+    TGNN_CHECK_ARG(ldh >= 32 && ldh % 4 == 0 && ((uintptr_t)h % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
+                       ((uintptr_t)bias % 16) == 0 && ((uintptr_t)wimg_scratch % 16) == 0, "alignment");
+    if (n_types > tgnn_nnconv_cols_max_types()) {
+        set_error("tgnn_nnconv_mean_cols_fwd: %d edge types do not fit the LDS weight image (max %d)", n_types,
+                  tgnn_nnconv_cols_max_types());
+        return TGNN_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    launch_nnconv_weight_image(wtab, &root, n_types, 1, wimg_scratch, s);
+    return launch_nnconv_cols(h, ldh, tile_col_ptr, col_meta, col_src, wimg_scratch, n_types, bias, n_nodes, act, out,
+                              bn_partial, n_partials_host, s);
+}

@@ -112,8 +112,10 @@ void launch_edge_weight_table_batched(const float *edge_attr, const int *type_re
 // NNConv B-operand weight images [(T+1)][1152] for `depth` layers (roots[i] = layer i's root matrix); nnconv.hip
 void launch_nnconv_weight_image(const float *wtab_all, const float *const *roots, int n_types, int depth,
                                 float *wimg_all, hipStream_t s);
-int launch_nnconv_tiled(const float *h, int64_t ldh, const int32_t *rowptr, const int32_t *tile_chunk_ptr,
-                        const int32_t *chunk_meta, const int32_t *slot_src, const float *wimg, int32_t n_types,
-                        const float *bias, int64_t n_nodes, int32_t act, float *out, double *bn_partial,
-                        int32_t *n_partials_host, hipStream_t s);
+int launch_nnconv_cols(const float *h, int64_t ldh, const int32_t *tile_col_ptr, const int32_t *col_meta,
+                       const int32_t *col_src, const float *wimg, int32_t n_types, const float *bias,
+                       int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
+                       hipStream_t s);
+constexpr int kWtNt = 16 * 36;             // floats per (type, column tile) of the MFMA weight image: [j=16][q=4][ks=8], row stride 36
+constexpr int kWtType = 2 * kWtNt;         // floats per type
 }  // namespace tgnn

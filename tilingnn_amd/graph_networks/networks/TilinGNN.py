@@ -133,5 +133,5 @@ class TilinGNN(Tracked, nn.Module):
         probs = torch.empty(n, self.output_dim, dtype=torch.float32, device=dev)
         g = graph.c_struct()
         check(lib.tgnn_forward(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), int(bn_train), int(not bn_train),
-                               ptr(probs), ptr(ws), ws_bytes, _lib.current_stream(dev), None))
+                               ptr(probs), ptr(ws), ws_bytes, _lib.current_stream(dev), _lib.side_stream(dev)))
         return probs, adj_e_features                                          # TilinGNN.py:78

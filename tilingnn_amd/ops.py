@@ -69,42 +69,42 @@ class PreparedGraph:
     col_rowptr: Tensor
     col_src: Tensor
     col_eid: Tensor
-    tiles: Optional["NNConvTiles"] = None      # MFMA NNConv tile structure (None: CSR kernel is used)
+    cols: Optional["NNConvColumns"] = None     # matrix-core NNConv column structure (None: CSR kernel is used)
 
     def c_struct(self) -> _lib.Graph:
-        t = self.tiles
+        t = self.cols
         return _lib.Graph(self.n_nodes, self.n_adj_edges, self.n_col_edges, self.n_types,
                           self.adj_rowptr.data_ptr(), self.adj_src.data_ptr(), self.adj_type.data_ptr(),
                           self.type_rep_edge.data_ptr(), self.col_rowptr.data_ptr(), self.col_src.data_ptr(),
-                          *((t.tile_chunk_ptr.data_ptr(), t.chunk_meta.data_ptr(), t.slot_src.data_ptr())
+                          *((t.tile_col_ptr.data_ptr(), t.col_meta.data_ptr(), t.col_src.data_ptr())
                             if t is not None else (None,) * 3))
 
 
 @dataclass
-class NNConvTiles:
-    """Per-64-row tiles of type-grouped, 16-padded in-edges (tgnn_nnconv_tiles_build)."""
-    tile_chunk_ptr: Tensor
-    chunk_meta: Tensor        # int32 [8 * n_chunks]: {type, 0, 0, 0, 16 destination-row bytes}
-    slot_src: Tensor
+class NNConvColumns:
+    """Per-16-row tiles of type-sorted source columns (tgnn_nnconv_cols_build, include/tgnn.h)."""
+    tile_col_ptr: Tensor      # int32 [ceil(N/16) + 1]
+    col_meta: Tensor          # int32 [cap]: type | first << 8 | last << 9 | end-of-tile << 10
+    col_src: Tensor           # int32 [16 * cap]: source row, -1 = none; root columns: float bits of 1/max(deg,1)
 
 
-def build_nnconv_tiles(n_nodes: int, n_edges: int, n_types: int, rowptr: Tensor, col_src: Tensor,
-                       col_type: Tensor) -> Optional[NNConvTiles]:
-    """None when the layout has more edge types than the MFMA kernel's LDS weight image holds."""
-    if n_types > lib.tgnn_nnconv_tiled_max_types():
+def build_nnconv_columns(n_nodes: int, n_edges: int, n_types: int, rowptr: Tensor, col_src: Tensor,
+                         col_type: Tensor) -> Optional[NNConvColumns]:
+    """None when the layout has more edge types than the matrix-core kernel's LDS weight image holds."""
+    if n_types > lib.tgnn_nnconv_cols_max_types():
         return None
     dev = rowptr.device
-    cap = int(lib.tgnn_nnconv_tiles_max_chunks(n_nodes, n_edges, n_types))
-    ntiles = (n_nodes + 63) // 64
-    tiles = NNConvTiles(torch.empty(ntiles + 1, dtype=torch.int32, device=dev),
-                        torch.empty(cap * 8, dtype=torch.int32, device=dev),
-                        torch.empty(cap * 16, dtype=torch.int32, device=dev))
-    ws_bytes = lib.tgnn_nnconv_tiles_workspace_bytes(n_nodes)
+    cap = int(lib.tgnn_nnconv_cols_max_columns(n_nodes, n_edges))
+    ntiles = (n_nodes + 15) // 16
+    cols = NNConvColumns(torch.empty(ntiles + 1, dtype=torch.int32, device=dev),
+                         torch.empty(cap, dtype=torch.int32, device=dev),
+                         torch.empty(cap * 16, dtype=torch.int32, device=dev))
+    ws_bytes = lib.tgnn_nnconv_cols_workspace_bytes(n_nodes)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    check(lib.tgnn_nnconv_tiles_build(ptr(rowptr), ptr(col_src), ptr(col_type), n_nodes, n_types,
-                                      ptr(tiles.tile_chunk_ptr), ptr(tiles.chunk_meta), ptr(tiles.slot_src),
-                                      ptr(ws), ws_bytes, _stream(rowptr)))
-    return tiles
+    check(lib.tgnn_nnconv_cols_build(ptr(rowptr), ptr(col_src), ptr(col_type), n_nodes, n_types,
+                                     ptr(cols.tile_col_ptr), ptr(cols.col_meta), ptr(cols.col_src),
+                                     ptr(ws), ws_bytes, _stream(rowptr)))
+    return cols
 
 
 def _check_edge_index(ei: Tensor, name: str) -> Tensor:
@@ -172,9 +172,9 @@ def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col
         raise IndexError(f"edge index out of range [0, {n_nodes}) in "
                          f"{'adj_e_index' if host[1] else 'col_e_idx'}")
     n_types = int(host[0])
-    tiles = build_nnconv_tiles(n_nodes, ea, n_types, a_rowptr, a_src, adj_type) if tile_width == 32 else None
+    cols = build_nnconv_columns(n_nodes, ea, n_types, a_rowptr, a_src, adj_type) if tile_width == 32 else None
     return PreparedGraph(n_nodes, ea, int(host[3]), n_types, a_rowptr, a_src, a_eid, adj_type, edge_type, rep,
-                         c_rowptr, c_src, c_eid, tiles)
+                         c_rowptr, c_src, c_eid, cols)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -200,8 +200,9 @@ def edge_weight_table(edge_attr: Tensor, graph: PreparedGraph, w1, b1, w2, b2, w
 
 def nnconv_mean(h: Tensor, graph: PreparedGraph, wtab: Tensor, root: Tensor, bias: Tensor, act: int = ACT_NONE,
                 partials: Optional[Tensor] = None, force_csr_kernel: bool = False) -> Tuple[Tensor, int]:
-    """NNConv mean: the MFMA tile kernel when the graph carries tiles (width 32, few edge types),
-    else the CSR / LDS-weight-table kernel (any type count that fits LDS) or the generic one."""
+    """NNConv mean: the matrix-core column kernel when the graph carries the column structure (width 32, few edge
+    types, source rows within 2 GB), else the CSR / LDS-weight-table kernel (any type count that fits LDS) or
+    the generic one."""
     h = _f32c(h, "x")
     c = int(h.shape[1])
     n = graph.n_nodes                      # destination rows; x may carry extra (halo) rows behind them
@@ -212,13 +213,12 @@ def nnconv_mean(h: Tensor, graph: PreparedGraph, wtab: Tensor, root: Tensor, bia
     out = torch.empty(n, c, dtype=torch.float32, device=h.device)
     npart = C.c_int32(0)
     wt = _f32c(wtab, "wtab")
-    tl = graph.tiles
-    if tl is not None and c == 32 and not force_csr_kernel:
+    tl = graph.cols
+    if tl is not None and c == 32 and not force_csr_kernel and int(h.shape[0]) * c * 4 < 2 ** 31:
         wimg = torch.empty(lib.tgnn_nnconv_weight_image_floats(graph.n_types), dtype=torch.float32, device=h.device)
-        check(lib.tgnn_nnconv_mean_tiled_fwd(ptr(h), c, ptr(graph.adj_rowptr), ptr(tl.tile_chunk_ptr), ptr(tl.chunk_meta),
-                                             ptr(tl.slot_src), ptr(wt), graph.n_types,
-                                             ptr(_f32c(root, "root")), ptr(_f32c(bias, "bias")), n, c, act, ptr(out),
-                                             ptr(wimg), ptr(partials), C.byref(npart), _stream(h)))
+        check(lib.tgnn_nnconv_mean_cols_fwd(ptr(h), c, ptr(tl.tile_col_ptr), ptr(tl.col_meta), ptr(tl.col_src), ptr(wt),
+                                            graph.n_types, ptr(_f32c(root, "root")), ptr(_f32c(bias, "bias")), n, c, act,
+                                            ptr(out), ptr(wimg), ptr(partials), C.byref(npart), _stream(h)))
     else:
         check(lib.tgnn_nnconv_mean_fwd(ptr(h), c, ptr(graph.adj_rowptr), ptr(graph.adj_src), ptr(graph.adj_type), ptr(wt),
                                        graph.n_types, ptr(_f32c(root, "root")), ptr(_f32c(bias, "bias")), n, c, act,
