@@ -20,6 +20,20 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, int mode_a, int 
       }
     }
     r = d0[0] + d1[1] + d2[2] + d3[3];
+  } else if (what == 3) {     // bf16 16x16x32: 8 passes? measure
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    bf16x8 a; for (int i = 0; i < 8; ++i) a[i] = (__bf16)r;
+    f32x4 d0 = {0,0,0,0}, d1 = d0, d2 = d0, d3 = d0;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, a, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, a, d1, 0, 0, 0);
+        d2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, a, d2, 0, 0, 0);
+        d3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, a, d3, 0, 0, 0);
+      }
+    }
+    r = d0[0] + d1[1] + d2[2] + d3[3];
   } else if (what == 2) {
     float a0 = r, a1 = r + 1, a2 = r + 2, a3 = r + 3, a4 = r + 4, a5 = r + 5, a6 = r + 6, a7 = r + 7;
     for (int i = 0; i < iters; ++i) {
@@ -42,8 +56,8 @@ float run(int a, int b, int iters) {
 }
 int main() {
   const int iters = 20000;
-  const char* names[] = {"idle", "MFMA", "VALU"};
-  int combos[][2] = {{1,0},{2,0},{1,1},{2,2},{1,2}};
+  const char* names[] = {"idle", "MFMA", "VALU", "BF16"};
+  int combos[][2] = {{1,0},{2,0},{1,1},{2,2},{1,2},{3,0},{3,3},{3,2}};
   for (auto& c : combos) {
     float ms = run(c[0], c[1], iters);
     printf("wave A: %-5s wave B: %-5s  %.3f ms  (%.0f cycles per iteration @2.4GHz; 512 = one role at full rate)\n", names[c[0]], names[c[1]], ms, ms * 1e-3 * 2.4e9 / iters);

@@ -66,13 +66,19 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
     }
     float *stg = stage + wave * kColStage;
 
-    // ---- this wave's run of 16-row tiles: XCD-contiguous (block b runs on XCD b % 8), then block, then wave
+    // ---- this wave's run of 16-row tiles.  Balance is needed per SIMD, not per wave (a wave that finishes early
+    // leaves its SIMD to its partners): waves w, w+4, .. of a block share SIMD w & 3 and split ONE contiguous
+    // share; shares follow the XCD (block b runs on XCD b % 8), then the block, then the SIMD.
+    static_assert(WAVES % 4 == 0, "whole SIMD quads");
     const int64_t n_tiles = (n + 15) / 16;
     const int nblk = gridDim.x;
-    int64_t wave_id = (int64_t)blockIdx.x * WAVES + wave;
-    if (nblk >= 8 && (nblk & 7) == 0) wave_id = ((int64_t)(blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3)) * WAVES + wave;
-    const int64_t n_waves = (int64_t)nblk * WAVES;
-    const int64_t t0 = n_tiles * wave_id / n_waves, t1 = n_tiles * (wave_id + 1) / n_waves;
+    int64_t blk = blockIdx.x;
+    if (nblk >= 8 && (nblk & 7) == 0) blk = (int64_t)(blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    const int64_t slot = blk * 4 + (wave & 3), n_slots = (int64_t)nblk * 4;
+    const int64_t q0 = n_tiles * slot / n_slots, q1 = n_tiles * (slot + 1) / n_slots;
+    constexpr int kSubs = WAVES / 4;
+    const int sub = wave >> 2;
+    const int64_t t0 = q0 + (q1 - q0) * sub / kSubs, t1 = q0 + (q1 - q0) * (sub + 1) / kSubs;
     const int cbeg = __builtin_amdgcn_readfirstlane(tile_col_ptr[t0]);
     const int cend = __builtin_amdgcn_readfirstlane(tile_col_ptr[t1]);
 
@@ -214,34 +220,47 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
         TGNN_CT(3)
     };
 
-    // ---- the column stream, in groups of 4: group g+2's index words are in flight, group g+1's gathers are issued
-    //      column by column as group g's columns are consumed (each into the registers just freed)
-    static_assert(DEPTH == 4, "the pipeline is written for groups of 4 columns");
-    int s4a, m4a, s4b, m4b;
-    load_group(cbeg, s4a, m4a);
-    load_group(cbeg + 4, s4b, m4b);
-    int xs[4], xm[4];
-    float4 x[4][2];
+    // ---- the column stream, in groups of 4 columns, G = DEPTH / 4 groups in flight: a group's index words are
+    //      fetched two rounds (8 G columns) ahead, its gathers one round (4 G columns) ahead, each gather into the
+    //      registers the consumed column just freed.  (Measured: deeper than one group does not pay -- at 4 waves
+    //      per SIMD the waves cover each other's memory latency, and the extra registers cost occupancy.)
+    static_assert(DEPTH % 4 == 0, "the pipeline moves groups of 4 columns");
+    constexpr int G = DEPTH / 4;
+    int s4n[G], m4n[G];
+    int xs[G][4], xm[G][4];
+    float4 x[G][4][2];
+    {
+        int s4[G], m4[G];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        unpack(cbeg, u, s4a, m4a, xs[u], xm[u]);
-        issue_gather(xs[u], xm[u], x[u]);
+        for (int g = 0; g < G; ++g) load_group(cbeg + 4 * g, s4[g], m4[g]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) load_group(cbeg + 4 * (G + g), s4n[g], m4n[g]);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                unpack(cbeg + 4 * g, u, s4[g], m4[g], xs[g][u], xm[g][u]);
+                issue_gather(xs[g][u], xm[g][u], x[g][u]);
+            }
     }
     TGNN_CT(0)
-    for (int base = cbeg; base < cend; base += 4) {
-        int s4c, m4c;
-        load_group(base + 8, s4c, m4c);
-        TGNN_CT(6)
+    for (int base = cbeg; base < cend; base += 4 * G) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            consume(xs[u], xm[u], x[u]);
-            unpack(base + 4, u, s4b, m4b, xs[u], xm[u]);
-            TGNN_CT(4)
-            issue_gather(xs[u], xm[u], x[u]);
-            TGNN_CT(5)
+        for (int g = 0; g < G; ++g) {
+            int s4c, m4c;
+            load_group(base + 4 * (2 * G + g), s4c, m4c);
+            TGNN_CT(6)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                consume(xs[g][u], xm[g][u], x[g][u]);
+                unpack(base + 4 * (G + g), u, s4n[g], m4n[g], xs[g][u], xm[g][u]);
+                TGNN_CT(4)
+                issue_gather(xs[g][u], xm[g][u], x[g][u]);
+                TGNN_CT(5)
+            }
+            s4n[g] = s4c;
+            m4n[g] = m4c;
         }
-        s4b = s4c;
-        m4b = m4c;
     }
 
     // ---- BN partials of the block: lanes (fj, fq) -> channel 16 m + fj; fold fq, then the waves, in fixed order
@@ -288,7 +307,7 @@ static int launch_cols_t(const float *h, int64_t ldh, const int32_t *tile_col_pt
         attr_set = true;
     }
     const int64_t n_tiles = (n_nodes + 15) / 16;
-    int64_t blocks = (n_tiles + WAVES - 1) / WAVES;      // at least one tile per wave
+    int64_t blocks = (n_tiles + WAVES - 1) / WAVES;      // about one tile per wave at least
     const int64_t cap = 256 * (int64_t)blocks_per_cu;
     if (blocks > cap) blocks = cap;
     if (blocks >= 8) blocks &= ~7;
@@ -304,7 +323,8 @@ int launch_nnconv_cols(const float *h, int64_t ldh, const int32_t *tile_col_ptr,
                        const int32_t *col_src, const float *wimg, int32_t n_types, const float *bias,
                        int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
                        hipStream_t s) {
-    // blocks per CU by what the LDS weight image leaves room for (2 at T <= 16)
+    // blocks per CU by what the LDS weight image leaves room for (2 at T <= 16).
+    // Measured at N = 100k, T = 13 (us): <depth 4, 16 waves/CU> 55.7 | <16, 8> 66.0 | <8, 8> 64.9 | <16, 4> 85.2 | <32, 4> 90.2
     const size_t per_block = cols_lds_bytes(n_types, 8);
     const int bpc = per_block * 2 <= 160 * 1024 ? 2 : 1;
     return launch_cols_t<4, 8, 4>(h, ldh, tile_col_ptr, col_meta, col_src, wimg, n_types, bias, n_nodes, act, out,
