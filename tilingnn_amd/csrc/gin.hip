@@ -25,7 +25,6 @@
 
 namespace tgnn {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 // ------------------------------------------------------------------------------------------
 // K6: neighbourhood sum (HBM-bound gather).  8 lanes x float4 per destination row, rows of one
@@ -82,113 +81,199 @@ __global__ __launch_bounds__(256) void gin32_aggregate_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// K7: the GIN MLP (32 -> 32 -> 64 -> 32, sigmoid after every Linear) on matrix cores.
-// Block = 4 waves, tile = 128 rows; wave w owns rows [32w, 32w+32) through all three layers, so
-// the hidden activations only ever travel wave-privately through LDS (no block barrier in the
-// loop).  v_mfma_f32_32x32x2_f32: exact fp32.  LDS: weights 21 KB (rows padded: conflict-free
-// fragment reads) + 12.5 KB per wave.
+// K7: the GIN MLP (32 -> 32 -> 64 -> 32, sigmoid after every Linear) on matrix cores, activations resident in
+// registers from the first layer to the last, fp32-class accuracy on the bf16 matrix pipe.
+//
+// (1) The TRANSPOSED product H^T = W . Z^T is computed (A operand = weights, B operand = activations): the
+//     accumulators of v_mfma_f32_16x16x32_bf16 then hold, in lane (n = lane & 15, q = lane >> 4), features
+//     16 mb + 4 q + r (r = 0..3) of batch row n for M block mb -- two M blocks are exactly the 8 values per lane
+//     the B operand of the next layer takes, if the K order of that layer is DEFINED as
+//         kf(q, e) = 4 q + e  (e < 4),  16 + 4 q + (e - 4)  (e >= 4)        [+ 32 for the second K step]
+//     The sum over K does not care about the order; the weights are stored in LDS in that order.  No LDS round
+//     trip and no barrier between the layers.
+// (2) Every fp32 operand is split exactly into three bf16 pieces (hi + mid + lo) and the product is accumulated
+//     in fp32 from the six leading cross terms (see dense.hip): 60 MFMAs of ~18 cycles per 16-row tile instead
+//     of 40 fp32 MFMAs of ~72.  On this chip MFMA and VALU time ADD (scratch/ubench/coissue.hip), so matrix
+//     cycles saved are wall-clock saved.
+// History: per-thread MLP through the scalar cache 297 us/layer; fp32 MFMA with H1/H2 through LDS 23.7 us;
+// the same chain register-resident in fp32 24.6 us (not the LDS traffic but matrix-pipe time and the 4-vs-3.05
+// tiles-per-SIMD quantisation of 32-row tiles were the cost); this one: see profiles/.
 // ------------------------------------------------------------------------------------------
-constexpr int kMlpThreads = 256;
-constexpr int kW1Ld = 33, kW2Ld = 33, kW3Ld = 65;        // padded k-strides
-constexpr int kBufALd = 65, kBufBLd = 33;                // per-wave buffers: A = Z then H2, B = H1
+constexpr int kMlpWaves = 8, kMlpThreads = kMlpWaves * 64;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-__device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+__device__ __forceinline__ int gin_kf(int q, int e) { return e < 4 ? 4 * q + e : 16 + 4 * q + (e - 4); }
+
+__device__ __forceinline__ void gin_split3(const float (&x)[8], bf16x8 &hi, bf16x8 &mid, bf16x8 &lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)x[i];
+        const float r1 = x[i] - (float)h;       // exact
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;         // exact
+        hi[i] = h;
+        mid[i] = m;
+        lo[i] = (__bf16)r2;
+    }
 }
 
-__global__ __launch_bounds__(kMlpThreads) void gin32_mlp_kernel(
+// acc += W . X over one K step of 32: six cross terms, smallest first
+__device__ __forceinline__ f32x4 gin_mma6(const bf16x8 *wpl, int plane_stride, const bf16x8 (&x)[3], f32x4 acc) {
+    const bf16x8 w0 = wpl[0], w1 = wpl[plane_stride], w2 = wpl[2 * plane_stride];
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, x[0], acc, 0, 0, 0);   // lo . hi
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x[2], acc, 0, 0, 0);   // hi . lo
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x[1], acc, 0, 0, 0);   // mid . mid
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x[0], acc, 0, 0, 0);   // mid . hi
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x[1], acc, 0, 0, 0);   // hi . mid
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x[0], acc, 0, 0, 0);   // hi . hi
+    return acc;
+}
+
+// (2 waves per SIMD on purpose: the compiler then keeps all 30 weight fragments in registers, 232 VGPRs; with
+//  16 waves per block and 128 VGPRs the same code spills: 59.6 us)
+__global__ __launch_bounds__(kMlpThreads, 2) void gin32_mlp_kernel(
     const float *__restrict__ z, const float *__restrict__ w1, const float *__restrict__ b1,
     const float *__restrict__ w2, const float *__restrict__ b2, const float *__restrict__ w3,
     const float *__restrict__ b3, int64_t n, int act, float *__restrict__ out, double *__restrict__ bn_partial) {
-    __shared__ float W1s[32 * kW1Ld];
-    __shared__ float W2s[64 * kW2Ld];
-    __shared__ float W3s[32 * kW3Ld];
-    __shared__ float bufA[4][32 * kBufALd];
-    __shared__ float bufB[4][32 * kBufBLd];
-    __shared__ double red[4 * 64];
+    // weight images: [plane 3][M block][i 16][q 4] x bf16x8 -- the A fragment of lane (i, q) is one ds_read_b128
+    __shared__ bf16x8 W1s[3 * 2 * 64];          // K = 32 (natural order 8 q + e: Z comes straight from memory)
+    __shared__ bf16x8 W2s[3 * 4 * 64];          // K = 32 in kf order
+    __shared__ bf16x8 W3s[3 * 2 * 2 * 64];      // [plane][M block][K step][..], K = 64 in kf order
+    __shared__ __attribute__((aligned(16))) float Bs[128];   // b1 | b2 | b3
+    __shared__ double red[kMlpWaves * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 31, fk = lane >> 5;
-    for (int i = tid; i < 32 * 32; i += kMlpThreads) W1s[(i >> 5) * kW1Ld + (i & 31)] = w1[i];
-    for (int i = tid; i < 64 * 32; i += kMlpThreads) W2s[(i >> 5) * kW2Ld + (i & 31)] = w2[i];
-    for (int i = tid; i < 32 * 64; i += kMlpThreads) W3s[(i >> 6) * kW3Ld + (i & 63)] = w3[i];
-    const float bias1 = b1[fr], bias2a = b2[fr], bias2b = b2[32 + fr], bias3 = b3[fr];
+    const int fn = lane & 15, fq = lane >> 4;
+
+    // ---- tile share of this wave (16-row tiles): balanced per SIMD (waves w, w + 4 of a block run on SIMD w & 3)
+    const int64_t n_tiles = (n + 15) / 16;
+    const int nblk = gridDim.x;
+    int64_t blk = blockIdx.x;
+    if (nblk >= 8 && (nblk & 7) == 0) blk = (int64_t)(blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    const int64_t slot = blk * 4 + (wave & 3), n_slots = (int64_t)nblk * 4;
+    const int64_t q0 = n_tiles * slot / n_slots, q1 = n_tiles * (slot + 1) / n_slots;
+    constexpr int kSubs = kMlpWaves / 4;
+    const int sub = wave >> 2;
+    const int64_t t0 = q0 + (q1 - q0) * sub / kSubs, t1 = q0 + (q1 - q0) * (sub + 1) / kSubs;
+
+    // Z rows of a tile: lane (n, q) reads floats 8 q .. 8 q + 7 of row n; one tile ahead
+    auto load_z = [&](int64_t tile, float4 (&zin)[2]) {
+        int64_t zr = tile * 16 + fn;                        // clamped, unconditional: rows >= n are masked at the store
+        zr = zr < n ? zr : n - 1;
+        const float4 *pz = reinterpret_cast<const float4 *>(z + zr * 32 + 8 * fq);
+        zin[0] = pz[0];
+        zin[1] = pz[1];
+    };
+    float4 zin[2];
+    load_z(t0 < t1 ? t0 : 0, zin);                          // in flight while the weight images are built
+
+    for (int i = tid; i < 2 * 64; i += kMlpThreads) {       // item = (M block, i, q): 8 weights
+        const int mb = i >> 6, ii = (i >> 2) & 15, q = i & 3;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = w1[(16 * mb + ii) * 32 + 8 * q + e];
+        gin_split3(x, W1s[(0 * 2 + mb) * 64 + ii * 4 + q], W1s[(1 * 2 + mb) * 64 + ii * 4 + q], W1s[(2 * 2 + mb) * 64 + ii * 4 + q]);
+    }
+    for (int i = tid; i < 4 * 64; i += kMlpThreads) {
+        const int mb = i >> 6, ii = (i >> 2) & 15, q = i & 3;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = w2[(16 * mb + ii) * 32 + gin_kf(q, e)];
+        gin_split3(x, W2s[(0 * 4 + mb) * 64 + ii * 4 + q], W2s[(1 * 4 + mb) * 64 + ii * 4 + q], W2s[(2 * 4 + mb) * 64 + ii * 4 + q]);
+    }
+    for (int i = tid; i < 4 * 64; i += kMlpThreads) {       // item = (M block, K step, i, q)
+        const int mb = i >> 7, ks = (i >> 6) & 1, ii = (i >> 2) & 15, q = i & 3;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = w3[(16 * mb + ii) * 64 + 32 * ks + gin_kf(q, e)];
+        const int o = (mb * 2 + ks) * 64 + ii * 4 + q;
+        gin_split3(x, W3s[0 * 256 + o], W3s[1 * 256 + o], W3s[2 * 256 + o]);
+    }
+    if (tid < 32) Bs[tid] = b1[tid];
+    else if (tid < 96) Bs[tid] = b2[tid - 32];
+    else if (tid < 128) Bs[tid] = b3[tid - 96];
     __syncthreads();
 
-    float *A = bufA[wave], *B = bufB[wave];
-    double csum = 0.0, csq = 0.0;
-    const int64_t n_tiles = (n + 127) / 128;
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t row0 = tile * 128 + wave * 32;
-        // ---- Z rows of this wave -> bufA (row stride 65): 4 x (64 lanes x float4) coalesced loads
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int idx = j * 64 + lane, r = idx >> 3, qq = idx & 7;
-            int64_t zr = row0 + r;                       // clamped, unconditional: rows >= n are masked at the store
-            zr = zr < n ? zr : n - 1;
-            const float4 v4 = *reinterpret_cast<const float4 *>(z + zr * 32 + 4 * qq);
-            float *d = A + r * kBufALd + 4 * qq;
-            d[0] = v4.x; d[1] = v4.y; d[2] = v4.z; d[3] = v4.w;
+    // this lane's accumulator registers hold features 16 mb + 4 q + r: bias vectors in that order
+    auto bias4 = [&](int base, int mb) {
+        const float4 t = *reinterpret_cast<const float4 *>(Bs + base + 16 * mb + 4 * fq);
+        return f32x4{t.x, t.y, t.z, t.w};
+    };
+    const bf16x8 *w1p = W1s + fn * 4 + fq, *w2p = W2s + fn * 4 + fq, *w3p = W3s + fn * 4 + fq;
+    double cs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cq[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // BN sums of this lane's 8 output features
+
+    for (int64_t tile = t0; tile < t1; ++tile) {
+        bf16x8 xb[3];
+        {
+            const float x[8] = {zin[0].x, zin[0].y, zin[0].z, zin[0].w, zin[1].x, zin[1].y, zin[1].z, zin[1].w};
+            gin_split3(x, xb[0], xb[1], xb[2]);
         }
-        wave_lds_fence();
-        // ---- layer 1: H1 = sigmoid(Z W1^T + b1)          [32 x 32], K = 32
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < 32; kk += 2)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[fr * kBufALd + kk + fk], W1s[fr * kW1Ld + kk + fk], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            B[((r & 3) + 8 * (r >> 2) + 4 * fk) * kBufBLd + fr] = sigmoidf_(acc[r] + bias1);
-        wave_lds_fence();
-        // ---- layer 2: H2 = sigmoid(H1 W2^T + b2)         [32 x 64], K = 32
-        f32x16 acc2a, acc2b;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2a[r] = acc2b[r] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < 32; kk += 2) {
-            const float av = B[fr * kBufBLd + kk + fk];
-            acc2a = __builtin_amdgcn_mfma_f32_32x32x2f32(av, W2s[fr * kW2Ld + kk + fk], acc2a, 0, 0, 0);
-            acc2b = __builtin_amdgcn_mfma_f32_32x32x2f32(av, W2s[(32 + fr) * kW2Ld + kk + fk], acc2b, 0, 0, 0);
+        load_z(tile + 1 < t1 ? tile + 1 : tile, zin);
+        // ---- layer 1: 2 M blocks
+        f32x4 h1a = gin_mma6(w1p + 0 * 64, 2 * 64, xb, bias4(0, 0));
+        f32x4 h1b = gin_mma6(w1p + 1 * 64, 2 * 64, xb, bias4(0, 1));
+        {
+            const float x[8] = {sigmoidf_(h1a[0]), sigmoidf_(h1a[1]), sigmoidf_(h1a[2]), sigmoidf_(h1a[3]),
+                                sigmoidf_(h1b[0]), sigmoidf_(h1b[1]), sigmoidf_(h1b[2]), sigmoidf_(h1b[3])};
+            gin_split3(x, xb[0], xb[1], xb[2]);
         }
+        // ---- layer 2: 4 M blocks
+        f32x4 h2[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * fk;
-            A[row * kBufALd + fr] = sigmoidf_(acc2a[r] + bias2a);       // Z is dead: reuse bufA
-            A[row * kBufALd + 32 + fr] = sigmoidf_(acc2b[r] + bias2b);
+        for (int mb = 0; mb < 4; ++mb) h2[mb] = gin_mma6(w2p + mb * 64, 4 * 64, xb, bias4(32, mb));
+        // ---- layer 3: 2 M blocks x 2 K steps
+        f32x4 o0 = bias4(96, 0), o1 = bias4(96, 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float x[8] = {sigmoidf_(h2[2 * ks][0]), sigmoidf_(h2[2 * ks][1]), sigmoidf_(h2[2 * ks][2]), sigmoidf_(h2[2 * ks][3]),
+                                sigmoidf_(h2[2 * ks + 1][0]), sigmoidf_(h2[2 * ks + 1][1]), sigmoidf_(h2[2 * ks + 1][2]), sigmoidf_(h2[2 * ks + 1][3])};
+            gin_split3(x, xb[0], xb[1], xb[2]);
+            o0 = gin_mma6(w3p + (0 * 2 + ks) * 64, 256, xb, o0);
+            o1 = gin_mma6(w3p + (1 * 2 + ks) * 64, 256, xb, o1);
         }
-        wave_lds_fence();
-        // ---- layer 3: OUT = act(sigmoid(H2 W3^T + b3))    [32 x 32], K = 64
+        // ---- epilogue: row fn, features 4 q + r and 16 + 4 q + r
+        float4 r0, r1;
+        r0.x = sigmoidf_(o0[0]); r0.y = sigmoidf_(o0[1]); r0.z = sigmoidf_(o0[2]); r0.w = sigmoidf_(o0[3]);
+        r1.x = sigmoidf_(o1[0]); r1.y = sigmoidf_(o1[1]); r1.z = sigmoidf_(o1[2]); r1.w = sigmoidf_(o1[3]);
+        if (act == TGNN_ACT_LEAKY_RELU) {
+            r0.x = leakyf_(r0.x); r0.y = leakyf_(r0.y); r0.z = leakyf_(r0.z); r0.w = leakyf_(r0.w);
+            r1.x = leakyf_(r1.x); r1.y = leakyf_(r1.y); r1.z = leakyf_(r1.z); r1.w = leakyf_(r1.w);
+        }
+        const int64_t row = tile * 16 + fn;
+        if (row < n) {
+            *reinterpret_cast<float4 *>(out + row * 32 + 4 * fq) = r0;
+            *reinterpret_cast<float4 *>(out + row * 32 + 16 + 4 * fq) = r1;
+            const float v[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < 64; kk += 2)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[fr * kBufALd + kk + fk], W3s[fr * kW3Ld + kk + fk], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-            float v = sigmoidf_(acc[r] + bias3);
-            if (act == TGNN_ACT_LEAKY_RELU) v = leakyf_(v);
-            if (row < n) {
-                out[row * 32 + fr] = v;
-                csum += (double)v;
-                csq += (double)v * (double)v;
+            for (int e = 0; e < 8; ++e) {
+                cs[e] += (double)v[e];
+                cq[e] += (double)v[e] * (double)v[e];
             }
         }
-        wave_lds_fence();   // bufA is rewritten by the next tile's Z
     }
     if (bn_partial) {
-        csum += __shfl_xor(csum, 32, 64);
-        csq += __shfl_xor(csq, 32, 64);
-        if (lane < 32) {
-            red[wave * 64 + lane] = csum;
-            red[wave * 64 + 32 + lane] = csq;
+        // lanes of one 16-lane row hold the same 8 features: fold the 16 batch rows (fixed butterfly), then the waves
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int d = 1; d <= 8; d <<= 1) {
+                cs[e] += __shfl_xor(cs[e], d, 64);
+                cq[e] += __shfl_xor(cq[e], d, 64);
+            }
+        if (fn == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int feat = (e < 4 ? 0 : 16) + 4 * fq + (e & 3);
+                red[wave * 64 + feat] = cs[e];
+                red[wave * 64 + 32 + feat] = cq[e];
+            }
         }
         __syncthreads();
-        if (tid < 64)
-            bn_partial[(int64_t)blockIdx.x * 64 + tid] = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+        if (tid < 64) {
+            double tot = 0.0;
+            for (int w = 0; w < kMlpWaves; ++w) tot += red[w * 64 + tid];
+            bn_partial[(int64_t)blockIdx.x * 64 + tid] = tot;
+        }
     }
 }
 
@@ -270,7 +355,10 @@ extern "C" int tgnn_gin_fwd(const float *a, int64_t lda, const float *in_stat, c
         const int64_t rows_per_xcd = (n_nodes + 7) / 8;
         const unsigned agg_blocks = (unsigned)(8 * ((rows_per_xcd + 31) / 32));
         gin32_aggregate_kernel<<<agg_blocks, 256, 0, s>>>(a, lda, in_stat, rowptr, col_src, eps, n_nodes, z_scratch);
-        blocks = producer_blocks(n_nodes, 128);
+        // persistent 8-wave blocks; the waves of one SIMD split a contiguous share of 32-row tiles
+        blocks = producer_blocks(n_nodes, 16 * kMlpWaves);
+        if (blocks > 256) blocks = 256;        // one block per CU: the weight prologue is paid once per block
+        if (blocks >= 8) blocks &= ~7;
         gin32_mlp_kernel<<<blocks, kMlpThreads, 0, s>>>(z_scratch, w1, b1, w2, b2, w3, b3, n_nodes, act, out,
                                                         bn_partial);
     } else {
