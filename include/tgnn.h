@@ -242,6 +242,34 @@ int tgnn_forward(const tgnn_model_dims *dims, const void *const *params_host, co
                  int32_t use_running_stats, float *probs, void *ws, size_t ws_bytes,
                  tgnn_stream_t stream, tgnn_stream_t stream2);
 
+/* ---- the same forward for ONE SHARD of a node-range partition (one process per GPU) -------------------------
+ * This device owns rows [0, n_own) of a layout whose buffers carry n_rows - n_own halo rows of other shards behind
+ * them: `graph` is built with n_nodes = n_own destinations and sources in [0, n_rows) (tgnn_csr_build's
+ * n_src_nodes), `x` has n_own rows.  Per layer the library needs two collectives, which stay with the caller
+ * (torch.distributed / RCCL in tilingnn_amd/dist.py): it enqueues its kernels on `stream`, calls back on the
+ * host, and continues; a callback must enqueue its collective on `stream` or order it with `stream`.
+ *   allreduce_f64(ctx, sum_buf, count, stream): sum_buf[0..count) <- sum over all shards      (BatchNorm sums)
+ *   alltoall_rows(ctx, send_buf, recv_buf, row_floats, stream): send_buf holds n_send rows of row_floats floats
+ *       (the owned rows listed in send_idx, grouped by destination shard); recv_buf must receive the n_rows - n_own
+ *       halo rows in the order they sit behind the owned rows.  row_floats is C for the first exchange, 2 C after.
+ * Both return 0 on success.  Train mode only (batch statistics over all n_total rows of the partition). */
+typedef struct tgnn_shard {
+    int64_t n_own, n_rows, n_total;
+    const int32_t *send_idx;        /* device, [n_send] local row numbers */
+    int64_t n_send;
+    double *sum_buf;                /* device, >= 2 * 2 * 256 doubles */
+    float *send_buf;                /* device, >= max(n_send, 1) * 2 C floats */
+    float *recv_buf;                /* device, >= max(n_rows - n_own, 1) * 2 C floats */
+    int (*allreduce_f64)(void *ctx, double *buf, int64_t count, tgnn_stream_t stream);
+    int (*alltoall_rows)(void *ctx, const float *send, float *recv, int32_t row_floats, tgnn_stream_t stream);
+    void *ctx;
+} tgnn_shard;
+size_t tgnn_forward_sharded_workspace_bytes(const tgnn_model_dims *dims, int64_t n_own, int64_t n_rows,
+                                            int32_t n_types);
+int tgnn_forward_sharded(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
+                         const float *adj_edge_attr, const tgnn_graph *graph, const tgnn_shard *shard,
+                         int32_t update_running, float *probs, void *ws, size_t ws_bytes, tgnn_stream_t stream);
+
 /* The same forward with a hipEvent pair around every launch (on `stream`, where the kernels run);
  * synchronises, then ADDS the elapsed milliseconds and launch counts per kernel class into the
  * two host arrays of TGNN_PROF_CLASSES entries.  Measurement aid for bench.py's roofline line. */

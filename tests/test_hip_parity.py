@@ -494,3 +494,53 @@ def test_sharded_hip_path_matches_unsharded(dev, world):
             k = "brch_2_coll_conv_layers.2.batch_norm"
             assert int(b[k + ".num_batches_tracked"]) == 1
             assert float((a[k + ".running_var"] - b[k + ".running_var"]).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_fused_sharded_forward_matches_unsharded(dev, world):
+    """tgnn_forward_sharded (the whole shard schedule in one library call, collectives through callbacks): P
+    virtual ranks = P threads on this one GPU (ThreadSimCollectives) against the unsharded forward and against the
+    per-op Python schedule; running statistics come from the GLOBAL sums."""
+    import threading
+    from tilingnn_amd import dist as tdist
+    from tilingnn_amd.synth import make_super_graph
+    sg = make_super_graph(6000, 60000, 75000, tile_count=2, n_edge_types=13, seed=8)
+    for depth, tol in ((3, 2e-5), (20, 5e-2)):
+        net, sd = make_net(dev, depth=depth)
+        x, adj, adj_attr, col, col_attr = sg.to_torch(dev)
+        want = net(x=x, adj_e_index=adj, adj_e_features=adj_attr, col_e_idx=col)[0]
+        shards = [tdist.make_shard(sg.node_feature, sg.align_edge_index, sg.align_edge_features,
+                                   sg.collide_edge_index, r, world) for r in range(world)]
+        tdist.LocalSimComm.setup(shards)
+        nets = [make_net(dev, depth=depth)[0] for _ in range(world)]
+        hub = tdist.ThreadSimCollectives.Hub(world)
+        runners = [tdist.FusedShardForward(nets[r], shards[r], dev, tdist.ThreadSimCollectives(hub, r))
+                   for r in range(world)]
+        parts, errors = [None] * world, []
+
+        def work(r):
+            try:
+                torch.cuda.set_device(dev)
+                parts[r] = runners[r].step()
+            except BaseException as exc:                     # a dead rank must not leave the others in the barrier
+                errors.append(exc)
+                hub.barrier.abort()
+
+        threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=120)
+        assert not errors, errors
+        torch.cuda.synchronize()
+        got = torch.cat(parts)
+        err = float((got - want).abs().max())
+        print(f"fused, world {world} depth {depth}: max |sharded - unsharded| = {err:.2e}")
+        assert got.shape == want.shape and err < tol
+        if depth == 3:
+            a, b = net.state_dict(), nets[0].state_dict()
+            k = "brch_2_coll_conv_layers.2.batch_norm"
+            assert int(b[k + ".num_batches_tracked"]) == 1
+            assert float((a[k + ".running_var"] - b[k + ".running_var"]).abs().max()) < 1e-5
+            k = "final_mlp.0.mlp.0.batch_norm"
+            assert float((a[k + ".running_mean"] - b[k + ".running_mean"]).abs().max()) < 1e-5

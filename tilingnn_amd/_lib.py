@@ -35,6 +35,18 @@ class Graph(C.Structure):
                 ("nn_tile_col_ptr", C.c_void_p), ("nn_col_meta", C.c_void_p), ("nn_col_src", C.c_void_p)]
 
 
+ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+ALLTOALL_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
+
+
+class ShardDesc(C.Structure):
+    """tgnn_shard"""
+    _fields_ = [("n_own", C.c_int64), ("n_rows", C.c_int64), ("n_total", C.c_int64),
+                ("send_idx", C.c_void_p), ("n_send", C.c_int64),
+                ("sum_buf", C.c_void_p), ("send_buf", C.c_void_p), ("recv_buf", C.c_void_p),
+                ("allreduce_f64", ALLREDUCE_CB), ("alltoall_rows", ALLTOALL_CB), ("ctx", C.c_void_p)]
+
+
 def _load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -70,6 +82,9 @@ def _load() -> C.CDLL:
         "tgnn_forward_workspace_bytes": (sz, [C.POINTER(ModelDims), i64, i32]),
         "tgnn_forward": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), p, p, C.POINTER(Graph), i32, i32,
                                    p, p, sz, p, p]),
+        "tgnn_forward_sharded_workspace_bytes": (sz, [C.POINTER(ModelDims), i64, i64, i32]),
+        "tgnn_forward_sharded": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), p, p, C.POINTER(Graph),
+                                           C.POINTER(ShardDesc), i32, p, p, sz, p]),
         "tgnn_forward_profiled": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), p, p, C.POINTER(Graph), i32,
                                             i32, p, p, sz, p, C.POINTER(C.c_float), pi32]),
         "tgnn_rows_gather": (C.c_int, [p, i64, p, i64, i32, p, i64, p]),
@@ -88,7 +103,7 @@ EXPORTED_SYMBOLS = (
     "tgnn_nnconv_mean_fwd", "tgnn_nnconv_cols_max_columns", "tgnn_nnconv_cols_workspace_bytes",
     "tgnn_nnconv_cols_build", "tgnn_nnconv_cols_max_types", "tgnn_nnconv_weight_image_floats", "tgnn_nnconv_mean_cols_fwd", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
     "tgnn_merge_fwd", "tgnn_param_count", "tgnn_param_name", "tgnn_forward_workspace_bytes", "tgnn_forward",
-    "tgnn_forward_profiled",
+    "tgnn_forward_profiled", "tgnn_forward_sharded_workspace_bytes", "tgnn_forward_sharded",
     "tgnn_rows_gather", "tgnn_rows_scatter")
 
 

@@ -138,14 +138,16 @@ struct Prof {
 
 static const int kFinalDims[4] = {256, 128, 64, 0};  // TilinGNN.py:46 hidden_layer_dims; [3] = C
 
-static Workspace carve(const tgnn_model_dims &d, int64_t n, int32_t n_types, void *ws, size_t ws_bytes) {
+// n = rows this device computes; nr >= n = rows of the buffers that are GATHERED from (owned rows, then halo rows
+// of other shards; nr == n on a single device)
+static Workspace carve(const tgnn_model_dims &d, int64_t n, int64_t nr, int32_t n_types, void *ws, size_t ws_bytes) {
     Carver cv(ws, ws_bytes);
     const int c = d.network_width, D = d.network_depth;
     Workspace w{};
-    w.mid = cv.take<float>((size_t)(D + 1) * n * c);
+    w.mid = cv.take<float>((size_t)(D + 1) * nr * c);
     w.a1 = cv.take<float>((size_t)n * c);
-    w.a2[0] = cv.take<float>((size_t)n * c);
-    w.a2[1] = cv.take<float>((size_t)n * c);
+    w.a2[0] = cv.take<float>((size_t)nr * c);
+    w.a2[1] = cv.take<float>((size_t)nr * c);
     w.t0 = cv.take<float>((size_t)n * c);
     w.f1 = cv.take<float>((size_t)n * 256);
     w.f2 = cv.take<float>((size_t)n * 128);
@@ -190,7 +192,13 @@ extern "C" int tgnn_param_name(const tgnn_model_dims *dims, int32_t index, char 
 
 extern "C" size_t tgnn_forward_workspace_bytes(const tgnn_model_dims *dims, int64_t n_nodes, int32_t n_types) {
     if (!dims_ok(dims) || n_nodes < 0) return 0;
-    return carve(*dims, n_nodes, n_types, nullptr, 0).bytes;
+    return carve(*dims, n_nodes, n_nodes, n_types, nullptr, 0).bytes;
+}
+
+extern "C" size_t tgnn_forward_sharded_workspace_bytes(const tgnn_model_dims *dims, int64_t n_own, int64_t n_rows,
+                                                       int32_t n_types) {
+    if (!dims_ok(dims) || n_own < 0 || n_rows < n_own) return 0;
+    return carve(*dims, n_own, n_rows, n_types, nullptr, 0).bytes;
 }
 
 #define TGNN_TRY(expr)               \
@@ -202,12 +210,12 @@ extern "C" size_t tgnn_forward_workspace_bytes(const tgnn_model_dims *dims, int6
 static int forward_impl(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
                         const float *adj_edge_attr, const tgnn_graph *graph, int32_t update_running,
                         int32_t use_running_stats, float *probs, void *ws, size_t ws_bytes, tgnn_stream_t stream,
-                        tgnn_stream_t stream2, Prof &prof) {
+                        tgnn_stream_t stream2, Prof &prof, const tgnn_shard *sh = nullptr) {
     TGNN_CHECK_ARG(dims_ok(dims), "model dims");
     TGNN_CHECK_ARG(params_host && graph && probs && x, "null pointer");
     const int64_t n = graph->n_nodes;
     TGNN_CHECK_ARG(n >= 1, "empty graph");
-    TGNN_CHECK_ARG(use_running_stats || n >= 2, "train-mode BatchNorm needs more than one row");
+    TGNN_CHECK_ARG(use_running_stats || sh || n >= 2, "train-mode BatchNorm needs more than one row");
     TGNN_CHECK_ARG(graph->adj_rowptr && graph->col_rowptr, "graph pointers");
     TGNN_CHECK_ARG(graph->n_types == 0 || (adj_edge_attr && graph->type_rep_edge && graph->adj_src && graph->adj_type),
                    "adjacency pointers");
@@ -217,7 +225,18 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
             set_error("tgnn_forward: params_host[%d] is null", i);
             return TGNN_ERR_INVALID_ARG;
         }
-    Workspace w = carve(*dims, n, graph->n_types, ws, ws_bytes);
+    // ---- sharded mode (tgnn_forward_sharded): this device owns rows [0, n) of buffers that carry nr - n halo rows
+    // of other shards behind them; BatchNorm statistics are summed over all shards, halo rows are exchanged once
+    // per layer.  The collectives are the caller's (callbacks, enqueued on / ordered with `stream`).
+    const int64_t nr = sh ? sh->n_rows : n, n_total = sh ? sh->n_total : n, n_halo = nr - n;
+    if (sh) {
+        TGNN_CHECK_ARG(sh->n_own == n && nr >= n && n_total >= n, "shard row counts");
+        TGNN_CHECK_ARG(!use_running_stats, "sharded forward runs in train mode");
+        TGNN_CHECK_ARG(sh->allreduce_f64 && sh->alltoall_rows && sh->sum_buf && sh->send_buf && sh->recv_buf,
+                       "shard callbacks / buffers");
+        TGNN_CHECK_ARG(sh->n_send == 0 || sh->send_idx, "send_idx");
+    }
+    Workspace w = carve(*dims, n, nr, graph->n_types, ws, ws_bytes);
     if (!ws || w.bytes > ws_bytes) {
         set_error("tgnn_forward: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
         return TGNN_ERR_WORKSPACE;
@@ -226,7 +245,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     // Two-stream schedule: the collision branch of layer i (GINConv, TilinGNN.py:63) does not depend on the
     // adjacency branch (:62); with a side stream it runs beside NNConv, whose gather-latency-bound waves leave
     // issue slots and whole CUs (tail) idle.  Fork after merge_{i-1}, join before the BN finalize of layer i.
-    hipStream_t s2 = prof.on ? nullptr : static_cast<hipStream_t>(stream2);
+    hipStream_t s2 = (prof.on || sh) ? nullptr : static_cast<hipStream_t>(stream2);
     if (s2 == s) s2 = nullptr;
     static thread_local hipEvent_t ev_cache[64][2] = {};   // per calling thread and device; never destroyed
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -249,14 +268,55 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     const int fin_mode = use_running_stats ? 3 : 0;
     int32_t np1 = 0, np2 = 0;
 
-    auto finalize1 = [&](double *part, int nparts, int f, const BnPtrs &b, float *stat) {
+    // BatchNorm statistics from the producers' partial rows.  Sharded: partials -> local sums (mode 1) -> all-reduce
+    // over the shards (caller's callback; both BatchNorms of a layer travel in one message) -> stat record (mode 2).
+    auto finalize_jobs = [&](BnJobs jobs, int nj, int f) -> int {
+        if (nj == 0) return TGNN_OK;
+        if (!sh) {
+            prof.begin(4);
+            launch_bn_finalize(jobs, nj, fin_mode, f, n, eps, momentum, s);
+            prof.end();
+            return TGNN_OK;
+        }
+        for (int j = 0; j < nj; ++j) jobs.job[j].sums = sh->sum_buf + (size_t)j * 2 * f;
+        launch_bn_finalize(jobs, nj, 1, f, n_total, eps, momentum, s);
+        if (sh->allreduce_f64(sh->ctx, sh->sum_buf, (int64_t)nj * 2 * f, stream) != 0) {
+            set_error("tgnn_forward_sharded: the all-reduce callback failed");
+            return TGNN_ERR_INVALID_ARG;
+        }
+        launch_bn_finalize(jobs, nj, 2, f, n_total, eps, momentum, s);
+        return TGNN_OK;
+    };
+    auto finalize1 = [&](double *part, int nparts, int f, const BnPtrs &b, float *stat) -> int {
         BnJobs jobs{};
         jobs.job[0] = BnJob{part, nparts, nullptr, b.gamma, b.beta, (update_running || use_running_stats) ? b.rm : nullptr,
                             (update_running || use_running_stats) ? b.rv : nullptr,
                             (update_running && !use_running_stats) ? b.nbt : nullptr, stat};
-        prof.begin(4);
-        launch_bn_finalize(jobs, 1, fin_mode, f, n, eps, momentum, s);
-        prof.end();
+        return finalize_jobs(jobs, 1, f);
+    };
+    // Halo exchange: the rows other shards need (send_idx) of slot `slot` of the skip buffer and, from layer 1 on,
+    // of the collision branch's pre-BN activations travel in ONE all-to-all (64 floats per row) and land behind the
+    // owned rows.
+    auto exchange = [&](int slot, const float *a2_own, float *a2_halo_dst) -> int {
+        if (!sh) return TGNN_OK;
+        const int rf = a2_own ? 2 * c : c;                     // floats per exchanged row
+        float *slot_rows = w.mid + (size_t)slot * nr * c;
+        if (sh->n_send > 0) {
+            TGNN_TRY(tgnn_rows_gather(slot_rows, c, sh->send_idx, sh->n_send, c, sh->send_buf, rf, s));
+            if (a2_own) TGNN_TRY(tgnn_rows_gather(a2_own, c, sh->send_idx, sh->n_send, c, sh->send_buf + c, rf, s));
+        }
+        if (sh->alltoall_rows(sh->ctx, sh->send_buf, sh->recv_buf, rf, stream) != 0) {
+            set_error("tgnn_forward_sharded: the all-to-all callback failed");
+            return TGNN_ERR_INVALID_ARG;
+        }
+        if (n_halo > 0) {
+            TGNN_CHECK_HIP(hipMemcpy2DAsync(slot_rows + (size_t)n * c, (size_t)c * 4, sh->recv_buf, (size_t)rf * 4,
+                                            (size_t)c * 4, (size_t)n_halo, hipMemcpyDeviceToDevice, s));
+            if (a2_own)
+                TGNN_CHECK_HIP(hipMemcpy2DAsync(a2_halo_dst + (size_t)n * c, (size_t)c * 4, sh->recv_buf + c, (size_t)rf * 4,
+                                                (size_t)c * 4, (size_t)n_halo, hipMemcpyDeviceToDevice, s));
+        }
+        return TGNN_OK;
     };
 
     // ---- K1: per-type NNConv matrices of all layers, one launch
@@ -270,7 +330,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         launch_edge_weight_table_batched(adj_edge_attr, graph->type_rep_edge, T, fe, layers, D, c, w.wtab, s);
         prof.end();
     }
-    const bool tiled = graph->nn_tile_col_ptr && c == 32 && (int64_t)n * c * 4 < (int64_t(1) << 31);   // buffer-addressed gathers
+    const bool tiled = graph->nn_tile_col_ptr && c == 32 && (int64_t)nr * c * 4 < (int64_t(1) << 31);   // buffer-addressed gathers
     if (tiled) {
         const float *roots[kMaxDepth];
         for (int i = 0; i < D; ++i) roots[i] = P.f(P.layer(i) + 6);
@@ -284,20 +344,21 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     TGNN_TRY(tgnn_dense_act_fwd(x, fx, 32, nullptr, P.f(P.init(0)), P.f(P.init(0) + 1), n, fx, c, TGNN_ACT_LEAKY_RELU,
                                 w.t0, c, w.partf, &np1, s));
     prof.end();
-    finalize1(w.partf, np1, c, P.bn(P.init(0) + 2), w.stat_i[0]);
+    TGNN_TRY(finalize1(w.partf, np1, c, P.bn(P.init(0) + 2), w.stat_i[0]));
     prof.begin(1);
     TGNN_TRY(tgnn_dense_act_fwd(w.t0, c, 32, w.stat_i[0], P.f(P.init(1)), P.f(P.init(1) + 1), n, c, c,
                                 TGNN_ACT_LEAKY_RELU, w.a1, c, w.partf, &np1, s));
     prof.end();
-    finalize1(w.partf, np1, c, P.bn(P.init(1) + 2), w.stat_i[1]);
+    TGNN_TRY(finalize1(w.partf, np1, c, P.bn(P.init(1) + 2), w.stat_i[1]));
     prof.begin(1);
     TGNN_TRY(tgnn_bn_apply(w.a1, c, w.stat_i[1], n, c, w.mid, c, s));  // middle[0] = brch_1 = brch_2 (:55,58)
     prof.end();
+    TGNN_TRY(exchange(0, nullptr, nullptr));
 
     // ---- main loop (TilinGNN.py:59-71)
     for (int i = 0; i < D; ++i) {
         const int b = P.layer(i);
-        const float *h1 = w.mid + (size_t)i * n * c;
+        const float *h1 = w.mid + (size_t)i * nr * c;
         if (s2) {   // everything layer i reads (middle[i], a2_{i-1}, its BN record) is complete on `s` here
             TGNN_CHECK_HIP(hipEventRecord(ev_fork, s));
             TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev_fork, 0));
@@ -334,16 +395,15 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
                                 (update_running && !use_running_stats) ? b1.nbt : nullptr, w.stat1};
             jobs.job[1] = BnJob{w.part2, np2, nullptr, b2.gamma, b2.beta, run ? b2.rm : nullptr, run ? b2.rv : nullptr,
                                 (update_running && !use_running_stats) ? b2.nbt : nullptr, w.stat2[i & 1]};
-            prof.begin(4);
-            launch_bn_finalize(jobs, 2, fin_mode, c, n, eps, momentum, s);
-            prof.end();
+            TGNN_TRY(finalize_jobs(jobs, 2, c));
         }
         // merge (:64-71): middle[i+1] = BN1(a1) * BN2(a2) (+ middle[i-2])
-        const float *resid = i >= 2 ? w.mid + (size_t)(i - 2) * n * c : nullptr;
+        const float *resid = i >= 2 ? w.mid + (size_t)(i - 2) * nr * c : nullptr;
         prof.begin(5);
         TGNN_TRY(tgnn_merge_fwd(w.a1, w.stat1, w.a2[i & 1], w.stat2[i & 1], resid, n, c,
-                                w.mid + (size_t)(i + 1) * n * c, nullptr, s));
+                                w.mid + (size_t)(i + 1) * nr * c, nullptr, s));
         prof.end();
+        if (i + 1 < D) TGNN_TRY(exchange(i + 1, w.a2[i & 1], w.a2[i & 1]));
     }
 
     // ---- K11: final MLP over the concatenation (TilinGNN.py:74-76); K block kb = middle[kb]
@@ -355,7 +415,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         if (l == 0) {
             TGNN_CHECK_ARG(c == 32, "final MLP over the slot-major buffer needs network_width == 32");
             prof.begin(6);
-            TGNN_TRY(tgnn_dense_act_fwd(w.mid, c, (int64_t)n * c, nullptr, P.f(pi), P.f(pi + 1), n, cat_dim, fdim[1],
+            TGNN_TRY(tgnn_dense_act_fwd(w.mid, c, (int64_t)nr * c, nullptr, P.f(pi), P.f(pi + 1), n, cat_dim, fdim[1],
                                         TGNN_ACT_LEAKY_RELU, fbuf[0], fdim[1], w.partf, &np1, s));
             prof.end();
         } else {
@@ -364,7 +424,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
                                         fdim[l + 1], TGNN_ACT_LEAKY_RELU, fbuf[l], fdim[l + 1], w.partf, &np1, s));
             prof.end();
         }
-        finalize1(w.partf, np1, fdim[l + 1], P.bn(pi + 2), w.stat_f[l]);
+        TGNN_TRY(finalize1(w.partf, np1, fdim[l + 1], P.bn(pi + 2), w.stat_f[l]));
     }
     prof.begin(6);
     TGNN_TRY(tgnn_dense_act_fwd(fbuf[3], c, 32, w.stat_f[3], P.f(P.last()), P.f(P.last() + 1), n, c, dims->output_dim,
@@ -381,6 +441,16 @@ extern "C" int tgnn_forward(const tgnn_model_dims *dims, const void *const *para
     Prof prof;
     return forward_impl(dims, params_host, x, adj_edge_attr, graph, update_running, use_running_stats, probs, ws,
                         ws_bytes, stream, stream2, prof);
+}
+
+extern "C" int tgnn_forward_sharded(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
+                                    const float *adj_edge_attr, const tgnn_graph *graph, const tgnn_shard *shard,
+                                    int32_t update_running, float *probs, void *ws, size_t ws_bytes,
+                                    tgnn_stream_t stream) {
+    TGNN_CHECK_ARG(shard, "null shard");
+    Prof prof;
+    return forward_impl(dims, params_host, x, adj_edge_attr, graph, update_running, 0, probs, ws, ws_bytes, stream,
+                        nullptr, prof, shard);
 }
 
 extern "C" int tgnn_forward_profiled(const tgnn_model_dims *dims, const void *const *params_host, const float *x,

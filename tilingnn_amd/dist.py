@@ -346,6 +346,129 @@ class LocalSimComm:
         return results
 
 
+class FusedShardForward:
+    """One shard's forward through `tgnn_forward_sharded` (csrc/forward.hip): the whole schedule of ShardProgram in
+    ONE library call that enqueues ~150 launches and calls back for the 47 collectives -- the per-op Python
+    schedule above costs ~2x the GPU time in host overhead at 100k nodes.  `comm` supplies
+    allreduce(tensor) and alltoall(send, send_splits, recv, recv_splits)."""
+
+    def __init__(self, net, shard: Shard, device, comm, inputs=None):
+        import ctypes as C
+        from . import _lib, ops
+        self._C, self._lib, self._ops = C, _lib, ops
+        self.net, self.shard, self.comm, self.dev = net, shard, comm, torch.device(device)
+        assert shard.send_ids is not None, "shard.send_ids not set: run the communicator's setup first"
+        self.inputs = inputs if inputs is not None else HipBackend(device).upload(shard)
+        c = net.network_width
+        self.n_send = int(self.inputs["send_idx"].shape[0])
+        self.n_halo = shard.n_rows - shard.n_own
+        self.send_splits = [int(x.shape[0]) for x in shard.send_ids]
+        self.recv_splits = list(shard.recv_counts)
+        self.sum_buf = torch.zeros(2 * 2 * 256, dtype=torch.float64, device=self.dev)
+        self.send_buf = torch.zeros(max(self.n_send, 1) * 2 * c, dtype=torch.float32, device=self.dev)
+        self.recv_buf = torch.zeros(max(self.n_halo, 1) * 2 * c, dtype=torch.float32, device=self.dev)
+        self._error = None
+
+        def allreduce_cb(_ctx, _buf, count, _stream):
+            try:
+                self.comm.allreduce(self.sum_buf[:count])
+                return 0
+            except BaseException as exc:                      # never let an exception cross the C frame
+                self._error = exc
+                return 1
+
+        def alltoall_cb(_ctx, _send, _recv, row_floats, _stream):
+            try:
+                send = self.send_buf[: self.n_send * row_floats].view(self.n_send, row_floats)
+                recv = self.recv_buf[: self.n_halo * row_floats].view(self.n_halo, row_floats)
+                self.comm.alltoall(send, self.send_splits, recv, self.recv_splits)
+                return 0
+            except BaseException as exc:
+                self._error = exc
+                return 1
+
+        self._cbs = (_lib.ALLREDUCE_CB(allreduce_cb), _lib.ALLTOALL_CB(alltoall_cb))   # keep them alive
+
+    def step(self) -> Tensor:
+        """Graph preparation + forward of this shard; returns probs of the owned rows."""
+        C, _lib, ops, sh, net = self._C, self._lib, self._ops, self.shard, self.net
+        inp = self.inputs
+        graph = ops.prepare_graph(sh.n_own, inp["adj"], inp["attr"], inp["col"], n_src_nodes=sh.n_rows)
+        dims = net._dims()
+        table, _ = net._param_table()
+        ws_bytes = _lib.lib.tgnn_forward_sharded_workspace_bytes(C.byref(dims), sh.n_own, sh.n_rows, graph.n_types)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.dev)
+        probs = torch.empty(sh.n_own, net.output_dim, dtype=torch.float32, device=self.dev)
+        desc = _lib.ShardDesc(sh.n_own, sh.n_rows, sh.n_total, inp["send_idx"].data_ptr(), self.n_send,
+                              self.sum_buf.data_ptr(), self.send_buf.data_ptr(), self.recv_buf.data_ptr(),
+                              self._cbs[0], self._cbs[1], None)
+        g = graph.c_struct()
+        self._error = None
+        rc = _lib.lib.tgnn_forward_sharded(C.byref(dims), table, ops.ptr(inp["x"]), ops.ptr(inp["attr"]), C.byref(g),
+                                           C.byref(desc), int(net.training), ops.ptr(probs), ops.ptr(ws), ws_bytes,
+                                           _lib.current_stream(self.dev))
+        if self._error is not None:
+            raise self._error
+        _lib.check(rc)
+        return probs
+
+
+class TorchDistCollectives:
+    """allreduce / alltoall of FusedShardForward over torch.distributed ("nccl" = RCCL)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+
+    def allreduce(self, t: Tensor) -> None:
+        self.dist.all_reduce(t, group=self.group)
+
+    def alltoall(self, send: Tensor, send_splits, recv: Tensor, recv_splits) -> None:
+        self.dist.all_to_all_single(recv, send, output_split_sizes=recv_splits, input_split_sizes=send_splits,
+                                    group=self.group)
+
+
+class ThreadSimCollectives:
+    """P virtual ranks = P Python threads on ONE device and ONE stream (tests): a collective is a rendezvous on a
+    barrier plus plain tensor copies.  ctypes releases the GIL for the duration of the library call and takes it
+    again inside the callbacks, so the ranks really interleave at the collectives like separate processes do."""
+
+    class Hub:
+        def __init__(self, world: int):
+            import threading
+            self.world, self.barrier = world, threading.Barrier(world)
+            self.slots = [None] * world
+
+    def __init__(self, hub: "ThreadSimCollectives.Hub", rank: int):
+        self.hub, self.rank = hub, rank
+
+    def allreduce(self, t: Tensor) -> None:
+        hub = self.hub
+        hub.slots[self.rank] = t
+        hub.barrier.wait()
+        total = torch.stack(list(hub.slots)).sum(0) if self.rank == 0 else None
+        if self.rank == 0:
+            hub.total = total
+        hub.barrier.wait()
+        t.copy_(hub.total)
+        hub.barrier.wait()
+
+    def alltoall(self, send: Tensor, send_splits, recv: Tensor, recv_splits) -> None:
+        hub = self.hub
+        hub.slots[self.rank] = (send, send_splits)
+        hub.barrier.wait()
+        off = 0
+        for src in range(hub.world):
+            k = recv_splits[src]
+            if k:
+                s_send, s_splits = hub.slots[src]
+                s0 = sum(s_splits[: self.rank])
+                assert s_splits[self.rank] == k
+                recv[off:off + k].copy_(s_send[s0:s0 + k])
+            off += k
+        hub.barrier.wait()
+
+
 class ShardedTilinGNN:
     """bench.py's handle on the multi-GPU path: rank `rank` of `world`, RCCL collectives."""
 
@@ -358,8 +481,12 @@ class ShardedTilinGNN:
         self.n_local, self.ea_local, self.ec_local = shard.n_own, int(shard.adj.shape[1]), int(shard.col.shape[1])
         self.inputs = self.backend.upload(shard)          # resident in HBM before any timed step
         self.program = None
+        self.fused = FusedShardForward(net, shard, device, TorchDistCollectives(group), inputs=self.inputs)
 
-    def step(self) -> Tensor:
-        """One forward of this rank's shard, graph preparation included (as in the 1-GPU benchmark)."""
+    def step(self, fused: bool = True) -> Tensor:
+        """One forward of this rank's shard, graph preparation included (as in the 1-GPU benchmark).
+        fused=False runs the per-op Python schedule (ShardProgram) instead of tgnn_forward_sharded."""
+        if fused:
+            return self.fused.step()
         self.program = ShardProgram(self.net, self.shard, self.backend, inputs=self.inputs)
         return self.comm.run(self.program)
