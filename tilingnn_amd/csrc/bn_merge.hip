@@ -20,15 +20,26 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(BnJobs jobs, int mode
     __shared__ double tot[512];
     const BnJob jb = jobs.job[blockIdx.x];
     const int tid = threadIdx.x, two_f = 2 * f;
+    // the affine parameters and running buffers are fetched up front: their round trip then overlaps the partial
+    // rows' instead of following it (this 1-block kernel is pure latency)
+    float pre_gamma = 1.f, pre_beta = 0.f, pre_rm = 0.f, pre_rv = 1.f;
+    if (tid < f && mode != 1) {
+        pre_gamma = jb.gamma[tid];
+        pre_beta = jb.beta[tid];
+        if (jb.running_mean) {
+            pre_rm = jb.running_mean[tid];
+            pre_rv = jb.running_var[tid];
+        }
+    }
     if (mode == 3) {
         if (tid < f) {
-            const double mean = (double)jb.running_mean[tid];
-            const double var = (double)jb.running_var[tid];
+            const double mean = (double)pre_rm;
+            const double var = (double)pre_rv;
             const float mh = (float)mean;
             jb.stat[tid] = mh;
             jb.stat[f + tid] = (float)(mean - (double)mh);
-            jb.stat[2 * f + tid] = (float)((double)jb.gamma[tid] / sqrt(var + (double)eps));
-            jb.stat[3 * f + tid] = jb.beta[tid];
+            jb.stat[2 * f + tid] = (float)((double)pre_gamma / sqrt(var + (double)eps));
+            jb.stat[3 * f + tid] = pre_beta;
         }
         return;
     }
@@ -79,12 +90,12 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(BnJobs jobs, int mode
         const float mh = (float)mean;
         jb.stat[tid] = mh;
         jb.stat[f + tid] = (float)(mean - (double)mh);
-        jb.stat[2 * f + tid] = (float)((double)jb.gamma[tid] / sqrt(var + (double)eps));
-        jb.stat[3 * f + tid] = jb.beta[tid];
+        jb.stat[2 * f + tid] = (float)((double)pre_gamma / sqrt(var + (double)eps));
+        jb.stat[3 * f + tid] = pre_beta;
         if (jb.running_mean) {
             const double unbiased = n_total > 1 ? var * ((double)n_total / (double)(n_total - 1)) : var;
-            jb.running_mean[tid] = (float)((1.0 - (double)momentum) * (double)jb.running_mean[tid] + (double)momentum * mean);
-            jb.running_var[tid] = (float)((1.0 - (double)momentum) * (double)jb.running_var[tid] + (double)momentum * unbiased);
+            jb.running_mean[tid] = (float)((1.0 - (double)momentum) * (double)pre_rm + (double)momentum * mean);
+            jb.running_var[tid] = (float)((1.0 - (double)momentum) * (double)pre_rv + (double)momentum * unbiased);
         }
     }
     if (tid == 0 && jb.num_batches_tracked) *jb.num_batches_tracked += 1;
