@@ -280,10 +280,10 @@ __global__ __launch_bounds__(kNNThreads) void nnconv32_lds_kernel(
 // ------------------------------------------------------------------------------------------
 // Weight image of the matrix-core kernel (nnconv_cols.hip), built once per forward for all layers.
 // ------------------------------------------------------------------------------------------
-// wtab [T][32][32] (+ root [32][32] as pseudo-type T) -> MFMA operand image [(T+1)][2][16][36]:
-// element (i, o) of type t -> wimg[t][o >> 4][o & 15][(i >> 3) * 8 + (i & 7)]  (row padded 32 -> 36 floats).
-// grid = (T+1, layers); done once per layer so that every NNConv block fills its LDS with a straight
-// coalesced float4 copy instead of a 28-trip scatter.
+// wtab [T][32][32] (+ root [32][32] as pseudo-type T) -> MFMA operand image, every weight split exactly into three
+// bf16 pieces (hi + mid + lo):  element (k, o) of type t -> plane p, M block o >> 4, row o & 15, group k >> 3,
+// element k & 7.  grid = (T+1, layers); done once per forward so that every NNConv block fills its LDS with a
+// straight coalesced 16-byte copy.
 struct RootPtrs {
     const float *p[kMaxDepth];
 };
@@ -291,13 +291,19 @@ __global__ __launch_bounds__(256) void nnconv_weight_image_kernel(const float *_
                                                                   int n_types, float *__restrict__ wimg_all) {
     const int t = blockIdx.x, layer = blockIdx.y;
     const float *src = t < n_types ? wtab_all + ((int64_t)layer * n_types + t) * 1024 : roots.p[layer];
-    float *dst = wimg_all + ((int64_t)layer * (n_types + 1) + t) * kWtType;
+    __bf16 *dst = reinterpret_cast<__bf16 *>(wimg_all + ((int64_t)layer * (n_types + 1) + t) * kWtType);
     for (int r = threadIdx.x; r < 1024; r += 256) {
-        const int i = r >> 5, o = r & 31;
-        dst[(o >> 4) * kWtNt + (o & 15) * 36 + (i >> 3) * 8 + (i & 7)] = src[r];
+        const int k = r >> 5, o = r & 31;                    // wtab flat index k * 32 + o (NNConv's .view(-1, C_in, C_out))
+        const float x = src[r];
+        const __bf16 h = (__bf16)x;
+        const float r1 = x - (float)h;                       // exact
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;                      // exact
+        const int at = (((o >> 4) * 16 + (o & 15)) * 4 + (k >> 3)) * 8 + (k & 7);
+        dst[0 * kWtPlane * 2 + at] = h;                      // (kWtPlane floats = 2 kWtPlane bf16)
+        dst[1 * kWtPlane * 2 + at] = m;
+        dst[2 * kWtPlane * 2 + at] = (__bf16)r2;
     }
-    for (int k = threadIdx.x; k < 2 * 16 * 4; k += 256)      // zero the 4 padding floats of every row
-        dst[(k >> 6) * kWtNt + ((k >> 2) & 15) * 36 + 32 + (k & 3)] = 0.f;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -24,6 +24,7 @@
 namespace tgnn {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 #ifdef TGNN_TIMING
 __device__ unsigned long long g_col_timing[512 * 8 * 8];
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
     const int *__restrict__ col_src, const float *__restrict__ wimg, int n_types, const float *__restrict__ bias,
     int64_t n, int act, float *__restrict__ out, double *__restrict__ bn_partial) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *wl = lds;                                        // [(T+1)][2][16][36]
+    float *wl = lds;                                        // [(T+1)][3 planes][2 M blocks][16][4] x 8 bf16
     float *stage = lds + (n_types + 1) * kWtType;           // [WAVES][16][20]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fj = lane & 15, fq = lane >> 4;
@@ -147,30 +148,40 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
         }
         TGNN_CT(1)
         if (mu & kColMetaLast) {
-            const float *wp = wl + t * kWtType + fj * 36 + fq * 8;
-            const float4 p0 = *reinterpret_cast<const float4 *>(wp), p1 = *reinterpret_cast<const float4 *>(wp + 4);
-            const float4 p2 = *reinterpret_cast<const float4 *>(wp + kWtNt), p3 = *reinterpret_cast<const float4 *>(wp + kWtNt + 4);
-            const float bw0[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
-            const float bw1[8] = {p2.x, p2.y, p2.z, p2.w, p3.x, p3.y, p3.z, p3.w};
-#ifdef TGNN_ABL_NOMFMA
-            if (true) {
+            // bf16 x 3 split precision (see dense.hip): the summed source rows are split exactly into hi + mid + lo,
+            // the weights were split when the image was built; six cross terms per M block, smallest first, fp32
+            // accumulation -- 12 MFMAs of ~18 cycles with K = 32 in one instruction instead of 16 fp32 MFMAs of ~36.
+            // Matrix and vector time ADD on this chip, so the matrix cycles saved pay for the 44 split instructions.
+            bf16x8 xh, xm, xl;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { de0[k & 3] += bw0[k] * af[k]; de1[k & 3] += bw1[k] * af[k]; }
-            } else
-#endif
-            if (t == n_types) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    dr0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw0[k], af[k], dr0, 0, 0, 0);
-                    dr1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw1[k], af[k], dr1, 0, 0, 0);
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    de0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw0[k], af[k], de0, 0, 0, 0);
-                    de1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw1[k], af[k], de1, 0, 0, 0);
-                }
+            for (int k = 0; k < 8; ++k) {
+                const __bf16 h = (__bf16)af[k];
+                const float r1 = af[k] - (float)h;           // exact
+                const __bf16 m = (__bf16)r1;
+                const float r2 = r1 - (float)m;              // exact
+                xh[k] = h; xm[k] = m; xl[k] = (__bf16)r2;
             }
+            const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(wl + t * kWtType) + fj * 4 + fq;
+            constexpr int kPl = kWtPlane / 4;                // 16-byte fragments per plane
+            const bf16x8 h0 = wp[0], h1 = wp[64], m0 = wp[kPl], m1 = wp[kPl + 64], l0 = wp[2 * kPl], l1 = wp[2 * kPl + 64];
+            f32x4 c0 = t == n_types ? dr0 : de0, c1 = t == n_types ? dr1 : de1;   // wave-uniform select
+#ifdef TGNN_ABL_NOMFMA
+            c0[0] += (float)h0[0] * af[0]; c1[0] += (float)h1[0] * af[0];
+#else
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l0, xh, c0, 0, 0, 0);   // lo . hi
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l1, xh, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0, xl, c0, 0, 0, 0);   // hi . lo
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, xl, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(m0, xm, c0, 0, 0, 0);   // mid . mid
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(m1, xm, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(m0, xh, c0, 0, 0, 0);   // mid . hi
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(m1, xh, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0, xm, c0, 0, 0, 0);   // hi . mid
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, xm, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0, xh, c0, 0, 0, 0);   // hi . hi
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, xh, c1, 0, 0, 0);
+#endif
+            if (t == n_types) { dr0 = c0; dr1 = c1; } else { de0 = c0; de1 = c1; }
         }
         TGNN_CT(2)
         if (mu & kColMetaEnd) {
@@ -323,12 +334,14 @@ int launch_nnconv_cols(const float *h, int64_t ldh, const int32_t *tile_col_ptr,
                        const int32_t *col_src, const float *wimg, int32_t n_types, const float *bias,
                        int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
                        hipStream_t s) {
-    // blocks per CU by what the LDS weight image leaves room for (2 at T <= 16).
-    // Measured at N = 100k, T = 13 (us): <depth 4, 16 waves/CU> 55.7 | <16, 8> 66.0 | <8, 8> 64.9 | <16, 4> 85.2 | <32, 4> 90.2
-    const size_t per_block = cols_lds_bytes(n_types, 8);
-    const int bpc = per_block * 2 <= 160 * 1024 ? 2 : 1;
-    return launch_cols_t<4, 8, 4>(h, ldh, tile_col_ptr, col_meta, col_src, wimg, n_types, bias, n_nodes, act, out,
-                                  bn_partial, n_partials_host, bpc, s);
+    // 16 waves per CU either way: two 8-wave blocks when two 6 KB-per-type weight images fit the LDS (T <= 11), else
+    // one 16-wave block.  Measured with the fp32 kernel at N = 100k, T = 13 (us): <depth 4, 16 waves/CU> 55.7 |
+    // <16, 8> 66.0 | <8, 8> 64.9 | <16, 4> 85.2 | <32, 4> 90.2
+    if (cols_lds_bytes(n_types, 8) * 2 <= 160 * 1024)
+        return launch_cols_t<4, 8, 4>(h, ldh, tile_col_ptr, col_meta, col_src, wimg, n_types, bias, n_nodes, act, out,
+                                      bn_partial, n_partials_host, 2, s);
+    return launch_cols_t<4, 16, 4>(h, ldh, tile_col_ptr, col_meta, col_src, wimg, n_types, bias, n_nodes, act, out,
+                                   bn_partial, n_partials_host, 1, s);
 }
 
 }  // namespace tgnn
@@ -341,7 +354,7 @@ extern "C" int tgnn_debug_col_timing(unsigned long long *host_out) {
 using namespace tgnn;
 
 extern "C" int32_t tgnn_nnconv_cols_max_types(void) {
-    return (int32_t)((kColsMaxLds / sizeof(float) - 8 * kColStage) / kWtType) - 1;
+    return (int32_t)((kColsMaxLds / sizeof(float) - 16 * kColStage) / kWtType) - 1;
 }
 
 extern "C" int tgnn_nnconv_mean_cols_fwd(const float *h, int64_t ldh, const int32_t *tile_col_ptr,

@@ -116,6 +116,8 @@ int launch_nnconv_cols(const float *h, int64_t ldh, const int32_t *tile_col_ptr,
                        const int32_t *col_src, const float *wimg, int32_t n_types, const float *bias,
                        int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
                        hipStream_t s);
-constexpr int kWtNt = 16 * 36;             // floats per (type, column tile) of the MFMA weight image: [j=16][q=4][ks=8], row stride 36
-constexpr int kWtType = 2 * kWtNt;         // floats per type
+// MFMA weight image of the column NNConv, per type: [plane 3 (hi, mid, lo)][M block 2][i 16][g 4] x 8 bf16 --
+// the A fragment of lane (i, g) for one (plane, M block) is one 16-byte read; 6144 B = 1536 floats per type
+constexpr int kWtPlane = 2 * 64 * 4;       // floats (16-byte fragments x 4) per plane
+constexpr int kWtType = 3 * kWtPlane;      // floats per type
 }  // namespace tgnn
