@@ -234,9 +234,10 @@ size_t tgnn_forward_workspace_bytes(const tgnn_model_dims *dims, int64_t n_nodes
 /* probs [N, output_dim].  BatchNorm runs with batch statistics and updates the running buffers
  * in `params` when update_running != 0 (train mode); with use_running_stats != 0 it normalises
  * with the running buffers instead (eval mode; never used by the reference's solver).
- * With stream2 != NULL (and != stream) the collision branch of every layer (TilinGNN.py:63) is enqueued on
- * stream2 beside the adjacency branch (:62) it does not depend on; the library forks and joins with events, so
- * on return all work is ordered on `stream` and the caller needs no synchronisation of its own with stream2. */
+ * With stream2 != NULL (and != stream) the collision branch -- a chain of its own, CollConv_i reads only
+ * CollConv_{i-1} (TilinGNN.py:63) -- is enqueued on stream2 and runs free beside the adjacency branch; the two
+ * meet at the product of :64 through events the library records itself, so on return all work is ordered on
+ * `stream` and the caller needs no synchronisation of its own with stream2. */
 int tgnn_forward(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
                  const float *adj_edge_attr, const tgnn_graph *graph, int32_t update_running,
                  int32_t use_running_stats, float *probs, void *ws, size_t ws_bytes,

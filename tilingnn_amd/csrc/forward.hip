@@ -242,23 +242,24 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         return TGNN_ERR_WORKSPACE;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // Two-stream schedule: the collision branch of layer i (GINConv, TilinGNN.py:63) does not depend on the
-    // adjacency branch (:62); with a side stream it runs beside NNConv, whose gather-latency-bound waves leave
-    // issue slots and whole CUs (tail) idle.  Fork after merge_{i-1}, join before the BN finalize of layer i.
+    // Two-chain schedule: the collision branch is a chain of its own -- CollConv_i reads only CollConv_{i-1}
+    // (TilinGNN.py:63); the branches meet in the product of :64 only.  With a side stream the whole GIN chain runs
+    // free beside the NNConv chain and fills the GPU wherever the latter leaves it idle (1-block BN finalizes, the
+    // HBM-bound merge, kernel tails); it is held back only by the two-deep buffers it shares with merge.
     hipStream_t s2 = (prof.on || sh) ? nullptr : static_cast<hipStream_t>(stream2);
     if (s2 == s) s2 = nullptr;
-    static thread_local hipEvent_t ev_cache[64][2] = {};   // per calling thread and device; never destroyed
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // Events of the two-chain schedule, per calling thread and device; created once, never destroyed.
+    constexpr int kEvPerDev = 1 + 2 * kMaxDepth;            // [0] init done, [1 + i] GIN_i done, [1 + kMaxDepth + i] merge_i done
+    static thread_local hipEvent_t ev_cache[64][kEvPerDev] = {};
+    hipEvent_t *ev = nullptr;
     if (s2) {
         int dev = 0;
         TGNN_CHECK_HIP(hipGetDevice(&dev));
         TGNN_CHECK_ARG(dev >= 0 && dev < 64, "device index");
-        if (!ev_cache[dev][0]) {
-            TGNN_CHECK_HIP(hipEventCreateWithFlags(&ev_cache[dev][0], hipEventDisableTiming));
-            TGNN_CHECK_HIP(hipEventCreateWithFlags(&ev_cache[dev][1], hipEventDisableTiming));
-        }
-        ev_fork = ev_cache[dev][0];
-        ev_join = ev_cache[dev][1];
+        if (!ev_cache[dev][0])
+            for (int k = 0; k < kEvPerDev; ++k)
+                TGNN_CHECK_HIP(hipEventCreateWithFlags(&ev_cache[dev][k], hipEventDisableTiming));
+        ev = ev_cache[dev];
     }
     prof.s = s;
     const int c = dims->network_width, D = dims->network_depth, fx = dims->node_features_dim,
@@ -356,12 +357,38 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     TGNN_TRY(exchange(0, nullptr, nullptr));
 
     // ---- main loop (TilinGNN.py:59-71)
+    const bool run_stats = update_running || use_running_stats;
+    auto bn_job = [&](double *part, int nparts, const BnPtrs &bp, float *stat) {
+        return BnJob{part, nparts, nullptr, bp.gamma, bp.beta, run_stats ? bp.rm : nullptr, run_stats ? bp.rv : nullptr,
+                     (update_running && !use_running_stats) ? bp.nbt : nullptr, stat};
+    };
+    // CollConv (:63): input = BN_{i-1}(a2_{i-1}) folded into the gather; layer 0 reads middle[0]
+    auto gin_layer = [&](int i, hipStream_t gs) -> int {
+        const int b = P.layer(i);
+        const float *gin_in = i == 0 ? w.mid : w.a2[(i - 1) & 1];
+        const float *gin_stat = i == 0 ? nullptr : w.stat2[(i - 1) & 1];
+        prof.begin(3);
+        TGNN_TRY(tgnn_gin_fwd(gin_in, c, gin_stat, graph->col_rowptr, graph->col_src, P.f(b + 13), P.f(b + 14),
+                              P.f(b + 15), P.f(b + 16), P.f(b + 17), P.f(b + 18), P.f(b + 19), n, c,
+                              TGNN_ACT_LEAKY_RELU, w.a2[i & 1], w.t0, w.part2, &np2, gs));
+        prof.end();
+        return TGNN_OK;
+    };
+    if (s2) {
+        TGNN_CHECK_HIP(hipEventRecord(ev[0], s));            // middle[0] is complete
+        TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[0], 0));
+    }
     for (int i = 0; i < D; ++i) {
         const int b = P.layer(i);
         const float *h1 = w.mid + (size_t)i * nr * c;
-        if (s2) {   // everything layer i reads (middle[i], a2_{i-1}, its BN record) is complete on `s` here
-            TGNN_CHECK_HIP(hipEventRecord(ev_fork, s));
-            TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev_fork, 0));
+        if (s2) {
+            // ---- collision chain, layer i, on the side stream: a2[i & 1] / stat2[i & 1] were last read by merge_{i-2}
+            if (i >= 2) TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[1 + kMaxDepth + i - 2], 0));
+            TGNN_TRY(gin_layer(i, s2));
+            BnJobs j2{};
+            j2.job[0] = bn_job(w.part2, np2, P.bn(b + 20), w.stat2[i & 1]);
+            launch_bn_finalize(j2, 1, fin_mode, c, n, eps, momentum, s2);
+            TGNN_CHECK_HIP(hipEventRecord(ev[1 + i], s2));
         }
         // GraphConv (:62): NNConv mean + LeakyReLU; BN statistics emitted as partials
         prof.begin(2);
@@ -375,26 +402,16 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
                                       TGNN_ACT_LEAKY_RELU, w.a1, w.part1, &np1, s));
         }
         prof.end();
-        // CollConv (:63): input = BN_{i-1}(a2_{i-1}) folded into the gather; layer 0 reads middle[0]
-        const float *gin_in = i == 0 ? w.mid : w.a2[(i - 1) & 1];
-        const float *gin_stat = i == 0 ? nullptr : w.stat2[(i - 1) & 1];
-        prof.begin(3);
-        TGNN_TRY(tgnn_gin_fwd(gin_in, c, gin_stat, graph->col_rowptr, graph->col_src, P.f(b + 13), P.f(b + 14),
-                              P.f(b + 15), P.f(b + 16), P.f(b + 17), P.f(b + 18), P.f(b + 19), n, c,
-                              TGNN_ACT_LEAKY_RELU, w.a2[i & 1], w.t0, w.part2, &np2, s2 ? s2 : s));
-        prof.end();
         if (s2) {
-            TGNN_CHECK_HIP(hipEventRecord(ev_join, s2));
-            TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev_join, 0));
-        }
-        {
-            const BnPtrs b1 = P.bn(b + 8), b2 = P.bn(b + 20);
-            const bool run = update_running || use_running_stats;
+            BnJobs j1{};
+            j1.job[0] = bn_job(w.part1, np1, P.bn(b + 8), w.stat1);
+            launch_bn_finalize(j1, 1, fin_mode, c, n, eps, momentum, s);
+            TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[1 + i], 0));
+        } else {
+            TGNN_TRY(gin_layer(i, s));
             BnJobs jobs{};
-            jobs.job[0] = BnJob{w.part1, np1, nullptr, b1.gamma, b1.beta, run ? b1.rm : nullptr, run ? b1.rv : nullptr,
-                                (update_running && !use_running_stats) ? b1.nbt : nullptr, w.stat1};
-            jobs.job[1] = BnJob{w.part2, np2, nullptr, b2.gamma, b2.beta, run ? b2.rm : nullptr, run ? b2.rv : nullptr,
-                                (update_running && !use_running_stats) ? b2.nbt : nullptr, w.stat2[i & 1]};
+            jobs.job[0] = bn_job(w.part1, np1, P.bn(b + 8), w.stat1);
+            jobs.job[1] = bn_job(w.part2, np2, P.bn(b + 20), w.stat2[i & 1]);
             TGNN_TRY(finalize_jobs(jobs, 2, c));
         }
         // merge (:64-71): middle[i+1] = BN1(a1) * BN2(a2) (+ middle[i-2])
@@ -403,6 +420,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         TGNN_TRY(tgnn_merge_fwd(w.a1, w.stat1, w.a2[i & 1], w.stat2[i & 1], resid, n, c,
                                 w.mid + (size_t)(i + 1) * nr * c, nullptr, s));
         prof.end();
+        if (s2) TGNN_CHECK_HIP(hipEventRecord(ev[1 + kMaxDepth + i], s));
         if (i + 1 < D) TGNN_TRY(exchange(i + 1, w.a2[i & 1], w.a2[i & 1]));
     }
 
