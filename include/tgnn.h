@@ -130,7 +130,7 @@ int tgnn_nnconv_mean_fwd(const float *h, int64_t ldh, const int32_t *rowptr, con
  *   tile_col_ptr int32 [ceil(N/16)+1]   column range of every tile
  *   col_meta     int32 [n_cols]         type | first-of-type << 8 | last-of-type << 9 | end-of-tile << 10
  *   col_src      int32 [16*n_cols]      source row per tile row, -1 = none; in a root column the float bits of
- *                                       1 / max(in-degree, 1), or -1 for rows >= N
+ *                                       max(in-degree, 1), or -1 for rows >= N
  * n_cols <= tgnn_nnconv_cols_max_columns(N, E) (allocate col_meta / col_src for that many: the kernel reads
  * index words a few columns past the end); the exact count is tile_col_ptr[ceil(N/16)].
  * Source rows must lie within 2 GB of h (buffer addressing): N_src * ldh * 4 < 2^31. */

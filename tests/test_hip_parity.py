@@ -104,7 +104,7 @@ def test_labyrinth_graph_has_13_edge_types(dev):
 def test_nnconv_column_structure(dev, n, e, t, seed):
     """Columns = per 16 destination rows, sorted by type: column (type k, rank r) holds every row's r-th in-edge
     of type k in CSR (= original) order or -1; as many columns per type as the tile's largest multiplicity; the
-    root column (type T, all three flags) closes the tile with 1/max(deg,1) as float bits, -1 beyond N."""
+    root column (type T, all three flags) closes the tile with max(deg,1) as float bits, -1 beyond N."""
     from tilingnn_amd import ops
     rng = np.random.default_rng(seed)
     ei = rng.integers(0, n, size=(2, e), dtype=np.int64)
@@ -140,9 +140,9 @@ def test_nnconv_column_structure(dev, n, e, t, seed):
             np.testing.assert_array_equal(meta[c0:c1 - 1], np.array(want_meta))
         assert meta[c1 - 1] == (t | FIRST | LAST | END)
         deg = np.diff(rp[r0:r1 + 1])
-        inv = (1.0 / np.maximum(deg, 1)).astype(np.float32)
+        degf = np.maximum(deg, 1).astype(np.float32)
         root = csrc[c1 - 1]
-        np.testing.assert_array_equal(root[: r1 - r0].astype(np.int32).view(np.float32), inv)
+        np.testing.assert_array_equal(root[: r1 - r0].astype(np.int32).view(np.float32), degf)
         assert (root[r1 - r0:] == -1).all()
 
 

@@ -337,7 +337,7 @@ __global__ void gather_i32_kernel(const int *__restrict__ src, int64_t n_src, co
 // ------------------------------------------------------------------------------------------
 // NNConv type columns (nnconv_cols.hip): per 16 destination rows a list of columns sorted by edge type;
 // column (t, r) holds the source of every row's r-th in-edge of type t (CSR = original order) or -1.
-// The last column of a tile is the root column (type T): 1/max(deg,1) as float bits, -1 for rows >= n.
+// The last column of a tile is the root column (type T): max(deg,1) as float bits, -1 for rows >= n.
 // col_meta = type | first-of-type << 8 | last-of-type << 9 | end-of-tile << 10.
 // One block = 64 rows = 4 tiles, one thread per row.
 // ------------------------------------------------------------------------------------------
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(64) void nnconv_col_kernel(const int *__restrict__ 
     }
     // root column
     const int deg = e1 - e0;
-    col_slot_src[(c0 + n_edge_cols) * 16 + i] = row < n ? __float_as_int(1.0f / (float)(deg > 0 ? deg : 1)) : -1;
+    col_slot_src[(c0 + n_edge_cols) * 16 + i] = row < n ? __float_as_int((float)(deg > 0 ? deg : 1)) : -1;
     if (i == 0) col_meta[c0 + n_edge_cols] = n_types | (1 << 8) | (1 << 9) | (1 << 10);
     // the 16 threads of a tile are lanes of one wavefront: their -1 stores above are ordered before these
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

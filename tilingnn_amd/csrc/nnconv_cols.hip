@@ -13,8 +13,8 @@
 // Layout built once per graph (graph_prep.hip: nnconv_col_*_kernel): for every 16-row tile a list of COLUMNS,
 // sorted by type; column (t, r) holds for each of the 16 rows the source of its r-th in-edge of type t or -1.
 // Columns of the same type are summed in registers (A-operand pre-add, CSR order), the last one of the run
-// triggers the 16 MFMAs against W_t.  The last column of a tile is the root column (type T): the row itself,
-// with 1/deg in the slot where the others keep the source row.
+// triggers the MFMAs against W_t.  The last column of a tile is the root column (type T): the row itself,
+// with max(deg, 1) in the slot where the others keep the source row.
 //
 // One wavefront owns a contiguous run of tiles and walks its columns as ONE stream through a DEPTH-deep
 // register pipeline (index load -> gather -> consume), across tile boundaries.  D^T = W^T . S^T is computed
@@ -131,7 +131,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
         if (root) ++gtile;                                   // wave-uniform
     };
 
-    f32x4 de0 = {0.f, 0.f, 0.f, 0.f}, de1 = de0, dr0 = de0, dr1 = de0;   // D^T tiles: edge sum / root term
+    // ONE accumulator pair: the root block's operand is pre-multiplied by max(deg, 1) (the root column carries it), so
+    // that a single 1/deg at the end turns the edge sum into the mean and leaves the root term as it is
+    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;               // D^T tiles: channels 4 fq + r and 16 + 4 fq + r of row fj
     float af[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t ctile = t0;
     auto consume = [&](int s, int mu, const float4 (&x)[2]) {
@@ -152,11 +154,14 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
             // the weights were split when the image was built; six cross terms per M block, smallest first, fp32
             // accumulation -- 12 MFMAs of ~18 cycles with K = 32 in one instruction instead of 16 fp32 MFMAs of ~36.
             // Matrix and vector time ADD on this chip, so the matrix cycles saved pay for the 44 split instructions.
+            const bool root = t == n_types;                  // wave-uniform
+            const float scale = root ? (s >= 0 ? __int_as_float(s) : 0.f) : 1.0f;   // root column: max(deg, 1) in the source slot
             bf16x8 xh, xm, xl;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const __bf16 h = (__bf16)af[k];
-                const float r1 = af[k] - (float)h;           // exact
+                const float a = af[k] * scale;
+                const __bf16 h = (__bf16)a;
+                const float r1 = a - (float)h;               // exact
                 const __bf16 m = (__bf16)r1;
                 const float r2 = r1 - (float)m;              // exact
                 xh[k] = h; xm[k] = m; xl[k] = (__bf16)r2;
@@ -164,35 +169,33 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
             const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(wl + t * kWtType) + fj * 4 + fq;
             constexpr int kPl = kWtPlane / 4;                // 16-byte fragments per plane
             const bf16x8 h0 = wp[0], h1 = wp[64], m0 = wp[kPl], m1 = wp[kPl + 64], l0 = wp[2 * kPl], l1 = wp[2 * kPl + 64];
-            f32x4 c0 = t == n_types ? dr0 : de0, c1 = t == n_types ? dr1 : de1;   // wave-uniform select
 #ifdef TGNN_ABL_NOMFMA
-            c0[0] += (float)h0[0] * af[0]; c1[0] += (float)h1[0] * af[0];
+            d0[0] += (float)h0[0] * af[0]; d1[0] += (float)h1[0] * af[0];
 #else
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l0, xh, c0, 0, 0, 0);   // lo . hi
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l1, xh, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0, xl, c0, 0, 0, 0);   // hi . lo
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, xl, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(m0, xm, c0, 0, 0, 0);   // mid . mid
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(m1, xm, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(m0, xh, c0, 0, 0, 0);   // mid . hi
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(m1, xh, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0, xm, c0, 0, 0, 0);   // hi . mid
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, xm, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0, xh, c0, 0, 0, 0);   // hi . hi
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, xh, c1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l0, xh, d0, 0, 0, 0);   // lo . hi
+            d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l1, xh, d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0, xl, d0, 0, 0, 0);   // hi . lo
+            d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, xl, d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(m0, xm, d0, 0, 0, 0);   // mid . mid
+            d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(m1, xm, d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(m0, xh, d0, 0, 0, 0);   // mid . hi
+            d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(m1, xh, d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0, xm, d0, 0, 0, 0);   // hi . mid
+            d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, xm, d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0, xh, d0, 0, 0, 0);   // hi . hi
+            d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, xh, d1, 0, 0, 0);
 #endif
-            if (t == n_types) { dr0 = c0; dr1 = c1; } else { de0 = c0; de1 = c1; }
         }
         TGNN_CT(2)
         if (mu & kColMetaEnd) {
             // lane (fj, fq): row fj of the tile, channels 4 fq .. 4 fq + 3 (de0/dr0) and 16 + the same (de1/dr1)
-            const float inv = valid ? __int_as_float(s) : 0.f;   // root column: 1/deg in the source slot
+            const float inv = valid ? 1.0f / __int_as_float(s) : 0.f;   // root column (always the last): max(deg, 1)
             const int64_t v = ctile * 16 + fj;
             float4 o0, o1;
-            o0.x = fmaf(de0[0], inv, dr0[0]) + bias0.x; o0.y = fmaf(de0[1], inv, dr0[1]) + bias0.y;
-            o0.z = fmaf(de0[2], inv, dr0[2]) + bias0.z; o0.w = fmaf(de0[3], inv, dr0[3]) + bias0.w;
-            o1.x = fmaf(de1[0], inv, dr1[0]) + bias1.x; o1.y = fmaf(de1[1], inv, dr1[1]) + bias1.y;
-            o1.z = fmaf(de1[2], inv, dr1[2]) + bias1.z; o1.w = fmaf(de1[3], inv, dr1[3]) + bias1.w;
+            o0.x = fmaf(d0[0], inv, bias0.x); o0.y = fmaf(d0[1], inv, bias0.y);
+            o0.z = fmaf(d0[2], inv, bias0.z); o0.w = fmaf(d0[3], inv, bias0.w);
+            o1.x = fmaf(d1[0], inv, bias1.x); o1.y = fmaf(d1[1], inv, bias1.y);
+            o1.z = fmaf(d1[2], inv, bias1.z); o1.w = fmaf(d1[3], inv, bias1.w);
             if (act == TGNN_ACT_LEAKY_RELU) {
                 o0.x = leakyf_(o0.x); o0.y = leakyf_(o0.y); o0.z = leakyf_(o0.z); o0.w = leakyf_(o0.w);
                 o1.x = leakyf_(o1.x); o1.y = leakyf_(o1.y); o1.z = leakyf_(o1.z); o1.w = leakyf_(o1.w);
@@ -225,7 +228,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
                 half_sums(o0, bs[0], bq[0]);
                 half_sums(o1, bs[1], bq[1]);
             }
-            de0 = f32x4{0.f, 0.f, 0.f, 0.f}; de1 = de0; dr0 = de0; dr1 = de0;
+            d0 = f32x4{0.f, 0.f, 0.f, 0.f};
+            d1 = d0;
             ++ctile;
         }
         TGNN_CT(3)

@@ -85,7 +85,7 @@ class NNConvColumns:
     """Per-16-row tiles of type-sorted source columns (tgnn_nnconv_cols_build, include/tgnn.h)."""
     tile_col_ptr: Tensor      # int32 [ceil(N/16) + 1]
     col_meta: Tensor          # int32 [cap]: type | first << 8 | last << 9 | end-of-tile << 10
-    col_src: Tensor           # int32 [16 * cap]: source row, -1 = none; root columns: float bits of 1/max(deg,1)
+    col_src: Tensor           # int32 [16 * cap]: source row, -1 = none; root columns: float bits of max(deg,1)
 
 
 def build_nnconv_columns(n_nodes: int, n_edges: int, n_types: int, rowptr: Tensor, col_src: Tensor,
