@@ -238,6 +238,27 @@ def main():
                                      "frac_of_hbm_peak": forward_bytes(n_total, ea_total, ec_total, graph.n_types)
                                      / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
+    # ---- the loss ML_Solver.predict evaluates on the probabilities: two launches, HBM bound
+    loss_info = None
+    if not sharded:
+        from tilingnn_amd.solver.ml_solver.losses import Losses
+        p1 = torch.rand(n_total, 1, device=dev)
+        for _ in range(3):
+            Losses.unsupervised_losses(p1, x, col, adj, adj_attr)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            Losses.unsupervised_losses(p1, x, col, adj, adj_attr)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        # algorithmic bytes: both index rows of both edge sets (int64), one length per adjacency edge, the
+        # probability and area columns once (the per-edge probability gathers are served by L2)
+        b_loss = (ec_total + ea_total) * 16 + ea_total * 4 + n_total * 8
+        loss_info = {"us_per_call": us, "algorithmic_bytes": b_loss, "achieved_GBs": b_loss / (us * 1e-6) / 1e9,
+                     "frac_of_hbm_peak": b_loss / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+
     if saved_stdout_fd is not None:
         sys.stdout.flush()
         os.dup2(saved_stdout_fd, 1)
@@ -257,6 +278,8 @@ def main():
         }
         if cached_ms is not None:
             line["cached_layout"] = {"ms_per_step": cached_ms, "value": n_total / (cached_ms * 1e-3)}
+        if loss_info is not None:
+            line["predict_loss"] = loss_info
         if class_ms is not None:
             line["kernel_classes"] = class_ms
         if not args.no_cpu_baseline:

@@ -291,6 +291,23 @@ int tgnn_forward_profiled(const tgnn_model_dims *dims, const void *const *params
  * Multi-GPU helpers: node-range shards exchange boundary rows each layer (RCCL does the moving)
  * ------------------------------------------------------------------------------------------ */
 /* out[i, :] = src[idx[i], :]  and  dst[idx[i], :] = in[i, :]   for [*, C] fp32 rows */
+/* ---- the loss on the predict path -------------------------------------------------
+ * Losses.calculate_unsupervised_loss (solver/ml_solver/losses.py:48-116), evaluated by ML_Solver.predict through
+ * get_best_prob_map (ml_solver.py:46,133-136): for every probability map m (column of probs [N, n_maps])
+ *   loss[m] = (1 - Wa log max(mean_v area[v] p[v], 1e-7))
+ *           * (1 - Wc mean_{collision edges} log(1 - clamp(p[i] p[j], 1e-7, 1 - 1e-7)))      (1 if there are none)
+ *           * (1 - Wl mean_{adjacency edges} log10 max(p[i] p[j] len_e, 1e-7))                 (1 if there are none)
+ * area_ratio = last column of the node features (x + Fx - 1, ld_area = Fx); adj_edge_len = column 1 of the
+ * adjacency edge attributes (attr + 1, ld_len = Fe); edge indices int64 [2, E] as everywhere.  Elements in fp32,
+ * sums in fp64 over a fixed tree.  losses: device [n_maps] doubles; terms (may be NULL): device [n_maps][3] =
+ * the three logarithmic terms.  The caller picks argmin (the reference: np.argsort(losses)[0]). */
+size_t tgnn_unsupervised_loss_workspace_bytes(int32_t n_maps);
+int tgnn_unsupervised_loss(const float *probs, int64_t ld_probs, int32_t n_maps, const float *area_ratio,
+                           int64_t ld_area, int64_t n_nodes, const int64_t *col_edge_index, int64_t n_col_edges,
+                           const int64_t *adj_edge_index, int64_t n_adj_edges, const float *adj_edge_len,
+                           int64_t ld_len, float collision_weight, float align_length_weight, float avg_area_weight,
+                           double *losses, double *terms, void *ws, size_t ws_bytes, tgnn_stream_t stream);
+
 int tgnn_rows_gather(const float *src, int64_t ld_src, const int32_t *idx, int64_t n_idx, int32_t c,
                      float *out, int64_t ld_out, tgnn_stream_t stream);
 int tgnn_rows_scatter(const float *in, const int32_t *idx, int64_t n_idx, int32_t c, float *dst,

@@ -594,3 +594,64 @@ def test_two_chain_schedule_is_bit_identical_to_one_stream(dev):
         torch.cuda.synchronize()
         outs.append(probs.cpu())
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
+
+
+# ------------------------------------------------------------------------------------------ loss on the predict path
+from tests.test_oracle_vs_reference_golden import LOSS_CASES, _loss_case_inputs   # noqa: E402
+
+
+@pytest.mark.parametrize("name", LOSS_CASES)
+def test_loss_kernel_matches_reference_golden(dev, name):
+    """tgnn_unsupervised_loss through the reference-shaped Losses.calculate_unsupervised_loss against the values the
+    REFERENCE produced in fp64 (tests/golden/ref_losses.npz): same losses (<= 1e-5 relative; the reference's own fp32
+    run is no closer), same best map, same scalar; empty edge sets switch their term off."""
+    from tilingnn_amd.solver.ml_solver.losses import Losses
+    ref, probs, x, col, adj, adj_attr = _loss_case_inputs(name)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+    loss, min_index, losses = Losses.calculate_unsupervised_loss(t(probs, torch.float32), t(x, torch.float32),
+                                                                 t(col, torch.int64), t(adj, torch.int64),
+                                                                 t(adj_attr, torch.float32))
+    want = ref[f"{name}.losses_fp64"]
+    ref32 = ref[f"{name}.losses_fp32"]
+    err = np.abs(losses.astype(np.float64) - want).max() / np.abs(want).max()
+    err_ref32 = np.abs(ref32 - want).max() / np.abs(want).max()
+    err_vs32 = np.abs(losses.astype(np.float64) - ref32).max() / np.abs(want).max()
+    print(f"{name}: rel err {err:.2e} (reference fp32 vs fp64: {err_ref32:.2e}; vs reference fp32: {err_vs32:.2e})")
+    # laby_extreme feeds p = 1 - 1e-9, which fp32 cannot hold: there the fp32 INPUT decides (1 - p p clamps at
+    # 1.19e-7 instead of 1e-7) and the reference's own fp32 run is the yardstick
+    assert err < 1e-5 or err_vs32 < 1e-5
+    assert int(min_index) == int(ref[f"{name}.min_index_fp64"])
+    want_loss = float(ref[f"{name}.loss_fp64"]) if err < 1e-5 else float(ref[f"{name}.loss_fp32"])
+    assert abs(float(loss) - want_loss) < 1e-5 * abs(want_loss)
+    assert losses.dtype == np.float32 and loss.dim() == 0 and loss.is_cuda
+
+
+def test_predict_picks_the_lowest_loss_map(dev):
+    """ML_Solver.predict with several probability maps (TilinGNN(output_dim=3)): the column returned is the one
+    get_best_prob_map picks, i.e. argsort of the unsupervised losses (ml_solver.py:46-47,133-136); full-size loss
+    against the fp64 oracle on the 100k-node workload of the benchmark."""
+    from tilingnn_amd import TilinGNN
+    from tilingnn_amd.solver.ml_solver.losses import Losses
+    from tilingnn_amd.solver.ml_solver.ml_solver import LayoutArrays, ML_Solver
+    from tilingnn_amd.weights import make_state_dict
+    g = load_labyrinth_graph()
+    net = TilinGNN(15, 20, 32, output_dim=3, node_features_dim=3)
+    net.load_state_dict(make_state_dict(15, 20, 32, 3, 3, seed=4))
+    net = net.to(dev)
+    layout = LayoutArrays(g["x"], g["adj"], g["adj_attr"], g["col"], g["col_attr"])
+    solver = ML_Solver(None, dev, None, net, num_prob_maps=3)
+    picked = solver.predict(layout)
+    x, adj, adj_attr, col, _ = layout.get_data_as_torch_tensor(dev)
+    probs = solver.network(x=x, adj_e_index=adj, adj_e_features=adj_attr, col_e_idx=col)[0]
+    assert probs.shape == (1254, 3)
+    want_losses = orc.unsupervised_losses(probs.double().cpu(), x.double().cpu(), col.cpu(), adj.cpu(), adj_attr.double().cpu())
+    k = int(torch.argsort(want_losses)[0])
+    np.testing.assert_array_equal(picked, probs[:, k].cpu().numpy())
+    # full size
+    from tilingnn_amd.synth import make_super_graph
+    sg = make_super_graph(100_000, 1_000_000, 1_250_000, tile_count=2, n_edge_types=13, seed=2)
+    x, adj, adj_attr, col, _ = sg.to_torch(dev)
+    p = torch.rand(100_000, 2, generator=torch.Generator().manual_seed(3)).to(dev)
+    got, _ = Losses.unsupervised_losses(p, x, col, adj, adj_attr)
+    want = orc.unsupervised_losses(p.double().cpu(), x.double().cpu(), col.cpu(), adj.cpu(), adj_attr.double().cpu())
+    assert orc.rel_max_err(got.cpu(), want) < 1e-6

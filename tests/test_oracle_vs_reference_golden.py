@@ -113,3 +113,36 @@ def test_unsupervised_loss_is_at_least_one():
     probs = torch.rand(x.shape[0], 3, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
     losses = orc.unsupervised_losses(probs, x, col, adj, adj_attr)
     assert losses.shape == (3,) and bool((losses >= 1.0).all())          # losses.py:108 assert
+
+
+# ------------------------------------------------------------------------------------------ loss on the predict path
+def _loss_case_inputs(name):
+    """Inputs of a case of tests/golden/ref_losses.npz (generate_loss_golden.py), float64 numpy."""
+    ref = load_npz("ref_losses.npz")
+    probs = ref[f"{name}.probs"]
+    if name.startswith("laby"):
+        g = load_labyrinth_graph()
+        x, col, adj, adj_attr = g["x"], g["col"], g["adj"], g["adj_attr"]
+    else:
+        t = load_npz("tiny_graph.npz")
+        x, col, adj, adj_attr = t["x"], t["col"], t["adj"], t["adj_attr"]
+        if name == "tiny_no_col":
+            col = np.zeros((2, 0), dtype=np.int64)
+        if name == "tiny_no_adj":
+            adj, adj_attr = np.zeros((2, 0), dtype=np.int64), np.zeros((0, adj_attr.shape[1]))
+    return ref, probs, x, col, adj, adj_attr
+
+
+LOSS_CASES = ["laby_ref_probs", "laby_3maps", "laby_extreme", "tiny_2maps", "tiny_no_col", "tiny_no_adj"]
+
+
+@pytest.mark.parametrize("name", LOSS_CASES)
+def test_oracle_loss_matches_reference(name):
+    """oracle.unsupervised_losses vs Losses.calculate_unsupervised_loss of the reference (losses.py:48-116)."""
+    ref, probs, x, col, adj, adj_attr = _loss_case_inputs(name)
+    got = orc.unsupervised_losses(torch.from_numpy(probs), torch.from_numpy(x), torch.from_numpy(col),
+                                  torch.from_numpy(adj), torch.from_numpy(adj_attr)).numpy()
+    want = ref[f"{name}.losses_fp64"]
+    assert np.abs(got - want).max() < 1e-12 * np.abs(want).max()
+    assert int(np.argsort(got)[0]) == int(ref[f"{name}.min_index_fp64"])
+    assert abs(got.min() - float(ref[f"{name}.loss_fp64"])) < 1e-12 * abs(got.min())

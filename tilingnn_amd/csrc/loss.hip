@@ -1,0 +1,111 @@
+// The unsupervised loss on the predict path.
+//
+// Reference: Losses.calculate_unsupervised_loss, /root/reference/solver/ml_solver/losses.py:48-116, called from
+// ML_Solver.predict through get_best_prob_map (ml_solver.py:46,133-136).  Per probability map m:
+//     l_area  = log( max( mean_v area[v] p[v], eps ) )                                   (:65-67)
+//     l_feas  = mean_{collision edges (i,j)} log( 1 - clamp(p[i] p[j], eps, 1 - eps) )     (:69-81)   0 without such edges
+//     l_align = mean_{adjacency edges (i,j)} log10( max(p[i] p[j] len_e, eps) )            (:83-98)   0 without such edges
+//     loss    = (1 - Wa l_area) (1 - Wc l_feas) (1 - Wl l_align)                           (:104-106)
+// The reference evaluates every element in fp32 and sums in fp32; here the elements are fp32 (same clamp / log) and
+// the three sums run in fp64 over a fixed tree: per-block partials, then one block per map.  Two launches, no atomics.
+#include "tgnn_common.h"
+
+namespace tgnn {
+
+constexpr float kLossEps = 1e-7f;          // losses.py:10
+constexpr int kLossThreads = 256;
+
+// grid = (blocks, maps); partial[(m * gridDim.x + b) * 3 + {0,1,2}]
+__global__ __launch_bounds__(kLossThreads) void loss_partial_kernel(
+    const float *__restrict__ probs, int64_t ldp, const float *__restrict__ area, int64_t lda, int64_t n,
+    const int64_t *__restrict__ col, int64_t ec, const int64_t *__restrict__ adj, int64_t ea,
+    const float *__restrict__ len, int64_t ldl, double *__restrict__ partial) {
+    const int m = blockIdx.y;
+    const float *p = probs + m;
+    double s_area = 0.0, s_feas = 0.0, s_align = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kLossThreads, t0 = (int64_t)blockIdx.x * kLossThreads + threadIdx.x;
+    for (int64_t v = t0; v < n; v += stride) s_area += (double)(area[v * lda] * p[v * ldp]);
+    for (int64_t e = t0; e < ec; e += stride) {
+        float pp = p[col[e] * ldp] * p[col[ec + e] * ldp];
+        pp = fminf(fmaxf(pp, kLossEps), 1.0f - kLossEps);
+        s_feas += (double)logf(1.0f - pp);
+    }
+    for (int64_t e = t0; e < ea; e += stride) {
+        float pp = p[adj[e] * ldp] * p[adj[ea + e] * ldp] * len[e * ldl];
+        pp = fmaxf(pp, kLossEps);
+        s_align += (double)(logf(pp) / 2.302585092994046f);
+    }
+    __shared__ double red[3][kLossThreads];
+    red[0][threadIdx.x] = s_area; red[1][threadIdx.x] = s_feas; red[2][threadIdx.x] = s_align;
+    __syncthreads();
+    for (int d = kLossThreads / 2; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d)
+            for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) partial[((int64_t)m * gridDim.x + blockIdx.x) * 3 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+// one block per map: fixed-order sum of the partial rows, then the product of the three factors
+__global__ __launch_bounds__(64) void loss_final_kernel(const double *__restrict__ partial, int n_blocks, int64_t n,
+                                                        int64_t ec, int64_t ea, float wc, float wl, float wa,
+                                                        double *__restrict__ losses, double *__restrict__ terms) {
+    const int m = blockIdx.x;
+    if (threadIdx.x >= 3) return;
+    double s = 0.0;
+    for (int b = 0; b < n_blocks; ++b) s += partial[((int64_t)m * n_blocks + b) * 3 + threadIdx.x];
+    __shared__ double t[3];
+    double v;
+    if (threadIdx.x == 0) v = log(fmax(s / (double)n, (double)kLossEps));
+    else if (threadIdx.x == 1) v = ec > 0 ? s / (double)ec : 0.0;
+    else v = ea > 0 ? s / (double)ea : 0.0;
+    t[threadIdx.x] = v;
+    if (terms) terms[m * 3 + threadIdx.x] = v;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (threadIdx.x == 0) losses[m] = (1.0 - (double)wa * t[0]) * (1.0 - (double)wc * t[1]) * (1.0 - (double)wl * t[2]);
+}
+
+static int loss_blocks(int64_t n, int64_t ec, int64_t ea) {
+    int64_t work = n > ec ? n : ec;
+    if (ea > work) work = ea;
+    int64_t b = (work + kLossThreads * 4 - 1) / (kLossThreads * 4);
+    if (b < 1) b = 1;
+    if (b > 512) b = 512;
+    return (int)b;
+}
+
+}  // namespace tgnn
+
+using namespace tgnn;
+
+extern "C" size_t tgnn_unsupervised_loss_workspace_bytes(int32_t n_maps) {
+    return (size_t)(n_maps > 0 ? n_maps : 1) * 512 * 3 * sizeof(double) + 256;
+}
+
+extern "C" int tgnn_unsupervised_loss(const float *probs, int64_t ld_probs, int32_t n_maps, const float *area_ratio,
+                                      int64_t ld_area, int64_t n_nodes, const int64_t *col_edge_index,
+                                      int64_t n_col_edges, const int64_t *adj_edge_index, int64_t n_adj_edges,
+                                      const float *adj_edge_len, int64_t ld_len, float collision_weight,
+                                      float align_length_weight, float avg_area_weight, double *losses,
+                                      double *terms, void *ws, size_t ws_bytes, tgnn_stream_t stream) {
+    TGNN_CHECK_ARG(n_maps >= 1 && n_maps <= 65535 && n_nodes >= 1, "shape");
+    TGNN_CHECK_ARG(probs && area_ratio && losses && ld_probs >= n_maps && ld_area >= 1, "null pointer / strides");
+    TGNN_CHECK_ARG(n_col_edges >= 0 && (n_col_edges == 0 || col_edge_index), "collision edges");
+    TGNN_CHECK_ARG(n_adj_edges >= 0 && (n_adj_edges == 0 || (adj_edge_index && adj_edge_len && ld_len >= 1)), "adjacency edges");
+    if (!ws || ws_bytes < tgnn_unsupervised_loss_workspace_bytes(n_maps)) {
+        set_error("tgnn_unsupervised_loss: workspace too small");
+        return TGNN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double *partial = static_cast<double *>(ws);
+    const int blocks = loss_blocks(n_nodes, n_col_edges, n_adj_edges);
+    loss_partial_kernel<<<dim3(blocks, n_maps), kLossThreads, 0, s>>>(probs, ld_probs, area_ratio, ld_area, n_nodes,
+                                                                      col_edge_index, n_col_edges, adj_edge_index,
+                                                                      n_adj_edges, adj_edge_len, ld_len, partial);
+    loss_final_kernel<<<n_maps, 64, 0, s>>>(partial, blocks, n_nodes, n_col_edges, n_adj_edges, collision_weight,
+                                            align_length_weight, avg_area_weight, losses, terms);
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}

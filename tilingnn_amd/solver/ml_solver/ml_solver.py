@@ -2,6 +2,7 @@
 /root/reference/solver/ml_solver/ml_solver.py that sits on it:
 
     predict(brick_layout)            ml_solver.py:29-49   (empty-edge early-out, forward, best-map pick)
+    get_unsupervised_losses_from_layout(layout, probs)    ml_solver.py:51-62 (losses.py on the GPU, csrc/loss.hip)
     get_predict_probs(brick_layout)  ml_solver.py:69-81
     load_saved_network(path)         ml_solver.py:129-131 (load_state_dict + network.train())
 
@@ -66,10 +67,21 @@ class ML_Solver:
     def _best_prob_map(self, predictions, brick_layout):
         """get_best_prob_map (ml_solver.py:133-136): argsort of the per-map unsupervised loss.
         With one probability map -- the only configuration the reference ever constructs
-        (Tiling-Shape.py:37, Tiling-GUI.py:570) -- the answer is 0 without evaluating the loss."""
+        (Tiling-Shape.py:37, Tiling-GUI.py:570) -- the answer is 0 and the loss (a device round trip) is skipped."""
         if predictions.shape[1] == 1:
             return 0
-        raise NotImplementedError("num_prob_maps > 1 needs the loss kernel (SURVEY.md section 8f-2)")
+        losses = self.get_unsupervised_losses_from_layout(brick_layout, predictions)
+        return int(np.argsort(losses)[0])
+
+    def get_unsupervised_losses_from_layout(self, brick_layout, probs):
+        """ml_solver.py:51-62: the per-map losses of `probs` on a layout, as numpy."""
+        from .losses import Losses
+        x, adj_edge_index, adj_edge_features, collide_edge_index, collide_edge_features = \
+            brick_layout.get_data_as_torch_tensor(self.device)
+        _, _, losses = Losses.calculate_unsupervised_loss(probs, x, collide_edge_index,
+                                                          adj_edges_index=adj_edge_index,
+                                                          adj_edge_features=adj_edge_features)
+        return losses
 
     def get_predict_probs(self, brick_layout):
         x, adj_edge_index, adj_edge_features, collide_edge_index, collide_edge_features = \
