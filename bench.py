@@ -259,6 +259,38 @@ def main():
         loss_info = {"us_per_call": us, "algorithmic_bytes": b_loss, "achieved_GBs": b_loss / (us * 1e-6) / 1e9,
                      "frac_of_hbm_peak": b_loss / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
 
+    # ---- one round of the greedy loop's layout re-indexing: stream compaction on the device,
+    #      half of the nodes still unlabelled; the CPU figure is the numpy restatement of compute_sub_layout (the
+    #      reference itself runs Python comprehensions with dict look-ups over all edges)
+    sub_info = None
+    if not sharded:
+        from tilingnn_amd.util.algorithms import DeviceLayout, SubLayoutBuilder
+        rng = np.random.default_rng(0)
+        alive_h = (rng.uniform(size=n_total) < 0.5).astype(np.int32)
+        alive_d = torch.from_numpy(alive_h).to(dev)
+        builder = SubLayoutBuilder(DeviceLayout(x, adj, adj_attr, col))
+        for _ in range(3):
+            builder.build(alive_d)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(10):
+            sub = builder.build(alive_d)
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t2) / 10 * 1e6
+        fe_ = int(adj_attr.shape[1])
+        kept_a, kept_c, kept_n = int(sub.align_edge_index.shape[1]), int(sub.collide_edge_index.shape[1]), int(sub.node_feature.shape[0])
+        b_sub = (ea_total + ec_total) * 16 + ea_total * 4 * fe_ * (kept_a / max(ea_total, 1)) + n_total * 4 \
+            + kept_a * (16 + 4 * fe_) + kept_c * 16 + kept_n * (8 + 4 * int(x.shape[1]))
+        sub_info = {"us_per_round": us, "alive_fraction": 0.5, "kept": [kept_n, kept_a, kept_c],
+                    "algorithmic_bytes": int(b_sub), "achieved_GBs": b_sub / (us * 1e-6) / 1e9}
+        if not args.no_cpu_baseline:
+            from oracle import greedy_oracle as go
+            xh, ah, aah, ch = x.cpu().numpy(), adj.cpu().numpy(), adj_attr.cpu().numpy(), col.cpu().numpy()
+            cah = np.zeros((ch.shape[1], 1), dtype=np.float32)
+            t3 = time.perf_counter()
+            go.compute_sub_layout(xh, ah, aah, ch, cah, np.flatnonzero(alive_h))
+            sub_info["cpu_numpy_us"] = (time.perf_counter() - t3) * 1e6
+
     if saved_stdout_fd is not None:
         sys.stdout.flush()
         os.dup2(saved_stdout_fd, 1)
@@ -280,6 +312,8 @@ def main():
             line["cached_layout"] = {"ms_per_step": cached_ms, "value": n_total / (cached_ms * 1e-3)}
         if loss_info is not None:
             line["predict_loss"] = loss_info
+        if sub_info is not None:
+            line["greedy_sublayout"] = sub_info
         if class_ms is not None:
             line["kernel_classes"] = class_ms
         if not args.no_cpu_baseline:

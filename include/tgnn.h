@@ -291,6 +291,21 @@ int tgnn_forward_profiled(const tgnn_model_dims *dims, const void *const *params
  * Multi-GPU helpers: node-range shards exchange boundary rows each layer (RCCL does the moving)
  * ------------------------------------------------------------------------------------------ */
 /* out[i, :] = src[idx[i], :]  and  dst[idx[i], :] = in[i, :]   for [*, C] fp32 rows */
+/* ---- sub-layout of the unlabelled nodes, for the greedy assembly loop -----------------
+ * BrickLayout.compute_sub_layout (tiling/brick_layout.py:248-286) as a stream compaction on the device:
+ * alive [N] (int32, != 0 = still unlabelled); the alive nodes in ascending order become nodes 0..N'-1; an edge
+ * survives iff both ends are alive; survivors keep their order, carry re-indexed ends and their attribute rows.
+ *   x_out [N'][Fx], inverse_out [N'] (new -> old node), adj_out [2][Ea'] (row 1 starts Ea' entries after row 0),
+ *   adj_attr_out [Ea'][Fe], col_out [2][Ec'];  counts_out (device int64 [3]) = {N', Ea', Ec'}.
+ * Output arrays are sized for the un-compacted counts.  (The collision attributes are not carried: the network
+ * never reads them, TilinGNN.py:51.)  err_flag (device, may be NULL) is set if an edge end is outside [0, N). */
+size_t tgnn_sublayout_workspace_bytes(int64_t n_nodes, int64_t n_adj_edges, int64_t n_col_edges);
+int tgnn_sublayout_compact(const int32_t *alive, int64_t n_nodes, const float *x, int32_t fx,
+                           const int64_t *adj_edge_index, int64_t n_adj_edges, const float *adj_edge_attr, int32_t fe,
+                           const int64_t *col_edge_index, int64_t n_col_edges, float *x_out, int64_t *inverse_out,
+                           int64_t *adj_out, float *adj_attr_out, int64_t *col_out, int64_t *counts_out,
+                           int32_t *err_flag, void *ws, size_t ws_bytes, tgnn_stream_t stream);
+
 /* ---- the loss on the predict path -------------------------------------------------
  * Losses.calculate_unsupervised_loss (solver/ml_solver/losses.py:48-116), evaluated by ML_Solver.predict through
  * get_best_prob_map (ml_solver.py:46,133-136): for every probability map m (column of probs [N, n_maps])

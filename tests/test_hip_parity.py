@@ -655,3 +655,111 @@ def test_predict_picks_the_lowest_loss_map(dev):
     got, _ = Losses.unsupervised_losses(p, x, col, adj, adj_attr)
     want = orc.unsupervised_losses(p.double().cpu(), x.double().cpu(), col.cpu(), adj.cpu(), adj_attr.double().cpu())
     assert orc.rel_max_err(got.cpu(), want) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------ greedy assembly loop
+from tests.test_oracle_vs_reference_golden import _greedy_fake_probs   # noqa: E402
+
+
+def _device_layout(g, dev):
+    from tilingnn_amd.solver.ml_solver.ml_solver import LayoutArrays
+    from tilingnn_amd.util.algorithms import DeviceLayout
+    return DeviceLayout.upload(LayoutArrays(g["x"], g["adj"], g["adj_attr"], g["col"], g["col_attr"]), dev)
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_sublayout_compaction_matches_reference_golden(dev, k):
+    """tgnn_sublayout_compact vs the arrays BrickLayout.compute_sub_layout of the REFERENCE produced
+    (tests/golden/ref_greedy.npz): bit-exact nodes, re-indexed edges in the original order, attribute rows, inverse."""
+    from tilingnn_amd.util.algorithms import SubLayoutBuilder
+    ref = load_npz("ref_greedy.npz")
+    g = load_labyrinth_graph()
+    n = g["x"].shape[0]
+    alive = np.ones(n, dtype=np.int32)
+    alive[ref[f"sub{k}.labelled"]] = 0
+    sub = SubLayoutBuilder(_device_layout(g, dev)).build(torch.from_numpy(alive).to(dev))
+    np.testing.assert_array_equal(sub.node_feature.cpu().numpy(), ref[f"sub{k}.x"].astype(np.float32))
+    np.testing.assert_array_equal(sub.align_edge_index.cpu().numpy(), ref[f"sub{k}.adj"])
+    np.testing.assert_array_equal(sub.align_edge_features.cpu().numpy(), ref[f"sub{k}.adj_attr"].astype(np.float32))
+    np.testing.assert_array_equal(sub.collide_edge_index.cpu().numpy(), ref[f"sub{k}.col"])
+    np.testing.assert_array_equal(sub.inverse_index.cpu().numpy(), ref[f"sub{k}.inverse"])
+
+
+@pytest.mark.parametrize("frac", [0.0, 0.3, 0.97, 1.0])
+def test_sublayout_compaction_full_size_vs_oracle(dev, frac):
+    """100k nodes / 2.25M edges, random label sets incl. "nothing labelled" and "everything labelled": bit-exact
+    against the pinned numpy restatement."""
+    from oracle import greedy_oracle as go
+    from tilingnn_amd.synth import make_super_graph
+    from tilingnn_amd.util.algorithms import DeviceLayout, SubLayoutBuilder
+    sg = make_super_graph(100_000, 1_000_000, 1_250_000, tile_count=2, n_edge_types=13, seed=2)
+    x, adj, adj_attr, col, _ = sg.to_torch(dev)
+    rng = np.random.default_rng(int(frac * 100))
+    alive = (rng.uniform(size=100_000) >= frac).astype(np.int32)
+    sub = SubLayoutBuilder(DeviceLayout(x, adj, adj_attr, col)).build(torch.from_numpy(alive).to(dev))
+    want = go.compute_sub_layout(x.cpu().numpy(), adj.cpu().numpy(), adj_attr.cpu().numpy(), col.cpu().numpy(),
+                                 np.zeros((col.shape[1], 1), dtype=np.float32), np.flatnonzero(alive))
+    np.testing.assert_array_equal(sub.node_feature.cpu().numpy(), want[0])
+    np.testing.assert_array_equal(sub.align_edge_index.cpu().numpy(), want[1])
+    np.testing.assert_array_equal(sub.align_edge_features.cpu().numpy(), want[2])
+    np.testing.assert_array_equal(sub.collide_edge_index.cpu().numpy(), want[3])
+    np.testing.assert_array_equal(sub.inverse_index.cpu().numpy(), want[5])
+
+
+class _FakeSolver:
+    """ML_Solver stand-in of tests/golden/generate_greedy_golden.py, reading the device-resident sub-layout."""
+    def __init__(self, dev):
+        self.device, self.sizes = dev, []
+
+    def predict(self, layout):
+        x, adj, attr, col, _ = layout.get_data_as_torch_tensor(self.device)
+        self.sizes.append((int(x.shape[0]), int(adj.shape[1]), int(col.shape[1])))
+        return _greedy_fake_probs(x.double().cpu().numpy(), adj.cpu().numpy(), attr.double().cpu().numpy(),
+                                  col.cpu().numpy(), None)
+
+
+@pytest.mark.parametrize("seed", [0, 7])
+def test_greedy_loop_matches_reference_golden(dev, seed):
+    """tilingnn_amd.util.algorithms.solve_by_probablistic_greedy (layout on the GPU, compaction kernel per round) against
+    what the REFERENCE's loop selected with the same fake predictor and the same numpy RNG seed: same tiles, same
+    order, same sub-layout sizes in every round."""
+    from tilingnn_amd.util.algorithms import solve_by_probablistic_greedy
+    ref = load_npz("ref_greedy.npz")
+    g = load_labyrinth_graph()
+    fake = _FakeSolver(dev)
+    np.random.seed(seed)
+    selection, score, order = solve_by_probablistic_greedy(fake, _device_layout(g, dev))
+    np.testing.assert_array_equal(np.asarray(fake.sizes), ref[f"greedy{seed}.sizes"])
+    np.testing.assert_array_equal(np.asarray(order), ref[f"greedy{seed}.order"])
+    np.testing.assert_array_equal(selection.astype(np.int8), ref[f"greedy{seed}.selection"])
+    assert score is None
+
+
+def test_greedy_loop_with_the_network_matches_the_restated_loop(dev):
+    """ML_Solver.solve end to end (network forward per round on the compacted layout) against the pinned restatement of
+    the reference's loop driven by the same predictor: the forward is bit-reproducible, so the two runs must select
+    the same tiles from the same RNG seed; the result is collision free and maximal."""
+    from oracle import greedy_oracle as go
+    from tilingnn_amd.solver.ml_solver.ml_solver import LayoutArrays, ML_Solver
+    g = load_labyrinth_graph()
+    net, _ = make_net(dev)
+    solver = ML_Solver(None, dev, None, net, num_prob_maps=1)
+    layout = LayoutArrays(g["x"], g["adj"], g["adj_attr"], g["col"], g["col_attr"])
+    np.random.seed(3)
+    out_layout, score = solver.solve(layout)
+    selection, order = np.asarray(out_layout.predict), list(out_layout.predict_order)
+    net2, _ = make_net(dev)                                    # fresh running statistics, as the first run had
+    solver2 = ML_Solver(None, dev, None, net2, num_prob_maps=1)
+
+    def predict(x, adj, adj_attr, col, col_attr):
+        return solver2.predict(LayoutArrays(x, adj, adj_attr, col, col_attr))
+
+    np.random.seed(3)
+    want_sel, want_order, _ = go.greedy_solve(predict, g["x"], g["adj"], g["adj_attr"], g["col"], g["col_attr"])
+    np.testing.assert_array_equal(order, want_order)
+    np.testing.assert_array_equal(selection.astype(np.int8), want_sel)
+    chosen = selection.astype(bool)
+    assert not (chosen[g["col"][0]] & chosen[g["col"][1]]).any()            # no two selected tiles collide
+    blocked = np.zeros_like(chosen)
+    blocked[g["col"][1][chosen[g["col"][0]]]] = True
+    assert (chosen | blocked).all()                                        # every tile is selected or blocked

@@ -146,3 +146,46 @@ def test_oracle_loss_matches_reference(name):
     assert np.abs(got - want).max() < 1e-12 * np.abs(want).max()
     assert int(np.argsort(got)[0]) == int(ref[f"{name}.min_index_fp64"])
     assert abs(got.min() - float(ref[f"{name}.loss_fp64"])) < 1e-12 * abs(got.min())
+
+
+# ------------------------------------------------------------------------------------------ greedy assembly loop
+def _greedy_fake_probs(x, adj, adj_attr, col, col_attr):
+    """The fake predictor of tests/golden/generate_greedy_golden.py (FakeSolver.predict + fake_probs)."""
+    n = x.shape[0]
+    if col.size == 0 or adj.size == 0:                       # ml_solver.py:31-32
+        return np.ones(n)
+    deg_a = np.bincount(adj[1], minlength=n)
+    deg_c = np.bincount(col[1], minlength=n)
+    t = np.sin(12.9898 * x[:, -1] + 78.233 * deg_a + 37.719 * deg_c + 0.37 * np.arange(n)) * 43758.5453
+    return 0.05 + 0.9 * (t - np.floor(t))
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_oracle_sub_layout_matches_reference(k):
+    """greedy_oracle.compute_sub_layout vs BrickLayout.compute_sub_layout of the reference (brick_layout.py:248-286)."""
+    from oracle import greedy_oracle as go
+    ref = load_npz("ref_greedy.npz")
+    g = load_labyrinth_graph()
+    n = g["x"].shape[0]
+    unl = np.setdiff1d(np.arange(n), ref[f"sub{k}.labelled"])
+    x2, adj2, aa2, col2, ca2, inv = go.compute_sub_layout(g["x"], g["adj"], g["adj_attr"], g["col"], g["col_attr"], unl)
+    np.testing.assert_array_equal(x2, ref[f"sub{k}.x"])
+    np.testing.assert_array_equal(adj2, ref[f"sub{k}.adj"])
+    np.testing.assert_array_equal(aa2, ref[f"sub{k}.adj_attr"])
+    np.testing.assert_array_equal(col2, ref[f"sub{k}.col"])
+    np.testing.assert_array_equal(ca2, ref[f"sub{k}.col_attr"])
+    np.testing.assert_array_equal(inv, ref[f"sub{k}.inverse"])
+
+
+@pytest.mark.parametrize("seed", [0, 7])
+def test_oracle_greedy_loop_matches_reference(seed):
+    """greedy_oracle.greedy_solve vs solve_by_probablistic_greedy of the reference (algorithms.py:18-62) on numpy's
+    global RNG stream: same selection, same order, same sub-layout sizes in every round."""
+    from oracle import greedy_oracle as go
+    ref = load_npz("ref_greedy.npz")
+    g = load_labyrinth_graph()
+    np.random.seed(seed)
+    sel, order, sizes = go.greedy_solve(_greedy_fake_probs, g["x"], g["adj"], g["adj_attr"], g["col"], g["col_attr"])
+    np.testing.assert_array_equal(sizes, ref[f"greedy{seed}.sizes"])
+    np.testing.assert_array_equal(order, ref[f"greedy{seed}.order"])
+    np.testing.assert_array_equal(sel, ref[f"greedy{seed}.selection"])

@@ -85,6 +85,8 @@ def _load() -> C.CDLL:
         "tgnn_forward_sharded_workspace_bytes": (sz, [C.POINTER(ModelDims), i64, i64, i32]),
         "tgnn_forward_sharded": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), p, p, C.POINTER(Graph),
                                            C.POINTER(ShardDesc), i32, p, p, sz, p]),
+        "tgnn_sublayout_workspace_bytes": (sz, [i64, i64, i64]),
+        "tgnn_sublayout_compact": (C.c_int, [p, i64, p, i32, p, i64, p, i32, p, i64, p, p, p, p, p, p, p, p, sz, p]),
         "tgnn_unsupervised_loss_workspace_bytes": (sz, [i32]),
         "tgnn_unsupervised_loss": (C.c_int, [p, i64, i32, p, i64, i64, p, i64, p, i64, p, i64, f32, f32, f32, p, p, p, sz, p]),
         "tgnn_forward_profiled": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), p, p, C.POINTER(Graph), i32,
@@ -106,7 +108,8 @@ EXPORTED_SYMBOLS = (
     "tgnn_nnconv_cols_build", "tgnn_nnconv_cols_max_types", "tgnn_nnconv_weight_image_floats", "tgnn_nnconv_mean_cols_fwd", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
     "tgnn_merge_fwd", "tgnn_param_count", "tgnn_param_name", "tgnn_forward_workspace_bytes", "tgnn_forward",
     "tgnn_forward_profiled", "tgnn_forward_sharded_workspace_bytes", "tgnn_forward_sharded",
-    "tgnn_rows_gather", "tgnn_rows_scatter", "tgnn_unsupervised_loss_workspace_bytes", "tgnn_unsupervised_loss")
+    "tgnn_rows_gather", "tgnn_rows_scatter", "tgnn_unsupervised_loss_workspace_bytes", "tgnn_unsupervised_loss",
+    "tgnn_sublayout_workspace_bytes", "tgnn_sublayout_compact")
 
 
 def check(rc: int) -> None:

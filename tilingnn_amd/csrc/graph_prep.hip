@@ -541,3 +541,109 @@ extern "C" int tgnn_nnconv_cols_build(const int32_t *rowptr, const int32_t *col_
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Sub-layout of the still unlabelled nodes (greedy assembly loop).
+//
+// Reference: BrickLayout.compute_sub_layout, /root/reference/tiling/brick_layout.py:248-286 -- the unlabelled nodes
+// in ascending order become nodes 0..N'-1, an edge survives iff both ends are unlabelled, surviving edges keep their
+// order and carry re-indexed ends and their attribute rows.  The reference runs four Python comprehensions with
+// dict look-ups over all edges per round; here: flags -> exclusive scans -> scatters (stream compaction), everything
+// stays on the device, only the three counts travel to the host.
+// ------------------------------------------------------------------------------------------
+__global__ void sub_node_flag_kernel(const int *__restrict__ alive, int64_t n, int *__restrict__ flag) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (int64_t)gridDim.x * blockDim.x)
+        flag[i] = i < n ? (alive[i] != 0) : 0;
+}
+__global__ void sub_edge_flag_kernel(const int64_t *__restrict__ ei, int64_t e, const int *__restrict__ alive, int64_t n,
+                                     int *__restrict__ flag, int *__restrict__ err_flag) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= e; i += (int64_t)gridDim.x * blockDim.x) {
+        int f = 0;
+        if (i < e) {
+            const int64_t a = ei[i], b = ei[e + i];
+            if (a < 0 || a >= n || b < 0 || b >= n) {
+                if (err_flag) *err_flag = 1;
+            } else {
+                f = alive[a] != 0 && alive[b] != 0;
+            }
+        }
+        flag[i] = f;
+    }
+}
+// pos = exclusive scan of the node flags (pos[n] = N')
+__global__ void sub_node_scatter_kernel(const int *__restrict__ alive, const int *__restrict__ pos, int64_t n,
+                                        const float *__restrict__ x, int fx, float *__restrict__ x_out,
+                                        int64_t *__restrict__ inverse, int64_t *__restrict__ counts) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (alive[i] == 0) continue;
+        const int64_t j = pos[i];
+        inverse[j] = i;
+        for (int k = 0; k < fx; ++k) x_out[j * fx + k] = x[i * fx + k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts[0] = pos[n];
+}
+// epos = exclusive scan of the edge flags (epos[e] = E'); rows of the output index are E' apart
+__global__ void sub_edge_scatter_kernel(const int64_t *__restrict__ ei, int64_t e, const int *__restrict__ eflag_pos,
+                                        const int *__restrict__ alive, const int *__restrict__ npos,
+                                        const float *__restrict__ attr, int fe, int64_t *__restrict__ ei_out,
+                                        float *__restrict__ attr_out, int64_t *__restrict__ count_out) {
+    const int64_t e_out = eflag_pos[e];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t a = ei[i], b = ei[e + i];
+        if (alive[a] == 0 || alive[b] == 0) continue;
+        const int64_t j = eflag_pos[i];
+        ei_out[j] = npos[a];
+        ei_out[e_out + j] = npos[b];
+        if (attr)
+            for (int k = 0; k < fe; ++k) attr_out[j * fe + k] = attr[i * fe + k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = e_out;
+}
+
+extern "C" size_t tgnn_sublayout_workspace_bytes(int64_t n_nodes, int64_t n_adj_edges, int64_t n_col_edges) {
+    const int64_t m = n_adj_edges > n_col_edges ? n_adj_edges : n_col_edges;
+    return align_up((size_t)(n_nodes + 1) * 4, 256) + align_up((size_t)(m + 1) * 4, 256) +
+           scan_ws_ints((m > n_nodes ? m : n_nodes) + 1) * 4 + 1024;
+}
+
+extern "C" int tgnn_sublayout_compact(const int32_t *alive, int64_t n_nodes, const float *x, int32_t fx,
+                                      const int64_t *adj_edge_index, int64_t n_adj_edges, const float *adj_edge_attr,
+                                      int32_t fe, const int64_t *col_edge_index, int64_t n_col_edges, float *x_out,
+                                      int64_t *inverse_out, int64_t *adj_out, float *adj_attr_out, int64_t *col_out,
+                                      int64_t *counts_out, int32_t *err_flag, void *ws, size_t ws_bytes,
+                                      tgnn_stream_t stream) {
+    TGNN_CHECK_ARG(n_nodes >= 1 && n_nodes < (1ll << 31) - 1 && fx >= 1, "node shape");
+    TGNN_CHECK_ARG(n_adj_edges >= 0 && n_adj_edges < (1ll << 31) - 1 && n_col_edges >= 0 && n_col_edges < (1ll << 31) - 1,
+                   "edge counts must fit int32");
+    TGNN_CHECK_ARG(alive && x && x_out && inverse_out && counts_out, "null pointer");
+    TGNN_CHECK_ARG(n_adj_edges == 0 || (adj_edge_index && adj_out && adj_edge_attr && adj_attr_out && fe >= 1), "adjacency arrays");
+    TGNN_CHECK_ARG(n_col_edges == 0 || (col_edge_index && col_out), "collision arrays");
+    if (!ws || ws_bytes < tgnn_sublayout_workspace_bytes(n_nodes, n_adj_edges, n_col_edges)) {
+        set_error("tgnn_sublayout_compact: workspace too small");
+        return TGNN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t m = n_adj_edges > n_col_edges ? n_adj_edges : n_col_edges;
+    Carver cv(ws, ws_bytes);
+    int *npos = cv.take<int>(n_nodes + 1);
+    int *epos = cv.take<int>(m + 1);
+    int *scan_ws = cv.take<int>(scan_ws_ints((m > n_nodes ? m : n_nodes) + 1));
+    sub_node_flag_kernel<<<grid_for(n_nodes + 1), 256, 0, s>>>(alive, n_nodes, npos);
+    exclusive_scan_i32(npos, npos, n_nodes + 1, scan_ws, s);
+    sub_node_scatter_kernel<<<grid_for(n_nodes), 256, 0, s>>>(alive, npos, n_nodes, x, fx, x_out, inverse_out, counts_out);
+    for (int set = 0; set < 2; ++set) {
+        const int64_t e = set == 0 ? n_adj_edges : n_col_edges;
+        const int64_t *ei = set == 0 ? adj_edge_index : col_edge_index;
+        if (e == 0) {
+            TGNN_CHECK_HIP(hipMemsetAsync(counts_out + 1 + set, 0, sizeof(int64_t), s));
+            continue;
+        }
+        sub_edge_flag_kernel<<<grid_for(e + 1), 256, 0, s>>>(ei, e, alive, n_nodes, epos, err_flag);
+        exclusive_scan_i32(epos, epos, e + 1, scan_ws, s);
+        sub_edge_scatter_kernel<<<grid_for(e), 256, 0, s>>>(ei, e, epos, alive, npos, set == 0 ? adj_edge_attr : nullptr, fe,
+                                                            set == 0 ? adj_out : col_out, set == 0 ? adj_attr_out : nullptr,
+                                                            counts_out + 1 + set);
+    }
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}

@@ -6,10 +6,9 @@
     get_predict_probs(brick_layout)  ml_solver.py:69-81
     load_saved_network(path)         ml_solver.py:129-131 (load_state_dict + network.train())
 
-`solve` (the greedy assembly loop, util/algorithms.py:18-62) and the debug dumps stay with the
-reference: when this class is used inside the reference tree, pass `greedy_solver=` the
-reference's `algorithms.solve_by_probablistic_greedy`; SURVEY.md section 8f-1 ranks a device-side
-loop as the next row after the forward.
+    solve(brick_layout)              ml_solver.py:64-73   (greedy assembly loop: tilingnn_amd/util/algorithms.py keeps the
+                                                           layout on the GPU; `greedy_solver=` swaps in the reference's)
+The debug dumps stay with the reference.
 
 `brick_layout` is duck-typed exactly as the reference uses it: `.node_feature`,
 `.align_edge_index`, `.collide_edge_index` (numpy) and `.get_data_as_torch_tensor(device)`.
@@ -52,8 +51,14 @@ class ML_Solver:
         self.num_prob_maps = num_prob_maps
         self._greedy_solver = greedy_solver
 
+    @staticmethod
+    def _no_edges(index) -> bool:
+        """`len(index) == 0` of the reference (an empty edge set is `np.array([]).T` there); a device-resident
+        sub-layout holds an empty [2, 0] tensor instead, and so may a caller's numpy layout."""
+        return index.numel() == 0 if torch.is_tensor(index) else np.asarray(index).size == 0
+
     def predict(self, brick_layout):
-        if len(brick_layout.collide_edge_index) == 0 or len(brick_layout.align_edge_index) == 0:
+        if self._no_edges(brick_layout.collide_edge_index) or self._no_edges(brick_layout.align_edge_index):
             # only one edge set left: select every remaining tile (ml_solver.py:31-32)
             predictions = torch.ones((brick_layout.node_feature.shape[0], self.num_prob_maps)).float().to(self.device)
         else:
@@ -91,10 +96,14 @@ class ML_Solver:
                                       col_e_features=collide_edge_features)
 
     def solve(self, brick_layout):
+        """ml_solver.py:64-73.  Default loop: tilingnn_amd.util.algorithms.solve_by_probablistic_greedy (layout resident
+        on the GPU, score None unless a score function is supplied); `greedy_solver=` swaps in another one, e.g. the
+        reference's own."""
         if self._greedy_solver is None:
-            raise NotImplementedError("pass greedy_solver=util.algorithms.solve_by_probablistic_greedy "
-                                      "(reference code) to use solve(); the forward is what this package replaces")
-        output_solution, score, predict_order = self._greedy_solver(self, brick_layout)
+            from ...util.algorithms import solve_by_probablistic_greedy
+            output_solution, score, predict_order = solve_by_probablistic_greedy(self, brick_layout)
+        else:
+            output_solution, score, predict_order = self._greedy_solver(self, brick_layout)
         output_layout = deepcopy(brick_layout)
         output_layout.predict_order = predict_order
         output_layout.predict = output_solution

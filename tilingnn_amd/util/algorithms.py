@@ -1,0 +1,133 @@
+"""`solve_by_probablistic_greedy` -- the greedy assembly loop around `ML_Solver.predict`
+(/root/reference/util/algorithms.py:18-62), with the layout resident on the GPU.
+
+Per round the reference rebuilds the sub-layout of the still unlabelled nodes with four Python comprehensions and
+dict look-ups over ALL edges (`BrickLayout.compute_sub_layout`, tiling/brick_layout.py:248-286) and ships it to the
+device again.  Here the five arrays of the original layout are uploaded once; a round is
+    alive mask -> `tgnn_sublayout_compact` (flags, scans, scatters: csrc/graph_prep.hip) -> `ml_solver.predict` on the
+    device-resident sub-layout -> probabilities to the host -> the acceptance sweep.
+The sweep itself stays on the host ON PURPOSE: it is sequential by definition (descending probability, stop at the
+first node a previous acceptance has killed), touches a handful of nodes per round, and consumes numpy's global RNG
+stream one `np.random.uniform()` per visited node (algorithms.py:51) -- the stream the reference consumes, so that a
+seeded run selects the same tiles.
+
+Same return values as the reference: (selection_predict, score, predict_order).  The reference scores through
+shapely polygon areas (`Losses.solution_score`, losses.py:120-148), which are outside this package: pass
+`score_fn(selection, origin_layout)` (e.g. the reference's) or get `None`.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib, ops
+from .._lib import check, lib, ptr
+
+
+class DeviceLayout:
+    """The data side of a BrickLayout (brick_layout.py:242-246) living on the GPU: what `ML_Solver.predict` reads."""
+
+    def __init__(self, node_feature, align_edge_index, align_edge_features, collide_edge_index, inverse_index=None):
+        self.node_feature = node_feature
+        self.align_edge_index = align_edge_index
+        self.align_edge_features = align_edge_features
+        self.collide_edge_index = collide_edge_index
+        self.collide_edge_features = None                     # never read by the network (TilinGNN.py:51)
+        self.inverse_index = inverse_index                    # sub-layout node -> original node
+
+    def get_data_as_torch_tensor(self, device):
+        return (self.node_feature, self.align_edge_index, self.align_edge_features, self.collide_edge_index,
+                self.collide_edge_features)
+
+    @staticmethod
+    def upload(layout, device) -> "DeviceLayout":
+        """From the numpy arrays of a BrickLayout / LayoutArrays, with the conversion of util/data_util.py:110-117."""
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(device)
+        adj = np.asarray(layout.align_edge_index).reshape(2, -1)
+        col = np.asarray(layout.collide_edge_index).reshape(2, -1)
+        fe = np.asarray(layout.align_edge_features).shape[-1] if np.asarray(layout.align_edge_features).size else 1
+        return DeviceLayout(t(layout.node_feature, torch.float32), t(adj, torch.int64),
+                            t(np.asarray(layout.align_edge_features).reshape(-1, fe), torch.float32), t(col, torch.int64))
+
+
+class SubLayoutBuilder:
+    """compute_sub_layout on the device: buffers sized once for the original layout, reused every round."""
+
+    def __init__(self, origin: DeviceLayout):
+        self.o = origin
+        x, adj, attr, col = origin.node_feature, origin.align_edge_index, origin.align_edge_features, origin.collide_edge_index
+        dev = x.device
+        self.n, self.fx = int(x.shape[0]), int(x.shape[1])
+        self.ea, self.ec, self.fe = int(adj.shape[1]), int(col.shape[1]), int(attr.shape[1]) if attr.numel() else 1
+        self.x_out = torch.empty(self.n, self.fx, dtype=torch.float32, device=dev)
+        self.inverse = torch.empty(self.n, dtype=torch.int64, device=dev)
+        self.adj_out = torch.empty(2 * max(self.ea, 1), dtype=torch.int64, device=dev)
+        self.attr_out = torch.empty(max(self.ea, 1) * self.fe, dtype=torch.float32, device=dev)
+        self.col_out = torch.empty(2 * max(self.ec, 1), dtype=torch.int64, device=dev)
+        self.counts = torch.zeros(3, dtype=torch.int64, device=dev)
+        self.err = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.ws_bytes = lib.tgnn_sublayout_workspace_bytes(self.n, self.ea, self.ec)
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+
+    def build(self, alive: torch.Tensor) -> DeviceLayout:
+        """alive: int32 [N] on the device (!= 0 = unlabelled).  One host sync (the three counts)."""
+        o = self.o
+        check(lib.tgnn_sublayout_compact(ptr(alive), self.n, ptr(o.node_feature), self.fx,
+                                         ptr(o.align_edge_index) if self.ea else None, self.ea,
+                                         ptr(o.align_edge_features) if self.ea else None, self.fe,
+                                         ptr(o.collide_edge_index) if self.ec else None, self.ec,
+                                         ptr(self.x_out), ptr(self.inverse), ptr(self.adj_out), ptr(self.attr_out),
+                                         ptr(self.col_out), ptr(self.counts), ptr(self.err), ptr(self.ws), self.ws_bytes,
+                                         _lib.current_stream(alive.device)))
+        n2, ea2, ec2 = (int(v) for v in self.counts.cpu().tolist())
+        if int(self.err.item()):
+            raise IndexError("edge index out of range in the layout")
+        return DeviceLayout(self.x_out[:n2], self.adj_out[:2 * ea2].view(2, ea2), self.attr_out[:ea2 * self.fe].view(ea2, self.fe),
+                            self.col_out[:2 * ec2].view(2, ec2), self.inverse[:n2])
+
+
+def solve_by_probablistic_greedy(ml_solver, origin_layout, score_fn=None, on_round=None):
+    """algorithms.py:18-62.  `origin_layout`: BrickLayout-like numpy arrays (uploaded once) or a DeviceLayout."""
+    device = ml_solver.device
+    origin = origin_layout if isinstance(origin_layout, DeviceLayout) else DeviceLayout.upload(origin_layout, device)
+    n = int(origin.node_feature.shape[0])
+    col_host = origin.collide_edge_index.cpu().numpy()
+    if col_host.size:                                           # collision neighbours in edge order (algorithms.py:199)
+        by_src = np.argsort(col_host[0], kind="stable")
+        starts = np.searchsorted(col_host[0][by_src], np.arange(n + 1))
+        nbr = col_host[1][by_src]
+    builder = SubLayoutBuilder(origin)
+    prob_saved = np.ones(n)                                     # SelectionSolution.unlabelled_nodes (:285)
+    unlabelled = np.ones(n, dtype=bool)
+    alive_dev = torch.ones(n, dtype=torch.int32, device=origin.node_feature.device)
+    selection = np.zeros(n)
+    order = []
+    round_cnt = 1
+    while unlabelled.any():
+        temp_layout = builder.build(alive_dev)
+        ids = temp_layout.inverse_index.cpu().numpy()           # == np.flatnonzero(unlabelled)
+        if on_round is not None:
+            on_round(temp_layout)
+        prob = np.asarray(ml_solver.predict(temp_layout), dtype=np.float64).reshape(-1)
+        prob_per_node = np.power(np.power(prob_saved[ids], round_cnt - 1) * prob, 1 / round_cnt)     # (:33-34)
+        prob_saved[ids] = prob_per_node
+        killed = []
+        for idx in np.argsort(-prob_per_node):                  # (:41)
+            origin_idx = ids[idx]
+            if not unlabelled[origin_idx]:                      # (:47-48)
+                break
+            if np.exp((prob_per_node[idx] - 1) * 1.0) > np.random.uniform():     # (:51)
+                unlabelled[origin_idx] = False
+                selection[origin_idx] = 1
+                order.append(int(origin_idx))
+                killed.append(origin_idx)
+                if col_host.size:                               # label_collision_neighbor (:196-207)
+                    for v in nbr[starts[origin_idx]:starts[origin_idx + 1]]:
+                        if unlabelled[v]:
+                            unlabelled[v] = False
+                            killed.append(v)
+        if killed:
+            alive_dev[torch.from_numpy(np.asarray(killed, dtype=np.int64)).to(alive_dev.device)] = 0
+        round_cnt += 1
+    score = score_fn(selection, origin_layout) if score_fn is not None else None
+    return selection, score, order
