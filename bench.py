@@ -151,9 +151,9 @@ def main():
         n_local, ea_local, ec_local = n_total, ea_total, ec_total
     else:
         from tilingnn_amd.dist import ShardedTilinGNN
-        sharded = ShardedTilinGNN(net, sg, rank, world, dev)
-        step = sharded.step
-        n_local, ea_local, ec_local = sharded.n_local, sharded.ea_local, sharded.ec_local
+        shard_runner = ShardedTilinGNN(net, sg, rank, world, dev)
+        step = shard_runner.step
+        n_local, ea_local, ec_local = shard_runner.n_local, shard_runner.ea_local, shard_runner.ec_local
 
     def barrier():
         if sharded:
@@ -316,7 +316,7 @@ def main():
             line["greedy_sublayout"] = sub_info
         if class_ms is not None:
             line["kernel_classes"] = class_ms
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:           # the CPU leg is a 1-GPU (rank 0, N = 1) measurement
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
