@@ -305,7 +305,7 @@ def main():
                                    f"per GPU, 30-60-90 (tile_count 2), T=13 edge types, width 32, depth 20, "
                                    f"train-mode BatchNorm, graph prep included",
                        "n_nodes": n_total, "n_adj_edges": ea_total, "n_col_edges": ec_total,
-                       "parallelism": "single GPU" if not sharded else f"node-range shards x{world}, halo exchange + BN all-reduce (RCCL)"},
+                       "parallelism": "single GPU" if not sharded else f"node-range shards x{world}, one all-to-all per layer (halo rows + BN sums) over RCCL"},
             "roofline": roofline,
         }
         if cached_ms is not None:

@@ -250,20 +250,32 @@ int tgnn_forward(const tgnn_model_dims *dims, const void *const *params_host, co
  * (torch.distributed / RCCL in tilingnn_amd/dist.py): it enqueues its kernels on `stream`, calls back on the
  * host, and continues; a callback must enqueue its collective on `stream` or order it with `stream`.
  *   allreduce_f64(ctx, sum_buf, count, stream): sum_buf[0..count) <- sum over all shards      (BatchNorm sums)
- *   alltoall_rows(ctx, send_buf, recv_buf, row_floats, stream): send_buf holds n_send rows of row_floats floats
+ *   alltoall_rows(ctx, send_buf, recv_buf, row_floats, extra_rows, stream): send_buf holds n_send rows of row_floats floats
  *       (the owned rows listed in send_idx, grouped by destination shard); recv_buf must receive the n_rows - n_own
  *       halo rows in the order they sit behind the owned rows.  row_floats is C for the first exchange, 2 C after.
- * Both return 0 on success.  Train mode only (batch statistics over all n_total rows of the partition). */
+ * Both return 0 on success.  Train mode only (batch statistics over all n_total rows of the partition).
+ *
+ * Fused mode (world >= 1 and the two *_fused index arrays given; width 32): per message-passing layer ONE all-to-all
+ * instead of an all-reduce plus an all-to-all.  Every shard sends to EVERY peer the raw rows of both branches the
+ * peer keeps as halo, followed by 4 rows (256 floats = 128 doubles) with its local BatchNorm sums; the receiver adds
+ * the sums of all shards in rank order (identical statistics everywhere) and merges its halo rows itself.
+ *   send_idx_fused [n_send + 4 world]: per destination rank its rows of send_idx, then -1, -2, -3, -4
+ *   recv_idx_fused [n_halo + 4 world]: per source rank the halo slots 0.. it fills, then -1 - (4 p + k), k = 0..3
+ * alltoall_rows is then called with extra_rows = 4: the per-peer row counts are the plain ones + 4. */
 typedef struct tgnn_shard {
     int64_t n_own, n_rows, n_total;
     const int32_t *send_idx;        /* device, [n_send] local row numbers */
     int64_t n_send;
-    double *sum_buf;                /* device, >= 2 * 2 * 256 doubles */
-    float *send_buf;                /* device, >= max(n_send, 1) * 2 C floats */
-    float *recv_buf;                /* device, >= max(n_rows - n_own, 1) * 2 C floats */
+    double *sum_buf;                /* device, >= max(1024, 128 (world + 2)) doubles */
+    float *send_buf;                /* device, >= max(n_send + 4 world, 1) * 2 C floats */
+    float *recv_buf;                /* device, >= max(n_rows - n_own + 4 world, 1) * 2 C floats */
     int (*allreduce_f64)(void *ctx, double *buf, int64_t count, tgnn_stream_t stream);
-    int (*alltoall_rows)(void *ctx, const float *send, float *recv, int32_t row_floats, tgnn_stream_t stream);
+    int (*alltoall_rows)(void *ctx, const float *send, float *recv, int32_t row_floats, int32_t extra_rows,
+                         tgnn_stream_t stream);
     void *ctx;
+    int32_t world, rank;            /* fused mode */
+    const int32_t *send_idx_fused;  /* device, may be NULL = plain mode */
+    const int32_t *recv_idx_fused;  /* device */
 } tgnn_shard;
 size_t tgnn_forward_sharded_workspace_bytes(const tgnn_model_dims *dims, int64_t n_own, int64_t n_rows,
                                             int32_t n_types);

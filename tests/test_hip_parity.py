@@ -496,11 +496,12 @@ def test_sharded_hip_path_matches_unsharded(dev, world):
             assert float((a[k + ".running_var"] - b[k + ".running_var"]).abs().max()) < 1e-5
 
 
-@pytest.mark.parametrize("world", [1, 2, 4])
-def test_fused_sharded_forward_matches_unsharded(dev, world):
+@pytest.mark.parametrize("world,one_collective", [(1, True), (2, True), (4, True), (3, True), (2, False), (4, False)])
+def test_fused_sharded_forward_matches_unsharded(dev, world, one_collective):
     """tgnn_forward_sharded (the whole shard schedule in one library call, collectives through callbacks): P
-    virtual ranks = P threads on this one GPU (ThreadSimCollectives) against the unsharded forward and against the
-    per-op Python schedule; running statistics come from the GLOBAL sums."""
+    virtual ranks = P threads on this one GPU (ThreadSimCollectives) against the unsharded forward; both collective
+    schemes: one all-to-all per layer carrying raw halo rows + BatchNorm sums (default) and all-reduce + all-to-all;
+    running statistics come from the GLOBAL sums."""
     import threading
     from tilingnn_amd import dist as tdist
     from tilingnn_amd.synth import make_super_graph
@@ -514,7 +515,7 @@ def test_fused_sharded_forward_matches_unsharded(dev, world):
         tdist.LocalSimComm.setup(shards)
         nets = [make_net(dev, depth=depth)[0] for _ in range(world)]
         hub = tdist.ThreadSimCollectives.Hub(world)
-        runners = [tdist.FusedShardForward(nets[r], shards[r], dev, tdist.ThreadSimCollectives(hub, r))
+        runners = [tdist.FusedShardForward(nets[r], shards[r], dev, tdist.ThreadSimCollectives(hub, r), fused=one_collective)
                    for r in range(world)]
         parts, errors = [None] * world, []
 
@@ -535,7 +536,8 @@ def test_fused_sharded_forward_matches_unsharded(dev, world):
         torch.cuda.synchronize()
         got = torch.cat(parts)
         err = float((got - want).abs().max())
-        print(f"fused, world {world} depth {depth}: max |sharded - unsharded| = {err:.2e}")
+        print(f"one call, world {world}, one collective per layer {one_collective}, depth {depth}: "
+              f"max |sharded - unsharded| = {err:.2e}")
         assert got.shape == want.shape and err < tol
         if depth == 3:
             a, b = net.state_dict(), nets[0].state_dict()

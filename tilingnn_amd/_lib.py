@@ -36,7 +36,7 @@ class Graph(C.Structure):
 
 
 ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
-ALLTOALL_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
+ALLTOALL_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p)
 
 
 class ShardDesc(C.Structure):
@@ -44,7 +44,8 @@ class ShardDesc(C.Structure):
     _fields_ = [("n_own", C.c_int64), ("n_rows", C.c_int64), ("n_total", C.c_int64),
                 ("send_idx", C.c_void_p), ("n_send", C.c_int64),
                 ("sum_buf", C.c_void_p), ("send_buf", C.c_void_p), ("recv_buf", C.c_void_p),
-                ("allreduce_f64", ALLREDUCE_CB), ("alltoall_rows", ALLTOALL_CB), ("ctx", C.c_void_p)]
+                ("allreduce_f64", ALLREDUCE_CB), ("alltoall_rows", ALLTOALL_CB), ("ctx", C.c_void_p),
+                ("world", C.c_int32), ("rank", C.c_int32), ("send_idx_fused", C.c_void_p), ("recv_idx_fused", C.c_void_p)]
 
 
 def _load() -> C.CDLL:

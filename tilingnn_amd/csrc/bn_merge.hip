@@ -169,6 +169,66 @@ static inline unsigned ew_grid(int64_t n, int cap = 256 * 8) {
     return (unsigned)g;
 }
 
+// ------------------------------------------------------------------------------------------
+// Sharded forward: ONE all-to-all per layer carries, to every peer, the raw (pre-BatchNorm) rows of both branches
+// that the peer keeps as halo AND this shard's local BatchNorm sums (4 extra rows of 64 floats = 128 doubles:
+// [bn1: sum, sumsq][bn2: sum, sumsq] x 32).  Every shard then adds the sums of all shards in rank order (the same
+// order everywhere -> identical statistics everywhere, no all-reduce) and merges its own AND its halo rows itself.
+// idx >= 0: a row to pack / a halo slot to fill; idx < 0: sum row number -1 - idx.
+// ------------------------------------------------------------------------------------------
+__global__ void shard_pack_kernel(const float *__restrict__ a1, const float *__restrict__ a2, const int *__restrict__ idx,
+                                  int64_t n_rows, const float *__restrict__ sums_as_float, float *__restrict__ out) {
+    const int64_t total = n_rows * 64;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i >> 6;
+        const int k = (int)(i & 63), id = idx[r];
+        float v;
+        if (id >= 0) v = k < 32 ? a1[(int64_t)id * 32 + k] : a2[(int64_t)id * 32 + (k - 32)];
+        else v = sums_as_float[(-1 - id) * 64 + k];
+        out[i] = v;
+    }
+}
+// idx >= 0: halo slot j -> a1[(n_own + j)], a2[(n_own + j)];  idx < 0: code = -1 - idx = 4 * peer + k -> peer_sums
+__global__ void shard_unpack_kernel(const float *__restrict__ in, const int *__restrict__ idx, int64_t n_rows,
+                                    int64_t n_own, float *__restrict__ a1, float *__restrict__ a2,
+                                    float *__restrict__ peer_sums_as_float) {
+    const int64_t total = n_rows * 64;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i >> 6;
+        const int k = (int)(i & 63), id = idx[r];
+        const float v = in[i];
+        if (id >= 0) {
+            if (k < 32) a1[(n_own + id) * 32 + k] = v;
+            else a2[(n_own + id) * 32 + (k - 32)] = v;
+        } else {
+            peer_sums_as_float[(int64_t)(-1 - id) * 64 + k] = v;
+        }
+    }
+}
+// total[j] = sum over the shards, in rank order, of their 128 sums (this shard's own at position `rank`)
+__global__ void shard_sum_peers_kernel(const double *__restrict__ peer_sums, const double *__restrict__ own, int world,
+                                       int rank, double *__restrict__ total) {
+    const int j = threadIdx.x;                             // 128 threads
+    double t = 0.0;
+    for (int p = 0; p < world; ++p) t += p == rank ? own[j] : peer_sums[(int64_t)p * 128 + j];
+    total[j] = t;
+}
+
+void launch_shard_pack(const float *a1, const float *a2, const int *idx, int64_t n_rows, const double *sums, float *out,
+                       hipStream_t s) {
+    if (n_rows > 0)
+        shard_pack_kernel<<<ew_grid(n_rows * 64), 256, 0, s>>>(a1, a2, idx, n_rows, reinterpret_cast<const float *>(sums), out);
+}
+void launch_shard_unpack(const float *in, const int *idx, int64_t n_rows, int64_t n_own, float *a1, float *a2,
+                         double *peer_sums, hipStream_t s) {
+    if (n_rows > 0)
+        shard_unpack_kernel<<<ew_grid(n_rows * 64), 256, 0, s>>>(in, idx, n_rows, n_own, a1, a2,
+                                                                 reinterpret_cast<float *>(peer_sums));
+}
+void launch_shard_sum_peers(const double *peer_sums, const double *own, int world, int rank, double *total, hipStream_t s) {
+    shard_sum_peers_kernel<<<1, 128, 0, s>>>(peer_sums, own, world, rank, total);
+}
+
 void launch_bn_finalize(const BnJobs &jobs, int n_jobs, int mode, int f, int64_t n_total, float eps, float momentum,
                         hipStream_t s) {
     bn_finalize_kernel<<<n_jobs, 1024, 0, s>>>(jobs, mode, f, n_total, eps, momentum);

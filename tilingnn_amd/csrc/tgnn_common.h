@@ -97,6 +97,13 @@ struct BnJobs {
 // one block per job (1 or 2 BatchNorms of the same width finalised by one launch); bn_merge.hip
 void launch_bn_finalize(const BnJobs &jobs, int n_jobs, int mode, int f, int64_t n_total, float eps, float momentum,
                         hipStream_t s);
+// sharded forward, one all-to-all per layer (width 32): pack halo rows of both branches + local BN sums, unpack, add
+// the shards' sums in rank order; bn_merge.hip
+void launch_shard_pack(const float *a1, const float *a2, const int *idx, int64_t n_rows, const double *sums, float *out,
+                       hipStream_t s);
+void launch_shard_unpack(const float *in, const int *idx, int64_t n_rows, int64_t n_own, float *a1, float *a2,
+                         double *peer_sums, hipStream_t s);
+void launch_shard_sum_peers(const double *peer_sums, const double *own, int world, int rank, double *total, hipStream_t s);
 
 // GraphConv edge-MLP parameters of up to 64 layers, passed by value to one batched launch; nnconv.hip
 struct EdgeMlpLayer {

@@ -348,11 +348,14 @@ class LocalSimComm:
 
 class FusedShardForward:
     """One shard's forward through `tgnn_forward_sharded` (csrc/forward.hip): the whole schedule of ShardProgram in
-    ONE library call that enqueues ~150 launches and calls back for the 47 collectives -- the per-op Python
+    ONE library call that enqueues ~150 launches and calls back for the collectives -- the per-op Python
     schedule above costs ~2x the GPU time in host overhead at 100k nodes.  `comm` supplies
-    allreduce(tensor) and alltoall(send, send_splits, recv, recv_splits)."""
+    allreduce(tensor) and alltoall(send, send_splits, recv, recv_splits).
+    fused=True (default): one all-to-all per message-passing layer carries the raw halo rows of both branches and
+    the local BatchNorm sums to every peer (27 collectives per forward); fused=False: all-reduce of the sums, then
+    all-to-all of the merged rows (47)."""
 
-    def __init__(self, net, shard: Shard, device, comm, inputs=None):
+    def __init__(self, net, shard: Shard, device, comm, inputs=None, fused: bool = True):
         import ctypes as C
         from . import _lib, ops
         self._C, self._lib, self._ops = C, _lib, ops
@@ -364,10 +367,23 @@ class FusedShardForward:
         self.n_halo = shard.n_rows - shard.n_own
         self.send_splits = [int(x.shape[0]) for x in shard.send_ids]
         self.recv_splits = list(shard.recv_counts)
-        self.sum_buf = torch.zeros(2 * 2 * 256, dtype=torch.float64, device=self.dev)
-        self.send_buf = torch.zeros(max(self.n_send, 1) * 2 * c, dtype=torch.float32, device=self.dev)
-        self.recv_buf = torch.zeros(max(self.n_halo, 1) * 2 * c, dtype=torch.float32, device=self.dev)
+        world = shard.world
+        self.sum_buf = torch.zeros(max(1024, 128 * (world + 2)), dtype=torch.float64, device=self.dev)
+        self.send_buf = torch.zeros(max(self.n_send + 4 * world, 1) * 2 * c, dtype=torch.float32, device=self.dev)
+        self.recv_buf = torch.zeros(max(self.n_halo + 4 * world, 1) * 2 * c, dtype=torch.float32, device=self.dev)
         self._error = None
+        # fused layers (one all-to-all per layer, include/tgnn.h): per peer its rows, then 4 rows of BatchNorm sums
+        send_ext, recv_ext, halo_at = [], [], 0
+        for p_ in range(world):
+            send_ext.append(np.asarray(shard.send_ids[p_], dtype=np.int32))
+            send_ext.append(np.array([-1, -2, -3, -4], dtype=np.int32))
+            k = int(shard.recv_counts[p_])
+            recv_ext.append(np.arange(halo_at, halo_at + k, dtype=np.int32))
+            recv_ext.append(np.array([-1 - (4 * p_ + j) for j in range(4)], dtype=np.int32))
+            halo_at += k
+        self.fused = fused and c == 32
+        self.send_idx_fused = torch.from_numpy(np.concatenate(send_ext)).to(self.dev)
+        self.recv_idx_fused = torch.from_numpy(np.concatenate(recv_ext)).to(self.dev)
 
         def allreduce_cb(_ctx, _buf, count, _stream):
             try:
@@ -377,11 +393,14 @@ class FusedShardForward:
                 self._error = exc
                 return 1
 
-        def alltoall_cb(_ctx, _send, _recv, row_floats, _stream):
+        def alltoall_cb(_ctx, _send, _recv, row_floats, extra_rows, _stream):
             try:
-                send = self.send_buf[: self.n_send * row_floats].view(self.n_send, row_floats)
-                recv = self.recv_buf[: self.n_halo * row_floats].view(self.n_halo, row_floats)
-                self.comm.alltoall(send, self.send_splits, recv, self.recv_splits)
+                n_out = self.n_send + extra_rows * self.shard.world
+                n_in = self.n_halo + extra_rows * self.shard.world
+                send = self.send_buf[: n_out * row_floats].view(n_out, row_floats)
+                recv = self.recv_buf[: n_in * row_floats].view(n_in, row_floats)
+                self.comm.alltoall(send, [k + extra_rows for k in self.send_splits], recv,
+                                   [k + extra_rows for k in self.recv_splits])
                 return 0
             except BaseException as exc:
                 self._error = exc
@@ -401,7 +420,9 @@ class FusedShardForward:
         probs = torch.empty(sh.n_own, net.output_dim, dtype=torch.float32, device=self.dev)
         desc = _lib.ShardDesc(sh.n_own, sh.n_rows, sh.n_total, inp["send_idx"].data_ptr(), self.n_send,
                               self.sum_buf.data_ptr(), self.send_buf.data_ptr(), self.recv_buf.data_ptr(),
-                              self._cbs[0], self._cbs[1], None)
+                              self._cbs[0], self._cbs[1], None, sh.world, sh.rank,
+                              self.send_idx_fused.data_ptr() if self.fused else None,
+                              self.recv_idx_fused.data_ptr() if self.fused else None)
         g = graph.c_struct()
         self._error = None
         rc = _lib.lib.tgnn_forward_sharded(C.byref(dims), table, ops.ptr(inp["x"]), ops.ptr(inp["attr"]), C.byref(g),
