@@ -237,7 +237,8 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(
 // bf16 x 3 split-precision variant for the big Linear blocks (in_dim % 32 == 0, out_dim >= 64).
 //
 // gfx950 runs bf16 MFMA at 16x the fp32 MFMA rate.  Every fp32 operand is split exactly into three bf16
-// pieces x = hi + mid + lo (|x - (hi+mid+lo)| <= 2^-25 |x|) while its tile is staged into LDS, and the product
+// pieces x = hi + mid + lo (by truncation, 8 + 8 + 8 significant bits: no rounding at all) while its tile is staged
+// into LDS, and the product
 // is accumulated in fp32 from the six leading cross terms
 //        hi.hi + hi.mid + mid.hi + mid.mid + hi.lo + lo.hi          (dropped terms <= 2^-24 |a||b|)
 // on v_mfma_f32_32x32x16_bf16: 6 x 32 cycles per 32x32x16 block instead of 8 x 64 for the fp32 MFMA --
@@ -250,16 +251,7 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 constexpr int kSplitLd = 40;   // bf16 elements per LDS row (32 used)
 
 __device__ __forceinline__ void split3(const float (&x)[8], bf16x8 &hi, bf16x8 &mid, bf16x8 &lo) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const __bf16 h = (__bf16)x[i];
-        const float r1 = x[i] - (float)h;       // exact
-        const __bf16 m = (__bf16)r1;
-        const float r2 = r1 - (float)m;         // exact
-        hi[i] = h;
-        mid[i] = m;
-        lo[i] = (__bf16)r2;
-    }
+    split3_trunc(x, hi, mid, lo);           // exact three-way split by truncation, tgnn_common.h
 }
 
 template <int TM, int WN>

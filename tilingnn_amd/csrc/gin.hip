@@ -106,16 +106,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 __device__ __forceinline__ int gin_kf(int q, int e) { return e < 4 ? 4 * q + e : 16 + 4 * q + (e - 4); }
 
 __device__ __forceinline__ void gin_split3(const float (&x)[8], bf16x8 &hi, bf16x8 &mid, bf16x8 &lo) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const __bf16 h = (__bf16)x[i];
-        const float r1 = x[i] - (float)h;       // exact
-        const __bf16 m = (__bf16)r1;
-        const float r2 = r1 - (float)m;         // exact
-        hi[i] = h;
-        mid[i] = m;
-        lo[i] = (__bf16)r2;
-    }
+    split3_trunc(x, hi, mid, lo);           // exact three-way split by truncation, tgnn_common.h
 }
 
 // acc += W . X over one K step of 32: six cross terms, smallest first

@@ -157,14 +157,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
             const bool root = t == n_types;                  // wave-uniform
             const float scale = root ? (s >= 0 ? __int_as_float(s) : 0.f) : 1.0f;   // root column: max(deg, 1) in the source slot
             bf16x8 xh, xm, xl;
+            {
+                float as[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float a = af[k] * scale;
-                const __bf16 h = (__bf16)a;
-                const float r1 = a - (float)h;               // exact
-                const __bf16 m = (__bf16)r1;
-                const float r2 = r1 - (float)m;              // exact
-                xh[k] = h; xm[k] = m; xl[k] = (__bf16)r2;
+                for (int k = 0; k < 8; ++k) as[k] = af[k] * scale;
+                split3_trunc(as, xh, xm, xl);
             }
             const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(wl + t * kWtType) + fj * 4 + fq;
             constexpr int kPl = kWtPlane / 4;                // 16-byte fragments per plane

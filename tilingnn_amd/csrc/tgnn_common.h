@@ -73,6 +73,35 @@ __device__ __forceinline__ float bn_apply1(float v, float mhi, float mlo, float 
     return ((v - mhi) - mlo) * g + b;
 }
 
+// ------------------------------------------------------------------------------------------
+// Exact split of 8 fp32 values into three bf16 pieces (hi + mid + lo == x), packed for the bf16 MFMAs.
+// By TRUNCATION on the bit pattern: hi = top 16 bits of x, mid = top 16 bits of x - hi, lo = x - hi - mid.  The 24
+// significant bits of x fall 8 + 8 + 8 into the three pieces, every subtraction is exact, lo needs no rounding.
+// 4.5 vector instructions per element (2 AND, 2 SUB as packed pairs, 3 byte-permutes per pair) against ~7 for
+// the convert-based sequence (convert, re-expand, subtract, twice).
+// ------------------------------------------------------------------------------------------
+using tgnn_bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using tgnn_u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+__device__ __forceinline__ void split3_trunc(const float (&x)[8], tgnn_bf16x8 &hi, tgnn_bf16x8 &mid, tgnn_bf16x8 &lo) {
+    tgnn_u32x4 ph, pm, pl;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const unsigned int a0 = __float_as_uint(x[2 * p]), a1 = __float_as_uint(x[2 * p + 1]);
+        const float r0 = x[2 * p] - __uint_as_float(a0 & 0xffff0000u);
+        const float r1 = x[2 * p + 1] - __uint_as_float(a1 & 0xffff0000u);
+        const unsigned int b0 = __float_as_uint(r0), b1 = __float_as_uint(r1);
+        const float s0 = r0 - __uint_as_float(b0 & 0xffff0000u);
+        const float s1 = r1 - __uint_as_float(b1 & 0xffff0000u);
+        // element 2p in the low half, 2p+1 in the high half: bytes {a0[2], a0[3], a1[2], a1[3]}
+        ph[p] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+        pm[p] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+        pl[p] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    }
+    hi = __builtin_bit_cast(tgnn_bf16x8, ph);
+    mid = __builtin_bit_cast(tgnn_bf16x8, pm);
+    lo = __builtin_bit_cast(tgnn_bf16x8, pl);
+}
+
 // Number of persistent blocks for a row-parallel producer: also the number of BN partial rows.
 static inline int producer_blocks(int64_t n_rows, int rows_per_block) {
     int64_t nb = (n_rows + rows_per_block - 1) / rows_per_block;
