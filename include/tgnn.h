@@ -171,6 +171,13 @@ int tgnn_dense_act_fwd(const float *a, int64_t lda, int64_t a_kblock_stride, con
                        const float *w, const float *b, int64_t n_rows, int32_t in_dim, int32_t out_dim,
                        int32_t act, float *out, int64_t ldo, double *bn_partial, int32_t *n_partials_host,
                        tgnn_stream_t stream);
+/* The same Linear block over a SLOT-MAJOR input [S][N][slot_width] (the skip-connection buffer read as the
+ * concatenation of its S slots, TilinGNN.py:74: in_dim = S * slot_width, feature k of row r lives at
+ * a[(k / slot_width) * slot_stride + r * slot_width + k % slot_width]); slot_width a multiple of 32. */
+int tgnn_dense_act_slots_fwd(const float *a, int32_t slot_width, int64_t slot_stride, const float *in_stat,
+                             const float *w, const float *b, int64_t n_rows, int32_t in_dim, int32_t out_dim,
+                             int32_t act, float *out, int64_t ldo, double *bn_partial, int32_t *n_partials_host,
+                             tgnn_stream_t stream);
 
 /* Train-mode BatchNorm1d statistics (fact 2 of SURVEY.md: the reference never leaves train mode).
  * mode 0: partials -> stat (+ running stats)      single GPU

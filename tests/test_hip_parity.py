@@ -765,3 +765,28 @@ def test_greedy_loop_with_the_network_matches_the_restated_loop(dev):
     blocked = np.zeros_like(chosen)
     blocked[g["col"][1][chosen[g["col"][0]]]] = True
     assert (chosen | blocked).all()                                        # every tile is selected or blocked
+
+
+@pytest.mark.parametrize("width", [64, 96])
+def test_other_network_widths_run_on_the_general_kernels(dev, width):
+    """network_width = 64 (BASELINE config #3) and 96: the matrix-core fast paths are built for the reference's default
+    width 32; other widths (multiples of 32) take the general CSR / generic kernels and the slot-major Linear with
+    several K blocks per slot.  Per-op parity against the fp64 oracle on the real graph, depth 3."""
+    g = load_labyrinth_graph()
+    net, sd = make_net(dev, depth=3, width=width)
+    sd64 = orc.cast_sd(sd, torch.float64)
+    x, adj, adj_attr, col, _ = graph_tensors(g, torch.float32, dev)
+    cap = {}
+    with torch.no_grad():
+        want, _ = orc.tilingnn_forward(sd64, *graph_tensors(g, torch.float64)[:4], update_running=False, capture=cap)
+    probs, _ = net(x=x, adj_e_index=adj, adj_e_features=adj_attr, col_e_idx=col)
+    assert probs.shape == (1254, 1) and bool(torch.isfinite(probs).all())
+    assert float((probs.cpu().double() - want).abs().max()) < 2e-3          # 3 layers: still far from the chaotic regime
+    # teacher-forced ops at this width
+    h = cap["h1_in.1"].float().to(dev)
+    l1, l2 = net.brch_1_graph_conv_layers[1], net.brch_2_coll_conv_layers[1]
+    with torch.no_grad():
+        w1 = orc.nnconv_mean(h.double().cpu(), adj.cpu(), adj_attr.double().cpu(), sd64, "brch_1_graph_conv_layers.1")
+        w2 = orc.gin_conv(h.double().cpu(), col.cpu(), sd64, "brch_2_coll_conv_layers.1")
+    assert orc.rel_max_err(l1.nnConv(h, adj, adj_attr).cpu(), w1) < TOL
+    assert orc.rel_max_err(l2.ginConv(h, col).cpu(), w2) < TOL

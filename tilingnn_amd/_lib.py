@@ -75,6 +75,7 @@ def _load() -> C.CDLL:
         "tgnn_nnconv_mean_cols_fwd": (C.c_int, [p, i64, p, p, p, p, i32, p, p, i64, i32, i32, p, p, p, pi32, p]),
         "tgnn_gin_fwd": (C.c_int, [p, i64, p, p, p, p, p, p, p, p, p, p, i64, i32, i32, p, p, p, pi32, p]),
         "tgnn_dense_act_fwd": (C.c_int, [p, i64, i64, p, p, p, i64, i32, i32, i32, p, i64, p, pi32, p]),
+        "tgnn_dense_act_slots_fwd": (C.c_int, [p, i32, i64, p, p, p, i64, i32, i32, i32, p, i64, p, pi32, p]),
         "tgnn_bn_finalize": (C.c_int, [i32, p, i32, p, i32, i64, p, p, f32, f32, p, p, p, p, p]),
         "tgnn_bn_apply": (C.c_int, [p, i64, p, i64, i32, p, i64, p]),
         "tgnn_merge_fwd": (C.c_int, [p, p, p, p, p, i64, i32, p, p, p]),
@@ -106,7 +107,7 @@ EXPORTED_SYMBOLS = (
     "tgnn_version", "tgnn_last_error", "tgnn_csr_workspace_bytes", "tgnn_csr_build",
     "tgnn_edge_dedup_workspace_bytes", "tgnn_edge_type_dedup", "tgnn_gather_i32", "tgnn_edge_weight_table",
     "tgnn_nnconv_mean_fwd", "tgnn_nnconv_cols_max_columns", "tgnn_nnconv_cols_workspace_bytes",
-    "tgnn_nnconv_cols_build", "tgnn_nnconv_cols_max_types", "tgnn_nnconv_weight_image_floats", "tgnn_nnconv_mean_cols_fwd", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
+    "tgnn_nnconv_cols_build", "tgnn_nnconv_cols_max_types", "tgnn_nnconv_weight_image_floats", "tgnn_nnconv_mean_cols_fwd", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_dense_act_slots_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
     "tgnn_merge_fwd", "tgnn_param_count", "tgnn_param_name", "tgnn_forward_workspace_bytes", "tgnn_forward",
     "tgnn_forward_profiled", "tgnn_forward_sharded_workspace_bytes", "tgnn_forward_sharded",
     "tgnn_rows_gather", "tgnn_rows_scatter", "tgnn_unsupervised_loss_workspace_bytes", "tgnn_unsupervised_loss",

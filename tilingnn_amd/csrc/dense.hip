@@ -27,6 +27,13 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kBM = 128, kBK = 32, kLD = 33;
 
+// Where the 32-column K block `kt` of the A operand starts.  A is a sequence of SLOTS of kps K blocks each: block kt
+// lives in slot kt / kps at column 32 (kt % kps); slots are `slot_stride` floats apart.  Row-major [N, K]: one slot
+// (or kps = 1, stride 32); the slot-major skip buffer [D+1][N][C]: kps = C / 32, stride N C.
+__device__ __forceinline__ int64_t a_kblock_offset(int kt, int kps, int64_t slot_stride) {
+    return kps == 1 ? (int64_t)kt * slot_stride : (int64_t)(kt / kps) * slot_stride + (int64_t)(kt % kps) * kBK;
+}
+
 struct Frag4 {
     float v[4];
 };
@@ -37,7 +44,7 @@ struct Frag4 {
 // per k-tile (measured: 47 TF; the same kernel branch-free: see profiles/).
 template <int NT, bool FAST>
 __global__ __launch_bounds__(256) void dense_mfma_kernel(
-    const float *__restrict__ a, int64_t lda, int64_t a_kb_stride, const float *__restrict__ in_stat,
+    const float *__restrict__ a, int64_t lda, int64_t a_kb_stride, int kps, const float *__restrict__ in_stat,
     const float *__restrict__ w, const float *__restrict__ bias, int64_t n, int in_dim, int out_dim, int act,
     float *__restrict__ out, int64_t ldo, double *__restrict__ bn_partial, int vec_a, int vec_w) {
     constexpr int BN = 32 * NT;
@@ -61,7 +68,7 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(
             for (int j = 0; j < 4; ++j) {
                 int64_t row = m0 + ld_r + 32 * j;
                 row = row < n ? row : n - 1;
-                const float4 t4 = *reinterpret_cast<const float4 *>(a + (int64_t)kt * a_kb_stride + row * lda + 4 * ld_q);
+                const float4 t4 = *reinterpret_cast<const float4 *>(a + a_kblock_offset(kt, kps, a_kb_stride) + row * lda + 4 * ld_q);
                 ra[j].v[0] = t4.x; ra[j].v[1] = t4.y; ra[j].v[2] = t4.z; ra[j].v[3] = t4.w;
             }
             return;
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) ra[j].v[e] = 0.f;
             if (row < n) {
-                const float *src = a + (int64_t)kt * a_kb_stride + row * lda + 4 * ld_q;
+                const float *src = a + a_kblock_offset(kt, kps, a_kb_stride) + row * lda + 4 * ld_q;
                 if (vec_a && k + 3 < in_dim) {
                     const float4 t4 = *reinterpret_cast<const float4 *>(src);
                     ra[j].v[0] = t4.x; ra[j].v[1] = t4.y; ra[j].v[2] = t4.z; ra[j].v[3] = t4.w;
@@ -256,7 +263,7 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8 &hi, bf16x8 &
 
 template <int TM, int WN>
 __global__ __launch_bounds__(256, 2) void dense_split_kernel(
-    const float *__restrict__ a, int64_t lda, int64_t a_kb_stride, const float *__restrict__ in_stat,
+    const float *__restrict__ a, int64_t lda, int64_t a_kb_stride, int kps, const float *__restrict__ in_stat,
     const float *__restrict__ w, const float *__restrict__ bias, int64_t n, int in_dim, int out_dim, int act,
     float *__restrict__ out, int64_t ldo, double *__restrict__ bn_partial) {
     constexpr int WM = 4 / WN;                 // waves along M
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(
             const int item = tid + 256 * j, r = item >> 2, o = item & 3;       // row r, k-octet o
             int64_t row = m0 + r;
             row = row < n ? row : n - 1;
-            const float4 *p = reinterpret_cast<const float4 *>(a + (int64_t)kt * a_kb_stride + row * lda + 8 * o);
+            const float4 *p = reinterpret_cast<const float4 *>(a + a_kblock_offset(kt, kps, a_kb_stride) + row * lda + 8 * o);
             ra[j][0] = p[0];
             ra[j][1] = p[1];
         }
@@ -424,9 +431,9 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(
 }
 
 template <int TM, int WN>
-static void launch_dense_split(int blocks_x, hipStream_t s, const float *a, int64_t lda, int64_t akb, const float *in_stat,
-                               const float *w, const float *b, int64_t n, int in_dim, int out_dim, int act, float *out,
-                               int64_t ldo, double *bn_partial) {
+static void launch_dense_split(int blocks_x, hipStream_t s, const float *a, int64_t lda, int64_t akb, int kps,
+                               const float *in_stat, const float *w, const float *b, int64_t n, int in_dim, int out_dim,
+                               int act, float *out, int64_t ldo, double *bn_partial) {
     constexpr int BM = (4 / WN) * TM * 32, BN = WN * 64;
     size_t lds = (size_t)3 * (BM + BN) * kSplitLd * 2;
     const size_t red = (size_t)(4 / WN) * 2 * BN * sizeof(double);
@@ -438,18 +445,18 @@ static void launch_dense_split(int blocks_x, hipStream_t s, const float *a, int6
         attr_set = true;
     }
     dense_split_kernel<TM, WN><<<dim3(blocks_x, (out_dim + BN - 1) / BN), 256, lds, s>>>(
-        a, lda, akb, in_stat, w, b, n, in_dim, out_dim, act, out, ldo, bn_partial);
+        a, lda, akb, kps, in_stat, w, b, n, in_dim, out_dim, act, out, ldo, bn_partial);
 }
 
 template <int NT, bool FAST>
-static void launch_dense(dim3 grid, hipStream_t s, const float *a, int64_t lda, int64_t akb, const float *in_stat,
+static void launch_dense(dim3 grid, hipStream_t s, const float *a, int64_t lda, int64_t akb, int kps, const float *in_stat,
                          const float *w, const float *b, int64_t n, int in_dim, int out_dim, int act, float *out,
                          int64_t ldo, double *bn_partial, int vec_a, int vec_w) {
     constexpr int BN = 32 * NT;
     size_t lds = (size_t)(kBM + BN) * kLD * sizeof(float);
     const size_t red = (size_t)4 * 2 * BN * sizeof(double);
     if (red > lds) lds = red;
-    dense_mfma_kernel<NT, FAST><<<grid, 256, lds, s>>>(a, lda, akb, in_stat, w, b, n, in_dim, out_dim, act, out, ldo,
+    dense_mfma_kernel<NT, FAST><<<grid, 256, lds, s>>>(a, lda, akb, kps, in_stat, w, b, n, in_dim, out_dim, act, out, ldo,
                                                        bn_partial, vec_a, vec_w);
 }
 
@@ -457,10 +464,9 @@ static void launch_dense(dim3 grid, hipStream_t s, const float *a, int64_t lda, 
 
 using namespace tgnn;
 
-extern "C" int tgnn_dense_act_fwd(const float *a, int64_t lda, int64_t a_kblock_stride, const float *in_stat,
-                                  const float *w, const float *b, int64_t n_rows, int32_t in_dim, int32_t out_dim,
-                                  int32_t act, float *out, int64_t ldo, double *bn_partial,
-                                  int32_t *n_partials_host, tgnn_stream_t stream) {
+static int dense_act_impl(const float *a, int64_t lda, int64_t a_kblock_stride, int kps, const float *in_stat,
+                          const float *w, const float *b, int64_t n_rows, int32_t in_dim, int32_t out_dim, int32_t act,
+                          float *out, int64_t ldo, double *bn_partial, int32_t *n_partials_host, tgnn_stream_t stream) {
     TGNN_CHECK_ARG(n_rows >= 0 && in_dim >= 1 && out_dim >= 1, "shape");
     TGNN_CHECK_ARG(act >= TGNN_ACT_NONE && act <= TGNN_ACT_SIGMOID, "activation");
     if (n_rows == 0) {
@@ -470,6 +476,7 @@ extern "C" int tgnn_dense_act_fwd(const float *a, int64_t lda, int64_t a_kblock_
     TGNN_CHECK_ARG(a && w && b && out, "null pointer");
     TGNN_CHECK_ARG(ldo >= out_dim, "ldo");
     TGNN_CHECK_ARG(in_dim <= kBK || lda >= kBK || a_kblock_stride == kBK, "A layout");
+    TGNN_CHECK_ARG(kps >= 1, "K blocks per slot");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int vec_a = (lda % 4 == 0) && (a_kblock_stride % 4 == 0) && ((uintptr_t)a % 16 == 0);
     const int vec_w = (in_dim % 4 == 0) && ((uintptr_t)w % 16 == 0);
@@ -480,12 +487,12 @@ extern "C" int tgnn_dense_act_fwd(const float *a, int64_t lda, int64_t a_kblock_
         // bf16 x 3 split-precision path (see dense_split_kernel)
         if (out_dim > 64) {
             const int bx = producer_blocks(n_rows, 128);
-            launch_dense_split<2, 2>(bx, s, a, lda, a_kblock_stride, in_stat, w, b, n_rows, in_dim, out_dim, act, out, ldo,
+            launch_dense_split<2, 2>(bx, s, a, lda, a_kblock_stride, kps, in_stat, w, b, n_rows, in_dim, out_dim, act, out, ldo,
                                      bn_partial);
             if (n_partials_host) *n_partials_host = bx;
         } else {
             const int bx = producer_blocks(n_rows, 128);
-            launch_dense_split<1, 1>(bx, s, a, lda, a_kblock_stride, in_stat, w, b, n_rows, in_dim, out_dim, act, out, ldo,
+            launch_dense_split<1, 1>(bx, s, a, lda, a_kblock_stride, kps, in_stat, w, b, n_rows, in_dim, out_dim, act, out, ldo,
                                      bn_partial);
             if (n_partials_host) *n_partials_host = bx;
         }
@@ -496,10 +503,10 @@ extern "C" int tgnn_dense_act_fwd(const float *a, int64_t lda, int64_t a_kblock_
     do {                                                                                                           \
         const dim3 grid_(blocks_x, (out_dim + 32 * NT_ - 1) / (32 * NT_));                                         \
         if (fast)                                                                                                  \
-            launch_dense<NT_, true>(grid_, s, a, lda, a_kblock_stride, in_stat, w, b, n_rows, in_dim, out_dim, act, \
+            launch_dense<NT_, true>(grid_, s, a, lda, a_kblock_stride, kps, in_stat, w, b, n_rows, in_dim, out_dim, act, \
                                     out, ldo, bn_partial, vec_a, vec_w);                                           \
         else                                                                                                       \
-            launch_dense<NT_, false>(grid_, s, a, lda, a_kblock_stride, in_stat, w, b, n_rows, in_dim, out_dim, act, \
+            launch_dense<NT_, false>(grid_, s, a, lda, a_kblock_stride, kps, in_stat, w, b, n_rows, in_dim, out_dim, act, \
                                      out, ldo, bn_partial, vec_a, vec_w);                                          \
     } while (0)
     static const int force_nt = getenv("TGNN_DENSE_NT") ? atoi(getenv("TGNN_DENSE_NT")) : 0;   // tuning knob (experiments)
@@ -520,4 +527,22 @@ extern "C" int tgnn_dense_act_fwd(const float *a, int64_t lda, int64_t a_kblock_
     if (n_partials_host) *n_partials_host = blocks_x;
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
+}
+
+extern "C" int tgnn_dense_act_fwd(const float *a, int64_t lda, int64_t a_kblock_stride, const float *in_stat,
+                                  const float *w, const float *b, int64_t n_rows, int32_t in_dim, int32_t out_dim,
+                                  int32_t act, float *out, int64_t ldo, double *bn_partial,
+                                  int32_t *n_partials_host, tgnn_stream_t stream) {
+    return dense_act_impl(a, lda, a_kblock_stride, 1, in_stat, w, b, n_rows, in_dim, out_dim, act, out, ldo, bn_partial,
+                          n_partials_host, stream);
+}
+
+extern "C" int tgnn_dense_act_slots_fwd(const float *a, int32_t slot_width, int64_t slot_stride, const float *in_stat,
+                                        const float *w, const float *b, int64_t n_rows, int32_t in_dim, int32_t out_dim,
+                                        int32_t act, float *out, int64_t ldo, double *bn_partial,
+                                        int32_t *n_partials_host, tgnn_stream_t stream) {
+    TGNN_CHECK_ARG(slot_width >= 32 && slot_width % 32 == 0 && in_dim % slot_width == 0,
+                   "slot-major input: slot width must be a multiple of 32 that divides in_dim");
+    return dense_act_impl(a, slot_width, slot_stride, slot_width / 32, in_stat, w, b, n_rows, in_dim, out_dim, act, out, ldo,
+                          bn_partial, n_partials_host, stream);
 }

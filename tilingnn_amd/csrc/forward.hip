@@ -461,10 +461,10 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     for (int l = 0; l < 4; ++l) {
         const int pi = P.fin(l);
         if (l == 0) {
-            TGNN_CHECK_ARG(c == 32, "final MLP over the slot-major buffer needs network_width == 32");
+            TGNN_CHECK_ARG(c % 32 == 0, "final MLP over the slot-major buffer needs a network_width that is a multiple of 32");
             prof.begin(6);
-            TGNN_TRY(tgnn_dense_act_fwd(w.mid, c, (int64_t)nr * c, nullptr, P.f(pi), P.f(pi + 1), n, cat_dim, fdim[1],
-                                        TGNN_ACT_LEAKY_RELU, fbuf[0], fdim[1], w.partf, &np1, s));
+            TGNN_TRY(tgnn_dense_act_slots_fwd(w.mid, c, (int64_t)nr * c, nullptr, P.f(pi), P.f(pi + 1), n, cat_dim, fdim[1],
+                                              TGNN_ACT_LEAKY_RELU, fbuf[0], fdim[1], w.partf, &np1, s));
             prof.end();
         } else {
             prof.begin(6);

@@ -247,12 +247,23 @@ def gin(a: Tensor, graph: PreparedGraph, eps: Tensor, w1, b1, w2, b2, w3, b3, ac
 def dense_act(a: Tensor, weight: Tensor, bias: Tensor, act: int, in_stat: Optional[Tensor] = None,
               partials: Optional[Tensor] = None, slot_major: bool = False) -> Tuple[Tensor, int]:
     """act(BN_in(a) @ weight.T + bias) for a row-major [N, in] matrix, or (slot_major) for the
-    [in/32, N, 32] skip-connection buffer read as 32-wide K blocks (torch.cat never happens)."""
+    [S, N, C] skip-connection buffer read as the concatenation of its S slots (torch.cat never happens; C a
+    multiple of 32)."""
     a = _f32c(a, "x")
     if slot_major:
-        if a.dim() != 3 or a.shape[2] != 32:
-            raise ValueError(f"slot-major input must be [K/32, N, 32], got {tuple(a.shape)}")
-        n, k, lda, kb = int(a.shape[1]), 32 * int(a.shape[0]), 32, int(a.shape[1]) * 32
+        if a.dim() != 3 or a.shape[2] % 32 != 0:
+            raise ValueError(f"slot-major input must be [S, N, C] with C a multiple of 32, got {tuple(a.shape)}")
+        n, cw = int(a.shape[1]), int(a.shape[2])
+        k = cw * int(a.shape[0])
+        m = int(weight.shape[0])
+        if int(weight.shape[1]) != k:
+            raise ValueError(f"Linear expects in_dim {int(weight.shape[1])}, got {k}")      # layers/util.py:16
+        out = torch.empty(n, m, dtype=torch.float32, device=a.device)
+        npart = C.c_int32(0)
+        check(lib.tgnn_dense_act_slots_fwd(ptr(a), cw, n * cw, ptr(in_stat), ptr(_f32c(weight, "weight")),
+                                           ptr(_f32c(bias, "bias")), n, k, m, act, ptr(out), m, ptr(partials),
+                                           C.byref(npart), _stream(a)))
+        return out, npart.value
     else:
         if a.dim() != 2:
             raise ValueError(f"expected a [N, F] matrix, got {tuple(a.shape)}")
