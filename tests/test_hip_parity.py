@@ -790,3 +790,22 @@ def test_other_network_widths_run_on_the_general_kernels(dev, width):
         w2 = orc.gin_conv(h.double().cpu(), col.cpu(), sd64, "brch_2_coll_conv_layers.1")
     assert orc.rel_max_err(l1.nnConv(h, adj, adj_attr).cpu(), w1) < TOL
     assert orc.rel_max_err(l2.ginConv(h, col).cpu(), w2) < TOL
+
+
+@pytest.mark.parametrize("case", ["no_adj", "no_col", "both_empty"])
+def test_forward_with_empty_edge_sets(dev, case):
+    """TilinGNN.forward called directly with an empty adjacency and / or collision set (ML_Solver.predict short-cuts
+    these, ml_solver.py:31-32, other callers may not): NNConv reduces to the root term, GIN to its self term."""
+    g = load_labyrinth_graph()
+    net, sd = make_net(dev, depth=3)
+    sd64 = orc.cast_sd(sd, torch.float64)
+    x, adj, adj_attr, col, _ = graph_tensors(g, torch.float32, dev)
+    if case in ("no_adj", "both_empty"):
+        adj, adj_attr = adj[:, :0], adj_attr[:0]
+    if case in ("no_col", "both_empty"):
+        col = col[:, :0]
+    probs, _ = net(x=x, adj_e_index=adj, adj_e_features=adj_attr, col_e_idx=col)
+    with torch.no_grad():
+        want, _ = orc.tilingnn_forward(sd64, x.double().cpu(), adj.cpu(), adj_attr.double().cpu(), col.cpu(),
+                                       update_running=False)
+    assert float((probs.cpu().double() - want).abs().max()) < 1e-3
