@@ -46,25 +46,28 @@ __global__ __launch_bounds__(kLossThreads) void loss_partial_kernel(
     if (threadIdx.x < 3) partial[((int64_t)m * gridDim.x + blockIdx.x) * 3 + threadIdx.x] = red[threadIdx.x][0];
 }
 
-// one block per map: fixed-order sum of the partial rows, then the product of the three factors
+// one wavefront per map: the partial rows are summed over a fixed tree (lane l takes rows l, l + 64, ..; then a
+// butterfly), then the product of the three factors.  (A first version let three threads walk the <= 512 rows one
+// dependent load after the other: 50 us.)
 __global__ __launch_bounds__(64) void loss_final_kernel(const double *__restrict__ partial, int n_blocks, int64_t n,
                                                         int64_t ec, int64_t ea, float wc, float wl, float wa,
                                                         double *__restrict__ losses, double *__restrict__ terms) {
-    const int m = blockIdx.x;
-    if (threadIdx.x >= 3) return;
-    double s = 0.0;
-    for (int b = 0; b < n_blocks; ++b) s += partial[((int64_t)m * n_blocks + b) * 3 + threadIdx.x];
-    __shared__ double t[3];
-    double v;
-    if (threadIdx.x == 0) v = log(fmax(s / (double)n, (double)kLossEps));
-    else if (threadIdx.x == 1) v = ec > 0 ? s / (double)ec : 0.0;
-    else v = ea > 0 ? s / (double)ea : 0.0;
-    t[threadIdx.x] = v;
-    if (terms) terms[m * 3 + threadIdx.x] = v;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (threadIdx.x == 0) losses[m] = (1.0 - (double)wa * t[0]) * (1.0 - (double)wc * t[1]) * (1.0 - (double)wl * t[2]);
+    const int m = blockIdx.x, lane = threadIdx.x;
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int b = lane; b < n_blocks; b += 64)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s[k] += partial[((int64_t)m * n_blocks + b) * 3 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s[k] += __shfl_xor(s[k], d, 64);
+    if (lane == 0) {
+        const double t0 = log(fmax(s[0] / (double)n, (double)kLossEps));
+        const double t1 = ec > 0 ? s[1] / (double)ec : 0.0;
+        const double t2 = ea > 0 ? s[2] / (double)ea : 0.0;
+        if (terms) { terms[m * 3] = t0; terms[m * 3 + 1] = t1; terms[m * 3 + 2] = t2; }
+        losses[m] = (1.0 - (double)wa * t0) * (1.0 - (double)wc * t1) * (1.0 - (double)wl * t2);
+    }
 }
 
 static int loss_blocks(int64_t n, int64_t ec, int64_t ea) {
