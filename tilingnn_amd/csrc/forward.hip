@@ -432,23 +432,36 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
                                     w.mid + (size_t)(i + 1) * nr * c, nullptr, s));
             continue;
         }
+        // Few partial rows (small layouts): merge derives the first BatchNorm's record from them itself -- one launch
+        // less on the critical chain of a launch-latency-bound forward.  (With the 256 rows of a 100k-node layout the
+        // repeated reduction costs every merge block more than the separate 1-block finalize: measured.)
+        static const int fuse_rows = getenv("TGNN_MERGE_BN1_ROWS") ? atoi(getenv("TGNN_MERGE_BN1_ROWS")) : 32;
+        const bool fused_bn1 = c == 32 && !use_running_stats && !sh && np1 <= fuse_rows;
         if (s2) {
-            BnJobs j1{};
-            j1.job[0] = bn_job(w.part1, np1, P.bn(b + 8), w.stat1);
-            launch_bn_finalize(j1, 1, fin_mode, c, n, eps, momentum, s);
+            if (!fused_bn1) {
+                BnJobs j1{};
+                j1.job[0] = bn_job(w.part1, np1, P.bn(b + 8), w.stat1);
+                launch_bn_finalize(j1, 1, fin_mode, c, n, eps, momentum, s);
+            }
             TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[1 + i], 0));
         } else {
             TGNN_TRY(gin_layer(i, s));
             BnJobs jobs{};
-            jobs.job[0] = bn_job(w.part1, np1, P.bn(b + 8), w.stat1);
-            jobs.job[1] = bn_job(w.part2, np2, P.bn(b + 20), w.stat2[i & 1]);
-            TGNN_TRY(finalize_jobs(jobs, 2, c));
+            int nj = 0;
+            if (!fused_bn1) jobs.job[nj++] = bn_job(w.part1, np1, P.bn(b + 8), w.stat1);
+            jobs.job[nj++] = bn_job(w.part2, np2, P.bn(b + 20), w.stat2[i & 1]);
+            TGNN_TRY(finalize_jobs(jobs, nj, c));
         }
         // merge (:64-71): middle[i+1] = BN1(a1) * BN2(a2) (+ middle[i-2])
         const float *resid = i >= 2 ? w.mid + (size_t)(i - 2) * nr * c : nullptr;
         prof.begin(5);
-        TGNN_TRY(tgnn_merge_fwd(w.a1, w.stat1, w.a2[i & 1], w.stat2[i & 1], resid, n, c,
-                                w.mid + (size_t)(i + 1) * nr * c, nullptr, s));
+        if (fused_bn1) {
+            launch_merge_bn1(w.a1, bn_job(w.part1, np1, P.bn(b + 8), w.stat1), n, eps, momentum, w.a2[i & 1],
+                             w.stat2[i & 1], resid, n, w.mid + (size_t)(i + 1) * nr * c, s);
+        } else {
+            TGNN_TRY(tgnn_merge_fwd(w.a1, w.stat1, w.a2[i & 1], w.stat2[i & 1], resid, n, c,
+                                    w.mid + (size_t)(i + 1) * nr * c, nullptr, s));
+        }
         prof.end();
         if (s2) TGNN_CHECK_HIP(hipEventRecord(ev[1 + kMaxDepth + i], s));
         if (i + 1 < D) TGNN_TRY(exchange(i + 1, w.a2[i & 1], w.a2[i & 1]));

@@ -126,6 +126,10 @@ struct BnJobs {
 // one block per job (1 or 2 BatchNorms of the same width finalised by one launch); bn_merge.hip
 void launch_bn_finalize(const BnJobs &jobs, int n_jobs, int mode, int f, int64_t n_total, float eps, float momentum,
                         hipStream_t s);
+// merge (width 32) that derives the first BatchNorm's record from its partial rows itself (mode-0 semantics of
+// bn_finalize incl. running-stat update, bit-identical statistics); bn_merge.hip
+void launch_merge_bn1(const float *a1, const BnJob &j1, int64_t n_total, float eps, float momentum, const float *a2,
+                      const float *stat2, const float *resid, int64_t n_nodes, float *out, hipStream_t s);
 // sharded forward, one all-to-all per layer (width 32): pack halo rows of both branches + local BN sums, unpack, add
 // the shards' sums in rank order; bn_merge.hip
 void launch_shard_pack(const float *a1, const float *a2, const int *idx, int64_t n_rows, const double *sums, float *out,
