@@ -259,6 +259,27 @@ def unsupervised_losses(probs: Tensor, node_feature: Tensor, collide_edge_index:
     return torch.stack(out)
 
 
+def training_step_grads(sd: SD, x: Tensor, adj_e_index: Tensor, adj_e_features: Tensor, col_e_idx: Tensor):
+    """One training step of Trainer.train (trainer.py:68-84) without the optimizer: forward in train mode, the
+    unsupervised loss (min over the probability maps, losses.py:108-109), backward -- by autograd over the
+    restatement above.  Returns (probs, loss, d loss / d probs, {key: gradient}) for every floating-point entry of
+    `sd` that is a parameter (BatchNorm running statistics and GIN's eps buffer are not).  Pinned against
+    tests/golden/ref_grads.npz."""
+    leaf = {}
+    for k, v in sd.items():
+        is_param = v.is_floating_point() and not k.endswith(("running_mean", "running_var", ".eps"))
+        leaf[k] = v.detach().clone().requires_grad_(True) if is_param else v.detach().clone()
+    probs, _ = tilingnn_forward(leaf, x, adj_e_index, adj_e_features, col_e_idx)
+    probs.retain_grad()
+    loss = unsupervised_losses(probs, x, col_e_idx, adj_e_index, adj_e_features).min()
+    loss.backward()
+    grads = {}
+    for k, v in leaf.items():
+        if v.requires_grad and ".nnConv.nn." not in k:            # aliases of '<prefix>.mlp.*' (same tensors in the reference)
+            grads[k] = v.grad.detach() if v.grad is not None else torch.zeros_like(v)
+    return probs.detach(), loss.detach(), probs.grad.detach(), grads
+
+
 # --------------------------------------------------------------------------------------
 # helpers for tests / bench
 # --------------------------------------------------------------------------------------
