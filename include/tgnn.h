@@ -342,6 +342,71 @@ int tgnn_unsupervised_loss(const float *probs, int64_t ld_probs, int32_t n_maps,
                            int64_t ld_len, float collision_weight, float align_length_weight, float avg_area_weight,
                            double *losses, double *terms, void *ws, size_t ws_bytes, tgnn_stream_t stream);
 
+/* ---- the training step: adjoints of the forward kernels ---------------------------------
+ * Trainer.train (solver/ml_solver/trainer.py:68-84) = forward in train mode, the unsupervised loss, loss.backward(),
+ * optimizer.step().  torch.autograd derives the backward there; these are the same adjoints per forward kernel
+ * (csrc/backward.hip; scheduled by tilingnn_amd/train.py).  Column sums run in fp64 over fixed trees. */
+int tgnn_transpose(const float *w, int32_t rows, int32_t cols, float *out, tgnn_stream_t stream);
+/* out[b][a][c] = in[a][b][c] (weight tables re-laid for the input-gradient product of NNConv) */
+int tgnn_swap_leading(const float *in, int32_t da, int32_t db, int32_t dc, float *out, tgnn_stream_t stream);
+/* z = (1 + eps) BN_in(a) + sum over the row's CSR slots of BN_in(a)[src] (width 32): the input of GINConv's MLP; on the
+ * transposed collision graph, the adjoint of that aggregation. */
+int tgnn_gin_aggregate(const float *a, int64_t lda, const float *in_stat, const int32_t *rowptr, const int32_t *col_src,
+                       const float *eps, int64_t n_nodes, int32_t c, float *z, tgnn_stream_t stream);
+/* out = d * t * (1 - t): derivative of torch.nn.Sigmoid given its output t (layers/util.py:34) */
+int tgnn_sigmoid_bwd(const float *d, int64_t ld_d, const float *t, int64_t ld_t, int64_t n_rows, int32_t c, float *out,
+                     int64_t ld_o, tgnn_stream_t stream);
+int tgnn_add_into(const float *src, int64_t ld_s, int64_t n_rows, int32_t c, float *dst, int64_t ld_d,
+                  tgnn_stream_t stream);
+/* scratch for tgnn_colsum / tgnn_bn_bwd_reduce / tgnn_merge_bwd_reduce on matrices of `width` columns */
+size_t tgnn_reduce_workspace_bytes(int32_t width);
+/* out[c] = sum_r x[r][c]: the bias gradient of a Linear (layers/util.py:32) */
+int tgnn_colsum(const float *x, int64_t ld, int64_t n_rows, int32_t c, float *out, void *ws, size_t ws_bytes,
+                tgnn_stream_t stream);
+/* Train-mode BatchNorm1d backward fused with the derivative of the activation in front of it
+ * (Linear_trans: Linear -> activation -> BatchNorm, layers/util.py:31-37; GraphConv / CollConv: conv -> LeakyReLU ->
+ * BatchNorm, edge_conv.py:24-30).  a = the activation's output (the BatchNorm's input), stat = the forward's record.
+ *   reduce: coef [2][F] (scratch for apply), dgamma, dbeta (may be NULL)
+ *   apply : dz = act'(a) gamma invstd (dy - mean(dy) - xhat mean(dy xhat));  scaled (may be NULL) = dz * row_scale[r] */
+int tgnn_bn_bwd_reduce(const float *dy, int64_t ld_dy, const float *a, int64_t ld_a, const float *stat, int64_t n_rows,
+                       int32_t f, float eps, float *coef, float *dgamma, float *dbeta, void *ws, size_t ws_bytes,
+                       tgnn_stream_t stream);
+int tgnn_bn_bwd_apply(const float *dy, int64_t ld_dy, const float *a, int64_t ld_a, const float *stat, const float *coef,
+                      int64_t n_rows, int32_t f, int32_t act, float *dz, int64_t ld_dz, const float *row_scale,
+                      float *scaled, int64_t ld_scaled, tgnn_stream_t stream);
+/* Backward of the branch merge h = BN1(a1) * BN2(a2) (+ resid) (TilinGNN.py:64-71) and the reductions of both
+ * BatchNorms behind it (width 32):  dy1 = dh * BN2(a2);  dy2 = dh * BN1(a1) (+ carry: the gradient arriving at
+ * BN2(a2) from the next CollConv, TilinGNN.py:63);  resid_grad (may be NULL) += dh. */
+int tgnn_merge_bwd_reduce(const float *dh, int64_t ld_dh, const float *a1, const float *stat1, const float *a2,
+                          const float *stat2, const float *carry, int64_t n_rows, int32_t c, float eps1, float eps2,
+                          float *dy1, float *dy2, float *resid_grad, int64_t ld_resid, float *coef1, float *dgamma1,
+                          float *dbeta1, float *coef2, float *dgamma2, float *dbeta2, void *ws, size_t ws_bytes,
+                          tgnn_stream_t stream);
+/* Weight gradient of a Linear: out [cout, cin] = dz^T . x (fp32 matrix cores).  x element (r, k) lives at
+ * x[(k / 32) * x_kblock_stride + r * ld_x + k % 32] when x_kblock_stride != 0 (the slot-major skip buffer), else at
+ * x[r * ld_x + k]. */
+size_t tgnn_wgrad_workspace_bytes(int64_t n_rows, int32_t cout, int32_t cin);
+int tgnn_wgrad(const float *dz, int64_t ld_dz, const float *x, int64_t ld_x, int64_t x_kblock_stride, int64_t n_rows,
+               int32_t cout, int32_t cin, float *out, void *ws, size_t ws_bytes, tgnn_stream_t stream);
+/* NNConv backward building block (edge_conv.py:25; PyG NNConv: message = x_j . W_e, mean, + x . root):
+ * out [n_nodes][(n_types + 1) * 32]: slot t < n_types = sum over the row's CSR slots of type t of rows[src];
+ * slot n_types = own[j] * root_scale[j] (NULL: 1).  With it  d W_t = slot_t^T . g  and  d x = slots . [W_t^T; root^T]
+ * are dense products (g = dz / deg). */
+int tgnn_nnconv_type_sum(const float *rows, int64_t ld_rows, const float *own, int64_t ld_own, const float *root_scale,
+                         const int32_t *rowptr, const int32_t *src, const int32_t *type, int64_t n_nodes, int32_t n_types,
+                         int32_t c, float *out, tgnn_stream_t stream);
+/* deg[j] = max(in-degree, 1) (scatter_mean's clamp) and 1 / deg[j] from a CSR row pointer */
+int tgnn_csr_degree(const int32_t *rowptr, int64_t n_nodes, float *deg, float *inv_deg, tgnn_stream_t stream);
+/* d loss / d probs of tgnn_unsupervised_loss for ONE probability map (the arg-min map: the reference back-propagates
+ * through torch.min, losses.py:108).  probs / dprobs point at that map's column; terms = the three doubles the forward
+ * wrote for it; grad_out (device float, NULL = 1) = d objective / d loss.  ws: n_nodes doubles. */
+int tgnn_unsupervised_loss_bwd(const float *probs, int64_t ld_probs, const float *area_ratio, int64_t ld_area,
+                               int64_t n_nodes, const int64_t *col_edge_index, int64_t n_col_edges,
+                               const int64_t *adj_edge_index, int64_t n_adj_edges, const float *adj_edge_len, int64_t ld_len,
+                               float collision_weight, float align_length_weight, float avg_area_weight,
+                               const double *terms, const float *grad_out, float *dprobs, int64_t ld_dprobs, void *ws,
+                               size_t ws_bytes, tgnn_stream_t stream);
+
 int tgnn_rows_gather(const float *src, int64_t ld_src, const int32_t *idx, int64_t n_idx, int32_t c,
                      float *out, int64_t ld_out, tgnn_stream_t stream);
 int tgnn_rows_scatter(const float *in, const int32_t *idx, int64_t n_idx, int32_t c, float *dst,

@@ -12,6 +12,9 @@ Stored (ref_grads.npz)
             probs, loss, d loss / d probs, and the gradient of EVERY parameter (rounded once to float32).
   laby.*    the full labyrinth graph, depth 20: probs, loss, d loss / d probs; for every parameter the triple
             (sum, L2 norm, dot with a seeded N(0,1) vector) of its gradient, and six gradients in full.
+  <case>.err32.* / err32stat.* / loss32
+            the reference's OWN float32 step against its float64 one, per parameter: the yardstick for a float32
+            implementation (gradients through 20 train-mode BatchNorms amplify rounding by orders of magnitude).
   tiny.*    the 6-node graph (self loops, zero-in-degree node), depth 3: the triples, and every gradient in full except
             the two largest tensors.
 """
@@ -37,8 +40,8 @@ def projection(name, shape):
     return np.random.default_rng(seed).standard_normal(shape)
 
 
-def step(net, Losses, g):
-    x, adj, adj_attr, col, col_attr = gg.to_t(g, torch.float64)
+def step(net, Losses, g, dtype=torch.float64):
+    x, adj, adj_attr, col, col_attr = gg.to_t(g, dtype)
     net.zero_grad()
     probs, _ = net(x=x, adj_e_index=adj, adj_e_features=adj_attr, col_e_idx=col, col_e_features=None)
     probs.retain_grad()
@@ -46,6 +49,23 @@ def step(net, Losses, g):
     loss.backward()
     grads = {k: p.grad.detach().numpy().copy() for k, p in net.named_parameters()}
     return probs.detach().numpy().copy(), float(loss.item()), probs.grad.detach().numpy().copy(), grads
+
+
+def stats(k, v):
+    v = v.astype(np.float64)
+    return np.array([v.sum(), np.sqrt((v ** 2).sum()), (v * projection(k, v.shape)).sum()])
+
+
+def fp32_spread(out, case, TilinGNN, Losses, g, fe, fx, seed, depth, grads64):
+    """The reference's OWN float32 training step against its float64 one: what single precision costs on this problem.
+    err32.<name> = max |g32 - g64| / max |g64|;  err32stat.<name> = |stats(g32) - stats(g64)|."""
+    net32 = gg.build_reference_net(TilinGNN, fe, fx, torch.float32, seed=seed, depth=depth, width=32)
+    _, loss32, dprobs32, grads32 = step(net32, Losses, g, torch.float32)
+    out[f"{case}.loss32"] = np.float64(loss32)
+    for k, v64 in grads64.items():
+        v32 = grads32[k].astype(np.float64)
+        out[f"{case}.err32.{k}"] = np.float64(np.abs(v32 - v64).max() / max(np.abs(v64).max(), 1e-300))
+        out[f"{case}.err32stat.{k}"] = np.abs(stats(k, v32) - stats(k, v64))
 
 
 def main():
@@ -64,6 +84,7 @@ def main():
     out["small.probs"], out["small.loss"], out["small.dprobs"] = probs, np.float64(loss), dprobs
     for k, v in grads.items():
         out[f"small.grad.{k}"] = v.astype(np.float32)
+    fp32_spread(out, "small", TilinGNN, Losses, gs, fe, fx, 5, 3, grads)
     print("small: loss", loss, "params", len(grads), "max |grad|", max(np.abs(v).max() for v in grads.values()))
 
     net = gg.build_reference_net(TilinGNN, fe, fx, torch.float64, seed=0, depth=20, width=32)
@@ -73,7 +94,10 @@ def main():
         out[f"laby.stat.{k}"] = np.array([v.sum(), np.sqrt((v ** 2).sum()), (v * projection(k, v.shape)).sum()])
     for k in FULL_KEYS:
         out[f"laby.grad.{k}"] = grads[k]
+    fp32_spread(out, "laby", TilinGNN, Losses, g, fe, fx, 0, 20, grads)
     print("laby: loss", loss, "params", len(grads), "max |grad|", max(np.abs(v).max() for v in grads.values()))
+    e = np.array([out[f"laby.err32.{k}"] for k in grads])
+    print("laby: reference fp32 vs fp64 gradient error: median %.2e  max %.2e" % (np.median(e), e.max()))
 
     tiny = dict(np.load(os.path.join(HERE, "tiny_graph.npz")))
     TilinGNN2 = gg.import_reference(2)
@@ -87,6 +111,7 @@ def main():
         out[f"tiny.stat.{k}"] = np.array([v.sum(), np.sqrt((v ** 2).sum()), (v * projection(k, v.shape)).sum()])
         if "mlp.mlp.2" not in k and "final_mlp.0.mlp.0.linear.weight" not in k:      # the two big ones: stats only
             out[f"tiny.grad.{k}"] = v.astype(np.float32)
+    fp32_spread(out, "tiny", TilinGNN2, Losses, tg, tiny["adj_attr"].shape[1], 3, 3, 3, grads)
     print("tiny: loss", loss)
     path = os.path.join(HERE, "ref_grads.npz")
     np.savez_compressed(path, **out)

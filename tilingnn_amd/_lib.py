@@ -93,6 +93,23 @@ def _load() -> C.CDLL:
         "tgnn_unsupervised_loss": (C.c_int, [p, i64, i32, p, i64, i64, p, i64, p, i64, p, i64, f32, f32, f32, p, p, p, sz, p]),
         "tgnn_forward_profiled": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), p, p, C.POINTER(Graph), i32,
                                             i32, p, p, sz, p, C.POINTER(C.c_float), pi32]),
+        "tgnn_transpose": (C.c_int, [p, i32, i32, p, p]),
+        "tgnn_swap_leading": (C.c_int, [p, i32, i32, i32, p, p]),
+        "tgnn_gin_aggregate": (C.c_int, [p, i64, p, p, p, p, i64, i32, p, p]),
+        "tgnn_sigmoid_bwd": (C.c_int, [p, i64, p, i64, i64, i32, p, i64, p]),
+        "tgnn_add_into": (C.c_int, [p, i64, i64, i32, p, i64, p]),
+        "tgnn_reduce_workspace_bytes": (sz, [i32]),
+        "tgnn_colsum": (C.c_int, [p, i64, i64, i32, p, p, sz, p]),
+        "tgnn_bn_bwd_reduce": (C.c_int, [p, i64, p, i64, p, i64, i32, f32, p, p, p, p, sz, p]),
+        "tgnn_bn_bwd_apply": (C.c_int, [p, i64, p, i64, p, p, i64, i32, i32, p, i64, p, p, i64, p]),
+        "tgnn_merge_bwd_reduce": (C.c_int, [p, i64, p, p, p, p, p, i64, i32, f32, f32, p, p, p, i64, p, p, p, p, p, p,
+                                            p, sz, p]),
+        "tgnn_wgrad_workspace_bytes": (sz, [i64, i32, i32]),
+        "tgnn_wgrad": (C.c_int, [p, i64, p, i64, i64, i64, i32, i32, p, p, sz, p]),
+        "tgnn_nnconv_type_sum": (C.c_int, [p, i64, p, i64, p, p, p, p, i64, i32, i32, p, p]),
+        "tgnn_csr_degree": (C.c_int, [p, i64, p, p, p]),
+        "tgnn_unsupervised_loss_bwd": (C.c_int, [p, i64, p, i64, i64, p, i64, p, i64, p, i64, f32, f32, f32, p, p, p, i64,
+                                                 p, sz, p]),
         "tgnn_rows_gather": (C.c_int, [p, i64, p, i64, i32, p, i64, p]),
         "tgnn_rows_scatter": (C.c_int, [p, p, i64, i32, p, i64, p]),
     }
@@ -111,7 +128,10 @@ EXPORTED_SYMBOLS = (
     "tgnn_merge_fwd", "tgnn_param_count", "tgnn_param_name", "tgnn_forward_workspace_bytes", "tgnn_forward",
     "tgnn_forward_profiled", "tgnn_forward_sharded_workspace_bytes", "tgnn_forward_sharded",
     "tgnn_rows_gather", "tgnn_rows_scatter", "tgnn_unsupervised_loss_workspace_bytes", "tgnn_unsupervised_loss",
-    "tgnn_sublayout_workspace_bytes", "tgnn_sublayout_compact")
+    "tgnn_sublayout_workspace_bytes", "tgnn_sublayout_compact",
+    "tgnn_transpose", "tgnn_swap_leading", "tgnn_gin_aggregate", "tgnn_sigmoid_bwd", "tgnn_add_into", "tgnn_reduce_workspace_bytes", "tgnn_colsum",
+    "tgnn_bn_bwd_reduce", "tgnn_bn_bwd_apply", "tgnn_merge_bwd_reduce", "tgnn_wgrad_workspace_bytes", "tgnn_wgrad",
+    "tgnn_nnconv_type_sum", "tgnn_csr_degree", "tgnn_unsupervised_loss_bwd")
 
 
 def check(rc: int) -> None:

@@ -361,3 +361,25 @@ extern "C" int tgnn_gin_fwd(const float *a, int64_t lda, const float *in_stat, c
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
 }
+
+/* z = (1 + eps) * BN_in(a) + sum over the row's CSR slots of BN_in(a)[src]  (the input of GINConv's MLP, PyG
+ * gin_conv.py; width 32).  Stand-alone because the backward needs it twice per layer: to re-derive the MLP's input, and --
+ * on the TRANSPOSED collision graph -- as the adjoint of the aggregation itself. */
+extern "C" int tgnn_gin_aggregate(const float *a, int64_t lda, const float *in_stat, const int32_t *rowptr,
+                                  const int32_t *col_src, const float *eps, int64_t n_nodes, int32_t c, float *z,
+                                  tgnn_stream_t stream) {
+    TGNN_CHECK_ARG(n_nodes >= 0, "shape");
+    if (c != 32) {
+        set_error("tgnn_gin_aggregate: width 32 only");
+        return TGNN_ERR_UNSUPPORTED;
+    }
+    if (n_nodes == 0) return TGNN_OK;
+    TGNN_CHECK_ARG(a && rowptr && eps && z, "null pointer");
+    TGNN_CHECK_ARG(lda >= c && lda % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)z % 16) == 0, "alignment");
+    const int64_t rows_per_xcd = (n_nodes + 7) / 8;
+    const unsigned agg_blocks = (unsigned)(8 * ((rows_per_xcd + 31) / 32));
+    gin32_aggregate_kernel<<<agg_blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(a, lda, in_stat, rowptr, col_src, eps,
+                                                                                    n_nodes, z);
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}

@@ -65,6 +65,10 @@ class TilinGNN(Tracked, nn.Module):
                 activation=torch.nn.LeakyReLU()),
             Linear_trans(network_width, output_dim, activation=torch.nn.Sigmoid(), batch_norm=False))
         self.cache_graph = True          # reuse the prepared CSR / edge types while the edge tensors are unchanged
+        # The reference runs inference with autograd recording (ml_solver.py:39 has no no_grad), so "grad enabled" cannot
+        # mean "training" here.  The differentiable forward (tilingnn_amd/train.py: keeps activations, backward through
+        # the adjoint kernels) is therefore opt-in: Trainer switches it on around its steps.
+        self.autograd = False
 
     # ---- host-side table of device pointers -------------------------------------------------
     def _dims(self):
@@ -119,6 +123,9 @@ class TilinGNN(Tracked, nn.Module):
                              f"got {tuple(adj_e_features.shape)}")
         n = int(x.shape[0])
         bn_train = self.training
+        if self.autograd and bn_train and torch.is_grad_enabled():
+            from ... import train
+            return train.forward_with_grad(self, x, adj_e_index, adj_e_features, col_e_idx), adj_e_features
         if bn_train and n < 2:
             raise ValueError("Expected more than 1 value per channel when training")
         xf = ops._f32c(x, "x")

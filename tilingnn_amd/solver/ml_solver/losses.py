@@ -1,8 +1,9 @@
 """`Losses.calculate_unsupervised_loss` -- the loss ML_Solver.predict evaluates to pick the best probability map
 (/root/reference/solver/ml_solver/losses.py:48-116, called through get_best_prob_map, ml_solver.py:46,133-136),
 on the GPU through `tgnn_unsupervised_loss` (csrc/loss.hip).  Same arguments and the same three return values as the
-reference: (min loss as a 0-dim tensor, arg-min as numpy, all losses as numpy).  Forward only -- the training use of
-this loss (trainer.py) needs gradients and stays with the reference."""
+reference: (min loss as a 0-dim tensor, arg-min as numpy, all losses as numpy).  When `probs` requires grad (the
+training step, trainer.py:76-80) the returned loss is differentiable: its backward is `tgnn_unsupervised_loss_bwd`
+(csrc/backward.hip) on the arg-min map -- the path torch.min's gradient takes in the reference (losses.py:108)."""
 import ctypes as C
 import math
 
@@ -58,6 +59,12 @@ class Losses:
 
     @staticmethod
     def calculate_unsupervised_loss(probs, node_feature, collide_edge_index, adj_edges_index, adj_edge_features):
+        if torch.is_grad_enabled() and probs.requires_grad:
+            return _differentiable_loss(probs, node_feature, collide_edge_index, adj_edges_index, adj_edge_features)
+        return Losses._calculate(probs, node_feature, collide_edge_index, adj_edges_index, adj_edge_features)[:3]
+
+    @staticmethod
+    def _calculate(probs, node_feature, collide_edge_index, adj_edges_index, adj_edge_features):
         losses, terms = Losses.unsupervised_losses(probs, node_feature, collide_edge_index, adj_edges_index,
                                                    adj_edge_features)
         host_terms = terms.cpu().numpy()
@@ -66,4 +73,46 @@ class Losses:
         host = losses.cpu().numpy()
         assert (host >= 1.0).all()
         min_index = np.argmin(host)
-        return losses[int(min_index)].to(probs.dtype), np.asarray(min_index), host.astype(np.float32)
+        return losses[int(min_index)].to(probs.dtype), np.asarray(min_index), host.astype(np.float32), terms
+
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, probs, node_feature, collide_edge_index, adj_edges_index, adj_edge_features, box):
+        loss, min_index, host, terms = Losses._calculate(probs.detach(), node_feature, collide_edge_index, adj_edges_index,
+                                                         adj_edge_features)
+        box.extend([min_index, host])
+        ctx.k, ctx.terms, ctx.weights = int(min_index), terms, loss_weights()
+        ctx.save_for_backward(probs, node_feature, collide_edge_index, adj_edges_index, adj_edge_features)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        probs, x, col, adj, attr = ctx.saved_tensors
+        p = ops._f32c(probs.detach(), "probs")
+        xf = ops._f32c(x, "node_feature")
+        n, m, fx = int(p.shape[0]), int(p.shape[1]), int(xf.shape[1])
+        e_col = int(col.shape[1]) if col.numel() > 0 else 0
+        e_adj = int(adj.shape[1]) if adj.numel() > 0 else 0
+        colc = ops._check_edge_index(col, "collide_edge_index") if e_col else None
+        adjc = ops._check_edge_index(adj, "adj_edges_index") if e_adj else None
+        attrc = ops._f32c(attr, "adj_edge_features") if e_adj else None
+        dev = p.device
+        dprobs = torch.zeros(n, m, dtype=torch.float32, device=dev)
+        ws = torch.empty(n, dtype=torch.float64, device=dev)
+        gout = grad_loss.detach().to(torch.float32).reshape(1).contiguous()
+        wc, wl, wa = ctx.weights
+        k = ctx.k
+        check(lib.tgnn_unsupervised_loss_bwd(
+            C.c_void_p(p.data_ptr() + 4 * k), m, C.c_void_p(xf.data_ptr() + 4 * (fx - 1)), fx, n,
+            ptr(colc) if e_col else None, e_col, ptr(adjc) if e_adj else None, e_adj,
+            C.c_void_p(attrc.data_ptr() + 4) if e_adj else None, int(attrc.shape[1]) if e_adj else 1, wc, wl, wa,
+            C.c_void_p(ctx.terms.data_ptr() + 24 * k), ptr(gout), C.c_void_p(dprobs.data_ptr() + 4 * k), m, ptr(ws),
+            n * 8, _lib.current_stream(dev)))
+        return dprobs.to(probs.dtype), None, None, None, None, None
+
+
+def _differentiable_loss(probs, node_feature, collide_edge_index, adj_edges_index, adj_edge_features):
+    box = []
+    loss = _LossFn.apply(probs, node_feature, collide_edge_index, adj_edges_index, adj_edge_features, box)
+    return loss, box[0], box[1]
