@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nodes-per-gpu", type=int, default=NODES_PER_GPU)
+    ap.add_argument("--no-train-step", action="store_true", help="skip the training-step timing")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the sharded (RCCL) schedule even at world size 1 (exercises the multi-GPU code path)")
     args = ap.parse_args()
@@ -291,6 +292,40 @@ def main():
             go.compute_sub_layout(xh, ah, aah, ch, cah, np.flatnonzero(alive_h))
             sub_info["cpu_numpy_us"] = (time.perf_counter() - t3) * 1e6
 
+    # ---- one training step at the same shape: forward keeping activations, loss, backward through the
+    #      adjoint kernels, Adam (torch's, the caller's optimizer in the reference: network_train.py)
+    train_info = None
+    if not sharded and not args.no_train_step:
+        from tilingnn_amd.solver.ml_solver.losses import Losses
+        net.cache_graph = True              # the transposed CSR is built once per layout, like the forward structures
+        net.autograd = True
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+
+        def train_step():
+            probs, _ = net(x=x, adj_e_index=adj, adj_e_features=adj_attr, col_e_idx=col)
+            opt.zero_grad()
+            loss, _, _ = Losses.calculate_unsupervised_loss(probs, x, col, adj, adj_attr)
+            loss.backward()
+            opt.step()
+            return loss
+        for _ in range(2):
+            train_step()
+        torch.cuda.synchronize()
+        t4 = time.perf_counter()
+        for _ in range(5):
+            train_step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t4) / 5 * 1e3
+        t5 = time.perf_counter()
+        for _ in range(5):
+            probs, _ = net(x=x, adj_e_index=adj, adj_e_features=adj_attr, col_e_idx=col)
+        torch.cuda.synchronize()
+        fwd_ms = (time.perf_counter() - t5) / 5 * 1e3
+        train_info = {"ms_per_step": ms, "forward_keeping_activations_ms": fwd_ms, "nodes_per_s": n_total / (ms * 1e-3),
+                      "optimizer": "torch.optim.Adam", "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}
+        net.autograd = False
+        net.cache_graph = False
+
     if saved_stdout_fd is not None:
         sys.stdout.flush()
         os.dup2(saved_stdout_fd, 1)
@@ -314,6 +349,8 @@ def main():
             line["predict_loss"] = loss_info
         if sub_info is not None:
             line["greedy_sublayout"] = sub_info
+        if train_info is not None:
+            line["train_step"] = train_info
         if class_ms is not None:
             line["kernel_classes"] = class_ms
         if not args.no_cpu_baseline and world == 1:           # the CPU leg is a 1-GPU (rank 0, N = 1) measurement

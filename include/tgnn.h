@@ -382,12 +382,13 @@ int tgnn_merge_bwd_reduce(const float *dh, int64_t ld_dh, const float *a1, const
                           float *dy1, float *dy2, float *resid_grad, int64_t ld_resid, float *coef1, float *dgamma1,
                           float *dbeta1, float *coef2, float *dgamma2, float *dbeta2, void *ws, size_t ws_bytes,
                           tgnn_stream_t stream);
-/* Weight gradient of a Linear: out [cout, cin] = dz^T . x (fp32 matrix cores).  x element (r, k) lives at
+/* Weight gradient of a Linear: out [cout, cin] = dz^T . x (fp32 matrix cores); dbias [cout] (may be NULL) = the column
+ * sums of dz from the same pass.  x element (r, k) lives at
  * x[(k / 32) * x_kblock_stride + r * ld_x + k % 32] when x_kblock_stride != 0 (the slot-major skip buffer), else at
  * x[r * ld_x + k]. */
 size_t tgnn_wgrad_workspace_bytes(int64_t n_rows, int32_t cout, int32_t cin);
 int tgnn_wgrad(const float *dz, int64_t ld_dz, const float *x, int64_t ld_x, int64_t x_kblock_stride, int64_t n_rows,
-               int32_t cout, int32_t cin, float *out, void *ws, size_t ws_bytes, tgnn_stream_t stream);
+               int32_t cout, int32_t cin, float *out, float *dbias, void *ws, size_t ws_bytes, tgnn_stream_t stream);
 /* NNConv backward building block (edge_conv.py:25; PyG NNConv: message = x_j . W_e, mean, + x . root):
  * out [n_nodes][(n_types + 1) * 32]: slot t < n_types = sum over the row's CSR slots of type t of rows[src];
  * slot n_types = own[j] * root_scale[j] (NULL: 1).  With it  d W_t = slot_t^T . g  and  d x = slots . [W_t^T; root^T]

@@ -39,6 +39,8 @@ def test_wgrad(n, cout, cin):
     r = _rng(n + cout)
     dz, x = r(n, cout).to(DEV), r(n, cin).to(DEV)
     assert _rel(train.wgrad(dz, x), dz.double().t() @ x.double()) < 2e-6
+    w, b = train.wgrad(dz, x, with_bias=True)                             # the bias gradient rides on the same pass
+    assert _rel(w, dz.double().t() @ x.double()) < 2e-6 and _rel(b, dz.double().sum(0)) < 2e-6
 
 
 def test_wgrad_slot_major_is_the_concatenation():
@@ -294,7 +296,7 @@ def test_training_step_against_the_reference(case, fe, depth, seed, slack):
             # the float32 noise on this tensor's sums: its own sample, or the median over all tensors if that is larger
             bound = (slack * max(rel_spread[k], stat_floor) + 1e-4) * scale[k]
             assert np.all(np.abs(_stats(k, got) - want_stat) <= bound), (k, np.abs(_stats(k, got) - want_stat), bound)
-    assert np.median(hip_err) <= 2 * floor + 1e-6
+    assert np.median(hip_err) <= slack / 2 * floor + 1e-6, (np.median(hip_err), floor)
 
 
 def test_autograd_switch_and_optimizer_step():
@@ -324,3 +326,36 @@ def test_autograd_switch_and_optimizer_step():
     with torch.no_grad():
         probs, _ = net(x, adj, attr, col)                                   # eval mode never takes the training path
     assert not probs.requires_grad
+
+
+def test_trainer_loop_on_layout_files(tmp_path):
+    """Trainer.train over layout files on disk: losses fall, checkpoints are written and load back."""
+    import os
+    from tests.golden_util import GOLDEN
+    from tilingnn_amd.solver.ml_solver.ml_solver import ML_Solver
+    from tilingnn_amd.solver.ml_solver.trainer import Trainer
+    from tilingnn_amd.tiling.tile_graph import TileGraph
+    from tilingnn_amd.util import data_util as du
+    graph = TileGraph(2)
+    graph.load_graph_state(os.path.join(GOLDEN, "complete_graph_small.pkl"), sidecar=False)
+    rng = np.random.default_rng(0)
+    for split, count in (("train", 4), ("test", 2)):
+        os.makedirs(tmp_path / split, exist_ok=True)
+        for i in range(count):
+            tiles = sorted(int(v) for v in rng.choice(150, size=int(rng.integers(60, 140)), replace=False))
+            x, ci, cf, ai, af, re_index = du.create_brick_layout_from_super_set(graph, tiles)
+            du.write_brick_layout_data(f"layout_{i}.pkl", re_index, node_features=x, collide_edge_index=ci,
+                                       collide_edge_features=cf, align_edge_index=ai, align_edge_features=af,
+                                       prefix=str(tmp_path / split / "raw"))
+    net, _ = _net(15, 3, 5)
+    solver = ML_Solver(None, DEV, graph, net, num_prob_maps=1)
+    opt = torch.optim.Adam(net.parameters(), lr=2e-3)
+    trainer = Trainer(None, None, DEV, net, str(tmp_path))
+    history = trainer.train(solver, opt, batch_size=1, training_epoch=4, save_model_per_epoch=2, shuffle_seed=1,
+                            log=lambda *_: None)
+    assert len(history) == 4 and history[-1][0] < history[0][0] and all(np.isfinite(h).all() for h in history)
+    saved = sorted(os.listdir(tmp_path / "model"))
+    assert any(f.startswith("model_0_") for f in saved) and any(f.startswith("optimizer_0_") for f in saved)
+    assert not net.autograd                                              # switched off again after the steps
+    with pytest.raises(NotImplementedError):
+        trainer.train(solver, opt, batch_size=4)

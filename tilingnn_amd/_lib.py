@@ -105,7 +105,7 @@ def _load() -> C.CDLL:
         "tgnn_merge_bwd_reduce": (C.c_int, [p, i64, p, p, p, p, p, i64, i32, f32, f32, p, p, p, i64, p, p, p, p, p, p,
                                             p, sz, p]),
         "tgnn_wgrad_workspace_bytes": (sz, [i64, i32, i32]),
-        "tgnn_wgrad": (C.c_int, [p, i64, p, i64, i64, i64, i32, i32, p, p, sz, p]),
+        "tgnn_wgrad": (C.c_int, [p, i64, p, i64, i64, i64, i32, i32, p, p, p, sz, p]),
         "tgnn_nnconv_type_sum": (C.c_int, [p, i64, p, i64, p, p, p, p, i64, i32, i32, p, p]),
         "tgnn_csr_degree": (C.c_int, [p, i64, p, p, p]),
         "tgnn_unsupervised_loss_bwd": (C.c_int, [p, i64, p, i64, i64, p, i64, p, i64, p, i64, f32, f32, f32, p, p, p, i64,

@@ -54,6 +54,18 @@ class _Scratch:
         return buf
 
 
+_zero_bufs: Dict = {}
+
+
+def _zeros(n: int, device) -> Tensor:
+    """A shared all-zero bias (never written)."""
+    key = torch.device(device).index
+    buf = _zero_bufs.get(key)
+    if buf is None or buf.numel() < n:
+        buf = _zero_bufs[key] = torch.zeros(max(n, 1024), dtype=torch.float32, device=device)
+    return buf[:n]
+
+
 def colsum(x: Tensor) -> Tensor:
     n, c = int(x.shape[0]), int(x.shape[1])
     out = torch.empty(c, dtype=torch.float32, device=x.device)
@@ -63,8 +75,9 @@ def colsum(x: Tensor) -> Tensor:
     return out
 
 
-def wgrad(dz: Tensor, x: Tensor, slot_major: bool = False) -> Tensor:
-    """dz^T . x -> [cout, cin].  slot_major: x is the [S, N, C] skip buffer read as [N, S * C]."""
+def wgrad(dz: Tensor, x: Tensor, slot_major: bool = False, with_bias: bool = False):
+    """dz^T . x -> [cout, cin] (with_bias: also the column sums of dz, from the same pass).
+    slot_major: x is the [S, N, C] skip buffer read as [N, S * C]."""
     n, cout = int(dz.shape[0]), int(dz.shape[1])
     if slot_major:
         cin, ld_x, kb = int(x.shape[0]) * int(x.shape[2]), int(x.shape[2]), int(x.shape[1]) * int(x.shape[2])
@@ -73,10 +86,11 @@ def wgrad(dz: Tensor, x: Tensor, slot_major: bool = False) -> Tensor:
     else:
         cin, ld_x, kb = int(x.shape[1]), x.stride(0), 0
     out = torch.empty(cout, cin, dtype=torch.float32, device=dz.device)
+    dbias = torch.empty(cout, dtype=torch.float32, device=dz.device) if with_bias else None
     nb = lib.tgnn_wgrad_workspace_bytes(n, cout, cin)
     ws = _Scratch.get("wgrad", nb, dz.device)
-    check(lib.tgnn_wgrad(ptr(dz), dz.stride(0), ptr(x), ld_x, kb, n, cout, cin, ptr(out), ptr(ws), nb, _s(dz)))
-    return out
+    check(lib.tgnn_wgrad(ptr(dz), dz.stride(0), ptr(x), ld_x, kb, n, cout, cin, ptr(out), ptr(dbias), ptr(ws), nb, _s(dz)))
+    return (out, dbias) if with_bias else out
 
 
 def transpose(w: Tensor) -> Tensor:
@@ -88,8 +102,7 @@ def transpose(w: Tensor) -> Tensor:
 def dense_dx(dz: Tensor, weight: Tensor) -> Tensor:
     """dz [N, out] . weight [out, in] -> [N, in]: the forward dense kernel on the transposed weight."""
     wt = transpose(weight)
-    zero = torch.zeros(int(wt.shape[0]), dtype=torch.float32, device=dz.device)
-    return ops.dense_act(dz, wt, zero, ACT_NONE)[0]
+    return ops.dense_act(dz, wt, _zeros(int(wt.shape[0]), dz.device), ACT_NONE)[0]
 
 
 def sigmoid_bwd(d: Tensor, t: Tensor) -> Tensor:
@@ -260,8 +273,8 @@ def _mlp_backward(layers, acts, stats, first_input, first_slot_major, dy, grads,
             inp, slot = first_input, first_slot_major
         else:
             inp, slot = ops.bn_apply(acts[k - 1], stats[k - 1]), False
-        grads[f"{prefix}.mlp.{k}.linear.weight"] = wgrad(dz, inp, slot_major=slot)
-        grads[f"{prefix}.mlp.{k}.linear.bias"] = colsum(dz)
+        grads[f"{prefix}.mlp.{k}.linear.weight"], grads[f"{prefix}.mlp.{k}.linear.bias"] = \
+            wgrad(dz, inp, slot_major=slot, with_bias=True)
         if k > 0 or need_dx:
             dy = dense_dx(dz, layer.linear.weight)
     return dy
@@ -274,8 +287,7 @@ def _sigmoid_mlp_backward(weights, acts, x_in, d_out, grads, names, need_dx=True
     for k in (2, 1, 0):
         dpre = sigmoid_bwd(d, acts[k])
         inp = acts[k - 1] if k > 0 else x_in
-        grads[names[k] + ".linear.weight"] = wgrad(dpre, inp)
-        grads[names[k] + ".linear.bias"] = colsum(dpre)
+        grads[names[k] + ".linear.weight"], grads[names[k] + ".linear.bias"] = wgrad(dpre, inp, with_bias=True)
         if k > 0 or need_dx:
             d = dense_dx(dpre, weights[2 * k])
     return d
@@ -298,7 +310,7 @@ def nnconv_backward(conv, prefix: str, tg: TrainGraph, wtab: Tensor, h: Tensor, 
     s_bwd = type_sum(g_scaled, g_scaled, tg.deg, tg.adjT_rowptr, tg.adjT_src, tg.adjT_type, n, T)
     wd = torch.empty(c, (T + 1) * c, dtype=torch.float32, device=dev)                             # [in][t][out]
     check(lib.tgnn_swap_leading(ptr(wtab), T + 1, c, c, ptr(wd), _s(wd)))
-    dh = ops.dense_act(s_bwd, wd, torch.zeros(c, dtype=torch.float32, device=dev), ACT_NONE)[0]
+    dh = ops.dense_act(s_bwd, wd, _zeros(c, dev), ACT_NONE)[0]
     # the edge MLP behind the T weight matrices (edge_conv.py:17-18), on the T distinct attribute rows
     ew = conv._edge_mlp_params()
     names = [f"{prefix}.mlp.mlp.{k}" for k in range(3)]
@@ -341,7 +353,7 @@ def backward_train(net, sv, dprobs: Tensor) -> Dict[str, Tensor]:
     last = net.final_mlp[1]
     dl = sigmoid_bwd(dprobs, sv.probs)
     y = ops.bn_apply(sv.fin_a[-1], sv.fin_stat[-1])
-    grads["final_mlp.1.linear.weight"], grads["final_mlp.1.linear.bias"] = wgrad(dl, y), colsum(dl)
+    grads["final_mlp.1.linear.weight"], grads["final_mlp.1.linear.bias"] = wgrad(dl, y, with_bias=True)
     dy = dense_dx(dl, last.linear.weight)
     dcat = _mlp_backward(list(net.final_mlp[0].mlp), sv.fin_a, sv.fin_stat, sv.skip, True, dy, grads, "final_mlp.0", True)
     ld = int(dcat.shape[1])                                          # (D + 1) * C: slot s = columns [s C, (s + 1) C)
