@@ -158,6 +158,7 @@ def test_nnconv_csr_kernel_and_tile_kernel_agree_with_oracle(dev):
     h = torch.randn(1254, 32, generator=gen)
     with torch.no_grad():
         want = orc.nnconv_mean(h.double(), adj.cpu(), adj_attr.cpu().double(), sd64, "brch_1_graph_conv_layers.4")
+    assert ops.prepare_graph(1254, adj, adj_attr, col, columns=False).cols is None
     pg = ops.prepare_graph(1254, adj, adj_attr, col)
     assert pg.cols is not None
     l1 = net.brch_1_graph_conv_layers[4]
@@ -286,10 +287,18 @@ def test_init_and_final_mlp_against_oracle(dev, laby):
     assert e_init < TOL_ILL and e_final < TOL
 
 
-def test_end_to_end_same_order_as_reference_fp32_gap(dev, laby):
+@pytest.mark.parametrize("cols_min_nodes", [None, 10 ** 9])
+def test_end_to_end_same_order_as_reference_fp32_gap(dev, laby, cols_min_nodes, monkeypatch):
+    """cols_min_nodes = 1e9: the whole forward on the CSR / LDS-weight-table NNConv kernel (default: the column kernel)."""
+    from tilingnn_amd import ops
+    from tilingnn_amd.graph_networks import _graph_cache
+    if cols_min_nodes is not None:
+        monkeypatch.setattr(ops, "COLS_MIN_NODES", cols_min_nodes)
+    _graph_cache.clear()
     g, net, sd, sd64, cap = laby
     ref = load_npz("ref_forward_labyrinth.npz")
     probs, passthrough = net(*graph_tensors(g, torch.float32, dev)[:4])
+    _graph_cache.clear()
     got = probs.cpu().numpy()
     gap_ref = np.abs(ref["probs_fp32"] - ref["probs_fp64"]).max()        # the reference against itself
     gap_hip = np.abs(got - ref["probs_fp64"]).max()
@@ -572,25 +581,27 @@ def test_split_precision_kernels_hold_fp32_accuracy_across_magnitudes(dev, scale
     assert orc.rel_max_err(got.cpu(), want.cpu()) < 2e-6
 
 
-def test_two_chain_schedule_is_bit_identical_to_one_stream(dev):
+@pytest.mark.parametrize("n_nodes,columns", [(20000, True), (2000, True), (2000, False), (300, False)])
+def test_two_chain_schedule_is_bit_identical_to_one_stream(dev, n_nodes, columns):
     """tgnn_forward with the collision chain on a side stream (default) and with everything on one stream produce
-    the same bits: same kernels, same reduction trees, only the interleaving differs."""
+    the same bits: same kernels, same reduction trees, only the interleaving differs (small layouts: merge derives the
+    first BatchNorm's record from the partial rows itself)."""
     import ctypes as C
     from tilingnn_amd import _lib, ops
     from tilingnn_amd.synth import make_super_graph
-    sg = make_super_graph(20000, 200000, 250000, tile_count=2, n_edge_types=13, seed=5)
+    sg = make_super_graph(n_nodes, 10 * n_nodes, 12 * n_nodes + n_nodes // 2, tile_count=2, n_edge_types=13, seed=5)
     x, adj, adj_attr, col, _ = sg.to_torch(dev)
     net, _ = make_net(dev)
-    graph = ops.prepare_graph(20000, adj, adj_attr, col)
+    graph = ops.prepare_graph(n_nodes, adj, adj_attr, col, columns=columns)
     dims = net._dims()
     table, _ = net._param_table()
-    ws_bytes = _lib.lib.tgnn_forward_workspace_bytes(C.byref(dims), 20000, graph.n_types)
+    ws_bytes = _lib.lib.tgnn_forward_workspace_bytes(C.byref(dims), n_nodes, graph.n_types)
     g = graph.c_struct()
     outs = []
     side = torch.cuda.Stream(device=dev)
     for s2 in (None, C.c_void_p(side.cuda_stream), None, C.c_void_p(side.cuda_stream)):
         ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
-        probs = torch.empty(20000, 1, device=dev)
+        probs = torch.empty(n_nodes, 1, device=dev)
         _lib.check(_lib.lib.tgnn_forward(C.byref(dims), table, ops.ptr(x), ops.ptr(adj_attr), C.byref(g), 0, 0, ops.ptr(probs),
                                         ops.ptr(ws), ws_bytes, _lib.current_stream(dev), s2))
         torch.cuda.synchronize()

@@ -435,7 +435,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         // Few partial rows (small layouts): merge derives the first BatchNorm's record from them itself -- one launch
         // less on the critical chain of a launch-latency-bound forward.  (With the 256 rows of a 100k-node layout the
         // repeated reduction costs every merge block more than the separate 1-block finalize: measured.)
-        static const int fuse_rows = getenv("TGNN_MERGE_BN1_ROWS") ? atoi(getenv("TGNN_MERGE_BN1_ROWS")) : 32;
+        static const int fuse_rows = getenv("TGNN_MERGE_BN1_ROWS") ? atoi(getenv("TGNN_MERGE_BN1_ROWS")) : 128;
         const bool fused_bn1 = c == 32 && !use_running_stats && !sh && np1 <= fuse_rows;
         if (s2) {
             if (!fused_bn1) {

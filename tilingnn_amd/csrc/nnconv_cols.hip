@@ -19,6 +19,8 @@
 // One wavefront owns a contiguous run of tiles and walks its columns as ONE stream through a DEPTH-deep
 // register pipeline (index load -> gather -> consume), across tile boundaries.  D^T = W^T . S^T is computed
 // (operands swapped) so that a lane ends up with 4 consecutive output channels of ONE row: float4 stores.
+#include <stdlib.h>
+
 #include "tgnn_common.h"
 
 namespace tgnn {
@@ -319,7 +321,10 @@ static int launch_cols_t(const float *h, int64_t ldh, const int32_t *tile_col_pt
         attr_set = true;
     }
     const int64_t n_tiles = (n_nodes + 15) / 16;
-    int64_t blocks = (n_tiles + WAVES - 1) / WAVES;      // about one tile per wave at least
+    // One tile per SIMD before a second wave of a SIMD gets one: a small layout is bound by the latency of a tile, and
+    // waves that share a SIMD stretch each other's (matrix and vector issue do not overlap).  Large layouts hit the cap.
+    static const int tiles_per_block = getenv("TGNN_COLS_TILES_PER_BLOCK") ? atoi(getenv("TGNN_COLS_TILES_PER_BLOCK")) : 4;
+    int64_t blocks = (n_tiles + tiles_per_block - 1) / tiles_per_block;
     const int64_t cap = 256 * (int64_t)blocks_per_cu;
     if (blocks > cap) blocks = cap;
     if (blocks >= 8) blocks &= ~7;

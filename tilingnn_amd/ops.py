@@ -8,6 +8,7 @@ no CPU path.  Shape / dtype / device errors raise ValueError before anything is 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -153,9 +154,19 @@ def dedup_edge_types(edge_attr: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
     return edge_type, rep, n_types
 
 
+# Layouts up to this many nodes would run NNConv on the CSR / LDS-weight-table kernel (one half wave per destination row)
+# instead of the type-column matrix-core kernel (one wave per 16-row tile).  0 = never: once the column kernel spreads a
+# small layout's tiles one per SIMD (csrc/nnconv_cols.hip: launch_cols_t) it is as fast or faster at every size measured
+# -- cached-layout forward on MI355X, columns / CSR-only, ms: labyrinth (1 254 nodes) 0.74 / 0.89, synthetic 300 nodes
+# 0.80 / 0.76, 2 500: 0.94 / 0.90, 5 000: 0.90 / 0.93, 10 000: 0.91 / 1.04, 20 000: 1.03 / 1.31, 100 000: 2.26 / 3.77
+# (scratch/cols_ab.py).  The knob stays for experiments and for the tests that pin the CSR kernel end to end.
+COLS_MIN_NODES = int(os.environ.get("TGNN_COLS_MIN_NODES", "0"))
+
+
 def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col_e_idx: Tensor,
-                  tile_width: int = 32, n_src_nodes: Optional[int] = None) -> PreparedGraph:
-    """Everything the 20 layers share: CSR of both edge sets, edge-type ids in CSR order.
+                  tile_width: int = 32, n_src_nodes: Optional[int] = None, columns: Optional[bool] = None) -> PreparedGraph:
+    """Everything the 20 layers share: CSR of both edge sets, edge-type ids in CSR order, and (columns: None = for
+    layouts above COLS_MIN_NODES) the NNConv column structure.
     Synchronises once (the type count and the self-loop-free collision edge count are read back)."""
     adj = _check_edge_index(adj_e_index, "adj_e_index")
     col = _check_edge_index(col_e_idx, "col_e_idx")
@@ -172,7 +183,9 @@ def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col
         raise IndexError(f"edge index out of range [0, {n_nodes}) in "
                          f"{'adj_e_index' if host[1] else 'col_e_idx'}")
     n_types = int(host[0])
-    cols = build_nnconv_columns(n_nodes, ea, n_types, a_rowptr, a_src, adj_type) if tile_width == 32 else None
+    if columns is None:
+        columns = n_nodes > COLS_MIN_NODES
+    cols = build_nnconv_columns(n_nodes, ea, n_types, a_rowptr, a_src, adj_type) if tile_width == 32 and columns else None
     return PreparedGraph(n_nodes, ea, int(host[3]), n_types, a_rowptr, a_src, a_eid, adj_type, edge_type, rep,
                          c_rowptr, c_src, c_eid, cols)
 
