@@ -485,7 +485,10 @@ static int dense_act_impl(const float *a, int64_t lda, int64_t a_kblock_stride, 
     static const int exact_only = getenv("TGNN_DENSE_EXACT_FP32") ? atoi(getenv("TGNN_DENSE_EXACT_FP32")) : 0;
     if (fast && out_dim >= 64 && !exact_only && lda % 8 == 0 && a_kblock_stride % 8 == 0 && in_dim % 8 == 0) {
         // bf16 x 3 split-precision path (see dense_split_kernel)
-        if (out_dim > 64) {
+        // few row tiles (small layouts): the 128 x 64 block tile puts twice as many blocks on the chip and halves the
+        // matrix work per k-step of each -- the kernel is then bound by the latency of its serial k loop
+        static const int small_rows = getenv("TGNN_DENSE_SMALL_ROWS") ? atoi(getenv("TGNN_DENSE_SMALL_ROWS")) : 16384;
+        if (out_dim > 64 && n_rows > small_rows) {
             const int bx = producer_blocks(n_rows, 128);
             launch_dense_split<2, 2>(bx, s, a, lda, a_kblock_stride, kps, in_stat, w, b, n_rows, in_dim, out_dim, act, out, ldo,
                                      bn_partial);

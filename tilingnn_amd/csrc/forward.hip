@@ -249,7 +249,8 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     hipStream_t s2 = (prof.on || sh) ? nullptr : static_cast<hipStream_t>(stream2);
     if (s2 == s) s2 = nullptr;
     // Events of the two-chain schedule, per calling thread and device; created once, never destroyed.
-    constexpr int kEvPerDev = 1 + 2 * kMaxDepth;            // [0] init done, [1 + i] GIN_i done, [1 + kMaxDepth + i] merge_i done
+    // [0] init done, [1 + i] GIN_i done, [1 + kMaxDepth + i] merge_i done, then: fork at entry, edge weights done
+    constexpr int kEvPerDev = 3 + 2 * kMaxDepth, kEvFork = 1 + 2 * kMaxDepth, kEvWeights = 2 + 2 * kMaxDepth;
     static thread_local hipEvent_t ev_cache[64][kEvPerDev] = {};
     hipEvent_t *ev = nullptr;
     if (s2) {
@@ -320,7 +321,16 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         return TGNN_OK;
     };
 
-    // ---- K1: per-type NNConv matrices of all layers, one launch
+    // ---- K1: per-type NNConv matrices of all layers, one launch -- on the side stream when there is one: it idles until
+    //      the init MLP is through, and these ~30 us (serial 3-layer MLP per (layer, type) + the bf16 image) then leave the
+    //      critical chain; the first NNConv waits for them.
+    hipStream_t sw = s;
+    static const bool weights_on_side = !(getenv("TGNN_WEIGHTS_SIDE") && atoi(getenv("TGNN_WEIGHTS_SIDE")) == 0);
+    if (s2 && weights_on_side) {
+        TGNN_CHECK_HIP(hipEventRecord(ev[kEvFork], s));     // everything the caller queued on `stream` so far
+        TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[kEvFork], 0));
+        sw = s2;
+    }
     if (T > 0) {
         EdgeMlpLayers layers{};
         for (int i = 0; i < D; ++i) {
@@ -328,7 +338,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
             layers.l[i] = EdgeMlpLayer{P.f(b), P.f(b + 1), P.f(b + 2), P.f(b + 3), P.f(b + 4), P.f(b + 5)};
         }
         prof.begin(0);
-        launch_edge_weight_table_batched(adj_edge_attr, graph->type_rep_edge, T, fe, layers, D, c, w.wtab, s);
+        launch_edge_weight_table_batched(adj_edge_attr, graph->type_rep_edge, T, fe, layers, D, c, w.wtab, sw);
         prof.end();
     }
     const bool tiled = graph->nn_tile_col_ptr && c == 32 && (int64_t)nr * c * 4 < (int64_t(1) << 31);   // buffer-addressed gathers
@@ -336,9 +346,10 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         const float *roots[kMaxDepth];
         for (int i = 0; i < D; ++i) roots[i] = P.f(P.layer(i) + 6);
         prof.begin(0);
-        launch_nnconv_weight_image(w.wtab, roots, T, D, w.wimg, s);
+        launch_nnconv_weight_image(w.wtab, roots, T, D, w.wimg, sw);
         prof.end();
     }
+    if (sw != s) TGNN_CHECK_HIP(hipEventRecord(ev[kEvWeights], s2));
 
     // ---- K10: init MLP  (TilinGNN.py:54)
     prof.begin(1);
@@ -380,6 +391,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     if (s2) {
         TGNN_CHECK_HIP(hipEventRecord(ev[0], s));            // middle[0] is complete
         TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[0], 0));
+        if (sw != s) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[kEvWeights], 0));
     }
     for (int i = 0; i < D; ++i) {
         const int b = P.layer(i);
