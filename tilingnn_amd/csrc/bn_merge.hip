@@ -314,6 +314,153 @@ __global__ void shard_sum_peers_kernel(const double *__restrict__ peer_sums, con
     total[j] = t;
 }
 
+// ---- sharded forward, one all-to-all per layer: the statistics work of a layer folded into the two kernels that move the
+// halo rows anyway.  Unfused the chain behind the convolutions was  finalize(partials -> sums) -> pack -> all-to-all ->
+// unpack -> sum over peers -> finalize(sums -> records) -> merge: five 1-block-class launches of ~5 us each on a
+// launch-latency-bound chain, 20 times per forward.  Block 0 of the pack kernel now reduces the partial rows itself and
+// block 0 of the unpack kernel adds the shards' sums (rank order) and writes the records; the other blocks move rows.
+__device__ __forceinline__ void bn_sums_from_partials_1024(const BnJob &jb, int two_f, double *red, double *tot) {
+    const int tid = threadIdx.x;
+    const int groups = 1024 / two_f;
+    const int j = tid % two_f, g = tid / two_f;
+    double acc = 0.0;
+    if (g < groups) {                                     // same tree as bn_finalize_kernel: the same bits
+        const double *src = jb.partials + j;
+        int p = g;
+        for (; p + 31 * groups < jb.n_partials; p += 32 * groups) {
+            double v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = src[(int64_t)(p + u * groups) * two_f];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc += v[u];
+        }
+        for (; p + 7 * groups < jb.n_partials; p += 8 * groups) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(p + u * groups) * two_f];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; p < jb.n_partials; p += groups) acc += src[(int64_t)p * two_f];
+    }
+    red[tid] = acc;
+    __syncthreads();
+    if (tid < two_f) {
+        double t = 0.0;
+        for (int gg = 0; gg < groups; ++gg) t += red[gg * two_f + tid];
+        tot[tid] = t;
+    }
+    __syncthreads();
+}
+
+// threads 0 .. f-1: record + running statistics from the column sums tot[0 .. 2f) over n_total rows (bn_finalize mode 2)
+__device__ __forceinline__ void bn_record_from_sums(const BnJob &jb, const double *tot, int f, int64_t n_total, float eps,
+                                                    float momentum) {
+    const int tid = threadIdx.x;
+    if (tid < f) {
+        const float gamma = jb.gamma[tid], beta = jb.beta[tid];
+        const double inv_n = 1.0 / (double)n_total;
+        const double mean = tot[tid] * inv_n;
+        double var = tot[f + tid] * inv_n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float mh = (float)mean;
+        jb.stat[tid] = mh;
+        jb.stat[f + tid] = (float)(mean - (double)mh);
+        jb.stat[2 * f + tid] = (float)((double)gamma / sqrt(var + (double)eps));
+        jb.stat[3 * f + tid] = beta;
+        if (jb.running_mean) {
+            const double unbiased = n_total > 1 ? var * ((double)n_total / (double)(n_total - 1)) : var;
+            jb.running_mean[tid] = (float)((1.0 - (double)momentum) * (double)jb.running_mean[tid] + (double)momentum * mean);
+            jb.running_var[tid] = (float)((1.0 - (double)momentum) * (double)jb.running_var[tid] + (double)momentum * unbiased);
+        }
+    }
+    if (tid == 0 && jb.num_batches_tracked) *jb.num_batches_tracked += 1;
+}
+
+// jobs.job[0/1].sums: this shard's 2 x 64 sums (128 contiguous doubles), also copied bit for bit into the message's sums
+// rows (idx < 0: floats (-1 - idx) * 64 .. of those 128 doubles).  Width 32.
+__global__ __launch_bounds__(1024) void shard_pack_sums_kernel(const float *__restrict__ a1, const float *__restrict__ a2,
+                                                               const int *__restrict__ idx, int64_t n_rows, BnJobs jobs,
+                                                               float *__restrict__ out) {
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0) {
+        __shared__ double red[1024];
+        __shared__ double tot[128];
+        bn_sums_from_partials_1024(jobs.job[0], 64, red, tot);
+        bn_sums_from_partials_1024(jobs.job[1], 64, red, tot + 64);
+        if (tid < 128) jobs.job[tid >> 6].sums[tid & 63] = tot[tid];
+        const float *tf = reinterpret_cast<const float *>(tot);
+        for (int64_t r = tid >> 6; r < n_rows; r += 16) {
+            const int id = idx[r];
+            if (id < 0) out[r * 64 + (tid & 63)] = tf[(-1 - id) * 64 + (tid & 63)];
+        }
+        return;
+    }
+    const int64_t total = n_rows * 64;
+    for (int64_t i = (int64_t)(blockIdx.x - 1) * 1024 + tid; i < total; i += (int64_t)(gridDim.x - 1) * 1024) {
+        const int64_t r = i >> 6;
+        const int k = (int)(i & 63), id = idx[r];
+        if (id >= 0) out[i] = k < 32 ? a1[(int64_t)id * 32 + k] : a2[(int64_t)id * 32 + (k - 32)];
+    }
+}
+
+// idx >= 0: halo slot j -> a1[n_own + j], a2[n_own + j];  idx < 0: code = -1 - idx = 4 * peer + k: row k of that peer's
+// sums.  Block 0: total = own + the peers' sums in rank order, then the two records (+ running statistics).
+__global__ __launch_bounds__(1024) void shard_unpack_finalize_kernel(const float *__restrict__ in, const int *__restrict__ idx,
+                                                                     int64_t n_rows, int64_t n_own, float *__restrict__ a1,
+                                                                     float *__restrict__ a2, BnJobs jobs, int world, int rank,
+                                                                     int64_t n_total, float eps, float momentum) {
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0) {
+        __shared__ int pos[4 * 64];
+        __shared__ double tot[128];
+        for (int64_t r = tid; r < n_rows; r += 1024) {
+            const int id = idx[r];
+            if (id < 0 && -1 - id < 4 * 64) pos[-1 - id] = (int)r;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int k = tid >> 5, jj = tid & 31;
+            const double *own = jobs.job[0].sums;
+            double t = 0.0;
+            for (int p = 0; p < world; ++p)
+                t += p == rank ? own[tid] : reinterpret_cast<const double *>(in + (int64_t)pos[4 * p + k] * 64)[jj];
+            tot[tid] = t;
+        }
+        __syncthreads();
+        bn_record_from_sums(jobs.job[0], tot, 32, n_total, eps, momentum);
+        bn_record_from_sums(jobs.job[1], tot + 64, 32, n_total, eps, momentum);
+        return;
+    }
+    const int64_t total = n_rows * 64;
+    for (int64_t i = (int64_t)(blockIdx.x - 1) * 1024 + tid; i < total; i += (int64_t)(gridDim.x - 1) * 1024) {
+        const int64_t r = i >> 6;
+        const int k = (int)(i & 63), id = idx[r];
+        if (id >= 0) {
+            const float v = in[i];
+            if (k < 32) a1[(n_own + id) * 32 + k] = v;
+            else a2[(n_own + id) * 32 + (k - 32)] = v;
+        }
+    }
+}
+
+static inline unsigned shard_copy_blocks(int64_t n_rows) {
+    int64_t b = (n_rows * 64 + 1023) / 1024;
+    if (b < 1) b = 1;
+    if (b > 1024) b = 1024;
+    return (unsigned)b;
+}
+void launch_shard_pack_sums(const float *a1, const float *a2, const int *idx, int64_t n_rows, const BnJobs &jobs, float *out,
+                            hipStream_t s) {
+    shard_pack_sums_kernel<<<1 + shard_copy_blocks(n_rows), 1024, 0, s>>>(a1, a2, idx, n_rows, jobs, out);
+}
+void launch_shard_unpack_finalize(const float *in, const int *idx, int64_t n_rows, int64_t n_own, float *a1, float *a2,
+                                  const BnJobs &jobs, int world, int rank, int64_t n_total, float eps, float momentum,
+                                  hipStream_t s) {
+    shard_unpack_finalize_kernel<<<1 + shard_copy_blocks(n_rows), 1024, 0, s>>>(in, idx, n_rows, n_own, a1, a2, jobs, world,
+                                                                                rank, n_total, eps, momentum);
+}
+
 void launch_shard_pack(const float *a1, const float *a2, const int *idx, int64_t n_rows, const double *sums, float *out,
                        hipStream_t s) {
     if (n_rows > 0)

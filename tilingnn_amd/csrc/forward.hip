@@ -376,7 +376,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     // CollConv (:63): input = BN_{i-1}(a2_{i-1}) folded into the gather; layer 0 reads middle[0]
     // one all-to-all per layer instead of all-reduce + all-to-all (see tgnn_shard in tgnn.h)
     const bool fused_shard = sh && sh->send_idx_fused && sh->recv_idx_fused && sh->world >= 1 && c == 32;
-    if (fused_shard) TGNN_CHECK_ARG(sh->rank >= 0 && sh->rank < sh->world, "shard rank");
+    if (fused_shard) TGNN_CHECK_ARG(sh->rank >= 0 && sh->rank < sh->world && sh->world <= 64, "shard rank / world (<= 64)");
     auto gin_layer = [&](int i, hipStream_t gs) -> int {
         const int b = P.layer(i);
         const float *gin_in = i == 0 ? w.mid : w.a2[(i - 1) & 1];
@@ -424,21 +424,17 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
             BnJobs jobs{};
             jobs.job[0] = bn_job(w.part1, np1, P.bn(b + 8), w.stat1);
             jobs.job[1] = bn_job(w.part2, np2, P.bn(b + 20), w.stat2[i & 1]);
-            double *own = sh->sum_buf, *total = sh->sum_buf + 128, *peers = sh->sum_buf + 256;
+            double *own = sh->sum_buf;
             jobs.job[0].sums = own;
             jobs.job[1].sums = own + 64;
-            launch_bn_finalize(jobs, 2, 1, c, n_total, eps, momentum, s);
             const int64_t n_out = sh->n_send + 4 * (int64_t)sh->world, n_in = n_halo + 4 * (int64_t)sh->world;
-            launch_shard_pack(w.a1, w.a2[i & 1], sh->send_idx_fused, n_out, own, sh->send_buf, s);
+            launch_shard_pack_sums(w.a1, w.a2[i & 1], sh->send_idx_fused, n_out, jobs, sh->send_buf, s);
             if (sh->alltoall_rows(sh->ctx, sh->send_buf, sh->recv_buf, 2 * c, 4, stream) != 0) {
                 set_error("tgnn_forward_sharded: the all-to-all callback failed");
                 return TGNN_ERR_INVALID_ARG;
             }
-            launch_shard_unpack(sh->recv_buf, sh->recv_idx_fused, n_in, n, w.a1, w.a2[i & 1], peers, s);
-            launch_shard_sum_peers(peers, own, sh->world, sh->rank, total, s);
-            jobs.job[0].sums = total;
-            jobs.job[1].sums = total + 64;
-            launch_bn_finalize(jobs, 2, 2, c, n_total, eps, momentum, s);
+            launch_shard_unpack_finalize(sh->recv_buf, sh->recv_idx_fused, n_in, n, w.a1, w.a2[i & 1], jobs, sh->world,
+                                         sh->rank, n_total, eps, momentum, s);
             const float *resid_f = i >= 2 ? w.mid + (size_t)(i - 2) * nr * c : nullptr;
             TGNN_TRY(tgnn_merge_fwd(w.a1, w.stat1, w.a2[i & 1], w.stat2[i & 1], resid_f, nr, c,
                                     w.mid + (size_t)(i + 1) * nr * c, nullptr, s));

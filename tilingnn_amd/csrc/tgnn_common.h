@@ -137,6 +137,14 @@ void launch_shard_pack(const float *a1, const float *a2, const int *idx, int64_t
 void launch_shard_unpack(const float *in, const int *idx, int64_t n_rows, int64_t n_own, float *a1, float *a2,
                          double *peer_sums, hipStream_t s);
 void launch_shard_sum_peers(const double *peer_sums, const double *own, int world, int rank, double *total, hipStream_t s);
+// the same with the statistics folded in: block 0 of the pack kernel reduces the two BatchNorms' partial rows to this
+// shard's sums (jobs.job[k].sums, 2 x 64 contiguous doubles) and writes them into the message; block 0 of the unpack kernel
+// adds the shards' sums in rank order and writes both records (jobs.job[k].stat, running statistics).  world <= 64.
+void launch_shard_pack_sums(const float *a1, const float *a2, const int *idx, int64_t n_rows, const BnJobs &jobs, float *out,
+                            hipStream_t s);
+void launch_shard_unpack_finalize(const float *in, const int *idx, int64_t n_rows, int64_t n_own, float *a1, float *a2,
+                                  const BnJobs &jobs, int world, int rank, int64_t n_total, float eps, float momentum,
+                                  hipStream_t s);
 
 // GraphConv edge-MLP parameters of up to 64 layers, passed by value to one batched launch; nnconv.hip
 struct EdgeMlpLayer {
