@@ -293,22 +293,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *__restrict__ dz
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) zok[i] = co0 + 32 * i + (lane & 31) < cout;
-#pragma unroll 2
-    for (int64_t rb = r0 + 2 * wave; rb < r1; rb += 8) {                   // uniform trip count: MFMA needs the whole wave
-        const int64_t r = rb + (lane >> 5);
-        const bool ok = r < r1;
-        float av[TM], bv[TN];
+    // two row pairs per trip, all loads of a trip issued before its first MFMA (the loop is bound by load latency: the
+    // compiler keeps one trip in flight, and a block walks its rows alone)
+    for (int64_t rb = r0 + 2 * wave; rb < r1; rb += 16) {                  // uniform trip count: MFMA needs the whole wave
+        float av[2][TM], bv[2][TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            av[i] = ok && zok[i] ? dz[r * ld_dz + co0 + 32 * i + (lane & 31)] : 0.f;
-            bsum[i] += av[i];
+        for (int h = 0; h < 2; ++h) {
+            const int64_t r = rb + 8 * h + (lane >> 5);
+            const bool ok = r < r1;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[h][i] = ok && zok[i] ? dz[r * ld_dz + co0 + 32 * i + (lane & 31)] : 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[h][j] = ok && xok[j] ? x[r * ld_x + xoff[j]] : 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bv[j] = ok && xok[j] ? x[r * ld_x + xoff[j]] : 0.f;
+        for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) bsum[i] += av[h][i];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[h][i], bv[h][j], acc[i][j], 0, 0, 0);
+        }
     }
     // cross-wave sum through LDS, one output tile at a time
     __shared__ float sh[4][32 * 32];
@@ -369,13 +376,13 @@ static inline void wgrad_plan(int64_t n, int cout, int cin, int &tm, int &tn, in
     tm = cout > 32 ? 2 : 1;
     tn = cin > 32 ? 2 : 1;
     const int tiles = ((cout + 32 * tm - 1) / (32 * tm)) * ((cin + 32 * tn - 1) / (32 * tn));
-    int64_t want = (1024 + tiles - 1) / tiles;
+    int64_t want = (2048 + tiles - 1) / tiles;
     const int64_t max_by_rows = (n + 63) / 64;
     if (want > max_by_rows) want = max_by_rows;
-    if (want > 128) want = 128;
+    if (want > 512) want = 512;
     if (want < 1) want = 1;
-    rows_per_block = ((n + want - 1) / want + 7) / 8 * 8;
-    if (rows_per_block < 8) rows_per_block = 8;
+    rows_per_block = ((n + want - 1) / want + 15) / 16 * 16;
+    if (rows_per_block < 16) rows_per_block = 16;
     parts = (int)((n + rows_per_block - 1) / rows_per_block);
     if (parts < 1) parts = 1;
 }
