@@ -35,7 +35,7 @@ def _f32c(t: Tensor, name: str) -> Tensor:
 
 
 def _stream(t: Tensor) -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return _lib.current_stream(t.device)
 
 
 def act_code(activation) -> int:

@@ -398,13 +398,15 @@ class TrainStep(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, x, adj_e_index, adj_e_features, col_e_idx, *params):
-        probs, sv = forward_train(net, x, adj_e_index, adj_e_features, col_e_idx)
+        with _lib.pinned_stream(x.device):
+            probs, sv = forward_train(net, x, adj_e_index, adj_e_features, col_e_idx)
         ctx.net, ctx.sv = net, sv
         return probs
 
     @staticmethod
     def backward(ctx, dprobs):
-        grads = backward_train(ctx.net, ctx.sv, dprobs.contiguous())
+        with _lib.pinned_stream(dprobs.device):
+            grads = backward_train(ctx.net, ctx.sv, dprobs.contiguous())
         ctx.sv = None
         out = []
         for name, p in ctx.net.named_parameters():
