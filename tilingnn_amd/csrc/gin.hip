@@ -21,6 +21,8 @@
 //  round trips at all: correct, but 29 us vs 23.7 us for this one -- 64 VGPRs of per-lane fp64 BN sums
 //  cap occupancy, the 16-B-strided row loads/stores are TA-expensive and the final 32-lane fp64
 //  butterfly is serial.  See DESIGN.md section 5.)
+#include <stdlib.h>
+
 #include "tgnn_common.h"
 
 namespace tgnn {
@@ -348,7 +350,10 @@ extern "C" int tgnn_gin_fwd(const float *a, int64_t lda, const float *in_stat, c
         gin32_aggregate_kernel<<<agg_blocks, 256, 0, s>>>(a, lda, in_stat, rowptr, col_src, eps, n_nodes, z_scratch);
         // persistent 8-wave blocks; the waves of one SIMD split a contiguous share of 32-row tiles
         blocks = producer_blocks(n_nodes, 16 * kMlpWaves);
-        if (blocks > 256) blocks = 256;        // one block per CU: the weight prologue is paid once per block
+        // one block per CU (the weight prologue is paid once per block), minus a few CUs left to the other chain's small
+        // kernels (see launch_cols_t in nnconv_cols.hip)
+        static const int reserve = getenv("TGNN_RESERVE_CUS") ? atoi(getenv("TGNN_RESERVE_CUS")) : 32;
+        if (blocks > 256 - reserve) blocks = 256 - reserve;
         if (blocks >= 8) blocks &= ~7;
         gin32_mlp_kernel<<<blocks, kMlpThreads, 0, s>>>(z_scratch, w1, b1, w2, b2, w3, b3, n_nodes, act, out,
                                                         bn_partial);

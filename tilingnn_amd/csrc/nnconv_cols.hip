@@ -325,7 +325,14 @@ static int launch_cols_t(const float *h, int64_t ldh, const int32_t *tile_col_pt
     // waves that share a SIMD stretch each other's (matrix and vector issue do not overlap).  Large layouts hit the cap.
     static const int tiles_per_block = getenv("TGNN_COLS_TILES_PER_BLOCK") ? atoi(getenv("TGNN_COLS_TILES_PER_BLOCK")) : 4;
     int64_t blocks = (n_tiles + tiles_per_block - 1) / tiles_per_block;
-    const int64_t cap = 256 * (int64_t)blocks_per_cu;
+    // Some CUs (4 per XCD) are left to the OTHER chain of the two-stream forward: this kernel's blocks own their CU's
+    // whole register file for its whole duration, and the 1-block BatchNorm finalize of the collision chain would
+    // otherwise sit in the queue until the first of them retires (rocprof: 4 us alone, 17 us on average beside this one).
+    // Measured, cached-layout forward, reserve 0 / 8 / 32 / 64: 20 000 nodes 1.02 / 0.96 / 0.94 / 0.93 ms, 50 000 nodes
+    // 1.43 / 1.36 / 1.35 / 1.39, 100 000 nodes 2.29 / 2.27 / 2.23 / 2.25; the isolated kernel at 100k nodes: 45.7 us on
+    // 256 CUs, 47.8 on 224 (6 250 tiles are 7 per SIMD either way), 56.5 on 192, 71.6 on 128.
+    static const int reserve = getenv("TGNN_RESERVE_CUS") ? atoi(getenv("TGNN_RESERVE_CUS")) : 32;
+    const int64_t cap = (256 - reserve) * (int64_t)blocks_per_cu;
     if (blocks > cap) blocks = cap;
     if (blocks >= 8) blocks &= ~7;
     if (blocks < 1) blocks = 1;
