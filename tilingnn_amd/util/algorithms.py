@@ -64,8 +64,9 @@ class SubLayoutBuilder:
         self.adj_out = torch.empty(2 * max(self.ea, 1), dtype=torch.int64, device=dev)
         self.attr_out = torch.empty(max(self.ea, 1) * self.fe, dtype=torch.float32, device=dev)
         self.col_out = torch.empty(2 * max(self.ec, 1), dtype=torch.int64, device=dev)
-        self.counts = torch.zeros(3, dtype=torch.int64, device=dev)
-        self.err = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._tail = torch.zeros(4, dtype=torch.int64, device=dev)       # counts [3] | error flag: ONE read-back per round
+        self.counts = self._tail[:3]
+        self.err = self._tail[3:].view(torch.int32)[:1]
         self.ws_bytes = lib.tgnn_sublayout_workspace_bytes(self.n, self.ea, self.ec)
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
 
@@ -79,8 +80,8 @@ class SubLayoutBuilder:
                                          ptr(self.x_out), ptr(self.inverse), ptr(self.adj_out), ptr(self.attr_out),
                                          ptr(self.col_out), ptr(self.counts), ptr(self.err), ptr(self.ws), self.ws_bytes,
                                          _lib.current_stream(alive.device)))
-        n2, ea2, ec2 = (int(v) for v in self.counts.cpu().tolist())
-        if int(self.err.item()):
+        n2, ea2, ec2, err = self._tail.cpu().tolist()
+        if err:
             raise IndexError("edge index out of range in the layout")
         return DeviceLayout(self.x_out[:n2], self.adj_out[:2 * ea2].view(2, ea2), self.attr_out[:ea2 * self.fe].view(ea2, self.fe),
                             self.col_out[:2 * ec2].view(2, ec2), self.inverse[:n2])
@@ -105,7 +106,7 @@ def solve_by_probablistic_greedy(ml_solver, origin_layout, score_fn=None, on_rou
     round_cnt = 1
     while unlabelled.any():
         temp_layout = builder.build(alive_dev)
-        ids = temp_layout.inverse_index.cpu().numpy()           # == np.flatnonzero(unlabelled)
+        ids = np.flatnonzero(unlabelled)                        # == temp_layout.inverse_index (kept on the device)
         if on_round is not None:
             on_round(temp_layout)
         prob = np.asarray(ml_solver.predict(temp_layout), dtype=np.float64).reshape(-1)
