@@ -28,3 +28,9 @@ print("ms/step", (time.perf_counter() - t) / 5 * 1e3)
 probs, _ = net(x, adj, attr, col); loss, _, _ = Losses.calculate_unsupervised_loss(probs, x, col, adj, attr)
 torch.cuda.synchronize(); t = time.perf_counter(); loss.backward(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
 print("backward: host issue %.1f ms, until done %.1f ms" % ((t1 - t) * 1e3, (t2 - t) * 1e3))
+# steady state: host time to ISSUE five steps (no sync inside) vs wall time until the GPU is done
+torch.cuda.synchronize(); t = time.perf_counter()
+for _ in range(5): step()
+t_issue = time.perf_counter() - t
+torch.cuda.synchronize(); t_done = time.perf_counter() - t
+print("5 steps: host issue %.1f ms, until done %.1f ms" % (t_issue * 1e3, t_done * 1e3))
