@@ -391,8 +391,8 @@ int tgnn_wgrad(const float *dz, int64_t ld_dz, const float *x, int64_t ld_x, int
                int32_t cout, int32_t cin, float *out, float *dbias, void *ws, size_t ws_bytes, tgnn_stream_t stream);
 /* NNConv backward building block (edge_conv.py:25; PyG NNConv: message = x_j . W_e, mean, + x . root):
  * out [n_nodes][(n_types + 1) * 32]: slot t < n_types = sum over the row's CSR slots of type t of rows[src];
- * slot n_types = own[j] * root_scale[j] (NULL: 1).  With it  d W_t = slot_t^T . g  and  d x = slots . [W_t^T; root^T]
- * are dense products (g = dz / deg). */
+ * slot n_types = own[j] * root_scale[j] (NULL: 1).  Run over the TRANSPOSED adjacency CSR on g = dz / deg (root slot = dz) it
+ * makes both adjoints dense products:  d x = slots . [W_t^T; root^T]  and  [d W_t; d root] = x^T . slots. */
 int tgnn_nnconv_type_sum(const float *rows, int64_t ld_rows, const float *own, int64_t ld_own, const float *root_scale,
                          const int32_t *rowptr, const int32_t *src, const int32_t *type, int64_t n_nodes, int32_t n_types,
                          int32_t c, float *out, tgnn_stream_t stream);

@@ -12,9 +12,9 @@
 //                                           a finalize, one pass to apply
 //   branch merge (TilinGNN.py:64-71)        dy1 = dh y2, dy2 = dh y1 + carry, residual += dh; fused with the two
 //                                           BatchNorm reductions that follow it (tgnn_merge_bwd_reduce)
-//   NNConv mean (edge_conv.py:25)           per node the sums of gathered rows per edge type (tgnn_nnconv_type_sum) turn
-//                                           both the weight gradient and the input gradient into plain dense products
-//                                           over [N, (T+1) 32] (see tilingnn_amd/train.py)
+//   NNConv mean (edge_conv.py:25)           per node the sums of gathered g = dz / deg rows per edge type over the transposed
+//                                           graph (tgnn_nnconv_type_sum) turn both the weight gradient and the input
+//                                           gradient into plain dense products over [N, (T+1) 32] (tilingnn_amd/train.py)
 //   GIN MLP sigmoids (coll_conv.py:14-18)   d . t (1 - t)  (tgnn_sigmoid_bwd)
 //   loss (losses.py:48-116)                 d loss / d probs: per-edge terms scattered with fp64 atomics, the area term and
 //                                           the product rule in a second pass (tgnn_unsupervised_loss_bwd)

@@ -15,10 +15,10 @@ Adjoints, per forward kernel (C = 32, T edge types, D layers):
                    dx = dz W (tgnn_dense_act_fwd with W^T).
   merge            tgnn_merge_bwd_reduce: dy1 = dh BN2(a2), dy2 = dh BN1(a1) + carry, residual slot += dh, and the six
                    column sums of both BatchNorm backward passes in the same sweep.
-  NNConv (mean)    with g = dz / deg:  S = per-type sums of gathered input rows (tgnn_nnconv_type_sum on the forward
-                   CSR, root slot = deg * h) gives  [dW_0 .. dW_{T-1}, d root] = S^T g  as ONE weight-gradient product;
-                   S' = the same sums of g over the TRANSPOSED graph (root slot = dz) gives  dh = S' [W_t^T; root^T]  as
-                   ONE dense product.  The edge MLP (T rows) is back-propagated with the generic dense pieces.
+  NNConv (mean)    with g = dz / deg:  S' = per-node sums of gathered g rows per edge type over the TRANSPOSED graph
+                   (tgnn_nnconv_type_sum, root slot = dz) gives the input gradient  dh = S' [W_t^T; root^T]  as ONE dense
+                   product and all weight gradients  [dW_0 .. dW_{T-1}, d root] = h^T S'  as ONE weight-gradient product.
+                   The edge MLP (T rows) is back-propagated with the generic dense pieces.
   GIN              t1, t2 re-derived from the kept aggregate; three sigmoid/Linear adjoints; the aggregation's adjoint is
                    the aggregation on the transposed collision graph (tgnn_gin_aggregate).
 Width 32 only (the reference's network_width, inputs/config.py:38); other widths raise.
@@ -301,16 +301,19 @@ def nnconv_backward(conv, prefix: str, tg: TrainGraph, wtab: Tensor, h: Tensor, 
     g = tg.g
     n, T, c = g.n_nodes, g.n_types, 32
     dev = h.device
-    # weight gradients through the per-type sums of the forward graph: [dW_0 .. dW_{T-1}, d root] = S^T g
-    s_fwd = type_sum(h, h, tg.deg, g.adj_rowptr, g.adj_src, g.adj_type, n, T)                     # [N, (T+1) C]
-    dwcat = wgrad(s_fwd, g_scaled)                                                                # [(T+1) C, C] = [t][in][out]
-    grads[prefix + ".nnConv.root"] = dwcat[T * c:]
-    grads[prefix + ".nnConv.bias"] = colsum(dz)
-    # input gradient through the per-type sums of g over the transposed graph (root slot = g * deg = dz)
-    s_bwd = type_sum(g_scaled, g_scaled, tg.deg, tg.adjT_rowptr, tg.adjT_src, tg.adjT_type, n, T)
+    # ONE gather pass serves both gradients: S'[j][t] = sum over the out-edges (j -> v) of type t of g[v]  (type sums over
+    # the TRANSPOSED graph; root slot = g[j] deg[j] = dz[j]).
+    #   input gradient:   dh[j]  = sum_t S'[j][t] W_t^T + dz[j] root^T              = S' . [W_t^T; root^T]   (dense)
+    #   weight gradients: dW_t   = sum_e h[src_e]^T g[dst_e] = sum_j h[j]^T S'[j][t];  d root = h^T dz       = h^T . S'
+    s_bwd = type_sum(g_scaled, g_scaled, tg.deg, tg.adjT_rowptr, tg.adjT_src, tg.adjT_type, n, T)   # [N, (T+1) C]
     wd = torch.empty(c, (T + 1) * c, dtype=torch.float32, device=dev)                             # [in][t][out]
     check(lib.tgnn_swap_leading(ptr(wtab), T + 1, c, c, ptr(wd), _s(wd)))
     dh = ops.dense_act(s_bwd, wd, _zeros(c, dev), ACT_NONE)[0]
+    dw_in_major = wgrad(h, s_bwd)                                                                 # [in][t][out]
+    dwcat = torch.empty((T + 1) * c, c, dtype=torch.float32, device=dev)                          # [t][in][out]
+    check(lib.tgnn_swap_leading(ptr(dw_in_major), c, T + 1, c, ptr(dwcat), _s(dwcat)))
+    grads[prefix + ".nnConv.root"] = dwcat[T * c:]
+    grads[prefix + ".nnConv.bias"] = colsum(dz)
     # the edge MLP behind the T weight matrices (edge_conv.py:17-18), on the T distinct attribute rows
     ew = conv._edge_mlp_params()
     names = [f"{prefix}.mlp.mlp.{k}" for k in range(3)]
