@@ -389,6 +389,15 @@ int tgnn_merge_bwd_reduce(const float *dh, int64_t ld_dh, const float *a1, const
 size_t tgnn_wgrad_workspace_bytes(int64_t n_rows, int32_t cout, int32_t cin);
 int tgnn_wgrad(const float *dz, int64_t ld_dz, const float *x, int64_t ld_x, int64_t x_kblock_stride, int64_t n_rows,
                int32_t cout, int32_t cin, float *out, float *dbias, void *ws, size_t ws_bytes, tgnn_stream_t stream);
+/* Backward of a 3-layer sigmoid MLP without BatchNorm (GraphConv's edge MLP, edge_conv.py:17-18; GINConv's MLP,
+ * coll_conv.py:14-18) in one call: hidden activations re-derived from x [n, d0]; per layer dpre = d t (1 - t),
+ * dW = dpre^T . in, db, d_in = dpre . W.  w_k [d_k, d_{k-1}]; t3 = the MLP's output [n, d3]; d_out: gradient at t3;
+ * dx [n, d0] may be NULL.  (b3 is not needed: t3 is given.) */
+size_t tgnn_sigmoid_mlp_bwd_workspace_bytes(int64_t n_rows, int32_t d0, int32_t d1, int32_t d2, int32_t d3);
+int tgnn_sigmoid_mlp_bwd(const float *x, int64_t n_rows, int32_t d0, int32_t d1, int32_t d2, int32_t d3, const float *w1,
+                         const float *b1, const float *w2, const float *b2, const float *w3, const float *t3,
+                         const float *d_out, int64_t ld_dout, float *dw1, float *db1, float *dw2, float *db2, float *dw3,
+                         float *db3, float *dx, void *ws, size_t ws_bytes, tgnn_stream_t stream);
 /* NNConv backward building block (edge_conv.py:25; PyG NNConv: message = x_j . W_e, mean, + x . root):
  * out [n_nodes][(n_types + 1) * 32]: slot t < n_types = sum over the row's CSR slots of type t of rows[src];
  * slot n_types = own[j] * root_scale[j] (NULL: 1).  Run over the TRANSPOSED adjacency CSR on g = dz / deg (root slot = dz) it

@@ -106,6 +106,9 @@ def _load() -> C.CDLL:
                                             p, sz, p]),
         "tgnn_wgrad_workspace_bytes": (sz, [i64, i32, i32]),
         "tgnn_wgrad": (C.c_int, [p, i64, p, i64, i64, i64, i32, i32, p, p, p, sz, p]),
+        "tgnn_sigmoid_mlp_bwd_workspace_bytes": (sz, [i64, i32, i32, i32, i32]),
+        "tgnn_sigmoid_mlp_bwd": (C.c_int, [p, i64, i32, i32, i32, i32, p, p, p, p, p, p, p, i64, p, p, p, p, p, p, p, p, sz,
+                                           p]),
         "tgnn_nnconv_type_sum": (C.c_int, [p, i64, p, i64, p, p, p, p, i64, i32, i32, p, p]),
         "tgnn_csr_degree": (C.c_int, [p, i64, p, p, p]),
         "tgnn_unsupervised_loss_bwd": (C.c_int, [p, i64, p, i64, i64, p, i64, p, i64, p, i64, f32, f32, f32, p, p, p, i64,
@@ -131,6 +134,7 @@ EXPORTED_SYMBOLS = (
     "tgnn_sublayout_workspace_bytes", "tgnn_sublayout_compact",
     "tgnn_transpose", "tgnn_swap_leading", "tgnn_gin_aggregate", "tgnn_sigmoid_bwd", "tgnn_add_into", "tgnn_reduce_workspace_bytes", "tgnn_colsum",
     "tgnn_bn_bwd_reduce", "tgnn_bn_bwd_apply", "tgnn_merge_bwd_reduce", "tgnn_wgrad_workspace_bytes", "tgnn_wgrad",
+    "tgnn_sigmoid_mlp_bwd_workspace_bytes", "tgnn_sigmoid_mlp_bwd",
     "tgnn_nnconv_type_sum", "tgnn_csr_degree", "tgnn_unsupervised_loss_bwd")
 
 

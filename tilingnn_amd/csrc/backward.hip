@@ -677,6 +677,82 @@ int tgnn_wgrad(const float *dz, int64_t ld_dz, const float *x, int64_t ld_x, int
     return TGNN_OK;
 }
 
+/* Backward of a 3-layer sigmoid MLP without BatchNorm (GraphConv's edge MLP edge_conv.py:17-18, GINConv's MLP
+ * coll_conv.py:14-18: Linear -> Sigmoid three times) in ONE call: re-derives the hidden activations t1, t2 from the input,
+ * then per layer  dpre = d * t (1 - t),  dW = dpre^T . in (+ bias gradient),  d_in = dpre . W.  The same kernels the
+ * per-op schedule launches, sequenced here instead of from Python (17 library calls -> 1).
+ * x [n, d0] dense; w_k [d_k, d_{k-1}]; t3 = the MLP's output [n, d3] dense; d_out: gradient at t3; dx may be NULL. */
+size_t tgnn_sigmoid_mlp_bwd_workspace_bytes(int64_t n_rows, int32_t d0, int32_t d1, int32_t d2, int32_t d3) {
+    const int64_t n = n_rows > 0 ? n_rows : 1;
+    const int dmax = d1 > d2 ? (d1 > d3 ? d1 : d3) : (d2 > d3 ? d2 : d3);
+    size_t wt = (size_t)d3 * d2;
+    if ((size_t)d2 * d1 > wt) wt = (size_t)d2 * d1;
+    if ((size_t)d1 * d0 > wt) wt = (size_t)d1 * d0;
+    size_t wg = tgnn_wgrad_workspace_bytes(n, d3, d2);
+    if (tgnn_wgrad_workspace_bytes(n, d2, d1) > wg) wg = tgnn_wgrad_workspace_bytes(n, d2, d1);
+    if (tgnn_wgrad_workspace_bytes(n, d1, d0) > wg) wg = tgnn_wgrad_workspace_bytes(n, d1, d0);
+    const int zmax = d0 > d1 ? (d0 > d2 ? d0 : d2) : (d1 > d2 ? d1 : d2);
+    return align_up((size_t)n * d1 * 4, 256) + align_up((size_t)n * d2 * 4, 256) + 2 * align_up((size_t)n * dmax * 4, 256) +
+           align_up(wt * 4, 256) + align_up((size_t)zmax * 4, 256) + wg + 256;
+}
+
+int tgnn_sigmoid_mlp_bwd(const float *x, int64_t n_rows, int32_t d0, int32_t d1, int32_t d2, int32_t d3, const float *w1,
+                         const float *b1, const float *w2, const float *b2, const float *w3, const float *t3,
+                         const float *d_out, int64_t ld_dout, float *dw1, float *db1, float *dw2, float *db2, float *dw3,
+                         float *db3, float *dx, void *ws, size_t ws_bytes, tgnn_stream_t stream) {
+    TGNN_CHECK_ARG(n_rows >= 0 && d0 >= 1 && d1 >= 1 && d2 >= 1 && d3 >= 1, "shape");
+    TGNN_CHECK_ARG(w1 && b1 && w2 && b2 && w3 && dw1 && db1 && dw2 && db2 && dw3 && db3, "null pointer");
+    TGNN_CHECK_ARG(n_rows == 0 || (x && t3 && d_out), "null pointer");
+    TGNN_CHECK_ARG(ws && ws_bytes >= tgnn_sigmoid_mlp_bwd_workspace_bytes(n_rows, d0, d1, d2, d3), "workspace");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = n_rows;
+    const int dmax = d1 > d2 ? (d1 > d3 ? d1 : d3) : (d2 > d3 ? d2 : d3);
+    size_t wt_elems = (size_t)d3 * d2;
+    if ((size_t)d2 * d1 > wt_elems) wt_elems = (size_t)d2 * d1;
+    if ((size_t)d1 * d0 > wt_elems) wt_elems = (size_t)d1 * d0;
+    const int zmax = d0 > d1 ? (d0 > d2 ? d0 : d2) : (d1 > d2 ? d1 : d2);
+    Carver cv(ws, ws_bytes);
+    const int64_t nn = n > 0 ? n : 1;
+    float *t1 = cv.take<float>((size_t)nn * d1), *t2 = cv.take<float>((size_t)nn * d2);
+    float *buf_a = cv.take<float>((size_t)nn * dmax), *buf_b = cv.take<float>((size_t)nn * dmax);
+    float *wt = cv.take<float>(wt_elems), *zero = cv.take<float>((size_t)zmax);
+    void *wg = cv.take<unsigned char>(1);
+    const size_t wg_bytes = ws_bytes - (size_t)((unsigned char *)wg - (unsigned char *)ws);
+    TGNN_CHECK_HIP(hipMemsetAsync(zero, 0, sizeof(float) * zmax, s));
+#define TGNN_TRY_(expr)            \
+    do {                           \
+        const int rc__ = (expr);   \
+        if (rc__ != TGNN_OK) return rc__; \
+    } while (0)
+    if (n > 0) {
+        TGNN_TRY_(tgnn_dense_act_fwd(x, d0, 32, nullptr, w1, b1, n, d0, d1, TGNN_ACT_SIGMOID, t1, d1, nullptr, nullptr, stream));
+        TGNN_TRY_(tgnn_dense_act_fwd(t1, d1, 32, nullptr, w2, b2, n, d1, d2, TGNN_ACT_SIGMOID, t2, d2, nullptr, nullptr, stream));
+    }
+    // layer 3
+    TGNN_TRY_(tgnn_sigmoid_bwd(d_out, ld_dout, t3, d3, n, d3, buf_a, d3, stream));
+    TGNN_TRY_(tgnn_wgrad(buf_a, d3, t2, d2, 0, n, d3, d2, dw3, db3, wg, wg_bytes, stream));
+    if (n > 0) {
+        TGNN_TRY_(tgnn_transpose(w3, d3, d2, wt, stream));
+        TGNN_TRY_(tgnn_dense_act_fwd(buf_a, d3, 32, nullptr, wt, zero, n, d3, d2, TGNN_ACT_NONE, buf_b, d2, nullptr, nullptr, stream));
+    }
+    // layer 2
+    TGNN_TRY_(tgnn_sigmoid_bwd(buf_b, d2, t2, d2, n, d2, buf_a, d2, stream));
+    TGNN_TRY_(tgnn_wgrad(buf_a, d2, t1, d1, 0, n, d2, d1, dw2, db2, wg, wg_bytes, stream));
+    if (n > 0) {
+        TGNN_TRY_(tgnn_transpose(w2, d2, d1, wt, stream));
+        TGNN_TRY_(tgnn_dense_act_fwd(buf_a, d2, 32, nullptr, wt, zero, n, d2, d1, TGNN_ACT_NONE, buf_b, d1, nullptr, nullptr, stream));
+    }
+    // layer 1
+    TGNN_TRY_(tgnn_sigmoid_bwd(buf_b, d1, t1, d1, n, d1, buf_a, d1, stream));
+    TGNN_TRY_(tgnn_wgrad(buf_a, d1, x, d0, 0, n, d1, d0, dw1, db1, wg, wg_bytes, stream));
+    if (dx && n > 0) {
+        TGNN_TRY_(tgnn_transpose(w1, d1, d0, wt, stream));
+        TGNN_TRY_(tgnn_dense_act_fwd(buf_a, d1, 32, nullptr, wt, zero, n, d1, d0, TGNN_ACT_NONE, dx, d0, nullptr, nullptr, stream));
+    }
+#undef TGNN_TRY_
+    return TGNN_OK;
+}
+
 /* Per-type sums of gathered rows + the (scaled) own row: out [n_nodes][(n_types + 1) * 32].  rowptr / src / type:
  * a CSR of tgnn_csr_build with the type of every slot. */
 int tgnn_nnconv_type_sum(const float *rows, int64_t ld_rows, const float *own, int64_t ld_own, const float *root_scale,

@@ -280,17 +280,25 @@ def _mlp_backward(layers, acts, stats, first_input, first_slot_major, dy, grads,
     return dy
 
 
-def _sigmoid_mlp_backward(weights, acts, x_in, d_out, grads, names, need_dx=True):
-    """Three Linear + Sigmoid layers without BatchNorm (GraphConv's edge MLP, GINConv's MLP).
-    weights = [w1, b1, w2, b2, w3, b3]; acts = [t1, t2, t3] (sigmoid outputs); names = the three `...mlp.k` prefixes."""
-    d = d_out
-    for k in (2, 1, 0):
-        dpre = sigmoid_bwd(d, acts[k])
-        inp = acts[k - 1] if k > 0 else x_in
-        grads[names[k] + ".linear.weight"], grads[names[k] + ".linear.bias"] = wgrad(dpre, inp, with_bias=True)
-        if k > 0 or need_dx:
-            d = dense_dx(dpre, weights[2 * k])
-    return d
+def sigmoid_mlp_backward(weights, x: Tensor, t3: Tensor, d_out: Tensor, grads: Dict[str, Tensor], names, need_dx: bool):
+    """Three Linear + Sigmoid layers without BatchNorm (GraphConv's edge MLP, GINConv's MLP) in one library call
+    (tgnn_sigmoid_mlp_bwd).  weights = [w1, b1, w2, b2, w3, b3]; t3 = the MLP's output; names = the `...mlp.k` prefixes."""
+    n, d0 = int(x.shape[0]), int(x.shape[1])
+    d1, d2, d3 = int(weights[0].shape[0]), int(weights[2].shape[0]), int(weights[4].shape[0])
+    dev = x.device
+    gw = [torch.empty_like(weights[2 * k]) for k in range(3)]
+    gb = [torch.empty_like(weights[2 * k + 1]) for k in range(3)]
+    dx = torch.empty(n, d0, dtype=torch.float32, device=dev) if need_dx else None
+    nb = lib.tgnn_sigmoid_mlp_bwd_workspace_bytes(n, d0, d1, d2, d3)
+    ws = _Scratch.get("mlp_bwd", nb, dev)
+    if not (x.is_contiguous() and t3.is_contiguous()):
+        raise ValueError("sigmoid_mlp_backward: x and t3 must be contiguous")
+    check(lib.tgnn_sigmoid_mlp_bwd(ptr(x), n, d0, d1, d2, d3, ptr(weights[0]), ptr(weights[1]), ptr(weights[2]),
+                                   ptr(weights[3]), ptr(weights[4]), ptr(t3), ptr(d_out), d_out.stride(0), ptr(gw[0]),
+                                   ptr(gb[0]), ptr(gw[1]), ptr(gb[1]), ptr(gw[2]), ptr(gb[2]), ptr(dx), ptr(ws), nb, _s(x)))
+    for k in range(3):
+        grads[names[k] + ".linear.weight"], grads[names[k] + ".linear.bias"] = gw[k], gb[k]
+    return dx
 
 
 def nnconv_backward(conv, prefix: str, tg: TrainGraph, wtab: Tensor, h: Tensor, dz: Tensor, g_scaled: Tensor,
@@ -321,10 +329,7 @@ def nnconv_backward(conv, prefix: str, tg: TrainGraph, wtab: Tensor, h: Tensor, 
         fe = int(edge_attr.shape[1])
         rows = torch.empty(T, fe, dtype=torch.float32, device=dev)
         check(lib.tgnn_rows_gather(ptr(edge_attr), fe, ptr(g.type_rep_edge), T, fe, ptr(rows), fe, _s(rows)))
-        e1 = ops.dense_act(rows, ew[0], ew[1], ACT_SIGMOID)[0]
-        e2 = ops.dense_act(e1, ew[2], ew[3], ACT_SIGMOID)[0]
-        e3 = wtab[:T].reshape(T, c * c)
-        _sigmoid_mlp_backward(ew, [e1, e2, e3], rows, dwcat[:T * c].reshape(T, c * c), grads, names, need_dx=False)
+        sigmoid_mlp_backward(ew, rows, wtab[:T].reshape(T, c * c), dwcat[:T * c].reshape(T, c * c), grads, names, False)
     else:
         for k in range(3):
             grads[names[k] + ".linear.weight"] = torch.zeros_like(ew[2 * k])
@@ -336,10 +341,7 @@ def gin_backward(conv, prefix: str, tg: TrainGraph, u: Tensor, t3: Tensor, dz: T
     """Adjoint of GINConv (coll_conv.py:25): u = the aggregate the MLP read, t3 = the MLP's output (= the layer's
     pre-BatchNorm activation: LeakyReLU is the identity on a sigmoid), dz: gradient at t3.  Returns the gradient at the
     conv's input: the aggregation run over the transposed collision graph."""
-    gw = conv._mlp_params()
-    t1 = ops.dense_act(u, gw[0], gw[1], ACT_SIGMOID)[0]
-    t2 = ops.dense_act(t1, gw[2], gw[3], ACT_SIGMOID)[0]
-    du = _sigmoid_mlp_backward(gw, [t1, t2, t3], u, dz, grads, [f"{prefix}.ginConv.nn.mlp.{k}" for k in range(3)])
+    du = sigmoid_mlp_backward(conv._mlp_params(), u, t3, dz, grads, [f"{prefix}.ginConv.nn.mlp.{k}" for k in range(3)], True)
     return gin_aggregate(du, tg.colT_rowptr, tg.colT_src, conv.eps, tg.g.n_nodes)
 
 
