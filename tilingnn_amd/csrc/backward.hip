@@ -150,9 +150,19 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double *__re
     const int col_raw = blockIdx.x * kFinCols + (threadIdx.x >> 4);
     const int col = col_raw < f ? col_raw : f - 1;
     const double *base = partial + offset + col;
-    const double s0 = partial_column_sum(base, row_doubles, n_partials, lane);
-    const double s1 = partial_column_sum(base + f, row_doubles, n_partials, lane);
-    const double s2 = partial_column_sum(base + 2 * f, row_doubles, n_partials, lane);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;               // one sweep, three independent chains
+    for (int p = lane; p < n_partials; p += kFinLanes) {
+        const double *row = base + (int64_t)p * row_doubles;
+        s0 += row[0];
+        s1 += row[f];
+        s2 += row[2 * f];
+    }
+#pragma unroll
+    for (int d = kFinLanes / 2; d >= 1; d >>= 1) {
+        s0 += __shfl_xor(s0, d);
+        s1 += __shfl_xor(s1, d);
+        s2 += __shfl_xor(s2, d);
+    }
     if (lane != 0 || col_raw >= f) return;
     const double inv_n = 1.0 / (double)n_rows;
     const double invstd = 1.0 / sqrt(s2 * inv_n + (double)eps);
@@ -353,22 +363,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *__restrict__ dz
 }
 
 // 64 consecutive elements x 4 lanes over the partial tiles (coalesced 256-byte rows), fixed tree through LDS
-// elements [0, w_elems) go to `out`, [w_elems, elems) to `dbias`
+// elements [0, w_elems) go to `out`, [w_elems, elems) to `dbias`.  16 consecutive elements x 16 lanes over the partial
+// tiles, butterfly over the lanes (fixed tree).  (4 lanes per element left every thread 128 dependent-latency loads at 512
+// partial tiles: 21 us per call, the largest single item of the training step.)
 __global__ __launch_bounds__(256) void wgrad_final_kernel(const float *__restrict__ partial, int n_partials, int64_t elems,
                                                           int64_t w_elems, float *__restrict__ out,
                                                           float *__restrict__ dbias) {
-    const int el = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 64 + el;
+    const int pl = threadIdx.x & 15, el = threadIdx.x >> 4;
+    const int64_t i_raw = (int64_t)blockIdx.x * 16 + el;
+    const int64_t i = i_raw < elems ? i_raw : elems - 1;
     double s = 0.0;
-    if (i < elems)
-        for (int p = pl; p < n_partials; p += 4) s += (double)partial[(int64_t)p * elems + i];
-    __shared__ double sh[4][64];
-    sh[pl][el] = s;
-    __syncthreads();
-    if (pl == 0 && i < elems) {
-        const float v = (float)((sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el]));
-        if (i < w_elems) out[i] = v;
-        else dbias[i - w_elems] = v;
+    for (int p = pl; p < n_partials; p += 16) s += (double)partial[(int64_t)p * elems + i];
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if (pl == 0 && i_raw < elems) {
+        if (i < w_elems) out[i] = (float)s;
+        else dbias[i - w_elems] = (float)s;
     }
 }
 
@@ -671,7 +681,7 @@ int tgnn_wgrad(const float *dz, int64_t ld_dz, const float *x, int64_t ld_x, int
     else if (tn == 2) TGNN_WGRAD(1, 2);
     else TGNN_WGRAD(1, 1);
 #undef TGNN_WGRAD
-    hipLaunchKernelGGL(wgrad_final_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(256), 0, s, partial, parts, elems,
+    hipLaunchKernelGGL(wgrad_final_kernel, dim3((unsigned)((elems + 15) / 16)), dim3(256), 0, s, partial, parts, elems,
                        w_elems, out, dbias);
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;

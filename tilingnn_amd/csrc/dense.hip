@@ -480,7 +480,16 @@ static int dense_act_impl(const float *a, int64_t lda, int64_t a_kblock_stride, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int vec_a = (lda % 4 == 0) && (a_kblock_stride % 4 == 0) && ((uintptr_t)a % 16 == 0);
     const int vec_w = (in_dim % 4 == 0) && ((uintptr_t)w % 16 == 0);
-    const int blocks_x = producer_blocks(n_rows, kBM);
+    // one block = one BatchNorm partial row, hence the cap of producer_blocks; a product nobody takes statistics of (the
+    // backward's dx = dz . W, the GIN hidden layers it re-derives) gets one block per row tile instead of walking two
+    // tiles per block behind a full chip: 23 -> ~13 us for [100k, 32] x [32, 32]
+    auto row_blocks = [&](int rows_per_block) {
+        if (bn_partial) return producer_blocks(n_rows, rows_per_block);
+        int64_t nb = (n_rows + rows_per_block - 1) / rows_per_block;
+        if (nb > 8192) nb = 8192;
+        return (int)(nb < 1 ? 1 : nb);
+    };
+    const int blocks_x = row_blocks(kBM);
     const bool fast = vec_a && vec_w && in_dim % kBK == 0;
     static const int exact_only = getenv("TGNN_DENSE_EXACT_FP32") ? atoi(getenv("TGNN_DENSE_EXACT_FP32")) : 0;
     if (fast && out_dim >= 64 && !exact_only && lda % 8 == 0 && a_kblock_stride % 8 == 0 && in_dim % 8 == 0) {
@@ -489,12 +498,12 @@ static int dense_act_impl(const float *a, int64_t lda, int64_t a_kblock_stride, 
         // matrix work per k-step of each -- the kernel is then bound by the latency of its serial k loop
         static const int small_rows = getenv("TGNN_DENSE_SMALL_ROWS") ? atoi(getenv("TGNN_DENSE_SMALL_ROWS")) : 16384;
         if (out_dim > 64 && n_rows > small_rows) {
-            const int bx = producer_blocks(n_rows, 128);
+            const int bx = row_blocks(128);
             launch_dense_split<2, 2>(bx, s, a, lda, a_kblock_stride, kps, in_stat, w, b, n_rows, in_dim, out_dim, act, out, ldo,
                                      bn_partial);
             if (n_partials_host) *n_partials_host = bx;
         } else {
-            const int bx = producer_blocks(n_rows, 128);
+            const int bx = row_blocks(128);
             launch_dense_split<1, 1>(bx, s, a, lda, a_kblock_stride, kps, in_stat, w, b, n_rows, in_dim, out_dim, act, out, ldo,
                                      bn_partial);
             if (n_partials_host) *n_partials_host = bx;
