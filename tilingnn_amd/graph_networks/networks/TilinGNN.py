@@ -6,8 +6,9 @@
     probs, *_ = network(x=x, adj_e_index=ei, adj_e_features=ea, col_e_idx=ci, col_e_features=cf)
 
 drops into ML_Solver.predict (solver/ml_solver/ml_solver.py:39-43) unchanged.  Differences a
-caller can observe: outputs carry no autograd graph (forward only -- training is out of scope,
-SURVEY.md section 8f-4), and a CPU module raises instead of computing (no fallback by design).
+caller can observe: outputs carry no autograd graph unless `network.autograd = True` (the training step of
+tilingnn_amd/train.py; off by default because the reference runs inference with autograd
+recording too), and a CPU module raises instead of computing (no fallback by design).
 BatchNorm follows module.training exactly like torch: batch statistics + running-stat updates in
 train mode (which is how the reference runs inference, ml_solver.py:129-131), running statistics
 in eval mode.
