@@ -149,13 +149,16 @@ def ptr(t) -> C.c_void_p:
     return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
 
 
-_pinned_stream = None            # (device index, c_void_p) while a `pinned_stream` block is active
+import threading
+
+_pinned = threading.local()      # .value = (device index, c_void_p) while a `pinned_stream` block is active in this thread
 
 
 def current_stream(device) -> C.c_void_p:
     import torch
-    if _pinned_stream is not None:
-        return _pinned_stream[1]
+    hit = getattr(_pinned, "value", None)
+    if hit is not None:
+        return hit[1]
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
@@ -167,15 +170,13 @@ class pinned_stream:
         self.device = device
 
     def __enter__(self):
-        global _pinned_stream
         import torch
-        self.prev = _pinned_stream
+        self.prev = getattr(_pinned, "value", None)
         dev = torch.device(self.device)
-        _pinned_stream = (dev.index, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        _pinned.value = (dev.index, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
 
     def __exit__(self, *exc):
-        global _pinned_stream
-        _pinned_stream = self.prev
+        _pinned.value = self.prev
 
 
 _side_streams = {}
