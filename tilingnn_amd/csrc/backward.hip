@@ -42,6 +42,32 @@ __global__ void transpose_kernel(const float *__restrict__ w, int rows, int cols
     }
 }
 
+// up to three transposes and one zero-fill in ONE launch (grid.y = job; the last job is the fill): the weight matrices of a
+// 3-layer MLP for the dx products of its backward
+struct TransposeJobs {
+    const float *src[3];
+    float *dst[3];
+    int rows[3], cols[3];
+    int n;
+    float *zero;
+    int n_zero;
+};
+__global__ void transpose_multi_kernel(TransposeJobs jobs) {
+    const int j = blockIdx.y;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == jobs.n) {
+        for (int64_t i = t0; i < jobs.n_zero; i += stride) jobs.zero[i] = 0.f;
+        return;
+    }
+    const int rows = jobs.rows[j], cols = jobs.cols[j];
+    const float *src = jobs.src[j];
+    float *dst = jobs.dst[j];
+    for (int64_t i = t0; i < (int64_t)rows * cols; i += stride) {
+        const int r = (int)(i / cols), c = (int)(i % cols);
+        dst[(int64_t)c * rows + r] = src[i];
+    }
+}
+
 // out[b][a][c] = in[a][b][c]
 __global__ void swap_leading_kernel(const float *__restrict__ in, int da, int db, int dc, float *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -277,7 +303,9 @@ template <int TM, int TN>
 __global__ __launch_bounds__(256) void wgrad_kernel(const float *__restrict__ dz, int64_t ld_dz,
                                                     const float *__restrict__ x, int64_t ld_x, int64_t x_kblock_stride,
                                                     int64_t n, int cout, int cin, int64_t rows_per_block,
-                                                    float *__restrict__ partial, int64_t partial_stride, int with_bias) {
+                                                    float *__restrict__ partial, int64_t partial_stride, int with_bias,
+                                                    float *__restrict__ direct_bias) {
+    // direct_bias != NULL: there is ONE row range; `partial` is the result itself and the bias gradient goes to direct_bias
     typedef float f16v __attribute__((ext_vector_type(16)));
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int co0 = blockIdx.y * 32 * TM, ci0 = blockIdx.z * 32 * TN;
@@ -355,9 +383,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *__restrict__ dz
         __syncthreads();
         if (threadIdx.x < 32 * TM) {
             const int co = co0 + threadIdx.x;
-            if (co < cout)
-                partial[(int64_t)blockIdx.x * partial_stride + (int64_t)cout * cin + co] =
-                    (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+            if (co < cout) {
+                const float v = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+                if (direct_bias) direct_bias[co] = v;
+                else partial[(int64_t)blockIdx.x * partial_stride + (int64_t)cout * cin + co] = v;
+            }
         }
     }
 }
@@ -390,7 +420,7 @@ static inline void wgrad_plan(int64_t n, int cout, int cin, int &tm, int &tn, in
     const int64_t max_by_rows = (n + 63) / 64;
     if (want > max_by_rows) want = max_by_rows;
     if (want > 512) want = 512;
-    if (want < 1) want = 1;
+    if (want < 1 || n <= 1024) want = 1;       // few rows: one row range, the result written directly (no second launch)
     rows_per_block = ((n + want - 1) / want + 15) / 16 * 16;
     if (rows_per_block < 16) rows_per_block = 16;
     parts = (int)((n + rows_per_block - 1) / rows_per_block);
@@ -670,19 +700,21 @@ int tgnn_wgrad(const float *dz, int64_t ld_dz, const float *x, int64_t ld_x, int
     int64_t rpb;
     wgrad_plan(n_rows, cout, cin, tm, tn, parts, rpb);
     const int64_t w_elems = (int64_t)cout * cin, elems = w_elems + (dbias ? cout : 0);
-    TGNN_CHECK_ARG(ws && ws_bytes >= (size_t)parts * elems * sizeof(float), "workspace");
-    float *partial = static_cast<float *>(ws);
+    const bool direct = parts == 1;            // one row range (small layouts): no partial tiles, no second launch
+    TGNN_CHECK_ARG(direct || (ws && ws_bytes >= (size_t)parts * elems * sizeof(float)), "workspace");
+    float *partial = direct ? out : static_cast<float *>(ws);
     const dim3 grid(parts, (cout + 32 * tm - 1) / (32 * tm), (cin + 32 * tn - 1) / (32 * tn));
 #define TGNN_WGRAD(TM_, TN_)                                                                                         \
     hipLaunchKernelGGL((wgrad_kernel<TM_, TN_>), grid, dim3(256), 0, s, dz, ld_dz, x, ld_x, x_kblock_stride, n_rows, cout, \
-                       cin, rpb, partial, elems, dbias ? 1 : 0)
+                       cin, rpb, partial, elems, dbias ? 1 : 0, direct ? dbias : nullptr)
     if (tm == 2 && tn == 2) TGNN_WGRAD(2, 2);
     else if (tm == 2) TGNN_WGRAD(2, 1);
     else if (tn == 2) TGNN_WGRAD(1, 2);
     else TGNN_WGRAD(1, 1);
 #undef TGNN_WGRAD
-    hipLaunchKernelGGL(wgrad_final_kernel, dim3((unsigned)((elems + 15) / 16)), dim3(256), 0, s, partial, parts, elems,
-                       w_elems, out, dbias);
+    if (!direct)
+        hipLaunchKernelGGL(wgrad_final_kernel, dim3((unsigned)((elems + 15) / 16)), dim3(256), 0, s, partial, parts, elems,
+                           w_elems, out, dbias);
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
 }
@@ -695,15 +727,13 @@ int tgnn_wgrad(const float *dz, int64_t ld_dz, const float *x, int64_t ld_x, int
 size_t tgnn_sigmoid_mlp_bwd_workspace_bytes(int64_t n_rows, int32_t d0, int32_t d1, int32_t d2, int32_t d3) {
     const int64_t n = n_rows > 0 ? n_rows : 1;
     const int dmax = d1 > d2 ? (d1 > d3 ? d1 : d3) : (d2 > d3 ? d2 : d3);
-    size_t wt = (size_t)d3 * d2;
-    if ((size_t)d2 * d1 > wt) wt = (size_t)d2 * d1;
-    if ((size_t)d1 * d0 > wt) wt = (size_t)d1 * d0;
+    const size_t wt = align_up((size_t)d3 * d2 * 4, 256) + align_up((size_t)d2 * d1 * 4, 256) + align_up((size_t)d1 * d0 * 4, 256);
     size_t wg = tgnn_wgrad_workspace_bytes(n, d3, d2);
     if (tgnn_wgrad_workspace_bytes(n, d2, d1) > wg) wg = tgnn_wgrad_workspace_bytes(n, d2, d1);
     if (tgnn_wgrad_workspace_bytes(n, d1, d0) > wg) wg = tgnn_wgrad_workspace_bytes(n, d1, d0);
     const int zmax = d0 > d1 ? (d0 > d2 ? d0 : d2) : (d1 > d2 ? d1 : d2);
     return align_up((size_t)n * d1 * 4, 256) + align_up((size_t)n * d2 * 4, 256) + 2 * align_up((size_t)n * dmax * 4, 256) +
-           align_up(wt * 4, 256) + align_up((size_t)zmax * 4, 256) + wg + 256;
+           wt + align_up((size_t)zmax * 4, 256) + wg + 256;
 }
 
 int tgnn_sigmoid_mlp_bwd(const float *x, int64_t n_rows, int32_t d0, int32_t d1, int32_t d2, int32_t d3, const float *w1,
@@ -717,18 +747,31 @@ int tgnn_sigmoid_mlp_bwd(const float *x, int64_t n_rows, int32_t d0, int32_t d1,
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = n_rows;
     const int dmax = d1 > d2 ? (d1 > d3 ? d1 : d3) : (d2 > d3 ? d2 : d3);
-    size_t wt_elems = (size_t)d3 * d2;
-    if ((size_t)d2 * d1 > wt_elems) wt_elems = (size_t)d2 * d1;
-    if ((size_t)d1 * d0 > wt_elems) wt_elems = (size_t)d1 * d0;
     const int zmax = d0 > d1 ? (d0 > d2 ? d0 : d2) : (d1 > d2 ? d1 : d2);
     Carver cv(ws, ws_bytes);
     const int64_t nn = n > 0 ? n : 1;
     float *t1 = cv.take<float>((size_t)nn * d1), *t2 = cv.take<float>((size_t)nn * d2);
     float *buf_a = cv.take<float>((size_t)nn * dmax), *buf_b = cv.take<float>((size_t)nn * dmax);
-    float *wt = cv.take<float>(wt_elems), *zero = cv.take<float>((size_t)zmax);
+    float *wt3 = cv.take<float>((size_t)d3 * d2), *wt2 = cv.take<float>((size_t)d2 * d1), *wt1 = cv.take<float>((size_t)d1 * d0);
+    float *zero = cv.take<float>((size_t)zmax);
     void *wg = cv.take<unsigned char>(1);
     const size_t wg_bytes = ws_bytes - (size_t)((unsigned char *)wg - (unsigned char *)ws);
-    TGNN_CHECK_HIP(hipMemsetAsync(zero, 0, sizeof(float) * zmax, s));
+    {   // W3^T, W2^T (and W1^T when dx is wanted) + the zero bias of the dx products: one launch
+        TransposeJobs tj{};
+        tj.src[0] = w3; tj.dst[0] = wt3; tj.rows[0] = d3; tj.cols[0] = d2;
+        tj.src[1] = w2; tj.dst[1] = wt2; tj.rows[1] = d2; tj.cols[1] = d1;
+        tj.src[2] = w1; tj.dst[2] = wt1; tj.rows[2] = d1; tj.cols[2] = d0;
+        tj.n = dx ? 3 : 2;
+        tj.zero = zero;
+        tj.n_zero = zmax;
+        size_t biggest = (size_t)d3 * d2;
+        if ((size_t)d2 * d1 > biggest) biggest = (size_t)d2 * d1;
+        if (dx && (size_t)d1 * d0 > biggest) biggest = (size_t)d1 * d0;
+        unsigned gx = (unsigned)((biggest + 255) / 256);
+        if (gx > 64) gx = 64;
+        if (gx < 1) gx = 1;
+        hipLaunchKernelGGL(transpose_multi_kernel, dim3(gx, tj.n + 1), dim3(256), 0, s, tj);
+    }
 #define TGNN_TRY_(expr)            \
     do {                           \
         const int rc__ = (expr);   \
@@ -742,22 +785,19 @@ int tgnn_sigmoid_mlp_bwd(const float *x, int64_t n_rows, int32_t d0, int32_t d1,
     TGNN_TRY_(tgnn_sigmoid_bwd(d_out, ld_dout, t3, d3, n, d3, buf_a, d3, stream));
     TGNN_TRY_(tgnn_wgrad(buf_a, d3, t2, d2, 0, n, d3, d2, dw3, db3, wg, wg_bytes, stream));
     if (n > 0) {
-        TGNN_TRY_(tgnn_transpose(w3, d3, d2, wt, stream));
-        TGNN_TRY_(tgnn_dense_act_fwd(buf_a, d3, 32, nullptr, wt, zero, n, d3, d2, TGNN_ACT_NONE, buf_b, d2, nullptr, nullptr, stream));
+        TGNN_TRY_(tgnn_dense_act_fwd(buf_a, d3, 32, nullptr, wt3, zero, n, d3, d2, TGNN_ACT_NONE, buf_b, d2, nullptr, nullptr, stream));
     }
     // layer 2
     TGNN_TRY_(tgnn_sigmoid_bwd(buf_b, d2, t2, d2, n, d2, buf_a, d2, stream));
     TGNN_TRY_(tgnn_wgrad(buf_a, d2, t1, d1, 0, n, d2, d1, dw2, db2, wg, wg_bytes, stream));
     if (n > 0) {
-        TGNN_TRY_(tgnn_transpose(w2, d2, d1, wt, stream));
-        TGNN_TRY_(tgnn_dense_act_fwd(buf_a, d2, 32, nullptr, wt, zero, n, d2, d1, TGNN_ACT_NONE, buf_b, d1, nullptr, nullptr, stream));
+        TGNN_TRY_(tgnn_dense_act_fwd(buf_a, d2, 32, nullptr, wt2, zero, n, d2, d1, TGNN_ACT_NONE, buf_b, d1, nullptr, nullptr, stream));
     }
     // layer 1
     TGNN_TRY_(tgnn_sigmoid_bwd(buf_b, d1, t1, d1, n, d1, buf_a, d1, stream));
     TGNN_TRY_(tgnn_wgrad(buf_a, d1, x, d0, 0, n, d1, d0, dw1, db1, wg, wg_bytes, stream));
     if (dx && n > 0) {
-        TGNN_TRY_(tgnn_transpose(w1, d1, d0, wt, stream));
-        TGNN_TRY_(tgnn_dense_act_fwd(buf_a, d1, 32, nullptr, wt, zero, n, d1, d0, TGNN_ACT_NONE, dx, d0, nullptr, nullptr, stream));
+        TGNN_TRY_(tgnn_dense_act_fwd(buf_a, d1, 32, nullptr, wt1, zero, n, d1, d0, TGNN_ACT_NONE, dx, d0, nullptr, nullptr, stream));
     }
 #undef TGNN_TRY_
     return TGNN_OK;
