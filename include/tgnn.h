@@ -250,6 +250,24 @@ int tgnn_forward(const tgnn_model_dims *dims, const void *const *params_host, co
                  int32_t use_running_stats, float *probs, void *ws, size_t ws_bytes,
                  tgnn_stream_t stream, tgnn_stream_t stream2);
 
+/* ---- the same forward for the TRAINING step (Trainer.train, solver/ml_solver/trainer.py:68-75: the network in train mode
+ * with autograd recording): identical kernels and schedule, but what the backward reads is kept in the caller's buffers
+ * instead of the rotating workspace ones.  C = network_width, D = network_depth, T = graph->n_types. */
+typedef struct tgnn_train_save {
+    float *init_a[2];    /* [N, C] x 2: pre-BatchNorm activations of the init MLP's two layers */
+    float *init_stat[2]; /* [4, C] x 2: their BatchNorm records */
+    float *a1, *a2;      /* [D][N][C]: LeakyReLU(conv) of the adjacency / collision branch, before BatchNorm */
+    float *u;            /* [D][N][C]: the aggregate GINConv's MLP read */
+    float *stat1, *stat2;/* [D][4][C]: the two BatchNorm records of every layer */
+    float *fin_a[4];     /* [N, 256], [N, 128], [N, 64], [N, C]: pre-BatchNorm activations of the final MLP */
+    float *fin_stat[4];  /* [4, 256], [4, 128], [4, 64], [4, C] */
+    float *skip;         /* [D + 1][N][C]: the skip-connection buffer = every layer's input */
+    float *wtab;         /* [D][max(T, 1)][C][C]: the per-edge-type NNConv matrices */
+} tgnn_train_save;
+int tgnn_forward_train(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
+                       const float *adj_edge_attr, const tgnn_graph *graph, const tgnn_train_save *keep, float *probs,
+                       void *ws, size_t ws_bytes, tgnn_stream_t stream, tgnn_stream_t stream2);
+
 /* ---- the same forward for ONE SHARD of a node-range partition (one process per GPU) -------------------------
  * This device owns rows [0, n_own) of a layout whose buffers carry n_rows - n_own halo rows of other shards behind
  * them: `graph` is built with n_nodes = n_own destinations and sources in [0, n_rows) (tgnn_csr_build's
@@ -347,8 +365,10 @@ int tgnn_unsupervised_loss(const float *probs, int64_t ld_probs, int32_t n_maps,
  * optimizer.step().  torch.autograd derives the backward there; these are the same adjoints per forward kernel
  * (csrc/backward.hip; scheduled by tilingnn_amd/train.py).  Column sums run in fp64 over fixed trees. */
 int tgnn_transpose(const float *w, int32_t rows, int32_t cols, float *out, tgnn_stream_t stream);
-/* out[b][a][c] = in[a][b][c] (weight tables re-laid for the input-gradient product of NNConv) */
-int tgnn_swap_leading(const float *in, int32_t da, int32_t db, int32_t dc, float *out, tgnn_stream_t stream);
+/* out[b][a][c] = in[a][b][c], with rows of out_da >= da entries in `out` (weight tables re-laid for the input-gradient
+ * product of NNConv: the T type matrices and, behind them, the root matrix) */
+int tgnn_swap_leading(const float *in, int32_t da, int32_t db, int32_t dc, float *out, int32_t out_da,
+                      tgnn_stream_t stream);
 /* z = (1 + eps) BN_in(a) + sum over the row's CSR slots of BN_in(a)[src] (width 32): the input of GINConv's MLP; on the
  * transposed collision graph, the adjoint of that aggregation. */
 int tgnn_gin_aggregate(const float *a, int64_t lda, const float *in_stat, const int32_t *rowptr, const int32_t *col_src,

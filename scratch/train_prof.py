@@ -11,7 +11,7 @@ sg = make_super_graph(n, 10 * n, int(12.5 * n), tile_count=2, n_edge_types=13, s
 net = TilinGNN(adj_edge_features_dim=15, network_depth=20, network_width=32, node_features_dim=3)
 net.load_state_dict(make_state_dict(15, 20, 32, 1, 3, seed=0)); net = net.cuda().train(); net.autograd = True
 x, adj, attr, col, _ = sg.to_torch("cuda:0")
-opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+opt = torch.optim.Adam(net.parameters(), lr=1e-4, **({"fused": True} if os.environ.get("ADAM_FUSED") == "1" else {}))
 def step():
     probs, _ = net(x, adj, attr, col)
     opt.zero_grad()

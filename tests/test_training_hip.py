@@ -182,9 +182,7 @@ def test_nnconv_and_gin_adjoints_teacher_forced(case):
     p1, p2 = "brch_1_graph_conv_layers.1", "brch_2_coll_conv_layers.1"
 
     # ---- NNConv
-    wtab = torch.empty(T + 1, 32, 32, device=DEV)
-    wtab[:T].copy_(ops.edge_weight_table(attr, tg.g, *l1.nnConv._edge_mlp_params(), 32))
-    wtab[T].copy_(l1.nnConv.root.detach())
+    wtab = ops.edge_weight_table(attr, tg.g, *l1.nnConv._edge_mlp_params(), 32).contiguous()
     grads = {}
     dh = train.nnconv_backward(l1.nnConv, p1, tg, wtab, h, dz, dz * tg.inv_deg[:, None], attr, grads)
     leaf = {k: (v.clone().requires_grad_(True) if k.startswith(p1) and v.is_floating_point() else v) for k, v in sd64.items()}

@@ -35,6 +35,13 @@ class Graph(C.Structure):
                 ("nn_tile_col_ptr", C.c_void_p), ("nn_col_meta", C.c_void_p), ("nn_col_src", C.c_void_p)]
 
 
+class TrainSave(C.Structure):
+    """tgnn_train_save"""
+    _fields_ = [("init_a", C.c_void_p * 2), ("init_stat", C.c_void_p * 2), ("a1", C.c_void_p), ("a2", C.c_void_p),
+                ("u", C.c_void_p), ("stat1", C.c_void_p), ("stat2", C.c_void_p), ("fin_a", C.c_void_p * 4),
+                ("fin_stat", C.c_void_p * 4), ("skip", C.c_void_p), ("wtab", C.c_void_p)]
+
+
 ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 ALLTOALL_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p)
 
@@ -94,7 +101,9 @@ def _load() -> C.CDLL:
         "tgnn_forward_profiled": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), p, p, C.POINTER(Graph), i32,
                                             i32, p, p, sz, p, C.POINTER(C.c_float), pi32]),
         "tgnn_transpose": (C.c_int, [p, i32, i32, p, p]),
-        "tgnn_swap_leading": (C.c_int, [p, i32, i32, i32, p, p]),
+        "tgnn_swap_leading": (C.c_int, [p, i32, i32, i32, p, i32, p]),
+        "tgnn_forward_train": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), p, p, C.POINTER(Graph),
+                                         C.POINTER(TrainSave), p, p, sz, p, p]),
         "tgnn_gin_aggregate": (C.c_int, [p, i64, p, p, p, p, i64, i32, p, p]),
         "tgnn_sigmoid_bwd": (C.c_int, [p, i64, p, i64, i64, i32, p, i64, p]),
         "tgnn_add_into": (C.c_int, [p, i64, i64, i32, p, i64, p]),
@@ -129,7 +138,7 @@ EXPORTED_SYMBOLS = (
     "tgnn_nnconv_mean_fwd", "tgnn_nnconv_cols_max_columns", "tgnn_nnconv_cols_workspace_bytes",
     "tgnn_nnconv_cols_build", "tgnn_nnconv_cols_max_types", "tgnn_nnconv_weight_image_floats", "tgnn_nnconv_mean_cols_fwd", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_dense_act_slots_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
     "tgnn_merge_fwd", "tgnn_param_count", "tgnn_param_name", "tgnn_forward_workspace_bytes", "tgnn_forward",
-    "tgnn_forward_profiled", "tgnn_forward_sharded_workspace_bytes", "tgnn_forward_sharded",
+    "tgnn_forward_profiled", "tgnn_forward_train", "tgnn_forward_sharded_workspace_bytes", "tgnn_forward_sharded",
     "tgnn_rows_gather", "tgnn_rows_scatter", "tgnn_unsupervised_loss_workspace_bytes", "tgnn_unsupervised_loss",
     "tgnn_sublayout_workspace_bytes", "tgnn_sublayout_compact",
     "tgnn_transpose", "tgnn_swap_leading", "tgnn_gin_aggregate", "tgnn_sigmoid_bwd", "tgnn_add_into", "tgnn_reduce_workspace_bytes", "tgnn_colsum",

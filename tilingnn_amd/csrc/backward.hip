@@ -68,14 +68,15 @@ __global__ void transpose_multi_kernel(TransposeJobs jobs) {
     }
 }
 
-// out[b][a][c] = in[a][b][c]
-__global__ void swap_leading_kernel(const float *__restrict__ in, int da, int db, int dc, float *__restrict__ out) {
+// out[b][a][c] = in[a][b][c], the rows of `out` out_da (>= da) entries long
+__global__ void swap_leading_kernel(const float *__restrict__ in, int da, int db, int dc, float *__restrict__ out,
+                                    int out_da) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < (int64_t)da * db * dc) {
         const int c = (int)(i % dc);
         const int b = (int)((i / dc) % db);
         const int a = (int)(i / ((int64_t)dc * db));
-        out[((int64_t)b * da + a) * dc + c] = in[i];
+        out[((int64_t)b * out_da + a) * dc + c] = in[i];
     }
 }
 
@@ -552,13 +553,14 @@ int tgnn_transpose(const float *w, int32_t rows, int32_t cols, float *out, tgnn_
     return TGNN_OK;
 }
 
-int tgnn_swap_leading(const float *in, int32_t da, int32_t db, int32_t dc, float *out, tgnn_stream_t stream) {
-    TGNN_CHECK_ARG(da >= 0 && db >= 0 && dc >= 0, "shape");
+int tgnn_swap_leading(const float *in, int32_t da, int32_t db, int32_t dc, float *out, int32_t out_da,
+                      tgnn_stream_t stream) {
+    TGNN_CHECK_ARG(da >= 0 && db >= 0 && dc >= 0 && out_da >= da, "shape");
     const int64_t total = (int64_t)da * db * dc;
     if (total == 0) return TGNN_OK;
     TGNN_CHECK_ARG(in && out, "null pointer");
     hipLaunchKernelGGL(swap_leading_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, da,
-                       db, dc, out);
+                       db, dc, out, out_da);
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
 }

@@ -210,7 +210,8 @@ extern "C" size_t tgnn_forward_sharded_workspace_bytes(const tgnn_model_dims *di
 static int forward_impl(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
                         const float *adj_edge_attr, const tgnn_graph *graph, int32_t update_running,
                         int32_t use_running_stats, float *probs, void *ws, size_t ws_bytes, tgnn_stream_t stream,
-                        tgnn_stream_t stream2, Prof &prof, const tgnn_shard *sh = nullptr) {
+                        tgnn_stream_t stream2, Prof &prof, const tgnn_shard *sh = nullptr,
+                        const tgnn_train_save *keep = nullptr) {
     TGNN_CHECK_ARG(dims_ok(dims), "model dims");
     TGNN_CHECK_ARG(params_host && graph && probs && x, "null pointer");
     const int64_t n = graph->n_nodes;
@@ -240,6 +241,22 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     if (!ws || w.bytes > ws_bytes) {
         set_error("tgnn_forward: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
         return TGNN_ERR_WORKSPACE;
+    }
+    if (keep) {
+        // training forward (tgnn_forward_train): what the backward reads lives in the caller's buffers instead of the
+        // rotating workspace ones -- the same kernels, the same schedule, only the destinations differ
+        TGNN_CHECK_ARG(!sh && !use_running_stats, "the training forward is single-device, train mode");
+        TGNN_CHECK_ARG(keep->skip && keep->wtab && keep->a1 && keep->a2 && keep->u && keep->stat1 && keep->stat2, "keep buffers");
+        for (int l = 0; l < 2; ++l) TGNN_CHECK_ARG(keep->init_a[l] && keep->init_stat[l], "keep buffers (init)");
+        for (int l = 0; l < 4; ++l) TGNN_CHECK_ARG(keep->fin_a[l] && keep->fin_stat[l], "keep buffers (final)");
+        w.mid = keep->skip;
+        w.wtab = keep->wtab;
+        w.t0 = keep->init_a[0];
+        w.a1 = keep->init_a[1];
+        w.stat_i[0] = keep->init_stat[0];
+        w.stat_i[1] = keep->init_stat[1];
+        w.f1 = keep->fin_a[0]; w.f2 = keep->fin_a[1]; w.f3 = keep->fin_a[2]; w.f4 = keep->fin_a[3];
+        for (int l = 0; l < 4; ++l) w.stat_f[l] = keep->fin_stat[l];
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     // Two-chain schedule: the collision branch is a chain of its own -- CollConv_i reads only CollConv_{i-1}
@@ -395,6 +412,13 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     }
     for (int i = 0; i < D; ++i) {
         const int b = P.layer(i);
+        if (keep) {                                          // this layer's own buffers (kernels already queued keep theirs)
+            w.a1 = keep->a1 + (size_t)i * n * c;
+            w.a2[i & 1] = keep->a2 + (size_t)i * n * c;
+            w.t0 = keep->u + (size_t)i * n * c;
+            w.stat1 = keep->stat1 + (size_t)i * 4 * c;
+            w.stat2[i & 1] = keep->stat2 + (size_t)i * 4 * c;
+        }
         const float *h1 = w.mid + (size_t)i * nr * c;
         if (s2) {
             // ---- collision chain, layer i, on the side stream: a2[i & 1] / stat2[i & 1] were last read by merge_{i-2}
@@ -510,6 +534,15 @@ extern "C" int tgnn_forward(const tgnn_model_dims *dims, const void *const *para
     Prof prof;
     return forward_impl(dims, params_host, x, adj_edge_attr, graph, update_running, use_running_stats, probs, ws,
                         ws_bytes, stream, stream2, prof);
+}
+
+extern "C" int tgnn_forward_train(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
+                                  const float *adj_edge_attr, const tgnn_graph *graph, const tgnn_train_save *keep,
+                                  float *probs, void *ws, size_t ws_bytes, tgnn_stream_t stream, tgnn_stream_t stream2) {
+    TGNN_CHECK_ARG(keep, "null keep struct");
+    Prof prof;
+    return forward_impl(dims, params_host, x, adj_edge_attr, graph, 1, 0, probs, ws, ws_bytes, stream, stream2, prof, nullptr,
+                        keep);
 }
 
 extern "C" int tgnn_forward_sharded(const tgnn_model_dims *dims, const void *const *params_host, const float *x,

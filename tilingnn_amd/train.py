@@ -4,9 +4,9 @@ itself, scheduled kernel by kernel over the C ABI.
 Reference: `Trainer.train` (/root/reference/solver/ml_solver/trainer.py:68-84):
     probs = network(x, adj_e_index, adj_e_features, col_e_idx); loss = Losses.calculate_unsupervised_loss(probs, ...);
     loss.backward(); optimizer.step()
-torch.autograd records the graph there.  Here the network is ONE autograd node (`TrainStep`): its forward runs the
-per-op kernels of the inference path (ops.py) and keeps the pre-BatchNorm activations, the BatchNorm records and the
-GIN aggregates; its backward walks the layers in reverse with the adjoint kernels of csrc/backward.hip.  Nothing is
+torch.autograd records the graph there.  Here the network is ONE autograd node (`TrainStep`): its forward is the fused
+inference forward with the pre-BatchNorm activations, the BatchNorm records and the GIN aggregates kept
+(`tgnn_forward_train`); its backward walks the layers in reverse with the adjoint kernels of csrc/backward.hip.  Nothing is
 differentiated by torch: `Function.backward` hands the finished parameter gradients to autograd, which only stores
 them in `.grad` for the caller's optimizer (the reference passes one in, network_train.py).
 
@@ -192,73 +192,49 @@ class _Saved:
     pass
 
 
-def _bn_stat(parts, n_parts, n, bn):
-    return ops.bn_finalize(parts, n_parts, n, bn, update_running=True, mode=0)
-
-
-def _mlp_forward(layers, x, n, parts, slot_major=False):
-    """Linear_trans stack with BatchNorm (layers/util.py:15-37): -> ([pre-BN activations], [BatchNorm records])."""
-    acts, stats, stat = [], [], None
-    for k, layer in enumerate(layers):
-        a, n_parts = ops.dense_act(x, layer.linear.weight, layer.linear.bias, ops.act_code(layer.activation),
-                                   in_stat=stat, partials=parts, slot_major=slot_major and k == 0)
-        stat = _bn_stat(parts, n_parts, n, layer.batch_norm)
-        acts.append(a)
-        stats.append(stat)
-        x = a
-    return acts, stats
-
-
 def forward_train(net, x: Tensor, adj_e_index: Tensor, adj_e_features: Tensor, col_e_idx: Tensor):
+    """The forward of the training step: `tgnn_forward_train` = the fused inference forward (same kernels, same two-stream
+    schedule) writing what the backward reads into buffers that outlive it.  -> (probs, saved)."""
     c, depth = net.network_width, net.network_depth
     if c != 32:
         raise NotImplementedError("the training path is built for network_width = 32 (inputs/config.py:38)")
     n = int(x.shape[0])
     if n < 2:
         raise ValueError("Expected more than 1 value per channel when training")
-    dev = x.device
+    table, dev = net._param_table()
     xf, ea = ops._f32c(x, "x"), ops._f32c(adj_e_features, "adj_e_features")
     tg = _train_graph(net, n, adj_e_index, adj_e_features, col_e_idx)
     g = tg.g
-    if g.n_types > 63:
+    T = g.n_types
+    if T > 63:
         raise NotImplementedError("the training path holds at most 63 distinct edge-attribute rows")
     sv = _Saved()
     sv.tg, sv.x, sv.ea, sv.n = tg, xf, ea, n
-    parts = ops.new_partials(256, dev)
-    skip = torch.empty(depth + 1, n, c, dtype=torch.float32, device=dev)
-
-    init_layers = list(net.init_node_feature_trans.mlp)
-    sv.init_a, sv.init_stat = _mlp_forward(init_layers, xf, n, parts)
-    check(lib.tgnn_bn_apply(ptr(sv.init_a[-1]), c, ptr(sv.init_stat[-1]), n, c, ptr(skip[0]), c, _s(xf)))
-
-    sv.a1, sv.stat1, sv.a2, sv.stat2, sv.u, sv.y2, sv.wtab = [], [], [], [], [], [], []
-    h2 = skip[0]
-    for i in range(depth):
-        l1, l2 = net.brch_1_graph_conv_layers[i], net.brch_2_coll_conv_layers[i]
-        wtab = torch.empty(g.n_types + 1, c, c, dtype=torch.float32, device=dev)     # slot T: the root matrix (backward)
-        if g.n_types:
-            wtab[:g.n_types].copy_(ops.edge_weight_table(ea, g, *l1.nnConv._edge_mlp_params(), c))
-        wtab[g.n_types].copy_(l1.nnConv.root.detach())
-        a1, np1 = ops.nnconv_mean(skip[i], g, wtab[:g.n_types], l1.nnConv.root, l1.nnConv.bias, act=ACT_LEAKY_RELU,
-                                  partials=parts)
-        stat1 = _bn_stat(parts, np1, n, l1.batch_norm)
-        gp = l2.ginConv._mlp_params()
-        a2 = torch.empty(n, c, dtype=torch.float32, device=dev)
-        u = torch.empty(n, c, dtype=torch.float32, device=dev)
-        np2 = C.c_int32(0)
-        check(lib.tgnn_gin_fwd(ptr(h2), c, None, ptr(g.col_rowptr), ptr(g.col_src), ptr(l2.ginConv.eps),
-                               *[ptr(p) for p in gp], n, c, ACT_LEAKY_RELU, ptr(a2), ptr(u), ptr(parts), C.byref(np2),
-                               _s(xf)))
-        stat2 = _bn_stat(parts, np2.value, n, l2.batch_norm)
-        _, h2 = ops.merge(a1, stat1, a2, stat2, skip[i - 2] if i >= 2 else None, out=skip[i + 1], want_h2=True)
-        sv.a1.append(a1); sv.stat1.append(stat1); sv.a2.append(a2); sv.stat2.append(stat2)
-        sv.u.append(u); sv.y2.append(h2); sv.wtab.append(wtab)
-
-    final_layers = list(net.final_mlp[0].mlp)
-    sv.fin_a, sv.fin_stat = _mlp_forward(final_layers, skip, n, parts, slot_major=True)
-    last = net.final_mlp[1]
-    probs, _ = ops.dense_act(sv.fin_a[-1], last.linear.weight, last.linear.bias, ACT_SIGMOID, in_stat=sv.fin_stat[-1])
-    sv.skip, sv.probs = skip, probs
+    f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+    sv.init_a, sv.init_stat = [f(n, c), f(n, c)], [f(4, c), f(4, c)]
+    a1, a2, u, st1, st2 = f(depth, n, c), f(depth, n, c), f(depth, n, c), f(depth, 4, c), f(depth, 4, c)
+    fin_dims = [int(l.linear.out_features) for l in net.final_mlp[0].mlp]
+    sv.fin_a, sv.fin_stat = [f(n, d) for d in fin_dims], [f(4, d) for d in fin_dims]
+    sv.skip = f(depth + 1, n, c)
+    wtab = f(depth, max(T, 1), c, c)
+    probs = f(n, net.output_dim)
+    keep = _lib.TrainSave()
+    for k in range(2):
+        keep.init_a[k], keep.init_stat[k] = sv.init_a[k].data_ptr(), sv.init_stat[k].data_ptr()
+    for k in range(4):
+        keep.fin_a[k], keep.fin_stat[k] = sv.fin_a[k].data_ptr(), sv.fin_stat[k].data_ptr()
+    keep.a1, keep.a2, keep.u, keep.stat1, keep.stat2 = a1.data_ptr(), a2.data_ptr(), u.data_ptr(), st1.data_ptr(), st2.data_ptr()
+    keep.skip, keep.wtab = sv.skip.data_ptr(), wtab.data_ptr()
+    dims = net._dims()
+    ws_bytes = lib.tgnn_forward_workspace_bytes(C.byref(dims), n, T)
+    ws = _Scratch.get("fwd", ws_bytes, dev)
+    gs = g.c_struct()
+    check(lib.tgnn_forward_train(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(gs), C.byref(keep), ptr(probs), ptr(ws),
+                                 ws_bytes, _lib.current_stream(dev), _lib.side_stream(dev)))
+    sv.a1, sv.a2, sv.u = list(a1), list(a2), list(u)
+    sv.stat1, sv.stat2 = list(st1), list(st2)
+    sv.wtab = [wtab[i, :T] for i in range(depth)]
+    sv.probs = probs
     return probs, sv
 
 
@@ -303,9 +279,9 @@ def sigmoid_mlp_backward(weights, x: Tensor, t3: Tensor, d_out: Tensor, grads: D
 
 def nnconv_backward(conv, prefix: str, tg: TrainGraph, wtab: Tensor, h: Tensor, dz: Tensor, g_scaled: Tensor,
                     edge_attr: Tensor, grads: Dict[str, Tensor]) -> Tensor:
-    """Adjoint of NNConv mean (edge_conv.py:25).  wtab [T + 1, C, C]: the T edge-type matrices and, in slot T, the root
-    matrix; h: the layer's input; dz: gradient at the conv's output; g_scaled = dz / deg.  Fills the gradients of root,
-    bias and the edge MLP under `prefix`; returns the gradient at h."""
+    """Adjoint of NNConv mean (edge_conv.py:25).  wtab [T, C, C]: the edge-type matrices the forward used; h: the layer's
+    input; dz: gradient at the conv's output; g_scaled = dz / deg.  Fills the gradients of root, bias and the edge MLP
+    under `prefix`; returns the gradient at h."""
     g = tg.g
     n, T, c = g.n_nodes, g.n_types, 32
     dev = h.device
@@ -314,12 +290,13 @@ def nnconv_backward(conv, prefix: str, tg: TrainGraph, wtab: Tensor, h: Tensor, 
     #   input gradient:   dh[j]  = sum_t S'[j][t] W_t^T + dz[j] root^T              = S' . [W_t^T; root^T]   (dense)
     #   weight gradients: dW_t   = sum_e h[src_e]^T g[dst_e] = sum_j h[j]^T S'[j][t];  d root = h^T dz       = h^T . S'
     s_bwd = type_sum(g_scaled, g_scaled, tg.deg, tg.adjT_rowptr, tg.adjT_src, tg.adjT_type, n, T)   # [N, (T+1) C]
-    wd = torch.empty(c, (T + 1) * c, dtype=torch.float32, device=dev)                             # [in][t][out]
-    check(lib.tgnn_swap_leading(ptr(wtab), T + 1, c, c, ptr(wd), _s(wd)))
+    wd = torch.empty(c, (T + 1) * c, dtype=torch.float32, device=dev)                             # [in][t][out]; t = T: root
+    check(lib.tgnn_swap_leading(ptr(wtab), T, c, c, ptr(wd), T + 1, _s(wd)))
+    check(lib.tgnn_swap_leading(ptr(conv.root), 1, c, c, C.c_void_p(wd.data_ptr() + 4 * T * c), T + 1, _s(wd)))
     dh = ops.dense_act(s_bwd, wd, _zeros(c, dev), ACT_NONE)[0]
     dw_in_major = wgrad(h, s_bwd)                                                                 # [in][t][out]
     dwcat = torch.empty((T + 1) * c, c, dtype=torch.float32, device=dev)                          # [t][in][out]
-    check(lib.tgnn_swap_leading(ptr(dw_in_major), c, T + 1, c, ptr(dwcat), _s(dwcat)))
+    check(lib.tgnn_swap_leading(ptr(dw_in_major), c, T + 1, c, ptr(dwcat), c, _s(dwcat)))
     grads[prefix + ".nnConv.root"] = dwcat[T * c:]
     grads[prefix + ".nnConv.bias"] = colsum(dz)
     # the edge MLP behind the T weight matrices (edge_conv.py:17-18), on the T distinct attribute rows
@@ -329,7 +306,7 @@ def nnconv_backward(conv, prefix: str, tg: TrainGraph, wtab: Tensor, h: Tensor, 
         fe = int(edge_attr.shape[1])
         rows = torch.empty(T, fe, dtype=torch.float32, device=dev)
         check(lib.tgnn_rows_gather(ptr(edge_attr), fe, ptr(g.type_rep_edge), T, fe, ptr(rows), fe, _s(rows)))
-        sigmoid_mlp_backward(ew, rows, wtab[:T].reshape(T, c * c), dwcat[:T * c].reshape(T, c * c), grads, names, False)
+        sigmoid_mlp_backward(ew, rows, wtab.reshape(T, c * c), dwcat[:T * c].reshape(T, c * c), grads, names, False)
     else:
         for k in range(3):
             grads[names[k] + ".linear.weight"] = torch.zeros_like(ew[2 * k])
