@@ -268,6 +268,22 @@ int tgnn_forward_train(const tgnn_model_dims *dims, const void *const *params_ho
                        const float *adj_edge_attr, const tgnn_graph *graph, const tgnn_train_save *keep, float *probs,
                        void *ws, size_t ws_bytes, tgnn_stream_t stream, tgnn_stream_t stream2);
 
+/* The backward of the training step (loss.backward() of trainer.py:79) as ONE call: the schedule of tilingnn_amd/train.py
+ * (backward_train: final MLP, D x (merge / BatchNorm / NNConv / GIN adjoints), init MLP) enqueued from the library.
+ * tgraph: what only the backward reads; keep: the buffers tgnn_forward_train filled; grads_host: one device pointer per
+ * entry of params_host (same indexing, tgnn_param_name); entries of buffers (running statistics, GIN's eps) are ignored.
+ * Width 32, at most 63 edge types. */
+typedef struct tgnn_train_graph {
+    const int32_t *adjT_rowptr, *adjT_src, *adjT_type; /* CSR of the TRANSPOSED adjacency edges + the type of every slot */
+    const int32_t *colT_rowptr, *colT_src;             /* CSR of the transposed collision edges, self loops dropped */
+    const float *deg, *inv_deg;                        /* max(in-degree, 1) of the adjacency graph, and 1 / it */
+} tgnn_train_graph;
+size_t tgnn_backward_workspace_bytes(const tgnn_model_dims *dims, int64_t n_nodes, int32_t n_types);
+int tgnn_backward(const tgnn_model_dims *dims, const void *const *params_host, void *const *grads_host, const float *x,
+                  const float *adj_edge_attr, const tgnn_graph *graph, const tgnn_train_graph *tgraph,
+                  const tgnn_train_save *keep, const float *probs, const float *dprobs, void *ws, size_t ws_bytes,
+                  tgnn_stream_t stream);
+
 /* ---- the same forward for ONE SHARD of a node-range partition (one process per GPU) -------------------------
  * This device owns rows [0, n_own) of a layout whose buffers carry n_rows - n_own halo rows of other shards behind
  * them: `graph` is built with n_nodes = n_own destinations and sources in [0, n_rows) (tgnn_csr_build's

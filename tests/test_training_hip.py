@@ -390,3 +390,20 @@ def test_training_step_with_many_edge_types():
     for k, e in errs.items():
         assert e <= 4 * max(err32[k], floor) + 1e-5, (k, e, err32[k], floor)
     assert float(np.median(list(errs.values()))) <= 2 * floor + 1e-6
+
+
+@pytest.mark.parametrize("case,fe,depth,seed", [("small", 15, 3, 5), ("tiny", 6, 3, 3), ("laby", 15, 20, 0)])
+def test_library_backward_equals_the_spelled_out_schedule(case, fe, depth, seed):
+    """tgnn_backward (csrc/train.hip) enqueues the kernels backward_train calls one by one: same inputs, same kernels, same
+    order -- the same bits in every gradient."""
+    from tilingnn_amd import train
+    g = {"small": _small, "tiny": _tiny, "laby": load_labyrinth_graph}[case]()
+    net, _ = _net(fe, depth, seed)
+    x, adj, attr, col, _ = graph_tensors(g, torch.float32, DEV)
+    probs, sv = train.forward_train(net, x, adj, attr, col)
+    dprobs = _rng(1)(int(x.shape[0]), 1).to(DEV) * 1e-2
+    a = train.backward_library(net, sv, dprobs)
+    b = train.backward_train(net, sv, dprobs)
+    assert sorted(a) == sorted(b) == sorted(k for k, _ in net.named_parameters())
+    for k in a:
+        assert torch.equal(a[k].reshape(-1), b[k].reshape(-1)), k

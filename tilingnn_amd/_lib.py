@@ -42,6 +42,12 @@ class TrainSave(C.Structure):
                 ("fin_stat", C.c_void_p * 4), ("skip", C.c_void_p), ("wtab", C.c_void_p)]
 
 
+class TrainGraphDesc(C.Structure):
+    """tgnn_train_graph"""
+    _fields_ = [("adjT_rowptr", C.c_void_p), ("adjT_src", C.c_void_p), ("adjT_type", C.c_void_p),
+                ("colT_rowptr", C.c_void_p), ("colT_src", C.c_void_p), ("deg", C.c_void_p), ("inv_deg", C.c_void_p)]
+
+
 ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 ALLTOALL_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p)
 
@@ -102,6 +108,9 @@ def _load() -> C.CDLL:
                                             i32, p, p, sz, p, C.POINTER(C.c_float), pi32]),
         "tgnn_transpose": (C.c_int, [p, i32, i32, p, p]),
         "tgnn_swap_leading": (C.c_int, [p, i32, i32, i32, p, i32, p]),
+        "tgnn_backward_workspace_bytes": (sz, [C.POINTER(ModelDims), i64, i32]),
+        "tgnn_backward": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), p, p,
+                                    C.POINTER(Graph), C.POINTER(TrainGraphDesc), C.POINTER(TrainSave), p, p, p, sz, p]),
         "tgnn_forward_train": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), p, p, C.POINTER(Graph),
                                          C.POINTER(TrainSave), p, p, sz, p, p]),
         "tgnn_gin_aggregate": (C.c_int, [p, i64, p, p, p, p, i64, i32, p, p]),
@@ -138,7 +147,7 @@ EXPORTED_SYMBOLS = (
     "tgnn_nnconv_mean_fwd", "tgnn_nnconv_cols_max_columns", "tgnn_nnconv_cols_workspace_bytes",
     "tgnn_nnconv_cols_build", "tgnn_nnconv_cols_max_types", "tgnn_nnconv_weight_image_floats", "tgnn_nnconv_mean_cols_fwd", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_dense_act_slots_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
     "tgnn_merge_fwd", "tgnn_param_count", "tgnn_param_name", "tgnn_forward_workspace_bytes", "tgnn_forward",
-    "tgnn_forward_profiled", "tgnn_forward_train", "tgnn_forward_sharded_workspace_bytes", "tgnn_forward_sharded",
+    "tgnn_forward_profiled", "tgnn_forward_train", "tgnn_backward_workspace_bytes", "tgnn_backward", "tgnn_forward_sharded_workspace_bytes", "tgnn_forward_sharded",
     "tgnn_rows_gather", "tgnn_rows_scatter", "tgnn_unsupervised_loss_workspace_bytes", "tgnn_unsupervised_loss",
     "tgnn_sublayout_workspace_bytes", "tgnn_sublayout_compact",
     "tgnn_transpose", "tgnn_swap_leading", "tgnn_gin_aggregate", "tgnn_sigmoid_bwd", "tgnn_add_into", "tgnn_reduce_workspace_bytes", "tgnn_colsum",

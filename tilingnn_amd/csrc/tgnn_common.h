@@ -110,6 +110,28 @@ static inline int producer_blocks(int64_t n_rows, int rows_per_block) {
     return static_cast<int>(nb);
 }
 
+// ---- parameter table of tgnn_forward / tgnn_backward: indices into params_host (order = tgnn_param_name) ---------------
+constexpr int kInitStride = 7, kLayerStride = 25, kFinalStride = 7;
+struct BnPtrs {
+    const float *gamma, *beta;
+    float *rm, *rv;
+    int64_t *nbt;
+};
+struct Params {
+    const void *const *p;
+    int depth;
+    const float *f(int i) const { return static_cast<const float *>(p[i]); }
+    BnPtrs bn(int i) const {
+        return BnPtrs{f(i), f(i + 1), const_cast<float *>(f(i + 2)), const_cast<float *>(f(i + 3)),
+                      const_cast<int64_t *>(static_cast<const int64_t *>(p[i + 4]))};
+    }
+    int init(int l) const { return l * kInitStride; }                // w, b, bn x5
+    int layer(int i) const { return 2 * kInitStride + i * kLayerStride; }
+    // layer block: 0-5 edge mlp (w1 b1 w2 b2 w3 b3), 6 root, 7 bias, 8-12 bn1, 13 eps, 14-19 gin mlp, 20-24 bn2
+    int fin(int l) const { return 2 * kInitStride + depth * kLayerStride + l * kFinalStride; }
+    int last() const { return fin(4); }
+};
+
 // ---- internal launchers shared between translation units -------------------------------
 struct BnJob {
     const double *partials;

@@ -26,6 +26,7 @@ Width 32 only (the reference's network_width, inputs/config.py:38); other widths
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -231,6 +232,7 @@ def forward_train(net, x: Tensor, adj_e_index: Tensor, adj_e_features: Tensor, c
     gs = g.c_struct()
     check(lib.tgnn_forward_train(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(gs), C.byref(keep), ptr(probs), ptr(ws),
                                  ws_bytes, _lib.current_stream(dev), _lib.side_stream(dev)))
+    sv.keep, sv._keep_alive = keep, (a1, a2, u, st1, st2, wtab)
     sv.a1, sv.a2, sv.u = list(a1), list(a2), list(u)
     sv.stat1, sv.stat2 = list(st1), list(st2)
     sv.wtab = [wtab[i, :T] for i in range(depth)]
@@ -375,6 +377,50 @@ def backward_train(net, sv, dprobs: Tensor) -> Dict[str, Tensor]:
     return grads
 
 
+# The backward schedule runs inside the library (csrc/train.hip: tgnn_backward) by default; backward_train above is the
+# same schedule spelled out call by call -- kept as the readable statement and as the checker (tests compare the two bit
+# for bit).  TGNN_PY_BACKWARD=1 or train.USE_LIBRARY_BACKWARD = False selects it.
+USE_LIBRARY_BACKWARD = os.environ.get("TGNN_PY_BACKWARD", "0") != "1"
+
+
+def backward_library(net, sv, dprobs: Tensor) -> Dict[str, Tensor]:
+    """One call: tgnn_backward.  -> {parameter name: gradient}."""
+    tg = sv.tg
+    g = tg.g
+    dev = sv.x.device
+    table, _ = net._param_table()
+    dims = net._dims()
+    layout = net.__dict__.get("_tgnn_grad_layout")
+    if layout is None or layout[0] != id(table):
+        # once per parameter table: which table entries are parameters, and where each sits in ONE flat gradient buffer
+        names = _lib.param_names(dims)
+        params = dict(net.named_parameters())
+        entries, off = [], 0
+        for k, name in enumerate(names):
+            p_ = params.get(name)
+            if p_ is not None:
+                entries.append((k, name, off, p_.numel(), tuple(p_.shape)))
+                off += (p_.numel() + 63) // 64 * 64                  # 256-byte aligned slices
+        layout = net.__dict__["_tgnn_grad_layout"] = (id(table), len(names), entries, off)
+    _, n_names, entries, total = layout
+    flat = torch.empty(total, dtype=torch.float32, device=dev)
+    base = flat.data_ptr()
+    grads, gtable = {}, (C.c_void_p * n_names)()
+    for k, name, off, numel, shape in entries:
+        grads[name] = flat[off:off + numel].view(shape)
+        gtable[k] = base + 4 * off
+    keep = sv.keep
+    tgd = _lib.TrainGraphDesc(tg.adjT_rowptr.data_ptr(), tg.adjT_src.data_ptr(), tg.adjT_type.data_ptr(),
+                              tg.colT_rowptr.data_ptr(), tg.colT_src.data_ptr(), tg.deg.data_ptr(), tg.inv_deg.data_ptr())
+    nb = lib.tgnn_backward_workspace_bytes(C.byref(dims), sv.n, g.n_types)
+    ws = _Scratch.get("bwd", nb, dev)
+    gs = g.c_struct()
+    dp = ops._f32c(dprobs, "grad of probs")
+    check(lib.tgnn_backward(C.byref(dims), table, gtable, ptr(sv.x), ptr(sv.ea), C.byref(gs), C.byref(tgd), C.byref(keep),
+                            ptr(sv.probs), ptr(dp), ptr(ws), nb, _lib.current_stream(dev)))
+    return grads
+
+
 class TrainStep(torch.autograd.Function):
     """probs = TrainStep.apply(net, x, adj_e_index, adj_e_features, col_e_idx, *net.parameters())"""
 
@@ -388,7 +434,8 @@ class TrainStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dprobs):
         with _lib.pinned_stream(dprobs.device):
-            grads = backward_train(ctx.net, ctx.sv, dprobs.contiguous())
+            run = backward_library if USE_LIBRARY_BACKWARD else backward_train
+            grads = run(ctx.net, ctx.sv, dprobs.contiguous())
         ctx.sv = None
         out = []
         for name, p in ctx.net.named_parameters():
