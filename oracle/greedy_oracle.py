@@ -74,3 +74,23 @@ def greedy_solve(predict, x, adj, adj_attr, col, col_attr, uniform=np.random.uni
                             unlabelled[v] = False
         round_cnt += 1
     return selection, np.asarray(order, dtype=np.int64), np.asarray(sizes, dtype=np.int64)
+
+
+def solution_score(predict, x, adj, adj_attr, perimeters, max_area, max_align_length, contour_area,
+                   weights=(1.0, 0.02)):
+    """Losses.solution_score, /root/reference/solver/ml_solver/losses.py:120-148, in the reference's float32:
+    AVG_AREA_WEIGHT * predict . (x[:, -1] max_area) / contour_area
+      + ALIGN_LENGTH_WEIGHT * ((p_i p_j) . (len max_align_length)) / sum of the selected tiles' perimeters.
+    `perimeters` [N] float64 (Tile.get_perimeter of every layout node); weights = (AVG_AREA_WEIGHT, ALIGN_LENGTH_WEIGHT).
+    PINNED by tests/golden/ref_scores.npz (tests/golden/generate_score_golden.py runs the reference's own function)."""
+    p = np.asarray(predict, dtype=np.float32)
+    x = np.asarray(x, dtype=np.float32)
+    filled_area = np.dot(p, x[:, -1] * np.float32(max_area)) / contour_area                  # :126
+    adj = np.asarray(adj)
+    if adj.size:
+        lengths = np.asarray(adj_attr, dtype=np.float32)[:, 1] * np.float32(max_align_length)   # :131
+        align = np.dot(p[adj[0]] * p[adj[1]], lengths)                                      # :132-141
+    else:
+        align = 0.0
+    all_edge_length = sum(float(perimeters[i]) for i in range(p.shape[0]) if p[i] == 1)      # :143-144
+    return float(weights[0] * filled_area + weights[1] * (align / all_edge_length))         # :148

@@ -496,13 +496,14 @@ __global__ __launch_bounds__(256) void loss_bwd_edges_kernel(const float *__rest
                                                              const int64_t *__restrict__ adj, int64_t ea,
                                                              const float *__restrict__ len, int64_t ldl,
                                                              const double *__restrict__ terms, float wc, float wl,
-                                                             float wa, double *__restrict__ acc) {
+                                                             float wa, double *__restrict__ acc, int64_t n) {
     const LossCoef k = loss_factors(terms, wc, wl, wa);
     const double coef_c = ec > 0 ? -(double)wc * k.a * k.c / (double)ec : 0.0;                   // d loss / d (sum log(1 - pp))
     const double coef_l = ea > 0 ? -(double)wl * k.a * k.b / ((double)ea * 2.302585092994046) : 0.0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int64_t e = t0; e < ec; e += stride) {
         const int64_t i = col[e], j = col[ec + e];
+        if (i < 0 || i >= n || j < 0 || j >= n) continue;       // (the forward reports these: NaN loss -> IndexError)
         const float pi = p[i * ldp], pj = p[j * ldp];
         const float pp = pi * pj;
         if (pp >= kLossEpsB && pp <= 1.0f - kLossEpsB) {         // torch.clamp passes the gradient inside [min, max]
@@ -513,6 +514,7 @@ __global__ __launch_bounds__(256) void loss_bwd_edges_kernel(const float *__rest
     }
     for (int64_t e = t0; e < ea; e += stride) {
         const int64_t i = adj[e], j = adj[ea + e];
+        if (i < 0 || i >= n || j < 0 || j >= n) continue;
         const float pi = p[i * ldp], pj = p[j * ldp];
         const float pp = pi * pj * len[e * ldl];
         if (pp >= kLossEpsB) {                                  // d log(pi pj len) / d pi = 1 / pi
@@ -860,7 +862,7 @@ int tgnn_unsupervised_loss_bwd(const float *probs, int64_t ld_probs, const float
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(loss_bwd_edges_kernel, dim3((unsigned)blocks), dim3(256), 0, s, probs, ld_probs, col_edge_index,
                            n_col_edges, adj_edge_index, n_adj_edges, adj_edge_len, ld_len, terms, collision_weight,
-                           align_length_weight, avg_area_weight, acc);
+                           align_length_weight, avg_area_weight, acc, n_nodes);
     }
     hipLaunchKernelGGL(loss_bwd_final_kernel, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, s, acc, area_ratio,
                        ld_area, n_nodes, terms, collision_weight, align_length_weight, avg_area_weight, grad_out, dprobs,

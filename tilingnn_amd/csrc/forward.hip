@@ -337,7 +337,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         launch_edge_weight_table_batched(adj_edge_attr, graph->type_rep_edge, T, fe, layers, D, c, w.wtab, sw);
         prof.end();
     }
-    const bool tiled = graph->nn_tile_col_ptr && c == 32 && (int64_t)nr * c * 4 < (int64_t(1) << 31);   // buffer-addressed gathers
+    const bool tiled = graph->nn_part_ptr && c == 32 && (int64_t)nr * c * 4 < (int64_t(1) << 31);   // buffer-addressed gathers
     if (tiled) {
         const float *roots[kMaxDepth];
         for (int i = 0; i < D; ++i) roots[i] = P.f(P.layer(i) + 6);
@@ -411,7 +411,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         // GraphConv (:62): NNConv mean + LeakyReLU; BN statistics emitted as partials
         prof.begin(2);
         if (tiled) {
-            TGNN_TRY(launch_nnconv_cols(h1, c, graph->nn_tile_col_ptr, graph->nn_col_meta, graph->nn_col_src,
+            TGNN_TRY(launch_nnconv_cols(h1, nr, graph->nn_part_ptr, graph->nn_col_meta, graph->nn_col_off,
                                         w.wimg + (size_t)i * (T + 1) * kWtType, T, P.f(b + 7), n, TGNN_ACT_LEAKY_RELU,
                                         w.a1, w.part1, &np1, s));
         } else {

@@ -182,8 +182,17 @@ void launch_edge_weight_table_batched(const float *edge_attr, const int *type_re
 // NNConv B-operand weight images [(T+1)][1152] for `depth` layers (roots[i] = layer i's root matrix); nnconv.hip
 void launch_nnconv_weight_image(const float *wtab_all, const float *const *roots, int n_types, int depth,
                                 float *wimg_all, hipStream_t s);
-int launch_nnconv_cols(const float *h, int64_t ldh, const int32_t *tile_col_ptr, const int32_t *col_meta,
-                       const int32_t *col_src, const float *wimg, int32_t n_types, const float *bias,
+// ---- column NNConv (nnconv_cols.hip; structure built in graph_prep.hip) ----------------------------------------------------
+// meta word of a column: type | flags
+constexpr int kColMetaFirst = 1 << 8, kColMetaLast = 1 << 9, kColMetaEnd = 1 << 10, kColMetaSkip = 1 << 11, kColMetaDeg = 1 << 12;
+constexpr int kColChunk = 8;               // a part (one wavefront's column stream) is a whole number of chunks
+constexpr int kColsReserveCus = 32;        // CUs the column kernel leaves to the collision chain of the two-stream forward
+struct ColsShape {
+    int waves, blocks;                     // wavefronts per block (8 / 16), blocks; parts = waves * blocks
+};
+ColsShape cols_shape(int64_t n_nodes, int n_types);
+int launch_nnconv_cols(const float *h, int64_t n_src_rows, const int32_t *part_ptr, const int32_t *col_meta,
+                       const int32_t *col_off, const float *wimg, int32_t n_types, const float *bias,
                        int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
                        hipStream_t s);
 // MFMA weight image of the column NNConv, per type: [plane 3 (hi, mid, lo)][M block 2][i 16][g 4] x 8 bf16 --

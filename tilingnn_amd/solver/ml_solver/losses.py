@@ -71,9 +71,74 @@ class Losses:
         # the reference asserts these signs (losses.py:100-102,108)
         assert (host_terms <= 0).all(), "loss terms must be non-positive"
         host = losses.cpu().numpy()
+        if np.isnan(host).any():                                # the kernel's report of an edge end outside [0, N)
+            raise IndexError(f"edge index out of range [0, {int(probs.shape[0])}) in collide_edge_index / adj_edges_index "
+                             "(torch.gather raises here in the reference, losses.py:70-73,85-88)")
         assert (host >= 1.0).all()
         min_index = np.argmin(host)
         return losses[int(min_index)].to(probs.dtype), np.asarray(min_index), host.astype(np.float32), terms
+
+
+    # to evaluate the quality of a collision-free solution
+    @staticmethod
+    def solution_score(predict, brick_layout, super_contour_area=None, device=None):
+        """losses.py:120-148, as `create_solution` (util/algorithms.py:210-220) calls it at the end of every greedy
+        solve:  AVG_AREA_WEIGHT * filled_area + ALIGN_LENGTH_WEIGHT * (aligned length / perimeter of the selected tiles).
+        The two dot products and the perimeter sum run on the GPU (`tgnn_solution_score_sums`, csrc/loss.hip).  The one
+        shapely number of the reference, `brick_layout.get_super_contour_poly().area` (a polygon union), is taken from
+        `super_contour_area`, else `brick_layout.super_contour_area`, else the layout's own `get_super_contour_poly()`
+        when it is the reference's class.  Perimeters come from the tiles' vertex rings (`Tile.get_perimeter`)."""
+        if device is None:
+            device = torch.device("cuda")
+        predict_h = np.asarray(predict, dtype=np.float64)
+        x, adj_edge_index, adj_edge_features, _, _ = brick_layout.get_data_as_torch_tensor(device)
+        n = int(x.shape[0])
+        if predict_h.shape != (n,):
+            raise ValueError(f"predict must have one entry per layout node ({n}), got {predict_h.shape}")
+        if super_contour_area is None:
+            super_contour_area = getattr(brick_layout, "super_contour_area", None)
+        if super_contour_area is None and hasattr(brick_layout, "get_super_contour_poly"):
+            super_contour_area = brick_layout.get_super_contour_poly().area
+        if super_contour_area is None:
+            raise ValueError("solution_score needs the area of the layout's super contour (a shapely polygon union in the "
+                             "reference, brick_layout.py:180-188): pass super_contour_area= or set "
+                             "brick_layout.super_contour_area")
+        cg = brick_layout.complete_graph
+        perims = getattr(brick_layout, "_tile_perimeters", None)
+        if perims is None or perims.shape[0] != n:
+            inv = brick_layout.inverse_index
+            perims = np.array([cg.tiles[inv[i]].get_perimeter() for i in range(n)], dtype=np.float64)
+            try:
+                brick_layout._tile_perimeters = perims
+            except AttributeError:
+                pass
+        p = torch.from_numpy(predict_h).float().to(device)                       # :122
+        xf = ops._f32c(x, "node_feature")
+        fx = int(xf.shape[1])
+        e_adj = int(adj_edge_features.shape[0]) if adj_edge_features.numel() > 0 else 0
+        adj = ops._check_edge_index(adj_edge_index, "adj_edge_index") if e_adj else None
+        attr = ops._f32c(adj_edge_features, "adj_edge_features") if e_adj else None
+        per = torch.from_numpy(perims).float().to(device)
+        sums = torch.empty(3, dtype=torch.float64, device=device)
+        ws_bytes = lib.tgnn_unsupervised_loss_workspace_bytes(1)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            check(lib.tgnn_solution_score_sums(ptr(p), C.c_void_p(xf.data_ptr() + 4 * (fx - 1)), fx, ptr(per), n,
+                                               ptr(adj) if e_adj else None, e_adj,
+                                               C.c_void_p(attr.data_ptr() + 4) if e_adj else None,
+                                               int(attr.shape[1]) if e_adj else 1, ptr(sums), ptr(ws), ws_bytes,
+                                               _lib.current_stream(device)))
+        s0, s1, s2 = sums.cpu().tolist()
+        if math.isnan(s0) or math.isnan(s1):
+            raise IndexError(f"edge index out of range [0, {n}) in the layout's align_edge_index")
+        filled_area = s0 * float(cg.max_area) / float(super_contour_area)                     # :126
+        assert -1e-7 <= filled_area <= 1 + 1e-7, filled_area                                  # :127
+        loss_align_length = s1 * float(cg.max_align_length) if e_adj else 0.0                 # :131-141
+        all_edge_length = s2                                                                  # :143-144
+        ratio = loss_align_length / all_edge_length                                           # (ZeroDivisionError on an empty selection, as in the reference)
+        assert -1e-7 < ratio < 1 + 1e-7, ratio                                                # :146
+        wc, wl, wa = loss_weights()
+        return float(wa * filled_area + wl * ratio)                                           # :148
 
 
 class _LossFn(torch.autograd.Function):

@@ -42,7 +42,7 @@ class LayoutArrays:
 
 
 class ML_Solver:
-    def __init__(self, debugger, device, complete_graph, network, num_prob_maps, greedy_solver=None):
+    def __init__(self, debugger, device, complete_graph, network, num_prob_maps, greedy_solver=None, score_fn=None):
         self.debugger = debugger
         self.device = device
         self.complete_graph = complete_graph
@@ -50,6 +50,7 @@ class ML_Solver:
         self.random_network = deepcopy(self.network)            # ml_solver.py:26
         self.num_prob_maps = num_prob_maps
         self._greedy_solver = greedy_solver
+        self._score_fn = score_fn                               # (selection, layout) -> float; default: Losses.solution_score
 
     @staticmethod
     def _no_edges(index) -> bool:
@@ -97,11 +98,11 @@ class ML_Solver:
 
     def solve(self, brick_layout):
         """ml_solver.py:64-73.  Default loop: tilingnn_amd.util.algorithms.solve_by_probablistic_greedy (layout resident
-        on the GPU, score None unless a score function is supplied); `greedy_solver=` swaps in another one, e.g. the
-        reference's own."""
+        on the GPU; score = Losses.solution_score when the layout carries its complete graph and super-contour area, or
+        `score_fn`, else None); `greedy_solver=` swaps in another one, e.g. the reference's own."""
         if self._greedy_solver is None:
             from ...util.algorithms import solve_by_probablistic_greedy
-            output_solution, score, predict_order = solve_by_probablistic_greedy(self, brick_layout)
+            output_solution, score, predict_order = solve_by_probablistic_greedy(self, brick_layout, score_fn=self._score_fn)
         else:
             output_solution, score, predict_order = self._greedy_solver(self, brick_layout)
         output_layout = deepcopy(brick_layout)

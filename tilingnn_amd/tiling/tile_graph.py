@@ -108,6 +108,17 @@ class Tile:
     def get_edge_num(self):                              # tile.py:33-35
         return self.tile_poly.exterior.shape[0] - 1
 
+    def get_edge(self, edge_idx):                        # tile.py:24-27
+        ring = self.tile_poly.exterior
+        return np.array(ring[edge_idx]), np.array(ring[edge_idx + 1])
+
+    def get_edge_length(self, edge_idx):                 # tile.py:29-31 over util/algo_util.py:72-74 (_distance)
+        p0, p1 = self.get_edge(edge_idx)
+        return np.sqrt(np.square(p0[0] - p1[0]) + np.square(p0[1] - p1[1]))
+
+    def get_perimeter(self):                             # tile.py:41-42
+        return np.sum([self.get_edge_length(i) for i in range(self.get_edge_num())])
+
 
 Polygon.__module__ = "shapely.geometry.polygon"          # pickles written from here name the reference's classes
 Tile.__module__ = "tiling.tile"
@@ -358,6 +369,13 @@ class GraphArrays:
             raise ValueError("adjacency feature rows are not one-hot past align_start_index (tile_graph.py:262-276)")
         return GraphArrays(ids, areas, np.ascontiguousarray(col), np.ascontiguousarray(adj), colf, adjf, adj_type,
                            float(g.max_area), float(g.max_align_length), int(g.tile_type_count))
+
+    @staticmethod
+    def perimeters(tiles) -> np.ndarray:
+        """`Tile.get_perimeter()` (tile.py:41-42) of every tile, float64 -- the same edge lengths added in the same order
+        (np.sum over a short list is a left-to-right pairwise-free sum for < 8 elements; longer rings go through np.sum
+        as in the reference)."""
+        return np.array([t.get_perimeter() for t in tiles], dtype=np.float64)
 
     def edge_rows(self, which: int, edges: np.ndarray) -> np.ndarray:
         """Rows (into colli_* if which == 0 else adj_*) of the given [2, E] complete-graph edges."""

@@ -11,9 +11,11 @@ first node a previous acceptance has killed), touches a handful of nodes per rou
 stream one `np.random.uniform()` per visited node (algorithms.py:51) -- the stream the reference consumes, so that a
 seeded run selects the same tiles.
 
-Same return values as the reference: (selection_predict, score, predict_order).  The reference scores through
-shapely polygon areas (`Losses.solution_score`, losses.py:120-148), which are outside this package: pass
-`score_fn(selection, origin_layout)` (e.g. the reference's) or get `None`.
+Same return values as the reference: (selection_predict, score, predict_order).  The score is
+`Losses.solution_score` (losses.py:120-148 -> tilingnn_amd/solver/ml_solver/losses.py, sums on the GPU) whenever the
+layout carries what it needs -- its complete graph (tile rings, max_area, max_align_length) and the area of its super
+contour (`layout.super_contour_area`, or the reference class's `get_super_contour_poly()`); a bare `DeviceLayout` has
+neither and scores `None` unless `score_fn(selection, origin_layout)` is given.
 """
 import ctypes as C
 
@@ -130,5 +132,16 @@ def solve_by_probablistic_greedy(ml_solver, origin_layout, score_fn=None, on_rou
         if killed:
             alive_dev[torch.from_numpy(np.asarray(killed, dtype=np.int64)).to(alive_dev.device)] = 0
         round_cnt += 1
-    score = score_fn(selection, origin_layout) if score_fn is not None else None
+    score = create_score(selection, origin_layout, score_fn, device)
     return selection, score, order
+
+
+def create_score(selection, origin_layout, score_fn=None, device=None):
+    """The score half of `create_solution` (algorithms.py:210-220)."""
+    if score_fn is not None:
+        return score_fn(selection, origin_layout)
+    has_area = getattr(origin_layout, "super_contour_area", None) is not None or hasattr(origin_layout, "get_super_contour_poly")
+    if getattr(origin_layout, "complete_graph", None) is None or not has_area:
+        return None
+    from ..solver.ml_solver.losses import Losses
+    return Losses.solution_score(selection, origin_layout, device=device)
