@@ -22,8 +22,10 @@
  *     sized by the matching *_workspace_bytes(); caller memory is never freed or resized;
  *   - return value: 0 = ok, <0 = error (TGNN_ERR_*); tgnn_last_error() returns a thread-local
  *     message for the last failing call on this thread;
- *   - functions are re-entrant; the only state kept between calls is idempotent per-device set-up (the one-time
- *     opt-in of a kernel to > 64 KB of LDS, the reusable events of the two-stream schedule per thread and device).
+ *   - functions are re-entrant; every call runs on the device its stream belongs to (the calling thread's current
+ *     device is switched for the duration of the call and restored); the only state kept between calls is idempotent
+ *     per-device set-up (the one-time opt-in of a kernel to > 64 KB of LDS, the reusable events of the two-stream
+ *     schedule per thread and device).
  */
 #ifndef TGNN_H
 #define TGNN_H
@@ -125,36 +127,29 @@ int tgnn_nnconv_mean_fwd(const float *h, int64_t ldh, const int32_t *rowptr, con
  * The sum over edges moves inside the product: sum_e h[src_e] . W_type(e) = sum_t (sum_{e of type t} h[src_e]) . W_t,
  * one dense [16 x 32(T+1)] x [32(T+1) x 32] product per 16 destination rows whose accumulator is the output tile.
  *
- * Column structure (adjacency set, once per layout): every 16 destination rows form a tile with a run of columns
- * sorted by edge type; column (t, r) holds, for each of the 16 rows, the BYTE OFFSET (source row x 128) of the row's
- * r-th in-edge of type t in original edge order, or 0x80000000 (none).  Then a degree column (the float bits of
- * -max(in-degree, 1) per row) and the root column (type T: the rows themselves; rows >= N: none), which closes the tile.
- * The stream of columns is cut into tgnn_nnconv_cols_parts(N, T) PARTS -- one per wavefront of the kernel's launch,
- * at tile boundaries, balanced by column count -- and every part is padded with skip columns to a multiple of 8:
- *   tile_col_ptr int32 [ceil(N/16)+1]   first column of every tile (last entry: length of the padded stream)
- *   part_ptr     int32 [n_parts+1][2]   {first tile, first column} of every part
- *   col_meta     int32 [n_cols]         type | first-of-type << 8 | last-of-type << 9 | end-of-tile << 10 | skip << 11
- *                                       | degree column << 12
- *   col_off      int32 [16*n_cols]      see above
- * n_cols <= tgnn_nnconv_cols_max_columns(N, E) (allocate col_meta / col_off for that many).  Sources may index halo
- * rows behind the N destination rows (n_src_nodes >= N); n_src_nodes * 128 < 2^31 (buffer addressing).  The structure
- * is tied to h rows of exactly 32 floats (ldh == 32). */
+ * Column structure (adjacency set, once per layout): every 16 destination rows form a tile with a list of
+ * columns sorted by edge type; column (t, r) holds, for each of the 16 rows, the source of the row's r-th
+ * in-edge of type t in original edge order, or -1.  The last column of a tile is the root column (type T):
+ *   tile_col_ptr int32 [ceil(N/16)+1]   column range of every tile
+ *   col_meta     int32 [n_cols]         type | first-of-type << 8 | last-of-type << 9 | end-of-tile << 10
+ *   col_src      int32 [16*n_cols]      source row per tile row, -1 = none; in a root column the float bits of
+ *                                       max(in-degree, 1), or -1 for rows >= N
+ * n_cols <= tgnn_nnconv_cols_max_columns(N, E) (allocate col_meta / col_src for that many: the kernel reads
+ * index words a few columns past the end); the exact count is tile_col_ptr[ceil(N/16)].
+ * Source rows must lie within 2 GB of h (buffer addressing): N_src * ldh * 4 < 2^31. */
 int64_t tgnn_nnconv_cols_max_columns(int64_t n_nodes, int64_t n_edges);
-int32_t tgnn_nnconv_cols_parts(int64_t n_nodes, int32_t n_types);
 size_t tgnn_nnconv_cols_workspace_bytes(int64_t n_nodes);
 int tgnn_nnconv_cols_build(const int32_t *rowptr, const int32_t *col_src, const int32_t *col_type,
-                           int64_t n_nodes, int64_t n_src_nodes, int32_t n_types, int32_t *tile_col_ptr,
-                           int32_t *part_ptr, int32_t *col_meta, int32_t *col_off, void *ws, size_t ws_bytes,
-                           tgnn_stream_t stream);
+                           int64_t n_nodes, int32_t n_types, int32_t *tile_col_ptr, int32_t *col_meta,
+                           int32_t *col_slot_src, void *ws, size_t ws_bytes, tgnn_stream_t stream);
 int32_t tgnn_nnconv_cols_max_types(void);
 /* wimg_scratch: tgnn_nnconv_weight_image_floats(T) floats of caller scratch (the [T][C][C] table and
- * the root matrix are re-laid out into MFMA operand order there before the main kernel runs).
- * n_src_rows: rows of h (>= n_nodes). */
+ * the root matrix are re-laid out into MFMA operand order there before the main kernel runs). */
 size_t tgnn_nnconv_weight_image_floats(int32_t n_types);
-int tgnn_nnconv_mean_cols_fwd(const float *h, int64_t ldh, int64_t n_src_rows, const int32_t *part_ptr,
-                              const int32_t *col_meta, const int32_t *col_off, const float *wtab, int32_t n_types,
-                              const float *root, const float *bias, int64_t n_nodes, int32_t c, int32_t act,
-                              float *out, float *wimg_scratch, double *bn_partial, int32_t *n_partials_host,
+int tgnn_nnconv_mean_cols_fwd(const float *h, int64_t ldh, const int32_t *tile_col_ptr, const int32_t *col_meta,
+                              const int32_t *col_src, const float *wtab, int32_t n_types, const float *root,
+                              const float *bias, int64_t n_nodes, int32_t c, int32_t act, float *out,
+                              float *wimg_scratch, double *bn_partial, int32_t *n_partials_host,
                               tgnn_stream_t stream);
 
 /* GINConv + optional LeakyReLU (coll_conv.py:25-27):
@@ -239,9 +234,9 @@ typedef struct tgnn_graph {
     const int32_t *col_rowptr;  /* [N+1] */
     const int32_t *col_src;     /* [Ec'] */
     /* NNConv type-column structure (all NULL => tgnn_forward uses the CSR kernel) */
-    const int32_t *nn_part_ptr;
+    const int32_t *nn_tile_col_ptr;
     const int32_t *nn_col_meta;
-    const int32_t *nn_col_off;
+    const int32_t *nn_col_src;
 } tgnn_graph;
 
 size_t tgnn_forward_workspace_bytes(const tgnn_model_dims *dims, int64_t n_nodes, int32_t n_types);

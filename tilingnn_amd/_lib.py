@@ -32,7 +32,7 @@ class Graph(C.Structure):
                 ("n_types", C.c_int32),
                 ("adj_rowptr", C.c_void_p), ("adj_src", C.c_void_p), ("adj_type", C.c_void_p),
                 ("type_rep_edge", C.c_void_p), ("col_rowptr", C.c_void_p), ("col_src", C.c_void_p),
-                ("nn_part_ptr", C.c_void_p), ("nn_col_meta", C.c_void_p), ("nn_col_off", C.c_void_p)]
+                ("nn_tile_col_ptr", C.c_void_p), ("nn_col_meta", C.c_void_p), ("nn_col_src", C.c_void_p)]
 
 
 class TrainSave(C.Structure):
@@ -82,11 +82,10 @@ def _load() -> C.CDLL:
         "tgnn_nnconv_mean_fwd": (C.c_int, [p, i64, p, p, p, p, i32, p, p, i64, i32, i32, p, p, pi32, p]),
         "tgnn_nnconv_cols_max_columns": (i64, [i64, i64]),
         "tgnn_nnconv_cols_workspace_bytes": (sz, [i64]),
-        "tgnn_nnconv_cols_parts": (i32, [i64, i32]),
-        "tgnn_nnconv_cols_build": (C.c_int, [p, p, p, i64, i64, i32, p, p, p, p, p, sz, p]),
+        "tgnn_nnconv_cols_build": (C.c_int, [p, p, p, i64, i32, p, p, p, p, sz, p]),
         "tgnn_nnconv_cols_max_types": (i32, []),
         "tgnn_nnconv_weight_image_floats": (sz, [i32]),
-        "tgnn_nnconv_mean_cols_fwd": (C.c_int, [p, i64, i64, p, p, p, p, i32, p, p, i64, i32, i32, p, p, p, pi32, p]),
+        "tgnn_nnconv_mean_cols_fwd": (C.c_int, [p, i64, p, p, p, p, i32, p, p, i64, i32, i32, p, p, p, pi32, p]),
         "tgnn_gin_fwd": (C.c_int, [p, i64, p, p, p, p, p, p, p, p, p, p, i64, i32, i32, p, p, p, pi32, p]),
         "tgnn_dense_act_fwd": (C.c_int, [p, i64, i64, p, p, p, i64, i32, i32, i32, p, i64, p, pi32, p]),
         "tgnn_dense_act_slots_fwd": (C.c_int, [p, i32, i64, p, p, p, i64, i32, i32, i32, p, i64, p, pi32, p]),
@@ -147,7 +146,7 @@ EXPORTED_SYMBOLS = (
     "tgnn_version", "tgnn_last_error", "tgnn_csr_workspace_bytes", "tgnn_csr_build",
     "tgnn_edge_dedup_workspace_bytes", "tgnn_edge_type_dedup", "tgnn_gather_i32", "tgnn_edge_weight_table",
     "tgnn_nnconv_mean_fwd", "tgnn_nnconv_cols_max_columns", "tgnn_nnconv_cols_workspace_bytes",
-    "tgnn_nnconv_cols_build", "tgnn_nnconv_cols_parts", "tgnn_nnconv_cols_max_types", "tgnn_nnconv_weight_image_floats", "tgnn_nnconv_mean_cols_fwd", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_dense_act_slots_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
+    "tgnn_nnconv_cols_build", "tgnn_nnconv_cols_max_types", "tgnn_nnconv_weight_image_floats", "tgnn_nnconv_mean_cols_fwd", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_dense_act_slots_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
     "tgnn_merge_fwd", "tgnn_param_count", "tgnn_param_name", "tgnn_forward_workspace_bytes", "tgnn_forward",
     "tgnn_forward_profiled", "tgnn_forward_train", "tgnn_backward_workspace_bytes", "tgnn_backward", "tgnn_forward_sharded_workspace_bytes", "tgnn_forward_sharded",
     "tgnn_rows_gather", "tgnn_rows_scatter", "tgnn_unsupervised_loss_workspace_bytes", "tgnn_unsupervised_loss", "tgnn_solution_score_sums",

@@ -545,6 +545,7 @@ using namespace tgnn;
 extern "C" {
 
 int tgnn_transpose(const float *w, int32_t rows, int32_t cols, float *out, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(rows >= 0 && cols >= 0, "shape");
     if ((int64_t)rows * cols == 0) return TGNN_OK;
     TGNN_CHECK_ARG(w && out, "null pointer");
@@ -557,6 +558,7 @@ int tgnn_transpose(const float *w, int32_t rows, int32_t cols, float *out, tgnn_
 
 int tgnn_swap_leading(const float *in, int32_t da, int32_t db, int32_t dc, float *out, int32_t out_da,
                       tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(da >= 0 && db >= 0 && dc >= 0 && out_da >= da, "shape");
     const int64_t total = (int64_t)da * db * dc;
     if (total == 0) return TGNN_OK;
@@ -569,6 +571,7 @@ int tgnn_swap_leading(const float *in, int32_t da, int32_t db, int32_t dc, float
 
 int tgnn_sigmoid_bwd(const float *d, int64_t ld_d, const float *t, int64_t ld_t, int64_t n_rows, int32_t c, float *out,
                      int64_t ld_o, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_rows >= 0 && c >= 1, "shape");
     if (n_rows == 0) return TGNN_OK;
     TGNN_CHECK_ARG(d && t && out, "null pointer");
@@ -581,6 +584,7 @@ int tgnn_sigmoid_bwd(const float *d, int64_t ld_d, const float *t, int64_t ld_t,
 
 int tgnn_add_into(const float *src, int64_t ld_s, int64_t n_rows, int32_t c, float *dst, int64_t ld_d,
                   tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_rows >= 0 && c >= 1, "shape");
     if (n_rows == 0) return TGNN_OK;
     TGNN_CHECK_ARG(src && dst, "null pointer");
@@ -597,6 +601,7 @@ size_t tgnn_reduce_workspace_bytes(int32_t width) {
 
 int tgnn_colsum(const float *x, int64_t ld, int64_t n_rows, int32_t c, float *out, void *ws, size_t ws_bytes,
                 tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_rows >= 0 && c >= 1 && ld >= c, "shape");
     TGNN_CHECK_ARG(out && (x || n_rows == 0), "null pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -620,6 +625,7 @@ int tgnn_colsum(const float *x, int64_t ld, int64_t n_rows, int32_t c, float *ou
 int tgnn_bn_bwd_reduce(const float *dy, int64_t ld_dy, const float *a, int64_t ld_a, const float *stat, int64_t n_rows,
                        int32_t f, float eps, float *coef, float *dgamma, float *dbeta, void *ws, size_t ws_bytes,
                        tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_rows >= 1 && f >= 1, "shape");
     TGNN_CHECK_ARG(dy && a && stat && coef, "null pointer");
     const int parts = red_partials(n_rows);
@@ -638,6 +644,7 @@ int tgnn_bn_bwd_reduce(const float *dy, int64_t ld_dy, const float *a, int64_t l
 int tgnn_bn_bwd_apply(const float *dy, int64_t ld_dy, const float *a, int64_t ld_a, const float *stat, const float *coef,
                       int64_t n_rows, int32_t f, int32_t act, float *dz, int64_t ld_dz, const float *row_scale,
                       float *scaled, int64_t ld_scaled, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_rows >= 0 && f >= 1, "shape");
     TGNN_CHECK_ARG(act == TGNN_ACT_NONE || act == TGNN_ACT_LEAKY_RELU, "activation");
     if (n_rows == 0) return TGNN_OK;
@@ -657,6 +664,7 @@ int tgnn_merge_bwd_reduce(const float *dh, int64_t ld_dh, const float *a1, const
                           float *dy1, float *dy2, float *resid_grad, int64_t ld_resid, float *coef1, float *dgamma1,
                           float *dbeta1, float *coef2, float *dgamma2, float *dbeta2, void *ws, size_t ws_bytes,
                           tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_rows >= 1, "shape");
     if (c != 32) {
         set_error("tgnn_merge_bwd_reduce: width 32 only");
@@ -691,6 +699,7 @@ size_t tgnn_wgrad_workspace_bytes(int64_t n_rows, int32_t cout, int32_t cin) {
  * dbias [cout] (may be NULL) = column sums of dz, from the same pass. */
 int tgnn_wgrad(const float *dz, int64_t ld_dz, const float *x, int64_t ld_x, int64_t x_kblock_stride, int64_t n_rows,
                int32_t cout, int32_t cin, float *out, float *dbias, void *ws, size_t ws_bytes, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_rows >= 0 && cout >= 1 && cin >= 1, "shape");
     TGNN_CHECK_ARG(out, "null pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -744,6 +753,7 @@ int tgnn_sigmoid_mlp_bwd(const float *x, int64_t n_rows, int32_t d0, int32_t d1,
                          const float *b1, const float *w2, const float *b2, const float *w3, const float *t3,
                          const float *d_out, int64_t ld_dout, float *dw1, float *db1, float *dw2, float *db2, float *dw3,
                          float *db3, float *dx, void *ws, size_t ws_bytes, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_rows >= 0 && d0 >= 1 && d1 >= 1 && d2 >= 1 && d3 >= 1, "shape");
     TGNN_CHECK_ARG(w1 && b1 && w2 && b2 && w3 && dw1 && db1 && dw2 && db2 && dw3 && db3, "null pointer");
     TGNN_CHECK_ARG(n_rows == 0 || (x && t3 && d_out), "null pointer");
@@ -812,6 +822,7 @@ int tgnn_sigmoid_mlp_bwd(const float *x, int64_t n_rows, int32_t d0, int32_t d1,
 int tgnn_nnconv_type_sum(const float *rows, int64_t ld_rows, const float *own, int64_t ld_own, const float *root_scale,
                          const int32_t *rowptr, const int32_t *src, const int32_t *type, int64_t n_nodes, int32_t n_types,
                          int32_t c, float *out, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_nodes >= 0 && n_types >= 0, "shape");
     if (c != 32 || n_types > 63) {
         set_error("tgnn_nnconv_type_sum: width 32 and at most 63 edge types");
@@ -829,6 +840,7 @@ int tgnn_nnconv_type_sum(const float *rows, int64_t ld_rows, const float *own, i
 }
 
 int tgnn_csr_degree(const int32_t *rowptr, int64_t n_nodes, float *deg, float *inv_deg, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_nodes >= 0, "shape");
     if (n_nodes == 0) return TGNN_OK;
     TGNN_CHECK_ARG(rowptr && deg && inv_deg, "null pointer");
@@ -848,6 +860,7 @@ int tgnn_unsupervised_loss_bwd(const float *probs, int64_t ld_probs, const float
                                float collision_weight, float align_length_weight, float avg_area_weight,
                                const double *terms, const float *grad_out, float *dprobs, int64_t ld_dprobs, void *ws,
                                size_t ws_bytes, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_nodes >= 1 && n_col_edges >= 0 && n_adj_edges >= 0, "shape");
     TGNN_CHECK_ARG(probs && area_ratio && terms && dprobs, "null pointer");
     TGNN_CHECK_ARG((n_col_edges == 0 || col_edge_index) && (n_adj_edges == 0 || (adj_edge_index && adj_edge_len)),

@@ -497,6 +497,7 @@ extern "C" int tgnn_bn_finalize(int32_t mode, const double *partials, int32_t n_
                                 int64_t n_rows_total, const float *gamma, const float *beta, float eps, float momentum,
                                 float *running_mean, float *running_var, int64_t *num_batches_tracked, float *stat,
                                 tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(mode >= 0 && mode <= 3, "mode");
     TGNN_CHECK_ARG(f >= 1 && f <= 256, "feature count must be in [1,256]");
     TGNN_CHECK_ARG(mode == 3 || n_rows_total >= 1, "n_rows_total");
@@ -514,6 +515,7 @@ extern "C" int tgnn_bn_finalize(int32_t mode, const double *partials, int32_t n_
 
 extern "C" int tgnn_bn_apply(const float *v, int64_t ldv, const float *stat, int64_t n_rows, int32_t f, float *out,
                              int64_t ldo, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     if (n_rows <= 0) return TGNN_OK;
     TGNN_CHECK_ARG(v && stat && out && f >= 1 && ldv >= f && ldo >= f, "arguments");
     bn_apply_kernel<<<ew_grid(n_rows * f), 256, 0, static_cast<hipStream_t>(stream)>>>(v, ldv, stat, n_rows, f, out, ldo);
@@ -524,6 +526,7 @@ extern "C" int tgnn_bn_apply(const float *v, int64_t ldv, const float *stat, int
 extern "C" int tgnn_merge_fwd(const float *a1, const float *stat1, const float *a2, const float *stat2,
                               const float *resid, int64_t n_nodes, int32_t c, float *out, float *h2_out,
                               tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     if (n_nodes <= 0) return TGNN_OK;
     TGNN_CHECK_ARG(a1 && stat1 && a2 && stat2 && out, "null pointer");
     TGNN_CHECK_ARG(c >= 4 && c % 4 == 0, "width must be a multiple of 4");
@@ -537,6 +540,7 @@ extern "C" int tgnn_merge_fwd(const float *a1, const float *stat1, const float *
 
 extern "C" int tgnn_rows_gather(const float *src, int64_t ld_src, const int32_t *idx, int64_t n_idx, int32_t c,
                                 float *out, int64_t ld_out, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     if (n_idx <= 0) return TGNN_OK;
     TGNN_CHECK_ARG(src && idx && out && c >= 1 && ld_src >= c && ld_out >= c, "arguments");
     rows_gather_kernel<<<ew_grid(n_idx * c), 256, 0, static_cast<hipStream_t>(stream)>>>(src, ld_src, idx, n_idx, c, out,
@@ -547,6 +551,7 @@ extern "C" int tgnn_rows_gather(const float *src, int64_t ld_src, const int32_t 
 
 extern "C" int tgnn_rows_scatter(const float *in, const int32_t *idx, int64_t n_idx, int32_t c, float *dst,
                                  int64_t ld_dst, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     if (n_idx <= 0) return TGNN_OK;
     TGNN_CHECK_ARG(in && idx && dst && c >= 1 && ld_dst >= c, "arguments");
     rows_scatter_kernel<<<ew_grid(n_idx * c), 256, 0, static_cast<hipStream_t>(stream)>>>(in, idx, n_idx, c, dst, ld_dst);

@@ -491,12 +491,12 @@ static int dense_act_impl(const float *a, int64_t lda, int64_t a_kblock_stride, 
     };
     const int blocks_x = row_blocks(kBM);
     const bool fast = vec_a && vec_w && in_dim % kBK == 0;
-    static const int exact_only = getenv("TGNN_DENSE_EXACT_FP32") ? atoi(getenv("TGNN_DENSE_EXACT_FP32")) : 0;
+    constexpr int exact_only = 0;     // 1: exact-fp32 MFMA kernels everywhere (the split-precision ones measured equal to 4e-7)
     if (fast && out_dim >= 64 && !exact_only && lda % 8 == 0 && a_kblock_stride % 8 == 0 && in_dim % 8 == 0) {
         // bf16 x 3 split-precision path (see dense_split_kernel)
         // few row tiles (small layouts): the 128 x 64 block tile puts twice as many blocks on the chip and halves the
         // matrix work per k-step of each -- the kernel is then bound by the latency of its serial k loop
-        static const int small_rows = getenv("TGNN_DENSE_SMALL_ROWS") ? atoi(getenv("TGNN_DENSE_SMALL_ROWS")) : 16384;
+        constexpr int small_rows = 16384;
         if (out_dim > 64 && n_rows > small_rows) {
             const int bx = row_blocks(128);
             launch_dense_split<2, 2>(bx, s, a, lda, a_kblock_stride, kps, in_stat, w, b, n_rows, in_dim, out_dim, act, out, ldo,
@@ -521,7 +521,7 @@ static int dense_act_impl(const float *a, int64_t lda, int64_t a_kblock_stride, 
             launch_dense<NT_, false>(grid_, s, a, lda, a_kblock_stride, kps, in_stat, w, b, n_rows, in_dim, out_dim, act, \
                                      out, ldo, bn_partial, vec_a, vec_w);                                          \
     } while (0)
-    static const int force_nt = getenv("TGNN_DENSE_NT") ? atoi(getenv("TGNN_DENSE_NT")) : 0;   // tuning knob (experiments)
+    constexpr int force_nt = 0;
     if (force_nt == 4 && out_dim > 32) {
         TGNN_DENSE(4);
     } else if (force_nt == 2 && out_dim > 32) {
@@ -545,6 +545,7 @@ extern "C" int tgnn_dense_act_fwd(const float *a, int64_t lda, int64_t a_kblock_
                                   const float *w, const float *b, int64_t n_rows, int32_t in_dim, int32_t out_dim,
                                   int32_t act, float *out, int64_t ldo, double *bn_partial,
                                   int32_t *n_partials_host, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     return dense_act_impl(a, lda, a_kblock_stride, 1, in_stat, w, b, n_rows, in_dim, out_dim, act, out, ldo, bn_partial,
                           n_partials_host, stream);
 }
@@ -553,6 +554,7 @@ extern "C" int tgnn_dense_act_slots_fwd(const float *a, int32_t slot_width, int6
                                         const float *w, const float *b, int64_t n_rows, int32_t in_dim, int32_t out_dim,
                                         int32_t act, float *out, int64_t ldo, double *bn_partial,
                                         int32_t *n_partials_host, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(slot_width >= 32 && slot_width % 32 == 0 && in_dim % slot_width == 0,
                    "slot-major input: slot width must be a multiple of 32 that divides in_dim");
     return dense_act_impl(a, slot_width, slot_stride, slot_width / 32, in_stat, w, b, n_rows, in_dim, out_dim, act, out, ldo,

@@ -321,7 +321,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     //      the init MLP is through, and these ~30 us (serial 3-layer MLP per (layer, type) + the bf16 image) then leave the
     //      critical chain; the first NNConv waits for them.
     hipStream_t sw = s;
-    static const bool weights_on_side = !(getenv("TGNN_WEIGHTS_SIDE") && atoi(getenv("TGNN_WEIGHTS_SIDE")) == 0);
+    constexpr bool weights_on_side = true;
     if (s2 && weights_on_side) {
         TGNN_CHECK_HIP(hipEventRecord(ev[kEvFork], s));     // everything the caller queued on `stream` so far
         TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[kEvFork], 0));
@@ -337,7 +337,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         launch_edge_weight_table_batched(adj_edge_attr, graph->type_rep_edge, T, fe, layers, D, c, w.wtab, sw);
         prof.end();
     }
-    const bool tiled = graph->nn_part_ptr && c == 32 && (int64_t)nr * c * 4 < (int64_t(1) << 31);   // buffer-addressed gathers
+    const bool tiled = graph->nn_tile_col_ptr && c == 32 && (int64_t)nr * c * 4 < (int64_t(1) << 31);   // buffer-addressed gathers
     if (tiled) {
         const float *roots[kMaxDepth];
         for (int i = 0; i < D; ++i) roots[i] = P.f(P.layer(i) + 6);
@@ -411,7 +411,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         // GraphConv (:62): NNConv mean + LeakyReLU; BN statistics emitted as partials
         prof.begin(2);
         if (tiled) {
-            TGNN_TRY(launch_nnconv_cols(h1, nr, graph->nn_part_ptr, graph->nn_col_meta, graph->nn_col_off,
+            TGNN_TRY(launch_nnconv_cols(h1, c, graph->nn_tile_col_ptr, graph->nn_col_meta, graph->nn_col_src,
                                         w.wimg + (size_t)i * (T + 1) * kWtType, T, P.f(b + 7), n, TGNN_ACT_LEAKY_RELU,
                                         w.a1, w.part1, &np1, s));
         } else {
@@ -446,7 +446,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         // Few partial rows (small layouts): merge derives the first BatchNorm's record from them itself -- one launch
         // less on the critical chain of a launch-latency-bound forward.  (With the 256 rows of a 100k-node layout the
         // repeated reduction costs every merge block more than the separate 1-block finalize: measured.)
-        static const int fuse_rows = getenv("TGNN_MERGE_BN1_ROWS") ? atoi(getenv("TGNN_MERGE_BN1_ROWS")) : 128;
+        constexpr int fuse_rows = 128;
         const bool fused_bn1 = c == 32 && !use_running_stats && !sh && np1 <= fuse_rows;
         if (s2) {
             if (!fused_bn1) {
@@ -510,6 +510,7 @@ extern "C" int tgnn_forward(const tgnn_model_dims *dims, const void *const *para
                             const float *adj_edge_attr, const tgnn_graph *graph, int32_t update_running,
                             int32_t use_running_stats, float *probs, void *ws, size_t ws_bytes, tgnn_stream_t stream,
                             tgnn_stream_t stream2) {
+    DeviceGuard guard__(stream);
     Prof prof;
     return forward_impl(dims, params_host, x, adj_edge_attr, graph, update_running, use_running_stats, probs, ws,
                         ws_bytes, stream, stream2, prof);
@@ -518,6 +519,7 @@ extern "C" int tgnn_forward(const tgnn_model_dims *dims, const void *const *para
 extern "C" int tgnn_forward_train(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
                                   const float *adj_edge_attr, const tgnn_graph *graph, const tgnn_train_save *keep,
                                   float *probs, void *ws, size_t ws_bytes, tgnn_stream_t stream, tgnn_stream_t stream2) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(keep, "null keep struct");
     Prof prof;
     return forward_impl(dims, params_host, x, adj_edge_attr, graph, 1, 0, probs, ws, ws_bytes, stream, stream2, prof, nullptr,
@@ -528,6 +530,7 @@ extern "C" int tgnn_forward_sharded(const tgnn_model_dims *dims, const void *con
                                     const float *adj_edge_attr, const tgnn_graph *graph, const tgnn_shard *shard,
                                     int32_t update_running, float *probs, void *ws, size_t ws_bytes,
                                     tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(shard, "null shard");
     Prof prof;
     return forward_impl(dims, params_host, x, adj_edge_attr, graph, update_running, 0, probs, ws, ws_bytes, stream,
@@ -538,6 +541,7 @@ extern "C" int tgnn_forward_profiled(const tgnn_model_dims *dims, const void *co
                                      const float *adj_edge_attr, const tgnn_graph *graph, int32_t update_running,
                                      int32_t use_running_stats, float *probs, void *ws, size_t ws_bytes,
                                      tgnn_stream_t stream, float *class_ms_host, int32_t *class_launches_host) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(class_ms_host && class_launches_host, "null profile arrays");
     Prof prof;
     prof.on = true;

@@ -333,6 +333,7 @@ extern "C" int tgnn_gin_fwd(const float *a, int64_t lda, const float *in_stat, c
                             const float *w2, const float *b2, const float *w3, const float *b3, int64_t n_nodes,
                             int32_t c, int32_t act, float *out, float *z_scratch, double *bn_partial,
                             int32_t *n_partials_host, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_nodes >= 0 && c >= 1 && c <= 256, "shape");
     TGNN_CHECK_ARG(act == TGNN_ACT_NONE || act == TGNN_ACT_LEAKY_RELU, "activation");
     if (n_nodes == 0) {
@@ -352,7 +353,7 @@ extern "C" int tgnn_gin_fwd(const float *a, int64_t lda, const float *in_stat, c
         blocks = producer_blocks(n_nodes, 16 * kMlpWaves);
         // one block per CU (the weight prologue is paid once per block), minus a few CUs left to the other chain's small
         // kernels (see launch_cols_t in nnconv_cols.hip)
-        static const int reserve = getenv("TGNN_RESERVE_CUS") ? atoi(getenv("TGNN_RESERVE_CUS")) : 32;
+        constexpr int reserve = 32;
         if (blocks > 256 - reserve) blocks = 256 - reserve;
         if (blocks >= 8) blocks &= ~7;
         gin32_mlp_kernel<<<blocks, kMlpThreads, 0, s>>>(z_scratch, w1, b1, w2, b2, w3, b3, n_nodes, act, out,
@@ -373,6 +374,7 @@ extern "C" int tgnn_gin_fwd(const float *a, int64_t lda, const float *in_stat, c
 extern "C" int tgnn_gin_aggregate(const float *a, int64_t lda, const float *in_stat, const int32_t *rowptr,
                                   const int32_t *col_src, const float *eps, int64_t n_nodes, int32_t c, float *z,
                                   tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_nodes >= 0, "shape");
     if (c != 32) {
         set_error("tgnn_gin_aggregate: width 32 only");

@@ -335,25 +335,21 @@ __global__ void gather_i32_kernel(const int *__restrict__ src, int64_t n_src, co
 }
 
 // ------------------------------------------------------------------------------------------
-// NNConv type columns (nnconv_cols.hip): per 16 destination rows a run of columns sorted by edge type; column (t, r)
-// holds, per row, the byte offset (source row x 128) of the row's r-th in-edge of type t (CSR = original order) or
-// 0x80000000; then the degree column (float bits of -max(deg, 1)) and the root column (type T: the rows themselves).
-// col_meta = type | first-of-type << 8 | last-of-type << 9 | end-of-tile << 10 | skip << 11 | degree << 12.
-// The stream is cut into PARTS (one per wavefront of the kernel's launch) at tile boundaries, balanced by column
-// count, every part padded with skip columns to whole chunks of 8.
+// NNConv type columns (nnconv_cols.hip): per 16 destination rows a list of columns sorted by edge type;
+// column (t, r) holds the source of every row's r-th in-edge of type t (CSR = original order) or -1.
+// The last column of a tile is the root column (type T): max(deg,1) as float bits, -1 for rows >= n.
+// col_meta = type | first-of-type << 8 | last-of-type << 9 | end-of-tile << 10.
 // One block = 64 rows = 4 tiles, one thread per row.
 // ------------------------------------------------------------------------------------------
 constexpr int kColTileRows = 16;
 constexpr int kMaxColTypes = 40;
-constexpr uint32_t kColNone = 0x80000000u;
 
-// pass 1 (FILL = false): columns per tile.  pass 2: the tile's columns at tile_col_ptr[tile].
 template <bool FILL>
 __global__ __launch_bounds__(64) void nnconv_col_kernel(const int *__restrict__ rowptr, const int *__restrict__ col_src,
                                                         const int *__restrict__ col_type, int64_t n, int n_types,
                                                         int *__restrict__ tile_cols,            // !FILL: out, columns per tile
                                                         const int *__restrict__ tile_col_ptr,   // FILL
-                                                        uint32_t *__restrict__ col_meta, uint32_t *__restrict__ col_off) {
+                                                        int *__restrict__ col_meta, int *__restrict__ col_slot_src) {
     __shared__ int cnt[64][kMaxColTypes + 1];    // +1: odd stride, the per-row walks hit distinct banks
     __shared__ int maxm[4][kMaxColTypes];
     __shared__ int base[4][kMaxColTypes + 1];
@@ -376,104 +372,32 @@ __global__ __launch_bounds__(64) void nnconv_col_kernel(const int *__restrict__ 
         int acc = 0;
         for (int t = 0; t < n_types; ++t) { base[k][t] = acc; acc += maxm[k][t]; }
         base[k][n_types] = acc;
-        if (!FILL && tile < n_tiles) tile_cols[tile] = acc + 2;     // + degree column + root column
+        if (!FILL && tile < n_tiles) tile_cols[tile] = acc + 1;
     }
     if (!FILL) return;
     __syncthreads();
     if (tile >= n_tiles) return;                 // whole 16-thread group: no barrier below
     const int64_t c0 = tile_col_ptr[tile];
     const int n_edge_cols = base[k][n_types];
-    for (int c = 0; c < n_edge_cols; ++c) col_off[(c0 + c) * 16 + i] = kColNone;
+    for (int c = 0; c < n_edge_cols; ++c) col_slot_src[(c0 + c) * 16 + i] = -1;
     for (int t = i; t < n_types; t += 16) {
         const int m = maxm[k][t];
         for (int r = 0; r < m; ++r)
-            col_meta[c0 + base[k][t] + r] = (uint32_t)t | (r == 0 ? kColMetaFirst : 0) | (r == m - 1 ? kColMetaLast : 0);
+            col_meta[c0 + base[k][t] + r] = t | (r == 0 ? 1 << 8 : 0) | (r == m - 1 ? 1 << 9 : 0);
     }
-    // degree column, root column
+    // root column
     const int deg = e1 - e0;
-    col_off[(c0 + n_edge_cols) * 16 + i] = __float_as_uint(-(float)(deg > 0 ? deg : 1));
-    col_off[(c0 + n_edge_cols + 1) * 16 + i] = row < n ? (uint32_t)row * 128u : kColNone;
-    if (i == 0) {
-        col_meta[c0 + n_edge_cols] = (uint32_t)n_types | kColMetaDeg;
-        col_meta[c0 + n_edge_cols + 1] = (uint32_t)n_types | kColMetaFirst | kColMetaLast | kColMetaEnd;
-    }
-    // the 16 threads of a tile are lanes of one wavefront: their "none" stores above are ordered before these
+    col_slot_src[(c0 + n_edge_cols) * 16 + i] = row < n ? __float_as_int((float)(deg > 0 ? deg : 1)) : -1;
+    if (i == 0) col_meta[c0 + n_edge_cols] = n_types | (1 << 8) | (1 << 9) | (1 << 10);
+    // the 16 threads of a tile are lanes of one wavefront: their -1 stores above are ordered before these
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for (int t = 0; t < n_types; ++t) cnt[tid][t] = 0;
     for (int e = e0; e < e1; ++e) {
         const int t = col_type[e];
         const int r = cnt[tid][t]++;
-        col_off[(c0 + base[k][t] + r) * 16 + i] = (uint32_t)col_src[e] * 128u;
+        col_slot_src[(c0 + base[k][t] + r) * 16 + i] = col_src[e];
     }
-}
-
-// The partition: part p takes the tiles [tb[p], tb[p+1]), tb[p] = first tile whose (unpadded) column position is
-// >= p * total / n_parts; its columns start at the sum of the padded sizes of the parts before it.  One block.
-// Writes part_ptr [n_parts + 1][2] = {first tile, first column}, the skip columns that pad every part, and the base
-// every tile adds to its unpadded position (tile_shift [n_tiles]: filled per part).
-constexpr int kPartThreads = 1024;
-__global__ __launch_bounds__(kPartThreads) void nnconv_col_part_kernel(const int *__restrict__ ptr0, int64_t n_tiles,
-                                                                       int n_parts, int *__restrict__ part_ptr,
-                                                                       int *__restrict__ tile_shift,
-                                                                       uint32_t *__restrict__ col_meta,
-                                                                       uint32_t *__restrict__ col_off) {
-    __shared__ int wave_tot[kPartThreads / 64];
-    __shared__ int carry;
-    const int tid = threadIdx.x;
-    const int64_t total = ptr0[n_tiles];
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    auto first_tile = [&](int p) -> int {
-        if (p >= n_parts) return (int)n_tiles;
-        const int64_t target = total * p / n_parts;
-        int64_t lo = 0, hi = n_tiles;                        // first tile with ptr0[tile] >= target
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (ptr0[mid] < target) lo = mid + 1; else hi = mid;
-        }
-        return (int)lo;
-    };
-    for (int p0 = 0; p0 < n_parts; p0 += kPartThreads) {
-        const int p = p0 + tid;
-        int t0 = 0, t1 = 0, cols = 0, padded = 0;
-        if (p < n_parts) {
-            t0 = first_tile(p); t1 = first_tile(p + 1);
-            cols = ptr0[t1] - ptr0[t0];
-            padded = (cols + kColChunk - 1) / kColChunk * kColChunk;
-        }
-        const int incl = wave_inclusive_scan(padded);
-        if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
-        __syncthreads();
-        int off = carry;
-        for (int w = 0; w < (tid >> 6); ++w) off += wave_tot[w];
-        const int start = off + incl - padded;
-        if (p < n_parts) {
-            part_ptr[2 * p] = t0;
-            part_ptr[2 * p + 1] = start;
-            const int shift = start - ptr0[t0];
-            for (int t = t0; t < t1; ++t) tile_shift[t] = shift;
-            for (int c = start + cols; c < start + padded; ++c) {
-                col_meta[c] = kColMetaSkip;
-                for (int j = 0; j < 16; ++j) col_off[(int64_t)c * 16 + j] = kColNone;
-            }
-        }
-        __syncthreads();
-        if (tid == kPartThreads - 1) carry = start + padded;
-        __syncthreads();
-    }
-    if (tid == 0) {
-        part_ptr[2 * n_parts] = (int)n_tiles;
-        part_ptr[2 * n_parts + 1] = carry;
-    }
-}
-
-// tile_col_ptr[t] = ptr0[t] + tile_shift[t]  (final position of the tile's first column)
-__global__ void nnconv_col_shift_kernel(const int *__restrict__ ptr0, const int *__restrict__ tile_shift, int64_t n_tiles,
-                                        const int *__restrict__ part_ptr, int n_parts, int *__restrict__ tile_col_ptr) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n_tiles) tile_col_ptr[t] = ptr0[t] + tile_shift[t];
-    if (t == n_tiles) tile_col_ptr[t] = part_ptr[2 * n_parts + 1];     // end of the padded stream
 }
 
 static inline unsigned grid_for(int64_t n, int threads = 256, int cap = 256 * 16) {
@@ -502,6 +426,7 @@ extern "C" size_t tgnn_csr_workspace_bytes(int64_t n_nodes, int64_t n_edges) {
 extern "C" int tgnn_csr_build(const int64_t *edge_index, int64_t n_edges, int64_t n_nodes, int64_t n_src_nodes,
                               int drop_self_loops, int32_t *rowptr, int32_t *col_src, int32_t *col_eid, int32_t *err_flag, void *ws,
                               size_t ws_bytes, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_nodes >= 0 && n_nodes < (1ll << 31) - 1, "n_nodes must fit int32");
     TGNN_CHECK_ARG(n_src_nodes >= n_nodes && n_src_nodes < (1ll << 31) - 1, "n_src_nodes must be >= n_nodes and fit int32");
     TGNN_CHECK_ARG(n_edges >= 0 && n_edges < (1ll << 31) - 1, "n_edges must fit int32");
@@ -538,6 +463,7 @@ extern "C" size_t tgnn_edge_dedup_workspace_bytes(int64_t n_edges, int32_t fe) {
 extern "C" int tgnn_edge_type_dedup(const float *edge_attr, int64_t n_edges, int32_t fe, int32_t *edge_type,
                                     int32_t *type_rep_edge, int32_t *n_types, void *ws, size_t ws_bytes,
                                     tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_edges >= 0 && n_edges < (1ll << 30), "n_edges out of range");
     TGNN_CHECK_ARG(fe >= 1, "fe must be >= 1");
     TGNN_CHECK_ARG(n_types, "null n_types");
@@ -573,6 +499,7 @@ extern "C" int tgnn_edge_type_dedup(const float *edge_attr, int64_t n_edges, int
 
 extern "C" int tgnn_gather_i32(const int32_t *src, int64_t n_src, const int32_t *idx, int64_t n, int32_t *out,
                                tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     if (n <= 0) return TGNN_OK;
     TGNN_CHECK_ARG(src && idx && out, "null pointer");
     gather_i32_kernel<<<grid_for(n), 256, 0, static_cast<hipStream_t>(stream)>>>(src, n_src, idx, n, out);
@@ -581,29 +508,23 @@ extern "C" int tgnn_gather_i32(const int32_t *src, int64_t n_src, const int32_t 
 }
 
 extern "C" int64_t tgnn_nnconv_cols_max_columns(int64_t n_nodes, int64_t n_edges) {
-    // every edge column holds at least one edge; a degree and a root column per tile; every part padded to whole chunks
-    return n_edges + 2 * ((n_nodes + kColTileRows - 1) / kColTileRows) + (int64_t)kColChunk * 256 * 16 + 64;
-}
-
-extern "C" int32_t tgnn_nnconv_cols_parts(int64_t n_nodes, int32_t n_types) {
-    const ColsShape sh = cols_shape(n_nodes, n_types);
-    return sh.waves * sh.blocks;
+    // every edge column holds at least one edge; one root column per tile; slack: the kernel fetches index words in
+    // groups of 4 columns and up to 3 groups ahead
+    return n_edges + (n_nodes + kColTileRows - 1) / kColTileRows + 32;
 }
 
 extern "C" size_t tgnn_nnconv_cols_workspace_bytes(int64_t n_nodes) {
     const int64_t ntiles = (n_nodes + kColTileRows - 1) / kColTileRows;
-    return 3 * align_up((size_t)(ntiles + 1) * 4, 256) + scan_ws_ints(ntiles + 1) * 4 + 1024;
+    return align_up((size_t)(ntiles + 1) * 4, 256) + scan_ws_ints(ntiles + 1) * 4 + 1024;
 }
 
 extern "C" int tgnn_nnconv_cols_build(const int32_t *rowptr, const int32_t *col_src, const int32_t *col_type,
-                                      int64_t n_nodes, int64_t n_src_nodes, int32_t n_types, int32_t *tile_col_ptr,
-                                      int32_t *part_ptr, int32_t *col_meta, int32_t *col_off, void *ws,
-                                      size_t ws_bytes, tgnn_stream_t stream) {
+                                      int64_t n_nodes, int32_t n_types, int32_t *tile_col_ptr, int32_t *col_meta,
+                                      int32_t *col_slot_src, void *ws, size_t ws_bytes, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_nodes >= 1, "n_nodes");
-    TGNN_CHECK_ARG(n_src_nodes >= n_nodes && n_src_nodes * 128 < (int64_t(1) << 31),
-                   "source rows of 128 bytes must lie within 2 GB (buffer addressing)");
     TGNN_CHECK_ARG(n_types >= 0 && n_types <= kMaxColTypes, "the column NNConv structure supports at most 40 edge types");
-    TGNN_CHECK_ARG(rowptr && tile_col_ptr && part_ptr && col_meta && col_off, "null pointer");
+    TGNN_CHECK_ARG(rowptr && tile_col_ptr && col_meta && col_slot_src, "null pointer");
     TGNN_CHECK_ARG(n_types == 0 || (col_src && col_type), "null CSR pointer");
     if (!ws || ws_bytes < tgnn_nnconv_cols_workspace_bytes(n_nodes)) {
         set_error("tgnn_nnconv_cols_build: workspace too small");
@@ -613,21 +534,14 @@ extern "C" int tgnn_nnconv_cols_build(const int32_t *rowptr, const int32_t *col_
     const int64_t nt16 = (n_nodes + kColTileRows - 1) / kColTileRows;
     Carver cv(ws, ws_bytes);
     int *tile_cols = cv.take<int>(nt16 + 1);
-    int *ptr0 = cv.take<int>(nt16 + 1);
-    int *tile_shift = cv.take<int>(nt16 + 1);
     int *scan_ws = cv.take<int>(scan_ws_ints(nt16 + 1));
     TGNN_CHECK_HIP(hipMemsetAsync(tile_cols + nt16, 0, 4, s));
     const unsigned blocks = (unsigned)((n_nodes + 63) / 64);
-    uint32_t *meta = reinterpret_cast<uint32_t *>(col_meta), *off = reinterpret_cast<uint32_t *>(col_off);
     nnconv_col_kernel<false><<<blocks, 64, 0, s>>>(rowptr, col_src, col_type, n_nodes, n_types, tile_cols, nullptr,
                                                    nullptr, nullptr);
-    exclusive_scan_i32(tile_cols, ptr0, nt16 + 1, scan_ws, s);
-    const ColsShape sh = cols_shape(n_nodes, n_types);
-    nnconv_col_part_kernel<<<1, kPartThreads, 0, s>>>(ptr0, nt16, sh.waves * sh.blocks, part_ptr, tile_shift, meta, off);
-    nnconv_col_shift_kernel<<<(unsigned)((nt16 + 256) / 256), 256, 0, s>>>(ptr0, tile_shift, nt16, part_ptr,
-                                                                          sh.waves * sh.blocks, tile_col_ptr);
+    exclusive_scan_i32(tile_cols, tile_col_ptr, nt16 + 1, scan_ws, s);
     nnconv_col_kernel<true><<<blocks, 64, 0, s>>>(rowptr, col_src, col_type, n_nodes, n_types, nullptr, tile_col_ptr,
-                                                  meta, off);
+                                                  col_meta, col_slot_src);
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
 }
@@ -702,6 +616,7 @@ extern "C" int tgnn_sublayout_compact(const int32_t *alive, int64_t n_nodes, con
                                       int64_t *inverse_out, int64_t *adj_out, float *adj_attr_out, int64_t *col_out,
                                       int64_t *counts_out, int32_t *err_flag, void *ws, size_t ws_bytes,
                                       tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_nodes >= 1 && n_nodes < (1ll << 31) - 1 && fx >= 1, "node shape");
     TGNN_CHECK_ARG(n_adj_edges >= 0 && n_adj_edges < (1ll << 31) - 1 && n_col_edges >= 0 && n_col_edges < (1ll << 31) - 1,
                    "edge counts must fit int32");

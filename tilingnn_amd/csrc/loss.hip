@@ -149,6 +149,7 @@ extern "C" int tgnn_unsupervised_loss(const float *probs, int64_t ld_probs, int3
                                       const float *adj_edge_len, int64_t ld_len, float collision_weight,
                                       float align_length_weight, float avg_area_weight, double *losses,
                                       double *terms, void *ws, size_t ws_bytes, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_maps >= 1 && n_maps <= 65535 && n_nodes >= 1, "shape");
     TGNN_CHECK_ARG(probs && area_ratio && losses && ld_probs >= n_maps && ld_area >= 1, "null pointer / strides");
     TGNN_CHECK_ARG(n_col_edges >= 0 && (n_col_edges == 0 || col_edge_index), "collision edges");
@@ -175,6 +176,7 @@ extern "C" int tgnn_solution_score_sums(const float *predict, const float *area_
                                         const float *perimeter, int64_t n_nodes, const int64_t *adj_edge_index,
                                         int64_t n_adj_edges, const float *adj_edge_len, int64_t ld_len, double *sums,
                                         void *ws, size_t ws_bytes, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_nodes >= 1 && predict && area_ratio && perimeter && sums && ld_area >= 1, "null pointer / shape");
     TGNN_CHECK_ARG(n_adj_edges >= 0 && (n_adj_edges == 0 || (adj_edge_index && adj_edge_len && ld_len >= 1)), "adjacency edges");
     if (!ws || ws_bytes < tgnn_unsupervised_loss_workspace_bytes(1)) {

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void nnconv_weight_image_kernel(const float *_
         const float r1 = x - (float)h;                       // exact
         const __bf16 m = (__bf16)r1;
         const float r2 = r1 - (float)m;                      // exact
-        const int at = (((o >> 4) * 16 + (o & 15)) * 4 + (k >> 3)) * 8 + (k & 7);
+        const int at = (((o >> 4) * 4 + (k >> 3)) * 16 + (o & 15)) * 8 + (k & 7);   // [M block][g = k / 8][i = o % 16][k % 8]
         dst[0 * kWtPlane * 2 + at] = h;                      // (kWtPlane floats = 2 kWtPlane bf16)
         dst[1 * kWtPlane * 2 + at] = m;
         dst[2 * kWtPlane * 2 + at] = (__bf16)r2;
@@ -378,6 +378,7 @@ extern "C" int tgnn_edge_weight_table(const float *edge_attr, const int32_t *typ
                                       int32_t fe, const float *w1, const float *b1, const float *w2,
                                       const float *b2, const float *w3, const float *b3, int32_t c, float *wtab,
                                       tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     if (n_types <= 0) return TGNN_OK;
     TGNN_CHECK_ARG(edge_attr && type_rep_edge && w1 && b1 && w2 && b2 && w3 && b3 && wtab, "null pointer");
     TGNN_CHECK_ARG(fe >= 1 && fe <= 1024, "edge feature dim must be in [1,1024]");
@@ -396,6 +397,7 @@ extern "C" int tgnn_nnconv_mean_fwd(const float *h, int64_t ldh, const int32_t *
                                     const float *root, const float *bias, int64_t n_nodes, int32_t c, int32_t act,
                                     float *out, double *bn_partial, int32_t *n_partials_host,
                                     tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_nodes >= 0 && c >= 1, "shape");
     TGNN_CHECK_ARG(act == TGNN_ACT_NONE || act == TGNN_ACT_LEAKY_RELU, "activation");
     if (n_nodes == 0) {

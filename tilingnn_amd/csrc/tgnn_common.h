@@ -41,6 +41,25 @@ void set_error(const char *fmt, ...);     // thread-local message, api.hip
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Every entry point launches on the device its stream belongs to, whatever the calling thread's current device is
+// (a model on cuda:1 called while cuda:0 is current): the guard switches for the duration of the call.  The NULL
+// stream belongs to the current device by definition.
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(tgnn_stream_t stream) {
+        if (!stream) return;
+        int cur = -1;
+        hipDevice_t dev = -1;
+        if (hipGetDevice(&cur) != hipSuccess || hipStreamGetDevice(static_cast<hipStream_t>(stream), &dev) != hipSuccess) return;
+        if (dev != cur && hipSetDevice(dev) == hipSuccess) prev = cur;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 // Carves aligned sub-buffers out of a caller-provided workspace.
 struct Carver {
     char *base;
@@ -182,21 +201,13 @@ void launch_edge_weight_table_batched(const float *edge_attr, const int *type_re
 // NNConv B-operand weight images [(T+1)][1152] for `depth` layers (roots[i] = layer i's root matrix); nnconv.hip
 void launch_nnconv_weight_image(const float *wtab_all, const float *const *roots, int n_types, int depth,
                                 float *wimg_all, hipStream_t s);
-// ---- column NNConv (nnconv_cols.hip; structure built in graph_prep.hip) ----------------------------------------------------
-// meta word of a column: type | flags
-constexpr int kColMetaFirst = 1 << 8, kColMetaLast = 1 << 9, kColMetaEnd = 1 << 10, kColMetaSkip = 1 << 11, kColMetaDeg = 1 << 12;
-constexpr int kColChunk = 8;               // a part (one wavefront's column stream) is a whole number of chunks
-constexpr int kColsReserveCus = 32;        // CUs the column kernel leaves to the collision chain of the two-stream forward
-struct ColsShape {
-    int waves, blocks;                     // wavefronts per block (8 / 16), blocks; parts = waves * blocks
-};
-ColsShape cols_shape(int64_t n_nodes, int n_types);
-int launch_nnconv_cols(const float *h, int64_t n_src_rows, const int32_t *part_ptr, const int32_t *col_meta,
-                       const int32_t *col_off, const float *wimg, int32_t n_types, const float *bias,
+int launch_nnconv_cols(const float *h, int64_t ldh, const int32_t *tile_col_ptr, const int32_t *col_meta,
+                       const int32_t *col_src, const float *wimg, int32_t n_types, const float *bias,
                        int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
                        hipStream_t s);
-// MFMA weight image of the column NNConv, per type: [plane 3 (hi, mid, lo)][M block 2][i 16][g 4] x 8 bf16 --
-// the A fragment of lane (i, g) for one (plane, M block) is one 16-byte read; 6144 B = 1536 floats per type
+// MFMA weight image of the column NNConv, per type: [plane 3 (hi, mid, lo)][M block 2][g 4][i 16] x 8 bf16 --
+// the A fragment of lane 16 g + i for one (plane, M block) is one 16-byte read, a wavefront reads 1 KB in lane order
+// (conflict-free: SQ_LDS_BANK_CONFLICT 2.3e6 -> 2.3e5 per launch against the [i][g] order of round 1); 6144 B per type
 constexpr int kWtPlane = 2 * 64 * 4;       // floats (16-byte fragments x 4) per plane
 constexpr int kWtType = 3 * kWtPlane;      // floats per type
 }  // namespace tgnn

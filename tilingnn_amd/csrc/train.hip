@@ -104,6 +104,7 @@ extern "C" int tgnn_backward(const tgnn_model_dims *dims, const void *const *par
                              const float *x, const float *adj_edge_attr, const tgnn_graph *graph,
                              const tgnn_train_graph *tgraph, const tgnn_train_save *keep, const float *probs,
                              const float *dprobs, void *ws, size_t ws_bytes, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(dims && params_host && grads_host && x && graph && tgraph && keep && probs && dprobs, "null pointer");
     const int c = dims->network_width, D = dims->network_depth, fx = dims->node_features_dim,
               fe = dims->adj_edge_features_dim, od = dims->output_dim, T = graph->n_types;

@@ -77,40 +77,33 @@ class PreparedGraph:
         return _lib.Graph(self.n_nodes, self.n_adj_edges, self.n_col_edges, self.n_types,
                           self.adj_rowptr.data_ptr(), self.adj_src.data_ptr(), self.adj_type.data_ptr(),
                           self.type_rep_edge.data_ptr(), self.col_rowptr.data_ptr(), self.col_src.data_ptr(),
-                          *((t.part_ptr.data_ptr(), t.col_meta.data_ptr(), t.col_off.data_ptr())
+                          *((t.tile_col_ptr.data_ptr(), t.col_meta.data_ptr(), t.col_src.data_ptr())
                             if t is not None else (None,) * 3))
 
 
 @dataclass
 class NNConvColumns:
-    """The column stream of the matrix-core NNConv (tgnn_nnconv_cols_build, include/tgnn.h): per 16-row tile the
-    type-sorted source columns, a degree column and the root column; cut into one part per wavefront of the launch."""
-    tile_col_ptr: Tensor      # int32 [ceil(N/16) + 1]: first column of every tile; last entry = length of the stream
-    part_ptr: Tensor          # int32 [n_parts + 1, 2]: {first tile, first column}
-    col_meta: Tensor          # int32 [cap]: type | first << 8 | last << 9 | end-of-tile << 10 | skip << 11 | degree << 12
-    col_off: Tensor           # int32 [16 * cap]: source row * 128, 0x80000000 = none; degree columns: bits of -max(deg,1)
-    n_src_nodes: int          # rows the offsets may address (>= N: halo rows of a shard)
+    """Per-16-row tiles of type-sorted source columns (tgnn_nnconv_cols_build, include/tgnn.h)."""
+    tile_col_ptr: Tensor      # int32 [ceil(N/16) + 1]
+    col_meta: Tensor          # int32 [cap]: type | first << 8 | last << 9 | end-of-tile << 10
+    col_src: Tensor           # int32 [16 * cap]: source row, -1 = none; root columns: float bits of max(deg,1)
 
 
 def build_nnconv_columns(n_nodes: int, n_edges: int, n_types: int, rowptr: Tensor, col_src: Tensor,
-                         col_type: Tensor, n_src_nodes: Optional[int] = None) -> Optional[NNConvColumns]:
-    """None when the layout has more edge types than the matrix-core kernel's LDS weight image holds, or its source
-    rows do not fit the 2 GB window of the kernel's buffer addressing."""
-    n_src = n_nodes if n_src_nodes is None else int(n_src_nodes)
-    if n_types > min(lib.tgnn_nnconv_cols_max_types(), 40) or n_src * 128 >= 2 ** 31:
+                         col_type: Tensor) -> Optional[NNConvColumns]:
+    """None when the layout has more edge types than the matrix-core kernel's LDS weight image holds."""
+    if n_types > lib.tgnn_nnconv_cols_max_types():
         return None
     dev = rowptr.device
     cap = int(lib.tgnn_nnconv_cols_max_columns(n_nodes, n_edges))
     ntiles = (n_nodes + 15) // 16
-    n_parts = int(lib.tgnn_nnconv_cols_parts(n_nodes, n_types))
     cols = NNConvColumns(torch.empty(ntiles + 1, dtype=torch.int32, device=dev),
-                         torch.empty(n_parts + 1, 2, dtype=torch.int32, device=dev),
                          torch.empty(cap, dtype=torch.int32, device=dev),
-                         torch.empty(cap * 16, dtype=torch.int32, device=dev), n_src)
+                         torch.empty(cap * 16, dtype=torch.int32, device=dev))
     ws_bytes = lib.tgnn_nnconv_cols_workspace_bytes(n_nodes)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    check(lib.tgnn_nnconv_cols_build(ptr(rowptr), ptr(col_src), ptr(col_type), n_nodes, n_src, n_types,
-                                     ptr(cols.tile_col_ptr), ptr(cols.part_ptr), ptr(cols.col_meta), ptr(cols.col_off),
+    check(lib.tgnn_nnconv_cols_build(ptr(rowptr), ptr(col_src), ptr(col_type), n_nodes, n_types,
+                                     ptr(cols.tile_col_ptr), ptr(cols.col_meta), ptr(cols.col_src),
                                      ptr(ws), ws_bytes, _stream(rowptr)))
     return cols
 
@@ -192,8 +185,7 @@ def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col
     n_types = int(host[0])
     if columns is None:
         columns = n_nodes > COLS_MIN_NODES
-    cols = build_nnconv_columns(n_nodes, ea, n_types, a_rowptr, a_src, adj_type, n_src_nodes) \
-        if tile_width == 32 and columns else None
+    cols = build_nnconv_columns(n_nodes, ea, n_types, a_rowptr, a_src, adj_type) if tile_width == 32 and columns else None
     return PreparedGraph(n_nodes, ea, int(host[3]), n_types, a_rowptr, a_src, a_eid, adj_type, edge_type, rep,
                          c_rowptr, c_src, c_eid, cols)
 
@@ -235,9 +227,9 @@ def nnconv_mean(h: Tensor, graph: PreparedGraph, wtab: Tensor, root: Tensor, bia
     npart = C.c_int32(0)
     wt = _f32c(wtab, "wtab")
     tl = graph.cols
-    if tl is not None and c == 32 and not force_csr_kernel and tl.n_src_nodes <= int(h.shape[0]) < 2 ** 24:
+    if tl is not None and c == 32 and not force_csr_kernel and int(h.shape[0]) * c * 4 < 2 ** 31:
         wimg = torch.empty(lib.tgnn_nnconv_weight_image_floats(graph.n_types), dtype=torch.float32, device=h.device)
-        check(lib.tgnn_nnconv_mean_cols_fwd(ptr(h), c, int(h.shape[0]), ptr(tl.part_ptr), ptr(tl.col_meta), ptr(tl.col_off), ptr(wt),
+        check(lib.tgnn_nnconv_mean_cols_fwd(ptr(h), c, ptr(tl.tile_col_ptr), ptr(tl.col_meta), ptr(tl.col_src), ptr(wt),
                                             graph.n_types, ptr(_f32c(root, "root")), ptr(_f32c(bias, "bias")), n, c, act,
                                             ptr(out), ptr(wimg), ptr(partials), C.byref(npart), _stream(h)))
     else:
