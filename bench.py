@@ -41,9 +41,13 @@ F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak = fp32 vector
 
 
 def nnconv_bytes(n, ea, t, c=32, s=4):
-    """ALGORITHMIC bytes of one NNConv-mean launch:
-    rowptr + src idx + type id (int32 here) + read h once + write out once + weight table."""
-    return (n + 1) * 4 + ea * 4 + ea * 4 + n * c * s + n * c * s + (t + 1) * c * c * s
+    """ALGORITHMIC bytes of one NNConv-mean launch, SURVEY.md section 8d verbatim:
+    B_nn = (N+1)*4 [rowptr] + Ea*4 [src idx] + Ea*1 [type id] + N*C*s [read h once] + N*C*s [write out] + T*C^2*s."""
+    return (n + 1) * 4 + ea * 4 + ea * 1 + n * c * s + n * c * s + t * c * c * s
+
+
+def merge_bytes(n, c=32, s=4):
+    return 4 * n * c * s
 
 
 def nnconv_flops(n, ea, c=32):
@@ -63,9 +67,19 @@ def forward_bytes(n, ea, ec, t, fe=15, fx=3, c=32, d=20, s=4):
     return api + d * (b_nn + b_gin + b_mrg + n * c * s) + n * (d + 1) * c * s + n * 4
 
 
-def cpu_baseline(seed=11):
-    """The reference's CPU op sequence (oracle = port, incl. the materialised [Ea, C*C] tensor),
-    fp32, no_grad, train-mode BN, all host cores; bounded sample of the same generator."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            return next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
+    except OSError:
+        return ""
+
+
+def cpu_baseline():
+    """The reference's CPU op sequence (oracle = port, incl. the materialised [Ea, C*C] tensor), fp32, no_grad,
+    train-mode BN, on this box's host cores: median of 3 forwards at BASELINE config 2 (10 000 nodes / 80 000 + 100 000
+    edges) = `value`, plus one forward of a 20 000-node / 200 000 + 250 000-edge sample of the benchmark's
+    own generator (1/5 of the GPU workload; the cost is linear in Ea).  Also the per-op parity probe of smoke()."""
     from oracle import tilingnn_oracle as orc
     from tilingnn_amd.synth import make_super_graph
     from tilingnn_amd.weights import make_state_dict
@@ -73,24 +87,104 @@ def cpu_baseline(seed=11):
     # the MI355X box (2 x EPYC 9575F): 8 thr 1121, 32 thr 1129, 64 thr 830, 128 thr 448, 256 thr 65 nodes/s.
     cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
-    n, ea, ec = 20_000, 200_000, 250_000
-    sg = make_super_graph(n, ea, ec, tile_count=TILE_COUNT, n_edge_types=N_TYPES, seed=seed)
     sd = make_state_dict(2 + N_TYPES, DEPTH, WIDTH, 1, TILE_COUNT + 1, seed=0)
-    x, adj, adj_attr, col, _ = sg.to_torch("cpu")
+
+    def run(n, ea, ec, seed, reps):
+        sg = make_super_graph(n, ea, ec, tile_count=TILE_COUNT, n_edge_types=N_TYPES, seed=seed)
+        x, adj, adj_attr, col, _ = sg.to_torch("cpu")
+        ts = []
+        with torch.no_grad():
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                probs, _ = orc.tilingnn_forward(sd, x, adj, adj_attr, col)
+                ts.append(time.perf_counter() - t0)
+        assert bool(torch.isfinite(probs).all())
+        return sorted(ts)[len(ts) // 2], ts
+
+    t2, all2 = run(10_000, 80_000, 100_000, 1, 3)
+    t20, _ = run(20_000, 200_000, 250_000, 11, 1)
+    return {"value": 10_000 / t2, "unit": "nodes/s", "cores": cores, "kind": "port",
+            "sample": f"median of 3 forwards at BASELINE config 2 (N=10000 Ea=80000 Ec=100000, seed 1): "
+                      f"{', '.join(f'{t:.1f}' for t in all2)} s; torch {torch.__version__} CPU, {_cpu_model()}",
+            "sample_20k": {"value": 20_000 / t20, "seconds": t20,
+                           "what": "1 forward, N=20000 Ea=200000 Ec=250000 (the benchmark's generator at 1/5 of its size)"}}
+
+
+def parity_probe(dev):
+    """Per-op, teacher-forced max-norm relative error against the fp64 oracle on the real labyrinth graph (what smoke()
+    asserts): GraphConv (NNConv + LeakyReLU + BN) and CollConv (GIN + LeakyReLU + BN) of layer 0."""
+    from oracle import tilingnn_oracle as orc
+    from tests.golden_util import graph_tensors, load_labyrinth_graph
+    from tilingnn_amd import TilinGNN
+    from tilingnn_amd.weights import make_state_dict
+    g = load_labyrinth_graph()
+    sd = make_state_dict(15, 20, 32, 1, 3, seed=0)
+    net = TilinGNN(adj_edge_features_dim=15, network_depth=20, network_width=32, node_features_dim=3)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).train()
+    x, adj, adj_attr, col, _ = graph_tensors(g, torch.float32, dev)
+    sd64 = orc.cast_sd(sd, torch.float64)
+    xc, adjc, attrc, colc, _ = graph_tensors(g, torch.float64)
     with torch.no_grad():
-        t0 = time.perf_counter()
-        probs, _ = orc.tilingnn_forward(sd, x, adj, adj_attr, col)
-        dt = time.perf_counter() - t0
-    assert bool(torch.isfinite(probs).all())
-    model = ""
-    try:
-        with open("/proc/cpuinfo") as f:
-            model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
-    except OSError:
-        pass
-    return {"value": n / dt, "unit": "nodes/s", "cores": cores, "kind": "port",
-            "sample": f"1 forward, N={n} Ea={ea} Ec={ec} (same generator, 1/5 of the GPU workload; cost is linear in Ea), "
-                      f"{dt:.1f} s, torch {torch.__version__} CPU, {model}"}
+        h0_32 = orc.init_node_feature_trans(xc, sd64).float()
+        want_g = orc.graph_conv(h0_32.double(), adjc, attrc, sd64, "brch_1_graph_conv_layers.0")
+        want_c = orc.coll_conv(h0_32.double(), colc, sd64, "brch_2_coll_conv_layers.0")
+    got_g = net.brch_1_graph_conv_layers[0](h0_32.to(dev), adj, adj_attr)[0]
+    got_c = net.brch_2_coll_conv_layers[0](h0_32.to(dev), col)[0]
+    return {"graph": "labyrinth ring-9 (1254 nodes), layer 0, teacher forced, vs fp64 oracle, max-norm relative",
+            "graphconv_bn": orc.rel_max_err(got_g.cpu(), want_g), "collconv_bn": orc.rel_max_err(got_c.cpu(), want_c),
+            "bars": "north_star 1e-5; SURVEY 8c allows 2e-4 for the ill-conditioned collision-branch BatchNorm"}
+
+
+CLASS_NAMES = ["edge_weights", "dense_init", "nnconv", "gin", "bn_finalize", "merge", "dense_final", "-"]
+
+
+def profiled_classes(net, x, adj, adj_attr, col, steps):
+    """Per-kernel-class time of the forward, HIP events on the launch stream (tgnn_forward_profiled: the single-stream
+    schedule with an event pair around every launch) -> ({class: {ms_per_forward, launches_per_forward}}, n_types)."""
+    from tilingnn_amd import ops
+    from tilingnn_amd._lib import check, lib, ptr
+    dev = x.device
+    n = int(x.shape[0])
+    graph = ops.prepare_graph(n, adj, adj_attr, col)
+    dims = net._dims()
+    table, _ = net._param_table()
+    ws_bytes = lib.tgnn_forward_workspace_bytes(C.byref(dims), n, graph.n_types)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    probs = torch.empty(n, 1, dtype=torch.float32, device=dev)
+    ms = (C.c_float * 8)()
+    cnt = (C.c_int32 * 8)()
+    g = graph.c_struct()
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for _ in range(steps):
+        check(lib.tgnn_forward_profiled(C.byref(dims), table, ptr(x), ptr(adj_attr), C.byref(g), 1, 0, ptr(probs),
+                                        ptr(ws), ws_bytes, stream, ms, cnt))
+    return ({CLASS_NAMES[i]: {"ms_per_forward": ms[i] / steps, "launches_per_forward": cnt[i] // steps} for i in range(7)},
+            graph.n_types)
+
+
+def kernel_roofline(class_ms, n, ea, ec, n_types):
+    """`roofline` of the NNConv column kernel (the path's scatter-add) + the GIN pair and merge, all against the HBM
+    bound with SURVEY 8d's algorithmic bytes; `achieved` = bytes / the average launch duration of the events above."""
+    def per_launch_s(k):
+        return class_ms[k]["ms_per_forward"] / max(1, class_ms[k]["launches_per_forward"]) * 1e-3
+    t_nn = per_launch_s("nnconv")
+    b_alg = nnconv_bytes(n, ea, n_types)
+    out = {"kernel": "nnconv32_cols_kernel (NNConv mean as a type-column MFMA product, per layer)", "bound": "hbm",
+           "achieved": b_alg / t_nn / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_alg / t_nn / 1e9 / HBM_PEAK_GBS,
+           "traffic": None, "algorithmic_bytes_per_launch": b_alg, "avg_launch_us": t_nn * 1e6,
+           "timing": "HIP events on the launch stream, instrumented single-stream pass of this run",
+           "flops_per_launch": nnconv_flops(n, ea), "achieved_tflops": nnconv_flops(n, ea) / t_nn / 1e12,
+           "frac_of_f32_peak": nnconv_flops(n, ea) / t_nn / 1e12 / F32_MFMA_PEAK_TFLOPS}
+    t_gin = per_launch_s("gin")           # aggregate + MLP kernels of one layer (one class in the profiled pass)
+    b_gin = gin_bytes(n, ec) + 2 * n * 32 * 4
+    out["gin_kernel"] = {"avg_launch_us": t_gin * 1e6, "algorithmic_bytes_per_launch": b_gin,
+                         "what": "gin32_aggregate_kernel + gin32_mlp_kernel of one layer (B_gin + the MLP's read and write)",
+                         "achieved": b_gin / t_gin / 1e9, "frac": b_gin / t_gin / 1e9 / HBM_PEAK_GBS}
+    t_m = per_launch_s("merge")
+    out["merge_kernel"] = {"avg_launch_us": t_m * 1e6, "algorithmic_bytes_per_launch": merge_bytes(n),
+                           "achieved": merge_bytes(n) / t_m / 1e9, "frac": merge_bytes(n) / t_m / 1e9 / HBM_PEAK_GBS}
+    return out
 
 
 def main():
@@ -101,6 +195,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nodes-per-gpu", type=int, default=NODES_PER_GPU)
     ap.add_argument("--no-train-step", action="store_true", help="skip the training-step timing")
+    ap.add_argument("--no-extra-sizes", action="store_true", help="skip the 500k / 2M-node single-GPU lines")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the sharded (RCCL) schedule even at world size 1 (exercises the multi-GPU code path)")
     args = ap.parse_args()
@@ -165,19 +260,28 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    # EXACTLY K steps between two barriers; one event behind every step: the spacing of consecutive events is the
+    # step time the stream saw (host gaps included), its median is what SURVEY 8d asks to be reported
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    evs[0].record()
+    for k in range(args.steps):
         out = step()
+        evs[k + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    per_step_ms = sorted(evs[k].elapsed_time(evs[k + 1]) for k in range(args.steps))
+    median_ms = per_step_ms[len(per_step_ms) // 2] if args.steps % 2 else \
+        0.5 * (per_step_ms[args.steps // 2 - 1] + per_step_ms[args.steps // 2])
     if sharded:
         import torch.distributed as dist
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt, median_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt, median_ms = float(tmax[0].item()), float(tmax[1].item())
     assert bool(torch.isfinite(out).all())
-    ms_per_step = dt / args.steps * 1e3
-    value = n_total * args.steps / dt
+    mean_ms = dt / args.steps * 1e3
+    ms_per_step = median_ms
+    value = n_total / (median_ms * 1e-3)
 
     # ---- cached-layout variant (prep amortised, e.g. repeated predict on one BrickLayout)
     cached_ms = None
@@ -196,48 +300,56 @@ def main():
     # ---- roofline of the dominant kernel: second, instrumented pass (HIP events on the launch stream)
     roofline, class_ms = None, None
     if not sharded:
-        from tilingnn_amd import ops
-        graph = ops.prepare_graph(n_total, adj, adj_attr, col)
-        dims = net._dims()
-        table, _ = net._param_table()
-        ws_bytes = lib.tgnn_forward_workspace_bytes(C.byref(dims), n_total, graph.n_types)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        probs = torch.empty(n_total, 1, dtype=torch.float32, device=dev)
-        ms = (C.c_float * 8)()
-        cnt = (C.c_int32 * 8)()
-        g = graph.c_struct()
-        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        for _ in range(args.steps):
-            check(lib.tgnn_forward_profiled(C.byref(dims), table, ptr(x), ptr(adj_attr), C.byref(g), 1, 0, ptr(probs),
-                                            ptr(ws), ws_bytes, stream, ms, cnt))
-        names = ["edge_weights", "dense_init", "nnconv", "gin", "bn_finalize", "merge", "dense_final", "-"]
-        class_ms = {names[i]: {"ms_per_forward": ms[i] / args.steps, "launches_per_forward": cnt[i] // args.steps}
-                    for i in range(7)}
+        class_ms, n_types_seen = profiled_classes(net, x, adj, adj_attr, col, args.steps)
         dom = max(("nnconv", "gin", "dense_final"), key=lambda k: class_ms[k]["ms_per_forward"])
-        per_launch_s = class_ms["nnconv"]["ms_per_forward"] / max(1, class_ms["nnconv"]["launches_per_forward"]) * 1e-3
-        b_alg = nnconv_bytes(n_total, ea_total, graph.n_types)
-        # HBM-side bytes per launch from the PMC passes (cannot be collected from inside this process): the committed
-        # measurement of the same kernel on the same workload, only quoted when the workload is that one
-        traffic, traffic_src = None, None
-        pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm.json")
-        if os.path.exists(pmc_file) and (n_total, ea_total, graph.n_types) == (100_000, 1_000_000, 13):
-            with open(pmc_file) as fh:
-                traffic = json.load(fh)["nnconv32_cols_kernel"]["hbm_bytes_per_launch_corrected"]
-            traffic_src = "profiles/r01_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 on gfx950)"
-        roofline = {"kernel": "nnconv32_cols_kernel (NNConv mean as a type-column MFMA product, per layer)", "bound": "hbm",
-                    "achieved": b_alg / per_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": b_alg / per_launch_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": b_alg, "avg_launch_us": per_launch_s * 1e6,
-                    "flops_per_launch": nnconv_flops(n_total, ea_total),
-                    "achieved_tflops": nnconv_flops(n_total, ea_total) / per_launch_s / 1e12,
-                    "frac_of_f32_peak": nnconv_flops(n_total, ea_total) / per_launch_s / 1e12 / F32_MFMA_PEAK_TFLOPS,
-                    "slowest_class": dom}
-        gl = class_ms["gin"]["ms_per_forward"] / max(1, class_ms["gin"]["launches_per_forward"]) * 1e-3
-        roofline["gin_kernel"] = {"avg_launch_us": gl * 1e6, "algorithmic_bytes_per_launch": gin_bytes(n_total, ec_total),
-                                  "achieved_GBs": gin_bytes(n_total, ec_total) / gl / 1e9}
-        roofline["whole_forward"] = {"algorithmic_bytes": forward_bytes(n_total, ea_total, ec_total, graph.n_types),
-                                     "frac_of_hbm_peak": forward_bytes(n_total, ea_total, ec_total, graph.n_types)
+        roofline = kernel_roofline(class_ms, n_total, ea_total, ec_total, n_types_seen)
+        roofline["slowest_class"] = dom
+        # quoted, not measured here: rocprofv3 of the same command (cannot run inside this process) and the PMC passes;
+        # only for the workload they were taken on, with the file they come from
+        prof_file = os.path.join(REPO, "profiles", "r02_nnconv.json")
+        if os.path.exists(prof_file) and (n_total, ea_total, n_types_seen) == (100_000, 1_000_000, 13):
+            with open(prof_file) as fh:
+                q = json.load(fh)
+            roofline["traffic"] = q.get("hbm_bytes_per_launch_corrected")
+            roofline["traffic_source"] = q.get("traffic_source")
+            if q.get("rocprof_avg_us_in_forward"):
+                roofline["rocprof"] = {"avg_launch_us_in_forward": q["rocprof_avg_us_in_forward"],
+                                       "frac": roofline["algorithmic_bytes_per_launch"] / (q["rocprof_avg_us_in_forward"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                       "source": q.get("rocprof_source")}
+        roofline["whole_forward"] = {"algorithmic_bytes": forward_bytes(n_total, ea_total, ec_total, n_types_seen),
+                                     "frac_of_hbm_peak": forward_bytes(n_total, ea_total, ec_total, n_types_seen)
                                      / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+    # ---- larger single-GPU layouts (BASELINE configs 4 / 5 are 500k / 2M nodes over 4 / 8 GPUs; here on ONE GPU, drawn
+    #      on the device): step time with graph preparation, kernel classes, fractions of the HBM bound per kernel
+    extras = None
+    if not sharded and not args.no_extra_sizes:
+        from tilingnn_amd.synth import make_super_graph_on_device
+        extras = []
+        for n_big, seed in ((500_000, 3), (2_000_000, 4)):
+            xb, adjb, attrb, colb, _ = make_super_graph_on_device(n_big, 10 * n_big, 10 * n_big // 4 * 5, dev,
+                                                                  tile_count=TILE_COUNT, n_edge_types=N_TYPES, seed=seed)
+            torch.cuda.synchronize()
+            for _ in range(2):
+                net(x=xb, adj_e_index=adjb, adj_e_features=attrb, col_e_idx=colb)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(5):
+                tb = time.perf_counter()
+                net(x=xb, adj_e_index=adjb, adj_e_features=attrb, col_e_idx=colb)
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - tb) * 1e3)
+            med = sorted(ts)[2]
+            cls, nt = profiled_classes(net, xb, adjb, attrb, colb, 3)
+            rf = kernel_roofline(cls, n_big, int(adjb.shape[1]), int(colb.shape[1]), nt)
+            extras.append({"n_nodes": n_big, "n_adj_edges": int(adjb.shape[1]), "n_col_edges": int(colb.shape[1]),
+                           "ms_per_step": med, "value": n_big / (med * 1e-3), "data": "synthetic, drawn on the device",
+                           "nnconv": {k: rf[k] for k in ("avg_launch_us", "achieved", "frac")},
+                           "gin_aggregate_plus_mlp": rf["gin_kernel"], "merge": rf["merge_kernel"],
+                           "whole_forward_frac_of_hbm_peak": forward_bytes(n_big, int(adjb.shape[1]), int(colb.shape[1]), nt)
+                           / (med * 1e-3) / 1e9 / HBM_PEAK_GBS})
+            del xb, adjb, attrb, colb
+            torch.cuda.empty_cache()
 
     # ---- the loss ML_Solver.predict evaluates on the probabilities: two launches, HBM bound
     loss_info = None
@@ -339,6 +451,9 @@ def main():
         line = {
             "metric": "scored tile-nodes/sec (GNN forward)", "value": value, "unit": "nodes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "timing": {"value_from": "median step time (event spacing over the K timed steps, max over ranks)",
+                       "ms_per_step_median": median_ms, "ms_per_step_mean": mean_ms, "value_mean": n_total / (mean_ms * 1e-3),
+                       "ms_per_step_min": per_step_ms[0], "ms_per_step_max": per_step_ms[-1]},
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"TilinGNN.forward on a seeded banded super-graph: {args.nodes_per_gpu} nodes / "
                                    f"{int(ADJ_PER_GPU * scale)} adjacency edges / {int(COL_PER_GPU * scale)} collision edges "
@@ -358,9 +473,16 @@ def main():
             line["train_step"] = train_info
         if class_ms is not None:
             line["kernel_classes"] = class_ms
+        if extras is not None:
+            line["larger_layouts_single_gpu"] = extras
+        if sharded:
+            import torch.distributed as dist
+            line["collectives"] = {"backend": dist.get_backend(), "ranks_seen": dist.get_world_size(),
+                                   "per_forward": shard_runner.collectives_per_forward}
         if not args.no_cpu_baseline and world == 1:           # the CPU leg is a 1-GPU (rank 0, N = 1) measurement
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
+            line["parity_probe"] = parity_probe(dev)
         print(json.dumps(line), flush=True)
     if sharded:
         os.dup2(2, 1)                      # teardown chatter, if any, goes to stderr

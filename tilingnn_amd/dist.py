@@ -440,11 +440,14 @@ class TorchDistCollectives:
     def __init__(self, group=None):
         import torch.distributed as dist
         self.dist, self.group = dist, group
+        self.n_allreduce = self.n_alltoall = 0               # calls issued so far (bench.py reports them per forward)
 
     def allreduce(self, t: Tensor) -> None:
+        self.n_allreduce += 1
         self.dist.all_reduce(t, group=self.group)
 
     def alltoall(self, send: Tensor, send_splits, recv: Tensor, recv_splits) -> None:
+        self.n_alltoall += 1
         self.dist.all_to_all_single(recv, send, output_split_sizes=recv_splits, input_split_sizes=send_splits,
                                     group=self.group)
 
@@ -502,12 +505,21 @@ class ShardedTilinGNN:
         self.n_local, self.ea_local, self.ec_local = shard.n_own, int(shard.adj.shape[1]), int(shard.col.shape[1])
         self.inputs = self.backend.upload(shard)          # resident in HBM before any timed step
         self.program = None
-        self.fused = FusedShardForward(net, shard, device, TorchDistCollectives(group), inputs=self.inputs)
+        self.collectives = TorchDistCollectives(group)
+        self.fused = FusedShardForward(net, shard, device, self.collectives, inputs=self.inputs)
+        self.steps = 0
+
+    @property
+    def collectives_per_forward(self):
+        """{all_to_all, all_reduce} issued through torch.distributed per fused forward (counted, not assumed)."""
+        k = max(self.steps, 1)
+        return {"all_to_all_single": self.collectives.n_alltoall / k, "all_reduce": self.collectives.n_allreduce / k}
 
     def step(self, fused: bool = True) -> Tensor:
         """One forward of this rank's shard, graph preparation included (as in the 1-GPU benchmark).
         fused=False runs the per-op Python schedule (ShardProgram) instead of tgnn_forward_sharded."""
         if fused:
+            self.steps += 1
             return self.fused.step()
         self.program = ShardProgram(self.net, self.shard, self.backend, inputs=self.inputs)
         return self.comm.run(self.program)
