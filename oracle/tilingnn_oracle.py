@@ -292,3 +292,31 @@ def rel_max_err(a: Tensor, b: Tensor) -> float:
     """max-norm relative error  max|a-b| / max|b|  (the parity metric of SURVEY.md section 8c)."""
     a, b = a.double(), b.double()
     return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+# --------------------------------------------------------------------------------------
+# NNConv at sizes where the reference's materialised [Ea, C, C] tensor does not fit the test box (fp64 at 1M edges:
+# 8 GB): the same arithmetic with the edge MLP evaluated once per DISTINCT attribute row and the messages formed in
+# chunks of edges.  Algebraically identical (W_e depends on the attribute row only); pinned equal to `nnconv_mean`
+# on the labyrinth graph by tests/test_oracle_vs_reference_golden.py::test_dedup_nnconv_equals_the_port.
+# --------------------------------------------------------------------------------------
+def nnconv_mean_dedup(x: Tensor, edge_index: Tensor, edge_attr: Tensor, sd: SD, prefix: str, chunk: int = 1 << 18) -> Tensor:
+    root = sd[prefix + ".nnConv.root"]
+    c_in, c_out = root.shape
+    n = x.shape[0]
+    src, dst = edge_index[0], edge_index[1]
+    uniq, inv = torch.unique(edge_attr, dim=0, return_inverse=True)
+    w = edge_weight_matrices(uniq.to(x.dtype), sd, prefix + ".mlp", c_in, c_out)     # [T, C, C]
+    agg = torch.zeros(n, c_out, dtype=x.dtype)
+    for e0 in range(0, int(src.shape[0]), chunk):
+        e1 = min(e0 + chunk, int(src.shape[0]))
+        xs = x.index_select(0, src[e0:e1])
+        msg = torch.zeros(e1 - e0, c_out, dtype=x.dtype)
+        for t in range(w.shape[0]):                                                  # grouped by type: [m, C] @ [C, C]
+            sel = (inv[e0:e1] == t).nonzero().squeeze(1)
+            if sel.numel():
+                msg.index_copy_(0, sel, xs.index_select(0, sel) @ w[t])
+        agg.index_add_(0, dst[e0:e1], msg)
+    cnt = torch.zeros(n, dtype=x.dtype).index_add_(0, dst, torch.ones_like(dst, dtype=x.dtype))
+    agg = agg / cnt.clamp(min=1).unsqueeze(1)
+    return agg + x @ root + sd[prefix + ".nnConv.bias"]

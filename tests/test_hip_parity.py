@@ -235,8 +235,10 @@ def test_tiny_graph_zero_indegree_and_self_loops(dev):
     assert orc.rel_max_err(got_gin, want_gin) < TOL
     probs, _ = net(x=x, adj_e_index=adj, adj_e_features=adj_attr, col_e_idx=col)
     assert probs.shape == (6, 1) and bool(torch.isfinite(probs).all())
-    # 6 nodes: BN over 6 rows is violently ill conditioned; only sanity-check against the reference
-    assert np.abs(probs.cpu().numpy() - z["probs_fp64"]).max() < 0.5
+    # 6 nodes: BN over 6 rows is ill conditioned; the gate is 10x what this implementation measures
+    gap = np.abs(probs.cpu().numpy() - z["probs_fp64"]).max()
+    print(f"tiny graph end-to-end max|p - p_fp64| = {gap:.3e}")
+    assert gap < 1e-3          # measured 1.0e-4 (depth 3; six rows per BatchNorm)
 
 
 # ------------------------------------------------------------------------------------------ per op vs oracle, full graph
@@ -304,7 +306,53 @@ def test_end_to_end_same_order_as_reference_fp32_gap(dev, laby, cols_min_nodes, 
     gap_hip = np.abs(got - ref["probs_fp64"]).max()
     print(f"end-to-end max|p - p_fp64|: HIP {gap_hip:.3e}; reference fp32 {gap_ref:.3e}")
     assert got.shape == (1254, 1) and np.isfinite(got).all()
-    assert gap_hip < 5 * gap_ref + 1e-3
+    # measured 2.1e-3 on both NNConv kernels (the reference's own fp32 run: 1.1e-1 -- twenty train-mode BatchNorms make the
+    # network chaotic end to end): gate at 5x the measurement, not at the reference's gap
+    assert gap_hip < 1e-2
+
+
+def _stat_record(v64, gamma, beta, eps=1e-5):
+    """The 4-row BatchNorm record (mean hi, mean lo, gamma / sigma, beta) of a [N, F] activation, in fp64 from the data."""
+    mean = v64.mean(0)
+    var = v64.var(0, unbiased=False)
+    mh = mean.float()
+    return torch.stack([mh, (mean - mh.double()).float(), (gamma.double() / torch.sqrt(var + eps)).float(), beta.float()])
+
+
+@pytest.mark.parametrize("layer", [0, 1, 2, 19])
+def test_merge_residual_and_concat_teacher_forced(dev, laby, layer):
+    """K9 (TilinGNN.py:64-74), teacher forced from the oracle's captures on the real graph: with the fp32-rounded
+    pre-BatchNorm branch outputs and skip map of the oracle as inputs, `merge` must give middle[i + 1] = BN1(a1) * BN2(a2)
+    (+ middle[i - 2] from layer 2 on); and the final Linear reading the slot-major skip buffer must equal the same Linear
+    on torch.cat(middle) -- the two halves of "torch.cat never happens"."""
+    from tilingnn_amd import ops
+    g, net, sd, sd64, cap = laby
+    i = layer
+    leaky = torch.nn.functional.leaky_relu
+    a1 = leaky(cap[f"nnconv.{i}"]).float()
+    a2 = leaky(cap[f"gin.{i}"]).float()
+    l1, l2 = net.brch_1_graph_conv_layers[i], net.brch_2_coll_conv_layers[i]
+    st1 = _stat_record(a1.double(), l1.batch_norm.weight.cpu(), l1.batch_norm.bias.cpu())
+    st2 = _stat_record(a2.double(), l2.batch_norm.weight.cpu(), l2.batch_norm.bias.cpu())
+    resid = cap["init"].float() if i == 2 else (cap[f"mid.{i - 2}"].float() if i > 2 else None)   # middle[i - 2]
+    bn = lambda v, st: ((v.double() - st[0].double()) - st[1].double()) * st[2].double() + st[3].double()
+    want = bn(a1, st1) * bn(a2, st2) + (resid.double() if resid is not None else 0.0)
+    got, h2 = ops.merge(a1.to(dev), st1.to(dev), a2.to(dev), st2.to(dev), resid.to(dev) if resid is not None else None)
+    err = orc.rel_max_err(got.cpu(), want)
+    # ... against the oracle's own middle[i + 1] (its statistics come from its fp64 activations, not the rounded ones)
+    err_cap = orc.rel_max_err(got.cpu(), cap[f"mid.{i + 1}"])
+    print(f"merge layer {i}: vs fp64 on the same inputs {err:.1e}; vs the oracle's middle[{i + 1}] {err_cap:.1e}")
+    assert err < TOL and err_cap < TOL_ILL
+    assert orc.rel_max_err(h2.cpu(), bn(a2, st2)) < TOL
+    if i == 19:
+        # the concatenation: slots [init, mid.1 .. mid.20] of the skip buffer read in place by the first final Linear
+        slots = torch.stack([cap["init"].float()] + [cap[f"mid.{k}"].float() for k in range(1, 21)])      # [21, N, 32]
+        assert torch.equal(torch.cat(list(slots), dim=1), cap["cat"].float())
+        lin = net.final_mlp[0].mlp[0].linear
+        got_s, _ = ops.dense_act(slots.to(dev), lin.weight, lin.bias, ops.ACT_LEAKY_RELU, slot_major=True)
+        got_c, _ = ops.dense_act(cap["cat"].float().to(dev), lin.weight, lin.bias, ops.ACT_LEAKY_RELU)
+        want_lin = leaky(cap["cat"].float().double() @ lin.weight.cpu().double().t() + lin.bias.cpu().double())
+        assert orc.rel_max_err(got_s.cpu(), want_lin) < TOL and orc.rel_max_err(got_c.cpu(), want_lin) < TOL
 
 
 def test_running_stats_follow_torch_semantics(dev):
@@ -428,6 +476,66 @@ def test_full_size_gin_aggregate_and_bn_properties(dev, big):
     assert float((g1 - g2).abs().max()) < 2e-5 * float(g1.abs().max())
 
 
+def test_full_size_layers_against_the_fp64_oracle(dev, big):
+    """BASELINE's benchmark size (100 000 nodes / 1 000 000 + 1 250 000 edges) against the ORACLE, not only through
+    properties: one NNConv (type-deduplicated, chunked fp64 oracle = the port on the labyrinth graph,
+    tests/test_oracle_vs_reference_golden.py), one GraphConv, one GINConv + CollConv and the final MLP on 21 random slots."""
+    sg, (x, adj, adj_attr, col, col_attr) = big
+    net, sd = make_net(dev)
+    sd64 = orc.cast_sd(sd, torch.float64)
+    gen = torch.Generator(device="cpu").manual_seed(4)
+    h = torch.randn(100_000, 32, generator=gen)
+    adjc, attrc, colc = adj.cpu(), adj_attr.cpu().double(), col.cpu()
+    i = 6
+    p1, p2 = f"brch_1_graph_conv_layers.{i}", f"brch_2_coll_conv_layers.{i}"
+    with torch.no_grad():
+        want_nn = orc.nnconv_mean_dedup(h.double(), adjc, attrc, sd64, p1)
+        want_g = orc.batch_norm_train(torch.nn.functional.leaky_relu(want_nn), sd64, p1 + ".batch_norm")
+        want_gin = orc.gin_conv(h.double(), colc, sd64, p2)
+        want_c = orc.coll_conv(h.double(), colc, sd64, p2)
+    l1, l2 = net.brch_1_graph_conv_layers[i], net.brch_2_coll_conv_layers[i]
+    errs = {"nnconv": orc.rel_max_err(l1.nnConv(h.to(dev), adj, adj_attr).cpu(), want_nn),
+            "gconv": orc.rel_max_err(l1(h.to(dev), adj, adj_attr)[0].cpu(), want_g),
+            "gin": orc.rel_max_err(l2.ginConv(h.to(dev), col).cpu(), want_gin),
+            "cconv": orc.rel_max_err(l2(h.to(dev), col)[0].cpu(), want_c)}
+    cat = torch.randn(100_000, 672, generator=gen)
+    with torch.no_grad():
+        want_f = orc.final_mlp(cat.double(), sd64)
+    errs["final"] = orc.rel_max_err(net.final_mlp(cat.to(dev)).cpu(), want_f)
+    print("100k / 1M vs fp64 oracle:", {k: f"{v:.1e}" for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v < (TOL_ILL if k == "cconv" else TOL), (k, v)
+
+
+@pytest.mark.parametrize("n,world,seed", [(500_000, 4, 3), (2_000_000, 8, 4)])
+def test_config4_and_config5_shapes(dev, n, world, seed):
+    """BASELINE configs 4 / 5 (500k / 6M over 4 GPUs, 2M / 20M over 8) on the ONE GPU of the test box: the forward runs and
+    is bit-reproducible at that size, NNConv stays linear, and the node-range split the multi-GPU run would use is sound
+    (every shard's halo lies in its neighbouring ranges; rows and edges partition exactly)."""
+    from tilingnn_amd.synth import make_super_graph_on_device
+    x, adj, attr, col, _ = make_super_graph_on_device(n, 10 * n, 10 * n // 4 * 5, dev, seed=seed)
+    net, _ = make_net(dev)
+    p1 = net(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)[0].clone()
+    p2 = make_net(dev)[0](x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)[0]
+    assert p1.shape == (n, 1) and bool(torch.isfinite(p1).all()) and torch.equal(p1, p2)
+    conv = net.brch_1_graph_conv_layers[1].nnConv
+    gen = torch.Generator(device=dev).manual_seed(0)
+    a = torch.randn(n, 32, generator=gen, device=dev)
+    b = torch.randn(n, 32, generator=gen, device=dev)
+    bias = conv.bias.detach()
+    fa, fb = conv(a, adj, attr) - bias, conv(b, adj, attr) - bias
+    fab = conv(2.0 * a - 0.5 * b, adj, attr) - bias
+    assert float((fab - (2.0 * fa - 0.5 * fb)).abs().max()) < 2e-5 * float(fab.abs().max())
+    # the node-range split: destination rows partition, sources reach at most into the neighbouring ranges
+    bounds = [n * r // world for r in range(world + 1)]
+    for ei in (adj, col):
+        owner_dst = torch.bucketize(ei[1], torch.tensor(bounds[1:-1], device=dev), right=True)
+        owner_src = torch.bucketize(ei[0], torch.tensor(bounds[1:-1], device=dev), right=True)
+        assert int((owner_dst - owner_src).abs().max()) <= 1
+        counts = torch.bincount(owner_dst, minlength=world)
+        assert int(counts.sum()) == ei.shape[1] and int(counts.min()) > 0.8 * ei.shape[1] / world
+
+
 def test_full_size_forward_runs_and_is_reproducible(dev, big):
     sg, (x, adj, adj_attr, col, col_attr) = big
     net, _ = make_net(dev)
@@ -483,7 +591,7 @@ def test_sharded_hip_path_matches_unsharded(dev, world):
     from tilingnn_amd import dist as tdist
     from tilingnn_amd.synth import make_super_graph
     sg = make_super_graph(6000, 60000, 75000, tile_count=2, n_edge_types=13, seed=8)
-    for depth, tol in ((3, 2e-5), (20, 5e-2)):
+    for depth, tol in ((3, 1e-5), (20, 1e-5)):                            # measured 1.1e-6 .. 1.6e-6 at both depths
         net, sd = make_net(dev, depth=depth)
         x, adj, adj_attr, col, col_attr = sg.to_torch(dev)
         want = net(x=x, adj_e_index=adj, adj_e_features=adj_attr, col_e_idx=col)[0]
@@ -515,7 +623,7 @@ def test_fused_sharded_forward_matches_unsharded(dev, world, one_collective):
     from tilingnn_amd import dist as tdist
     from tilingnn_amd.synth import make_super_graph
     sg = make_super_graph(6000, 60000, 75000, tile_count=2, n_edge_types=13, seed=8)
-    for depth, tol in ((3, 2e-5), (20, 5e-2)):
+    for depth, tol in ((3, 1e-5), (20, 1e-5)):                            # measured 0 (world 1), 1.1e-6 .. 1.6e-6
         net, sd = make_net(dev, depth=depth)
         x, adj, adj_attr, col, col_attr = sg.to_torch(dev)
         want = net(x=x, adj_e_index=adj, adj_e_features=adj_attr, col_e_idx=col)[0]

@@ -189,3 +189,20 @@ def test_oracle_greedy_loop_matches_reference(seed):
     np.testing.assert_array_equal(sizes, ref[f"greedy{seed}.sizes"])
     np.testing.assert_array_equal(order, ref[f"greedy{seed}.order"])
     np.testing.assert_array_equal(sel, ref[f"greedy{seed}.selection"])
+
+
+def test_dedup_nnconv_equals_the_port():
+    """The chunked, type-deduplicated NNConv the full-size GPU tests compare against (oracle.nnconv_mean_dedup) is the
+    port's `nnconv_mean` (itself pinned against the reference above) on the real labyrinth graph: fp64, every layer
+    sampled, difference at rounding level."""
+    g = load_labyrinth_graph()
+    sd64 = orc.cast_sd(make_state_dict(15, 20, 32, 1, 3, seed=0), torch.float64)
+    x, adj, attr, col, _ = graph_tensors(g, torch.float64)
+    gen = torch.Generator().manual_seed(1)
+    h = torch.randn(x.shape[0], 32, generator=gen, dtype=torch.float64)
+    with torch.no_grad():
+        for i in (0, 7, 19):
+            p = f"brch_1_graph_conv_layers.{i}"
+            a = orc.nnconv_mean(h, adj, attr, sd64, p)
+            b = orc.nnconv_mean_dedup(h, adj, attr, sd64, p, chunk=1000)
+            assert float((a - b).abs().max()) < 1e-12 * float(a.abs().max())
