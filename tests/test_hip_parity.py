@@ -928,3 +928,40 @@ def test_forward_with_empty_edge_sets(dev, case):
         want, _ = orc.tilingnn_forward(sd64, x.double().cpu(), adj.cpu(), adj_attr.double().cpu(), col.cpu(),
                                        update_running=False)
     assert float((probs.cpu().double() - want).abs().max()) < 1e-3
+
+
+def test_storage_swaps_under_live_parameters_are_seen(dev):
+    """The cached host table of device pointers must follow `p.data = t`, torch.utils.swap_tensors and
+    load_state_dict(assign=True) (none of which goes through __setattr__ / _apply)."""
+    g = load_labyrinth_graph()
+    net, sd = make_net(dev, depth=3)
+    args = graph_tensors(g, torch.float32, dev)[:4]
+    p0 = net(*args)[0].clone()
+    w = net.final_mlp[1].linear.weight
+    w.data = (w.data * 0.5).clone()                                   # new storage under the same Parameter
+    p1 = net(*args)[0].clone()
+    assert not torch.equal(p0, p1)
+    w.data = (w.data * 2.0).clone()
+    assert torch.equal(net(*args)[0], p0)
+    other = torch.zeros_like(w.data)
+    torch.utils.swap_tensors(net.final_mlp[1].linear.bias, torch.nn.Parameter(torch.full_like(net.final_mlp[1].linear.bias, 3.0)))
+    p2 = net(*args)[0]
+    assert float((p2 - torch.sigmoid(torch.logit(p0) + 3.0 - sd["final_mlp.1.linear.bias"].to(dev))).abs().max()) < 1e-4
+    net.load_state_dict({k: v.to(dev) for k, v in sd.items()}, strict=True, assign=True)
+    assert torch.equal(net(*args)[0], p0)
+    del other
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_forward_on_a_device_that_is_not_current():
+    """Every C-ABI entry switches to the device of its stream (DeviceGuard): a model on cuda:1 runs while cuda:0 is the
+    current device, and leaves the current device alone."""
+    g = load_labyrinth_graph()
+    d1 = torch.device("cuda:1")
+    torch.cuda.set_device(0)
+    net, _ = make_net(d1, depth=3)
+    probs = net(*graph_tensors(g, torch.float32, d1)[:4])[0]
+    ref, _ = make_net(torch.device("cuda:0"), depth=3)
+    want = ref(*graph_tensors(g, torch.float32, torch.device("cuda:0"))[:4])[0]
+    assert torch.cuda.current_device() == 0 and probs.device == d1
+    assert torch.equal(probs.cpu(), want.cpu())

@@ -13,6 +13,14 @@ _entries = OrderedDict()
 enabled = True
 
 
+def reserve(n_layouts: int) -> None:
+    """Make room for `n_layouts` prepared graphs (a data set kept on the GPU: `LayoutDataset` calls this with its
+    size, so that neither a training step nor a validation forward re-prepares a layout it has already seen -- with the
+    default of 4 every step of an epoch over more layouts would rebuild both CSRs and synchronise)."""
+    global _MAX
+    _MAX = max(_MAX, int(n_layouts) + 2)
+
+
 def _key(*tensors):
     return tuple((id(t), t._version, tuple(t.shape)) for t in tensors)
 

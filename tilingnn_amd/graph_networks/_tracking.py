@@ -30,6 +30,10 @@ class Tracked:
         bump()
         return super()._apply(fn, *args, **kwargs)
 
+    def _load_from_state_dict(self, *args, **kwargs):
+        bump()                      # load_state_dict(assign=True) re-binds parameters and buffers in place of copying
+        return super()._load_from_state_dict(*args, **kwargs)
+
 
 class Linear(Tracked, torch.nn.Linear):
     pass

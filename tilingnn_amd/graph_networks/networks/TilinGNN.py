@@ -79,7 +79,10 @@ class TilinGNN(Tracked, nn.Module):
     def _param_table(self):
         cache = self.__dict__.get("_tgnn_table")
         if cache is not None and cache[0] == _tracking.epoch():
-            return cache[1], cache[2]
+            # the epoch covers attribute assignment, _apply and load_state_dict; storage swaps underneath a live
+            # Parameter (`p.data = t`, torch.utils.swap_tensors) show up as a changed data_ptr (~25 us for 400 entries)
+            if tuple(map(torch.Tensor.data_ptr, cache[3])) == cache[4]:
+                return cache[1], cache[2]
         dims = self._dims()
         sd = dict(self.named_parameters())
         sd.update(dict(self.named_buffers()))
@@ -102,7 +105,7 @@ class TilinGNN(Tracked, nn.Module):
                 raise ValueError("all parameters must live on one device")
             table[i] = t.data_ptr()
             keep.append(t)
-        self.__dict__["_tgnn_table"] = (_tracking.epoch(), table, dev, keep)
+        self.__dict__["_tgnn_table"] = (_tracking.epoch(), table, dev, keep, tuple(t.data_ptr() for t in keep))
         return table, dev
 
     def __getstate__(self):                      # copy.deepcopy(network) (ml_solver.py:26) and pickling

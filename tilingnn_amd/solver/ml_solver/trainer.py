@@ -39,6 +39,8 @@ class LayoutDataset:
             if x is None or col_idx is None or adj_idx is None or adj_feat is None:
                 raise ValueError(f"{f}: a training layout file must carry its features (write_bricklayout(with_features=True))")
             self.layouts.append(DeviceLayout.upload(_Arrays(x, adj_idx, adj_feat, col_idx), device))
+        from ...graph_networks import _graph_cache
+        _graph_cache.reserve(len(_graph_cache._entries) + len(self.layouts))    # every layout's prepared graph stays cached
 
     def __len__(self):
         return len(self.layouts)
