@@ -471,6 +471,45 @@ int tgnn_unsupervised_loss_bwd(const float *probs, int64_t ld_probs, const float
                                const double *terms, const float *grad_out, float *dprobs, int64_t ld_dprobs, void *ws,
                                size_t ws_bytes, tgnn_stream_t stream);
 
+/* ---- BASELINE config 3: network_width 64, bf16 STORAGE of the activations that cross HBM between kernels (skip buffer,
+ * pre-BatchNorm branch outputs, GIN aggregate), fp32 accumulation, fp64 BatchNorm sums, fp32 stat records and final-MLP
+ * activations (inputs/config.py:17,37-38).  csrc/bf16_path.hip.  bf16 buffers are `void *` here
+ * (2 bytes per element, row-major, 64 per row).  Same graph structure (tgnn_graph incl. the NNConv columns), same parameter
+ * table and BatchNorm semantics as tgnn_forward; train mode only.  Per-op entries (the layer seams, for parity tests): */
+int tgnn_f32_to_bf16(const float *src, int64_t count, void *dst_bf16, tgnn_stream_t stream);     /* round to nearest even */
+size_t tgnn_nnconv64_image_elems(int32_t n_types);   /* bf16 elements of wimg_scratch */
+/* NNConv mean + root + bias (+ LeakyReLU) over the type-column structure: every column feeds 8 MFMAs against the bf16
+ * image of W_type; out_bf16 [N][64]; BatchNorm partial rows [blocks][2][64] of the ROUNDED output */
+int tgnn_nnconv64_bf16_fwd(const void *h_bf16, int64_t n_src_rows, const int32_t *tile_col_ptr, const int32_t *col_meta,
+                           const int32_t *col_src, const float *wtab, int32_t n_types, const float *root,
+                           const float *bias, int64_t n_nodes, int32_t act, void *out_bf16, void *wimg_scratch,
+                           double *bn_partial, int32_t *n_partials_host, tgnn_stream_t stream);
+/* GINConv (MLP 64 -> 32 -> 64 -> 64, sigmoids) + optional LeakyReLU; in_stat as in tgnn_gin_fwd; z_scratch_bf16 [N][64] */
+int tgnn_gin64_bf16_fwd(const void *a_bf16, const float *in_stat, const int32_t *rowptr, const int32_t *col_src,
+                        const float *eps, const float *w1, const float *b1, const float *w2, const float *b2,
+                        const float *w3, const float *b3, int64_t n_nodes, int32_t act, void *out_bf16,
+                        void *z_scratch_bf16, double *bn_partial, int32_t *n_partials_host, tgnn_stream_t stream);
+/* CollConv.forward (coll_conv.py:24-30) incl. its train-mode BatchNorm, the OUTPUT stored as bf16 (the pre-BatchNorm sigmoid
+ * columns vary by ~5e-3: 16-bit storage in front of the BatchNorm would destroy them).  Two passes over the MLP (statistics,
+ * then normalise + store).  stat_scratch: 4 x 64 floats (the record); bn_partial: TGNN_BN_MAX_PARTIALS x 128 doubles. */
+int tgnn_collconv64_bf16_fwd(const void *h2_in_bf16, const int32_t *rowptr, const int32_t *col_src, const float *eps,
+                             const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
+                             const float *b3, const float *gamma, const float *beta, float *running_mean,
+                             float *running_var, int64_t *num_batches_tracked, int64_t n_nodes, void *out_bf16,
+                             void *z_scratch_bf16, float *stat_scratch, double *bn_partial, tgnn_stream_t stream);
+/* stat2 == NULL: a2 holds BN2's output already (tgnn_collconv64_bf16_fwd) */
+int tgnn_merge_bf16_fwd(const void *a1_bf16, const float *stat1, const void *a2_bf16, const float *stat2,
+                        const void *resid_bf16, int64_t n_nodes, int32_t c, void *out_bf16, tgnn_stream_t stream);
+/* act(cat . w^T + b) with cat = the slot-major bf16 skip buffer [n_slots][n_rows][64] read in place; w fp32
+ * [out_dim][64 n_slots] is rounded to bf16 into wb_scratch (out_dim * 64 * n_slots bf16 elements); out fp32 */
+int tgnn_dense_bf16_slots_fwd(const void *a_bf16, int64_t slot_stride, int32_t n_slots, const float *w, const float *b,
+                              int64_t n_rows, int32_t out_dim, int32_t act, float *out, void *wb_scratch,
+                              double *bn_partial, int32_t *n_partials_host, tgnn_stream_t stream);
+size_t tgnn_forward_bf16_workspace_bytes(const tgnn_model_dims *dims, int64_t n_nodes, int32_t n_types);
+int tgnn_forward_bf16(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
+                      const float *adj_edge_attr, const tgnn_graph *graph, int32_t update_running, float *probs,
+                      void *ws, size_t ws_bytes, tgnn_stream_t stream);
+
 int tgnn_rows_gather(const float *src, int64_t ld_src, const int32_t *idx, int64_t n_idx, int32_t c,
                      float *out, int64_t ld_out, tgnn_stream_t stream);
 int tgnn_rows_scatter(const float *in, const int32_t *idx, int64_t n_idx, int32_t c, float *dst,

@@ -132,6 +132,15 @@ def _load() -> C.CDLL:
         "tgnn_csr_degree": (C.c_int, [p, i64, p, p, p]),
         "tgnn_unsupervised_loss_bwd": (C.c_int, [p, i64, p, i64, i64, p, i64, p, i64, p, i64, f32, f32, f32, p, p, p, i64,
                                                  p, sz, p]),
+        "tgnn_f32_to_bf16": (C.c_int, [p, i64, p, p]),
+        "tgnn_nnconv64_image_elems": (sz, [i32]),
+        "tgnn_nnconv64_bf16_fwd": (C.c_int, [p, i64, p, p, p, p, i32, p, p, i64, i32, p, p, p, pi32, p]),
+        "tgnn_gin64_bf16_fwd": (C.c_int, [p, p, p, p, p, p, p, p, p, p, p, i64, i32, p, p, p, pi32, p]),
+        "tgnn_collconv64_bf16_fwd": (C.c_int, [p, p, p, p, p, p, p, p, p, p, p, p, p, p, p, i64, p, p, p, p, p]),
+        "tgnn_merge_bf16_fwd": (C.c_int, [p, p, p, p, p, i64, i32, p, p]),
+        "tgnn_dense_bf16_slots_fwd": (C.c_int, [p, i64, i32, p, p, i64, i32, i32, p, p, p, pi32, p]),
+        "tgnn_forward_bf16_workspace_bytes": (sz, [C.POINTER(ModelDims), i64, i32]),
+        "tgnn_forward_bf16": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), p, p, C.POINTER(Graph), i32, p, p, sz, p]),
         "tgnn_rows_gather": (C.c_int, [p, i64, p, i64, i32, p, i64, p]),
         "tgnn_rows_scatter": (C.c_int, [p, p, i64, i32, p, i64, p]),
     }
@@ -154,7 +163,9 @@ EXPORTED_SYMBOLS = (
     "tgnn_transpose", "tgnn_swap_leading", "tgnn_gin_aggregate", "tgnn_sigmoid_bwd", "tgnn_add_into", "tgnn_reduce_workspace_bytes", "tgnn_colsum",
     "tgnn_bn_bwd_reduce", "tgnn_bn_bwd_apply", "tgnn_merge_bwd_reduce", "tgnn_wgrad_workspace_bytes", "tgnn_wgrad",
     "tgnn_sigmoid_mlp_bwd_workspace_bytes", "tgnn_sigmoid_mlp_bwd",
-    "tgnn_nnconv_type_sum", "tgnn_csr_degree", "tgnn_unsupervised_loss_bwd")
+    "tgnn_nnconv_type_sum", "tgnn_csr_degree", "tgnn_unsupervised_loss_bwd",
+    "tgnn_f32_to_bf16", "tgnn_nnconv64_image_elems", "tgnn_nnconv64_bf16_fwd", "tgnn_gin64_bf16_fwd", "tgnn_collconv64_bf16_fwd", "tgnn_merge_bf16_fwd",
+    "tgnn_dense_bf16_slots_fwd", "tgnn_forward_bf16_workspace_bytes", "tgnn_forward_bf16")
 
 
 def check(rc: int) -> None:

@@ -70,6 +70,9 @@ class TilinGNN(Tracked, nn.Module):
         # mean "training" here.  The differentiable forward (tilingnn_amd/train.py: keeps activations, backward through
         # the adjoint kernels) is therefore opt-in: Trainer switches it on around its steps.
         self.autograd = False
+        # torch.bfloat16: the activations that cross HBM between kernels are stored in bf16 (fp32 accumulation, fp64
+        # BatchNorm sums) -- BASELINE config 3, network_width 64 only (tilingnn_amd/ops_bf16.py, csrc/bf16_path.hip)
+        self.activation_dtype = torch.float32
 
     # ---- host-side table of device pointers -------------------------------------------------
     def _dims(self):
@@ -132,6 +135,12 @@ class TilinGNN(Tracked, nn.Module):
             return train.forward_with_grad(self, x, adj_e_index, adj_e_features, col_e_idx), adj_e_features
         if bn_train and n < 2:
             raise ValueError("Expected more than 1 value per channel when training")
+        if self.activation_dtype == torch.bfloat16:
+            from ... import ops_bf16
+            graph = _graph_cache.get_full(n, adj_e_index, adj_e_features, col_e_idx) if self.cache_graph else None
+            return ops_bf16.forward(self, x, adj_e_index, adj_e_features, col_e_idx, graph), adj_e_features
+        if self.activation_dtype != torch.float32:
+            raise ValueError("activation_dtype must be torch.float32 or torch.bfloat16")
         xf = ops._f32c(x, "x")
         ea = ops._f32c(adj_e_features, "adj_e_features")
         if self.cache_graph:
