@@ -508,7 +508,7 @@ int tgnn_dense_bf16_slots_fwd(const void *a_bf16, int64_t slot_stride, int32_t n
 size_t tgnn_forward_bf16_workspace_bytes(const tgnn_model_dims *dims, int64_t n_nodes, int32_t n_types);
 int tgnn_forward_bf16(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
                       const float *adj_edge_attr, const tgnn_graph *graph, int32_t update_running, float *probs,
-                      void *ws, size_t ws_bytes, tgnn_stream_t stream);
+                      void *ws, size_t ws_bytes, tgnn_stream_t stream, tgnn_stream_t stream2);
 
 int tgnn_rows_gather(const float *src, int64_t ld_src, const int32_t *idx, int64_t n_idx, int32_t c,
                      float *out, int64_t ld_out, tgnn_stream_t stream);

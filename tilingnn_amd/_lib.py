@@ -140,7 +140,7 @@ def _load() -> C.CDLL:
         "tgnn_merge_bf16_fwd": (C.c_int, [p, p, p, p, p, i64, i32, p, p]),
         "tgnn_dense_bf16_slots_fwd": (C.c_int, [p, i64, i32, p, p, i64, i32, i32, p, p, p, pi32, p]),
         "tgnn_forward_bf16_workspace_bytes": (sz, [C.POINTER(ModelDims), i64, i32]),
-        "tgnn_forward_bf16": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), p, p, C.POINTER(Graph), i32, p, p, sz, p]),
+        "tgnn_forward_bf16": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), p, p, C.POINTER(Graph), i32, p, p, sz, p, p]),
         "tgnn_rows_gather": (C.c_int, [p, i64, p, i64, i32, p, i64, p]),
         "tgnn_rows_scatter": (C.c_int, [p, p, i64, i32, p, i64, p]),
     }

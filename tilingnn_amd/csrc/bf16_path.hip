@@ -57,8 +57,18 @@ __global__ __launch_bounds__(256) void merge_bf16_kernel(const __bf16 *__restric
                                                          const __bf16 *__restrict__ a2, const float *__restrict__ st2,
                                                          const __bf16 *__restrict__ resid, int64_t n8, int c,
                                                          __bf16 *__restrict__ out) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
-        const int col = (int)((i * 8) % c);
+    // c divides the grid stride (c <= 2048 = 8 x 256): a thread keeps its 8 columns, the records are loaded once
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int col = (int)((i0 * 8) % c);
+    float m1h[8], m1l[8], g1[8], b1[8], m2h[8], m2l[8], g2[8], b2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int cc = col + k;
+        m1h[k] = st1[cc]; m1l[k] = st1[c + cc]; g1[k] = st1[2 * c + cc]; b1[k] = st1[3 * c + cc];
+        m2h[k] = st2 ? st2[cc] : 0.f; m2l[k] = st2 ? st2[c + cc] : 0.f;
+        g2[k] = st2 ? st2[2 * c + cc] : 1.f; b2[k] = st2 ? st2[3 * c + cc] : 0.f;
+    }
+    for (int64_t i = i0; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         float x1[8], x2[8], r[8];
         unpack8(reinterpret_cast<const bf16x8 *>(a1)[i], x1);
         unpack8(reinterpret_cast<const bf16x8 *>(a2)[i], x2);
@@ -66,9 +76,8 @@ __global__ __launch_bounds__(256) void merge_bf16_kernel(const __bf16 *__restric
         bf16x8 o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int cc = col + k;
-            const float y2 = st2 ? bn_apply1(x2[k], st2[cc], st2[c + cc], st2[2 * c + cc], st2[3 * c + cc]) : x2[k];
-            float v = bn_apply1(x1[k], st1[cc], st1[c + cc], st1[2 * c + cc], st1[3 * c + cc]) * y2;
+            const float y2 = st2 ? bn_apply1(x2[k], m2h[k], m2l[k], g2[k], b2[k]) : x2[k];
+            float v = bn_apply1(x1[k], m1h[k], m1l[k], g1[k], b1[k]) * y2;
             if (resid) v += r[k];
             o[k] = (__bf16)v;
         }
@@ -537,117 +546,125 @@ __global__ __launch_bounds__(kMlp64Threads, 2) void gin64_bf16_mlp_kernel(
 
 // ------------------------------------------------------------------------------------------ first final Linear
 // out [N, M] (fp32) = act(cat . W^T + b), cat = the slot-major bf16 skip buffer [S][N][64] read in place (TilinGNN.py:74-76),
-// W rounded to bf16 once (wb [M][K], K = 64 S).  Block = 4 waves, 128 rows x 128 outputs, one slot (64 k) per step staged
-// through LDS; wave (wr, wc) owns 64 x 64 as 2 x 2 v_mfma_f32_32x32x16_bf16 tiles.  Persistent over row tiles: one
+// W rounded to bf16 once (wb [M][K], K = 64 S).  Block = 8 waves, 128 rows x 256 outputs (every output column: the
+// 269 MB of activations are read ONCE), one slot (64 k) per step staged through LDS with the next step's pieces already
+// in registers; wave (wr, wc) owns 64 x 64 as 2 x 2 v_mfma_f32_32x32x16_bf16 tiles.  Persistent over row tiles: one
 // BatchNorm partial row per block.
-constexpr int kDbM = 128, kDbN = 128, kDbK = 64, kDbLd = kDbK + 8;   // LDS row pitch in bf16 (pad: 16 B)
+constexpr int kDbM = 128, kDbN = 256, kDbK = 64, kDbLd = kDbK + 8;   // LDS row pitch in bf16 (pad: 16 B)
+constexpr int kDbThreads = 512;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-__global__ __launch_bounds__(256) void dense_bf16_slots_kernel(const __bf16 *__restrict__ a, int64_t slot_stride, int n_slots,
-                                                               const __bf16 *__restrict__ wb, const float *__restrict__ bias,
-                                                               int64_t n, int out_dim, int act, float *__restrict__ out,
-                                                               double *__restrict__ bn_partial) {
+__global__ __launch_bounds__(kDbThreads) void dense_bf16_slots_kernel(const __bf16 *__restrict__ a, int64_t slot_stride,
+                                                                      int n_slots, const __bf16 *__restrict__ wb,
+                                                                      const float *__restrict__ bias, int64_t n, int out_dim,
+                                                                      int act, float *__restrict__ out,
+                                                                      double *__restrict__ bn_partial) {
     __shared__ __attribute__((aligned(16))) __bf16 As[kDbM * kDbLd];
     __shared__ __attribute__((aligned(16))) __bf16 Bsm[kDbN * kDbLd];
-    __shared__ double red[4][2][kDbN / 2];
+    __shared__ double red[2][2][kDbN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave >> 2, wc = wave & 3;
     const int li = lane & 31, lg = lane >> 5;
     const int K = n_slots * kDbK;
     const int64_t row_tiles = (n + kDbM - 1) / kDbM;
-    const int col_tiles = (out_dim + kDbN - 1) / kDbN;
-    for (int ct = 0; ct < col_tiles; ++ct) {
-        double csum[2][1], csq[2][1];                         // this lane's column (per N tile nt): col = li
-        csum[0][0] = csum[1][0] = csq[0][0] = csq[1][0] = 0.0;
-        for (int64_t rt = blockIdx.x; rt < row_tiles; rt += gridDim.x) {
-            f32x16 acc[2][2];
+    double csum[2] = {0.0, 0.0}, csq[2] = {0.0, 0.0};        // this lane's columns wc * 64 + j * 32 + li
+    // pieces of 16 bytes this thread moves per step: A 128 x 8 = 2 per thread, B 256 x 8 = 4 per thread
+    bf16x8 pa[2], pb[4];
+    auto fetch = [&](int64_t rt, int sl) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * kDbThreads, r = i >> 3, p = i & 7;
+            int64_t row = rt * kDbM + r;
+            row = row < n ? row : n - 1;
+            pa[u] = *reinterpret_cast<const bf16x8 *>(a + (int64_t)sl * slot_stride + row * kDbK + 8 * p);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + u * kDbThreads, r = i >> 3, p = i & 7;
+            const int o = r < out_dim ? r : out_dim - 1;
+            pb[u] = *reinterpret_cast<const bf16x8 *>(wb + (int64_t)o * K + sl * kDbK + 8 * p);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * kDbThreads, r = i >> 3, p = i & 7;
+            *reinterpret_cast<bf16x8 *>(As + r * kDbLd + 8 * p) = pa[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + u * kDbThreads, r = i >> 3, p = i & 7;
+            *reinterpret_cast<bf16x8 *>(Bsm + r * kDbLd + 8 * p) = pb[u];
+        }
+    };
+    for (int64_t rt = blockIdx.x; rt < row_tiles; rt += gridDim.x) {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        fetch(rt, 0);
+        for (int sl = 0; sl < n_slots; ++sl) {
+            __syncthreads();                                  // everybody is done reading the previous step's tiles
+            stash();
+            __syncthreads();
+            if (sl + 1 < n_slots) fetch(rt, sl + 1);          // in flight during the products
+#pragma unroll
+            for (int ks = 0; ks < kDbK / 16; ++ks) {
+                bf16x8 af[2], bf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    af[i] = *reinterpret_cast<const bf16x8 *>(As + (wr * 64 + i * 32 + li) * kDbLd + ks * 16 + lg * 8);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-            for (int sl = 0; sl < n_slots; ++sl) {
-                __syncthreads();
-                // stage A: 128 rows x 64 bf16 (8 x 16 B per row) and B: 128 outputs x 64 k
-                for (int i = tid; i < kDbM * 8; i += 256) {
-                    const int r = i >> 3, p = i & 7;
-                    int64_t row = rt * kDbM + r;
-                    row = row < n ? row : n - 1;
-                    const bf16x8 v = *reinterpret_cast<const bf16x8 *>(a + (int64_t)sl * slot_stride + row * kDbK + 8 * p);
-                    *reinterpret_cast<bf16x8 *>(As + r * kDbLd + 8 * p) = v;
-                }
-                for (int i = tid; i < kDbN * 8; i += 256) {
-                    const int r = i >> 3, p = i & 7;
-                    int o = ct * kDbN + r;
-                    o = o < out_dim ? o : out_dim - 1;
-                    const bf16x8 v = *reinterpret_cast<const bf16x8 *>(wb + (int64_t)o * K + sl * kDbK + 8 * p);
-                    *reinterpret_cast<bf16x8 *>(Bsm + r * kDbLd + 8 * p) = v;
-                }
-                __syncthreads();
-#pragma unroll
-                for (int ks = 0; ks < kDbK / 16; ++ks) {
-                    bf16x8 af[2], bf[2];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        af[i] = *reinterpret_cast<const bf16x8 *>(As + (wr * 64 + i * 32 + li) * kDbLd + ks * 16 + lg * 8);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        bf[j] = *reinterpret_cast<const bf16x8 *>(Bsm + (wc * 64 + j * 32 + li) * kDbLd + ks * 16 + lg * 8);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-                }
-            }
-            // epilogue: acc[i][j][e]: row = wr*64 + i*32 + (e&3) + 8*(e>>2) + 4*lg, col = wc*64 + j*32 + li
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = ct * kDbN + wc * 64 + j * 32 + li;
-                const float bcol = col < out_dim ? bias[col] : 0.f;
+                    bf[j] = *reinterpret_cast<const bf16x8 *>(Bsm + (wc * 64 + j * 32 + li) * kDbLd + ks * 16 + lg * 8);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int64_t row = rt * kDbM + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lg;
-                        float v = acc[i][j][e] + bcol;
-                        v = act_apply(v, act);
-                        if (row < n && col < out_dim) {
-                            out[row * out_dim + col] = v;
-                            csum[j][0] += (double)v;
-                            csq[j][0] += (double)v * (double)v;
-                        }
-                    }
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
         }
-        if (bn_partial) {
-            // fold the two row halves (lg) of a wave, then the two row-waves (wr) of a column half
+        // epilogue: acc[i][j][e]: row = wr*64 + i*32 + (e&3) + 8*(e>>2) + 4*lg, col = wc*64 + j*32 + li
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = wc * 64 + j * 32 + li;
+            const float bcol = col < out_dim ? bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t row = rt * kDbM + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lg;
+                    const float v = act_apply(acc[i][j][e] + bcol, act);
+                    if (row < n && col < out_dim) {
+                        out[row * out_dim + col] = v;
+                        csum[j] += (double)v;
+                        csq[j] += (double)v * (double)v;
+                    }
+                }
+        }
+    }
+    if (bn_partial) {
+        // fold the two row halves (lg) of a wave, then the two row-waves (wr) of a column
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            csum[j] += __shfl_xor(csum[j], 32, 64);
+            csq[j] += __shfl_xor(csq[j], 32, 64);
+        }
+        __syncthreads();
+        if (lg == 0) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                csum[j][0] += __shfl_xor(csum[j][0], 32, 64);
-                csq[j][0] += __shfl_xor(csq[j][0], 32, 64);
+                red[wr][0][wc * 64 + j * 32 + li] = csum[j];
+                red[wr][1][wc * 64 + j * 32 + li] = csq[j];
             }
-            __syncthreads();
-            if (lg == 0) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    red[wave][0][j * 32 + li] = csum[j][0];
-                    red[wave][1][j * 32 + li] = csq[j][0];
-                }
-            }
-            __syncthreads();
-            if (tid < kDbN) {                                 // column tid of this column tile
-                const int wcc = tid >> 6, c64 = tid & 63;
-                const int col = ct * kDbN + tid;
-                if (col < out_dim) {
-                    const double s0 = red[0 * 2 + wcc][0][c64] + red[1 * 2 + wcc][0][c64];
-                    const double s1 = red[0 * 2 + wcc][1][c64] + red[1 * 2 + wcc][1][c64];
-                    bn_partial[(int64_t)blockIdx.x * 2 * out_dim + col] = s0;
-                    bn_partial[(int64_t)blockIdx.x * 2 * out_dim + out_dim + col] = s1;
-                }
-            }
-            __syncthreads();
+        }
+        __syncthreads();
+        if (tid < kDbN && tid < out_dim) {
+            bn_partial[(int64_t)blockIdx.x * 2 * out_dim + tid] = red[0][0][tid] + red[1][0][tid];
+            bn_partial[(int64_t)blockIdx.x * 2 * out_dim + out_dim + tid] = red[0][1][tid] + red[1][1][tid];
         }
     }
 }
@@ -818,7 +835,7 @@ extern "C" int tgnn_collconv64_bf16_fwd(const void *h2_in_bf16, const int32_t *r
 extern "C" int tgnn_merge_bf16_fwd(const void *a1, const float *stat1, const void *a2, const float *stat2, const void *resid,
                                    int64_t n_nodes, int32_t c, void *out, tgnn_stream_t stream) {
     DeviceGuard guard__(stream);
-    TGNN_CHECK_ARG(n_nodes >= 0 && c >= 8 && c % 8 == 0, "shape");
+    TGNN_CHECK_ARG(n_nodes >= 0 && c >= 8 && c <= 2048 && (2048 % c) == 0, "width must divide 2048 (8 columns per thread)");
     if (n_nodes == 0) return TGNN_OK;
     TGNN_CHECK_ARG(a1 && stat1 && a2 && out, "null pointer");       /* stat2 == NULL: a2 is normalised already */
     const int64_t n8 = n_nodes * c / 8;
@@ -835,7 +852,8 @@ static int dense_bf16_slots_launch(const __bf16 *a, int64_t slot_stride, int n_s
     int64_t blocks = (n + kDbM - 1) / kDbM;
     if (blocks > TGNN_BN_MAX_PARTIALS) blocks = TGNN_BN_MAX_PARTIALS;
     if (blocks < 1) blocks = 1;
-    dense_bf16_slots_kernel<<<(unsigned)blocks, 256, 0, s>>>(a, slot_stride, n_slots, wb, bias, n, out_dim, act, out, bn_partial);
+    dense_bf16_slots_kernel<<<(unsigned)blocks, kDbThreads, 0, s>>>(a, slot_stride, n_slots, wb, bias, n, out_dim, act, out,
+                                                                    bn_partial);
     if (n_partials_host) *n_partials_host = (int32_t)blocks;
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
@@ -866,7 +884,7 @@ extern "C" size_t tgnn_forward_bf16_workspace_bytes(const tgnn_model_dims *dims,
  * structure and BatchNorm semantics as tgnn_forward.  Train mode only (the mode the reference runs inference in). */
 extern "C" int tgnn_forward_bf16(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
                                  const float *adj_edge_attr, const tgnn_graph *graph, int32_t update_running, float *probs,
-                                 void *ws, size_t ws_bytes, tgnn_stream_t stream) {
+                                 void *ws, size_t ws_bytes, tgnn_stream_t stream, tgnn_stream_t stream2) {
     DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(dims && dims->network_width == kC && dims->network_depth >= 1 && dims->network_depth <= kMaxDepth,
                    "the bf16-storage path is built for network_width 64");
@@ -888,6 +906,21 @@ extern "C" int tgnn_forward_bf16(const tgnn_model_dims *dims, const void *const 
         return TGNN_ERR_WORKSPACE;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // two-chain schedule as in tgnn_forward: the collision branch is a chain of its own (CollConv_i reads only CollConv_{i-1},
+    // TilinGNN.py:63) and runs on stream2 beside the adjacency branch; the chains meet in merge only
+    hipStream_t s2 = static_cast<hipStream_t>(stream2);
+    if (s2 == s) s2 = nullptr;
+    constexpr int kEv = 1 + 2 * kMaxDepth;        // [0] middle[0] done, [1 + i] CollConv_i done, [1 + kMaxDepth + i] merge_i done
+    static thread_local hipEvent_t ev_cache[64][kEv] = {};
+    hipEvent_t *ev = nullptr;
+    if (s2) {
+        int dev = 0;
+        TGNN_CHECK_HIP(hipGetDevice(&dev));
+        TGNN_CHECK_ARG(dev >= 0 && dev < 64, "device index");
+        if (!ev_cache[dev][0])
+            for (int k = 0; k < kEv; ++k) TGNN_CHECK_HIP(hipEventCreateWithFlags(&ev_cache[dev][k], hipEventDisableTiming));
+        ev = ev_cache[dev];
+    }
     const Params P{params_host, D};
     const float eps = 1e-5f, momentum = 0.1f;
     int32_t np1 = 0;
@@ -923,22 +956,31 @@ extern "C" int tgnn_forward_bf16(const tgnn_model_dims *dims, const void *const 
     finalize1(w.partf, np1, kC, P.bn(P.init(1) + 2), w.stat_i[1]);
     bn_apply_bf16_kernel<<<ew_grid64(n * kC), 256, 0, s>>>(w.ainit, w.stat_i[1], n, kC, w.mid);
     // ---- main loop.  a2[i & 1] holds h2_i = the collision branch's BatchNorm OUTPUT (stored normalised, see the MLP kernel)
+    if (s2) {
+        TGNN_CHECK_HIP(hipEventRecord(ev[0], s));
+        TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[0], 0));
+    }
+    hipStream_t sc = s2 ? s2 : s;
     for (int i = 0; i < D; ++i) {
         const int b = P.layer(i);
         const __bf16 *h1 = w.mid + (size_t)i * n * kC;
         const __bf16 *h2_in = i == 0 ? w.mid : w.a2[(i - 1) & 1];
+        if (s2 && i >= 2) TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[1 + kMaxDepth + i - 2], 0));   // a2[i & 1] was read by merge_{i-2}
         TGNN_TRY64(collconv64_launch(h2_in, graph->col_rowptr, graph->col_src, P.f(b + 13), P.f(b + 14), P.f(b + 15), P.f(b + 16),
                                      P.f(b + 17), P.f(b + 18), P.f(b + 19), bn_job(nullptr, 0, P.bn(b + 20), w.stat2[i & 1]), n, n,
-                                     eps, momentum, w.a2[i & 1], w.z, w.part2, s));
+                                     eps, momentum, w.a2[i & 1], w.z, w.part2, sc));
+        if (s2) TGNN_CHECK_HIP(hipEventRecord(ev[1 + i], s2));
         TGNN_TRY64(launch_nnconv64(h1, n, graph->nn_tile_col_ptr, graph->nn_col_meta, graph->nn_col_src,
                                    w.wimg + (size_t)i * (T + 1) * kC * kC, T, P.f(b + 7), n, TGNN_ACT_LEAKY_RELU, w.a1, w.part1,
                                    &np1, s));
         BnJobs jobs{};
         jobs.job[0] = bn_job(w.part1, np1, P.bn(b + 8), w.stat1);
         launch_bn_finalize(jobs, 1, 0, kC, n, eps, momentum, s);
+        if (s2) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[1 + i], 0));
         const __bf16 *resid = i >= 2 ? w.mid + (size_t)(i - 2) * n * kC : nullptr;
         merge_bf16_kernel<<<ew_grid64(n * kC / 8), 256, 0, s>>>(w.a1, w.stat1, w.a2[i & 1], nullptr, resid, n * kC / 8, kC,
                                                                 w.mid + (size_t)(i + 1) * n * kC);
+        if (s2) TGNN_CHECK_HIP(hipEventRecord(ev[1 + kMaxDepth + i], s));
     }
     // ---- final MLP: the first Linear reads the bf16 skip buffer in place, the rest runs on the fp32 dense kernels
     {

@@ -138,5 +138,5 @@ def forward(net, x: Tensor, adj_e_index: Tensor, adj_e_features: Tensor, col_e_i
     probs = torch.empty(n, net.output_dim, dtype=torch.float32, device=dev)
     g = graph.c_struct()
     check(lib.tgnn_forward_bf16(C.byref(dims), table, ptr(ops._f32c(x, "x")), ptr(ops._f32c(adj_e_features, "adj_e_features")),
-                                C.byref(g), 1, ptr(probs), ptr(ws), ws_bytes, _lib.current_stream(dev)))
+                                C.byref(g), 1, ptr(probs), ptr(ws), ws_bytes, _lib.current_stream(dev), _lib.side_stream(dev)))
     return probs
