@@ -351,6 +351,44 @@ def main():
             del xb, adjb, attrb, colb
             torch.cuda.empty_cache()
 
+    # ---- BASELINE config 3: 30-60-90 + equilateral (tile_count 4), the same 100k / 1M / 1.25M graph shape, network_width 64,
+    #      bf16 activation storage (csrc/bf16_path.hip); fp32 accumulate, fp64 BatchNorm sums.  Step = forward incl. graph prep.
+    config3 = None
+    if not sharded and not args.no_extra_sizes:
+        sg3 = make_super_graph(args.nodes_per_gpu, int(ADJ_PER_GPU * scale), int(COL_PER_GPU * scale), tile_count=4,
+                               n_edge_types=N_TYPES, seed=2)
+        x3, adj3, attr3, col3, _ = sg3.to_torch(dev)
+        net3 = TilinGNN(adj_edge_features_dim=fe, network_depth=DEPTH, network_width=64, node_features_dim=5)
+        net3.load_state_dict(make_state_dict(fe, DEPTH, 64, 1, 5, seed=0), strict=True)
+        net3 = net3.to(dev).train()
+        net3.activation_dtype = torch.bfloat16
+        res3 = {}
+        for cached in (False, True):
+            net3.cache_graph = cached
+            for _ in range(3):
+                net3(x=x3, adj_e_index=adj3, adj_e_features=attr3, col_e_idx=col3)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(max(5, args.steps // 2)):
+                tb = time.perf_counter()
+                p3 = net3(x=x3, adj_e_index=adj3, adj_e_features=attr3, col_e_idx=col3)[0]
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - tb) * 1e3)
+            res3["cached_layout_ms" if cached else "ms_per_step"] = sorted(ts)[len(ts) // 2]
+        assert bool(torch.isfinite(p3).all())
+        n3, ea3, ec3 = int(x3.shape[0]), int(adj3.shape[1]), int(col3.shape[1])
+        b3 = forward_bytes(n3, ea3, ec3, N_TYPES, fe=fe, fx=5, c=64, d=DEPTH, s=2)
+        config3 = {"workload": f"TilinGNN.forward, {n3} nodes / {ea3} + {ec3} edges, tile_count 4 (Fx 5), T=13, width 64, depth 20, "
+                               "bf16 storage of the skip buffer and branch outputs, fp32 accumulate, graph prep included",
+                   "dtype": "bf16 storage / f32 accumulate", "ms_per_step": res3["ms_per_step"],
+                   "value": n3 / (res3["ms_per_step"] * 1e-3), "cached_layout_ms": res3["cached_layout_ms"],
+                   "whole_forward": {"algorithmic_bytes": b3, "frac_of_hbm_peak": b3 / (res3["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                   "nnconv_algorithmic_bytes_per_launch": nnconv_bytes(n3, ea3, N_TYPES, c=64, s=2),
+                   "profile": "profiles/r02_config3_kernel_stats.txt (rocprofv3 --kernel-trace --stats of scratch/time_config3.py), "
+                              "profiles/r02_config3_pmc.txt (HBM / MFMA counters of nnconv64_bf16_cols_kernel)"}
+        del net3, x3, adj3, attr3, col3
+        torch.cuda.empty_cache()
+
     # ---- the loss ML_Solver.predict evaluates on the probabilities: two launches, HBM bound
     loss_info = None
     if not sharded:
@@ -475,6 +513,8 @@ def main():
             line["kernel_classes"] = class_ms
         if extras is not None:
             line["larger_layouts_single_gpu"] = extras
+        if config3 is not None:
+            line["config3_width64_bf16"] = config3
         if sharded:
             import torch.distributed as dist
             line["collectives"] = {"backend": dist.get_backend(), "ranks_seen": dist.get_world_size(),
