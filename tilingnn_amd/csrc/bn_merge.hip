@@ -242,6 +242,104 @@ __global__ __launch_bounds__(256) void merge_bn1_kernel(const float *__restrict_
     }
 }
 
+// The same for layouts whose producer emits many partial rows (one per CU: 224 at 100k nodes): 1024 threads per block
+// reduce them exactly as bn_finalize_kernel does (16 row groups x 64 columns, every thread ONE batch of independent loads,
+// then the fixed 16-way fold: the same tree, the same bits), so that NNConv -> merge needs no launch in between.  256 blocks
+// x 115 KB of partial rows come out of L2; the element-wise part then walks ~3 float4 per thread.
+__global__ __launch_bounds__(1024) void merge_bn1_wide_kernel(const float *__restrict__ a1, BnJob j1, int64_t n_total, float eps,
+                                                              float momentum, const float *__restrict__ a2,
+                                                              const float *__restrict__ st2, const float *__restrict__ resid,
+                                                              int64_t n4, float *__restrict__ out) {
+    constexpr int c = 32, two_f = 64, groups = 16;
+    __shared__ double red[groups * two_f];
+    __shared__ double tot[two_f];
+    __shared__ __attribute__((aligned(16))) float st1[4 * c];
+    __shared__ __attribute__((aligned(16))) float st2s[4 * c];
+    const int tid = threadIdx.x;
+    float pre_gamma = 1.f, pre_beta = 0.f, pre_rm = 0.f, pre_rv = 1.f;
+    if (tid < c) {
+        pre_gamma = j1.gamma[tid];
+        pre_beta = j1.beta[tid];
+        if (blockIdx.x == 0 && j1.running_mean) {
+            pre_rm = j1.running_mean[tid];
+            pre_rv = j1.running_var[tid];
+        }
+    }
+    if (tid >= 1024 - 4 * c) st2s[tid - (1024 - 4 * c)] = st2[tid - (1024 - 4 * c)];
+    {
+        const int j = tid % two_f, g = tid / two_f;
+        const double *src = j1.partials + j;
+        double acc = 0.0;
+        int p = g;
+        for (; p + 31 * groups < j1.n_partials; p += 32 * groups) {
+            double v[32];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) v[q] = src[(int64_t)(p + q * groups) * two_f];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) acc += v[q];
+        }
+        for (; p + 7 * groups < j1.n_partials; p += 8 * groups) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = src[(int64_t)(p + q * groups) * two_f];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += v[q];
+        }
+        for (; p < j1.n_partials; p += groups) acc += src[(int64_t)p * two_f];
+        red[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < two_f) {
+        double t = 0.0;
+        for (int gg = 0; gg < groups; ++gg) t += red[gg * two_f + tid];
+        tot[tid] = t;
+    }
+    __syncthreads();
+    if (tid < c) {
+        const double inv_n = 1.0 / (double)n_total;
+        const double mean = tot[tid] * inv_n;
+        double var = tot[c + tid] * inv_n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float mh = (float)mean;
+        st1[tid] = mh;
+        st1[c + tid] = (float)(mean - (double)mh);
+        st1[2 * c + tid] = (float)((double)pre_gamma / sqrt(var + (double)eps));
+        st1[3 * c + tid] = pre_beta;
+        if (blockIdx.x == 0) {
+            if (j1.stat) {
+                j1.stat[tid] = st1[tid]; j1.stat[c + tid] = st1[c + tid];
+                j1.stat[2 * c + tid] = st1[2 * c + tid]; j1.stat[3 * c + tid] = st1[3 * c + tid];
+            }
+            if (j1.running_mean) {
+                const double unbiased = n_total > 1 ? var * ((double)n_total / (double)(n_total - 1)) : var;
+                j1.running_mean[tid] = (float)((1.0 - (double)momentum) * (double)pre_rm + (double)momentum * mean);
+                j1.running_var[tid] = (float)((1.0 - (double)momentum) * (double)pre_rv + (double)momentum * unbiased);
+            }
+            if (tid == 0 && j1.num_batches_tracked) *j1.num_batches_tracked += 1;
+        }
+    }
+    __syncthreads();
+    const int col = (tid * 4) % c;                            // (the grid stride is a multiple of 32 floats)
+    const float4 m1h = *reinterpret_cast<const float4 *>(st1 + col), m1l = *reinterpret_cast<const float4 *>(st1 + c + col);
+    const float4 g1 = *reinterpret_cast<const float4 *>(st1 + 2 * c + col), b1 = *reinterpret_cast<const float4 *>(st1 + 3 * c + col);
+    const float4 m2h = *reinterpret_cast<const float4 *>(st2s + col), m2l = *reinterpret_cast<const float4 *>(st2s + c + col);
+    const float4 g2 = *reinterpret_cast<const float4 *>(st2s + 2 * c + col), b2 = *reinterpret_cast<const float4 *>(st2s + 3 * c + col);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + tid; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 x1 = reinterpret_cast<const float4 *>(a1)[i];
+        const float4 x2 = reinterpret_cast<const float4 *>(a2)[i];
+        float4 o;
+        o.x = bn_apply1(x1.x, m1h.x, m1l.x, g1.x, b1.x) * bn_apply1(x2.x, m2h.x, m2l.x, g2.x, b2.x);
+        o.y = bn_apply1(x1.y, m1h.y, m1l.y, g1.y, b1.y) * bn_apply1(x2.y, m2h.y, m2l.y, g2.y, b2.y);
+        o.z = bn_apply1(x1.z, m1h.z, m1l.z, g1.z, b1.z) * bn_apply1(x2.z, m2h.z, m2l.z, g2.z, b2.z);
+        o.w = bn_apply1(x1.w, m1h.w, m1l.w, g1.w, b1.w) * bn_apply1(x2.w, m2h.w, m2l.w, g2.w, b2.w);
+        if (resid) {
+            const float4 r = reinterpret_cast<const float4 *>(resid)[i];
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        reinterpret_cast<float4 *>(out)[i] = o;
+    }
+}
+
 __global__ void rows_gather_kernel(const float *__restrict__ src, int64_t ld, const int *__restrict__ idx, int64_t n_idx,
                                    int c, float *__restrict__ out, int64_t ld_out) {
     const int64_t total = n_idx * c;
@@ -479,6 +577,12 @@ void launch_shard_sum_peers(const double *peer_sums, const double *own, int worl
 void launch_merge_bn1(const float *a1, const BnJob &j1, int64_t n_total, float eps, float momentum, const float *a2,
                       const float *stat2, const float *resid, int64_t n_nodes, float *out, hipStream_t s) {
     const int64_t n4 = n_nodes * 32 / 4;
+    if (j1.n_partials > 128) {
+        int64_t blocks = (n4 + 1023) / 1024;
+        if (blocks > 256) blocks = 256;
+        merge_bn1_wide_kernel<<<(unsigned)blocks, 1024, 0, s>>>(a1, j1, n_total, eps, momentum, a2, stat2, resid, n4, out);
+        return;
+    }
     int64_t blocks = (n4 + 255) / 256;
     if (blocks > 256) blocks = 256;          // every block repeats the statistics reduction
     merge_bn1_kernel<<<(unsigned)blocks, 256, 0, s>>>(a1, j1, n_total, eps, momentum, a2, stat2, resid, n4, out);

@@ -446,7 +446,9 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         // Few partial rows (small layouts): merge derives the first BatchNorm's record from them itself -- one launch
         // less on the critical chain of a launch-latency-bound forward.  (With the 256 rows of a 100k-node layout the
         // repeated reduction costs every merge block more than the separate 1-block finalize: measured.)
-        constexpr int fuse_rows = 128;
+        // (round 2: with 1024-thread blocks -- one batch of independent loads per thread -- the repeated reduction pays at every
+        //  size: the launch it replaces sits on the critical NNConv -> merge chain.  TGNN_BN_MAX_PARTIALS rows at most.)
+        constexpr int fuse_rows = TGNN_BN_MAX_PARTIALS;
         const bool fused_bn1 = c == 32 && !use_running_stats && !sh && np1 <= fuse_rows;
         if (s2) {
             if (!fused_bn1) {
