@@ -226,8 +226,12 @@ __global__ __launch_bounds__(kMlpThreads, 2) void gin32_mlp_kernel(
         }
         // ---- epilogue: row fn, features 4 q + r and 16 + 4 q + r
         float4 r0, r1;
-        r0.x = sigmoidf_(o0[0]); r0.y = sigmoidf_(o0[1]); r0.z = sigmoidf_(o0[2]); r0.w = sigmoidf_(o0[3]);
-        r1.x = sigmoidf_(o1[0]); r1.y = sigmoidf_(o1[1]); r1.z = sigmoidf_(o1[2]); r1.w = sigmoidf_(o1[3]);
+        // the OUTPUT sigmoid in full precision (libm expf + IEEE division, ~1.5 ulp instead of the hardware
+        // transcendentals' ~3): the BatchNorm behind this kernel divides columns that vary by ~1 % of their value, so
+        // every ulp here is ~100 ulp there (CollConv incl. BatchNorm vs fp64: 1.4e-5 with the fast form)
+        auto sig_out = [](float v) { return 1.0f / (1.0f + expf(-v)); };
+        r0.x = sig_out(o0[0]); r0.y = sig_out(o0[1]); r0.z = sig_out(o0[2]); r0.w = sig_out(o0[3]);
+        r1.x = sig_out(o1[0]); r1.y = sig_out(o1[1]); r1.z = sig_out(o1[2]); r1.w = sig_out(o1[3]);
         if (act == TGNN_ACT_LEAKY_RELU) {
             r0.x = leakyf_(r0.x); r0.y = leakyf_(r0.y); r0.z = leakyf_(r0.z); r0.w = leakyf_(r0.w);
             r1.x = leakyf_(r1.x); r1.y = leakyf_(r1.y); r1.z = leakyf_(r1.z); r1.w = leakyf_(r1.w);
