@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void nnconv64_image_kernel(const float *__rest
     }
 }
 
-constexpr int kMetaFirst = 1 << 8, kMetaLast = 1 << 9, kMetaEnd = 1 << 10, kMetaSkip = 1 << 11;
+constexpr int kMetaFirst = 1 << 8, kMetaEnd = 1 << 10, kMetaSkip = 1 << 11;    // (bit 9: last of a run, unused here)
 constexpr int kStage64 = 16 * 20;
 
 // Same column structure and the same walk as nnconv32_cols_kernel (one wave = a run of 16-row tiles, columns streamed
@@ -302,14 +302,8 @@ static int launch_nnconv64(const __bf16 *h, int64_t n_src_rows, const int32_t *t
                            int32_t act, __bf16 *out, double *bn_partial, int32_t *n_partials_host, hipStream_t s) {
     constexpr int WAVES = 16;
     auto kern = nnconv64_bf16_cols_kernel<WAVES>;
-    static std::atomic<bool> attr_set[64];
-    int dev = 0;
-    TGNN_CHECK_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
-        TGNN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)kMaxLds64));
-        if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
-    }
+    static LdsOptIn site;
+    TGNN_CHECK_HIP(opt_in_dynamic_lds(kern, (int)kMaxLds64, site));
     const int64_t n_tiles = (n_nodes + 15) / 16;
     int64_t blocks = (n_tiles + 3) / 4;
     const int64_t cap = 256 - 32;                            // (CUs left to the collision chain, as in the fp32 path)

@@ -438,12 +438,8 @@ static void launch_dense_split(int blocks_x, hipStream_t s, const float *a, int6
     size_t lds = (size_t)3 * (BM + BN) * kSplitLd * 2;
     const size_t red = (size_t)(4 / WN) * 2 * BN * sizeof(double);
     if (red > lds) lds = red;
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dense_split_kernel<TM, WN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-        attr_set = true;
-    }
+    static LdsOptIn site;
+    if (lds > 64 * 1024) (void)opt_in_dynamic_lds(dense_split_kernel<TM, WN>, 160 * 1024 - 256, site);
     dense_split_kernel<TM, WN><<<dim3(blocks_x, (out_dim + BN - 1) / BN), 256, lds, s>>>(
         a, lda, akb, kps, in_stat, w, b, n, in_dim, out_dim, act, out, ldo, bn_partial);
 }

@@ -410,12 +410,8 @@ extern "C" int tgnn_nnconv_mean_fwd(const float *h, int64_t ldh, const int32_t *
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t lds_bytes = (size_t)(n_types + 1) * kTypeStride * sizeof(float);
     if (c == 32 && lds_bytes <= kMaxDynLds) {
-        static bool attr_set = false;  // idempotent, racing setters write the same value
-        if (!attr_set) {
-            TGNN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nnconv32_lds_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds));
-            attr_set = true;
-        }
+        static LdsOptIn site;
+        TGNN_CHECK_HIP(opt_in_dynamic_lds(nnconv32_lds_kernel, (int)kMaxDynLds, site));
         // one wave per row; at least one row per wave; a multiple of 8 blocks for the XCD split;
         // at most one block per CU (the LDS image is per block)
         int blocks = producer_blocks(n_nodes, kNNWaves);

@@ -315,14 +315,8 @@ static int launch_cols_t(const float *h, int64_t ldh, const int32_t *tile_col_pt
                          int blocks_per_cu, hipStream_t s) {
     auto kern = nnconv32_cols_kernel<DEPTH, WAVES, OCC>;
     // the opt-in to > 64 KB of dynamic LDS is a per-device attribute of the function: set once per device (idempotent)
-    static std::atomic<bool> attr_set[64];
-    int dev = 0;
-    TGNN_CHECK_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
-        TGNN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kColsMaxLds));
-        if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
-    }
+    static LdsOptIn site;
+    TGNN_CHECK_HIP(opt_in_dynamic_lds(kern, (int)kColsMaxLds, site));
     const int64_t n_tiles = (n_nodes + 15) / 16;
     // One tile per SIMD before a second wave of a SIMD gets one: a small layout is bound by the latency of a tile, and
     // waves that share a SIMD stretch each other's (matrix and vector issue do not overlap).  Large layouts hit the cap.

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "../../include/tgnn.h"
 
 namespace tgnn {
@@ -59,6 +61,23 @@ struct DeviceGuard {
     DeviceGuard(const DeviceGuard &) = delete;
     DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
+
+// The opt-in to more than 64 KB of dynamic LDS is a per-device attribute of a kernel: applied once per device and
+// call site (`done` = that site's static flag array; idempotent, racing setters write the same value).
+struct LdsOptIn {
+    std::atomic<bool> done[64];
+};
+template <class Kern>
+static inline hipError_t opt_in_dynamic_lds(Kern kern, int bytes, LdsOptIn &site) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const bool tracked = dev >= 0 && dev < 64;
+    if (tracked && site.done[dev].load(std::memory_order_acquire)) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && tracked) site.done[dev].store(true, std::memory_order_release);
+    return e;
+}
 
 // Carves aligned sub-buffers out of a caller-provided workspace.
 struct Carver {
