@@ -327,6 +327,15 @@ int tgnn_forward_sharded(const tgnn_model_dims *dims, const void *const *params_
                          const float *adj_edge_attr, const tgnn_graph *graph, const tgnn_shard *shard,
                          int32_t update_running, float *probs, void *ws, size_t ws_bytes, tgnn_stream_t stream);
 
+/* Small layouts (what the greedy loop of the reference scores: 1 254 nodes for the labyrinth example): tgnn_forward runs
+ * the message-passing layers (TilinGNN.py:59-71) as ONE persistent kernel with grid barriers instead of ~5 dependent
+ * launches per layer (csrc/forward_small.hip) when the layout has at most this many nodes, width 32, train-mode
+ * BatchNorm and few enough edge types for the weights to sit in LDS.  Same formulas; the BatchNorm sums and the NNConv
+ * tile products are associated differently than in the general schedule (fp64 / fp32 rounding), deterministic either way.
+ * Process-wide setting, default 16384; 0 switches the path off (the general schedule then runs at every size). */
+void tgnn_set_small_layout_limit(int64_t n_nodes);
+int64_t tgnn_get_small_layout_limit(void);
+
 /* The same forward with a hipEvent pair around every launch (on `stream`, where the kernels run);
  * synchronises, then ADDS the elapsed milliseconds and launch counts per kernel class into the
  * two host arrays of TGNN_PROF_CLASSES entries.  Measurement aid for bench.py's roofline line. */

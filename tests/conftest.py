@@ -15,3 +15,17 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(REPO, "tests", "golden")
+
+
+@pytest.fixture
+def general_schedule():
+    """Layouts of up to 4 096 nodes normally run the layer loop as one persistent kernel (csrc/forward_small.hip), which
+    associates the BatchNorm / tile sums differently than the general launch schedule.  Tests that compare the general
+    schedule's variants bit for bit (two streams vs one, sharded vs unsharded) switch it off."""
+    from tilingnn_amd import _lib
+    before = _lib.lib.tgnn_get_small_layout_limit()
+    _lib.lib.tgnn_set_small_layout_limit(0)
+    try:
+        yield
+    finally:
+        _lib.lib.tgnn_set_small_layout_limit(before)

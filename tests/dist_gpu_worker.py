@@ -35,6 +35,8 @@ def main():
     ref_net = TilinGNN(adj_edge_features_dim=15, network_depth=depth, network_width=32, node_features_dim=3)
     ref_net.load_state_dict(make_state_dict(15, depth, 32, 1, 3, seed=0), strict=True)
     ref_net = ref_net.to(dev).train()
+    from tilingnn_amd import _lib
+    _lib.lib.tgnn_set_small_layout_limit(0)      # the sharded step runs the general schedule's kernels: compare with those
     x, adj, attr, col, _ = sg.to_torch(dev)
     want = ref_net(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)[0]
     lo = runner.shard.lo

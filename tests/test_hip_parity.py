@@ -584,7 +584,7 @@ def test_errors_are_loud(dev):
 
 # ------------------------------------------------------------------------------------------ sharded path on one GPU
 @pytest.mark.parametrize("world", [2, 4])
-def test_sharded_hip_path_matches_unsharded(dev, world):
+def test_sharded_hip_path_matches_unsharded(dev, world, general_schedule):
     """tilingnn_amd.dist with the HIP backend, P virtual ranks stepped in lock-step on this one GPU
     (LocalSimComm): same ShardProgram, kernels, halo layout and BN-sum exchange as the RCCL path.
     A shallow network keeps the comparison out of the chaotic regime; depth 20 is sanity-checked."""
@@ -614,7 +614,7 @@ def test_sharded_hip_path_matches_unsharded(dev, world):
 
 
 @pytest.mark.parametrize("world,one_collective", [(1, True), (2, True), (4, True), (3, True), (2, False), (4, False)])
-def test_fused_sharded_forward_matches_unsharded(dev, world, one_collective):
+def test_fused_sharded_forward_matches_unsharded(dev, world, one_collective, general_schedule):
     """tgnn_forward_sharded (the whole shard schedule in one library call, collectives through callbacks): P
     virtual ranks = P threads on this one GPU (ThreadSimCollectives) against the unsharded forward; both collective
     schemes: one all-to-all per layer carrying raw halo rows + BatchNorm sums (default) and all-reduce + all-to-all;
@@ -690,7 +690,7 @@ def test_split_precision_kernels_hold_fp32_accuracy_across_magnitudes(dev, scale
 
 
 @pytest.mark.parametrize("n_nodes,columns", [(20000, True), (2000, True), (2000, False), (300, False)])
-def test_two_chain_schedule_is_bit_identical_to_one_stream(dev, n_nodes, columns):
+def test_two_chain_schedule_is_bit_identical_to_one_stream(dev, n_nodes, columns, general_schedule):
     """tgnn_forward with the collision chain on a side stream (default) and with everything on one stream produce
     the same bits: same kernels, same reduction trees, only the interleaving differs (small layouts: merge derives the
     first BatchNorm's record from the partial rows itself)."""

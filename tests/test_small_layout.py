@@ -1,0 +1,137 @@
+"""Small layouts: the persistent whole-layer-loop kernel (csrc/forward_small.hip) against the general launch schedule
+(same formulas, different association of the BatchNorm / tile sums) and against the fp64 oracle."""
+import contextlib
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tilingnn_oracle as orc
+from tests.golden_util import graph_tensors, load_labyrinth_graph, load_npz
+from tests.test_hip_parity import make_net
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+@contextlib.contextmanager
+def small_limit(n):
+    from tilingnn_amd import _lib
+    before = _lib.lib.tgnn_get_small_layout_limit()
+    _lib.lib.tgnn_set_small_layout_limit(n)
+    try:
+        yield
+    finally:
+        _lib.lib.tgnn_set_small_layout_limit(before)
+
+
+def _forward_with_slots(net, inputs, n, dev, update_running=0):
+    """tgnn_forward on a zeroed workspace; returns (probs, skip-buffer slots [D + 1, n, 32]) -- the slots are the first
+    carve of the workspace (csrc/forward.hip: carve)."""
+    from tilingnn_amd import _lib, ops
+    x, adj, adj_attr, col = inputs
+    graph = ops.prepare_graph(n, adj, adj_attr, col)
+    dims = net._dims()
+    table, _ = net._param_table()
+    ws_bytes = _lib.lib.tgnn_forward_workspace_bytes(C.byref(dims), n, graph.n_types)
+    ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
+    probs = torch.empty(n, 1, device=dev)
+    g = graph.c_struct()
+    _lib.check(_lib.lib.tgnn_forward(C.byref(dims), table, ops.ptr(x), ops.ptr(adj_attr), C.byref(g), update_running, 0,
+                                    ops.ptr(probs), ops.ptr(ws), ws_bytes, _lib.current_stream(dev), _lib.side_stream(dev)))
+    torch.cuda.synchronize()
+    d = net.network_depth
+    slots = ws[: (d + 1) * n * 32 * 4].view(torch.float32).view(d + 1, n, 32).clone()
+    return probs.cpu(), slots.cpu()
+
+
+def _synthetic(n, dev, seed=5):
+    from tilingnn_amd.synth import make_super_graph
+    ea, ec = (10 * n, 12 * n + n // 2) if n >= 100 else (4 * n, 3 * n)
+    sg = make_super_graph(n, ea, ec, tile_count=2, n_edge_types=13, seed=seed)
+    x, adj, adj_attr, col, _ = sg.to_torch(dev)
+    return (x, adj, adj_attr, col)
+
+
+@pytest.mark.parametrize("n", [17, 300, 1254, 2000, 3333, 4096])
+def test_small_kernel_matches_the_general_schedule_layer_by_layer(dev, n):
+    """Depth 3 (residual, two-deep collision buffers, BatchNorm folding all exercised): every slot of the skip buffer."""
+    from tilingnn_amd import _lib
+    assert _lib.lib.tgnn_get_small_layout_limit() >= 4096
+    inputs = _synthetic(n, dev)
+    net, _ = make_net(dev, depth=3)
+    with small_limit(0):
+        p_gen, s_gen = _forward_with_slots(net, inputs, n, dev)
+    p_small, s_small = _forward_with_slots(net, inputs, n, dev)
+    assert torch.equal(s_gen[0], s_small[0])                    # the init MLP is the same kernels
+    for k in range(1, 4):
+        err = orc.rel_max_err(s_small[k], s_gen[k].double())
+        print(f"n {n} slot {k}: {err:.2e}")
+        # BatchNorm of near-constant collision columns amplifies the last-bit differences of the sums
+        assert err < 2e-5 * (4 ** (k - 1)), (k, err)
+    assert not torch.equal(s_gen[1], s_small[1])                # (it IS a different path)
+    assert float((p_small - p_gen).abs().max()) < 1e-3
+
+
+def test_layouts_above_the_limit_take_the_general_schedule(dev):
+    inputs = _synthetic(4097, dev)
+    net, _ = make_net(dev, depth=3)
+    with small_limit(0):
+        p_gen, s_gen = _forward_with_slots(net, inputs, 4097, dev)
+    p, s = _forward_with_slots(net, inputs, 4097, dev)
+    assert torch.equal(p, p_gen) and torch.equal(s, s_gen)
+
+
+def test_small_kernel_on_the_real_graph_against_the_reference(dev):
+    g = load_labyrinth_graph()
+    ref = load_npz("ref_forward_labyrinth.npz")
+    inputs = graph_tensors(g, torch.float32, dev)[:4]
+    gaps = {}
+    for name, limit in (("general", 0), ("small", 4096)):
+        net, _ = make_net(dev)
+        with small_limit(limit):
+            probs, _ = _forward_with_slots(net, inputs, 1254, dev, update_running=1)
+        gaps[name] = float(np.abs(probs.numpy() - ref["probs_fp64"]).max())
+        sd = net.state_dict()
+        for k, tol in (("init_node_feature_trans.mlp.0.batch_norm", 1e-5), ("brch_1_graph_conv_layers.0.batch_norm", 1e-3)):
+            np.testing.assert_allclose(sd[k + ".running_mean"].cpu().numpy(), ref[k + ".running_mean"], rtol=tol, atol=tol)
+            np.testing.assert_allclose(sd[k + ".running_var"].cpu().numpy(), ref[k + ".running_var"], rtol=tol, atol=tol)
+        assert all(int(v) == 1 for k, v in sd.items() if k.endswith("num_batches_tracked"))
+    print("max |p - p_fp64| on the labyrinth graph:", gaps)
+    assert gaps["small"] < 1e-2 and gaps["general"] < 1e-2
+
+
+@pytest.mark.parametrize("n", [1254, 2500, 4096])
+def test_small_kernel_is_bit_reproducible(dev, n):
+    """Cross-block data moves through sc1 loads / stores and a counter barrier without cache maintenance: a stale read
+    would show up as run-to-run differences."""
+    inputs = _synthetic(n, dev, seed=11)
+    net, _ = make_net(dev)
+    first = None
+    for _ in range(12):
+        probs, slots = _forward_with_slots(net, inputs, n, dev)
+        if first is None:
+            first = (probs, slots)
+        else:
+            assert torch.equal(first[0], probs) and torch.equal(first[1], slots)
+
+
+def test_small_kernel_running_statistics_match_the_general_schedule(dev):
+    inputs = _synthetic(3000, dev, seed=3)
+    sds = []
+    for limit in (0, 4096):
+        net, _ = make_net(dev, depth=4)
+        with small_limit(limit):
+            _forward_with_slots(net, inputs, 3000, dev, update_running=1)
+        sds.append({k: v.detach().cpu().double() for k, v in net.state_dict().items()})
+    for k in sds[0]:
+        if "running" in k:
+            assert orc.rel_max_err(sds[1][k], sds[0][k]) < 1e-4, k
+        elif k.endswith("num_batches_tracked"):
+            assert int(sds[0][k]) == int(sds[1][k]) == 1, k

@@ -77,6 +77,9 @@ static bool dims_ok(const tgnn_model_dims *d) {
 struct Workspace {
     float *mid, *a1, *a2[2], *t0, *f1, *f2, *f3, *f4, *wtab, *wimg;
     double *part1, *part2, *partf;
+    float *small_pack;            // small-layout kernel: per-layer parameter packs, its partial rows, its barrier counter
+    double *small_part;
+    unsigned *small_ctr;
     float *stat1, *stat2[2], *stat_i[2], *stat_f[4];
     size_t bytes;
 };
@@ -137,6 +140,9 @@ static Workspace carve(const tgnn_model_dims &d, int64_t n, int64_t nr, int32_t 
     w.part1 = cv.take<double>((size_t)TGNN_BN_MAX_PARTIALS * 2 * c);
     w.part2 = cv.take<double>((size_t)TGNN_BN_MAX_PARTIALS * 2 * c);
     w.partf = cv.take<double>((size_t)TGNN_BN_MAX_PARTIALS * 2 * 256);
+    w.small_pack = cv.take<float>(small_pack_floats(D));
+    w.small_part = cv.take<double>((size_t)256 * 128);
+    w.small_ctr = cv.take<unsigned>(64);
     w.stat1 = cv.take<float>(4 * c);
     w.stat2[0] = cv.take<float>(4 * c);
     w.stat2[1] = cv.take<float>(4 * c);
@@ -345,6 +351,9 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         launch_nnconv_weight_image(w.wtab, roots, T, D, w.wimg, sw);
         prof.end();
     }
+    // Small layouts: the layer loop below is replaced by one persistent kernel (forward_small.hip)
+    const int small_teams = (tiled && !sh && !keep && !use_running_stats && !prof.on && nr == n) ? small_layout_teams(n, T, D) : 0;
+    if (small_teams) launch_small_pack(P, D, w.small_pack, w.small_ctr, sw);
     if (sw != s) TGNN_CHECK_HIP(hipEventRecord(ev[kEvWeights], s2));
 
     // ---- K10: init MLP  (TilinGNN.py:54)
@@ -384,12 +393,16 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         prof.end();
         return TGNN_OK;
     };
-    if (s2) {
+    if (small_teams) {
+        if (sw != s) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[kEvWeights], 0));
+        TGNN_TRY(launch_forward_layers_small(small_teams, P, w.mid, w.a2[0], w.a2[1], w.wimg, w.small_pack, graph, w.small_part,
+                                             w.small_ctr, n, D, update_running, eps, momentum, s));
+    } else if (s2) {
         TGNN_CHECK_HIP(hipEventRecord(ev[0], s));            // middle[0] is complete
         TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[0], 0));
         if (sw != s) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[kEvWeights], 0));
     }
-    for (int i = 0; i < D; ++i) {
+    for (int i = 0; i < (small_teams ? 0 : D); ++i) {
         const int b = P.layer(i);
         if (keep) {                                          // this layer's own buffers (kernels already queued keep theirs)
             w.a1 = keep->a1 + (size_t)i * n * c;

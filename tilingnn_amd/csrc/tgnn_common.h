@@ -224,6 +224,14 @@ int launch_nnconv_cols(const float *h, int64_t ldh, const int32_t *tile_col_ptr,
                        const int32_t *col_src, const float *wimg, int32_t n_types, const float *bias,
                        int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
                        hipStream_t s);
+// Small layouts: the whole layer loop as one persistent kernel (forward_small.hip).  small_layout_teams: 0 = not
+// eligible (too large, too many edge types for LDS), else the tiles per block; the pack is built per forward.
+int small_layout_teams(int64_t n_nodes, int n_types, int depth);
+size_t small_pack_floats(int depth);
+void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrier_ctr, hipStream_t s);
+int launch_forward_layers_small(int teams, const Params &P, float *mid, float *a2_0, float *a2_1, const float *wimg,
+                                const float *pack, const tgnn_graph *graph, double *part, unsigned *ctr, int64_t n, int depth,
+                                int update_running, float eps, float momentum, hipStream_t s);
 // MFMA weight image of the column NNConv, per type: [plane 3 (hi, mid, lo)][M block 2][g 4][i 16] x 8 bf16 --
 // the A fragment of lane 16 g + i for one (plane, M block) is one 16-byte read, a wavefront reads 1 KB in lane order
 // (conflict-free: SQ_LDS_BANK_CONFLICT 2.3e6 -> 2.3e5 per launch against the [i][g] order of round 1); 6144 B per type
