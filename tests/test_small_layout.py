@@ -69,7 +69,9 @@ def test_small_kernel_matches_the_general_schedule_layer_by_layer(dev, n):
     with small_limit(0):
         p_gen, s_gen = _forward_with_slots(net, inputs, n, dev)
     p_small, s_small = _forward_with_slots(net, inputs, n, dev)
-    assert torch.equal(s_gen[0], s_small[0])                    # the init MLP is the same kernels
+    e0 = orc.rel_max_err(s_small[0], s_gen[0].double())         # the init MLP: two BatchNorms, fx = 3 input columns
+    print(f"n {n} slot 0: {e0:.2e}")
+    assert e0 < 2e-5
     for k in range(1, 4):
         err = orc.rel_max_err(s_small[k], s_gen[k].double())
         print(f"n {n} slot {k}: {err:.2e}")

@@ -940,7 +940,7 @@ extern "C" int tgnn_forward_bf16(const tgnn_model_dims *dims, const void *const 
             const int b = P.layer(i);
             layers.l[i] = EdgeMlpLayer{P.f(b), P.f(b + 1), P.f(b + 2), P.f(b + 3), P.f(b + 4), P.f(b + 5)};
         }
-        launch_edge_weight_table_batched(adj_edge_attr, graph->type_rep_edge, T, fe, layers, D, kC, w.wtab, s);
+        launch_edge_weight_table_batched(adj_edge_attr, graph->type_rep_edge, T, fe, layers, D, kC, w.wtab, nullptr, nullptr, s);
     }
     {
         RootPtrs64 rp{};

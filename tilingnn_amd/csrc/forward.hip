@@ -78,7 +78,7 @@ struct Workspace {
     float *mid, *a1, *a2[2], *t0, *f1, *f2, *f3, *f4, *wtab, *wimg;
     double *part1, *part2, *partf;
     float *small_pack;            // small-layout kernel: per-layer parameter packs, its partial rows, its barrier counter
-    double *small_part;
+    double *small_part, *small_part_wide;
     unsigned *small_ctr;
     float *stat1, *stat2[2], *stat_i[2], *stat_f[4];
     size_t bytes;
@@ -142,6 +142,7 @@ static Workspace carve(const tgnn_model_dims &d, int64_t n, int64_t nr, int32_t 
     w.partf = cv.take<double>((size_t)TGNN_BN_MAX_PARTIALS * 2 * 256);
     w.small_pack = cv.take<float>(small_pack_floats(D));
     w.small_part = cv.take<double>((size_t)256 * 128);
+    w.small_part_wide = cv.take<double>((size_t)256 * 512);
     w.small_ctr = cv.take<unsigned>(64);
     w.stat1 = cv.take<float>(4 * c);
     w.stat2[0] = cv.take<float>(4 * c);
@@ -333,28 +334,33 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[kEvFork], 0));
         sw = s2;
     }
-    if (T > 0) {
+    const bool tiled = graph->nn_tile_col_ptr && c == 32 && (int64_t)nr * c * 4 < (int64_t(1) << 31);   // buffer-addressed gathers
+    if (T > 0 || tiled) {
+        // edge MLP of every (layer, type) and, for the matrix-core NNConv, its operand images (root = pseudo-type T): one launch
         EdgeMlpLayers layers{};
+        const float *roots[kMaxDepth];
         for (int i = 0; i < D; ++i) {
             const int b = P.layer(i);
             layers.l[i] = EdgeMlpLayer{P.f(b), P.f(b + 1), P.f(b + 2), P.f(b + 3), P.f(b + 4), P.f(b + 5)};
+            roots[i] = P.f(b + 6);
         }
         prof.begin(0);
-        launch_edge_weight_table_batched(adj_edge_attr, graph->type_rep_edge, T, fe, layers, D, c, w.wtab, sw);
-        prof.end();
-    }
-    const bool tiled = graph->nn_tile_col_ptr && c == 32 && (int64_t)nr * c * 4 < (int64_t(1) << 31);   // buffer-addressed gathers
-    if (tiled) {
-        const float *roots[kMaxDepth];
-        for (int i = 0; i < D; ++i) roots[i] = P.f(P.layer(i) + 6);
-        prof.begin(0);
-        launch_nnconv_weight_image(w.wtab, roots, T, D, w.wimg, sw);
+        launch_edge_weight_table_batched(adj_edge_attr, graph->type_rep_edge, T, fe, layers, D, c, w.wtab, tiled ? roots : nullptr,
+                                         tiled ? w.wimg : nullptr, sw);
         prof.end();
     }
     // Small layouts: the layer loop below is replaced by one persistent kernel (forward_small.hip)
-    const int small_teams = (tiled && !sh && !keep && !use_running_stats && !prof.on && nr == n) ? small_layout_teams(n, T, D) : 0;
-    if (small_teams) launch_small_pack(P, D, w.small_pack, w.small_ctr, sw);
+    const int small_teams = (tiled && !sh && !keep && !use_running_stats && !prof.on && nr == n) ? small_layout_teams(dims, n, T) : 0;
+    if (small_teams) launch_small_pack(P, D, w.small_pack, w.small_ctr, s);   // on the main stream: it has nothing else to do yet
     if (sw != s) TGNN_CHECK_HIP(hipEventRecord(ev[kEvWeights], s2));
+    if (small_teams) {
+        // init MLP, the layers and the final MLP: one persistent kernel behind the pre-pass
+        if (sw != s) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[kEvWeights], 0));
+        TGNN_TRY(launch_forward_small(dims, P, x, probs, w.mid, w.a2[0], w.a2[1], w.wimg, w.small_pack, graph, w.small_part,
+                                      w.small_part_wide, w.small_ctr, n, update_running, eps, momentum, s));
+        TGNN_CHECK_LAUNCH();
+        return TGNN_OK;
+    }
 
     // ---- K10: init MLP  (TilinGNN.py:54)
     prof.begin(1);
@@ -393,16 +399,12 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         prof.end();
         return TGNN_OK;
     };
-    if (small_teams) {
-        if (sw != s) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[kEvWeights], 0));
-        TGNN_TRY(launch_forward_layers_small(small_teams, P, w.mid, w.a2[0], w.a2[1], w.wimg, w.small_pack, graph, w.small_part,
-                                             w.small_ctr, n, D, update_running, eps, momentum, s));
-    } else if (s2) {
+    if (s2) {
         TGNN_CHECK_HIP(hipEventRecord(ev[0], s));            // middle[0] is complete
         TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[0], 0));
         if (sw != s) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[kEvWeights], 0));
     }
-    for (int i = 0; i < (small_teams ? 0 : D); ++i) {
+    for (int i = 0; i < D; ++i) {
         const int b = P.layer(i);
         if (keep) {                                          // this layer's own buffers (kernels already queued keep theirs)
             w.a1 = keep->a1 + (size_t)i * n * c;

@@ -46,13 +46,37 @@ struct SmallPackLayers {
 
 __device__ __forceinline__ int small_kf(int q, int e) { return e < 4 ? 4 * q + e : 16 + 4 * q + (e - 4); }   // gin.hip: gin_kf
 
-// one block per layer; block 0 of the first chunk re-arms the barrier counter of the persistent kernel
-__global__ __launch_bounds__(256) void small_pack_kernel(SmallPackLayers layers, float *__restrict__ pack,
-                                                         unsigned *__restrict__ barrier_ctr) {
-    const SmallPackLayer L = layers.l[blockIdx.x];
-    float *out = pack + (size_t)blockIdx.x * kSpStride;
+struct SmallImageJob {
+    const float *w;              // [m][k] row-major (torch Linear.weight)
+    float *img;
+    int m, k;                    // multiples of 16 / 32
+};
+struct SmallImageJobs {
+    SmallImageJob j[5];
+};
+// The per-forward pre-pass of the persistent kernel, one launch: blockIdx.y < n_layers: the parameter pack of that layer
+// (block x = 0; it also re-arms the barrier counter); above: the MFMA image of one dense layer, one thread per (mb, ks, lane)
+__global__ __launch_bounds__(256) void small_pack_kernel(SmallPackLayers layers, int n_layers, float *__restrict__ pack,
+                                                         unsigned *__restrict__ barrier_ctr, SmallImageJobs jobs) {
     const int tid = threadIdx.x;
-    if (barrier_ctr && blockIdx.x == 0 && tid == 0) *barrier_ctr = 0u;
+    if ((int)blockIdx.y >= n_layers) {
+        const SmallImageJob J = jobs.j[blockIdx.y - n_layers];
+        const int ksteps = J.k / 32, items = (J.m / 16) * ksteps * 64;
+        for (int it = blockIdx.x * 256 + tid; it < items; it += gridDim.x * 256) {
+            const int lane = it & 63, blk = it >> 6, ks = blk % ksteps, mb = blk / ksteps;
+            const int i = lane & 15, q = lane >> 4;
+            const float4 *src = reinterpret_cast<const float4 *>(J.w + (size_t)(16 * mb + i) * J.k + 32 * ks + 8 * q);
+            const float4 a = src[0], b = src[1];
+            const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            bf16x8 *dst = reinterpret_cast<bf16x8 *>(J.img) + (size_t)blk * 3 * 64 + lane;
+            split3_trunc(x, dst[0], dst[64], dst[128]);
+        }
+        return;
+    }
+    if (blockIdx.x != 0) return;
+    const SmallPackLayer L = layers.l[blockIdx.y];
+    float *out = pack + (size_t)blockIdx.y * kSpStride;
+    if (barrier_ctr && blockIdx.y == 0 && tid == 0) *barrier_ctr = 0u;
     if (tid < 32) {
         out[kSpBias + tid] = L.nn_bias[tid];
         out[kSpG1 + tid] = L.g1[tid];
@@ -114,6 +138,24 @@ struct SmallArgs {
     float eps, momentum;
 };
 
+// ---- the init MLP (TilinGNN.py:54) and the final MLP (:74-76) inside the same kernel -----------------------------------
+// One BatchNorm'd Linear_trans: MFMA image of the weights [M / 16][K / 32][plane 3][lane 64] x 8 bf16 (the A fragment of
+// lane (i, q) for output block mb, K step ks: W[16 mb + i][32 ks + 8 q .. + 7], split hi / mid / lo), bias, BatchNorm
+struct SmallDense {
+    const float *img, *bias, *gamma, *beta;
+    float *rm, *rv;
+    int64_t *nbt;
+};
+struct SmallEnds {
+    const float *x;              // node features [n][fx]
+    const float *w0;             // init Linear 0 [32][fx] (computed on the vector pipe: fx = tile_count + 1 is tiny)
+    SmallDense i0, i1;           // init Linear_trans 0 (img unused), 1 (32 -> 32)
+    SmallDense f[4];             // final MLP: 32 (depth + 1) -> 256 -> 128 -> 64 -> 32
+    const float *w_last, *b_last;   // final_mlp.1: Linear(32, out_dim) + sigmoid, no BatchNorm
+    float *probs;                // [n][out_dim]
+    double *part_wide;           // [blocks][512]: column sums | sums of squares of one dense layer
+    int fx, out_dim;
+};
 #ifdef TGNN_SMALL_TIMING
 // phase timers of block 0 / the slowest arrival (scratch builds only): wall_clock64 ticks (100 MHz), summed over the layers
 __device__ unsigned long long g_small_timing[32 * 260];
@@ -152,7 +194,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void *p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)0x80000000u, 0x00020000);
 }
 
-// All blocks are resident (cooperative launch).  Stores of this block are acknowledged (vmcnt(0)) before its arrival
+// All blocks are resident (small_layout_teams checks the device's capacity).  Stores of this block are acknowledged (vmcnt(0)) before its arrival
 // is published; the data itself is sc1, so no cache maintenance is needed on either side.
 __device__ __forceinline__ void small_grid_barrier(unsigned *ctr, unsigned &target, unsigned nblk) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -171,6 +213,10 @@ constexpr int kNnWaves = 6;
 // LDS, floats, after the weight images: parameter vectors of two layers | NNConv partial products [6][64][8] (phase B: the
 // fp64 fold [8][128]) | second half of the collision sums [64][8] | a1 tile | a2 tile | records | root degrees
 constexpr int kLdsSpv = 2 * kSpGinW, kLdsNnRed = kNnWaves * 64 * 8, kLdsGinRed = 64 * 8, kLdsTile = 512;
+#ifndef TGNN_SMALL_NN_DELAY
+#define TGNN_SMALL_NN_DELAY 16           // x 64 clocks
+#endif
+constexpr int kGinCached = 16;        // collision neighbours per row whose gather offsets stay in registers
 constexpr int kPfW = 14, kPfG = 4;   // float4 per thread of the next layer's weight images (NNConv, GIN) held across barrier 1
 
 __device__ __forceinline__ f32x4 small_mma6(const bf16x8 *wpl, int plane_stride, const bf16x8 (&x)[3], f32x4 acc) {
@@ -211,7 +257,151 @@ __device__ __forceinline__ void small_run_mma(const float *wl, int t, int lane, 
     d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, xh, d1, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(SmallArgs A, SmallRunTab R) {
+// ---- dense layers on one 16-row tile, block-wide (8 waves) ------------------------------------------------------------------
+// LDS of these phases (the weight images of the message-passing layers are not live then), floats from the start:
+//   B-operand planes of the layer's input [K / 32][3][64] x 16 B (capacity: max(depth + 1, 8) K steps) | activations of the
+//   tile [16][kDActLd] fp32 | fp64 fold [512 / M][2 M] = 1024 doubles | BatchNorm record [4][256]
+constexpr int kDActLd = 260, kDPlaneStep = 3 * 64 * 4;
+constexpr int kSmallMaxDepth = 40;
+__host__ __device__ constexpr int small_dense_ksteps(int depth) { return depth + 1 > 8 ? depth + 1 : 8; }
+__host__ __device__ constexpr int small_dense_lds_floats(int depth) {
+    return small_dense_ksteps(depth) * kDPlaneStep + 16 * kDActLd + 2048 + 1024;
+}
+
+// out[n][16 mb + 4 q + r] = LeakyReLU(sum_k W[.][k] x[n][k] + b): D^T = W . X^T, split precision (bf16 x 3, six cross terms).
+// Output blocks go round the waves, MBW at a time (sharing the B fragments); A fragments stream from the image in global
+// memory one K step ahead.
+template <int MBW>
+__device__ __forceinline__ void small_tile_dense(const float *img, int ksteps, int mblocks, const float *bias, const float *lds_x,
+                                                 float *act, int tw, int lane) {
+    const int fn = lane & 15, fq = lane >> 4;
+    const bf16x8 *xp = reinterpret_cast<const bf16x8 *>(lds_x) + lane;
+    for (int mb0 = tw * MBW; mb0 < mblocks; mb0 += 8 * MBW) {
+        f32x4 acc[MBW];
+        const bf16x8 *wp[MBW];
+#pragma unroll
+        for (int m = 0; m < MBW; ++m) {
+            const int mb = mb0 + m < mblocks ? mb0 + m : mblocks - 1;
+            const float4 b = *reinterpret_cast<const float4 *>(bias + 16 * mb + 4 * fq);
+            acc[m] = f32x4{b.x, b.y, b.z, b.w};
+            wp[m] = reinterpret_cast<const bf16x8 *>(img) + (size_t)mb * ksteps * 3 * 64 + lane;
+        }
+        bf16x8 cur[MBW][3], nxt[MBW][3];
+#pragma unroll
+        for (int m = 0; m < MBW; ++m)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) cur[m][pl] = wp[m][pl * 64];
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const int kn = ks + 1 < ksteps ? ks + 1 : ks;
+#pragma unroll
+            for (int m = 0; m < MBW; ++m)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) nxt[m][pl] = wp[m][(kn * 3 + pl) * 64];
+            const bf16x8 x0 = xp[(ks * 3 + 0) * 64], x1 = xp[(ks * 3 + 1) * 64], x2 = xp[(ks * 3 + 2) * 64];
+#pragma unroll
+            for (int m = 0; m < MBW; ++m) {
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[m][2], x0, acc[m], 0, 0, 0);   // lo . hi
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[m][0], x2, acc[m], 0, 0, 0);   // hi . lo
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[m][1], x1, acc[m], 0, 0, 0);   // mid . mid
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[m][1], x0, acc[m], 0, 0, 0);   // mid . hi
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[m][0], x1, acc[m], 0, 0, 0);   // hi . mid
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[m][0], x0, acc[m], 0, 0, 0);   // hi . hi
+            }
+#pragma unroll
+            for (int m = 0; m < MBW; ++m)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) cur[m][pl] = nxt[m][pl];
+        }
+#pragma unroll
+        for (int m = 0; m < MBW; ++m)
+            if (mb0 + m < mblocks)
+                *reinterpret_cast<float4 *>(act + fn * kDActLd + 16 * (mb0 + m) + 4 * fq) =
+                    make_float4(leakyf_(acc[m][0]), leakyf_(acc[m][1]), leakyf_(acc[m][2]), leakyf_(acc[m][3]));
+    }
+}
+
+// B-operand planes of BatchNorm(act) for the next dense layer: item (ks, lane (n, q)) = floats 32 ks + 8 q .. + 7 of row n
+__device__ __forceinline__ void small_tile_planes_from_act(const float *act, const float *rec, int m_in, int valid_rows, float *lds_x,
+                                                           int tid) {
+    const int items = (m_in / 32) * 64;
+    for (int it = tid; it < items; it += kSmallThreads) {
+        const int lane = it & 63, ks = it >> 6, n = lane & 15, q = lane >> 4, k0 = 32 * ks + 8 * q;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            x[e] = n < valid_rows ? bn_apply1(act[n * kDActLd + k0 + e], rec[k0 + e], rec[256 + k0 + e], rec[512 + k0 + e], rec[768 + k0 + e]) : 0.f;
+        bf16x8 *dst = reinterpret_cast<bf16x8 *>(lds_x) + (size_t)ks * 3 * 64 + lane;
+        split3_trunc(x, dst[0], dst[64], dst[128]);
+    }
+}
+
+// Train-mode BatchNorm statistics of act [valid_rows][M] over ALL tiles: this block's column sums -> its partial row -> grid
+// barrier -> every block folds all rows in the same order -> record [4][256] in LDS (block 0 updates the running buffers).
+template <int M>
+__device__ __forceinline__ void small_tile_bn(const float *act, int valid_rows, const SmallDense &L, double *part_wide, double *red,
+                                              float *rec, int64_t n_total, float eps, float momentum, int update_running,
+                                              unsigned *ctr, unsigned &target, unsigned nblk, int tid) {
+    static_assert(M == 32 || M == 64 || M == 128 || M == 256, "width");
+    const __amdgpu_buffer_rsrc_t rs = rsrc_of(part_wide);
+    if (tid < 2 * M) {
+        const int ch = tid % M;
+        const bool sq = tid >= M;
+        double acc = 0.0;
+        for (int r = 0; r < valid_rows; ++r) {
+            const double v = (double)act[r * kDActLd + ch];
+            acc += sq ? v * v : v;
+        }
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, acc), rs, ((uint32_t)blockIdx.x * 512u + (uint32_t)tid) * 8u, 0, kCpSc1);
+    }
+    small_grid_barrier(ctr, target, nblk);
+    {
+        constexpr int groups = kSmallThreads / M;              // thread = (column pair, row group): 2 M doubles per row = M pairs
+        const int jp = tid % M, g = tid / M;
+        double acc0 = 0.0, acc1 = 0.0;
+        for (int p0 = g; p0 < (int)nblk; p0 += 16 * groups) {
+            u32x4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int p = p0 + u * groups;
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, p < (int)nblk ? ((uint32_t)p * 512u + 2u * (uint32_t)jp) * 8u : kOob, 0, kCpSc1);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                acc0 += __builtin_bit_cast(double, u32x2{v[u][0], v[u][1]});
+                acc1 += __builtin_bit_cast(double, u32x2{v[u][2], v[u][3]});
+            }
+        }
+        red[g * 2 * M + 2 * jp] = acc0;
+        red[g * 2 * M + 2 * jp + 1] = acc1;
+        __syncthreads();
+        if (tid < M) {
+            double t_sum = 0.0, t_sq = 0.0;
+#pragma unroll
+            for (int gg = 0; gg < groups; ++gg) {
+                t_sum += red[gg * 2 * M + tid];
+                t_sq += red[gg * 2 * M + M + tid];
+            }
+            const double inv_n = 1.0 / (double)n_total;
+            const double mean = t_sum * inv_n;
+            double var = t_sq * inv_n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float mh = (float)mean;
+            rec[tid] = mh;
+            rec[256 + tid] = (float)(mean - (double)mh);
+            rec[512 + tid] = (float)((double)L.gamma[tid] / sqrt(var + (double)eps));
+            rec[768 + tid] = L.beta[tid];
+            if (blockIdx.x == 0 && update_running) {
+                const double unbiased = n_total > 1 ? var * ((double)n_total / (double)(n_total - 1)) : var;
+                L.rm[tid] = (float)((1.0 - (double)momentum) * (double)L.rm[tid] + (double)momentum * mean);
+                L.rv[tid] = (float)((1.0 - (double)momentum) * (double)L.rv[tid] + (double)momentum * unbiased);
+                if (tid == 0) *L.nbt += 1;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(SmallArgs A, SmallRunTab R, SmallEnds E) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NT = kSmallThreads;
     const int T = A.n_types, D = A.depth;
@@ -265,6 +455,41 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
             if (tid + u * NT < kSpGinFrags) reinterpret_cast<u32x4 *>(gw)[tid + u * NT] = pfg[u];                           \
         if (tid < kSpGinW / 4) reinterpret_cast<u32x4 *>(spv + ((LAYER) & 1) * kSpGinW)[tid] = pfs;                         \
     }
+
+    // ====================================== init MLP (TilinGNN.py:54) ======================================
+    // Linear(fx, 32) + LeakyReLU + BatchNorm, Linear(32, 32) + LeakyReLU + BatchNorm -> slot 0 of the skip buffer, own rows
+    {
+        float *dx = lds, *dact = lds + small_dense_ksteps(D) * kDPlaneStep;
+        double *dred = reinterpret_cast<double *>(dact + 16 * kDActLd);
+        float *drec = dact + 16 * kDActLd + 2048;
+        const int valid_rows = n - tile * 16 < 16 ? (int)(n - tile * 16) : 16;
+        {   // Linear 0 on the vector pipe: thread = (row, channel), k ascending
+            const int r = tid >> 5, ch = tid & 31;
+            float acc = E.i0.bias[ch];
+            if (r < valid_rows)
+                for (int k = 0; k < E.fx; ++k) acc = fmaf(E.x[(tile * 16 + r) * E.fx + k], E.w0[ch * E.fx + k], acc);
+            dact[r * kDActLd + ch] = leakyf_(acc);
+        }
+        __syncthreads();
+        small_tile_bn<32>(dact, valid_rows, E.i0, E.part_wide, dred, drec, n, A.eps, A.momentum, A.update_running, A.ctr, target, nblk, tid);
+        small_tile_planes_from_act(dact, drec, 32, valid_rows, dx, tid);
+        __syncthreads();
+        small_tile_dense<1>(E.i1.img, 1, 2, E.i1.bias, dx, dact, tw, lane);
+        __syncthreads();
+        small_tile_bn<32>(dact, valid_rows, E.i1, E.part_wide, dred, drec, n, A.eps, A.momentum, A.update_running, A.ctr, target, nblk, tid);
+        if (tid < 128) {
+            const int row = tid >> 3, c4 = (tid & 7) * 4;
+            if (row < valid_rows) {
+                float4 o;
+                o.x = bn_apply1(dact[row * kDActLd + c4 + 0], drec[c4 + 0], drec[256 + c4 + 0], drec[512 + c4 + 0], drec[768 + c4 + 0]);
+                o.y = bn_apply1(dact[row * kDActLd + c4 + 1], drec[c4 + 1], drec[256 + c4 + 1], drec[512 + c4 + 1], drec[768 + c4 + 1]);
+                o.z = bn_apply1(dact[row * kDActLd + c4 + 2], drec[c4 + 2], drec[256 + c4 + 2], drec[512 + c4 + 2], drec[768 + c4 + 2]);
+                o.w = bn_apply1(dact[row * kDActLd + c4 + 3], drec[c4 + 3], drec[256 + c4 + 3], drec[512 + c4 + 3], drec[768 + c4 + 3]);
+                st_sc1_f4(rsrc_of(A.mid), (uint32_t)(tile * 16 + row) * 128u + (uint32_t)c4 * 4u, o);
+            }
+        }
+        small_grid_barrier(A.ctr, target, nblk);                 // (also: everybody is done with the LDS of this phase)
+    }
     TGNN_SMALL_PREFETCH(0)
 
     // ---- layer-invariant pieces of the tile, kept in registers for all layers
@@ -273,15 +498,19 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
     uint32_t coff[8];
     int cmeta[8];
     float my_root_deg = 0.f;                                      // the wave that holds the root column: max(deg, 1) of row fj, 0 = row >= n
-    // collision waves: half of row fj's neighbour list; the first 8 neighbours' gather offsets
-    int gbeg = 0, gend = 0, deg_all = 0;
-    uint32_t noff[8];
+    // collision waves (one per half tile; gather mapping: lane = (row slot r = lane >> 3, 16-byte piece p = lane & 7) of the
+    // rows 8 h + r): the neighbour list of row r and the first kGinCached neighbours' gather offsets
+    const int gh = tw - kNnWaves, gr = lane >> 3, gp = lane & 7;
+    const int64_t g_row = tile * 16 + 8 * gh + gr;
+    int gbeg = 0, gend = 0;
+    uint32_t noff[kGinCached];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         coff[k] = kOob;
         cmeta[k] = kColSkip;
-        noff[k] = kOob;
     }
+#pragma unroll
+    for (int k = 0; k < kGinCached; ++k) noff[k] = kOob;
     if (tw < kNnWaves) {
         const int c0 = __builtin_amdgcn_readfirstlane(A.tile_col_ptr[tile]);
         const int c1 = __builtin_amdgcn_readfirstlane(A.tile_col_ptr[tile + 1]);
@@ -299,15 +528,12 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
                 if (root) my_root_deg = s >= 0 ? __int_as_float(s) : 0.f;
             }
         }
-    } else if (row_ok) {
-        const int b0 = A.col_rowptr[my_row], e0 = A.col_rowptr[my_row + 1];
-        deg_all = e0 - b0;
-        const int mid = b0 + (deg_all + 1) / 2;
-        gbeg = tw == kNnWaves ? b0 : mid;
-        gend = tw == kNnWaves ? mid : e0;
+    } else if (g_row < n) {
+        gbeg = A.col_rowptr[g_row];
+        gend = A.col_rowptr[g_row + 1];
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (gbeg + k < gend) noff[k] = (uint32_t)A.col_nbr[gbeg + k] * 128u + (uint32_t)fq * 32u;
+        for (int k = 0; k < kGinCached; ++k)
+            if (gbeg + k < gend) noff[k] = (uint32_t)A.col_nbr[gbeg + k] * 128u + (uint32_t)gp * 16u;
     }
     TGNN_SMALL_COMMIT(0)
     __syncthreads();
@@ -316,10 +542,11 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
         const float *sp = spv + (layer & 1) * kSpGinW;
         TGNN_ST(0)
         // =========================================== phase A ===========================================
-        float gacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};               // collision waves: this half's neighbourhood sum
-        float4 self0 = make_float4(0.f, 0.f, 0.f, 0.f), self1 = self0;
         if (tw < kNnWaves) {
             // ---- NNConv: partial product over columns [cb, ce) -- every gather of the chunk in flight at once
+            // (the collision waves' 2 x 17 whole-row gathers go first through the CU's address path: their chain -- gather, MLP --
+            //  is the longer one, and behind the 96 gathers of these six waves it started ~3 us late)
+            __builtin_amdgcn_s_sleep(TGNN_SMALL_NN_DELAY);
             TGNN_ST3_RESET
             const __amdgpu_buffer_rsrc_t h_rs = rsrc_of(A.mid + (size_t)layer * slot);
             float4 x[8][2];
@@ -376,101 +603,68 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
             if (tw == kNnWaves - 1 && fq == 0) rootdeg[fj] = my_root_deg;   // (the last chunk holds the tile's last column: the root)
             TGNN_ST3(3)
         } else {
-            // ---- CollConv, gather: sum over this half of row fj's collision neighbours of (x - mean), x = the previous layer's
-            //      pre-BatchNorm rows (the BatchNorm is folded into the sum as in gin32_aggregate_kernel), in the B-operand layout
-            //      of the MLP: lane (n, q) holds floats 8 q .. 8 q + 7 of row n
+            // ---- CollConv of half a tile on ONE wave, no hand-over: gather whole 128-byte rows (8 lanes x 16 bytes per row: a
+            //      sixteenth of the CU's address-path time per byte of the 16-rows x 64-bytes pattern of the matrix layout), the
+            //      neighbourhood sum in registers, z through a wave-private LDS tile into the B-operand layout, then the
+            //      32 -> 32 -> 64 -> 32 MLP of gin32_mlp_kernel on the half-filled 16-row tile.  Runs beside the NNConv waves.
+            TGNN_ST2_RESET
             const float *src = layer == 0 ? A.mid : ((layer - 1) & 1 ? A.a2[1] : A.a2[0]);
             const __amdgpu_buffer_rsrc_t a_rs = rsrc_of(src);
-            float4 xr[8][2];
+            float4 xr[kGinCached];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                xr[k][0] = ld_gather_f4(a_rs, noff[k]);
-                xr[k][1] = ld_gather_f4(a_rs, noff[k] == kOob ? kOob : noff[k] + 16u);
-            }
-            if (tw == kNnWaves) {
-                const uint32_t self_off = row_ok ? (uint32_t)my_row * 128u + (uint32_t)fq * 32u : kOob;
-                self0 = ld_gather_f4(a_rs, self_off);
-                self1 = ld_gather_f4(a_rs, self_off == kOob ? kOob : self_off + 16u);
-            }
+            for (int k = 0; k < kGinCached; ++k) xr[k] = ld_gather_f4(a_rs, noff[k]);
+            const float4 selfv = ld_gather_f4(a_rs, g_row < n ? (uint32_t)g_row * 128u + (uint32_t)gp * 16u : kOob);
+            TGNN_ST2(5)
+#ifdef TGNN_SMALL_TIMING
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            TGNN_ST2(6)
+#endif
             const bool use_stat = layer > 0;
-            float mhi[8], mlo[8];
+            // x = BatchNorm of the previous layer's pre-BN rows, folded into the sum as in gin32_aggregate_kernel
+            const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
+            const float4 mhi = use_stat ? *reinterpret_cast<const float4 *>(st + 128 + 4 * gp) : zero4;
+            const float4 mlo = use_stat ? *reinterpret_cast<const float4 *>(st + 160 + 4 * gp) : zero4;
+            const float4 gv = use_stat ? *reinterpret_cast<const float4 *>(st + 192 + 4 * gp) : one4;
+            const float4 bv = use_stat ? *reinterpret_cast<const float4 *>(st + 224 + 4 * gp) : zero4;
+            float4 acc = zero4;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                mhi[c] = use_stat ? st[128 + 8 * fq + c] : 0.f;
-                mlo[c] = use_stat ? st[128 + 32 + 8 * fq + c] : 0.f;
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float xv[8] = {xr[k][0].x, xr[k][0].y, xr[k][0].z, xr[k][0].w, xr[k][1].x, xr[k][1].y, xr[k][1].z, xr[k][1].w};
+            for (int k = 0; k < kGinCached; ++k)
                 if (noff[k] != kOob) {
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) gacc[c] += (xv[c] - mhi[c]) - mlo[c];
+                    acc.x += (xr[k].x - mhi.x) - mlo.x; acc.y += (xr[k].y - mhi.y) - mlo.y;
+                    acc.z += (xr[k].z - mhi.z) - mlo.z; acc.w += (xr[k].w - mhi.w) - mlo.w;
                 }
-            }
-            for (int e = gbeg + 8; __any(e < gend); ++e) {       // more than 16 collision neighbours: one at a time
-                const uint32_t off = e < gend ? (uint32_t)A.col_nbr[e] * 128u + (uint32_t)fq * 32u : kOob;
-                const float4 y0 = ld_gather_f4(a_rs, off), y1 = ld_gather_f4(a_rs, off == kOob ? kOob : off + 16u);
-                const float xv[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
-                if (e < gend) {
+            for (int e = gbeg + kGinCached; __any(e < gend); e += 8) {   // longer neighbour lists: 8 rows in flight at a time
+                float4 y[8];
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) gacc[c] += (xv[c] - mhi[c]) - mlo[c];
-                }
-            }
-            if (tw == kNnWaves + 1) {
-                *reinterpret_cast<float4 *>(ginred + lane * 8) = make_float4(gacc[0], gacc[1], gacc[2], gacc[3]);
-                *reinterpret_cast<float4 *>(ginred + lane * 8 + 4) = make_float4(gacc[4], gacc[5], gacc[6], gacc[7]);
-            }
-        }
-        TGNN_ST(1)
-        __syncthreads();
-        // the next layer's weight images start their trip now -- behind this layer's gathers in the CU's memory pipeline (114 KB:
-        // ahead of them they delayed every gather by ~1 us), in flight during the epilogue / MLP below, in registers until
-        // this layer is through with the images in LDS
-        if (layer + 1 < D) TGNN_SMALL_PREFETCH(layer + 1)
-        TGNN_ST(2)
-        if (tw == kNnWaves - 1) {
-            // ---- NNConv epilogue: the six partial products in fixed order, mean, bias, LeakyReLU
-            float t8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int k = 0; k < 8; ++k)
+                    y[k] = ld_gather_f4(a_rs, e + k < gend ? (uint32_t)A.col_nbr[e + k] * 128u + (uint32_t)gp * 16u : kOob);
 #pragma unroll
-            for (int w = 0; w < kNnWaves; ++w) {
-                const float *pw = nnred + (w * 64 + lane) * 8;
-                const float4 a = *reinterpret_cast<const float4 *>(pw), b = *reinterpret_cast<const float4 *>(pw + 4);
-                if (w == 0) {
-                    t8[0] = a.x; t8[1] = a.y; t8[2] = a.z; t8[3] = a.w; t8[4] = b.x; t8[5] = b.y; t8[6] = b.z; t8[7] = b.w;
-                } else {
-                    t8[0] += a.x; t8[1] += a.y; t8[2] += a.z; t8[3] += a.w; t8[4] += b.x; t8[5] += b.y; t8[6] += b.z; t8[7] += b.w;
-                }
+                for (int k = 0; k < 8; ++k)
+                    if (e + k < gend) {
+                        acc.x += (y[k].x - mhi.x) - mlo.x; acc.y += (y[k].y - mhi.y) - mlo.y;
+                        acc.z += (y[k].z - mhi.z) - mlo.z; acc.w += (y[k].w - mhi.w) - mlo.w;
+                    }
             }
-            const float rd = rootdeg[fj];
-            const bool valid = rd > 0.f;
-            const float inv = valid ? 1.0f / rd : 0.f;
-            const float4 bias0 = *reinterpret_cast<const float4 *>(sp + kSpBias + 4 * fq);
-            const float4 bias1 = *reinterpret_cast<const float4 *>(sp + kSpBias + 16 + 4 * fq);
-            float4 o0, o1;
-            o0.x = leakyf_(fmaf(t8[0], inv, bias0.x)); o0.y = leakyf_(fmaf(t8[1], inv, bias0.y));
-            o0.z = leakyf_(fmaf(t8[2], inv, bias0.z)); o0.w = leakyf_(fmaf(t8[3], inv, bias0.w));
-            o1.x = leakyf_(fmaf(t8[4], inv, bias1.x)); o1.y = leakyf_(fmaf(t8[5], inv, bias1.y));
-            o1.z = leakyf_(fmaf(t8[6], inv, bias1.z)); o1.w = leakyf_(fmaf(t8[7], inv, bias1.w));
-            if (!valid) o0 = o1 = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4 *>(a1s + fj * 32 + 4 * fq) = o0;
-            *reinterpret_cast<float4 *>(a1s + fj * 32 + 16 + 4 * fq) = o1;
-        } else if (tw == kNnWaves) {
-            // ---- CollConv: z = gamma' ((1 + eps)(x[v] - mean) + sum) + (1 + eps + deg) beta, then the MLP of gin32_mlp_kernel
-            TGNN_ST2_RESET
-            const bool use_stat = layer > 0;
             const float one_eps = sp[kSpEps];
-            const float kb = one_eps + (float)deg_all;
+            const float kb = one_eps + (float)(gend - gbeg);
+            float4 z4;
+            z4.x = fmaf(gv.x, fmaf(one_eps, (selfv.x - mhi.x) - mlo.x, acc.x), kb * bv.x);
+            z4.y = fmaf(gv.y, fmaf(one_eps, (selfv.y - mhi.y) - mlo.y, acc.y), kb * bv.y);
+            z4.z = fmaf(gv.z, fmaf(one_eps, (selfv.z - mhi.z) - mlo.z, acc.z), kb * bv.z);
+            z4.w = fmaf(gv.w, fmaf(one_eps, (selfv.w - mhi.w) - mlo.w, acc.w), kb * bv.w);
+            float *zs = ginred + gh * 256;                       // [8 rows][32]
+            *reinterpret_cast<float4 *>(zs + gr * 32 + 4 * gp) = z4;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // matrix layout: lane (n = fj, q = fq) holds floats 8 q .. 8 q + 7 of tile row n; rows of the other half are zero
+            const bool mine = (fj >> 3) == gh;
             float z[8];
             {
-                const float4 h0 = *reinterpret_cast<const float4 *>(ginred + lane * 8), h1 = *reinterpret_cast<const float4 *>(ginred + lane * 8 + 4);
-                const float other[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-                const float sv[8] = {self0.x, self0.y, self0.z, self0.w, self1.x, self1.y, self1.z, self1.w};
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float mh = use_stat ? st[128 + 8 * fq + c] : 0.f, ml = use_stat ? st[128 + 32 + 8 * fq + c] : 0.f;
-                    const float gvc = use_stat ? st[128 + 64 + 8 * fq + c] : 1.f, bvc = use_stat ? st[128 + 96 + 8 * fq + c] : 0.f;
-                    z[c] = fmaf(gvc, fmaf(one_eps, (sv[c] - mh) - ml, gacc[c] + other[c]), kb * bvc);
-                }
+                const float4 za = *reinterpret_cast<const float4 *>(zs + (fj & 7) * 32 + 8 * fq);
+                const float4 zb = *reinterpret_cast<const float4 *>(zs + (fj & 7) * 32 + 8 * fq + 4);
+                z[0] = mine ? za.x : 0.f; z[1] = mine ? za.y : 0.f; z[2] = mine ? za.z : 0.f; z[3] = mine ? za.w : 0.f;
+                z[4] = mine ? zb.x : 0.f; z[5] = mine ? zb.y : 0.f; z[6] = mine ? zb.z : 0.f; z[7] = mine ? zb.w : 0.f;
             }
             const bf16x8 *W1s = reinterpret_cast<const bf16x8 *>(gw), *W2s = W1s + 3 * 2 * 64, *W3s = W2s + 3 * 4 * 64;
             const float *Bs = sp + kSpGinB;
@@ -507,16 +701,52 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
             float4 r0, r1;
             r0.x = leakyf_(sig_out(o0[0])); r0.y = leakyf_(sig_out(o0[1])); r0.z = leakyf_(sig_out(o0[2])); r0.w = leakyf_(sig_out(o0[3]));
             r1.x = leakyf_(sig_out(o1[0])); r1.y = leakyf_(sig_out(o1[1])); r1.z = leakyf_(sig_out(o1[2])); r1.w = leakyf_(sig_out(o1[3]));
-            if (!row_ok) r0 = r1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!row_ok) r0 = r1 = zero4;
             // row fj, channels 4 fq + r and 16 + 4 fq + r: to the LDS tile (merge, BatchNorm sums) and to HBM (next layer's gathers)
-            *reinterpret_cast<float4 *>(a2s + fj * 32 + 4 * fq) = r0;
-            *reinterpret_cast<float4 *>(a2s + fj * 32 + 16 + 4 * fq) = r1;
+            if (mine) {
+                *reinterpret_cast<float4 *>(a2s + fj * 32 + 4 * fq) = r0;
+                *reinterpret_cast<float4 *>(a2s + fj * 32 + 16 + 4 * fq) = r1;
+            }
             TGNN_ST2(3)
             const __amdgpu_buffer_rsrc_t o_rs = rsrc_of(layer & 1 ? A.a2[1] : A.a2[0]);
-            const uint32_t o_off = row_ok ? (uint32_t)my_row * 128u + (uint32_t)fq * 16u : kOob;
+            const uint32_t o_off = mine && row_ok ? (uint32_t)my_row * 128u + (uint32_t)fq * 16u : kOob;
             st_sc1_f4(o_rs, o_off, r0);
             st_sc1_f4(o_rs, o_off == kOob ? kOob : o_off + 64u, r1);
             TGNN_ST2(4)
+        }
+        TGNN_ST(1)
+        __syncthreads();
+        // the next layer's weight images start their trip now -- behind this layer's gathers in the CU's memory pipeline (114 KB:
+        // ahead of them they delayed every gather by ~1 us), in flight during the epilogue / MLP below, in registers until
+        // this layer is through with the images in LDS
+        if (layer + 1 < D) TGNN_SMALL_PREFETCH(layer + 1)
+        TGNN_ST(2)
+        if (tw == kNnWaves - 1) {
+            // ---- NNConv epilogue: the six partial products in fixed order, mean, bias, LeakyReLU
+            float t8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int w = 0; w < kNnWaves; ++w) {
+                const float *pw = nnred + (w * 64 + lane) * 8;
+                const float4 a = *reinterpret_cast<const float4 *>(pw), b = *reinterpret_cast<const float4 *>(pw + 4);
+                if (w == 0) {
+                    t8[0] = a.x; t8[1] = a.y; t8[2] = a.z; t8[3] = a.w; t8[4] = b.x; t8[5] = b.y; t8[6] = b.z; t8[7] = b.w;
+                } else {
+                    t8[0] += a.x; t8[1] += a.y; t8[2] += a.z; t8[3] += a.w; t8[4] += b.x; t8[5] += b.y; t8[6] += b.z; t8[7] += b.w;
+                }
+            }
+            const float rd = rootdeg[fj];
+            const bool valid = rd > 0.f;
+            const float inv = valid ? 1.0f / rd : 0.f;
+            const float4 bias0 = *reinterpret_cast<const float4 *>(sp + kSpBias + 4 * fq);
+            const float4 bias1 = *reinterpret_cast<const float4 *>(sp + kSpBias + 16 + 4 * fq);
+            float4 o0, o1;
+            o0.x = leakyf_(fmaf(t8[0], inv, bias0.x)); o0.y = leakyf_(fmaf(t8[1], inv, bias0.y));
+            o0.z = leakyf_(fmaf(t8[2], inv, bias0.z)); o0.w = leakyf_(fmaf(t8[3], inv, bias0.w));
+            o1.x = leakyf_(fmaf(t8[4], inv, bias1.x)); o1.y = leakyf_(fmaf(t8[5], inv, bias1.y));
+            o1.z = leakyf_(fmaf(t8[6], inv, bias1.z)); o1.w = leakyf_(fmaf(t8[7], inv, bias1.w));
+            if (!valid) o0 = o1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(a1s + fj * 32 + 4 * fq) = o0;
+            *reinterpret_cast<float4 *>(a1s + fj * 32 + 16 + 4 * fq) = o1;
         }
         __syncthreads();
         if (tid < 128) {
@@ -558,9 +788,13 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
                     acc1 += __builtin_bit_cast(double, u32x2{v[u][2], v[u][3]});
                 }
             };
+            TGNN_ST3_RESET
             fetch(g);
+            TGNN_ST3(4)
             if (layer + 1 < D) TGNN_SMALL_COMMIT(layer + 1)
+            TGNN_ST3(5)
             fold();
+            TGNN_ST3(6)
             if (nblk > 128) {                                     // (at most 256 blocks)
                 fetch(g + 128);
                 fold();
@@ -568,6 +802,7 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
             red[g * 128 + 2 * jp] = acc0;
             red[g * 128 + 2 * jp + 1] = acc1;
             __syncthreads();
+            TGNN_ST3(7)
             if (tid < 64) {                                       // the two records, as bn_finalize_kernel writes them
                 const int job = tid >> 5, ch = tid & 31;
                 double t_sum = 0.0, t_sq = 0.0;
@@ -634,6 +869,55 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
         }
         TGNN_ST(7)
     }
+
+    // ====================================== final MLP (TilinGNN.py:74-76) ======================================
+    // over the concatenation of the depth + 1 slots (K step ks = slot ks), own rows; 4 x (Linear + LeakyReLU + BatchNorm), then
+    // Linear(32, out_dim) + sigmoid
+    {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own rows only: the last merge's stores are through, and
+        __syncthreads();                                             // the LDS of the layer loop is free
+        float *dx = lds, *dact = lds + small_dense_ksteps(D) * kDPlaneStep;
+        double *dred = reinterpret_cast<double *>(dact + 16 * kDActLd);
+        float *drec = dact + 16 * kDActLd + 2048;
+        const int valid_rows = n - tile * 16 < 16 ? (int)(n - tile * 16) : 16;
+        for (int it = tid; it < (D + 1) * 64; it += NT) {        // B-operand planes of the own rows of every slot
+            const int ln = it & 63, ks = it >> 6, nn = ln & 15, q = ln >> 4;
+            const uint32_t off = nn < valid_rows ? (uint32_t)(tile * 16 + nn) * 128u + (uint32_t)q * 32u : kOob;
+            const __amdgpu_buffer_rsrc_t s_rs = rsrc_of(A.mid + (size_t)ks * slot);
+            const float4 a = ld_sc1_f4(s_rs, off), b = ld_sc1_f4(s_rs, off == kOob ? kOob : off + 16u);
+            const float xv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            bf16x8 *dst = reinterpret_cast<bf16x8 *>(dx) + (size_t)ks * 3 * 64 + ln;
+            split3_trunc(xv, dst[0], dst[64], dst[128]);
+        }
+        __syncthreads();
+        small_tile_dense<2>(E.f[0].img, D + 1, 16, E.f[0].bias, dx, dact, tw, lane);
+        __syncthreads();
+        small_tile_bn<256>(dact, valid_rows, E.f[0], E.part_wide, dred, drec, n, A.eps, A.momentum, A.update_running, A.ctr, target, nblk, tid);
+        small_tile_planes_from_act(dact, drec, 256, valid_rows, dx, tid);
+        __syncthreads();
+        small_tile_dense<1>(E.f[1].img, 8, 8, E.f[1].bias, dx, dact, tw, lane);
+        __syncthreads();
+        small_tile_bn<128>(dact, valid_rows, E.f[1], E.part_wide, dred, drec, n, A.eps, A.momentum, A.update_running, A.ctr, target, nblk, tid);
+        small_tile_planes_from_act(dact, drec, 128, valid_rows, dx, tid);
+        __syncthreads();
+        small_tile_dense<1>(E.f[2].img, 4, 4, E.f[2].bias, dx, dact, tw, lane);
+        __syncthreads();
+        small_tile_bn<64>(dact, valid_rows, E.f[2], E.part_wide, dred, drec, n, A.eps, A.momentum, A.update_running, A.ctr, target, nblk, tid);
+        small_tile_planes_from_act(dact, drec, 64, valid_rows, dx, tid);
+        __syncthreads();
+        small_tile_dense<1>(E.f[3].img, 2, 2, E.f[3].bias, dx, dact, tw, lane);
+        __syncthreads();
+        small_tile_bn<32>(dact, valid_rows, E.f[3], E.part_wide, dred, drec, n, A.eps, A.momentum, A.update_running, A.ctr, target, nblk, tid);
+        for (int it = tid; it < 16 * E.out_dim; it += NT) {      // final_mlp.1
+            const int r = it / E.out_dim, o = it - r * E.out_dim;
+            if (r < valid_rows) {
+                float acc = E.b_last[o];
+                for (int k = 0; k < 32; ++k)
+                    acc = fmaf(bn_apply1(dact[r * kDActLd + k], drec[k], drec[256 + k], drec[512 + k], drec[768 + k]), E.w_last[o * 32 + k], acc);
+                E.probs[(tile * 16 + r) * E.out_dim + o] = sigmoidf_(acc);
+            }
+        }
+    }
 #ifdef TGNN_SMALL_TIMING
     if (tid == 0 && blockIdx.x < 260)
         for (int k = 0; k < 8; ++k) g_small_timing[blockIdx.x * 32 + k] = tacc[k];
@@ -644,27 +928,74 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
 #endif
 }
 
-static size_t small_lds_bytes(int n_types) {
-    return ((size_t)(n_types + 1) * kWtType + kSpGinFrags * 4 + kLdsSpv + kLdsNnRed + kLdsGinRed + 2 * kLdsTile) * sizeof(float) +
-           (256 + 16) * sizeof(float);
+static size_t small_lds_bytes(int n_types, int depth) {
+    const size_t loop = ((size_t)(n_types + 1) * kWtType + kSpGinFrags * 4 + kLdsSpv + kLdsNnRed + kLdsGinRed + 2 * kLdsTile) * sizeof(float) +
+                        (256 + 16) * sizeof(float);
+    const size_t ends = (size_t)small_dense_lds_floats(depth) * sizeof(float);
+    return loop > ends ? loop : ends;
 }
 constexpr size_t kSmallMaxLds = 160 * 1024 - 256;
 
 static std::atomic<int64_t> g_small_limit{4096};
 
 // 1 = eligible: one 16-row tile per block and at most one block per CU, the weight images of a layer fit LDS and the
-// prefetch registers
-int small_layout_teams(int64_t n_nodes, int n_types, int depth) {
+// prefetch registers, the final MLP's input planes fit LDS
+int small_layout_teams(const tgnn_model_dims *d, int64_t n_nodes, int n_types) {
     const int64_t limit = g_small_limit.load(std::memory_order_relaxed);
-    if (n_nodes < 2 || n_nodes > limit || n_nodes > 4096 || depth < 1 || depth > kMaxDepth) return 0;
-    if (small_lds_bytes(n_types) > kSmallMaxLds) return 0;
+    if (n_nodes < 2 || n_nodes > limit || n_nodes > 4096) return 0;
+    if (d->network_width != 32 || d->network_depth < 1 || d->network_depth > kSmallMaxDepth || d->output_dim > 256 ||
+        d->node_features_dim > 256)
+        return 0;
+    if (small_lds_bytes(n_types, d->network_depth) > kSmallMaxLds) return 0;
     if ((n_types + 1) * kWtType / 4 > kPfW * kSmallThreads) return 0;
-    return 1;
+    // The grid barrier needs every block resident at the same time.  The kernel is launched as an ordinary kernel on the
+    // caller's stream (a cooperative launch goes through a queue of its own: ~25 us of cross-queue dependency before and
+    // after the kernel, measured), so the guarantee a cooperative launch gives is checked here instead: blocks <= CUs of
+    // the device (of the partition, in CPX / NPS modes) x resident blocks per CU for this kernel's registers and LDS.
+    static std::atomic<int> capacity[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int cap = capacity[dev].load(std::memory_order_acquire);
+    if (cap == 0) {
+        static LdsOptIn site;
+        int per_cu = 0, cus = 0;
+        if (opt_in_dynamic_lds(forward_layers_small_kernel, (int)kSmallMaxLds, site) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, forward_layers_small_kernel, kSmallThreads, kSmallMaxLds) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            return 0;
+        cap = per_cu > 0 && cus > 0 ? (per_cu > 1 ? 1 : per_cu) * cus : -1;   // (counted as one block per CU: the LDS images fill it)
+        capacity[dev].store(cap, std::memory_order_release);
+    }
+    return (n_nodes + 15) / 16 <= cap ? 1 : 0;
 }
 
-size_t small_pack_floats(int depth) { return (size_t)depth * kSpStride; }
+// workspace of the path, floats: per-layer packs | dense images (init 1, final 0..3)
+static size_t small_image_floats(int depth, size_t (&off)[5]) {
+    const size_t sz[5] = {32 * 32 * 3 / 2, (size_t)256 * 32 * (depth + 1) * 3 / 2, 128 * 256 * 3 / 2, 64 * 128 * 3 / 2, 32 * 64 * 3 / 2};
+    size_t at = 0;
+    for (int k = 0; k < 5; ++k) {
+        off[k] = at;
+        at += sz[k];
+    }
+    return at;
+}
+size_t small_pack_floats(int depth) {
+    size_t off[5];
+    return (size_t)depth * kSpStride + small_image_floats(depth, off);
+}
 
+// Per-forward pre-pass (side stream): parameter packs + GIN images of the layers, MFMA images of the dense layers; re-arms
+// the barrier counter
 void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrier_ctr, hipStream_t s) {
+    size_t off[5];
+    small_image_floats(depth, off);
+    float *img = pack + (size_t)depth * kSpStride;
+    SmallImageJobs J{};
+    J.j[0] = SmallImageJob{P.f(P.init(1)), img + off[0], 32, 32};
+    J.j[1] = SmallImageJob{P.f(P.fin(0)), img + off[1], 256, 32 * (depth + 1)};
+    J.j[2] = SmallImageJob{P.f(P.fin(1)), img + off[2], 128, 256};
+    J.j[3] = SmallImageJob{P.f(P.fin(2)), img + off[3], 64, 128};
+    J.j[4] = SmallImageJob{P.f(P.fin(3)), img + off[4], 32, 64};
     for (int lo = 0; lo < depth; lo += kSmallPackChunk) {
         const int nl = depth - lo < kSmallPackChunk ? depth - lo : kSmallPackChunk;
         SmallPackLayers L{};
@@ -673,15 +1004,17 @@ void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrie
             L.l[k] = SmallPackLayer{P.f(b + 7), P.f(b + 8), P.f(b + 9), P.f(b + 20), P.f(b + 21), P.f(b + 13),
                                     P.f(b + 14), P.f(b + 15), P.f(b + 16), P.f(b + 17), P.f(b + 18), P.f(b + 19)};
         }
-        small_pack_kernel<<<nl, 256, 0, s>>>(L, pack + (size_t)lo * kSpStride, lo == 0 ? barrier_ctr : nullptr);
+        const bool first = lo == 0;                             // the dense images ride along with the first chunk
+        small_pack_kernel<<<dim3(first ? 64 : 1, nl + (first ? 5 : 0)), 256, 0, s>>>(L, nl, pack + (size_t)lo * kSpStride,
+                                                                                     first ? barrier_ctr : nullptr, J);
     }
 }
 
-// mid slot 0 holds the init MLP's output; on return (stream order) slots 1 .. depth are filled
-int launch_forward_layers_small(int teams, const Params &P, float *mid, float *a2_0, float *a2_1, const float *wimg,
-                                const float *pack, const tgnn_graph *graph, double *part, unsigned *ctr, int64_t n,
-                                int depth, int update_running, float eps, float momentum, hipStream_t s) {
-    (void)teams;
+// The whole forward behind the pre-pass: x -> probs (stream order)
+int launch_forward_small(const tgnn_model_dims *d, const Params &P, const float *x, float *probs, float *mid, float *a2_0,
+                         float *a2_1, const float *wimg, float *pack, const tgnn_graph *graph, double *part, double *part_wide,
+                         unsigned *ctr, int64_t n, int update_running, float eps, float momentum, hipStream_t s) {
+    const int depth = d->network_depth;
     SmallArgs A{};
     A.mid = mid;
     A.a2[0] = a2_0;
@@ -706,12 +1039,29 @@ int launch_forward_layers_small(int teams, const Params &P, float *mid, float *a
         const BnPtrs b1 = P.bn(P.layer(i) + 8), b2 = P.bn(P.layer(i) + 20);
         R.l[i] = SmallRun{b1.rm, b1.rv, b1.nbt, b2.rm, b2.rv, b2.nbt};
     }
+    size_t off[5];
+    small_image_floats(depth, off);
+    const float *img = pack + (size_t)depth * kSpStride;
+    auto dense = [&](int pi, const float *image) {
+        const BnPtrs b = P.bn(pi + 2);
+        return SmallDense{image, P.f(pi + 1), b.gamma, b.beta, b.rm, b.rv, b.nbt};
+    };
+    SmallEnds E{};
+    E.x = x;
+    E.w0 = P.f(P.init(0));
+    E.i0 = dense(P.init(0), nullptr);
+    E.i1 = dense(P.init(1), img + off[0]);
+    for (int l = 0; l < 4; ++l) E.f[l] = dense(P.fin(l), img + off[1 + l]);
+    E.w_last = P.f(P.last());
+    E.b_last = P.f(P.last() + 1);
+    E.probs = probs;
+    E.part_wide = part_wide;
+    E.fx = d->node_features_dim;
+    E.out_dim = d->output_dim;
     const int blocks = (int)((n + 15) / 16);
     static LdsOptIn site;
     TGNN_CHECK_HIP(opt_in_dynamic_lds(forward_layers_small_kernel, (int)kSmallMaxLds, site));
-    void *args[] = {&A, &R};
-    TGNN_CHECK_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(forward_layers_small_kernel), dim3(blocks),
-                                              dim3(kSmallThreads), args, small_lds_bytes(graph->n_types), s));
+    forward_layers_small_kernel<<<dim3(blocks), dim3(kSmallThreads), small_lds_bytes(graph->n_types, depth), s>>>(A, R, E);
     return TGNN_OK;
 }
 

@@ -29,13 +29,41 @@ namespace tgnn {
 constexpr int kEH1 = 32, kEH2 = 64;  // edge-MLP hidden sizes (edge_conv.py:9)
 
 // grid = (T, depth): blockIdx.y selects the layer
+// (root matrices of all layers, by value: the weight image treats the root as pseudo-type T)
+struct RootPtrs {
+    const float *p[kMaxDepth];
+};
+
+// One weight -> its slot of the matrix-core kernel's operand image (nnconv_cols.hip): element (k, o) of a type's [32][32]
+// matrix, flat index r = k * 32 + o (NNConv's .view(-1, C_in, C_out)), split exactly into three bf16 pieces (hi + mid + lo)
+//   -> plane p, [M block o >> 4][g = k >> 3][i = o & 15][k & 7]
+__device__ __forceinline__ void weight_image_put(__bf16 *dst, int r, float x) {
+    const int k = r >> 5, o = r & 31;
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;                       // exact
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;                      // exact
+    const int at = (((o >> 4) * 4 + (k >> 3)) * 16 + (o & 15)) * 8 + (k & 7);
+    dst[0 * kWtPlane * 2 + at] = h;                      // (kWtPlane floats = 2 kWtPlane bf16)
+    dst[1 * kWtPlane * 2 + at] = m;
+    dst[2 * kWtPlane * 2 + at] = (__bf16)r2;
+}
+
 __global__ __launch_bounds__(256) void edge_weight_table_kernel(
     const float *__restrict__ edge_attr, const int *__restrict__ type_rep_edge, int fe, EdgeMlpLayers layers, int cc,
-    float *__restrict__ wtab_all) {
+    float *__restrict__ wtab_all, int n_types, RootPtrs roots, float *__restrict__ wimg_all) {
+    // wimg_all != NULL (width 32): the block also writes its type's slice of the matrix-core operand image, and one more
+    // block per layer (blockIdx.x == n_types) the root matrix's -- no second launch on the way to the first NNConv
+    __bf16 *img = wimg_all ? reinterpret_cast<__bf16 *>(wimg_all + ((int64_t)blockIdx.y * (n_types + 1) + blockIdx.x) * kWtType) : nullptr;
+    if ((int)blockIdx.x == n_types) {
+        const float *src = roots.p[blockIdx.y];
+        for (int r = threadIdx.x; r < 1024; r += 256) weight_image_put(img, r, src[r]);
+        return;
+    }
     const EdgeMlpLayer L = layers.l[blockIdx.y];
     const float *__restrict__ w1 = L.w1, *__restrict__ b1 = L.b1, *__restrict__ w2 = L.w2, *__restrict__ b2 = L.b2,
                 *__restrict__ w3 = L.w3, *__restrict__ b3 = L.b3;
-    float *__restrict__ wtab = wtab_all + (int64_t)blockIdx.y * gridDim.x * cc;
+    float *__restrict__ wtab = wtab_all + (int64_t)blockIdx.y * n_types * cc;
     __shared__ float e_s[1024];
     __shared__ float h1_s[kEH1];
     __shared__ float h2_s[kEH2];
@@ -70,7 +98,9 @@ __global__ __launch_bounds__(256) void edge_weight_table_kernel(
             acc = fmaf(h2_s[4 * q + 2], w.z, acc);
             acc = fmaf(h2_s[4 * q + 3], w.w, acc);
         }
-        wtab[(int64_t)t * cc + j] = sigmoidf_(acc);
+        const float v = sigmoidf_(acc);
+        wtab[(int64_t)t * cc + j] = v;
+        if (img) weight_image_put(img, j, v);
     }
 }
 
@@ -284,26 +314,12 @@ __global__ __launch_bounds__(kNNThreads) void nnconv32_lds_kernel(
 // bf16 pieces (hi + mid + lo):  element (k, o) of type t -> plane p, M block o >> 4, row o & 15, group k >> 3,
 // element k & 7.  grid = (T+1, layers); done once per forward so that every NNConv block fills its LDS with a
 // straight coalesced 16-byte copy.
-struct RootPtrs {
-    const float *p[kMaxDepth];
-};
 __global__ __launch_bounds__(256) void nnconv_weight_image_kernel(const float *__restrict__ wtab_all, RootPtrs roots,
                                                                   int n_types, float *__restrict__ wimg_all) {
     const int t = blockIdx.x, layer = blockIdx.y;
     const float *src = t < n_types ? wtab_all + ((int64_t)layer * n_types + t) * 1024 : roots.p[layer];
     __bf16 *dst = reinterpret_cast<__bf16 *>(wimg_all + ((int64_t)layer * (n_types + 1) + t) * kWtType);
-    for (int r = threadIdx.x; r < 1024; r += 256) {
-        const int k = r >> 5, o = r & 31;                    // wtab flat index k * 32 + o (NNConv's .view(-1, C_in, C_out))
-        const float x = src[r];
-        const __bf16 h = (__bf16)x;
-        const float r1 = x - (float)h;                       // exact
-        const __bf16 m = (__bf16)r1;
-        const float r2 = r1 - (float)m;                      // exact
-        const int at = (((o >> 4) * 4 + (k >> 3)) * 16 + (o & 15)) * 8 + (k & 7);   // [M block][g = k / 8][i = o % 16][k % 8]
-        dst[0 * kWtPlane * 2 + at] = h;                      // (kWtPlane floats = 2 kWtPlane bf16)
-        dst[1 * kWtPlane * 2 + at] = m;
-        dst[2 * kWtPlane * 2 + at] = (__bf16)r2;
-    }
+    for (int r = threadIdx.x; r < 1024; r += 256) weight_image_put(dst, r, src[r]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -366,8 +382,14 @@ __global__ __launch_bounds__(256) void nnconv_generic_kernel(
 constexpr size_t kMaxDynLds = 160 * 1024 - 256;
 
 void launch_edge_weight_table_batched(const float *edge_attr, const int *type_rep_edge, int n_types, int fe,
-                                      const EdgeMlpLayers &layers, int depth, int c, float *wtab, hipStream_t s) {
-    edge_weight_table_kernel<<<dim3(n_types, depth), 256, 0, s>>>(edge_attr, type_rep_edge, fe, layers, c * c, wtab);
+                                      const EdgeMlpLayers &layers, int depth, int c, float *wtab, const float *const *roots,
+                                      float *wimg_all, hipStream_t s) {
+    RootPtrs rp{};
+    const bool image = wimg_all && roots && c == 32;
+    if (image)
+        for (int i = 0; i < depth; ++i) rp.p[i] = roots[i];
+    edge_weight_table_kernel<<<dim3(n_types + (image ? 1 : 0), depth), 256, 0, s>>>(edge_attr, type_rep_edge, fe, layers, c * c, wtab,
+                                                                                  n_types, rp, image ? wimg_all : nullptr);
 }
 
 }  // namespace tgnn
@@ -386,7 +408,7 @@ extern "C" int tgnn_edge_weight_table(const float *edge_attr, const int32_t *typ
     TGNN_CHECK_ARG((uintptr_t)w3 % 16 == 0, "w3 must be 16-byte aligned");
     EdgeMlpLayers layers{};
     layers.l[0] = EdgeMlpLayer{w1, b1, w2, b2, w3, b3};
-    launch_edge_weight_table_batched(edge_attr, type_rep_edge, n_types, fe, layers, 1, c, wtab,
+    launch_edge_weight_table_batched(edge_attr, type_rep_edge, n_types, fe, layers, 1, c, wtab, nullptr, nullptr,
                                      static_cast<hipStream_t>(stream));
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;

@@ -215,8 +215,10 @@ struct EdgeMlpLayers {
     EdgeMlpLayer l[kMaxDepth];
 };
 // wtab [depth][T][C*C]
+// roots + wimg_all given (width 32): the same launch also writes the NNConv operand images [(T+1)][kWtType] of all layers
 void launch_edge_weight_table_batched(const float *edge_attr, const int *type_rep_edge, int n_types, int fe,
-                                      const EdgeMlpLayers &layers, int depth, int c, float *wtab, hipStream_t s);
+                                      const EdgeMlpLayers &layers, int depth, int c, float *wtab, const float *const *roots,
+                                      float *wimg_all, hipStream_t s);
 // NNConv B-operand weight images [(T+1)][1152] for `depth` layers (roots[i] = layer i's root matrix); nnconv.hip
 void launch_nnconv_weight_image(const float *wtab_all, const float *const *roots, int n_types, int depth,
                                 float *wimg_all, hipStream_t s);
@@ -224,14 +226,14 @@ int launch_nnconv_cols(const float *h, int64_t ldh, const int32_t *tile_col_ptr,
                        const int32_t *col_src, const float *wimg, int32_t n_types, const float *bias,
                        int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
                        hipStream_t s);
-// Small layouts: the whole layer loop as one persistent kernel (forward_small.hip).  small_layout_teams: 0 = not
-// eligible (too large, too many edge types for LDS), else the tiles per block; the pack is built per forward.
-int small_layout_teams(int64_t n_nodes, int n_types, int depth);
+// Small layouts: the whole forward behind a pre-pass as one persistent kernel (forward_small.hip).  small_layout_teams:
+// 0 = not eligible (too large, too many edge types for LDS, ...); the packs / images are built per forward.
+int small_layout_teams(const tgnn_model_dims *d, int64_t n_nodes, int n_types);
 size_t small_pack_floats(int depth);
 void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrier_ctr, hipStream_t s);
-int launch_forward_layers_small(int teams, const Params &P, float *mid, float *a2_0, float *a2_1, const float *wimg,
-                                const float *pack, const tgnn_graph *graph, double *part, unsigned *ctr, int64_t n, int depth,
-                                int update_running, float eps, float momentum, hipStream_t s);
+int launch_forward_small(const tgnn_model_dims *d, const Params &P, const float *x, float *probs, float *mid, float *a2_0,
+                         float *a2_1, const float *wimg, float *pack, const tgnn_graph *graph, double *part, double *part_wide,
+                         unsigned *ctr, int64_t n, int update_running, float eps, float momentum, hipStream_t s);
 // MFMA weight image of the column NNConv, per type: [plane 3 (hi, mid, lo)][M block 2][g 4][i 16] x 8 bf16 --
 // the A fragment of lane 16 g + i for one (plane, M block) is one 16-byte read, a wavefront reads 1 KB in lane order
 // (conflict-free: SQ_LDS_BANK_CONFLICT 2.3e6 -> 2.3e5 per launch against the [i][g] order of round 1); 6144 B per type
