@@ -237,6 +237,10 @@ typedef struct tgnn_graph {
     const int32_t *nn_tile_col_ptr;
     const int32_t *nn_col_meta;
     const int32_t *nn_col_src;
+    /* largest adjacency in-degree of a node, if the caller knows it (tilingnn_amd.ops.prepare_graph reads it back together
+     * with the type count); 0 = unknown.  The small-layout kernel (tgnn_set_small_layout_limit) keeps a row's gather list in
+     * registers and runs only when 1 <= nn_max_in_degree <= 31; otherwise the general schedule does. */
+    int32_t nn_max_in_degree;
 } tgnn_graph;
 
 size_t tgnn_forward_workspace_bytes(const tgnn_model_dims *dims, int64_t n_nodes, int32_t n_types);

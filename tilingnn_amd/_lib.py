@@ -32,7 +32,8 @@ class Graph(C.Structure):
                 ("n_types", C.c_int32),
                 ("adj_rowptr", C.c_void_p), ("adj_src", C.c_void_p), ("adj_type", C.c_void_p),
                 ("type_rep_edge", C.c_void_p), ("col_rowptr", C.c_void_p), ("col_src", C.c_void_p),
-                ("nn_tile_col_ptr", C.c_void_p), ("nn_col_meta", C.c_void_p), ("nn_col_src", C.c_void_p)]
+                ("nn_tile_col_ptr", C.c_void_p), ("nn_col_meta", C.c_void_p), ("nn_col_src", C.c_void_p),
+                ("nn_max_in_degree", C.c_int32)]
 
 
 class TrainSave(C.Structure):

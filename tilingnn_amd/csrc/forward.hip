@@ -350,7 +350,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         prof.end();
     }
     // Small layouts: the layer loop below is replaced by one persistent kernel (forward_small.hip)
-    const int small_teams = (tiled && !sh && !keep && !use_running_stats && !prof.on && nr == n) ? small_layout_teams(dims, n, T) : 0;
+    const int small_teams = (tiled && !sh && !keep && !use_running_stats && !prof.on && nr == n) ? small_layout_teams(dims, n, T, graph->nn_max_in_degree) : 0;
     if (small_teams) launch_small_pack(P, D, w.small_pack, w.small_ctr, s);   // on the main stream: it has nothing else to do yet
     if (sw != s) TGNN_CHECK_HIP(hipEventRecord(ev[kEvWeights], s2));
     if (small_teams) {

@@ -207,7 +207,7 @@ __device__ __forceinline__ void small_grid_barrier(unsigned *ctr, unsigned &targ
     __syncthreads();
 }
 
-constexpr int kColFirst = 1 << 8, kColLast = 1 << 9, kColSkip = 1 << 11;   // col_meta flags (graph_prep.hip; bit 10 = end of tile: the root column)
+constexpr int kColFirst = 1 << 8;    // col_meta flag (graph_prep.hip): first column of a run of same-type columns; low byte = type
 constexpr int kSmallThreads = 512;   // 8 waves per tile: 6 NNConv column chunks, 2 halves of the collision neighbourhoods
 constexpr int kNnWaves = 6;
 // LDS, floats, after the weight images: parameter vectors of two layers | NNConv partial products [6][64][8] (phase B: the
@@ -217,7 +217,8 @@ constexpr int kLdsSpv = 2 * kSpGinW, kLdsNnRed = kNnWaves * 64 * 8, kLdsGinRed =
 #define TGNN_SMALL_NN_DELAY 16           // x 64 clocks
 #endif
 constexpr int kGinCached = 16;        // collision neighbours per row whose gather offsets stay in registers
-constexpr int kPfW = 14, kPfG = 4;   // float4 per thread of the next layer's weight images (NNConv, GIN) held across barrier 1
+constexpr int kPfG = 4;               // float4 per thread of the next layer's GIN weight image held across barrier 1
+constexpr int kNnEntries = 32;        // gather entries per row (adjacency in-edges + the root row): in-degree <= 31
 
 __device__ __forceinline__ f32x4 small_mma6(const bf16x8 *wpl, int plane_stride, const bf16x8 (&x)[3], f32x4 acc) {
     const bf16x8 w0 = wpl[0], w1 = wpl[plane_stride], w2 = wpl[2 * plane_stride];
@@ -266,6 +267,12 @@ constexpr int kSmallMaxDepth = 40;
 __host__ __device__ constexpr int small_dense_ksteps(int depth) { return depth + 1 > 8 ? depth + 1 : 8; }
 __host__ __device__ constexpr int small_dense_lds_floats(int depth) {
     return small_dense_ksteps(depth) * kDPlaneStep + 16 * kDActLd + 2048 + 1024;
+}
+// the type-sum tiles of the layer loop sit behind both layouts (they are zeroed once and must not be touched by anything else)
+constexpr int kLoopFixedFloats = kSpGinFrags * 4 + kLdsSpv + kLdsNnRed + kLdsGinRed + 2 * kLdsTile + 256 + 16 + 32 + 16 * kNnEntries * 2 +
+                                 16 * kGinCached;
+__host__ __device__ constexpr int small_s_offset(int depth) {
+    return small_dense_lds_floats(depth) > kLoopFixedFloats ? small_dense_lds_floats(depth) : kLoopFixedFloats;
 }
 
 // out[n][16 mb + 4 q + r] = LeakyReLU(sum_k W[.][k] x[n][k] + b): D^T = W . X^T, split precision (bf16 x 3, six cross terms).
@@ -406,15 +413,20 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
     constexpr int NT = kSmallThreads;
     const int T = A.n_types, D = A.depth;
     const int64_t n = A.n;
-    const int n4w = (T + 1) * kWtType / 4;                        // float4 count of the NNConv image
-    float *wl = lds;                                              // NNConv weight image of the layer
-    float *gw = wl + (size_t)(T + 1) * kWtType;                   // GIN MLP weight image (contiguous with wl)
+    // LDS of the layer loop: GIN weight image | parameter vectors of two layers | NNConv partial products [6][64][8] (phase B:
+    // the fp64 fold [8][128]; set-up: the entry lists) | collision z tiles [2][8][32] | a1 tile | a2 tile | records | root degrees |
+    // run types; then, behind everything the init / final phases use, the type-sum tiles S [(T + 1)][16][32]
+    float *gw = lds;                                              // GIN MLP weight image of the layer
     float *spv = gw + kSpGinFrags * 4;                            // [2][kSpGinW]: parameter vectors, by layer parity
     float *nnred = spv + kLdsSpv;
     float *ginred = nnred + kLdsNnRed;
     float *a1s = ginred + kLdsGinRed, *a2s = a1s + kLdsTile;
     float *st = a2s + kLdsTile;                                   // [2][4][32]: records of BN1, BN2
     float *rootdeg = st + 256;                                    // [16]
+    int *run_type = reinterpret_cast<int *>(rootdeg + 16);        // [32] type of the tile's r-th run of same-type columns; [31] = count
+    int2 *ent = reinterpret_cast<int2 *>(run_type + 32);          // [16 rows][kNnEntries] NNConv gather entries (see the set-up below)
+    uint32_t *gnb = reinterpret_cast<uint32_t *>(ent + 16 * kNnEntries);   // [16 rows][kGinCached] collision neighbours' row offsets
+    float *S = lds + small_s_offset(D);                           // type-sum tiles; empty slots stay zero for the whole kernel
     double *red = reinterpret_cast<double *>(nnred);              // phase B: [8][128]
 
     const int tid = threadIdx.x, lane = tid & 63, tw = tid >> 6;
@@ -431,26 +443,20 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
     unsigned long long tacc3[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast3 = tlast;
 #endif
 
-    // ---- weight images: global -> registers -> LDS; the registers are in flight across barrier 1 of the previous layer.
-    // Buffer loads with exact-size descriptors: one offset register per thread, reads past the end return zeros.
-    // (native vectors: the float4 struct is copied by memcpy, which pins the array in scratch memory)
-    u32x4 pfw[kPfW], pfg[kPfG], pfs;
+    // ---- the GIN weight image and the parameter vectors of the next layer: global -> registers -> LDS (exact-size descriptor,
+    // one offset register per thread; native vectors: a float4 struct is copied by memcpy, which pins arrays in scratch memory)
+    u32x4 pfg[kPfG], pfs;
     const uint32_t pf_off = (uint32_t)tid * 16u;
 #define TGNN_SMALL_PREFETCH(LAYER)                                                                                          \
     {                                                                                                                       \
-        const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(                                             \
-            const_cast<float *>(A.wimg + (size_t)(LAYER) * (T + 1) * kWtType), 0, n4w * 16, 0x00020000);                   \
         const __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc(                                             \
             const_cast<float *>(A.pack + (size_t)(LAYER) * kSpStride), 0, kSpStride * 4, 0x00020000);                      \
-        _Pragma("unroll") for (int u = 0; u < kPfW; ++u) pfw[u] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, pf_off, u * NT * 16, 0); \
         _Pragma("unroll") for (int u = 0; u < kPfG; ++u)                                                                    \
             pfg[u] = __builtin_amdgcn_raw_buffer_load_b128(g_rs, pf_off, kSpGinW * 4 + u * NT * 16, 0);                     \
         pfs = __builtin_amdgcn_raw_buffer_load_b128(g_rs, tid < kSpGinW / 4 ? pf_off : 0u, 0, 0);                           \
     }
 #define TGNN_SMALL_COMMIT(LAYER)                                                                                            \
     {                                                                                                                       \
-        _Pragma("unroll") for (int u = 0; u < kPfW; ++u)                                                                    \
-            if (tid + u * NT < n4w) reinterpret_cast<u32x4 *>(wl)[tid + u * NT] = pfw[u];                                   \
         _Pragma("unroll") for (int u = 0; u < kPfG; ++u)                                                                    \
             if (tid + u * NT < kSpGinFrags) reinterpret_cast<u32x4 *>(gw)[tid + u * NT] = pfg[u];                           \
         if (tid < kSpGinW / 4) reinterpret_cast<u32x4 *>(spv + ((LAYER) & 1) * kSpGinW)[tid] = pfs;                         \
@@ -493,47 +499,82 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
     TGNN_SMALL_PREFETCH(0)
 
     // ---- layer-invariant pieces of the tile, kept in registers for all layers
-    // NNConv waves: chunk [cb, ce) of the tile's columns; the first 8 columns' gather offsets and meta words
-    int cb = 0, ce = 0;
-    uint32_t coff[8];
-    int cmeta[8];
-    float my_root_deg = 0.f;                                      // the wave that holds the root column: max(deg, 1) of row fj, 0 = row >= n
+    // NNConv, stage 1 (waves 0, 1; gather mapping: lane = (row slot o = lane >> 3, 16-byte piece p = lane & 7), rows 8 w + o):
+    //   the row's entries in column order -- source row offset and LDS address of the type-sum slot S[run][row] it is stored to
+    //   (first column of its run) or added to (later columns: further edges of the same type)
+    // NNConv, stage 2 (waves 0 .. 5): runs w, w + 6, w + 12 of the tile: type (weight image) of each
+    int n_ent = 0;                                                // waves 0, 1: entries of the longest of the wave's 8 rows
+    int my_run_t[3] = {-1, -1, -1};
+    {
+        const int c0 = __builtin_amdgcn_readfirstlane(A.tile_col_ptr[tile]);
+        const int c1 = __builtin_amdgcn_readfirstlane(A.tile_col_ptr[tile + 1]);
+        const int nc = c1 - c0;
+        int *s_src = reinterpret_cast<int *>(S);                  // [nc][16] source words of the tile's columns (S is zeroed below)
+        int *s_meta = reinterpret_cast<int *>(nnred);             // [nc] meta words, then run | rank << 8
+        int *s_cnt = s_meta + 2048;                               // [16] entries per row
+        for (int i = tid; i < nc * 16; i += NT) s_src[i] = A.col_src[(int64_t)c0 * 16 + i];
+        for (int i = tid; i < nc; i += NT) s_meta[i] = A.col_meta[c0 + i];
+        __syncthreads();
+        if (tid == 0) {                                           // runs of same-type columns, in column order
+            int run = -1, first = 0;
+            for (int k = 0; k < nc; ++k) {
+                const int m = s_meta[k];
+                if (m & kColFirst) {
+                    ++run;
+                    first = k;
+                    run_type[run & 31] = m & 0xff;
+                }
+                s_meta[k] = run | ((k - first) << 8);
+            }
+            run_type[31] = run + 1;
+        }
+        __syncthreads();
+        if (tid < 16) {
+            // one thread per row: its entries in column order = (byte offset of the source row, LDS byte offset of the type-sum
+            // slot S[run][row] | 1: add to the slot (a further edge of the same type) | 2: valid)
+            int cnt = 0;
+            float rd = 0.f;
+            for (int k = 0; k < nc; ++k) {
+                const int sv = s_src[k * 16 + tid];
+                if (sv < 0) continue;
+                const int rr = s_meta[k], run = rr & 0xff;
+                const bool root = run_type[run & 31] == T;
+                if (root) rd = __int_as_float(sv);                // the root column carries max(deg, 1) in the source slot
+                const int64_t srow = root ? tile * 16 + tid : (int64_t)sv;
+                if (cnt < kNnEntries) ent[tid * kNnEntries + cnt] = make_int2((int)(srow * 128), (int)((run * 16 + tid) * 128) | ((rr >> 8) ? 1 : 0) | 2);
+                ++cnt;
+            }
+            for (int i = cnt; i < kNnEntries; ++i) ent[tid * kNnEntries + i] = make_int2(0, 0);
+            rootdeg[tid] = rd;
+            s_cnt[tid] = cnt < kNnEntries ? cnt : kNnEntries;
+        }
+        __syncthreads();
+        if (tw < 2) {
+            int m = 0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) m = max(m, s_cnt[8 * tw + r]);
+            n_ent = __builtin_amdgcn_readfirstlane(m);
+        }
+        const int nruns = run_type[31];
+        if (tw < kNnWaves) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) my_run_t[j] = tw + 6 * j < nruns ? __builtin_amdgcn_readfirstlane(run_type[(tw + 6 * j) & 31]) : -1;
+        }
+        __syncthreads();
+        for (int i = tid; i < (T + 1) * 512 / 4; i += NT) reinterpret_cast<float4 *>(S)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     // collision waves (one per half tile; gather mapping: lane = (row slot r = lane >> 3, 16-byte piece p = lane & 7) of the
     // rows 8 h + r): the neighbour list of row r and the first kGinCached neighbours' gather offsets
     const int gh = tw - kNnWaves, gr = lane >> 3, gp = lane & 7;
     const int64_t g_row = tile * 16 + 8 * gh + gr;
     int gbeg = 0, gend = 0;
-    uint32_t noff[kGinCached];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        coff[k] = kOob;
-        cmeta[k] = kColSkip;
-    }
-#pragma unroll
-    for (int k = 0; k < kGinCached; ++k) noff[k] = kOob;
-    if (tw < kNnWaves) {
-        const int c0 = __builtin_amdgcn_readfirstlane(A.tile_col_ptr[tile]);
-        const int c1 = __builtin_amdgcn_readfirstlane(A.tile_col_ptr[tile + 1]);
-        const int nc = c1 - c0;
-        cb = c0 + nc * tw / kNnWaves;
-        ce = c0 + nc * (tw + 1) / kNnWaves;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (cb + k < ce) {                                    // wave-uniform
-                const int s = A.col_src[(int64_t)(cb + k) * 16 + fj];
-                const int m = __builtin_amdgcn_readfirstlane(A.col_meta[cb + k]);
-                const bool root = (m & 0xff) == T;
-                cmeta[k] = m;
-                coff[k] = s >= 0 ? (root ? (uint32_t)my_row : (uint32_t)s) * 128u + (uint32_t)fq * 32u : kOob;
-                if (root) my_root_deg = s >= 0 ? __int_as_float(s) : 0.f;
-            }
-        }
-    } else if (g_row < n) {
+    if (tw >= kNnWaves && g_row < n) {
         gbeg = A.col_rowptr[g_row];
         gend = A.col_rowptr[g_row + 1];
-#pragma unroll
-        for (int k = 0; k < kGinCached; ++k)
-            if (gbeg + k < gend) noff[k] = (uint32_t)A.col_nbr[gbeg + k] * 128u + (uint32_t)gp * 16u;
+        if (gp == 0)
+            for (int k = 0; k < kGinCached; ++k) gnb[(8 * gh + gr) * kGinCached + k] = gbeg + k < gend ? (uint32_t)A.col_nbr[gbeg + k] * 128u : kOob;
+    } else if (tw >= kNnWaves && gp == 0) {
+        for (int k = 0; k < kGinCached; ++k) gnb[(8 * gh + gr) * kGinCached + k] = kOob;
     }
     TGNN_SMALL_COMMIT(0)
     __syncthreads();
@@ -543,65 +584,79 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
         TGNN_ST(0)
         // =========================================== phase A ===========================================
         if (tw < kNnWaves) {
-            // ---- NNConv: partial product over columns [cb, ce) -- every gather of the chunk in flight at once
-            // (the collision waves' 2 x 17 whole-row gathers go first through the CU's address path: their chain -- gather, MLP --
-            //  is the longer one, and behind the 96 gathers of these six waves it started ~3 us late)
-            __builtin_amdgcn_s_sleep(TGNN_SMALL_NN_DELAY);
-            TGNN_ST3_RESET
-            const __amdgpu_buffer_rsrc_t h_rs = rsrc_of(A.mid + (size_t)layer * slot);
-            float4 x[8][2];
+            // ---- NNConv.  Stage 0: the weight fragments of this wave's runs straight from the image in global memory (used once
+            //      per tile: no LDS staging), in flight while stage 1 runs
+            const bf16x8 *wimg_l = reinterpret_cast<const bf16x8 *>(A.wimg + (size_t)layer * (T + 1) * kWtType) + lane;
+            constexpr int kPl = kWtPlane / 4, kTy = kWtType / 4;  // 16-byte fragments per plane / per type
+            bf16x8 wf[3][6];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                x[k][0] = ld_gather_f4(h_rs, coff[k]);
-                x[k][1] = ld_gather_f4(h_rs, coff[k] == kOob ? kOob : coff[k] + 16u);
+            for (int j = 0; j < 3; ++j) {
+                const bf16x8 *wp = wimg_l + (size_t)(my_run_t[j] >= 0 ? my_run_t[j] : 0) * kTy;
+                wf[j][0] = wp[0]; wf[j][1] = wp[64]; wf[j][2] = wp[kPl]; wf[j][3] = wp[kPl + 64]; wf[j][4] = wp[2 * kPl]; wf[j][5] = wp[2 * kPl + 64];
             }
-            TGNN_ST3(0)
-#ifdef TGNN_SMALL_TIMING
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            TGNN_ST3(1)
-#endif
-            f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;           // D^T: row fj, channels 4 fq + r and 16 + 4 fq + r
-            float af[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            // Stage 1 (waves 0, 1): gather whole 128-byte source rows, 8 rows per instruction (8 lanes x 16 bytes each: a fraction
+            //      of the address-path time of the 16-rows x 64-bytes pattern of the matrix layout), and store / add them to the
+            //      type-sum tiles: S[run][row] = sum of the sources of the row's edges of that type, in edge order
+            if (tw < 2) {
+                TGNN_ST3_RESET
+                const __amdgpu_buffer_rsrc_t h_rs = rsrc_of(A.mid + (size_t)layer * slot);
+                char *lds_b = reinterpret_cast<char *>(S);
+                const int2 *my_ent = ent + (8 * tw + (lane >> 3)) * kNnEntries;
+                const uint32_t pp16 = (uint32_t)(lane & 7) * 16u;
+                for (int b0 = 0; b0 < n_ent; b0 += 16) {          // (wave-uniform trip count: 1 up to 15 in-edges per row)
+                    f32x4 x[16];
+                    uint32_t dd[16];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int mu = cmeta[k];
-                if (!(mu & kColSkip)) {                           // wave-uniform
-                    const bool first = (mu & kColFirst) || k == 0, last = (mu & kColLast) || cb + k == ce - 1;
-                    const float xv[8] = {x[k][0].x, x[k][0].y, x[k][0].z, x[k][0].w, x[k][1].x, x[k][1].y, x[k][1].z, x[k][1].w};
-                    if (first) {
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) af[c] = xv[c];
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) af[c] += xv[c];
+                    for (int i = 0; i < 16; ++i) {
+                        const int2 e = my_ent[b0 + i];
+                        dd[i] = (uint32_t)e.y;
+                        x[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(h_rs, (e.y & 2) ? (uint32_t)e.x + pp16 : kOob, 0, kCpGather));
                     }
-                    if (last) small_run_mma(wl, mu & 0xff, lane, af, (mu & 0xff) == T ? my_root_deg : 1.0f, d0, d1);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        if (dd[i] & 2u) {
+                            f32x4 *dst = reinterpret_cast<f32x4 *>(lds_b + (dd[i] & ~3u) + pp16);
+                            if (dd[i] & 1u) *dst = *dst + x[i];
+                            else *dst = x[i];
+                        }
+                    }
                 }
+                TGNN_ST3(1)
             }
-            TGNN_ST3(2)
-            // chunks longer than 8 columns (tiles with more than 48): one column at a time, index words from memory
-            for (int p = cb + 8; p < ce; ++p) {
-                const int s = A.col_src[(int64_t)p * 16 + fj];
-                const int mu = __builtin_amdgcn_readfirstlane(A.col_meta[p]);
-                const bool root = (mu & 0xff) == T;
-                const uint32_t off = s >= 0 ? (root ? (uint32_t)my_row : (uint32_t)s) * 128u + (uint32_t)fq * 32u : kOob;
-                const float4 y0 = ld_gather_f4(h_rs, off), y1 = ld_gather_f4(h_rs, off == kOob ? kOob : off + 16u);
-                const float xv[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
-                if (mu & kColFirst) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_barrier();                         // (all eight waves: the collision waves pass theirs after issuing their gathers)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // Stage 2: D^T += W_t^T . S_t^T for this wave's runs (root run: operand pre-multiplied by max(deg, 1))
+            f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;           // row fj, channels 4 fq + r and 16 + 4 fq + r
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) af[c] = xv[c];
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) af[c] += xv[c];
+            for (int j = 0; j < 3; ++j) {
+                if (my_run_t[j] >= 0) {                           // wave-uniform
+                    const float *srow = S + ((tw + 6 * j) * 16 + fj) * 32 + 8 * fq;
+                    const float4 sa = *reinterpret_cast<const float4 *>(srow), sb = *reinterpret_cast<const float4 *>(srow + 4);
+                    const float scale = my_run_t[j] == T ? rootdeg[fj] : 1.0f;
+                    bf16x8 xh, xm, xl;
+                    {
+                        const float as[8] = {sa.x * scale, sa.y * scale, sa.z * scale, sa.w * scale, sb.x * scale, sb.y * scale, sb.z * scale, sb.w * scale};
+                        split3_trunc(as, xh, xm, xl);
+                    }
+                    d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][4], xh, d0, 0, 0, 0);   // lo . hi
+                    d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][5], xh, d1, 0, 0, 0);
+                    d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], xl, d0, 0, 0, 0);   // hi . lo
+                    d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], xl, d1, 0, 0, 0);
+                    d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][2], xm, d0, 0, 0, 0);   // mid . mid
+                    d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][3], xm, d1, 0, 0, 0);
+                    d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][2], xh, d0, 0, 0, 0);   // mid . hi
+                    d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][3], xh, d1, 0, 0, 0);
+                    d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], xm, d0, 0, 0, 0);   // hi . mid
+                    d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], xm, d1, 0, 0, 0);
+                    d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], xh, d0, 0, 0, 0);   // hi . hi
+                    d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], xh, d1, 0, 0, 0);
                 }
-                if (root) my_root_deg = s >= 0 ? __int_as_float(s) : 0.f;
-                if ((mu & kColLast) || p == ce - 1) small_run_mma(wl, mu & 0xff, lane, af, root ? my_root_deg : 1.0f, d0, d1);
             }
             float *mine = nnred + (tw * 64 + lane) * 8;
             *reinterpret_cast<float4 *>(mine) = make_float4(d0[0], d0[1], d0[2], d0[3]);
             *reinterpret_cast<float4 *>(mine + 4) = make_float4(d1[0], d1[1], d1[2], d1[3]);
-            if (tw == kNnWaves - 1 && fq == 0) rootdeg[fj] = my_root_deg;   // (the last chunk holds the tile's last column: the root)
-            TGNN_ST3(3)
+            TGNN_ST3(2)
         } else {
             // ---- CollConv of half a tile on ONE wave, no hand-over: gather whole 128-byte rows (8 lanes x 16 bytes per row: a
             //      sixteenth of the CU's address-path time per byte of the 16-rows x 64-bytes pattern of the matrix layout), the
@@ -611,9 +666,17 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
             const float *src = layer == 0 ? A.mid : ((layer - 1) & 1 ? A.a2[1] : A.a2[0]);
             const __amdgpu_buffer_rsrc_t a_rs = rsrc_of(src);
             float4 xr[kGinCached];
+            uint32_t noff[kGinCached];
 #pragma unroll
-            for (int k = 0; k < kGinCached; ++k) xr[k] = ld_gather_f4(a_rs, noff[k]);
+            for (int k = 0; k < kGinCached; ++k) {
+                const uint32_t o = gnb[(8 * gh + gr) * kGinCached + k];
+                noff[k] = o == kOob ? kOob : o + (uint32_t)gp * 16u;
+                xr[k] = ld_gather_f4(a_rs, noff[k]);
+            }
             const float4 selfv = ld_gather_f4(a_rs, g_row < n ? (uint32_t)g_row * 128u + (uint32_t)gp * 16u : kOob);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_barrier();                         // (the NNConv waves' stage 1 -> stage 2 barrier: every wave of the block
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   //  passes one; here it costs nothing, the gathers are in flight)
             TGNN_ST2(5)
 #ifdef TGNN_SMALL_TIMING
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -721,32 +784,25 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
         // this layer is through with the images in LDS
         if (layer + 1 < D) TGNN_SMALL_PREFETCH(layer + 1)
         TGNN_ST(2)
-        if (tw == kNnWaves - 1) {
-            // ---- NNConv epilogue: the six partial products in fixed order, mean, bias, LeakyReLU
-            float t8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (tw == kNnWaves - 2 || tw == kNnWaves - 1) {
+            // ---- NNConv epilogue, one wave per 16-channel half: the six partial products in fixed order, mean, bias, LeakyReLU
+            const int half = tw - (kNnWaves - 2);                // channels 16 half + 4 fq + r of row fj
+            float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int w = 0; w < kNnWaves; ++w) {
-                const float *pw = nnred + (w * 64 + lane) * 8;
-                const float4 a = *reinterpret_cast<const float4 *>(pw), b = *reinterpret_cast<const float4 *>(pw + 4);
-                if (w == 0) {
-                    t8[0] = a.x; t8[1] = a.y; t8[2] = a.z; t8[3] = a.w; t8[4] = b.x; t8[5] = b.y; t8[6] = b.z; t8[7] = b.w;
-                } else {
-                    t8[0] += a.x; t8[1] += a.y; t8[2] += a.z; t8[3] += a.w; t8[4] += b.x; t8[5] += b.y; t8[6] += b.z; t8[7] += b.w;
-                }
+                const float4 a = *reinterpret_cast<const float4 *>(nnred + (w * 64 + lane) * 8 + 4 * half);
+                if (w == 0) t4 = a;
+                else t4 = make_float4(t4.x + a.x, t4.y + a.y, t4.z + a.z, t4.w + a.w);
             }
             const float rd = rootdeg[fj];
             const bool valid = rd > 0.f;
             const float inv = valid ? 1.0f / rd : 0.f;
-            const float4 bias0 = *reinterpret_cast<const float4 *>(sp + kSpBias + 4 * fq);
-            const float4 bias1 = *reinterpret_cast<const float4 *>(sp + kSpBias + 16 + 4 * fq);
-            float4 o0, o1;
-            o0.x = leakyf_(fmaf(t8[0], inv, bias0.x)); o0.y = leakyf_(fmaf(t8[1], inv, bias0.y));
-            o0.z = leakyf_(fmaf(t8[2], inv, bias0.z)); o0.w = leakyf_(fmaf(t8[3], inv, bias0.w));
-            o1.x = leakyf_(fmaf(t8[4], inv, bias1.x)); o1.y = leakyf_(fmaf(t8[5], inv, bias1.y));
-            o1.z = leakyf_(fmaf(t8[6], inv, bias1.z)); o1.w = leakyf_(fmaf(t8[7], inv, bias1.w));
-            if (!valid) o0 = o1 = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4 *>(a1s + fj * 32 + 4 * fq) = o0;
-            *reinterpret_cast<float4 *>(a1s + fj * 32 + 16 + 4 * fq) = o1;
+            const float4 bias = *reinterpret_cast<const float4 *>(sp + kSpBias + 16 * half + 4 * fq);
+            float4 o;
+            o.x = leakyf_(fmaf(t4.x, inv, bias.x)); o.y = leakyf_(fmaf(t4.y, inv, bias.y));
+            o.z = leakyf_(fmaf(t4.z, inv, bias.z)); o.w = leakyf_(fmaf(t4.w, inv, bias.w));
+            if (!valid) o = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(a1s + fj * 32 + 16 * half + 4 * fq) = o;
         }
         __syncthreads();
         if (tid < 128) {
@@ -929,10 +985,7 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
 }
 
 static size_t small_lds_bytes(int n_types, int depth) {
-    const size_t loop = ((size_t)(n_types + 1) * kWtType + kSpGinFrags * 4 + kLdsSpv + kLdsNnRed + kLdsGinRed + 2 * kLdsTile) * sizeof(float) +
-                        (256 + 16) * sizeof(float);
-    const size_t ends = (size_t)small_dense_lds_floats(depth) * sizeof(float);
-    return loop > ends ? loop : ends;
+    return ((size_t)small_s_offset(depth) + (size_t)(n_types + 1) * 512) * sizeof(float);
 }
 constexpr size_t kSmallMaxLds = 160 * 1024 - 256;
 
@@ -940,14 +993,15 @@ static std::atomic<int64_t> g_small_limit{4096};
 
 // 1 = eligible: one 16-row tile per block and at most one block per CU, the weight images of a layer fit LDS and the
 // prefetch registers, the final MLP's input planes fit LDS
-int small_layout_teams(const tgnn_model_dims *d, int64_t n_nodes, int n_types) {
+int small_layout_teams(const tgnn_model_dims *d, int64_t n_nodes, int n_types, int max_in_degree) {
     const int64_t limit = g_small_limit.load(std::memory_order_relaxed);
     if (n_nodes < 2 || n_nodes > limit || n_nodes > 4096) return 0;
+    if (max_in_degree < 1 || max_in_degree + 1 > kNnEntries) return 0;   // a row's gather list (edges + the root row) in registers
     if (d->network_width != 32 || d->network_depth < 1 || d->network_depth > kSmallMaxDepth || d->output_dim > 256 ||
         d->node_features_dim > 256)
         return 0;
     if (small_lds_bytes(n_types, d->network_depth) > kSmallMaxLds) return 0;
-    if ((n_types + 1) * kWtType / 4 > kPfW * kSmallThreads) return 0;
+    if (n_types + 1 > 18 || n_types + 1 > 31) return 0;      // three runs per NNConv wave; run_type[32]
     // The grid barrier needs every block resident at the same time.  The kernel is launched as an ordinary kernel on the
     // caller's stream (a cooperative launch goes through a queue of its own: ~25 us of cross-queue dependency before and
     // after the kernel, measured), so the guarantee a cooperative launch gives is checked here instead: blocks <= CUs of

@@ -228,7 +228,7 @@ int launch_nnconv_cols(const float *h, int64_t ldh, const int32_t *tile_col_ptr,
                        hipStream_t s);
 // Small layouts: the whole forward behind a pre-pass as one persistent kernel (forward_small.hip).  small_layout_teams:
 // 0 = not eligible (too large, too many edge types for LDS, ...); the packs / images are built per forward.
-int small_layout_teams(const tgnn_model_dims *d, int64_t n_nodes, int n_types);
+int small_layout_teams(const tgnn_model_dims *d, int64_t n_nodes, int n_types, int max_in_degree);
 size_t small_pack_floats(int depth);
 void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrier_ctr, hipStream_t s);
 int launch_forward_small(const tgnn_model_dims *d, const Params &P, const float *x, float *probs, float *mid, float *a2_0,

@@ -71,6 +71,7 @@ class PreparedGraph:
     col_src: Tensor
     col_eid: Tensor
     cols: Optional["NNConvColumns"] = None     # matrix-core NNConv column structure (None: CSR kernel is used)
+    max_in_degree: int = 0                     # largest adjacency in-degree (0 = not known: no small-layout kernel)
 
     def c_struct(self) -> _lib.Graph:
         t = self.cols
@@ -78,7 +79,7 @@ class PreparedGraph:
                           self.adj_rowptr.data_ptr(), self.adj_src.data_ptr(), self.adj_type.data_ptr(),
                           self.type_rep_edge.data_ptr(), self.col_rowptr.data_ptr(), self.col_src.data_ptr(),
                           *((t.tile_col_ptr.data_ptr(), t.col_meta.data_ptr(), t.col_src.data_ptr())
-                            if t is not None else (None,) * 3))
+                            if t is not None else (None,) * 3), self.max_in_degree)
 
 
 @dataclass
@@ -178,7 +179,8 @@ def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col
     edge_type, rep, n_types = dedup_edge_types(adj_e_features)
     adj_type = torch.empty(max(ea, 1), dtype=torch.int32, device=adj.device)
     check(lib.tgnn_gather_i32(ptr(edge_type), ea, ptr(a_eid), ea, ptr(adj_type), _stream(adj)))
-    host = torch.cat([n_types, a_err, c_err, c_rowptr[n_nodes:n_nodes + 1]]).cpu().tolist()   # the one sync
+    max_deg = (a_rowptr[1:n_nodes + 1] - a_rowptr[:n_nodes]).max().reshape(1).to(torch.int32) if n_nodes > 0 else n_types * 0
+    host = torch.cat([n_types, a_err, c_err, c_rowptr[n_nodes:n_nodes + 1], max_deg]).cpu().tolist()   # the one sync
     if host[1] or host[2]:
         raise IndexError(f"edge index out of range [0, {n_nodes}) in "
                          f"{'adj_e_index' if host[1] else 'col_e_idx'}")
@@ -187,7 +189,7 @@ def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col
         columns = n_nodes > COLS_MIN_NODES
     cols = build_nnconv_columns(n_nodes, ea, n_types, a_rowptr, a_src, adj_type) if tile_width == 32 and columns else None
     return PreparedGraph(n_nodes, ea, int(host[3]), n_types, a_rowptr, a_src, a_eid, adj_type, edge_type, rep,
-                         c_rowptr, c_src, c_eid, cols)
+                         c_rowptr, c_src, c_eid, cols, max(1, int(host[4])))
 
 
 # ----------------------------------------------------------------------------------------------
