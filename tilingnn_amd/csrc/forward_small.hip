@@ -584,16 +584,7 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
         TGNN_ST(0)
         // =========================================== phase A ===========================================
         if (tw < kNnWaves) {
-            // ---- NNConv.  Stage 0: the weight fragments of this wave's runs straight from the image in global memory (used once
-            //      per tile: no LDS staging), in flight while stage 1 runs
-            const bf16x8 *wimg_l = reinterpret_cast<const bf16x8 *>(A.wimg + (size_t)layer * (T + 1) * kWtType) + lane;
-            constexpr int kPl = kWtPlane / 4, kTy = kWtType / 4;  // 16-byte fragments per plane / per type
-            bf16x8 wf[3][6];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const bf16x8 *wp = wimg_l + (size_t)(my_run_t[j] >= 0 ? my_run_t[j] : 0) * kTy;
-                wf[j][0] = wp[0]; wf[j][1] = wp[64]; wf[j][2] = wp[kPl]; wf[j][3] = wp[kPl + 64]; wf[j][4] = wp[2 * kPl]; wf[j][5] = wp[2 * kPl + 64];
-            }
+            // ---- NNConv
             // Stage 1 (waves 0, 1): gather whole 128-byte source rows, 8 rows per instruction (8 lanes x 16 bytes each: a fraction
             //      of the address-path time of the 16-rows x 64-bytes pattern of the matrix layout), and store / add them to the
             //      type-sum tiles: S[run][row] = sum of the sources of the row's edges of that type, in edge order
@@ -626,7 +617,18 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_s_barrier();                         // (all eight waves: the collision waves pass theirs after issuing their gathers)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            // Stage 2: D^T += W_t^T . S_t^T for this wave's runs (root run: operand pre-multiplied by max(deg, 1))
+            // Stage 2: the weight fragments of this wave's runs straight from the image in global memory (used once per tile: no LDS
+            //      staging).  Issued only now: ahead of the gathers, these 108 KB per tile held up the collision waves' gathers --
+            //      the longer chain -- by ~2 us in the CU's memory pipeline; this chain has the slack.
+            const bf16x8 *wimg_l = reinterpret_cast<const bf16x8 *>(A.wimg + (size_t)layer * (T + 1) * kWtType) + lane;
+            constexpr int kPl = kWtPlane / 4, kTy = kWtType / 4;  // 16-byte fragments per plane / per type
+            bf16x8 wf[3][6];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const bf16x8 *wp = wimg_l + (size_t)(my_run_t[j] >= 0 ? my_run_t[j] : 0) * kTy;
+                wf[j][0] = wp[0]; wf[j][1] = wp[64]; wf[j][2] = wp[kPl]; wf[j][3] = wp[kPl + 64]; wf[j][4] = wp[2 * kPl]; wf[j][5] = wp[2 * kPl + 64];
+            }
+            //      D^T += W_t^T . S_t^T for this wave's runs (root run: operand pre-multiplied by max(deg, 1))
             f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;           // row fj, channels 4 fq + r and 16 + 4 fq + r
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
