@@ -78,7 +78,7 @@ struct Workspace {
     float *mid, *a1, *a2[2], *t0, *f1, *f2, *f3, *f4, *wtab, *wimg;
     double *part1, *part2, *partf;
     float *small_pack;            // small-layout kernel: per-layer parameter packs, its partial rows, its barrier counter
-    double *small_part, *small_part_wide;
+    double *small_part, *small_part_wide, *small_runstat;
     unsigned *small_ctr;
     float *stat1, *stat2[2], *stat_i[2], *stat_f[4];
     size_t bytes;
@@ -143,6 +143,7 @@ static Workspace carve(const tgnn_model_dims &d, int64_t n, int64_t nr, int32_t 
     w.small_pack = cv.take<float>(small_pack_floats(D));
     w.small_part = cv.take<double>((size_t)256 * 128);
     w.small_part_wide = cv.take<double>((size_t)256 * 512);
+    w.small_runstat = cv.take<double>((size_t)D * 128);
     w.small_ctr = cv.take<unsigned>(64);
     w.stat1 = cv.take<float>(4 * c);
     w.stat2[0] = cv.take<float>(4 * c);
@@ -357,7 +358,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         // init MLP, the layers and the final MLP: one persistent kernel behind the pre-pass
         if (sw != s) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[kEvWeights], 0));
         TGNN_TRY(launch_forward_small(dims, P, x, probs, w.mid, w.a2[0], w.a2[1], w.wimg, w.small_pack, graph, w.small_part,
-                                      w.small_part_wide, w.small_ctr, n, update_running, eps, momentum, s));
+                                      w.small_part_wide, w.small_runstat, w.small_ctr, n, update_running, eps, momentum, s));
         TGNN_CHECK_LAUNCH();
         return TGNN_OK;
     }

@@ -1,27 +1,32 @@
-// The 20 message-passing layers of TilinGNN.forward (/root/reference/graph_networks/networks/TilinGNN.py:59-71) for SMALL
-// layouts as ONE persistent kernel with grid-wide barriers.
+// TilinGNN.forward (/root/reference/graph_networks/networks/TilinGNN.py:54-76) for SMALL layouts -- init MLP, the 20 message-passing
+// layers, final MLP -- as ONE persistent kernel with grid-wide barriers.
 //
 // Why: the layouts the greedy solver actually scores (1 254 nodes for the labyrinth example, shrinking every round) have
 // ~80 16-row tiles -- fewer than the chip has CUs.  The general schedule (forward.hip) spends such a forward in ~130
 // dependent kernel launches at ~5 us of GPU-side dispatch latency each (measured: hipGraph replay does not help, the
-// gap is between dependent dispatches, not in the host's launch path).  Here one block owns TEAMS tiles for all layers:
-//     phase A   NNConv of the tile on three waves (column chunks, partial products summed through LDS) while the fourth
-//               wave gathers the tile's collision neighbourhoods and runs the GIN MLP; BatchNorm column sums of the
-//               block -> one partial row
+// gap is between dependent dispatches, not in the host's launch path).  Here one block (8 waves) owns one 16-row tile
+// from the first Linear to the sigmoid.  A message-passing layer is
+//     phase A   NNConv: two waves gather the tile's source rows -- whole 128-byte rows, 8 per load instruction, a row's edges
+//               as a list -- into per-type sum tiles in LDS, then six waves multiply them by the types' weight fragments
+//               (straight from the image in global memory, used once per tile) and two waves finish the mean / bias / LeakyReLU.
+//               Beside them one wave per half tile runs the whole collision branch: gather, neighbourhood sum, GIN MLP.
+//               BatchNorm column sums of the tile -> one partial row
 //     barrier   (all blocks)
 //     phase B   every block folds all partial rows in the same fixed order -> both BatchNorm records; merge of its own
 //               rows (BN1(a1) * BN2(a2) + residual) -> the next slot of the skip buffer
 //     barrier
-// so a layer costs two barriers (~1.5 us each at 80 blocks) instead of five dependent launches.
+// i.e. two barriers (~1.5 us each at 80 blocks) instead of five dependent launches; the dense layers of the init / final MLP
+// run on the tile's own rows with one barrier per BatchNorm.
 //
 // Cross-block data (skip-buffer rows, the collision branch's pre-BN rows, the partial rows) is written and read with sc1
 // (agent-scope) buffer instructions: each XCD has its own L2, and the release/acquire fences that would make ordinary
 // accesses visible across XCDs (buffer_wbl2 / buffer_inv) serialise per XCD -- 10.8 us per barrier at 256 blocks against
-// 3.8 us without them (scratch/ubench/gridsync.hip).  The barrier itself is a monotonic counter.
+// 3.8 us without them (scratch/ubench/gridsync.hip).  The barrier itself is a monotonic counter.  All blocks must be
+// resident at once: small_layout_teams() checks the device's capacity (see there why this is not a cooperative launch).
 //
-// Arithmetic: the same formulas as the general path's kernels (nnconv_cols.hip, gin.hip, bn_merge.hip); what differs is the
-// association of two sums (NNConv: three partial products per tile; BatchNorm: one partial row per block), i.e. fp32 / fp64
-// rounding only.  Deterministic: every order is fixed.
+// Arithmetic: the same formulas as the general path's kernels (nnconv_cols.hip, gin.hip, dense.hip, bn_merge.hip); what differs
+// is the association of sums (NNConv: six partial products per tile; BatchNorm: one partial row per tile; dense layers: K in
+// steps of 32), i.e. fp32 / fp64 rounding only.  Deterministic: every order is fixed.
 #include "tgnn_common.h"
 
 namespace tgnn {
@@ -132,6 +137,7 @@ struct SmallArgs {
     const int *tile_col_ptr, *col_meta, *col_src;   // NNConv column structure (graph_prep.hip)
     const int *col_rowptr, *col_nbr;                // collision CSR by destination
     double *part;                // [blocks][128]: bn1 sum | bn1 sumsq | bn2 sum | bn2 sumsq
+    double *runstat;             // [depth][2][mean 32 | unbiased variance 32]: batch statistics of the layers, for the running buffers
     unsigned *ctr;               // barrier counter (zeroed by small_pack_kernel)
     int64_t n;
     int n_types, depth, update_running;
@@ -881,13 +887,11 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
                 rec[64 + ch] = (float)((double)gamma / sqrt(var + (double)A.eps));
                 rec[96 + ch] = beta;
                 if (blockIdx.x == 0 && A.update_running) {
-                    const SmallRun run = R.l[layer];
-                    float *rm = job ? run.rm2 : run.rm1, *rv = job ? run.rv2 : run.rv1;
-                    int64_t *nbt = job ? run.nbt2 : run.nbt1;
-                    const double unbiased = n > 1 ? var * ((double)n / (double)(n - 1)) : var;
-                    rm[ch] = (float)((1.0 - (double)A.momentum) * (double)rm[ch] + (double)A.momentum * mean);
-                    rv[ch] = (float)((1.0 - (double)A.momentum) * (double)rv[ch] + (double)A.momentum * unbiased);
-                    if (ch == 0) *nbt += 1;
+                    // the running buffers are updated after the last layer (their read-modify-write round trips would make
+                    // block 0 the straggler of every barrier): park the batch statistics
+                    double *rs = A.runstat + (size_t)layer * 128 + job * 64;
+                    rs[ch] = mean;
+                    rs[32 + ch] = n > 1 ? var * ((double)n / (double)(n - 1)) : var;
                 }
             }
             __syncthreads();
@@ -926,6 +930,20 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
 #endif
         }
         TGNN_ST(7)
+    }
+
+    if (blockIdx.x == 0 && A.update_running) {
+        // running statistics of the 2 x depth BatchNorms of the layers (momentum update, num_batches_tracked)
+        __syncthreads();
+        for (int idx = tid; idx < D * 64; idx += NT) {
+            const int l = idx >> 6, job = (idx >> 5) & 1, ch = idx & 31;
+            const SmallRun run = R.l[l];
+            float *rm = job ? run.rm2 : run.rm1, *rv = job ? run.rv2 : run.rv1;
+            const double *rs = A.runstat + (size_t)l * 128 + job * 64;
+            rm[ch] = (float)((1.0 - (double)A.momentum) * (double)rm[ch] + (double)A.momentum * rs[ch]);
+            rv[ch] = (float)((1.0 - (double)A.momentum) * (double)rv[ch] + (double)A.momentum * rs[32 + ch]);
+            if (ch == 0) *(job ? run.nbt2 : run.nbt1) += 1;
+        }
     }
 
     // ====================================== final MLP (TilinGNN.py:74-76) ======================================
@@ -1069,7 +1087,7 @@ void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrie
 // The whole forward behind the pre-pass: x -> probs (stream order)
 int launch_forward_small(const tgnn_model_dims *d, const Params &P, const float *x, float *probs, float *mid, float *a2_0,
                          float *a2_1, const float *wimg, float *pack, const tgnn_graph *graph, double *part, double *part_wide,
-                         unsigned *ctr, int64_t n, int update_running, float eps, float momentum, hipStream_t s) {
+                         double *runstat, unsigned *ctr, int64_t n, int update_running, float eps, float momentum, hipStream_t s) {
     const int depth = d->network_depth;
     SmallArgs A{};
     A.mid = mid;
@@ -1083,6 +1101,7 @@ int launch_forward_small(const tgnn_model_dims *d, const Params &P, const float 
     A.col_rowptr = graph->col_rowptr;
     A.col_nbr = graph->col_src;
     A.part = part;
+    A.runstat = runstat;
     A.ctr = ctr;
     A.n = n;
     A.n_types = graph->n_types;

@@ -233,7 +233,7 @@ size_t small_pack_floats(int depth);
 void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrier_ctr, hipStream_t s);
 int launch_forward_small(const tgnn_model_dims *d, const Params &P, const float *x, float *probs, float *mid, float *a2_0,
                          float *a2_1, const float *wimg, float *pack, const tgnn_graph *graph, double *part, double *part_wide,
-                         unsigned *ctr, int64_t n, int update_running, float eps, float momentum, hipStream_t s);
+                         double *runstat, unsigned *ctr, int64_t n, int update_running, float eps, float momentum, hipStream_t s);
 // MFMA weight image of the column NNConv, per type: [plane 3 (hi, mid, lo)][M block 2][g 4][i 16] x 8 bf16 --
 // the A fragment of lane 16 g + i for one (plane, M block) is one 16-byte read, a wavefront reads 1 KB in lane order
 // (conflict-free: SQ_LDS_BANK_CONFLICT 2.3e6 -> 2.3e5 per launch against the [i][g] order of round 1); 6144 B per type
