@@ -389,6 +389,45 @@ def main():
         del net3, x3, adj3, attr3, col3
         torch.cuda.empty_cache()
 
+    # ---- BASELINE config 0: the reference's own example, the real labyrinth layout (1 254 nodes, 8 502 + 10 472 edges, T = 13):
+    #      what a greedy round scores.  Small layouts run the forward as one persistent kernel (csrc/forward_small.hip); the
+    #      general launch schedule is timed beside it (tgnn_set_small_layout_limit(0)).
+    real_layout = None
+    if not sharded and not args.no_extra_sizes:
+        try:
+            from tests.golden_util import graph_tensors, load_labyrinth_graph
+            from tilingnn_amd import _lib
+            gl = load_labyrinth_graph()
+            xl, adjl, attrl, coll, _ = graph_tensors(gl, torch.float32, dev)
+            netl = TilinGNN(adj_edge_features_dim=int(attrl.shape[1]), network_depth=DEPTH, network_width=WIDTH,
+                            node_features_dim=int(xl.shape[1]))
+            netl.load_state_dict(make_state_dict(int(attrl.shape[1]), DEPTH, WIDTH, 1, int(xl.shape[1]), seed=0), strict=True)
+            netl = netl.to(dev).train()
+            resl = {}
+            limit0 = _lib.lib.tgnn_get_small_layout_limit()
+            for name, limit, cached in (("persistent_kernel_ms", limit0, False), ("persistent_kernel_cached_layout_ms", limit0, True),
+                                        ("general_schedule_ms", 0, False), ("general_schedule_cached_layout_ms", 0, True)):
+                _lib.lib.tgnn_set_small_layout_limit(limit)
+                netl.cache_graph = cached
+                for _ in range(5):
+                    netl(x=xl, adj_e_index=adjl, adj_e_features=attrl, col_e_idx=coll)
+                torch.cuda.synchronize()
+                ts = []
+                for _ in range(30):
+                    tb = time.perf_counter()
+                    netl(x=xl, adj_e_index=adjl, adj_e_features=attrl, col_e_idx=coll)
+                    torch.cuda.synchronize()
+                    ts.append((time.perf_counter() - tb) * 1e3)
+                resl[name] = sorted(ts)[len(ts) // 2]
+            _lib.lib.tgnn_set_small_layout_limit(limit0)
+            real_layout = {"workload": "TilinGNN.forward on data/labyrinth's complete graph (1254 nodes, 8502 + 10472 edges, T=13), "
+                                       "width 32, depth 20, fp32; median of 30, host-synchronised per forward",
+                           **resl, "value": 1254 / (resl["persistent_kernel_ms"] * 1e-3), "unit": "tile-nodes/s",
+                           "design": "DESIGN.md section 12"}
+            del netl
+        except FileNotFoundError:
+            real_layout = None
+
     # ---- the loss ML_Solver.predict evaluates on the probabilities: two launches, HBM bound
     loss_info = None
     if not sharded:
@@ -513,6 +552,8 @@ def main():
             line["kernel_classes"] = class_ms
         if extras is not None:
             line["larger_layouts_single_gpu"] = extras
+        if real_layout is not None:
+            line["config0_real_layout"] = real_layout
         if config3 is not None:
             line["config3_width64_bf16"] = config3
         if sharded:
