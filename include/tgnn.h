@@ -340,6 +340,23 @@ int tgnn_forward_sharded(const tgnn_model_dims *dims, const void *const *params_
 void tgnn_set_small_layout_limit(int64_t n_nodes);
 int64_t tgnn_get_small_layout_limit(void);
 
+/* Small layouts (<= tgnn_graph_prep_small_max_nodes() nodes, <= ..._max_edges() edges per set): everything above --
+ * tgnn_csr_build of both edge sets (self loops dropped from the collision set), tgnn_edge_type_dedup, the types in CSR
+ * order, tgnn_nnconv_cols_build -- in ONE launch (up to 16 resident blocks with grid barriers); every output bit-identical
+ * to the separate calls.  tmp: tgnn_graph_prep_small_tmp_ints() ints.  counters: 2 words that are zero before the first
+ * call and zero again when a call has finished (one call at a time per counter pair).  result [32] (device; 8 used): n_types,
+ * adjacency index error, collision index error, collision CSR slots, largest adjacency in-degree, 1 = column structure
+ * built (n_types <= tgnn_nnconv_cols_max_types()), 1 = fall back to the separate calls (more than 1024 distinct attribute
+ * rows).  Asynchronous. */
+int64_t tgnn_graph_prep_small_max_nodes(void);
+int64_t tgnn_graph_prep_small_max_edges(void);
+size_t tgnn_graph_prep_small_tmp_ints(int64_t n_nodes, int64_t n_adj_edges, int64_t n_col_edges);
+int tgnn_graph_prep_small(const int64_t *adj_edge_index, int64_t n_adj_edges, const float *adj_edge_attr, int32_t fe,
+                          const int64_t *col_edge_index, int64_t n_col_edges, int64_t n_nodes, int32_t *adj_rowptr,
+                          int32_t *adj_src, int32_t *adj_eid, int32_t *adj_type, int32_t *edge_type, int32_t *type_rep_edge,
+                          int32_t *col_rowptr, int32_t *col_src, int32_t *col_eid, int32_t *tile_col_ptr, int32_t *col_meta,
+                          int32_t *col_slot_src, int32_t *tmp, int32_t *result, uint32_t *counters, tgnn_stream_t stream);
+
 /* The same forward with a hipEvent pair around every launch (on `stream`, where the kernels run);
  * synchronises, then ADDS the elapsed milliseconds and launch counts per kernel class into the
  * two host arrays of TGNN_PROF_CLASSES entries.  Measurement aid for bench.py's roofline line. */

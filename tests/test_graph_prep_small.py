@@ -1,0 +1,91 @@
+"""The one-launch preparation of small layouts (tgnn_graph_prep_small) against the separate calls: every array bit-identical."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import graph_tensors, load_labyrinth_graph
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _both(n, adj, attr, col, monkeypatch):
+    from tilingnn_amd import ops
+    monkeypatch.setattr(ops, "SMALL_PREP", False)
+    ref = ops.prepare_graph(n, adj, attr, col)
+    monkeypatch.setattr(ops, "SMALL_PREP", True)
+    got = ops.prepare_graph(n, adj, attr, col)
+    return ref, got
+
+
+def _same(ref, got):
+    assert (got.n_nodes, got.n_adj_edges, got.n_col_edges, got.n_types, got.max_in_degree) == \
+        (ref.n_nodes, ref.n_adj_edges, ref.n_col_edges, ref.n_types, ref.max_in_degree)
+    n, t = ref.n_nodes, ref.n_types
+    na, nc = int(ref.adj_rowptr[n]), int(ref.col_rowptr[n])
+    for name, cut in (("adj_rowptr", n + 1), ("adj_src", na), ("adj_eid", na), ("adj_type", na), ("edge_type", ref.n_adj_edges),
+                      ("type_rep_edge", t), ("col_rowptr", n + 1), ("col_src", nc), ("col_eid", nc)):
+        a, b = getattr(ref, name)[:cut].cpu(), getattr(got, name)[:cut].cpu()
+        assert torch.equal(a, b), name
+    assert (ref.cols is None) == (got.cols is None)
+    if ref.cols is not None:
+        ntiles = (n + 15) // 16
+        assert torch.equal(ref.cols.tile_col_ptr[:ntiles + 1].cpu(), got.cols.tile_col_ptr[:ntiles + 1].cpu())
+        ncol = int(ref.cols.tile_col_ptr[ntiles])
+        assert torch.equal(ref.cols.col_meta[:ncol].cpu(), got.cols.col_meta[:ncol].cpu())
+        assert torch.equal(ref.cols.col_src[:ncol * 16].cpu(), got.cols.col_src[:ncol * 16].cpu())
+
+
+def test_labyrinth_layout(dev, monkeypatch):
+    x, adj, attr, col, _ = graph_tensors(load_labyrinth_graph(), torch.float32, dev)
+    ref, got = _both(1254, adj, attr, col, monkeypatch)
+    assert got.adj_rowptr.data_ptr() != ref.adj_rowptr.data_ptr() and got.n_types == 13
+    _same(ref, got)
+
+
+@pytest.mark.parametrize("n,ea,ec,t,seed", [(17, 68, 50, 13, 1), (300, 3000, 3750, 13, 2), (1000, 6800, 8350, 5, 3),
+                                            (2500, 25000, 31250, 13, 4), (4096, 40960, 51200, 30, 5), (640, 6400, 8000, 60, 6)])
+def test_synthetic_layouts(dev, monkeypatch, n, ea, ec, t, seed):
+    from tilingnn_amd.synth import make_super_graph
+    sg = make_super_graph(n, ea, ec, tile_count=2, n_edge_types=t, seed=seed)
+    x, adj, attr, col, _ = sg.to_torch(dev)
+    _same(*_both(n, adj, attr, col, monkeypatch))
+
+
+def test_self_loops_isolated_rows_and_signed_zeros(dev, monkeypatch):
+    n = 40
+    rng = np.random.default_rng(0)
+    adj = torch.tensor(rng.integers(0, 20, size=(2, 150)), device=dev)          # rows 20 .. 39 have no in-edges
+    col = torch.tensor(rng.integers(0, n, size=(2, 200)), device=dev)
+    col[1, :30] = col[0, :30]                                                   # self loops: dropped from the collision set
+    attr = torch.tensor(rng.integers(0, 3, size=(150, 4)).astype(np.float32), device=dev)
+    attr[::7, 0] = -0.0                                                         # -0.0 == +0.0 for the de-duplication
+    attr[attr == 0] = torch.where(torch.rand_like(attr[attr == 0]) < 0.5, 0.0, -0.0)
+    _same(*_both(n, adj, attr, col, monkeypatch))
+
+
+def test_index_errors_are_raised(dev):
+    from tilingnn_amd import ops
+    adj = torch.tensor([[0, 1, 2], [1, 2, 99]], device=dev)
+    col = torch.tensor([[0, 1], [1, 0]], device=dev)
+    attr = torch.zeros(3, 2, device=dev)
+    with pytest.raises(IndexError):
+        ops.prepare_graph(10, adj, attr, col)
+    with pytest.raises(IndexError):
+        ops.prepare_graph(10, col, attr[:2], adj)
+
+
+def test_many_distinct_rows_fall_back(dev, monkeypatch):
+    n, e = 500, 4000
+    rng = np.random.default_rng(1)
+    adj = torch.tensor(rng.integers(0, n, size=(2, e)), device=dev)
+    col = torch.tensor(rng.integers(0, n, size=(2, 100)), device=dev)
+    attr = torch.tensor(rng.normal(size=(e, 3)).astype(np.float32), device=dev)   # every row distinct: 4 000 "types"
+    ref, got = _both(n, adj, attr, col, monkeypatch)
+    assert got.n_types == e and got.cols is None
+    _same(ref, got)

@@ -400,6 +400,424 @@ __global__ __launch_bounds__(64) void nnconv_col_kernel(const int *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Small layouts (what the greedy loop scores every round: ~1 000 nodes, ~20 000 edges): the whole preparation -- both CSRs,
+// the exact edge-type de-duplication, types in CSR order, the NNConv column structure -- in ONE launch instead of ~30 tiny
+// ones (0.19 ms per layout of which the kernels themselves were a fifth): up to 16 resident blocks that pass through the
+// phases together (grid barrier: counter + agent-scope release / acquire by one thread per block, ~1 us at 16 blocks).
+// A single block was tried first: 150-200 us, every phase a chain of global round trips with one CU to hide them behind.
+// Every output is bit-identical to what tgnn_csr_build / tgnn_edge_type_dedup / tgnn_gather_i32 / tgnn_nnconv_cols_build
+// produce (tests/test_graph_prep_small.py).
+// ------------------------------------------------------------------------------------------
+constexpr int kSmallPrepThreads = 1024, kSmallPrepMaxNodes = 4096, kSmallPrepMaxBlocks = 16;
+constexpr int kSmallPrepLocal = 8192;                 // slots of a block's LDS de-dup table (its <= 8192 edges, <= 4096 distinct)
+constexpr int kSmallPrepGlobal = 8192;                // slots of the global table of block representatives (<= 1024 types)
+constexpr int kSmallPrepMaxTypes = 1024;
+
+struct SmallPrepArgs {
+    const int64_t *adj_ei, *col_ei;                   // [2][E]: sources, then destinations
+    const float *attr;                                // [Ea][fe]
+    int64_t n, ea, ec;
+    int fe, max_col_types;
+    int *adj_rowptr, *adj_src, *adj_eid, *adj_type;   // CSR of the adjacency set, types in CSR order
+    int *edge_type, *type_rep;                        // types in edge order; first edge of every type
+    int *col_rowptr, *col_src, *col_eid;              // CSR of the collision set (self loops dropped)
+    int *tile_col_ptr, *col_meta, *col_slot_src;      // NNConv column structure
+    int *tmp;                                         // tgnn_graph_prep_small_tmp_ints()
+    int *result;                                      // [8]: n_types, adj_err, col_err, n_col_edges, max_in_degree, cols_built, fallback
+    unsigned *ctr;                                    // [2] barrier counter, exit counter: zero before the first use, zero on return
+};
+
+// block-wide exclusive scan of a[0 .. m) in LDS, m <= 5 * 1024; returns the total
+__device__ int small_block_scan(int *a, int m, int *wave_tot) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int v[5], tsum = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        v[k] = tid * 5 + k < m ? a[tid * 5 + k] : 0;
+        tsum += v[k];
+    }
+    const int incl = wave_inclusive_scan(tsum);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int woff = 0, total = 0;
+    for (int w = 0; w < kSmallPrepThreads / 64; ++w) {
+        if (w < wave) woff += wave_tot[w];
+        total += wave_tot[w];
+    }
+    int run = woff + incl - tsum;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        if (tid * 5 + k < m) a[tid * 5 + k] = run;
+        run += v[k];
+    }
+    __syncthreads();
+    return total;
+}
+
+// all blocks resident (<= 16); ordinary loads / stores on both sides: one thread per block releases / acquires at agent scope
+__device__ __forceinline__ void small_prep_barrier(unsigned *ctr, unsigned &target, unsigned nblk) {
+    __syncthreads();
+    target += nblk;
+    if (nblk > 1 && threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kSmallPrepThreads) void graph_prep_small_kernel(SmallPrepArgs A) {
+    extern __shared__ int sm[];
+    int *rpA = sm;                                    // [n + 1] row starts of the adjacency CSR (every block scans its own copy)
+    int *rpC = rpA + kSmallPrepMaxNodes + 8;
+    int *ltab = rpC + kSmallPrepMaxNodes + 8;         // [kSmallPrepLocal] this block's de-dup table; later: type of a global slot
+    int *gslot = ltab + kSmallPrepLocal;              // [kSmallPrepLocal] global slot of a local slot; later: the column counts
+    int *misc = gslot + kSmallPrepLocal;              // [64]
+    int *wave_tot = misc;
+    const int tid = threadIdx.x, NT = kSmallPrepThreads, G = gridDim.x, blk = blockIdx.x;
+    const int gtid = blk * NT + tid, GT = G * NT;
+    const int n = (int)A.n, ea = (int)A.ea, ec = (int)A.ec;
+    const int emax = ea > ec ? ea : ec, nt16 = (n + kColTileRows - 1) / kColTileRows;
+    // global scratch
+    int *g_cntA = A.tmp, *g_cntC = g_cntA + n + 1;
+    int *g_rankA = g_cntC + n + 1, *g_rankC = g_rankA + ea;
+    int *t_eidA = g_rankC + ec, *t_eidC = t_eidA + ea;
+    int *slot_of_edge = t_eidC + ec;
+    int *g_table = slot_of_edge + ea;
+    int *g_tile_cols = g_table + kSmallPrepGlobal;
+    int *g_flags = g_tile_cols + nt16 + 1;            // 0 adj_err, 1 col_err, 2 fallback, 3 claimed global slots
+    (void)emax;
+    unsigned target = 0;
+#ifdef TGNN_PREP_TIMING
+    unsigned long long tl = wall_clock64();
+    int tslot = 8;
+#define TGNN_PT { const unsigned long long now_ = wall_clock64(); if (gtid == 0) A.result[tslot] = (int)(now_ - tl); ++tslot; tl = now_; }
+#else
+#define TGNN_PT
+#endif
+
+    // ---- phase 0: zero the counters
+    for (int i = gtid; i <= n; i += GT) g_cntA[i] = g_cntC[i] = 0;
+    for (int i = gtid; i < kSmallPrepGlobal; i += GT) g_table[i] = -1;
+    if (gtid < 16) g_flags[gtid] = 0;
+    small_prep_barrier(A.ctr, target, G);
+
+    TGNN_PT
+    // ---- phase 1: in-degree counts; the value the atomic returns is the edge's arrival rank inside its row (csr_count_kernel)
+    for (int i = gtid; i < ea; i += GT) {
+        const int64_t s = A.adj_ei[i], d = A.adj_ei[(int64_t)ea + i];
+        int r = -1;
+        if (s < 0 || s >= n || d < 0 || d >= n) g_flags[0] = 1;
+        else r = atomicAdd(&g_cntA[d], 1);
+        g_rankA[i] = r;
+    }
+    for (int i = gtid; i < ec; i += GT) {
+        const int64_t s = A.col_ei[i], d = A.col_ei[(int64_t)ec + i];
+        int r = -1;
+        if (s < 0 || s >= n || d < 0 || d >= n) g_flags[1] = 1;
+        else if (s != d) r = atomicAdd(&g_cntC[d], 1);
+        g_rankC[i] = r;
+    }
+    small_prep_barrier(A.ctr, target, G);
+
+    TGNN_PT
+    // ---- phase 2: row starts (every block its own copy in LDS); block 0 writes them out
+    int maxdeg = 0;
+    for (int i = tid; i <= n; i += NT) {
+        rpA[i] = g_cntA[i];
+        rpC[i] = g_cntC[i];
+        if (i < n) maxdeg = max(maxdeg, rpA[i]);
+    }
+    if (tid < 64) misc[32 + (tid & 15)] = 0;
+    __syncthreads();
+    atomicMax(&misc[32], maxdeg);
+    const int ea_valid = small_block_scan(rpA, n + 1, wave_tot);
+    const int ec_valid = small_block_scan(rpC, n + 1, wave_tot);
+    maxdeg = misc[32];
+    if (blk == 0)
+        for (int i = tid; i <= n; i += NT) {
+            A.adj_rowptr[i] = rpA[i];
+            A.col_rowptr[i] = rpC[i];
+        }
+
+    TGNN_PT
+    // ---- phase 3: edge numbers in arrival order; phase 4: every edge finds its rank inside its row by edge number -- the
+    //      original edge order, which is what the reference's scatter sees (csr_fill_kernel + csr_sort_rows_kernel)
+    for (int i = gtid; i < ea; i += GT) {
+        const int r = g_rankA[i];
+        if (r >= 0) t_eidA[rpA[A.adj_ei[(int64_t)ea + i]] + r] = i;
+    }
+    for (int i = gtid; i < ec; i += GT) {
+        const int r = g_rankC[i];
+        if (r >= 0) t_eidC[rpC[A.col_ei[(int64_t)ec + i]] + r] = i;
+    }
+    small_prep_barrier(A.ctr, target, G);
+    TGNN_PT
+    for (int pass = 0; pass < 2; ++pass) {
+        const int64_t *ei = pass ? A.col_ei : A.adj_ei;
+        const int e = pass ? ec : ea;
+        const int *rank_in = pass ? g_rankC : g_rankA, *t_eid = pass ? t_eidC : t_eidA, *rp = pass ? rpC : rpA;
+        int *o_src = pass ? A.col_src : A.adj_src, *o_eid = pass ? A.col_eid : A.adj_eid;
+        for (int i = gtid; i < e; i += GT) {
+            if (rank_in[i] < 0) continue;
+            const int d = (int)ei[(int64_t)e + i], b = rp[d], en = rp[d + 1];
+            int rank = 0;
+            for (int q = b; q < en; q += 8) {          // 8 keys of the row in flight
+                int kq[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) kq[u] = q + u < en ? t_eid[q + u] : 0x7fffffff;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) rank += kq[u] < i;
+            }
+            o_src[b + rank] = (int)ei[i];
+            o_eid[b + rank] = i;
+        }
+    }
+
+    TGNN_PT
+    // ---- phase 5: exact de-duplication of the attribute rows (tgnn_edge_type_dedup).  Level 1: the block's contiguous share
+    //      of the edges in its LDS table (slot = smallest of its edges with that content); level 2: the block's
+    //      representatives in the global table (slot = smallest edge overall)
+    auto same_row = [&](int a, int b) {                 // all loads of both rows before the first compare (no early exit)
+        const float *ra = A.attr + (int64_t)a * A.fe, *rb = A.attr + (int64_t)b * A.fe;
+        uint32_t diff = 0;
+#pragma unroll 8
+        for (int k = 0; k < A.fe; ++k) diff |= canon_bits(ra[k]) ^ canon_bits(rb[k]);
+        return diff == 0;
+    };
+    for (int i = tid; i < kSmallPrepLocal; i += NT) ltab[i] = -1;
+    if (tid == 0) misc[40] = 0;                        // distinct rows of this block
+    __syncthreads();
+    const int e_lo = (int)((int64_t)ea * blk / G), e_hi = (int)((int64_t)ea * (blk + 1) / G);
+    int my_l[8];                                        // local slots of this thread's (at most 8) edges
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = e_lo + u * NT + tid;
+        my_l[u] = -1;
+        if (i < e_hi) {
+            uint64_t h = 0xCBF29CE484222325ull;
+#pragma unroll 8
+            for (int k = 0; k < A.fe; ++k) h = mix64(h, canon_bits(A.attr[(int64_t)i * A.fe + k]));
+            uint32_t sl = (uint32_t)(h ^ (h >> 32)) & (kSmallPrepLocal - 1);
+            int probes = 0;
+            while (true) {
+                int cur = ltab[sl];
+                if (cur < 0) {
+                    const int prev = atomicCAS(&ltab[sl], -1, i);
+                    if (prev < 0) {
+                        if (atomicAdd(&misc[40], 1) >= kSmallPrepLocal / 2) g_flags[2] = 1;
+                        break;
+                    }
+                    cur = prev;
+                }
+                if (cur == i || same_row(cur, i)) {
+                    if (i < cur) atomicMin(&ltab[sl], i);
+                    break;
+                }
+                sl = (sl + 1) & (kSmallPrepLocal - 1);
+                if (++probes >= kSmallPrepLocal) {
+                    g_flags[2] = 1;
+                    break;
+                }
+            }
+            my_l[u] = (int)sl;
+        }
+    }
+    __syncthreads();
+    for (int sl = tid; sl < kSmallPrepLocal; sl += NT) {
+        const int i = ltab[sl];
+        if (i < 0) continue;
+        uint64_t h = 0xCBF29CE484222325ull;
+#pragma unroll 8
+        for (int k = 0; k < A.fe; ++k) h = mix64(h, canon_bits(A.attr[(int64_t)i * A.fe + k]));
+        uint32_t slot = (uint32_t)(h ^ (h >> 32)) & (kSmallPrepGlobal - 1);
+        int probes = 0;
+        while (true) {
+            int cur = __hip_atomic_load(&g_table[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur < 0) {
+                const int prev = atomicCAS(&g_table[slot], -1, i);
+                if (prev < 0) {
+                    if (atomicAdd(&g_flags[3], 1) >= kSmallPrepMaxTypes) g_flags[2] = 1;
+                    break;
+                }
+                cur = prev;
+            }
+            if (cur == i || same_row(cur, i)) {
+                if (i < cur) atomicMin(&g_table[slot], i);
+                break;
+            }
+            slot = (slot + 1) & (kSmallPrepGlobal - 1);
+            if (++probes >= kSmallPrepGlobal) {
+                g_flags[2] = 1;
+                break;
+            }
+        }
+        gslot[sl] = (int)slot;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = e_lo + u * NT + tid;
+        if (i < e_hi) slot_of_edge[i] = my_l[u] >= 0 ? gslot[my_l[u]] : 0;
+    }
+    small_prep_barrier(A.ctr, target, G);
+
+    TGNN_PT
+    // ---- phase 6: types are numbered in the order of their first edges: rank of a representative among the representatives
+    //      (every block for itself: type of a global slot in LDS)
+    const bool fallback = __hip_atomic_load(&g_flags[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    int *type_of = ltab, *reps = gslot, *rep_slot = gslot + kSmallPrepMaxTypes, *occ = gslot + 2 * kSmallPrepMaxTypes;
+    int n_types = 0;
+    if (!fallback) {
+        constexpr int per = kSmallPrepGlobal / kSmallPrepThreads;
+        int c = 0;
+        for (int k = 0; k < per; ++k) {
+            type_of[tid * per + k] = g_table[tid * per + k];
+            c += type_of[tid * per + k] >= 0;
+        }
+        occ[tid] = c;
+        __syncthreads();
+        n_types = small_block_scan(occ, NT, wave_tot);       // (<= kSmallPrepMaxTypes: more would have raised the flag)
+        int at = occ[tid];
+        for (int k = 0; k < per; ++k) {
+            const int sl = tid * per + k;
+            if (type_of[sl] >= 0) {
+                reps[at] = type_of[sl];
+                rep_slot[at] = sl;
+                ++at;
+            }
+        }
+        __syncthreads();
+        if (tid < n_types) {
+            const int mine = reps[tid];
+            int rank = 0;
+            for (int j = 0; j < n_types; ++j) rank += reps[j] < mine;
+            if (blk == 0) A.type_rep[rank] = mine;
+            type_of[rep_slot[tid]] = rank;
+        }
+        __syncthreads();
+        // ---- phase 7: types in edge order and in CSR order
+        for (int i = gtid; i < ea; i += GT) A.edge_type[i] = type_of[slot_of_edge[i]];
+        for (int p = gtid; p < ea; p += GT) A.adj_type[p] = p < ea_valid ? type_of[slot_of_edge[A.adj_eid[p]]] : 0;
+    }
+    small_prep_barrier(A.ctr, target, G);
+
+    TGNN_PT
+    // ---- phase 8: NNConv column structure (nnconv_col_kernel, both passes): groups of tiles round the blocks, one thread per row
+    const bool cols = !fallback && n_types <= A.max_col_types && n_types <= kMaxColTypes;
+    if (cols) {
+        // counts [rows of the group][ld], ld = (types + 1) | 1 (odd: the per-row walks hit distinct banks)
+        const int ld = (n_types + 1) | 1;
+        int tiles_pp = (kSmallPrepLocal - 2 * 64 * (kMaxColTypes + 1)) / (16 * ld);
+        tiles_pp = tiles_pp > 64 ? 64 : tiles_pp;
+        const int rows_pp = tiles_pp * 16;
+        int *cnt = gslot;                              // (the de-dup lists are done with)
+        int *maxm = cnt + rows_pp * ld;                // [tiles_pp][kMaxColTypes]
+        int *base = maxm + 64 * kMaxColTypes;          // [tiles_pp][kMaxColTypes + 1]
+        int *tile_ptr = rpC;                           // [n_tiles + 1] (the collision row starts are done with)
+        const int k = tid >> 4, i = tid & 15;          // tile of the group, row of the tile
+        const bool act = tid < rows_pp;
+        for (int fill = 0; fill < 2; ++fill) {
+            for (int r0 = blk * rows_pp; r0 < n; r0 += G * rows_pp) {
+                const int row = r0 + tid, tile = r0 / kColTileRows + k;
+                int e0 = 0, e1 = 0;
+                if (act) {
+                    for (int t = 0; t < n_types; ++t) cnt[tid * ld + t] = 0;
+                    if (row < n) {
+                        e0 = rpA[row];
+                        e1 = rpA[row + 1];
+                    }
+                    for (int e = e0; e < e1; e += 8) {
+                        int ty[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) ty[u] = e + u < e1 ? A.adj_type[e + u] : -1;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (ty[u] >= 0) cnt[tid * ld + ty[u]]++;
+                    }
+                }
+                __syncthreads();
+                if (act)
+                    for (int t = i; t < n_types; t += 16) {
+                        int m = 0;
+                        for (int r = 0; r < 16; ++r) m = max(m, cnt[(k * 16 + r) * ld + t]);
+                        maxm[k * kMaxColTypes + t] = m;
+                    }
+                __syncthreads();
+                if (act && i == 0) {
+                    int acc = 0;
+                    for (int t = 0; t < n_types; ++t) {
+                        base[k * (kMaxColTypes + 1) + t] = acc;
+                        acc += maxm[k * kMaxColTypes + t];
+                    }
+                    base[k * (kMaxColTypes + 1) + n_types] = acc;
+                    if (!fill && tile < nt16) g_tile_cols[tile] = acc + 1;
+                }
+                __syncthreads();
+                if (fill && act && tile < nt16) {
+                    const int64_t c0 = tile_ptr[tile];
+                    const int n_edge_cols = base[k * (kMaxColTypes + 1) + n_types];
+                    for (int c = 0; c < n_edge_cols; ++c) A.col_slot_src[(c0 + c) * 16 + i] = -1;
+                    for (int t = i; t < n_types; t += 16) {
+                        const int m = maxm[k * kMaxColTypes + t];
+                        for (int r = 0; r < m; ++r)
+                            A.col_meta[c0 + base[k * (kMaxColTypes + 1) + t] + r] = t | (r == 0 ? 1 << 8 : 0) | (r == m - 1 ? 1 << 9 : 0);
+                    }
+                    const int deg = e1 - e0;
+                    A.col_slot_src[(c0 + n_edge_cols) * 16 + i] = row < n ? __float_as_int((float)(deg > 0 ? deg : 1)) : -1;
+                    if (i == 0) A.col_meta[c0 + n_edge_cols] = n_types | (1 << 8) | (1 << 9) | (1 << 10);
+                    // the 16 threads of a tile are lanes of one wavefront: their -1 stores above are ordered before these
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    for (int t = 0; t < n_types; ++t) cnt[tid * ld + t] = 0;
+                    for (int e = e0; e < e1; e += 8) {
+                        int ty[8], sr[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            ty[u] = e + u < e1 ? A.adj_type[e + u] : -1;
+                            sr[u] = e + u < e1 ? A.adj_src[e + u] : 0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (ty[u] >= 0) {
+                                const int r = cnt[tid * ld + ty[u]]++;
+                                A.col_slot_src[(c0 + base[k * (kMaxColTypes + 1) + ty[u]] + r) * 16 + i] = sr[u];
+                            }
+                    }
+                }
+                __syncthreads();
+            }
+            if (!fill) {
+                small_prep_barrier(A.ctr, target, G);
+                for (int t = tid; t <= nt16; t += NT) tile_ptr[t] = t < nt16 ? g_tile_cols[t] : 0;
+                __syncthreads();
+                small_block_scan(tile_ptr, nt16 + 1, wave_tot);
+                if (blk == 0)
+                    for (int t = tid; t <= nt16; t += NT) A.tile_col_ptr[t] = tile_ptr[t];
+                __syncthreads();
+            }
+        }
+    } else {
+        small_prep_barrier(A.ctr, target, G);          // (every block passes the same barriers)
+    }
+    TGNN_PT
+    if (blk == 0 && tid == 0) {
+        A.result[0] = n_types;
+        A.result[1] = g_flags[0];
+        A.result[2] = g_flags[1];
+        A.result[3] = ec_valid;
+        A.result[4] = maxdeg;
+        A.result[5] = cols ? 1 : 0;
+        A.result[6] = fallback ? 1 : 0;
+    }
+    // the last block out re-arms the counters for the next call
+    __syncthreads();
+    if (tid == 0 && atomicAdd(&A.ctr[1], 1u) == (unsigned)G - 1) {
+        __hip_atomic_store(&A.ctr[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&A.ctr[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 static inline unsigned grid_for(int64_t n, int threads = 256, int cap = 256 * 16) {
     int64_t g = (n + threads - 1) / threads;
     if (g < 1) g = 1;
@@ -649,6 +1067,52 @@ extern "C" int tgnn_sublayout_compact(const int32_t *alive, int64_t n_nodes, con
                                                             set == 0 ? adj_out : col_out, set == 0 ? adj_attr_out : nullptr,
                                                             counts_out + 1 + set);
     }
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}
+
+/* ---- small layouts: everything tgnn_forward needs of a layout in one launch -------------------------------------------- */
+extern "C" int64_t tgnn_graph_prep_small_max_nodes(void) { return kSmallPrepMaxNodes; }
+extern "C" int64_t tgnn_graph_prep_small_max_edges(void) { return (int64_t)kSmallPrepMaxBlocks * kSmallPrepLocal; }
+extern "C" size_t tgnn_graph_prep_small_tmp_ints(int64_t n_nodes, int64_t n_adj_edges, int64_t n_col_edges) {
+    return (size_t)(2 * (n_nodes + 1) + 3 * n_adj_edges + 2 * n_col_edges + kSmallPrepGlobal + (n_nodes + 15) / 16 + 1 + 16 + 64);
+}
+
+extern "C" int tgnn_graph_prep_small(const int64_t *adj_edge_index, int64_t n_adj_edges, const float *adj_edge_attr, int32_t fe,
+                                     const int64_t *col_edge_index, int64_t n_col_edges, int64_t n_nodes, int32_t *adj_rowptr,
+                                     int32_t *adj_src, int32_t *adj_eid, int32_t *adj_type, int32_t *edge_type,
+                                     int32_t *type_rep_edge, int32_t *col_rowptr, int32_t *col_src, int32_t *col_eid,
+                                     int32_t *tile_col_ptr, int32_t *col_meta, int32_t *col_slot_src, int32_t *tmp,
+                                     int32_t *result, uint32_t *counters, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
+    TGNN_CHECK_ARG(n_nodes >= 1 && n_nodes <= kSmallPrepMaxNodes, "n_nodes");
+    const int64_t emax_allowed = (int64_t)kSmallPrepMaxBlocks * kSmallPrepLocal;
+    TGNN_CHECK_ARG(n_adj_edges >= 0 && n_adj_edges <= emax_allowed && n_col_edges >= 0 && n_col_edges <= emax_allowed, "edge counts");
+    TGNN_CHECK_ARG(fe >= 1, "fe");
+    TGNN_CHECK_ARG(adj_rowptr && col_rowptr && tile_col_ptr && col_meta && col_slot_src && tmp && result && counters, "null pointer");
+    TGNN_CHECK_ARG(n_adj_edges == 0 || (adj_edge_index && adj_edge_attr && adj_src && adj_eid && adj_type && edge_type && type_rep_edge),
+                   "null adjacency pointer");
+    TGNN_CHECK_ARG(n_col_edges == 0 || (col_edge_index && col_src && col_eid), "null collision pointer");
+    SmallPrepArgs A{};
+    A.adj_ei = adj_edge_index; A.col_ei = col_edge_index; A.attr = adj_edge_attr;
+    A.n = n_nodes; A.ea = n_adj_edges; A.ec = n_col_edges; A.fe = fe;
+    A.max_col_types = tgnn_nnconv_cols_max_types();
+    A.adj_rowptr = adj_rowptr; A.adj_src = adj_src; A.adj_eid = adj_eid; A.adj_type = adj_type;
+    A.edge_type = edge_type; A.type_rep = type_rep_edge;
+    A.col_rowptr = col_rowptr; A.col_src = col_src; A.col_eid = col_eid;
+    A.tile_col_ptr = tile_col_ptr; A.col_meta = col_meta; A.col_slot_src = col_slot_src;
+    A.tmp = tmp; A.result = result; A.ctr = counters;
+    // blocks: ~2048 edges each, and enough of them that a block's share of the adjacency edges fits its LDS table
+    const int64_t emax = n_adj_edges > n_col_edges ? n_adj_edges : n_col_edges;
+    int64_t blocks = (emax + 2047) / 2048;
+    const int64_t need = (n_adj_edges + kSmallPrepLocal - 1) / kSmallPrepLocal;
+    if (blocks < need) blocks = need;
+    if (blocks < 1) blocks = 1;
+    if (blocks > kSmallPrepMaxBlocks) blocks = kSmallPrepMaxBlocks;
+    const size_t lds = (size_t)(2 * (kSmallPrepMaxNodes + 8) + 2 * kSmallPrepLocal + 64) * sizeof(int);
+    static LdsOptIn site;
+    TGNN_CHECK_HIP(opt_in_dynamic_lds(graph_prep_small_kernel, (int)lds, site));
+    graph_prep_small_kernel<<<(unsigned)blocks, kSmallPrepThreads, lds, static_cast<hipStream_t>(stream)>>>(A);
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
 }

@@ -164,6 +164,57 @@ def dedup_edge_types(edge_attr: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
 COLS_MIN_NODES = int(os.environ.get("TGNN_COLS_MIN_NODES", "0"))
 
 
+def _small_prep_limits(_cache=[]):
+    if not _cache:
+        _cache.append((int(lib.tgnn_graph_prep_small_max_nodes()), int(lib.tgnn_graph_prep_small_max_edges())))
+    return _cache[0]
+
+
+def _small_prep_counters(dev, _cache={}):
+    """Barrier counters of tgnn_graph_prep_small: zero before the first call, left at zero by every call; one pair per
+    (device, stream) so that preparations on different streams cannot meet in them."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    if key not in _cache:
+        _cache[key] = torch.zeros(2, dtype=torch.int32, device=dev)
+    return _cache[key]
+
+
+SMALL_PREP = True      # layouts of up to 4 096 nodes: one launch (tgnn_graph_prep_small); False: always the separate calls
+
+
+def _prepare_graph_small(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor) -> Optional[PreparedGraph]:
+    """prepare_graph for a small layout in one launch + the one sync; None = not applicable (fall back)."""
+    ea, ec = int(adj.shape[1]), int(col.shape[1])
+    if attr.dim() != 2 or attr.shape[1] < 1:
+        return None
+    attr = _f32c(attr, "adj_e_features")
+    dev = adj.device
+    ntiles = (n_nodes + 15) // 16
+    cap = int(lib.tgnn_nnconv_cols_max_columns(n_nodes, ea))
+    e1, c1 = max(ea, 1), max(ec, 1)
+    sizes = [n_nodes + 1, e1, e1, e1, e1, e1, n_nodes + 1, c1, c1, ntiles + 1, cap, cap * 16,
+             int(lib.tgnn_graph_prep_small_tmp_ints(n_nodes, ea, ec)), 32]
+    offs, at = [], 0
+    for sz in sizes:
+        offs.append(at)
+        at += (sz + 3) // 4 * 4
+    buf = torch.empty(at, dtype=torch.int32, device=dev)
+    v = [buf[o:o + sz] for o, sz in zip(offs, sizes)]
+    (a_rowptr, a_src, a_eid, adj_type, edge_type, rep, c_rowptr, c_src, c_eid, tile_col_ptr, col_meta, col_slot_src, tmp, res) = v
+    check(lib.tgnn_graph_prep_small(ptr(adj), ea, ptr(attr), int(attr.shape[1]), ptr(col), ec, n_nodes, ptr(a_rowptr), ptr(a_src),
+                                    ptr(a_eid), ptr(adj_type), ptr(edge_type), ptr(rep), ptr(c_rowptr), ptr(c_src), ptr(c_eid),
+                                    ptr(tile_col_ptr), ptr(col_meta), ptr(col_slot_src), ptr(tmp), ptr(res),
+                                    ptr(_small_prep_counters(dev)), _stream(adj)))
+    host = res.cpu().tolist()                                                    # the one sync
+    if host[1] or host[2]:
+        raise IndexError(f"edge index out of range [0, {n_nodes}) in {'adj_e_index' if host[1] else 'col_e_idx'}")
+    if host[6]:
+        return None
+    cols = NNConvColumns(tile_col_ptr, col_meta, col_slot_src) if host[5] else None
+    return PreparedGraph(n_nodes, ea, int(host[3]), int(host[0]), a_rowptr, a_src, a_eid, adj_type, edge_type, rep,
+                         c_rowptr, c_src, c_eid, cols, max(1, int(host[4])))
+
+
 def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col_e_idx: Tensor,
                   tile_width: int = 32, n_src_nodes: Optional[int] = None, columns: Optional[bool] = None) -> PreparedGraph:
     """Everything the 20 layers share: CSR of both edge sets, edge-type ids in CSR order, and (columns: None = for
@@ -174,6 +225,11 @@ def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col
     ea, ec = int(adj.shape[1]), int(col.shape[1])
     if adj_e_features.shape[0] != ea:
         raise ValueError(f"adj_e_features has {adj_e_features.shape[0]} rows for {ea} edges")
+    if (SMALL_PREP and tile_width == 32 and n_src_nodes is None and columns in (None, True) and COLS_MIN_NODES == 0
+            and 1 <= n_nodes <= _small_prep_limits()[0] and max(ea, ec) <= _small_prep_limits()[1]):
+        g = _prepare_graph_small(n_nodes, adj, adj_e_features, col)
+        if g is not None:
+            return g
     a_rowptr, a_src, a_eid, a_err = build_csr(adj, n_nodes, False, n_src_nodes)
     c_rowptr, c_src, c_eid, c_err = build_csr(col, n_nodes, True, n_src_nodes)        # GINConv strips self loops
     edge_type, rep, n_types = dedup_edge_types(adj_e_features)
