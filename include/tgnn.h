@@ -357,6 +357,15 @@ int tgnn_graph_prep_small(const int64_t *adj_edge_index, int64_t n_adj_edges, co
                           int32_t *col_rowptr, int32_t *col_src, int32_t *col_eid, int32_t *tile_col_ptr, int32_t *col_meta,
                           int32_t *col_slot_src, int32_t *tmp, int32_t *result, uint32_t *counters, tgnn_stream_t stream);
 
+/* The same at any size: one call that queues every launch of the preparation itself (no host round trip in the middle:
+ * the column structure reads the type count from the device).  result [32] as above (words 4 and 6 stay 0). */
+size_t tgnn_graph_prep_workspace_bytes(int64_t n_nodes, int64_t n_adj_edges, int64_t n_col_edges, int32_t fe);
+int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edges, const float *adj_edge_attr, int32_t fe,
+                    const int64_t *col_edge_index, int64_t n_col_edges, int64_t n_nodes, int32_t *adj_rowptr, int32_t *adj_src,
+                    int32_t *adj_eid, int32_t *adj_type, int32_t *edge_type, int32_t *type_rep_edge, int32_t *col_rowptr,
+                    int32_t *col_src, int32_t *col_eid, int32_t *tile_col_ptr, int32_t *col_meta, int32_t *col_slot_src, void *ws,
+                    size_t ws_bytes, int32_t *result, tgnn_stream_t stream);
+
 /* The same forward with a hipEvent pair around every launch (on `stream`, where the kernels run);
  * synchronises, then ADDS the elapsed milliseconds and launch counts per kernel class into the
  * two host arrays of TGNN_PROF_CLASSES entries.  Measurement aid for bench.py's roofline line. */

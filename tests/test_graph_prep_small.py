@@ -1,4 +1,6 @@
-"""The one-launch preparation of small layouts (tgnn_graph_prep_small) against the separate calls: every array bit-identical."""
+"""prepare_graph as one library call -- tgnn_graph_prep_small (one launch, layouts of up to 4 096 nodes) and tgnn_graph_prep (any
+size: the launches queued by the library, no host round trip in the middle) -- against the separate calls: every array
+bit-identical."""
 import numpy as np
 import pytest
 import torch
@@ -55,6 +57,16 @@ def test_synthetic_layouts(dev, monkeypatch, n, ea, ec, t, seed):
     sg = make_super_graph(n, ea, ec, tile_count=2, n_edge_types=t, seed=seed)
     x, adj, attr, col, _ = sg.to_torch(dev)
     _same(*_both(n, adj, attr, col, monkeypatch))
+
+
+@pytest.mark.parametrize("n,ea,ec,t,seed", [(5000, 50000, 62500, 13, 7), (20000, 200000, 250000, 13, 8), (20000, 160000, 200000, 50, 9)])
+def test_larger_layouts_one_call(dev, monkeypatch, n, ea, ec, t, seed):
+    from tilingnn_amd.synth import make_super_graph
+    sg = make_super_graph(n, ea, ec, tile_count=2, n_edge_types=t, seed=seed)
+    x, adj, attr, col, _ = sg.to_torch(dev)
+    ref, got = _both(n, adj, attr, col, monkeypatch)
+    assert got.adj_src.data_ptr() - got.adj_rowptr.data_ptr() == ((n + 1 + 63) // 64) * 256     # (pieces of one allocation)
+    _same(ref, got)
 
 
 def test_self_loops_isolated_rows_and_signed_zeros(dev, monkeypatch):

@@ -346,10 +346,17 @@ constexpr int kMaxColTypes = 40;
 
 template <bool FILL>
 __global__ __launch_bounds__(64) void nnconv_col_kernel(const int *__restrict__ rowptr, const int *__restrict__ col_src,
-                                                        const int *__restrict__ col_type, int64_t n, int n_types,
+                                                        const int *__restrict__ col_type, int64_t n, int n_types_host,
                                                         int *__restrict__ tile_cols,            // !FILL: out, columns per tile
                                                         const int *__restrict__ tile_col_ptr,   // FILL
-                                                        int *__restrict__ col_meta, int *__restrict__ col_slot_src) {
+                                                        int *__restrict__ col_meta, int *__restrict__ col_slot_src,
+                                                        const int *__restrict__ n_types_dev = nullptr, int max_types = kMaxColTypes,
+                                                        int *__restrict__ built_flag = nullptr) {
+    // n_types_dev: the count is still on the device (tgnn_graph_prep queues the whole preparation without a host round trip);
+    // more types than the structure / the matrix-core kernel take: nothing is built, *built_flag stays 0
+    const int n_types = n_types_dev ? *n_types_dev : n_types_host;
+    if (n_types > max_types || n_types > kMaxColTypes) return;
+    if (built_flag && blockIdx.x == 0 && threadIdx.x == 0) *built_flag = 1;
     __shared__ int cnt[64][kMaxColTypes + 1];    // +1: odd stride, the per-row walks hit distinct banks
     __shared__ int maxm[4][kMaxColTypes];
     __shared__ int base[4][kMaxColTypes + 1];
@@ -1113,6 +1120,65 @@ extern "C" int tgnn_graph_prep_small(const int64_t *adj_edge_index, int64_t n_ad
     static LdsOptIn site;
     TGNN_CHECK_HIP(opt_in_dynamic_lds(graph_prep_small_kernel, (int)lds, site));
     graph_prep_small_kernel<<<(unsigned)blocks, kSmallPrepThreads, lds, static_cast<hipStream_t>(stream)>>>(A);
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}
+
+/* ---- any size: the same preparation as one call that queues every launch itself (no host round trip in the middle: the
+ *      column structure reads the type count from the device) ------------------------------------------------------------- */
+__global__ void prep_result_kernel(const int *__restrict__ col_rowptr, int64_t n, int *__restrict__ result) {
+    result[3] = col_rowptr[n];
+}
+
+extern "C" size_t tgnn_graph_prep_workspace_bytes(int64_t n_nodes, int64_t n_adj_edges, int64_t n_col_edges, int32_t fe) {
+    const int64_t emax = n_adj_edges > n_col_edges ? n_adj_edges : n_col_edges;
+    return align_up(tgnn_csr_workspace_bytes(n_nodes, emax), 256) + align_up(tgnn_edge_dedup_workspace_bytes(n_adj_edges, fe), 256) +
+           align_up(tgnn_nnconv_cols_workspace_bytes(n_nodes), 256) + 1024;
+}
+
+extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edges, const float *adj_edge_attr, int32_t fe,
+                               const int64_t *col_edge_index, int64_t n_col_edges, int64_t n_nodes, int32_t *adj_rowptr,
+                               int32_t *adj_src, int32_t *adj_eid, int32_t *adj_type, int32_t *edge_type, int32_t *type_rep_edge,
+                               int32_t *col_rowptr, int32_t *col_src, int32_t *col_eid, int32_t *tile_col_ptr, int32_t *col_meta,
+                               int32_t *col_slot_src, void *ws, size_t ws_bytes, int32_t *result, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
+    TGNN_CHECK_ARG(n_nodes >= 1 && fe >= 1 && n_adj_edges >= 0 && n_col_edges >= 0, "shape");
+    TGNN_CHECK_ARG(adj_rowptr && col_rowptr && tile_col_ptr && col_meta && col_slot_src && result, "null pointer");
+    if (!ws || ws_bytes < tgnn_graph_prep_workspace_bytes(n_nodes, n_adj_edges, n_col_edges, fe)) {
+        set_error("tgnn_graph_prep: workspace too small");
+        return TGNN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t emax = n_adj_edges > n_col_edges ? n_adj_edges : n_col_edges;
+    Carver cv(ws, ws_bytes);
+    const size_t csr_b = tgnn_csr_workspace_bytes(n_nodes, emax), dd_b = tgnn_edge_dedup_workspace_bytes(n_adj_edges, fe),
+                 col_b = tgnn_nnconv_cols_workspace_bytes(n_nodes);
+    void *ws_csr = cv.take<unsigned char>(csr_b), *ws_dd = cv.take<unsigned char>(dd_b), *ws_col = cv.take<unsigned char>(col_b);
+    TGNN_CHECK_HIP(hipMemsetAsync(result, 0, 32 * sizeof(int32_t), s));
+    int rc = tgnn_csr_build(adj_edge_index, n_adj_edges, n_nodes, n_nodes, 0, adj_rowptr, adj_src, adj_eid, result + 1, ws_csr, csr_b, stream);
+    if (rc != TGNN_OK) return rc;
+    rc = tgnn_csr_build(col_edge_index, n_col_edges, n_nodes, n_nodes, 1, col_rowptr, col_src, col_eid, result + 2, ws_csr, csr_b, stream);
+    if (rc != TGNN_OK) return rc;
+    rc = tgnn_edge_type_dedup(adj_edge_attr, n_adj_edges, fe, edge_type, type_rep_edge, result + 0, ws_dd, dd_b, stream);
+    if (rc != TGNN_OK) return rc;
+    if (n_adj_edges > 0) {
+        rc = tgnn_gather_i32(edge_type, n_adj_edges, adj_eid, n_adj_edges, adj_type, stream);
+        if (rc != TGNN_OK) return rc;
+    }
+    prep_result_kernel<<<1, 1, 0, s>>>(col_rowptr, n_nodes, result);
+    // column structure with the type count read on the device
+    const int64_t nt16 = (n_nodes + kColTileRows - 1) / kColTileRows;
+    Carver cc(ws_col, col_b);
+    int *tile_cols = cc.take<int>(nt16 + 1);
+    int *scan_ws = cc.take<int>(scan_ws_ints(nt16 + 1));
+    TGNN_CHECK_HIP(hipMemsetAsync(tile_cols, 0, (size_t)(nt16 + 1) * 4, s));
+    const unsigned blocks = (unsigned)((n_nodes + 63) / 64);
+    const int max_types = tgnn_nnconv_cols_max_types();
+    nnconv_col_kernel<false><<<blocks, 64, 0, s>>>(adj_rowptr, adj_src, adj_type, n_nodes, 0, tile_cols, nullptr, nullptr, nullptr,
+                                                   result + 0, max_types, nullptr);
+    exclusive_scan_i32(tile_cols, tile_col_ptr, nt16 + 1, scan_ws, s);
+    nnconv_col_kernel<true><<<blocks, 64, 0, s>>>(adj_rowptr, adj_src, adj_type, n_nodes, 0, nullptr, tile_col_ptr, col_meta,
+                                                  col_slot_src, result + 0, max_types, result + 5);
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
 }

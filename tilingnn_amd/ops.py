@@ -179,11 +179,12 @@ def _small_prep_counters(dev, _cache={}):
     return _cache[key]
 
 
-SMALL_PREP = True      # layouts of up to 4 096 nodes: one launch (tgnn_graph_prep_small); False: always the separate calls
+SMALL_PREP = True      # one library call per layout (up to 4 096 nodes: one launch, tgnn_graph_prep_small); False: the separate calls
 
 
-def _prepare_graph_small(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor) -> Optional[PreparedGraph]:
-    """prepare_graph for a small layout in one launch + the one sync; None = not applicable (fall back)."""
+def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, small: bool) -> Optional[PreparedGraph]:
+    """prepare_graph as ONE library call + the one sync: `small`: tgnn_graph_prep_small (one launch); else tgnn_graph_prep
+    (the launches of the separate calls, queued by the library without a host round trip).  None = fall back."""
     ea, ec = int(adj.shape[1]), int(col.shape[1])
     if attr.dim() != 2 or attr.shape[1] < 1:
         return None
@@ -192,27 +193,31 @@ def _prepare_graph_small(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor) -
     ntiles = (n_nodes + 15) // 16
     cap = int(lib.tgnn_nnconv_cols_max_columns(n_nodes, ea))
     e1, c1 = max(ea, 1), max(ec, 1)
-    sizes = [n_nodes + 1, e1, e1, e1, e1, e1, n_nodes + 1, c1, c1, ntiles + 1, cap, cap * 16,
-             int(lib.tgnn_graph_prep_small_tmp_ints(n_nodes, ea, ec)), 32]
+    fe = int(attr.shape[1])
+    ws_ints = int(lib.tgnn_graph_prep_small_tmp_ints(n_nodes, ea, ec)) if small else \
+        (int(lib.tgnn_graph_prep_workspace_bytes(n_nodes, ea, ec, fe)) + 3) // 4 + 64
+    sizes = [n_nodes + 1, e1, e1, e1, e1, e1, n_nodes + 1, c1, c1, ntiles + 1, cap, cap * 16, 32, ws_ints]
     offs, at = [], 0
     for sz in sizes:
         offs.append(at)
-        at += (sz + 3) // 4 * 4
+        at += (sz + 63) // 64 * 64                     # 256-byte aligned pieces of ONE allocation
     buf = torch.empty(at, dtype=torch.int32, device=dev)
     v = [buf[o:o + sz] for o, sz in zip(offs, sizes)]
-    (a_rowptr, a_src, a_eid, adj_type, edge_type, rep, c_rowptr, c_src, c_eid, tile_col_ptr, col_meta, col_slot_src, tmp, res) = v
-    check(lib.tgnn_graph_prep_small(ptr(adj), ea, ptr(attr), int(attr.shape[1]), ptr(col), ec, n_nodes, ptr(a_rowptr), ptr(a_src),
-                                    ptr(a_eid), ptr(adj_type), ptr(edge_type), ptr(rep), ptr(c_rowptr), ptr(c_src), ptr(c_eid),
-                                    ptr(tile_col_ptr), ptr(col_meta), ptr(col_slot_src), ptr(tmp), ptr(res),
-                                    ptr(_small_prep_counters(dev)), _stream(adj)))
-    host = res.cpu().tolist()                                                    # the one sync
+    (a_rowptr, a_src, a_eid, adj_type, edge_type, rep, c_rowptr, c_src, c_eid, tile_col_ptr, col_meta, col_slot_src, res, tmp) = v
+    head = (ptr(adj), ea, ptr(attr), fe, ptr(col), ec, n_nodes, ptr(a_rowptr), ptr(a_src), ptr(a_eid), ptr(adj_type), ptr(edge_type),
+            ptr(rep), ptr(c_rowptr), ptr(c_src), ptr(c_eid), ptr(tile_col_ptr), ptr(col_meta), ptr(col_slot_src))
+    if small:
+        check(lib.tgnn_graph_prep_small(*head, ptr(tmp), ptr(res), ptr(_small_prep_counters(dev)), _stream(adj)))
+    else:
+        check(lib.tgnn_graph_prep(*head, ptr(tmp), ws_ints * 4, ptr(res), _stream(adj)))
+    host = res[:8].cpu().tolist()                                                # the one sync
     if host[1] or host[2]:
         raise IndexError(f"edge index out of range [0, {n_nodes}) in {'adj_e_index' if host[1] else 'col_e_idx'}")
     if host[6]:
         return None
     cols = NNConvColumns(tile_col_ptr, col_meta, col_slot_src) if host[5] else None
     return PreparedGraph(n_nodes, ea, int(host[3]), int(host[0]), a_rowptr, a_src, a_eid, adj_type, edge_type, rep,
-                         c_rowptr, c_src, c_eid, cols, max(1, int(host[4])))
+                         c_rowptr, c_src, c_eid, cols, int(host[4]))
 
 
 def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col_e_idx: Tensor,
@@ -225,9 +230,9 @@ def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col
     ea, ec = int(adj.shape[1]), int(col.shape[1])
     if adj_e_features.shape[0] != ea:
         raise ValueError(f"adj_e_features has {adj_e_features.shape[0]} rows for {ea} edges")
-    if (SMALL_PREP and tile_width == 32 and n_src_nodes is None and columns in (None, True) and COLS_MIN_NODES == 0
-            and 1 <= n_nodes <= _small_prep_limits()[0] and max(ea, ec) <= _small_prep_limits()[1]):
-        g = _prepare_graph_small(n_nodes, adj, adj_e_features, col)
+    if SMALL_PREP and tile_width == 32 and n_src_nodes is None and columns in (None, True) and COLS_MIN_NODES == 0 and n_nodes >= 1:
+        small = n_nodes <= _small_prep_limits()[0] and max(ea, ec) <= _small_prep_limits()[1]
+        g = _prepare_graph_fused(n_nodes, adj, adj_e_features, col, small)
         if g is not None:
             return g
     a_rowptr, a_src, a_eid, a_err = build_csr(adj, n_nodes, False, n_src_nodes)
