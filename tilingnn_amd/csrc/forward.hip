@@ -330,12 +330,18 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     //      critical chain; the first NNConv waits for them.
     hipStream_t sw = s;
     constexpr bool weights_on_side = true;
+    const bool tiled = graph->nn_tile_col_ptr && c == 32 && (int64_t)nr * c * 4 < (int64_t(1) << 31);   // buffer-addressed gathers
+    // Small layouts: the layer loop below is replaced by one persistent kernel (forward_small.hip)
+    const int small_teams = (tiled && !sh && !keep && !use_running_stats && !prof.on && nr == n) ? small_layout_teams(dims, n, T, graph->nn_max_in_degree) : 0;
+    // ... which, with CUs to spare, does not wait for the edge weights on the host's event but on a counter of that kernel's
+    // finished blocks: its init MLP runs beside them
+    unsigned *weights_done = (small_teams == 2 && s2 && weights_on_side) ? w.small_ctr + 16 : nullptr;
+    if (weights_done) TGNN_CHECK_HIP(hipMemsetAsync(weights_done, 0, 4, s));
     if (s2 && weights_on_side) {
         TGNN_CHECK_HIP(hipEventRecord(ev[kEvFork], s));     // everything the caller queued on `stream` so far
         TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[kEvFork], 0));
         sw = s2;
     }
-    const bool tiled = graph->nn_tile_col_ptr && c == 32 && (int64_t)nr * c * 4 < (int64_t(1) << 31);   // buffer-addressed gathers
     if (T > 0 || tiled) {
         // edge MLP of every (layer, type) and, for the matrix-core NNConv, its operand images (root = pseudo-type T): one launch
         EdgeMlpLayers layers{};
@@ -347,18 +353,17 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         }
         prof.begin(0);
         launch_edge_weight_table_batched(adj_edge_attr, graph->type_rep_edge, T, fe, layers, D, c, w.wtab, tiled ? roots : nullptr,
-                                         tiled ? w.wimg : nullptr, sw);
+                                         tiled ? w.wimg : nullptr, sw, weights_done);
         prof.end();
     }
-    // Small layouts: the layer loop below is replaced by one persistent kernel (forward_small.hip)
-    const int small_teams = (tiled && !sh && !keep && !use_running_stats && !prof.on && nr == n) ? small_layout_teams(dims, n, T, graph->nn_max_in_degree) : 0;
     if (small_teams) launch_small_pack(P, D, w.small_pack, w.small_ctr, s);   // on the main stream: it has nothing else to do yet
     if (sw != s) TGNN_CHECK_HIP(hipEventRecord(ev[kEvWeights], s2));
     if (small_teams) {
         // init MLP, the layers and the final MLP: one persistent kernel behind the pre-pass
-        if (sw != s) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[kEvWeights], 0));
+        if (sw != s && !weights_done) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[kEvWeights], 0));
         TGNN_TRY(launch_forward_small(dims, P, x, probs, w.mid, w.a2[0], w.a2[1], w.wimg, w.small_pack, graph, w.small_part,
-                                      w.small_part_wide, w.small_runstat, w.small_ctr, n, update_running, eps, momentum, s));
+                                      w.small_part_wide, w.small_runstat, w.small_ctr, weights_done, (unsigned)((T + 1) * D), n,
+                                      update_running, eps, momentum, s));
         TGNN_CHECK_LAUNCH();
         return TGNN_OK;
     }

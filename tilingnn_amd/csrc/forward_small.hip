@@ -139,6 +139,8 @@ struct SmallArgs {
     double *part;                // [blocks][128]: bn1 sum | bn1 sumsq | bn2 sum | bn2 sumsq
     double *runstat;             // [depth][2][mean 32 | unbiased variance 32]: batch statistics of the layers, for the running buffers
     unsigned *ctr;               // barrier counter (zeroed by small_pack_kernel)
+    const unsigned *weights_done;   // NULL, or: blocks of the edge-weight kernel that have finished (the kernel may start before them)
+    unsigned weights_target;
     int64_t n;
     int n_types, depth, update_running;
     float eps, momentum;
@@ -583,6 +585,14 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
         for (int k = 0; k < kGinCached; ++k) gnb[(8 * gh + gr) * kGinCached + k] = kOob;
     }
     TGNN_SMALL_COMMIT(0)
+    if (A.weights_done) {
+        // the NNConv operand images come from a kernel on another stream that may still be running (the init MLP above did not
+        // need them): wait for its last block, then drop what this CU / XCD caches of other XCDs' lines
+        if (tid == 0)
+            while (__hip_atomic_load(A.weights_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < A.weights_target) __builtin_amdgcn_s_sleep(8);
+        __syncthreads();
+        if (tw == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     __syncthreads();
 
     for (int layer = 0; layer < D; ++layer) {
@@ -1040,7 +1050,8 @@ int small_layout_teams(const tgnn_model_dims *d, int64_t n_nodes, int n_types, i
         cap = per_cu > 0 && cus > 0 ? (per_cu > 1 ? 1 : per_cu) * cus : -1;   // (counted as one block per CU: the LDS images fill it)
         capacity[dev].store(cap, std::memory_order_release);
     }
-    return (n_nodes + 15) / 16 <= cap ? 1 : 0;
+    // 2: at least 16 CUs stay free -- the pre-pass may then still be running when the kernel starts (it waits on a flag)
+    return (n_nodes + 15) / 16 <= cap - 16 ? 2 : (n_nodes + 15) / 16 <= cap ? 1 : 0;
 }
 
 // workspace of the path, floats: per-layer packs | dense images (init 1, final 0..3)
@@ -1087,7 +1098,8 @@ void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrie
 // The whole forward behind the pre-pass: x -> probs (stream order)
 int launch_forward_small(const tgnn_model_dims *d, const Params &P, const float *x, float *probs, float *mid, float *a2_0,
                          float *a2_1, const float *wimg, float *pack, const tgnn_graph *graph, double *part, double *part_wide,
-                         double *runstat, unsigned *ctr, int64_t n, int update_running, float eps, float momentum, hipStream_t s) {
+                         double *runstat, unsigned *ctr, const unsigned *weights_done, unsigned weights_target, int64_t n,
+                         int update_running, float eps, float momentum, hipStream_t s) {
     const int depth = d->network_depth;
     SmallArgs A{};
     A.mid = mid;
@@ -1103,6 +1115,8 @@ int launch_forward_small(const tgnn_model_dims *d, const Params &P, const float 
     A.part = part;
     A.runstat = runstat;
     A.ctr = ctr;
+    A.weights_done = weights_done;
+    A.weights_target = weights_target;
     A.n = n;
     A.n_types = graph->n_types;
     A.depth = depth;

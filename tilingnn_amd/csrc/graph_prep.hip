@@ -464,6 +464,7 @@ __device__ int small_block_scan(int *a, int m, int *wave_tot) {
 
 // all blocks resident (<= 16); ordinary loads / stores on both sides: one thread per block releases / acquires at agent scope
 __device__ __forceinline__ void small_prep_barrier(unsigned *ctr, unsigned &target, unsigned nblk) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every wave's stores are in L2 before thread 0 writes L2 back
     __syncthreads();
     target += nblk;
     if (nblk > 1 && threadIdx.x == 0) {

@@ -51,13 +51,18 @@ __device__ __forceinline__ void weight_image_put(__bf16 *dst, int r, float x) {
 
 __global__ __launch_bounds__(256) void edge_weight_table_kernel(
     const float *__restrict__ edge_attr, const int *__restrict__ type_rep_edge, int fe, EdgeMlpLayers layers, int cc,
-    float *__restrict__ wtab_all, int n_types, RootPtrs roots, float *__restrict__ wimg_all) {
+    float *__restrict__ wtab_all, int n_types, RootPtrs roots, float *__restrict__ wimg_all, unsigned *__restrict__ done_ctr) {
     // wimg_all != NULL (width 32): the block also writes its type's slice of the matrix-core operand image, and one more
     // block per layer (blockIdx.x == n_types) the root matrix's -- no second launch on the way to the first NNConv
     __bf16 *img = wimg_all ? reinterpret_cast<__bf16 *>(wimg_all + ((int64_t)blockIdx.y * (n_types + 1) + blockIdx.x) * kWtType) : nullptr;
     if ((int)blockIdx.x == n_types) {
         const float *src = roots.p[blockIdx.y];
         for (int r = threadIdx.x; r < 1024; r += 256) weight_image_put(img, r, src[r]);
+        if (done_ctr) {                                     // (a consumer on another stream counts the finished blocks)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's stores are in L2 before thread 0 writes L2 back
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(done_ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
         return;
     }
     const EdgeMlpLayer L = layers.l[blockIdx.y];
@@ -101,6 +106,11 @@ __global__ __launch_bounds__(256) void edge_weight_table_kernel(
         const float v = sigmoidf_(acc);
         wtab[(int64_t)t * cc + j] = v;
         if (img) weight_image_put(img, j, v);
+    }
+    if (done_ctr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(done_ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -383,13 +393,13 @@ constexpr size_t kMaxDynLds = 160 * 1024 - 256;
 
 void launch_edge_weight_table_batched(const float *edge_attr, const int *type_rep_edge, int n_types, int fe,
                                       const EdgeMlpLayers &layers, int depth, int c, float *wtab, const float *const *roots,
-                                      float *wimg_all, hipStream_t s) {
+                                      float *wimg_all, hipStream_t s, unsigned *done_ctr) {
     RootPtrs rp{};
     const bool image = wimg_all && roots && c == 32;
     if (image)
         for (int i = 0; i < depth; ++i) rp.p[i] = roots[i];
     edge_weight_table_kernel<<<dim3(n_types + (image ? 1 : 0), depth), 256, 0, s>>>(edge_attr, type_rep_edge, fe, layers, c * c, wtab,
-                                                                                  n_types, rp, image ? wimg_all : nullptr);
+                                                                                  n_types, rp, image ? wimg_all : nullptr, done_ctr);
 }
 
 }  // namespace tgnn

@@ -218,7 +218,7 @@ struct EdgeMlpLayers {
 // roots + wimg_all given (width 32): the same launch also writes the NNConv operand images [(T+1)][kWtType] of all layers
 void launch_edge_weight_table_batched(const float *edge_attr, const int *type_rep_edge, int n_types, int fe,
                                       const EdgeMlpLayers &layers, int depth, int c, float *wtab, const float *const *roots,
-                                      float *wimg_all, hipStream_t s);
+                                      float *wimg_all, hipStream_t s, unsigned *done_ctr = nullptr);
 // NNConv B-operand weight images [(T+1)][1152] for `depth` layers (roots[i] = layer i's root matrix); nnconv.hip
 void launch_nnconv_weight_image(const float *wtab_all, const float *const *roots, int n_types, int depth,
                                 float *wimg_all, hipStream_t s);
@@ -233,7 +233,8 @@ size_t small_pack_floats(int depth);
 void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrier_ctr, hipStream_t s);
 int launch_forward_small(const tgnn_model_dims *d, const Params &P, const float *x, float *probs, float *mid, float *a2_0,
                          float *a2_1, const float *wimg, float *pack, const tgnn_graph *graph, double *part, double *part_wide,
-                         double *runstat, unsigned *ctr, int64_t n, int update_running, float eps, float momentum, hipStream_t s);
+                         double *runstat, unsigned *ctr, const unsigned *weights_done, unsigned weights_target, int64_t n,
+                         int update_running, float eps, float momentum, hipStream_t s);
 // MFMA weight image of the column NNConv, per type: [plane 3 (hi, mid, lo)][M block 2][g 4][i 16] x 8 bf16 --
 // the A fragment of lane 16 g + i for one (plane, M block) is one 16-byte read, a wavefront reads 1 KB in lane order
 // (conflict-free: SQ_LDS_BANK_CONFLICT 2.3e6 -> 2.3e5 per launch against the [i][g] order of round 1); 6144 B per type
