@@ -68,6 +68,10 @@ def _load() -> C.CDLL:
             f"{LIB_PATH} is missing: the HIP extension has not been built. Build it with\n"
             f"    python -c 'import __graft_entry__ as g; g.build()'    (or: make -C tilingnn_amd/csrc)\n"
             "tilingnn_amd has no CPU fallback by design.")
+    # torch first: its wheel carries its own HIP runtime, and a process must have ONE.  Loaded the other way round, the
+    # library binds /opt/rocm's libamdhip64, torch then brings its copy, and whichever initialises second reports "no
+    # ROCm-capable device" (seen with build() followed by smoke() in one process).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     p, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
     pi32 = C.POINTER(C.c_int32)
