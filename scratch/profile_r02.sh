@@ -28,3 +28,16 @@ for grp in "FETCH_SIZE" "WRITE_SIZE"; do
 done
 cat gpurun_out/r02/pmc_nnconv.txt
 head -12 gpurun_out/r02/kernel_stats_summary.txt
+
+# ---- the small-layout path: kernel stats of labyrinth forwards, phase timers of the persistent kernel, the timing table
+rm -rf gpurun_out/r02/small_ks
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02/small_ks -o small -- python scratch/small_trace.py > gpurun_out/r02/small_ks.log 2>&1
+f=$(find gpurun_out/r02/small_ks -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && { cp $f gpurun_out/r02/small_layout_kernel_stats.csv; python scratch/kstats.py $f 12 > gpurun_out/r02/small_layout_kernel_stats.txt; }
+scratch/small_trace.sh > gpurun_out/r02/small_layout_timeline.txt 2>&1
+timeout 300 python scratch/time_small.py 300 1254 2500 4096 > gpurun_out/r02/small_layout_times.txt 2>&1
+scratch/prep_trace.sh > gpurun_out/r02/small_prep_timeline.txt 2>&1
+if [ -f scratch/libs/libtgnn_SMALLTIME.so ]; then
+  TGNN_LIB_PATH=$PWD/scratch/libs/libtgnn_SMALLTIME.so timeout 300 python scratch/small_phases.py laby 300 2500 > gpurun_out/r02/small_layout_phases.txt 2>&1
+fi
+timeout 300 python scratch/time_greedy.py > gpurun_out/r02/greedy_solve.txt 2>&1
