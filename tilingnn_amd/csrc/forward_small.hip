@@ -218,6 +218,13 @@ __device__ __forceinline__ void small_grid_barrier(unsigned *ctr, unsigned &targ
 constexpr int kColFirst = 1 << 8;    // col_meta flag (graph_prep.hip): first column of a run of same-type columns; low byte = type
 constexpr int kSmallThreads = 512;   // 8 waves per tile: 6 NNConv column chunks, 2 halves of the collision neighbourhoods
 constexpr int kNnWaves = 6;
+#ifndef TGNN_SMALL_RUN_WAVES
+#define TGNN_SMALL_RUN_WAVES 6
+#endif
+// Stage 2 of the NNConv (matrix products of the tile's runs) on all six NNConv waves.  (4: only on waves 0, 1, 4, 5, so that
+// waves 2, 3, which share their SIMDs with the two collision waves -- the longer chain --, only do the short epilogue:
+// measured equal, 0.337 vs 0.337 ms on the labyrinth layout; six waves take up to 18 runs.)
+constexpr int kRunWaves = TGNN_SMALL_RUN_WAVES, kRunsPerWave = kRunWaves == 4 ? 4 : 3;
 // LDS, floats, after the weight images: parameter vectors of two layers | NNConv partial products [6][64][8] (phase B: the
 // fp64 fold [8][128]) | second half of the collision sums [64][8] | a1 tile | a2 tile | records | root degrees
 constexpr int kLdsSpv = 2 * kSpGinW, kLdsNnRed = kNnWaves * 64 * 8, kLdsGinRed = 64 * 8, kLdsTile = 512;
@@ -512,7 +519,11 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
     //   (first column of its run) or added to (later columns: further edges of the same type)
     // NNConv, stage 2 (waves 0 .. 5): runs w, w + 6, w + 12 of the tile: type (weight image) of each
     int n_ent = 0;                                                // waves 0, 1: entries of the longest of the wave's 8 rows
-    int my_run_t[3] = {-1, -1, -1};
+    int my_run_t[kRunsPerWave];
+#pragma unroll
+    for (int j = 0; j < kRunsPerWave; ++j) my_run_t[j] = -1;
+    // this wave's slot among the waves that multiply: its runs are slot, slot + kRunWaves, ...
+    const int run_slot = kRunWaves == 6 ? tw : (tw < 2 ? tw : (tw == 4 || tw == 5) ? tw - 2 : -1);
     {
         const int c0 = __builtin_amdgcn_readfirstlane(A.tile_col_ptr[tile]);
         const int c1 = __builtin_amdgcn_readfirstlane(A.tile_col_ptr[tile + 1]);
@@ -564,9 +575,10 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
             n_ent = __builtin_amdgcn_readfirstlane(m);
         }
         const int nruns = run_type[31];
-        if (tw < kNnWaves) {
+        if (tw < kNnWaves && run_slot >= 0) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) my_run_t[j] = tw + 6 * j < nruns ? __builtin_amdgcn_readfirstlane(run_type[(tw + 6 * j) & 31]) : -1;
+            for (int j = 0; j < kRunsPerWave; ++j)
+                my_run_t[j] = run_slot + kRunWaves * j < nruns ? __builtin_amdgcn_readfirstlane(run_type[(run_slot + kRunWaves * j) & 31]) : -1;
         }
         __syncthreads();
         for (int i = tid; i < (T + 1) * 512 / 4; i += NT) reinterpret_cast<float4 *>(S)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -638,18 +650,18 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
             //      the longer chain -- by ~2 us in the CU's memory pipeline; this chain has the slack.
             const bf16x8 *wimg_l = reinterpret_cast<const bf16x8 *>(A.wimg + (size_t)layer * (T + 1) * kWtType) + lane;
             constexpr int kPl = kWtPlane / 4, kTy = kWtType / 4;  // 16-byte fragments per plane / per type
-            bf16x8 wf[3][6];
+            bf16x8 wf[kRunsPerWave][6];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
+            for (int j = 0; j < kRunsPerWave; ++j) {
                 const bf16x8 *wp = wimg_l + (size_t)(my_run_t[j] >= 0 ? my_run_t[j] : 0) * kTy;
                 wf[j][0] = wp[0]; wf[j][1] = wp[64]; wf[j][2] = wp[kPl]; wf[j][3] = wp[kPl + 64]; wf[j][4] = wp[2 * kPl]; wf[j][5] = wp[2 * kPl + 64];
             }
             //      D^T += W_t^T . S_t^T for this wave's runs (root run: operand pre-multiplied by max(deg, 1))
             f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;           // row fj, channels 4 fq + r and 16 + 4 fq + r
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
+            for (int j = 0; j < kRunsPerWave; ++j) {
                 if (my_run_t[j] >= 0) {                           // wave-uniform
-                    const float *srow = S + ((tw + 6 * j) * 16 + fj) * 32 + 8 * fq;
+                    const float *srow = S + ((run_slot + kRunWaves * j) * 16 + fj) * 32 + 8 * fq;
                     const float4 sa = *reinterpret_cast<const float4 *>(srow), sb = *reinterpret_cast<const float4 *>(srow + 4);
                     const float scale = my_run_t[j] == T ? rootdeg[fj] : 1.0f;
                     bf16x8 xh, xm, xl;
@@ -802,9 +814,10 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
         // this layer is through with the images in LDS
         if (layer + 1 < D) TGNN_SMALL_PREFETCH(layer + 1)
         TGNN_ST(2)
-        if (tw == kNnWaves - 2 || tw == kNnWaves - 1) {
+        constexpr int kEpiWave = kRunWaves == 4 ? 2 : kNnWaves - 2;
+        if (tw == kEpiWave || tw == kEpiWave + 1) {
             // ---- NNConv epilogue, one wave per 16-channel half: the six partial products in fixed order, mean, bias, LeakyReLU
-            const int half = tw - (kNnWaves - 2);                // channels 16 half + 4 fq + r of row fj
+            const int half = tw - kEpiWave;                      // channels 16 half + 4 fq + r of row fj
             float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int w = 0; w < kNnWaves; ++w) {
@@ -1031,7 +1044,7 @@ int small_layout_teams(const tgnn_model_dims *d, int64_t n_nodes, int n_types, i
         d->node_features_dim > 256)
         return 0;
     if (small_lds_bytes(n_types, d->network_depth) > kSmallMaxLds) return 0;
-    if (n_types + 1 > 18 || n_types + 1 > 31) return 0;      // three runs per NNConv wave; run_type[32]
+    if (n_types + 1 > kRunWaves * kRunsPerWave || n_types + 1 > 31) return 0;      // runs per multiplying wave; run_type[32]
     // The grid barrier needs every block resident at the same time.  The kernel is launched as an ordinary kernel on the
     // caller's stream (a cooperative launch goes through a queue of its own: ~25 us of cross-queue dependency before and
     // after the kernel, measured), so the guarantee a cooperative launch gives is checked here instead: blocks <= CUs of
