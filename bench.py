@@ -103,7 +103,22 @@ def cpu_baseline():
 
     t2, all2 = run(10_000, 80_000, 100_000, 1, 3)
     t20, _ = run(20_000, 200_000, 250_000, 11, 1)
-    return {"value": 10_000 / t2, "unit": "nodes/s", "cores": cores, "kind": "port",
+    # BASELINE config 0: the reference's own example layout (what its greedy solver scores every round)
+    real = None
+    try:
+        from tests.golden_util import graph_tensors, load_labyrinth_graph
+        xl, adjl, attrl, coll, _ = graph_tensors(load_labyrinth_graph(), torch.float32)
+        sdl = make_state_dict(int(attrl.shape[1]), DEPTH, WIDTH, 1, int(xl.shape[1]), seed=0)
+        tl = []
+        with torch.no_grad():
+            for _ in range(5):
+                t0 = time.perf_counter()
+                orc.tilingnn_forward(sdl, xl, adjl, attrl, coll)
+                tl.append(time.perf_counter() - t0)
+        real = {"ms_per_forward": sorted(tl)[2] * 1e3, "what": "median of 5 forwards of the labyrinth layout (1254 nodes, 8502 + 10472 edges)"}
+    except FileNotFoundError:
+        pass
+    return {"config0_real_layout": real, "value": 10_000 / t2, "unit": "nodes/s", "cores": cores, "kind": "port",
             "sample": f"median of 3 forwards at BASELINE config 2 (N=10000 Ea=80000 Ec=100000, seed 1): "
                       f"{', '.join(f'{t:.1f}' for t in all2)} s; torch {torch.__version__} CPU, {_cpu_model()}",
             "sample_20k": {"value": 20_000 / t20, "seconds": t20,
