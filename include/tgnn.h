@@ -324,6 +324,9 @@ typedef struct tgnn_shard {
     int32_t world, rank;            /* fused mode */
     const int32_t *send_idx_fused;  /* device, may be NULL = plain mode */
     const int32_t *recv_idx_fused;  /* device */
+    tgnn_stream_t side_stream;      /* may be NULL.  Not NULL (and != stream): the collision branch of a layer runs on it beside
+                                     * the adjacency branch, as in tgnn_forward; the two meet before the layer's exchange.  The
+                                     * callbacks are still only ever handed `stream`. */
 } tgnn_shard;
 size_t tgnn_forward_sharded_workspace_bytes(const tgnn_model_dims *dims, int64_t n_own, int64_t n_rows,
                                             int32_t n_types);

@@ -59,7 +59,8 @@ class ShardDesc(C.Structure):
                 ("send_idx", C.c_void_p), ("n_send", C.c_int64),
                 ("sum_buf", C.c_void_p), ("send_buf", C.c_void_p), ("recv_buf", C.c_void_p),
                 ("allreduce_f64", ALLREDUCE_CB), ("alltoall_rows", ALLTOALL_CB), ("ctx", C.c_void_p),
-                ("world", C.c_int32), ("rank", C.c_int32), ("send_idx_fused", C.c_void_p), ("recv_idx_fused", C.c_void_p)]
+                ("world", C.c_int32), ("rank", C.c_int32), ("send_idx_fused", C.c_void_p), ("recv_idx_fused", C.c_void_p),
+                ("side_stream", C.c_void_p)]
 
 
 def _load() -> C.CDLL:

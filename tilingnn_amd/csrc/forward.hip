@@ -250,7 +250,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     // (TilinGNN.py:63); the branches meet in the product of :64 only.  With a side stream the whole GIN chain runs
     // free beside the NNConv chain and fills the GPU wherever the latter leaves it idle (1-block BN finalizes, the
     // HBM-bound merge, kernel tails); it is held back only by the two-deep buffers it shares with merge.
-    hipStream_t s2 = (prof.on || sh) ? nullptr : static_cast<hipStream_t>(stream2);
+    hipStream_t s2 = prof.on ? nullptr : static_cast<hipStream_t>(sh ? sh->side_stream : stream2);
     if (s2 == s) s2 = nullptr;
     // Events of the two-chain schedule, per calling thread and device; created once, never destroyed.
     // [0] init done, [1 + i] GIN_i done, [1 + kMaxDepth + i] merge_i done, then: fork at entry, edge weights done
@@ -422,11 +422,19 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         const float *h1 = w.mid + (size_t)i * nr * c;
         if (s2) {
             // ---- collision chain, layer i, on the side stream: a2[i & 1] / stat2[i & 1] were last read by merge_{i-2}
-            if (i >= 2) TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[1 + kMaxDepth + i - 2], 0));
+            // (sharded: the halo rows and the statistics GIN_i reads arrive with the exchange of layer i-1, and the statistics of
+            //  its own output are the shards' business: only the gather + MLP run here)
+            if (sh) {
+                if (i >= 1) TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[1 + kMaxDepth + i - 1], 0));
+            } else if (i >= 2) {
+                TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[1 + kMaxDepth + i - 2], 0));
+            }
             TGNN_TRY(gin_layer(i, s2));
-            BnJobs j2{};
-            j2.job[0] = bn_job(w.part2, np2, P.bn(b + 20), w.stat2[i & 1]);
-            launch_bn_finalize(j2, 1, fin_mode, c, n, eps, momentum, s2);
+            if (!sh) {
+                BnJobs j2{};
+                j2.job[0] = bn_job(w.part2, np2, P.bn(b + 20), w.stat2[i & 1]);
+                launch_bn_finalize(j2, 1, fin_mode, c, n, eps, momentum, s2);
+            }
             TGNN_CHECK_HIP(hipEventRecord(ev[1 + i], s2));
         }
         // GraphConv (:62): NNConv mean + LeakyReLU; BN statistics emitted as partials
@@ -444,7 +452,8 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         if (fused_shard && i + 1 < D) {
             // ---- sharded, fused: local sums -> ONE all-to-all (raw halo rows of both branches + the sums) -> the sums of
             //      all shards added in rank order -> statistics -> merge of the own AND the halo rows
-            TGNN_TRY(gin_layer(i, s));
+            if (s2) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[1 + i], 0));
+            else TGNN_TRY(gin_layer(i, s));
             BnJobs jobs{};
             jobs.job[0] = bn_job(w.part1, np1, P.bn(b + 8), w.stat1);
             jobs.job[1] = bn_job(w.part2, np2, P.bn(b + 20), w.stat2[i & 1]);
@@ -462,6 +471,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
             const float *resid_f = i >= 2 ? w.mid + (size_t)(i - 2) * nr * c : nullptr;
             TGNN_TRY(tgnn_merge_fwd(w.a1, w.stat1, w.a2[i & 1], w.stat2[i & 1], resid_f, nr, c,
                                     w.mid + (size_t)(i + 1) * nr * c, nullptr, s));
+            if (s2) TGNN_CHECK_HIP(hipEventRecord(ev[1 + kMaxDepth + i], s));
             continue;
         }
         // Few partial rows (small layouts): merge derives the first BatchNorm's record from them itself -- one launch
@@ -471,7 +481,13 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         //  size: the launch it replaces sits on the critical NNConv -> merge chain.  TGNN_BN_MAX_PARTIALS rows at most.)
         constexpr int fuse_rows = TGNN_BN_MAX_PARTIALS;
         const bool fused_bn1 = c == 32 && !use_running_stats && !sh && np1 <= fuse_rows;
-        if (s2) {
+        if (s2 && sh) {
+            TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[1 + i], 0));
+            BnJobs jobs{};
+            jobs.job[0] = bn_job(w.part1, np1, P.bn(b + 8), w.stat1);
+            jobs.job[1] = bn_job(w.part2, np2, P.bn(b + 20), w.stat2[i & 1]);
+            TGNN_TRY(finalize_jobs(jobs, 2, c));
+        } else if (s2) {
             if (!fused_bn1) {
                 BnJobs j1{};
                 j1.job[0] = bn_job(w.part1, np1, P.bn(b + 8), w.stat1);
@@ -497,8 +513,9 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
                                     w.mid + (size_t)(i + 1) * nr * c, nullptr, s));
         }
         prof.end();
-        if (s2) TGNN_CHECK_HIP(hipEventRecord(ev[1 + kMaxDepth + i], s));
+        if (s2 && !sh) TGNN_CHECK_HIP(hipEventRecord(ev[1 + kMaxDepth + i], s));
         if (i + 1 < D) TGNN_TRY(exchange(i + 1, w.a2[i & 1], w.a2[i & 1]));
+        if (s2 && sh) TGNN_CHECK_HIP(hipEventRecord(ev[1 + kMaxDepth + i], s));     // (the next GIN also reads the halo rows)
     }
 
     // ---- K11: final MLP over the concatenation (TilinGNN.py:74-76); K block kb = middle[kb]

@@ -382,6 +382,10 @@ class FusedShardForward:
             recv_ext.append(np.array([-1 - (4 * p_ + j) for j in range(4)], dtype=np.int32))
             halo_at += k
         self.fused = fused and c == 32
+        # True: the collision branch of a layer on the side stream beside the adjacency branch (tgnn_shard.side_stream).  Measured at
+        # world 1, 100k nodes: 3.65 ms against 3.41 ms on one stream -- GIN_i needs the exchange of layer i-1, so only NNConv_i and
+        # GIN_i overlap, and the two cross-queue dependencies per layer cost more than that gains (scratch/time_sharded.py)
+        self.two_streams = False
         self.send_idx_fused = torch.from_numpy(np.concatenate(send_ext)).to(self.dev)
         self.recv_idx_fused = torch.from_numpy(np.concatenate(recv_ext)).to(self.dev)
 
@@ -422,7 +426,8 @@ class FusedShardForward:
                               self.sum_buf.data_ptr(), self.send_buf.data_ptr(), self.recv_buf.data_ptr(),
                               self._cbs[0], self._cbs[1], None, sh.world, sh.rank,
                               self.send_idx_fused.data_ptr() if self.fused else None,
-                              self.recv_idx_fused.data_ptr() if self.fused else None)
+                              self.recv_idx_fused.data_ptr() if self.fused else None,
+                              _lib.side_stream(self.dev) if self.two_streams else None)
         g = graph.c_struct()
         self._error = None
         rc = _lib.lib.tgnn_forward_sharded(C.byref(dims), table, ops.ptr(inp["x"]), ops.ptr(inp["attr"]), C.byref(g),
