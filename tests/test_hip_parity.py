@@ -665,6 +665,26 @@ def test_fused_sharded_forward_matches_unsharded(dev, world, one_collective, gen
             assert float((a[k + ".running_mean"] - b[k + ".running_mean"]).abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("one_collective", [True, False])
+def test_sharded_forward_with_the_collision_branch_on_a_side_stream(dev, one_collective, general_schedule):
+    """tgnn_shard.side_stream: a layer's collision branch beside its adjacency branch (off by default: measured slower).  Same
+    kernels, same order of every sum: the same bits as on one stream."""
+    from tilingnn_amd import dist as tdist
+    from tilingnn_amd.synth import make_super_graph
+    sg = make_super_graph(6000, 60000, 75000, tile_count=2, n_edge_types=13, seed=8)
+    outs = []
+    for two in (False, True):
+        shard = tdist.make_shard(sg.node_feature, sg.align_edge_index, sg.align_edge_features, sg.collide_edge_index, 0, 1)
+        tdist.LocalSimComm.setup([shard])
+        net, _ = make_net(dev, depth=5)
+        hub = tdist.ThreadSimCollectives.Hub(1)
+        runner = tdist.FusedShardForward(net, shard, dev, tdist.ThreadSimCollectives(hub, 0), fused=one_collective)
+        runner.two_streams = two
+        outs.append(runner.step().clone())
+        torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("scale_a,scale_w", [(1.0, 1.0), (1e3, 1e-2), (1e-4, 3.0), (2e4, 1e-5)])
 def test_split_precision_kernels_hold_fp32_accuracy_across_magnitudes(dev, scale_a, scale_w):
     """The bf16x3 kernels (wide Linear blocks, GIN MLP, column NNConv) split every fp32 operand exactly into three
