@@ -251,7 +251,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     // free beside the NNConv chain and fills the GPU wherever the latter leaves it idle (1-block BN finalizes, the
     // HBM-bound merge, kernel tails); it is held back only by the two-deep buffers it shares with merge.
     hipStream_t s2 = prof.on ? nullptr : static_cast<hipStream_t>(sh ? sh->side_stream : stream2);
-    if (s2 == s) s2 = nullptr;
+    if (s2 == s || (sh && dims->network_width != 32)) s2 = nullptr;
     // Events of the two-chain schedule, per calling thread and device; created once, never destroyed.
     // [0] init done, [1 + i] GIN_i done, [1 + kMaxDepth + i] merge_i done, then: fork at entry, edge weights done
     constexpr int kEvPerDev = 3 + 2 * kMaxDepth, kEvFork = 1 + 2 * kMaxDepth, kEvWeights = 2 + 2 * kMaxDepth;
@@ -422,15 +422,17 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         const float *h1 = w.mid + (size_t)i * nr * c;
         if (s2) {
             // ---- collision chain, layer i, on the side stream: a2[i & 1] / stat2[i & 1] were last read by merge_{i-2}
-            // (sharded: the halo rows and the statistics GIN_i reads arrive with the exchange of layer i-1, and the statistics of
-            //  its own output are the shards' business: only the gather + MLP run here)
+            // (sharded: the halo rows and the statistics GIN_i reads arrive with the exchange of layer i-1, so the chain cannot run
+            //  ahead; only the HBM-bound neighbourhood sum goes beside the merge / NNConv -- the MLP, which finds no CU beside an
+            //  NNConv block, follows on the main stream: 52 us beside the NNConv against 19 us behind it, measured)
             if (sh) {
                 if (i >= 1) TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[1 + kMaxDepth + i - 1], 0));
-            } else if (i >= 2) {
-                TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[1 + kMaxDepth + i - 2], 0));
-            }
-            TGNN_TRY(gin_layer(i, s2));
-            if (!sh) {
+                const float *gin_in = i == 0 ? w.mid : w.a2[(i - 1) & 1];
+                TGNN_TRY(tgnn_gin_aggregate(gin_in, c, i == 0 ? nullptr : w.stat2[(i - 1) & 1], graph->col_rowptr, graph->col_src,
+                                            P.f(b + 13), n, c, w.t0, s2));
+            } else {
+                if (i >= 2) TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[1 + kMaxDepth + i - 2], 0));
+                TGNN_TRY(gin_layer(i, s2));
                 BnJobs j2{};
                 j2.job[0] = bn_job(w.part2, np2, P.bn(b + 20), w.stat2[i & 1]);
                 launch_bn_finalize(j2, 1, fin_mode, c, n, eps, momentum, s2);
@@ -452,8 +454,13 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         if (fused_shard && i + 1 < D) {
             // ---- sharded, fused: local sums -> ONE all-to-all (raw halo rows of both branches + the sums) -> the sums of
             //      all shards added in rank order -> statistics -> merge of the own AND the halo rows
-            if (s2) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[1 + i], 0));
-            else TGNN_TRY(gin_layer(i, s));
+            if (s2) {
+                TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[1 + i], 0));
+                TGNN_TRY(launch_gin32_mlp(w.t0, P.f(b + 14), P.f(b + 15), P.f(b + 16), P.f(b + 17), P.f(b + 18), P.f(b + 19), n,
+                                          TGNN_ACT_LEAKY_RELU, w.a2[i & 1], w.part2, &np2, s));
+            } else {
+                TGNN_TRY(gin_layer(i, s));
+            }
             BnJobs jobs{};
             jobs.job[0] = bn_job(w.part1, np1, P.bn(b + 8), w.stat1);
             jobs.job[1] = bn_job(w.part2, np2, P.bn(b + 20), w.stat2[i & 1]);
@@ -468,10 +475,12 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
             }
             launch_shard_unpack_finalize(sh->recv_buf, sh->recv_idx_fused, n_in, n, w.a1, w.a2[i & 1], jobs, sh->world,
                                          sh->rank, n_total, eps, momentum, s);
+            // (what the next GIN reads -- the collision rows incl. halo and their statistics -- is complete here: it starts beside
+            //  the merge, not behind it)
+            if (s2) TGNN_CHECK_HIP(hipEventRecord(ev[1 + kMaxDepth + i], s));
             const float *resid_f = i >= 2 ? w.mid + (size_t)(i - 2) * nr * c : nullptr;
             TGNN_TRY(tgnn_merge_fwd(w.a1, w.stat1, w.a2[i & 1], w.stat2[i & 1], resid_f, nr, c,
                                     w.mid + (size_t)(i + 1) * nr * c, nullptr, s));
-            if (s2) TGNN_CHECK_HIP(hipEventRecord(ev[1 + kMaxDepth + i], s));
             continue;
         }
         // Few partial rows (small layouts): merge derives the first BatchNorm's record from them itself -- one launch
@@ -483,6 +492,8 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         const bool fused_bn1 = c == 32 && !use_running_stats && !sh && np1 <= fuse_rows;
         if (s2 && sh) {
             TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[1 + i], 0));
+            TGNN_TRY(launch_gin32_mlp(w.t0, P.f(b + 14), P.f(b + 15), P.f(b + 16), P.f(b + 17), P.f(b + 18), P.f(b + 19), n,
+                                      TGNN_ACT_LEAKY_RELU, w.a2[i & 1], w.part2, &np2, s));
             BnJobs jobs{};
             jobs.job[0] = bn_job(w.part1, np1, P.bn(b + 8), w.stat1);
             jobs.job[1] = bn_job(w.part2, np2, P.bn(b + 20), w.stat2[i & 1]);

@@ -372,6 +372,23 @@ extern "C" int tgnn_gin_fwd(const float *a, int64_t lda, const float *in_stat, c
     return TGNN_OK;
 }
 
+namespace tgnn {
+// the MLP half of tgnn_gin_fwd (width 32) on an aggregate tgnn_gin_aggregate wrote; forward.hip's sharded schedule runs the two
+// halves on different streams
+int launch_gin32_mlp(const float *z, const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
+                     const float *b3, int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
+                     hipStream_t s) {
+    int blocks = producer_blocks(n_nodes, 16 * kMlpWaves);
+    constexpr int reserve = 32;
+    if (blocks > 256 - reserve) blocks = 256 - reserve;
+    if (blocks >= 8) blocks &= ~7;
+    gin32_mlp_kernel<<<blocks, kMlpThreads, 0, s>>>(z, w1, b1, w2, b2, w3, b3, n_nodes, act, out, bn_partial);
+    if (n_partials_host) *n_partials_host = blocks;
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}
+}  // namespace tgnn
+
 /* z = (1 + eps) * BN_in(a) + sum over the row's CSR slots of BN_in(a)[src]  (the input of GINConv's MLP, PyG
  * gin_conv.py; width 32).  Stand-alone because the backward needs it twice per layer: to re-derive the MLP's input, and --
  * on the TRANSPOSED collision graph -- as the adjoint of the aggregation itself. */

@@ -226,6 +226,10 @@ int launch_nnconv_cols(const float *h, int64_t ldh, const int32_t *tile_col_ptr,
                        const int32_t *col_src, const float *wimg, int32_t n_types, const float *bias,
                        int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
                        hipStream_t s);
+// the MLP half of tgnn_gin_fwd (width 32) behind tgnn_gin_aggregate; gin.hip
+int launch_gin32_mlp(const float *z, const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
+                     const float *b3, int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
+                     hipStream_t s);
 // Small layouts: the whole forward behind a pre-pass as one persistent kernel (forward_small.hip).  small_layout_teams:
 // 0 = not eligible (too large, too many edge types for LDS, ...); the packs / images are built per forward.
 int small_layout_teams(const tgnn_model_dims *d, int64_t n_nodes, int n_types, int max_in_degree);

@@ -382,9 +382,11 @@ class FusedShardForward:
             recv_ext.append(np.array([-1 - (4 * p_ + j) for j in range(4)], dtype=np.int32))
             halo_at += k
         self.fused = fused and c == 32
-        # True: the collision branch of a layer on the side stream beside the adjacency branch (tgnn_shard.side_stream).  Measured at
-        # world 1, 100k nodes: 3.65 ms against 3.41 ms on one stream -- GIN_i needs the exchange of layer i-1, so only NNConv_i and
-        # GIN_i overlap, and the two cross-queue dependencies per layer cost more than that gains (scratch/time_sharded.py)
+        # True: the neighbourhood sum of a layer's collision branch on the side stream (tgnn_shard.side_stream), beside the merge of
+        # the layer before and the head of the NNConv.  Measured at world 1, 100k nodes, per step: one stream 3.29 ms; the whole
+        # GIN there 3.65 ms (its MLP finds no CU beside an NNConv block: 52 us instead of 19); only the sum there 3.49 ms -- GIN_i
+        # needs the exchange of layer i-1, the chain cannot run ahead as it does unsharded, and every cross-queue dependency on
+        # the critical path costs ~10-15 us (scratch/time_sharded.py, scratch/sharded_trace.sh)
         self.two_streams = False
         self.send_idx_fused = torch.from_numpy(np.concatenate(send_ext)).to(self.dev)
         self.recv_idx_fused = torch.from_numpy(np.concatenate(recv_ext)).to(self.dev)
