@@ -37,6 +37,9 @@ __global__ __launch_bounds__(256) void gin32_aggregate_kernel(
     const float *__restrict__ a, int64_t lda, const float *__restrict__ in_stat, const int *__restrict__ rowptr,
     const int *__restrict__ col_src, const float *__restrict__ eps_p, int64_t n, float *__restrict__ z) {
     constexpr int C = 32;
+#ifdef TGNN_ABL_EMPTYGIN
+    if (n > 0) return;                                     // (timing ablation)
+#endif
     const int tid = threadIdx.x, g = tid >> 3, q = tid & 7;
     // block -> (xcd, chunk): XCD x owns rows [n*x/8, n*(x+1)/8), 32 rows per block
     const int xcd = blockIdx.x & 7, chunk = blockIdx.x >> 3;
@@ -137,6 +140,9 @@ __global__ __launch_bounds__(kMlpThreads, 2) void gin32_mlp_kernel(
     __shared__ double red[kMlpWaves * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fn = lane & 15, fq = lane >> 4;
+#ifdef TGNN_ABL_EMPTYGIN
+    if (n > 0) return;
+#endif
 
     // ---- tile share of this wave (16-row tiles): balanced per SIMD (waves w, w + 4 of a block run on SIMD w & 3)
     const int64_t n_tiles = (n + 15) / 16;

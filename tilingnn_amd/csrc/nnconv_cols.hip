@@ -49,6 +49,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fj = lane & 15, fq = lane >> 4;
     constexpr int kThreads = WAVES * 64;
+#ifdef TGNN_ABL_EMPTY
+    if (n > 0) return;                                     // (timing ablation: what the forward costs without this kernel)
+#endif
 
 #ifdef TGNN_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
