@@ -81,6 +81,37 @@ def test_small_kernel_matches_the_general_schedule_layer_by_layer(dev, n):
     assert float((p_small - p_gen).abs().max()) < 1e-3
 
 
+@pytest.mark.parametrize("depth,t,tile_count,out_dim,n", [(1, 13, 2, 1, 900), (2, 17, 2, 1, 1500), (6, 3, 4, 3, 700), (30, 13, 2, 1, 400),
+                                                         (3, 1, 2, 1, 333)])
+def test_small_kernel_other_shapes(dev, depth, t, tile_count, out_dim, n):
+    """Depths 1 .. 30 (at 34 and 13 types the final MLP's input planes plus the type-sum tiles no longer fit LDS: general schedule), 1 .. 17 edge types, tile_count 4 (five node features),
+    several probability maps: the probabilities of both schedules."""
+    import ctypes as C
+    from tilingnn_amd import TilinGNN, _lib, ops
+    from tilingnn_amd.synth import make_super_graph
+    from tilingnn_amd.weights import make_state_dict
+    sg = make_super_graph(n, 8 * n, 10 * n, tile_count=tile_count, n_edge_types=t, seed=depth)
+    x, adj, attr, col, _ = sg.to_torch(dev)
+    fe, fx = int(attr.shape[1]), int(x.shape[1])
+    outs = {}
+    for name, limit in (("general", 0), ("small", 4096)):
+        net = TilinGNN(adj_edge_features_dim=fe, network_depth=depth, network_width=32, output_dim=out_dim, node_features_dim=fx)
+        net.load_state_dict(make_state_dict(fe, depth, 32, out_dim, fx, seed=3), strict=True)
+        net = net.to(dev).train()
+        with small_limit(limit):
+            outs[name] = net(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)[0].cpu()
+        graph = ops.prepare_graph(n, adj, attr, col)
+        assert graph.n_types == t
+        dims = net._dims()
+        assert bool(_lib.lib.tgnn_get_small_layout_limit() >= 0) and C.sizeof(dims) > 0
+    assert outs["small"].shape == (n, out_dim) and bool(torch.isfinite(outs["small"]).all())
+    err = float((outs["small"] - outs["general"]).abs().max())
+    print(f"depth {depth} types {t} maps {out_dim}: max |p_small - p_general| = {err:.2e}")
+    # shallow: rounding only; deep: twenty-plus train-mode BatchNorms amplify it (the reference's own float32 run is 1e-1 off)
+    assert err < (2e-5 if depth <= 2 else 2e-3 if depth <= 6 else 1e-1)
+    assert not torch.equal(outs["small"], outs["general"])
+
+
 def test_layouts_above_the_limit_take_the_general_schedule(dev):
     inputs = _synthetic(4097, dev)
     net, _ = make_net(dev, depth=3)
