@@ -190,3 +190,34 @@ def test_small_kernel_running_statistics_match_the_general_schedule(dev):
             assert orc.rel_max_err(sds[1][k], sds[0][k]) < 1e-4, k
         elif k.endswith("num_batches_tracked"):
             assert int(sds[0][k]) == int(sds[1][k]) == 1, k
+
+
+def test_two_streams_two_threads_do_not_deadlock(dev):
+    """Two persistent kernels launched from two threads on two streams: the library orders them (one at a time per device)."""
+    import threading
+    inputs = _synthetic(3000, dev, seed=2)                      # 188 tiles each: two of them do not fit the chip together
+    nets = [make_net(dev, depth=6, seed=k)[0] for k in range(2)]
+    want = [nets[k](*inputs)[0].clone() for k in range(2)]
+    torch.cuda.synchronize()
+    got, errors = [None, None], []
+
+    def work(k):
+        try:
+            torch.cuda.set_device(dev)
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                for _ in range(20):
+                    got[k] = nets[k](*inputs)[0]
+            st.synchronize()
+        except BaseException as exc:                             # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors and not any(t.is_alive() for t in threads)
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert torch.equal(got[k], want[k])

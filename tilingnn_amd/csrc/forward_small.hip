@@ -27,6 +27,8 @@
 // Arithmetic: the same formulas as the general path's kernels (nnconv_cols.hip, gin.hip, dense.hip, bn_merge.hip); what differs
 // is the association of sums (NNConv: six partial products per tile; BatchNorm: one partial row per tile; dense layers: K in
 // steps of 32), i.e. fp32 / fp64 rounding only.  Deterministic: every order is fixed.
+#include <mutex>
+
 #include "tgnn_common.h"
 
 namespace tgnn {
@@ -1165,7 +1167,22 @@ int launch_forward_small(const tgnn_model_dims *d, const Params &P, const float 
     const int blocks = (int)((n + 15) / 16);
     static LdsOptIn site;
     TGNN_CHECK_HIP(opt_in_dynamic_lds(forward_layers_small_kernel, (int)kSmallMaxLds, site));
-    forward_layers_small_kernel<<<dim3(blocks), dim3(kSmallThreads), small_lds_bytes(graph->n_types, depth), s>>>(A, R, E);
+    // One persistent kernel at a time per device: two of them launched side by side from different streams could each get
+    // half of the CUs and wait for the other half for ever (what a cooperative launch rules out by serialising such kernels).
+    // Every launch waits for the one before it (an event, whichever stream that was on) and leaves its own.  Other PROCESSES
+    // on the same GPU are outside this: they delay the kernel (blocks wait for a CU) but do not depend on it.
+    static std::mutex mu;
+    static hipEvent_t last_done[64] = {};
+    int dev = 0;
+    TGNN_CHECK_HIP(hipGetDevice(&dev));
+    TGNN_CHECK_ARG(dev >= 0 && dev < 64, "device index");
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!last_done[dev]) TGNN_CHECK_HIP(hipEventCreateWithFlags(&last_done[dev], hipEventDisableTiming));
+        else TGNN_CHECK_HIP(hipStreamWaitEvent(s, last_done[dev], 0));
+        forward_layers_small_kernel<<<dim3(blocks), dim3(kSmallThreads), small_lds_bytes(graph->n_types, depth), s>>>(A, R, E);
+        TGNN_CHECK_HIP(hipEventRecord(last_done[dev], s));
+    }
     return TGNN_OK;
 }
 
