@@ -142,7 +142,7 @@ static Workspace carve(const tgnn_model_dims &d, int64_t n, int64_t nr, int32_t 
     w.partf = cv.take<double>((size_t)TGNN_BN_MAX_PARTIALS * 2 * 256);
     w.small_pack = cv.take<float>(small_pack_floats(D));
     w.small_part = cv.take<double>((size_t)256 * 128);
-    w.small_part_wide = cv.take<double>((size_t)256 * 512);
+    w.small_part_wide = cv.take<double>((size_t)2 * 256 * 512);
     w.small_runstat = cv.take<double>((size_t)D * 128);
     w.small_ctr = cv.take<unsigned>(64);
     w.stat1 = cv.take<float>(4 * c);

@@ -163,7 +163,7 @@ struct SmallEnds {
     SmallDense f[4];             // final MLP: 32 (depth + 1) -> 256 -> 128 -> 64 -> 32
     const float *w_last, *b_last;   // final_mlp.1: Linear(32, out_dim) + sigmoid, no BatchNorm
     float *probs;                // [n][out_dim]
-    double *part_wide;           // [blocks][512]: column sums | sums of squares of one dense layer
+    double *part_wide;           // [2][256][512]: column sums | sums of squares of one dense layer, two sets
     int fx, out_dim;
 };
 #ifdef TGNN_SMALL_TIMING
@@ -281,6 +281,7 @@ __device__ __forceinline__ void small_run_mma(const float *wl, int t, int lane, 
 //   tile [16][kDActLd] fp32 | fp64 fold [512 / M][2 M] = 1024 doubles | BatchNorm record [4][256]
 constexpr int kDActLd = 260, kDPlaneStep = 3 * 64 * 4;
 constexpr int kSmallMaxDepth = 40;
+constexpr size_t kPartWideSet = (size_t)256 * 512;   // doubles of one set of wide partial rows (two sets: see small_tile_bn)
 __host__ __device__ constexpr int small_dense_ksteps(int depth) { return depth + 1 > 8 ? depth + 1 : 8; }
 __host__ __device__ constexpr int small_dense_lds_floats(int depth) {
     return small_dense_ksteps(depth) * kDPlaneStep + 16 * kDActLd + 2048 + 1024;
@@ -361,6 +362,8 @@ __device__ __forceinline__ void small_tile_planes_from_act(const float *act, con
 
 // Train-mode BatchNorm statistics of act [valid_rows][M] over ALL tiles: this block's column sums -> its partial row -> grid
 // barrier -> every block folds all rows in the same order -> record [4][256] in LDS (block 0 updates the running buffers).
+// Consecutive calls alternate between two sets of partial rows (`part_wide` = the caller's set for this call): nothing but this
+// one barrier separates a fast block's next row from a slow block's reads of the current ones.
 template <int M>
 __device__ __forceinline__ void small_tile_bn(const float *act, int valid_rows, const SmallDense &L, double *part_wide, double *red,
                                               float *rec, int64_t n_total, float eps, float momentum, int update_running,
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
         __syncthreads();
         small_tile_dense<1>(E.i1.img, 1, 2, E.i1.bias, dx, dact, tw, lane);
         __syncthreads();
-        small_tile_bn<32>(dact, valid_rows, E.i1, E.part_wide, dred, drec, n, A.eps, A.momentum, A.update_running, A.ctr, target, nblk, tid);
+        small_tile_bn<32>(dact, valid_rows, E.i1, E.part_wide + kPartWideSet, dred, drec, n, A.eps, A.momentum, A.update_running, A.ctr, target, nblk, tid);
         if (tid < 128) {
             const int row = tid >> 3, c4 = (tid & 7) * 4;
             if (row < valid_rows) {
@@ -1000,7 +1003,7 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
         __syncthreads();
         small_tile_dense<1>(E.f[1].img, 8, 8, E.f[1].bias, dx, dact, tw, lane);
         __syncthreads();
-        small_tile_bn<128>(dact, valid_rows, E.f[1], E.part_wide, dred, drec, n, A.eps, A.momentum, A.update_running, A.ctr, target, nblk, tid);
+        small_tile_bn<128>(dact, valid_rows, E.f[1], E.part_wide + kPartWideSet, dred, drec, n, A.eps, A.momentum, A.update_running, A.ctr, target, nblk, tid);
         small_tile_planes_from_act(dact, drec, 128, valid_rows, dx, tid);
         __syncthreads();
         small_tile_dense<1>(E.f[2].img, 4, 4, E.f[2].bias, dx, dact, tw, lane);
@@ -1010,7 +1013,7 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
         __syncthreads();
         small_tile_dense<1>(E.f[3].img, 2, 2, E.f[3].bias, dx, dact, tw, lane);
         __syncthreads();
-        small_tile_bn<32>(dact, valid_rows, E.f[3], E.part_wide, dred, drec, n, A.eps, A.momentum, A.update_running, A.ctr, target, nblk, tid);
+        small_tile_bn<32>(dact, valid_rows, E.f[3], E.part_wide + kPartWideSet, dred, drec, n, A.eps, A.momentum, A.update_running, A.ctr, target, nblk, tid);
         for (int it = tid; it < 16 * E.out_dim; it += NT) {      // final_mlp.1
             const int r = it / E.out_dim, o = it - r * E.out_dim;
             if (r < valid_rows) {
