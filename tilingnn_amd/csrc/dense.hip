@@ -492,7 +492,8 @@ static int dense_act_impl(const float *a, int64_t lda, int64_t a_kblock_stride, 
         // bf16 x 3 split-precision path (see dense_split_kernel)
         // few row tiles (small layouts): the 128 x 64 block tile puts twice as many blocks on the chip and halves the
         // matrix work per k-step of each -- the kernel is then bound by the latency of its serial k loop
-        // (round 2: a 128 x 256 tile -- A split once per row tile instead of once per column tile, but 92 KB of LDS = one block
+        // (round 2: the weights pre-split into bf16 planes once per forward -- three 16-byte copies per item instead of a split per
+        //  block and k-tile -- changed nothing measurable, 2.17-2.24 vs 2.20-2.22 ms per forward; a 128 x 256 tile -- A split once per row tile instead of once per column tile, but 92 KB of LDS = one block
         //  per CU -- runs 672 -> 256 in 449 us against 281 us: the kernel lives on a second block covering the first one's
         //  two barriers per k-tile)
         constexpr int small_rows = 16384;
