@@ -153,31 +153,39 @@ int tgnn_nnconv_mean_cols_fwd(const float *h, int64_t ldh, const int32_t *tile_c
                               tgnn_stream_t stream);
 
 /* The same NNConv as a STREAM of gathered rows through an LDS ring (csrc/nnconv_stream.hip; the throughput kernel, production
- * path of tgnn_forward when the graph carries the structure): two loader waves fetch the source rows of a block's tiles by
- * LDS-DMA, eight multiplying waves keep the weight fragments of their edge types in registers, two epilogue waves finish
- * the rows.  Built from the adjacency CSR + the edge types in CSR order (once per layout):
+ * path of tgnn_forward when the graph carries the structure): message, scatter-mean, update in the reference's order.  Two
+ * loader waves fetch the source rows of a block's tiles by LDS-DMA -- rows pre-split into fp16 pairs, so that a gathered row
+ * is a matrix operand --, eight multiplying waves keep the weight fragments of their edge types in registers and multiply 16
+ * edges of one type at a time, two epilogue waves add every destination row's messages in CSR order.  Built from the
+ * adjacency CSR + the edge types in CSR order (once per layout):
  *   tile_ent_ptr int32  [ceil(N/16)+1]   entries before every 16-row tile (multiples of 8)
- *   ent          uint32 [<= tgnn_nnconv_stream_max_entries(N, E)]  entry words (source row << 7 | piece permutation << 4):
- *                                        per tile its edge types in order, the tile's own rows last (root run); inside a type
- *                                        the destination rows ascending, a row's edges in CSR order
- *   info         uint32 [ceil(N/16)][64] per multiplying wave 8 words: the count planes of its two types, their first entries
- *                                        and lengths, the tile's ring slot (16-byte aligned array)
+ *   ent          uint32 [tgnn_nnconv_stream_max_entries(N, E)]  entry words (source row << 7 | piece permutation << 4): per
+ *                                        tile its edge types in order, the tile's own rows last (root run); inside a type the
+ *                                        destination rows ascending, a row's edges in CSR order
+ *   rowlist      uint16 [same count]     per tile, row by row: where the messages of the row's edges (CSR order), then of
+ *                                        the row itself, sit in the kernel's message ring
+ *   info         uint32 [ceil(N/16)][64] per multiplying wave the first entry / length of its two type runs; the rows' list
+ *                                        positions
  *   inv_deg      float  [16 ceil(N/16)]  1 / max(in-degree, 1)
- * result (device int32 [4]): largest padded entry count of a tile, most same-type in-edges of one row, 1 = built.  The
- * kernel takes layouts with n_types <= *max_types, result[0] <= *max_tile_entries, result[1] <= *max_multiplicity
+ * result (device int32 [4]): most (padded) entries of two consecutive tiles, most entries of one type run, 1 = built.  The
+ * kernel takes layouts with n_types <= *max_types, result[0] <= *max_pair_entries, result[1] <= *max_run_entries
  * (tgnn_nnconv_stream_limits); otherwise use the column kernel.  n_types_dev (may be NULL): the type count read from the
  * device instead (tgnn_graph_prep queues the whole preparation without a host round trip).
  * Source rows are dense [n_src_rows][32] floats (row stride 128 bytes) within 2 GB. */
-void tgnn_nnconv_stream_limits(int32_t *max_types, int32_t *max_tile_entries, int32_t *max_multiplicity);
+void tgnn_nnconv_stream_limits(int32_t *max_types, int32_t *max_pair_entries, int32_t *max_run_entries);
 int64_t tgnn_nnconv_stream_max_entries(int64_t n_nodes, int64_t n_edges);
 size_t tgnn_nnconv_stream_scan_ws_bytes(int64_t n_nodes);
 int tgnn_nnconv_stream_build(const int32_t *rowptr, const int32_t *col_src, const int32_t *col_type, int64_t n_nodes,
-                             int32_t n_types, const int32_t *n_types_dev, int32_t *tile_ent_ptr, uint32_t *ent, uint32_t *info,
-                             float *inv_deg, int32_t *result, void *ws, size_t ws_bytes, tgnn_stream_t stream);
+                             int32_t n_types, const int32_t *n_types_dev, int32_t *tile_ent_ptr, uint32_t *ent, uint32_t *rowlist,
+                             uint32_t *info, float *inv_deg, int32_t *result, void *ws, size_t ws_bytes, tgnn_stream_t stream);
 int tgnn_nnconv_mean_stream_fwd(const float *h, int64_t n_src_rows, const int32_t *tile_ent_ptr, const uint32_t *ent,
-                                const uint32_t *info, const float *inv_deg, const float *wtab, int32_t n_types,
-                                const float *root, const float *bias, int64_t n_nodes, int32_t c, int32_t act, float *out,
-                                float *wimg_scratch, double *bn_partial, int32_t *n_partials_host, tgnn_stream_t stream);
+                                const uint32_t *rowlist, const uint32_t *info, const float *inv_deg, const float *wtab,
+                                int32_t n_types, const float *root, const float *bias, int64_t n_nodes, int32_t c, int32_t act,
+                                float *out, void *split_scratch, double *bn_partial, int32_t *n_partials_host,
+                                tgnn_stream_t stream);
+/* split_scratch: tgnn_nnconv_stream_split_bytes(n_src_rows) bytes, 256-byte aligned: the source rows as fp16 pairs
+ * (hi + lo, scaled by a power of two chosen from the largest |h|), which is the form the kernel gathers. */
+size_t tgnn_nnconv_stream_split_bytes(int64_t n_src_rows);
 
 /* GINConv + optional LeakyReLU (coll_conv.py:25-27):
  *   z[v]  = (1+eps) * f(a[v]) + sum_{e: dst_e = v} f(a[src_e]),   f = identity or the BatchNorm
@@ -272,6 +280,7 @@ typedef struct tgnn_graph {
      * inside tgnn_nnconv_stream_limits. */
     const int32_t *nn_st_tile_ent_ptr;
     const uint32_t *nn_st_ent_src;
+    const uint32_t *nn_st_rowlist;
     const uint32_t *nn_st_info;
     const float *nn_st_inv_deg;
 } tgnn_graph;
@@ -394,16 +403,16 @@ int tgnn_graph_prep_small(const int64_t *adj_edge_index, int64_t n_adj_edges, co
                           int32_t *col_slot_src, int32_t *tmp, int32_t *result, uint32_t *counters, tgnn_stream_t stream);
 
 /* The same at any size: one call that queues every launch of the preparation itself (no host round trip in the middle:
- * the column structure reads the type count from the device).  result [32] as above (words 4 and 6 stay 0).  The four
+ * the column structure reads the type count from the device).  result [32] as above (words 4 and 6 stay 0).  The five
  * st_* arrays (all or none; sized as for tgnn_nnconv_stream_build) also receive the NNConv stream structure: result[8..10] =
- * largest padded entry count of a tile, most same-type in-edges of one row, 1 = built. */
+ * that call's result words. */
 size_t tgnn_graph_prep_workspace_bytes(int64_t n_nodes, int64_t n_adj_edges, int64_t n_col_edges, int32_t fe);
 int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edges, const float *adj_edge_attr, int32_t fe,
                     const int64_t *col_edge_index, int64_t n_col_edges, int64_t n_nodes, int32_t *adj_rowptr, int32_t *adj_src,
                     int32_t *adj_eid, int32_t *adj_type, int32_t *edge_type, int32_t *type_rep_edge, int32_t *col_rowptr,
                     int32_t *col_src, int32_t *col_eid, int32_t *tile_col_ptr, int32_t *col_meta, int32_t *col_slot_src,
-                    int32_t *st_tile_ent_ptr, uint32_t *st_ent_src, uint32_t *st_info, float *st_inv_deg, void *ws,
-                    size_t ws_bytes, int32_t *result, tgnn_stream_t stream);
+                    int32_t *st_tile_ent_ptr, uint32_t *st_ent_src, uint32_t *st_rowlist, uint32_t *st_info, float *st_inv_deg,
+                    void *ws, size_t ws_bytes, int32_t *result, tgnn_stream_t stream);
 
 /* The same forward with a hipEvent pair around every launch (on `stream`, where the kernels run);
  * synchronises, then ADDS the elapsed milliseconds and launch counts per kernel class into the

@@ -23,3 +23,11 @@ names = ["mult"] * 8 + ["load"] * 2 + ["epil"] * 2
 print("cycles (100 MHz counter? s_memtime ticks) per block, mean over 256 blocks")
 for w in range(12):
     print(f" wave {w:2d} {names[w]}: work {a[:, w, 0].mean():9.0f}  barrier wait {a[:, w, 1].mean():9.0f}  steps {a[:, w, 2].mean():5.1f}  total {a[:, w, 3].mean():9.0f}  (max total {a[:, w, 3].max():9.0f})")
+
+buf2 = (ctypes.c_ulonglong * (512 * 12 * 4))()
+if hasattr(_lib.lib, "tgnn_debug_stream_seg"):
+    _lib.lib.tgnn_debug_stream_seg(buf2)
+    b = np.frombuffer(buf2, dtype=np.uint64).reshape(512, 12, 4)[:256].astype(np.float64)
+    print("segments (mult: next info | run A | run B;  epil: DMA issue | row info wait | row sums | finish + store + DMA wait)")
+    for w in range(12):
+        print(f" wave {w:2d} {names[w]}: " + "  ".join(f"{b[:, w, k].mean():9.0f}" for k in range(4)))

@@ -1145,8 +1145,9 @@ extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edge
                                const int64_t *col_edge_index, int64_t n_col_edges, int64_t n_nodes, int32_t *adj_rowptr,
                                int32_t *adj_src, int32_t *adj_eid, int32_t *adj_type, int32_t *edge_type, int32_t *type_rep_edge,
                                int32_t *col_rowptr, int32_t *col_src, int32_t *col_eid, int32_t *tile_col_ptr, int32_t *col_meta,
-                               int32_t *col_slot_src, int32_t *st_tile_ent_ptr, uint32_t *st_ent_src, uint32_t *st_info,
-                               float *st_inv_deg, void *ws, size_t ws_bytes, int32_t *result, tgnn_stream_t stream) {
+                               int32_t *col_slot_src, int32_t *st_tile_ent_ptr, uint32_t *st_ent_src, uint32_t *st_rowlist,
+                               uint32_t *st_info, float *st_inv_deg, void *ws, size_t ws_bytes, int32_t *result,
+                               tgnn_stream_t stream) {
     DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_nodes >= 1 && fe >= 1 && n_adj_edges >= 0 && n_col_edges >= 0, "shape");
     TGNN_CHECK_ARG(adj_rowptr && col_rowptr && tile_col_ptr && col_meta && col_slot_src && result, "null pointer");
@@ -1186,12 +1187,12 @@ extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edge
     nnconv_col_kernel<true><<<blocks, 64, 0, s>>>(adj_rowptr, adj_src, adj_type, n_nodes, 0, nullptr, tile_col_ptr, col_meta,
                                                   col_slot_src, result + 0, max_types, result + 5);
     TGNN_CHECK_LAUNCH();
-    if (st_tile_ent_ptr && st_ent_src && st_info && st_inv_deg && n_nodes < (int64_t(1) << 24)) {
+    if (st_tile_ent_ptr && st_ent_src && st_rowlist && st_info && st_inv_deg && n_nodes < (int64_t(1) << 24)) {
         // the stream structure of the throughput NNConv kernel (nnconv_stream.hip; the type count is read on the device);
-        // result[8..10] = largest padded entry count of a tile, most same-type in-edges of a row, 1 = built
+        // result[8..10] = most entries of two consecutive tiles, most entries of one type run of a tile, 1 = built
         void *ws_st = cv.take<unsigned char>(tgnn_nnconv_stream_scan_ws_bytes(n_nodes));
         rc = nnconv_stream_build_gated(adj_rowptr, adj_src, adj_type, n_nodes, 0, result + 0, nullptr, st_tile_ent_ptr,
-                                       st_ent_src, st_info, st_inv_deg, result + 8, ws_st, s);
+                                       st_ent_src, st_rowlist, st_info, st_inv_deg, result + 8, ws_st, s);
         if (rc != TGNN_OK) return rc;
     }
     return TGNN_OK;

@@ -226,16 +226,19 @@ int launch_nnconv_cols(const float *h, int64_t ldh, const int32_t *tile_col_ptr,
                        const int32_t *col_src, const float *wimg, int32_t n_types, const float *bias,
                        int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
                        hipStream_t s);
-// the stream NNConv kernel (nnconv_stream.hip); wimg = one layer's operand image [(T+1)][kWtType]; reserve_cus CUs stay free
-int launch_nnconv_stream(const float *h, int64_t n_src_rows, const int32_t *tile_ent_ptr, const uint32_t *ent_src,
-                         const uint32_t *info, const float *inv_deg, const float *wimg, int32_t n_types, const float *bias,
-                         int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
-                         int reserve_cus, hipStream_t s);
+// the stream NNConv kernel (nnconv_stream.hip) over rows pre-split into fp16 pairs (launch_nnconv_split16: hs [rows][128 B],
+// hs_scale {s, 1/s}); wtab = one layer's [T][32][32] table; reserve_cus CUs stay free
+int launch_nnconv_split16(const float *h, int64_t n_rows, void *hs, float *scale2, unsigned *max_bits, hipStream_t s);
+int launch_nnconv_stream(const void *hs, const float *hs_scale, int64_t n_src_rows, const int32_t *tile_ent_ptr,
+                         const uint32_t *ent_src, const uint32_t *rowlist, const uint32_t *info, const float *inv_deg,
+                         const float *wtab, const float *root, int32_t n_types, const float *bias, int64_t n_nodes, int32_t act,
+                         float *out, double *bn_partial, int32_t *n_partials_host, int reserve_cus, hipStream_t s);
 // queues the stream structure's three launches (from the adjacency CSR + edge types in CSR order); gate (may be NULL):
 // device word, nothing is built while it is 0
 int nnconv_stream_build_gated(const int32_t *rowptr, const int32_t *col_src, const int32_t *col_type, int64_t n_nodes,
                               int32_t n_types, const int32_t *n_types_dev, const int32_t *gate, int32_t *tile_ent_ptr,
-                              uint32_t *ent_src, uint32_t *info, float *inv_deg, int32_t *result, void *ws, hipStream_t s);
+                              uint32_t *ent_src, uint32_t *rowlist, uint32_t *info, float *inv_deg, int32_t *result, void *ws,
+                              hipStream_t s);
 // the MLP half of tgnn_gin_fwd (width 32) behind tgnn_gin_aggregate; gin.hip
 int launch_gin32_mlp(const float *z, const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
                      const float *b3, int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,

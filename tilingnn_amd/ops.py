@@ -81,8 +81,8 @@ class PreparedGraph:
                           self.type_rep_edge.data_ptr(), self.col_rowptr.data_ptr(), self.col_src.data_ptr(),
                           *((t.tile_col_ptr.data_ptr(), t.col_meta.data_ptr(), t.col_src.data_ptr())
                             if t is not None else (None,) * 3), self.max_in_degree,
-                          *((st.tile_ent_ptr.data_ptr(), st.ent_src.data_ptr(), st.info.data_ptr(), st.inv_deg.data_ptr())
-                            if st is not None else (None,) * 4))
+                          *((st.tile_ent_ptr.data_ptr(), st.ent_src.data_ptr(), st.rowlist.data_ptr(), st.info.data_ptr(),
+                             st.inv_deg.data_ptr()) if st is not None else (None,) * 5))
 
 
 @dataclass
@@ -97,12 +97,16 @@ class NNConvColumns:
 class NNConvStream:
     """Gathered-row stream of the throughput NNConv kernel (tgnn_nnconv_stream_build, include/tgnn.h)."""
     tile_ent_ptr: Tensor      # int32 [ceil(N/16) + 1]
-    ent_src: Tensor           # int32 (uint32 bits) [cap]: source row per entry
+    ent_src: Tensor           # int32 (uint32 bits) [cap]: entry words
+    rowlist: Tensor           # int32 (pairs of uint16) [cap / 2]: message-ring slots of every row's edges + itself
     info: Tensor              # int32 (uint32 bits) [ceil(N/16) * 64]
     inv_deg: Tensor           # float32 [16 * ceil(N/16)]
 
 
-STREAM_NNCONV = os.environ.get("TGNN_STREAM_NNCONV", "1") != "0"     # 0: the column kernel everywhere (A/B runs)
+# The stream kernel (csrc/nnconv_stream.hip) is an EXPERIMENT kept for its measurements (DESIGN.md section 13): parity-tested,
+# 38 us at 100k nodes against the column kernel's 44, and it wants its input rows pre-split -- not worth the switch.  Opt in
+# with TGNN_STREAM_NNCONV=1 (prepare_graph then also builds its structure) or per call with nnconv_mean(kernel="stream").
+STREAM_NNCONV = os.environ.get("TGNN_STREAM_NNCONV", "0") == "1"
 
 
 def stream_limits(_cache=[]):
@@ -113,9 +117,9 @@ def stream_limits(_cache=[]):
     return _cache[0]
 
 
-def stream_fits(n_types: int, max_tile_entries: int, max_multiplicity: int, built: int, n_src_rows: int) -> bool:
+def stream_fits(n_types: int, max_pair_entries: int, max_run_entries: int, built: int, n_src_rows: int) -> bool:
     lim = stream_limits()
-    return bool(STREAM_NNCONV and built and n_types <= lim[0] and max_tile_entries <= lim[1] and max_multiplicity <= lim[2]
+    return bool(built and n_types <= lim[0] and max_pair_entries <= lim[1] and max_run_entries <= lim[2]
                 and n_src_rows < 2 ** 24)
 
 
@@ -123,19 +127,20 @@ def build_nnconv_stream(n_nodes: int, n_edges: int, n_types: int, rowptr: Tensor
                         n_src_rows: Optional[int] = None) -> Optional[NNConvStream]:
     """The stream structure from the adjacency CSR + edge types in CSR order (synchronises: the layout's largest tile and
     the most same-type in-edges of a row decide whether the kernel takes it).  None when it does not."""
-    if not STREAM_NNCONV or n_types > stream_limits()[0] or n_nodes >= 2 ** 24:
+    if n_types > stream_limits()[0] or n_nodes >= 2 ** 24:
         return None
     dev = rowptr.device
     ntiles = (n_nodes + 15) // 16
     cap = int(lib.tgnn_nnconv_stream_max_entries(n_nodes, n_edges))
     st = NNConvStream(torch.empty(ntiles + 1, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.int32, device=dev),
+                      torch.empty(cap // 2 + 64, dtype=torch.int32, device=dev),
                       torch.empty(ntiles * 64, dtype=torch.int32, device=dev),
                       torch.empty(ntiles * 16, dtype=torch.float32, device=dev))
     res = torch.zeros(4, dtype=torch.int32, device=dev)
     ws_bytes = int(lib.tgnn_nnconv_stream_scan_ws_bytes(n_nodes))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     check(lib.tgnn_nnconv_stream_build(ptr(rowptr), ptr(col_src), ptr(col_type), n_nodes, n_types, None, ptr(st.tile_ent_ptr),
-                                       ptr(st.ent_src), ptr(st.info), ptr(st.inv_deg), ptr(res), ptr(ws), ws_bytes,
+                                       ptr(st.ent_src), ptr(st.rowlist), ptr(st.info), ptr(st.inv_deg), ptr(res), ptr(ws), ws_bytes,
                                        _stream(rowptr)))
     host = res.cpu().tolist()
     return st if stream_fits(n_types, host[0], host[1], host[2], n_src_rows or n_nodes) else None
@@ -250,7 +255,8 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
     want_stream = not small and STREAM_NNCONV and n_nodes < 2 ** 24
     st_cap = int(lib.tgnn_nnconv_stream_max_entries(n_nodes, ea)) if want_stream else 0
     sizes = [n_nodes + 1, e1, e1, e1, e1, e1, n_nodes + 1, c1, c1, ntiles + 1, cap, cap * 16, 32, ws_ints,
-             (ntiles + 1) if want_stream else 0, st_cap, ntiles * 64 if want_stream else 0, ntiles * 16 if want_stream else 0]
+             (ntiles + 1) if want_stream else 0, st_cap, (st_cap // 2 + 64) if want_stream else 0,
+             ntiles * 64 if want_stream else 0, ntiles * 16 if want_stream else 0]
     offs, at = [], 0
     for sz in sizes:
         offs.append(at)
@@ -258,13 +264,13 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
     buf = torch.empty(at, dtype=torch.int32, device=dev)
     v = [buf[o:o + sz] for o, sz in zip(offs, sizes)]
     (a_rowptr, a_src, a_eid, adj_type, edge_type, rep, c_rowptr, c_src, c_eid, tile_col_ptr, col_meta, col_slot_src, res, tmp,
-     st_ptr, st_src, st_info, st_inv) = v
+     st_ptr, st_src, st_rl, st_info, st_inv) = v
     head = (ptr(adj), ea, ptr(attr), fe, ptr(col), ec, n_nodes, ptr(a_rowptr), ptr(a_src), ptr(a_eid), ptr(adj_type), ptr(edge_type),
             ptr(rep), ptr(c_rowptr), ptr(c_src), ptr(c_eid), ptr(tile_col_ptr), ptr(col_meta), ptr(col_slot_src))
     if small:
         check(lib.tgnn_graph_prep_small(*head, ptr(tmp), ptr(res), ptr(_small_prep_counters(dev)), _stream(adj)))
     else:
-        st_args = (ptr(st_ptr), ptr(st_src), ptr(st_info), ptr(st_inv)) if want_stream else (None,) * 4
+        st_args = (ptr(st_ptr), ptr(st_src), ptr(st_rl), ptr(st_info), ptr(st_inv)) if want_stream else (None,) * 5
         check(lib.tgnn_graph_prep(*head, *st_args, ptr(tmp), ws_ints * 4, ptr(res), _stream(adj)))
     host = res[:12].cpu().tolist()                                               # the one sync
     if host[1] or host[2]:
@@ -274,7 +280,7 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
     cols = NNConvColumns(tile_col_ptr, col_meta, col_slot_src) if host[5] else None
     stream = None
     if want_stream and cols is not None and stream_fits(int(host[0]), host[8], host[9], host[10], n_nodes):
-        stream = NNConvStream(st_ptr, st_src, st_info, st_inv.view(torch.float32))
+        stream = NNConvStream(st_ptr, st_src, st_rl, st_info, st_inv.view(torch.float32))
     return PreparedGraph(n_nodes, ea, int(host[3]), int(host[0]), a_rowptr, a_src, a_eid, adj_type, edge_type, rep,
                          c_rowptr, c_src, c_eid, cols, int(host[4]), stream)
 
@@ -316,7 +322,7 @@ def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col
         columns = n_nodes > COLS_MIN_NODES
     cols = build_nnconv_columns(n_nodes, ea, n_types, a_rowptr, a_src, adj_type) if tile_width == 32 and columns else None
     stream = None
-    if cols is not None and n_nodes > _small_prep_limits()[0]:
+    if STREAM_NNCONV and cols is not None and n_nodes > _small_prep_limits()[0]:
         stream = build_nnconv_stream(n_nodes, ea, n_types, a_rowptr, a_src, adj_type, n_src_nodes)
     return PreparedGraph(n_nodes, ea, int(host[3]), n_types, a_rowptr, a_src, a_eid, adj_type, edge_type, rep,
                          c_rowptr, c_src, c_eid, cols, int(host[4]), stream)
@@ -365,10 +371,10 @@ def nnconv_mean(h: Tensor, graph: PreparedGraph, wtab: Tensor, root: Tensor, bia
     if kernel == "stream" and st is None:
         raise ValueError("the graph carries no stream structure")
     if st is not None and c == 32 and not force_csr_kernel and int(h.shape[0]) < 2 ** 24:
-        wimg = torch.empty(lib.tgnn_nnconv_weight_image_floats(graph.n_types), dtype=torch.float32, device=h.device)
-        check(lib.tgnn_nnconv_mean_stream_fwd(ptr(h), int(h.shape[0]), ptr(st.tile_ent_ptr), ptr(st.ent_src), ptr(st.info),
-                                              ptr(st.inv_deg), ptr(wt), graph.n_types, ptr(_f32c(root, "root")),
-                                              ptr(_f32c(bias, "bias")), n, c, act, ptr(out), ptr(wimg), ptr(partials),
+        split = torch.empty(lib.tgnn_nnconv_stream_split_bytes(int(h.shape[0])), dtype=torch.uint8, device=h.device)
+        check(lib.tgnn_nnconv_mean_stream_fwd(ptr(h), int(h.shape[0]), ptr(st.tile_ent_ptr), ptr(st.ent_src), ptr(st.rowlist),
+                                              ptr(st.info), ptr(st.inv_deg), ptr(wt), graph.n_types, ptr(_f32c(root, "root")),
+                                              ptr(_f32c(bias, "bias")), n, c, act, ptr(out), ptr(split), ptr(partials),
                                               C.byref(npart), _stream(h)))
     elif tl is not None and c == 32 and not force_csr_kernel and int(h.shape[0]) * c * 4 < 2 ** 31:
         wimg = torch.empty(lib.tgnn_nnconv_weight_image_floats(graph.n_types), dtype=torch.float32, device=h.device)
