@@ -381,15 +381,19 @@ int tgnn_forward_sharded(const tgnn_model_dims *dims, const void *const *params_
  * launches per layer (csrc/forward_small.hip) when the layout has at most this many nodes, width 32, train-mode
  * BatchNorm and few enough edge types for the weights to sit in LDS.  Same formulas; the BatchNorm sums and the NNConv
  * tile products are associated differently than in the general schedule (fp64 / fp32 rounding), deterministic either way.
- * Process-wide setting, default 16384; 0 switches the path off (the general schedule then runs at every size). */
+ * Process-wide setting, default and maximum 4096 (one 16-row tile per CU); 0 switches the path off (the general schedule then
+ * runs at every size).  The persistent kernel and tgnn_graph_prep_small synchronise their blocks with spin barriers and need
+ * all of them resident: the library serialises such launches per device (a process-wide mutex and one event per device, waited
+ * on and re-recorded by every launch, whichever stream it is on) -- state beyond the "idempotent set-up" of the conventions
+ * above, and the reason these two calls cannot be captured into a HIP graph. */
 void tgnn_set_small_layout_limit(int64_t n_nodes);
 int64_t tgnn_get_small_layout_limit(void);
 
 /* Small layouts (<= tgnn_graph_prep_small_max_nodes() nodes, <= ..._max_edges() edges per set): everything above --
  * tgnn_csr_build of both edge sets (self loops dropped from the collision set), tgnn_edge_type_dedup, the types in CSR
  * order, tgnn_nnconv_cols_build -- in ONE launch (up to 16 resident blocks with grid barriers); every output bit-identical
- * to the separate calls.  tmp: tgnn_graph_prep_small_tmp_ints() ints.  counters: 2 words that are zero before the first
- * call and zero again when a call has finished (one call at a time per counter pair).  result [32] (device; 8 used): n_types,
+ * to the separate calls.  tmp: tgnn_graph_prep_small_tmp_ints() ints.  counters: 2 words of scratch, zeroed by the call on
+ * `stream` (one call at a time per counter pair).  result [32] (device; 8 used): n_types,
  * adjacency index error, collision index error, collision CSR slots, largest adjacency in-degree, 1 = column structure
  * built (n_types <= tgnn_nnconv_cols_max_types()), 1 = fall back to the separate calls (more than 1024 distinct attribute
  * rows).  Asynchronous. */

@@ -306,9 +306,11 @@ def test_end_to_end_same_order_as_reference_fp32_gap(dev, laby, cols_min_nodes, 
     gap_hip = np.abs(got - ref["probs_fp64"]).max()
     print(f"end-to-end max|p - p_fp64|: HIP {gap_hip:.3e}; reference fp32 {gap_ref:.3e}")
     assert got.shape == (1254, 1) and np.isfinite(got).all()
-    # measured 2.1e-3 on both NNConv kernels (the reference's own fp32 run: 1.1e-1 -- twenty train-mode BatchNorms make the
-    # network chaotic end to end): gate at 5x the measurement, not at the reference's gap
-    assert gap_hip < 1e-2
+    # This layout (1 254 nodes) runs as the persistent small-layout kernel: measured 8.3e-3 (the general launch schedule on either
+    # NNConv kernel: 2.1e-3; the reference's own fp32 run: 1.1e-1 -- twenty train-mode BatchNorms make the network chaotic end
+    # to end, the two schedules are two rounding realisations).  The same single gate as tests/test_small_layout.py holds
+    # both schedules to; per layer both are gated absolutely against the oracle there.
+    assert gap_hip < 2e-2
 
 
 def _stat_record(v64, gamma, beta, eps=1e-5):

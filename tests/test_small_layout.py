@@ -138,8 +138,54 @@ def test_small_kernel_on_the_real_graph_against_the_reference(dev):
         assert all(int(v) == 1 for k, v in sd.items() if k.endswith("num_batches_tracked"))
     print("max |p - p_fp64| on the labyrinth graph:", gaps)
     # the reference's own float32 run: 1.1e-1 (chaotic end to end); measured: general 2.1e-3, persistent kernel 8.3e-3 -- two
-    # rounding realisations of the same formulas (the layer-by-layer test above is the parity statement)
-    assert gaps["general"] < 1e-2 and gaps["small"] < 3e-2
+    # rounding realisations of the same formulas: per layer both sit on the float32 floor of their slot (the absolute gates
+    # above, the per-layer table in DESIGN.md section 12), and which realisation ends closer after 20 chaotic layers is chance
+    # (other weight seeds order them the other way).  ONE gate for both schedules:
+    assert gaps["general"] < 2e-2 and gaps["small"] < 2e-2
+
+
+# Absolute gates of a skip-buffer slot against the float64 oracle, free running (nothing teacher forced), BOTH schedules:
+# slot 0 = the init MLP (two BatchNorms over node features with only tile_count distinct rows: the ill-conditioned class,
+# 2e-4), slot k >= 1 = k message-passing layers behind it; every layer's two train-mode BatchNorms multiply what
+# came in (the collision branch divides sigmoid columns that vary by ~0.3 % of their value), measured growth <= 4x per layer.
+SLOT0_TOL = 2e-5
+def slot_tol(k):
+    return SLOT0_TOL if k == 0 else 2e-5 * 4 ** (k - 1)
+
+
+def _slot_errors(dev, inputs64, inputs, n, depth, limit, seed=0):
+    net, sd = make_net(dev, depth=depth, seed=seed)
+    with small_limit(limit):
+        probs, slots = _forward_with_slots(net, inputs, n, dev)
+    cap = {}
+    with torch.no_grad():
+        want = orc.tilingnn_forward(orc.cast_sd(sd, torch.float64), *inputs64, capture=cap)[0]
+    errs = [orc.rel_max_err(slots[0], cap["init"])] + [orc.rel_max_err(slots[k], cap[f"mid.{k}"]) for k in range(1, depth + 1)]
+    return errs, float((probs.double() - want.cpu()).abs().max())
+
+
+@pytest.mark.parametrize("depth", [1, 4])
+@pytest.mark.parametrize("which", ["labyrinth", "synthetic-4096"])
+def test_persistent_kernel_slots_against_the_fp64_oracle_absolute(dev, depth, which):
+    """The persistent kernel is the default path of every layout the solver scores: its own absolute gates against the oracle
+    (depth 1 = one layer behind the init MLP, depth 4 = residual and two-deep collision buffers in play), not a comparison
+    with the other schedule.  The general schedule is held to the same numbers beside it."""
+    if which == "labyrinth":
+        g = load_labyrinth_graph()
+        n = 1254
+        inputs, inputs64 = graph_tensors(g, torch.float32, dev)[:4], graph_tensors(g, torch.float64)
+    else:
+        from tilingnn_amd.synth import make_super_graph
+        n = 4096
+        sg = make_super_graph(n, 10 * n, 12 * n + n // 2, tile_count=2, n_edge_types=13, seed=5)
+        inputs = sg.to_torch(dev)[:4]
+        inputs64 = tuple(t.double() if t.is_floating_point() else t for t in sg.to_torch("cpu"))
+    for name, limit in (("persistent", 4096), ("general", 0)):
+        errs, pgap = _slot_errors(dev, inputs64, inputs, n, depth, limit)
+        print(f"{which} depth {depth} {name}: slots " + " ".join(f"{e:.1e}" for e in errs) + f"  max |p - p64| {pgap:.1e}")
+        for k, e in enumerate(errs):
+            assert e < slot_tol(k), (name, k, e, slot_tol(k))
+        assert pgap < 1e-4 * 4 ** (depth - 1)
 
 
 def test_both_schedules_are_equally_close_to_the_fp64_oracle(dev):
@@ -217,6 +263,45 @@ def test_two_streams_two_threads_do_not_deadlock(dev):
         t.start()
     for t in threads:
         t.join(timeout=120)
+    assert not errors and not any(t.is_alive() for t in threads)
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert torch.equal(got[k], want[k])
+
+
+def test_uncached_preparation_beside_a_persistent_forward_does_not_deadlock(dev):
+    """The one-launch graph preparation also synchronises its (up to 16) blocks with spin barriers: beside a persistent forward
+    that fills the chip (n close to 4096: 256 tiles, one per CU) neither could get all its blocks resident -- both go through
+    the per-device chain of spin-barrier kernels.  Two threads, two streams, every forward prepares its layout again."""
+    import threading
+    from tilingnn_amd.graph_networks import _graph_cache
+    inputs = _synthetic(4090, dev, seed=4)
+    nets = [make_net(dev, depth=4, seed=k)[0] for k in range(2)]
+    want = [nets[k](*inputs)[0].clone() for k in range(2)]
+    torch.cuda.synchronize()
+    got, errors = [None, None], []
+
+    def work(k):
+        try:
+            torch.cuda.set_device(dev)
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                for _ in range(15):
+                    got[k] = nets[k](*inputs)[0]
+            st.synchronize()
+        except BaseException as exc:                             # noqa: BLE001
+            errors.append(exc)
+
+    before = _graph_cache.enabled
+    _graph_cache.enabled = False
+    try:
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=180)
+    finally:
+        _graph_cache.enabled = before
     assert not errors and not any(t.is_alive() for t in threads)
     torch.cuda.synchronize()
     for k in range(2):

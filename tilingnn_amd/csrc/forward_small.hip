@@ -1115,6 +1115,22 @@ void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrie
     }
 }
 
+#define TGNN_TRY_SMALL(expr) do { const int rc__ = (expr); if (rc__ != TGNN_OK) return rc__; } while (0)
+
+int spin_kernel_chain(hipStream_t s, void (*launch)(void *ctx, hipStream_t s), void *ctx) {
+    static std::mutex mu;
+    static hipEvent_t last_done[64] = {};
+    int dev = 0;
+    TGNN_CHECK_HIP(hipGetDevice(&dev));
+    TGNN_CHECK_ARG(dev >= 0 && dev < 64, "device index");
+    std::lock_guard<std::mutex> lock(mu);
+    if (!last_done[dev]) TGNN_CHECK_HIP(hipEventCreateWithFlags(&last_done[dev], hipEventDisableTiming));
+    else TGNN_CHECK_HIP(hipStreamWaitEvent(s, last_done[dev], 0));
+    launch(ctx, s);
+    TGNN_CHECK_HIP(hipEventRecord(last_done[dev], s));
+    return TGNN_OK;
+}
+
 // The whole forward behind the pre-pass: x -> probs (stream order)
 int launch_forward_small(const tgnn_model_dims *d, const Params &P, const float *x, float *probs, float *mid, float *a2_0,
                          float *a2_1, const float *wimg, float *pack, const tgnn_graph *graph, double *part, double *part_wide,
@@ -1170,22 +1186,13 @@ int launch_forward_small(const tgnn_model_dims *d, const Params &P, const float 
     const int blocks = (int)((n + 15) / 16);
     static LdsOptIn site;
     TGNN_CHECK_HIP(opt_in_dynamic_lds(forward_layers_small_kernel, (int)kSmallMaxLds, site));
-    // One persistent kernel at a time per device: two of them launched side by side from different streams could each get
-    // half of the CUs and wait for the other half for ever (what a cooperative launch rules out by serialising such kernels).
-    // Every launch waits for the one before it (an event, whichever stream that was on) and leaves its own.  Other PROCESSES
-    // on the same GPU are outside this: they delay the kernel (blocks wait for a CU) but do not depend on it.
-    static std::mutex mu;
-    static hipEvent_t last_done[64] = {};
-    int dev = 0;
-    TGNN_CHECK_HIP(hipGetDevice(&dev));
-    TGNN_CHECK_ARG(dev >= 0 && dev < 64, "device index");
-    {
-        std::lock_guard<std::mutex> lock(mu);
-        if (!last_done[dev]) TGNN_CHECK_HIP(hipEventCreateWithFlags(&last_done[dev], hipEventDisableTiming));
-        else TGNN_CHECK_HIP(hipStreamWaitEvent(s, last_done[dev], 0));
-        forward_layers_small_kernel<<<dim3(blocks), dim3(kSmallThreads), small_lds_bytes(graph->n_types, depth), s>>>(A, R, E);
-        TGNN_CHECK_HIP(hipEventRecord(last_done[dev], s));
-    }
+    // One spin-barrier kernel at a time per device (spin_kernel_chain; the one-launch graph preparation shares the chain).
+    // Other PROCESSES on the same GPU are outside this: they delay the kernel (blocks wait for a CU) but do not depend on it.
+    struct Ctx { SmallArgs *A; SmallRunTab *R; SmallEnds *E; int blocks; size_t lds; } ctx{&A, &R, &E, blocks, small_lds_bytes(graph->n_types, depth)};
+    TGNN_TRY_SMALL(spin_kernel_chain(s, [](void *c, hipStream_t st) {
+        Ctx *x = static_cast<Ctx *>(c);
+        forward_layers_small_kernel<<<dim3(x->blocks), dim3(kSmallThreads), x->lds, st>>>(*x->A, *x->R, *x->E);
+    }, &ctx));
     return TGNN_OK;
 }
 

@@ -1124,7 +1124,17 @@ extern "C" int tgnn_graph_prep_small(const int64_t *adj_edge_index, int64_t n_ad
     const size_t lds = (size_t)(2 * (kSmallPrepMaxNodes + 8) + 2 * kSmallPrepLocal + 64) * sizeof(int);
     static LdsOptIn site;
     TGNN_CHECK_HIP(opt_in_dynamic_lds(graph_prep_small_kernel, (int)lds, site));
-    graph_prep_small_kernel<<<(unsigned)blocks, kSmallPrepThreads, lds, static_cast<hipStream_t>(stream)>>>(A);
+    // the counters are zero on entry whatever a previous call left behind (an aborted launch would otherwise make every
+    // later preparation on this pair hang or pass its barriers early); on the per-device chain of spin-barrier kernels: beside
+    // a persistent forward of another stream / thread neither could get all its blocks resident
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TGNN_CHECK_HIP(hipMemsetAsync(counters, 0, 2 * sizeof(uint32_t), s));
+    struct Ctx { SmallPrepArgs *A; unsigned blocks; size_t lds; } ctx{&A, (unsigned)blocks, lds};
+    const int rc = spin_kernel_chain(s, [](void *c, hipStream_t st) {
+        Ctx *x = static_cast<Ctx *>(c);
+        graph_prep_small_kernel<<<x->blocks, kSmallPrepThreads, x->lds, st>>>(*x->A);
+    }, &ctx);
+    if (rc != TGNN_OK) return rc;
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
 }
