@@ -434,6 +434,14 @@ int tgnn_forward_profiled(const tgnn_model_dims *dims, const void *const *params
                           int32_t use_running_stats, float *probs, void *ws, size_t ws_bytes,
                           tgnn_stream_t stream, float *class_ms_host, int32_t *class_launches_host);
 
+/* The same measurement INSIDE the two-stream forward (the schedule tgnn_forward runs): event pairs on `stream` around the
+ * kernels of the adjacency chain only (TGNN_PROF_NNCONV, TGNN_PROF_MERGE) while the collision chain runs beside them on
+ * stream2 -- the average launch duration the production forward actually sees, contention included.  Train mode. */
+int tgnn_forward_profiled_two_stream(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
+                                     const float *adj_edge_attr, const tgnn_graph *graph, int32_t update_running,
+                                     float *probs, void *ws, size_t ws_bytes, tgnn_stream_t stream, tgnn_stream_t stream2,
+                                     float *class_ms_host, int32_t *class_launches_host);
+
 /* ------------------------------------------------------------------------------------------
  * Multi-GPU helpers: node-range shards exchange boundary rows each layer (RCCL does the moving)
  * ------------------------------------------------------------------------------------------ */

@@ -509,16 +509,21 @@ def test_full_size_layers_against_the_fp64_oracle(dev, big):
         assert v < (TOL_ILL if k == "cconv" else TOL), (k, v)
 
 
-@pytest.mark.parametrize("n,world,seed", [(500_000, 4, 3), (2_000_000, 8, 4)])
-def test_config4_and_config5_shapes(dev, n, world, seed):
-    """BASELINE configs 4 / 5 (500k / 6M over 4 GPUs, 2M / 20M over 8) on the ONE GPU of the test box: the forward runs and
-    is bit-reproducible at that size, NNConv stays linear, and the node-range split the multi-GPU run would use is sound
-    (every shard's halo lies in its neighbouring ranges; rows and edges partition exactly)."""
+# config 4 = 500 000 nodes / 6 000 000 adjacency + 7 500 000 collision edges, tile_count 2 (Fx = 3), 4 GPUs, seed 3;
+#            config 5 = 2 000 000 / 20 000 000 + 25 000 000, tile_count 1 (Fx = 2), 8 GPUs, seed 4
+@pytest.mark.parametrize("n,ea,ec,tile_count,world,seed", [(500_000, 6_000_000, 7_500_000, 2, 4, 3),
+                                                           (2_000_000, 20_000_000, 25_000_000, 1, 8, 4)])
+def test_config4_and_config5_shapes(dev, n, ea, ec, tile_count, world, seed):
+    """BASELINE configs 4 / 5 as SURVEY 8d states them, on the ONE GPU of the test box: the forward runs and is
+    bit-reproducible at that size, NNConv stays linear, and the node-range split the multi-GPU run would use is sound (every
+    shard's halo lies in its neighbouring ranges; rows and edges partition exactly)."""
     from tilingnn_amd.synth import make_super_graph_on_device
-    x, adj, attr, col, _ = make_super_graph_on_device(n, 10 * n, 10 * n // 4 * 5, dev, seed=seed)
-    net, _ = make_net(dev)
+    x, adj, attr, col, _ = make_super_graph_on_device(n, ea, ec, dev, tile_count=tile_count, seed=seed)
+    assert x.shape == (n, tile_count + 1) and adj.shape == (2, ea) and col.shape == (2, ec)
+    fx = tile_count + 1
+    net, _ = make_net(dev, fx=fx)
     p1 = net(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)[0].clone()
-    p2 = make_net(dev)[0](x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)[0]
+    p2 = make_net(dev, fx=fx)[0](x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)[0]
     assert p1.shape == (n, 1) and bool(torch.isfinite(p1).all()) and torch.equal(p1, p2)
     conv = net.brch_1_graph_conv_layers[1].nnConv
     gen = torch.Generator(device=dev).manual_seed(0)
@@ -536,6 +541,38 @@ def test_config4_and_config5_shapes(dev, n, world, seed):
         assert int((owner_dst - owner_src).abs().max()) <= 1
         counts = torch.bincount(owner_dst, minlength=world)
         assert int(counts.sum()) == ei.shape[1] and int(counts.min()) > 0.8 * ei.shape[1] / world
+
+
+def test_config5_greedy_rounds_at_two_million_nodes(dev):
+    """BASELINE config 5's "batched greedy selection": masked rounds of the assembly loop (util/algorithms.py:18-62 of the
+    reference: mask the labelled nodes, re-index the rest -- brick_layout.py:248-286 --, score the sub-layout) at 2 000 000
+    nodes / 20 M + 25 M edges, tile_count 1.  Three rounds with shrinking alive sets: the device compaction is bit-exact
+    against the pinned numpy restatement (oracle/greedy_oracle.py) at that size, and the forward scores every sub-layout."""
+    from oracle import greedy_oracle as go
+    from tilingnn_amd.synth import make_super_graph_on_device
+    from tilingnn_amd.util.algorithms import DeviceLayout, SubLayoutBuilder
+    n, ea, ec = 2_000_000, 20_000_000, 25_000_000
+    x, adj, attr, col, _ = make_super_graph_on_device(n, ea, ec, dev, tile_count=1, seed=4)
+    net, _ = make_net(dev, fx=2)
+    builder = SubLayoutBuilder(DeviceLayout(x, adj, attr, col))
+    xh, adjh, attrh, colh = x.cpu().numpy(), adj.cpu().numpy(), attr.cpu().numpy(), col.cpu().numpy()
+    dummy = np.zeros((ec, 1), dtype=np.float32)
+    rng = np.random.default_rng(5)
+    alive = np.ones(n, dtype=np.int32)
+    for rnd, keep in enumerate((0.8, 0.5, 0.1)):
+        alive &= (rng.uniform(size=n) < keep).astype(np.int32)          # what a round's acceptances and their collisions remove
+        sub = builder.build(torch.from_numpy(alive).to(dev))
+        want = go.compute_sub_layout(xh, adjh, attrh, colh, dummy, np.flatnonzero(alive))
+        n2 = int(want[0].shape[0])
+        assert sub.node_feature.shape[0] == n2 and n2 == int(alive.sum())
+        np.testing.assert_array_equal(sub.inverse_index.cpu().numpy(), want[5])
+        np.testing.assert_array_equal(sub.align_edge_index.cpu().numpy(), want[1])
+        np.testing.assert_array_equal(sub.collide_edge_index.cpu().numpy(), want[3])
+        np.testing.assert_array_equal(sub.align_edge_features.cpu().numpy(), want[2])
+        probs = net(x=sub.node_feature, adj_e_index=sub.align_edge_index, adj_e_features=sub.align_edge_features,
+                    col_e_idx=sub.collide_edge_index)[0]
+        assert probs.shape == (n2, 1) and bool(torch.isfinite(probs).all())
+        print(f"round {rnd}: {n2} nodes, {want[1].shape[1]} + {want[3].shape[1]} edges alive")
 
 
 def test_full_size_forward_runs_and_is_reproducible(dev, big):

@@ -306,7 +306,7 @@ static int launch_nnconv64(const __bf16 *h, int64_t n_src_rows, const int32_t *t
     TGNN_CHECK_HIP(opt_in_dynamic_lds(kern, (int)kMaxLds64, site));
     const int64_t n_tiles = (n_nodes + 15) / 16;
     int64_t blocks = (n_tiles + 3) / 4;
-    const int64_t cap = 256 - 32;                            // (CUs left to the collision chain, as in the fp32 path)
+    const int64_t cap = cus_minus(32);                       // (CUs left to the collision chain, as in the fp32 path)
     if (blocks > cap) blocks = cap;
     if (blocks >= 8) blocks &= ~(int64_t)7;
     if (blocks < 1) blocks = 1;
@@ -765,7 +765,7 @@ static unsigned gin64_agg_blocks(int64_t n) {
 }
 static int gin64_mlp_blocks(int64_t n) {
     int blocks = producer_blocks(n, 16 * kMlp64Waves);
-    if (blocks > 256 - 32) blocks = 256 - 32;
+    if (blocks > cus_minus(32)) blocks = cus_minus(32);
     if (blocks >= 8) blocks &= ~7;
     return blocks;
 }

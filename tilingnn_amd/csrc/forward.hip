@@ -90,8 +90,11 @@ struct Prof {
     std::vector<hipEvent_t> ev;      // pairs
     std::vector<int> slot;
     bool on = false;
+    unsigned class_mask = ~0u;       // two-stream mode: only these classes (main-stream kernels) are bracketed
+    bool two_stream = false, open = false;
     void begin(int sl) {
-        if (!on) return;
+        open = on && ((class_mask >> sl) & 1u);
+        if (!open) return;
         hipEvent_t a, b;
         (void)hipEventCreate(&a);
         (void)hipEventCreate(&b);
@@ -101,8 +104,9 @@ struct Prof {
         slot.push_back(sl);
     }
     void end() {
-        if (!on) return;
+        if (!open) return;
         (void)hipEventRecord(ev.back(), s);
+        open = false;
     }
     void collect(float *ms_out, int32_t *count_out) {
         if (!on) return;
@@ -250,7 +254,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     // (TilinGNN.py:63); the branches meet in the product of :64 only.  With a side stream the whole GIN chain runs
     // free beside the NNConv chain and fills the GPU wherever the latter leaves it idle (1-block BN finalizes, the
     // HBM-bound merge, kernel tails); it is held back only by the two-deep buffers it shares with merge.
-    hipStream_t s2 = prof.on ? nullptr : static_cast<hipStream_t>(sh ? sh->side_stream : stream2);
+    hipStream_t s2 = (prof.on && !prof.two_stream) ? nullptr : static_cast<hipStream_t>(sh ? sh->side_stream : stream2);
     if (s2 == s || (sh && dims->network_width != 32)) s2 = nullptr;
     // Events of the two-chain schedule, per calling thread and device; created once, never destroyed.
     // [0] init done, [1 + i] GIN_i done, [1 + kMaxDepth + i] merge_i done, then: fork at entry, edge weights done
@@ -598,6 +602,22 @@ extern "C" int tgnn_forward_profiled(const tgnn_model_dims *dims, const void *co
     prof.on = true;
     const int rc = forward_impl(dims, params_host, x, adj_edge_attr, graph, update_running, use_running_stats, probs,
                                 ws, ws_bytes, stream, nullptr, prof);
+    prof.collect(class_ms_host, class_launches_host);
+    return rc;
+}
+
+extern "C" int tgnn_forward_profiled_two_stream(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
+                                                const float *adj_edge_attr, const tgnn_graph *graph, int32_t update_running,
+                                                float *probs, void *ws, size_t ws_bytes, tgnn_stream_t stream,
+                                                tgnn_stream_t stream2, float *class_ms_host, int32_t *class_launches_host) {
+    DeviceGuard guard__(stream);
+    TGNN_CHECK_ARG(class_ms_host && class_launches_host, "null profile arrays");
+    Prof prof;
+    prof.on = true;
+    prof.two_stream = true;
+    prof.class_mask = (1u << TGNN_PROF_NNCONV) | (1u << TGNN_PROF_MERGE);   // the adjacency chain: launched on `stream`
+    const int rc = forward_impl(dims, params_host, x, adj_edge_attr, graph, update_running, 0, probs, ws, ws_bytes, stream,
+                                stream2, prof);
     prof.collect(class_ms_host, class_launches_host);
     return rc;
 }

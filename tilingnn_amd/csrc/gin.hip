@@ -364,7 +364,7 @@ extern "C" int tgnn_gin_fwd(const float *a, int64_t lda, const float *in_stat, c
         // one block per CU (the weight prologue is paid once per block), minus a few CUs left to the other chain's small
         // kernels (see launch_cols_t in nnconv_cols.hip)
         constexpr int reserve = 32;
-        if (blocks > 256 - reserve) blocks = 256 - reserve;
+        if (blocks > cus_minus(reserve)) blocks = cus_minus(reserve);
         if (blocks >= 8) blocks &= ~7;
         gin32_mlp_kernel<<<blocks, kMlpThreads, 0, s>>>(z_scratch, w1, b1, w2, b2, w3, b3, n_nodes, act, out,
                                                         bn_partial);
@@ -386,7 +386,7 @@ int launch_gin32_mlp(const float *z, const float *w1, const float *b1, const flo
                      hipStream_t s) {
     int blocks = producer_blocks(n_nodes, 16 * kMlpWaves);
     constexpr int reserve = 32;
-    if (blocks > 256 - reserve) blocks = 256 - reserve;
+    if (blocks > cus_minus(reserve)) blocks = cus_minus(reserve);
     if (blocks >= 8) blocks &= ~7;
     gin32_mlp_kernel<<<blocks, kMlpThreads, 0, s>>>(z, w1, b1, w2, b2, w3, b3, n_nodes, act, out, bn_partial);
     if (n_partials_host) *n_partials_host = blocks;

@@ -332,7 +332,7 @@ static int launch_cols_t(const float *h, int64_t ldh, const int32_t *tile_col_pt
     // 1.43 / 1.36 / 1.35 / 1.39, 100 000 nodes 2.29 / 2.27 / 2.23 / 2.25; the isolated kernel at 100k nodes: 45.7 us on
     // 256 CUs, 47.8 on 224 (6 250 tiles are 7 per SIMD either way), 56.5 on 192, 71.6 on 128.
     constexpr int reserve = 32;
-    const int64_t cap = (256 - reserve) * (int64_t)blocks_per_cu;
+    const int64_t cap = cus_minus(reserve) * (int64_t)blocks_per_cu;
     if (blocks > cap) blocks = cap;
     if (blocks >= 8) blocks &= ~7;
     if (blocks < 1) blocks = 1;

@@ -657,11 +657,8 @@ int launch_nnconv_stream(const void *hs, const float *hs_scale, int64_t n_src_ro
     auto kern = nnconv32_stream_kernel;
     static LdsOptIn site;
     TGNN_CHECK_HIP(opt_in_dynamic_lds(kern, kStLdsBytes, site));
-    int dev = 0, cus = 0;
-    TGNN_CHECK_HIP(hipGetDevice(&dev));
-    TGNN_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int64_t n_tiles = (n_nodes + 15) / 16;
-    int64_t blocks = cus - reserve_cus;
+    int64_t blocks = cus_minus(reserve_cus);
     if (blocks > TGNN_BN_MAX_PARTIALS / 2) blocks = TGNN_BN_MAX_PARTIALS / 2;   // two partial rows per block
     if (blocks > n_tiles) blocks = n_tiles;
     if (blocks >= 8) blocks &= ~7;

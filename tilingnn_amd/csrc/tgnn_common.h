@@ -79,6 +79,26 @@ static inline hipError_t opt_in_dynamic_lds(Kern kern, int bytes, LdsOptIn &site
     return e;
 }
 
+// Compute units of the current device (of the partition, in CPX / NPS modes), cached per device; 256 when the query fails.
+// The producers size their persistent grids as "one block per CU minus a few left to the other chain" with it.
+static inline int device_cus() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int v = cached[dev].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    cached[dev].store(cus, std::memory_order_relaxed);
+    return cus;
+}
+// blocks of a persistent producer: all CUs but `reserve` (never fewer than a quarter of them)
+static inline int cus_minus(int reserve) {
+    const int cus = device_cus();
+    const int left = cus - reserve;
+    return left > cus / 4 ? left : (cus / 4 > 0 ? cus / 4 : 1);
+}
+
 // Carves aligned sub-buffers out of a caller-provided workspace.
 struct Carver {
     char *base;
