@@ -151,6 +151,16 @@ int tgnn_nnconv_mean_cols_fwd(const float *h, int64_t ldh, const int32_t *tile_c
                               const float *bias, int64_t n_nodes, int32_t c, int32_t act, float *out,
                               float *wimg_scratch, double *bn_partial, int32_t *n_partials_host,
                               tgnn_stream_t stream);
+/* The same kernel with the fp16 x 2 split (tgnn_set_split_precision: three matrix terms instead of six) as tgnn_forward runs
+ * it, as one op for tests: the bounds tgnn_forward gets from the kernels that produce h are computed here (largest |h| over
+ * the n_src_rows >= n_nodes rows of h, rows packed: ldh == 32; largest |root|) into bounds_scratch (2 words of device scratch);
+ * max_in_degree >= the layout's largest in-degree (a larger value only lowers the scale: the result must not move).
+ * width 32 only. */
+int tgnn_nnconv_mean_cols_f16_fwd(const float *h, int64_t ldh, int64_t n_src_rows, const int32_t *tile_col_ptr,
+                                  const int32_t *col_meta, const int32_t *col_src, const float *wtab, int32_t n_types,
+                                  const float *root, const float *bias, int64_t n_nodes, int32_t max_in_degree, int32_t act,
+                                  float *out, float *wimg_scratch, uint32_t *bounds_scratch, double *bn_partial,
+                                  int32_t *n_partials_host, tgnn_stream_t stream);
 
 /* The same NNConv as a STREAM of gathered rows through an LDS ring (csrc/nnconv_stream.hip; the throughput kernel, production
  * path of tgnn_forward when the graph carries the structure): message, scatter-mean, update in the reference's order.  Two
@@ -216,6 +226,12 @@ int tgnn_dense_act_slots_fwd(const float *a, int32_t slot_width, int64_t slot_st
                              const float *w, const float *b, int64_t n_rows, int32_t in_dim, int32_t out_dim,
                              int32_t act, float *out, int64_t ldo, double *bn_partial, int32_t *n_partials_host,
                              tgnn_stream_t stream);
+/* The same (no input BatchNorm, slots of 32 channels with packed rows, out_dim >= 64) with the fp16 x 2 split as tgnn_forward runs
+ * it (tgnn_set_split_precision), as one op for tests: the bounds tgnn_forward gets from the kernels that fill the slots are
+ * computed here into bounds_scratch (in_dim / 32 + 1 words of device scratch). */
+int tgnn_dense_act_slots_f16_fwd(const float *a, int32_t slot_width, int64_t slot_stride, const float *w, const float *b,
+                                 int64_t n_rows, int32_t in_dim, int32_t out_dim, int32_t act, float *out, int64_t ldo,
+                                 uint32_t *bounds_scratch, double *bn_partial, int32_t *n_partials_host, tgnn_stream_t stream);
 
 /* Train-mode BatchNorm1d statistics (fact 2 of SURVEY.md: the reference never leaves train mode).
  * mode 0: partials -> stat (+ running stats)      single GPU
@@ -389,6 +405,18 @@ int tgnn_forward_sharded(const tgnn_model_dims *dims, const void *const *params_
 void tgnn_set_small_layout_limit(int64_t n_nodes);
 int64_t tgnn_get_small_layout_limit(void);
 
+/* Split precision of the general schedule's matrix-core kernels (NNConv, the final MLP's first Linear).  Both hold the fp32
+ * operands to fp32-class accuracy on the low-precision matrix instructions of gfx950:
+ *   0: bf16 x 3 -- every operand split exactly into three bf16 pieces, six cross terms;
+ *   1: fp16 x 2 (default) -- operands scaled by a power of two, split into an fp16 pair (2^-22 relative), three cross terms:
+ *      half the matrix cycles.  Needs a bound of every operand: the kernels that write the skip buffer leave the largest
+ *      magnitude of each slot, one small launch per forward those of the weights; the layout's largest in-degree comes from
+ *      the preparation (tgnn_graph.nn_max_in_degree; 0 = unknown: bf16 x 3 runs).  Train-mode BatchNorm, single device or
+ *      the one-all-to-all sharded schedule (every shard scales by its own bounds); eval mode, the all-reduce + all-to-all
+ *      sharded scheme and the per-op entry points stay on bf16 x 3.
+ * Process-wide; returns the previous mode (any other argument: only queries). */
+int32_t tgnn_set_split_precision(int32_t mode);
+
 /* Small layouts (<= tgnn_graph_prep_small_max_nodes() nodes, <= ..._max_edges() edges per set): everything above --
  * tgnn_csr_build of both edge sets (self loops dropped from the collision set), tgnn_edge_type_dedup, the types in CSR
  * order, tgnn_nnconv_cols_build -- in ONE launch (up to 16 resident blocks with grid barriers); every output bit-identical
@@ -407,7 +435,7 @@ int tgnn_graph_prep_small(const int64_t *adj_edge_index, int64_t n_adj_edges, co
                           int32_t *col_slot_src, int32_t *tmp, int32_t *result, uint32_t *counters, tgnn_stream_t stream);
 
 /* The same at any size: one call that queues every launch of the preparation itself (no host round trip in the middle:
- * the column structure reads the type count from the device).  result [32] as above (words 4 and 6 stay 0).  The five
+ * the column structure reads the type count from the device).  result [32] as above (word 6 stays 0).  The five
  * st_* arrays (all or none; sized as for tgnn_nnconv_stream_build) also receive the NNConv stream structure: result[8..10] =
  * that call's result words. */
 size_t tgnn_graph_prep_workspace_bytes(int64_t n_nodes, int64_t n_adj_edges, int64_t n_col_edges, int32_t fe);

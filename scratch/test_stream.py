@@ -23,7 +23,7 @@ def ref64(h, adj, etype, wtab, root, bias, n):
     return torch.where(out >= 0, out, out * 0.01)
 
 
-for n in sizes:
+for n in (sizes if __name__ == "__main__" else []):
     ea = 10 * n
     sg = make_super_graph(n, ea, ea // 4 * 5, tile_count=2, n_edge_types=13, seed=2)
     x, adj, adj_attr, col, _ = sg.to_torch(dev)

@@ -29,3 +29,15 @@ def general_schedule():
         yield
     finally:
         _lib.lib.tgnn_set_small_layout_limit(before)
+
+
+@pytest.fixture
+def bf16x3_split():
+    """The single-device general schedule runs its matrix-core kernels with the fp16 x 2 split (tgnn_set_split_precision), the
+    sharded schedule with bf16 x 3: tests that compare the two at rounding level put both on bf16 x 3."""
+    from tilingnn_amd import _lib
+    before = _lib.lib.tgnn_set_split_precision(0)
+    try:
+        yield
+    finally:
+        _lib.lib.tgnn_set_split_precision(before)

@@ -623,10 +623,13 @@ def test_errors_are_loud(dev):
 
 # ------------------------------------------------------------------------------------------ sharded path on one GPU
 @pytest.mark.parametrize("world", [2, 4])
-def test_sharded_hip_path_matches_unsharded(dev, world, general_schedule):
+def test_sharded_hip_path_matches_unsharded(dev, world, general_schedule, bf16x3_split):
     """tilingnn_amd.dist with the HIP backend, P virtual ranks stepped in lock-step on this one GPU
     (LocalSimComm): same ShardProgram, kernels, halo layout and BN-sum exchange as the RCCL path.
-    A shallow network keeps the comparison out of the chaotic regime; depth 20 is sanity-checked."""
+    A shallow network keeps the comparison out of the chaotic regime; depth 20 is sanity-checked.
+    (The per-op entry points this program is made of split bf16 x 3; the unsharded forward is put on the same split --
+    against its default fp16 x 2, equally close to the oracle, the two differ by 1.2e-5 at depth 3: other roundings
+    through three train-mode BatchNorms.)"""
     from tilingnn_amd import dist as tdist
     from tilingnn_amd.synth import make_super_graph
     sg = make_super_graph(6000, 60000, 75000, tile_count=2, n_edge_types=13, seed=8)
@@ -746,6 +749,46 @@ def test_split_precision_kernels_hold_fp32_accuracy_across_magnitudes(dev, scale
     got, _ = ops.dense_act(mid, w, b, ops.ACT_NONE, slot_major=True)
     want = mid.double().permute(1, 0, 2).reshape(n, 672) @ w.double().t()
     assert orc.rel_max_err(got.cpu(), want.cpu()) < 2e-6
+
+
+@pytest.mark.parametrize("scale_a,scale_w", [(1.0, 1.0), (1e3, 1e-2), (1e-4, 3.0), (2e4, 1e-5)])
+def test_fp16_pair_split_kernels_hold_fp32_accuracy_across_magnitudes(dev, scale_a, scale_w):
+    """The fp16 x 2 kernels tgnn_forward runs by default (tgnn_set_split_precision): operands scaled by powers of two from
+    bounds of their magnitude, split into fp16 pairs, three matrix terms.  Same claim, same gate as bf16 x 3 above: slot-major
+    672 -> 256 (a heavy tail in one slot: the bound is the largest slot's) and the column NNConv against fp64, over 9 orders
+    of magnitude; the NNConv result must not move when the in-degree bound is inflated (a lower scale)."""
+    from tilingnn_amd import ops
+    from tilingnn_amd.synth import make_super_graph
+    gen = torch.Generator().manual_seed(12)
+    for n in (4099, 20000):                                                   # (both row-tile shapes of the kernel)
+        mid = (torch.randn(21, n, 32, generator=gen) * scale_a)
+        mid[7] *= torch.randn(n, 32, generator=gen).abs() * 4                 # one slot with a heavy tail
+        mid = mid.to(dev)
+        w = (torch.randn(256, 672, generator=gen) * scale_w / 672 ** 0.5).to(dev)
+        b = (torch.randn(256, generator=gen) * scale_a * scale_w).to(dev)
+        got, _ = ops.dense_act(mid, w, b, ops.ACT_NONE, slot_major=True, f16_split=True)
+        want = mid.double().permute(1, 0, 2).reshape(n, 672) @ w.double().t() + b.double()
+        assert orc.rel_max_err(got.cpu(), want.cpu()) < 2e-6, n
+    n = 6000
+    sg = make_super_graph(n, 10 * n, 12 * n, tile_count=2, n_edge_types=13, seed=3)
+    x, adj, adj_attr, col, _ = sg.to_torch(dev)
+    g = ops.prepare_graph(n, adj, adj_attr, col)
+    assert g.cols is not None and g.max_in_degree >= 1
+    h = (torch.randn(n, 32, generator=gen) * torch.randn(n, 32, generator=gen) * scale_a).to(dev)   # (as the skip buffer: a product)
+    wtab = torch.rand(g.n_types, 32, 32, generator=gen).to(dev)               # edge-MLP outputs are sigmoids
+    root = (torch.randn(32, 32, generator=gen) * scale_w).to(dev)             # the root matrix is a free parameter
+    bias = (torch.randn(32, generator=gen) * scale_a).to(dev)
+    src, dst = adj[0], adj[1]
+    et = g.edge_type[:adj.shape[1]].long()
+    msg = torch.einsum("ek,eko->eo", h.double()[src], wtab.double()[et])
+    agg = torch.zeros(n, 32, dtype=torch.float64, device=dev).index_add_(0, dst, msg)
+    deg = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, dst, torch.ones_like(dst, dtype=torch.float64))
+    want = agg / deg.clamp(min=1).unsqueeze(1) + h.double() @ root.double() + bias.double()
+    outs = [ops.nnconv_mean(h, g, wtab, root, bias, ops.ACT_NONE, ops.new_partials(32, dev), kernel="cols_f16",
+                            max_in_degree=mul * g.max_in_degree)[0] for mul in (1, 4, 64)]
+    for o in outs:
+        assert orc.rel_max_err(o.cpu(), want.cpu()) < 2e-6
+    assert orc.rel_max_err(outs[1].cpu(), outs[0].cpu()) < 2e-7 and orc.rel_max_err(outs[2].cpu(), outs[0].cpu()) < 5e-7
 
 
 @pytest.mark.parametrize("n_nodes,columns", [(20000, True), (2000, True), (2000, False), (300, False)])

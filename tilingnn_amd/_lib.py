@@ -94,6 +94,7 @@ def _load() -> C.CDLL:
         "tgnn_nnconv_cols_max_types": (i32, []),
         "tgnn_nnconv_weight_image_floats": (sz, [i32]),
         "tgnn_nnconv_mean_cols_fwd": (C.c_int, [p, i64, p, p, p, p, i32, p, p, i64, i32, i32, p, p, p, pi32, p]),
+        "tgnn_nnconv_mean_cols_f16_fwd": (C.c_int, [p, i64, i64, p, p, p, p, i32, p, p, i64, i32, i32, p, p, p, p, pi32, p]),
         "tgnn_nnconv_stream_limits": (None, [pi32, pi32, pi32]),
         "tgnn_nnconv_stream_max_entries": (i64, [i64, i64]),
         "tgnn_nnconv_stream_scan_ws_bytes": (sz, [i64]),
@@ -103,6 +104,7 @@ def _load() -> C.CDLL:
         "tgnn_gin_fwd": (C.c_int, [p, i64, p, p, p, p, p, p, p, p, p, p, i64, i32, i32, p, p, p, pi32, p]),
         "tgnn_dense_act_fwd": (C.c_int, [p, i64, i64, p, p, p, i64, i32, i32, i32, p, i64, p, pi32, p]),
         "tgnn_dense_act_slots_fwd": (C.c_int, [p, i32, i64, p, p, p, i64, i32, i32, i32, p, i64, p, pi32, p]),
+        "tgnn_dense_act_slots_f16_fwd": (C.c_int, [p, i32, i64, p, p, i64, i32, i32, i32, p, i64, p, p, pi32, p]),
         "tgnn_bn_finalize": (C.c_int, [i32, p, i32, p, i32, i64, p, p, f32, f32, p, p, p, p, p]),
         "tgnn_bn_apply": (C.c_int, [p, i64, p, i64, i32, p, i64, p]),
         "tgnn_merge_fwd": (C.c_int, [p, p, p, p, p, i64, i32, p, p, p]),
@@ -127,6 +129,7 @@ def _load() -> C.CDLL:
         "tgnn_graph_prep": (C.c_int, [p, i64, p, i32, p, i64, i64] + [p] * 18 + [sz, p, p]),
         "tgnn_set_small_layout_limit": (None, [i64]),
         "tgnn_get_small_layout_limit": (i64, []),
+        "tgnn_set_split_precision": (i32, [i32]),
         "tgnn_forward_profiled": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), p, p, C.POINTER(Graph), i32,
                                             i32, p, p, sz, p, C.POINTER(C.c_float), pi32]),
         "tgnn_forward_profiled_two_stream": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), p, p, C.POINTER(Graph), i32,
@@ -179,12 +182,12 @@ EXPORTED_SYMBOLS = (
     "tgnn_version", "tgnn_last_error", "tgnn_csr_workspace_bytes", "tgnn_csr_build",
     "tgnn_edge_dedup_workspace_bytes", "tgnn_edge_type_dedup", "tgnn_gather_i32", "tgnn_edge_weight_table",
     "tgnn_nnconv_mean_fwd", "tgnn_nnconv_cols_max_columns", "tgnn_nnconv_cols_workspace_bytes",
-    "tgnn_nnconv_cols_build", "tgnn_nnconv_cols_max_types", "tgnn_nnconv_weight_image_floats", "tgnn_nnconv_mean_cols_fwd",
+    "tgnn_nnconv_cols_build", "tgnn_nnconv_cols_max_types", "tgnn_nnconv_weight_image_floats", "tgnn_nnconv_mean_cols_fwd", "tgnn_nnconv_mean_cols_f16_fwd",
     "tgnn_nnconv_stream_limits", "tgnn_nnconv_stream_max_entries", "tgnn_nnconv_stream_scan_ws_bytes", "tgnn_nnconv_stream_build",
-    "tgnn_nnconv_mean_stream_fwd", "tgnn_nnconv_stream_split_bytes", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_dense_act_slots_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
+    "tgnn_nnconv_mean_stream_fwd", "tgnn_nnconv_stream_split_bytes", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_dense_act_slots_fwd", "tgnn_dense_act_slots_f16_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
     "tgnn_merge_fwd", "tgnn_param_count", "tgnn_param_name", "tgnn_forward_workspace_bytes", "tgnn_forward",
     "tgnn_forward_profiled", "tgnn_forward_profiled_two_stream", "tgnn_graph_prep_small_max_nodes", "tgnn_graph_prep_small_max_edges", "tgnn_graph_prep_small_tmp_ints",
-    "tgnn_graph_prep_small", "tgnn_graph_prep_workspace_bytes", "tgnn_graph_prep", "tgnn_set_small_layout_limit", "tgnn_get_small_layout_limit", "tgnn_forward_train", "tgnn_backward_workspace_bytes", "tgnn_backward", "tgnn_forward_sharded_workspace_bytes", "tgnn_forward_sharded",
+    "tgnn_graph_prep_small", "tgnn_graph_prep_workspace_bytes", "tgnn_graph_prep", "tgnn_set_small_layout_limit", "tgnn_get_small_layout_limit", "tgnn_set_split_precision", "tgnn_forward_train", "tgnn_backward_workspace_bytes", "tgnn_backward", "tgnn_forward_sharded_workspace_bytes", "tgnn_forward_sharded",
     "tgnn_rows_gather", "tgnn_rows_scatter", "tgnn_unsupervised_loss_workspace_bytes", "tgnn_unsupervised_loss", "tgnn_solution_score_sums",
     "tgnn_sublayout_workspace_bytes", "tgnn_sublayout_compact",
     "tgnn_transpose", "tgnn_swap_leading", "tgnn_gin_aggregate", "tgnn_sigmoid_bwd", "tgnn_add_into", "tgnn_reduce_workspace_bytes", "tgnn_colsum",

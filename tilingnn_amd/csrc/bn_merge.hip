@@ -101,21 +101,29 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(BnJobs jobs, int mode
     if (tid == 0 && jb.num_batches_tracked) *jb.num_batches_tracked += 1;
 }
 
+// absmax_out (optional, here and in the merge kernels): the largest |out| as float bits, by atomicMax into a word the caller
+// zeroed -- the bound the fp16-pair kernels scale their operand with (tgnn_common.h: split2_f16)
 __global__ void bn_apply_kernel(const float *__restrict__ v, int64_t ldv, const float *__restrict__ stat, int64_t n,
-                                int f, float *__restrict__ out, int64_t ldo) {
+                                int f, float *__restrict__ out, int64_t ldo, unsigned *__restrict__ absmax_out) {
     const int64_t total = n * f;
+    float am = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / f;
         const int c = (int)(i - r * f);
-        out[r * ldo + c] = bn_apply1(v[r * ldv + c], stat[c], stat[f + c], stat[2 * f + c], stat[3 * f + c]);
+        const float o = bn_apply1(v[r * ldv + c], stat[c], stat[f + c], stat[2 * f + c], stat[3 * f + c]);
+        out[r * ldo + c] = o;
+        am = fmaxf(am, fabsf(o));
     }
+    absmax_flush(am, absmax_out);
 }
 
 // out = BN1(a1) * BN2(a2) (+ resid); h2_out = BN2(a2) (optional).  float4 per thread, C % 4 == 0.
 __global__ __launch_bounds__(256) void merge_kernel(const float *__restrict__ a1, const float *__restrict__ st1,
                                                     const float *__restrict__ a2, const float *__restrict__ st2,
                                                     const float *__restrict__ resid, int64_t n4, int c,
-                                                    float *__restrict__ out, float *__restrict__ h2_out) {
+                                                    float *__restrict__ out, float *__restrict__ h2_out,
+                                                    unsigned *__restrict__ absmax_out) {
+    float am = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const int col = (int)((i * 4) % c);
         const float4 x1 = reinterpret_cast<const float4 *>(a1)[i];
@@ -138,8 +146,10 @@ __global__ __launch_bounds__(256) void merge_kernel(const float *__restrict__ a1
             o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
         reinterpret_cast<float4 *>(out)[i] = o;
+        am = absmax4(am, o);
         if (h2_out) reinterpret_cast<float4 *>(h2_out)[i] = y2;
     }
+    absmax_flush(am, absmax_out);
 }
 
 // merge with the FIRST BatchNorm's statistics taken straight from the producer's partial rows: every block repeats
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(256) void merge_kernel(const float *__restrict__ a1
 __global__ __launch_bounds__(256) void merge_bn1_kernel(const float *__restrict__ a1, BnJob j1, int64_t n_total, float eps,
                                                         float momentum, const float *__restrict__ a2,
                                                         const float *__restrict__ st2, const float *__restrict__ resid,
-                                                        int64_t n4, float *__restrict__ out) {
+                                                        int64_t n4, float *__restrict__ out, unsigned *__restrict__ absmax_out) {
     constexpr int c = 32, two_f = 64, groups = 16;
     __shared__ double red[groups * two_f];
     __shared__ double tot[two_f];
@@ -221,6 +231,7 @@ __global__ __launch_bounds__(256) void merge_bn1_kernel(const float *__restrict_
         }
     }
     __syncthreads();
+    float am = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + tid; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const int col = (int)((i * 4) % c);
         const float4 x1 = reinterpret_cast<const float4 *>(a1)[i];
@@ -239,7 +250,9 @@ __global__ __launch_bounds__(256) void merge_bn1_kernel(const float *__restrict_
             o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
         reinterpret_cast<float4 *>(out)[i] = o;
+        am = absmax4(am, o);
     }
+    absmax_flush(am, absmax_out);
 }
 
 // The same for layouts whose producer emits many partial rows (one per CU: 224 at 100k nodes): 1024 threads per block
@@ -249,7 +262,7 @@ __global__ __launch_bounds__(256) void merge_bn1_kernel(const float *__restrict_
 __global__ __launch_bounds__(1024) void merge_bn1_wide_kernel(const float *__restrict__ a1, BnJob j1, int64_t n_total, float eps,
                                                               float momentum, const float *__restrict__ a2,
                                                               const float *__restrict__ st2, const float *__restrict__ resid,
-                                                              int64_t n4, float *__restrict__ out) {
+                                                              int64_t n4, float *__restrict__ out, unsigned *__restrict__ absmax_out) {
     constexpr int c = 32, two_f = 64, groups = 16;
     __shared__ double red[groups * two_f];
     __shared__ double tot[two_f];
@@ -324,6 +337,7 @@ __global__ __launch_bounds__(1024) void merge_bn1_wide_kernel(const float *__res
     const float4 g1 = *reinterpret_cast<const float4 *>(st1 + 2 * c + col), b1 = *reinterpret_cast<const float4 *>(st1 + 3 * c + col);
     const float4 m2h = *reinterpret_cast<const float4 *>(st2s + col), m2l = *reinterpret_cast<const float4 *>(st2s + c + col);
     const float4 g2 = *reinterpret_cast<const float4 *>(st2s + 2 * c + col), b2 = *reinterpret_cast<const float4 *>(st2s + 3 * c + col);
+    float am = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + tid; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 x1 = reinterpret_cast<const float4 *>(a1)[i];
         const float4 x2 = reinterpret_cast<const float4 *>(a2)[i];
@@ -337,7 +351,9 @@ __global__ __launch_bounds__(1024) void merge_bn1_wide_kernel(const float *__res
             o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
         reinterpret_cast<float4 *>(out)[i] = o;
+        am = absmax4(am, o);
     }
+    absmax_flush(am, absmax_out);
 }
 
 __global__ void rows_gather_kernel(const float *__restrict__ src, int64_t ld, const int *__restrict__ idx, int64_t n_idx,
@@ -575,17 +591,27 @@ void launch_shard_sum_peers(const double *peer_sums, const double *own, int worl
 }
 
 void launch_merge_bn1(const float *a1, const BnJob &j1, int64_t n_total, float eps, float momentum, const float *a2,
-                      const float *stat2, const float *resid, int64_t n_nodes, float *out, hipStream_t s) {
+                      const float *stat2, const float *resid, int64_t n_nodes, float *out, hipStream_t s, unsigned *absmax_out) {
     const int64_t n4 = n_nodes * 32 / 4;
     if (j1.n_partials > 128) {
         int64_t blocks = (n4 + 1023) / 1024;
         if (blocks > 256) blocks = 256;
-        merge_bn1_wide_kernel<<<(unsigned)blocks, 1024, 0, s>>>(a1, j1, n_total, eps, momentum, a2, stat2, resid, n4, out);
+        merge_bn1_wide_kernel<<<(unsigned)blocks, 1024, 0, s>>>(a1, j1, n_total, eps, momentum, a2, stat2, resid, n4, out, absmax_out);
         return;
     }
     int64_t blocks = (n4 + 255) / 256;
     if (blocks > 256) blocks = 256;          // every block repeats the statistics reduction
-    merge_bn1_kernel<<<(unsigned)blocks, 256, 0, s>>>(a1, j1, n_total, eps, momentum, a2, stat2, resid, n4, out);
+    merge_bn1_kernel<<<(unsigned)blocks, 256, 0, s>>>(a1, j1, n_total, eps, momentum, a2, stat2, resid, n4, out, absmax_out);
+}
+
+void launch_merge(const float *a1, const float *stat1, const float *a2, const float *stat2, const float *resid, int64_t n_nodes,
+                  int c, float *out, float *h2_out, unsigned *absmax_out, hipStream_t s) {
+    const int64_t n4 = n_nodes * c / 4;
+    merge_kernel<<<ew_grid(n4, absmax_out ? 512 : 256 * 8), 256, 0, s>>>(a1, stat1, a2, stat2, resid, n4, c, out, h2_out, absmax_out);
+}
+void launch_bn_apply(const float *v, int64_t ldv, const float *stat, int64_t n_rows, int f, float *out, int64_t ldo,
+                     unsigned *absmax_out, hipStream_t s) {
+    bn_apply_kernel<<<ew_grid(n_rows * f, absmax_out ? 512 : 256 * 8), 256, 0, s>>>(v, ldv, stat, n_rows, f, out, ldo, absmax_out);
 }
 
 void launch_bn_finalize(const BnJobs &jobs, int n_jobs, int mode, int f, int64_t n_total, float eps, float momentum,
@@ -622,7 +648,7 @@ extern "C" int tgnn_bn_apply(const float *v, int64_t ldv, const float *stat, int
     DeviceGuard guard__(stream);
     if (n_rows <= 0) return TGNN_OK;
     TGNN_CHECK_ARG(v && stat && out && f >= 1 && ldv >= f && ldo >= f, "arguments");
-    bn_apply_kernel<<<ew_grid(n_rows * f), 256, 0, static_cast<hipStream_t>(stream)>>>(v, ldv, stat, n_rows, f, out, ldo);
+    launch_bn_apply(v, ldv, stat, n_rows, f, out, ldo, nullptr, static_cast<hipStream_t>(stream));
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
 }
@@ -636,8 +662,7 @@ extern "C" int tgnn_merge_fwd(const float *a1, const float *stat1, const float *
     TGNN_CHECK_ARG(c >= 4 && c % 4 == 0, "width must be a multiple of 4");
     TGNN_CHECK_ARG(((uintptr_t)a1 | (uintptr_t)a2 | (uintptr_t)out | (uintptr_t)resid | (uintptr_t)h2_out |
                     (uintptr_t)stat1 | (uintptr_t)stat2) % 16 == 0, "pointers must be 16-byte aligned");
-    const int64_t n4 = n_nodes * c / 4;
-    merge_kernel<<<ew_grid(n4), 256, 0, static_cast<hipStream_t>(stream)>>>(a1, stat1, a2, stat2, resid, n4, c, out, h2_out);
+    launch_merge(a1, stat1, a2, stat2, resid, n_nodes, c, out, h2_out, nullptr, static_cast<hipStream_t>(stream));
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
 }

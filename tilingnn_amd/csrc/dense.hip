@@ -261,21 +261,52 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8 &hi, bf16x8 &
     split3_trunc(x, hi, mid, lo);           // exact three-way split by truncation, tgnn_common.h
 }
 
-template <int TM, int WN>
+// F16: fp16 x 2 instead (tgnn_common.h: split2_f16) -- three cross terms  hi.hi + hi.lo + lo.hi  on v_mfma_f32_32x32x16_f16,
+// half the matrix cycles and 24 instead of 44 split instructions per 8 elements, where bounds of both operands are at hand:
+// a_max[0 .. n_a_max) / w_max hold max |a| (per slot of the skip buffer, left by the kernels that wrote them) and max |w| as
+// float bits; the operands are scaled by the powers of two that bring the maxima just below 2^15 and the accumulators
+// un-scaled in the epilogue.  Holds a and w to 2^-22 relative (elements below 2^-39 of the maximum: to 2^-39 of it).
+using f16x8 = tgnn_f16x8;
+template <int TM, int WN, bool F16>
 __global__ __launch_bounds__(256, 2) void dense_split_kernel(
     const float *__restrict__ a, int64_t lda, int64_t a_kb_stride, int kps, const float *__restrict__ in_stat,
     const float *__restrict__ w, const float *__restrict__ bias, int64_t n, int in_dim, int out_dim, int act,
-    float *__restrict__ out, int64_t ldo, double *__restrict__ bn_partial) {
+    float *__restrict__ out, int64_t ldo, double *__restrict__ bn_partial, const unsigned *__restrict__ a_max, int n_a_max,
+    const unsigned *__restrict__ w_max, int nbx, int nby) {
     constexpr int WM = 4 / WN;                 // waves along M
     constexpr int BM = WM * TM * 32, BN = WN * 64;
     constexpr int RA = BM * 4 / 256, RB = BN * 4 / 256;   // (row, k-octet) items per thread when staging
+    constexpr int NP = F16 ? 2 : 3;                       // planes
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    __bf16 *As = reinterpret_cast<__bf16 *>(smem_b);                 // [3][BM][40]
-    __bf16 *Bs = As + 3 * BM * kSplitLd;                            // [3][BN][40]
+    __bf16 *As = reinterpret_cast<__bf16 *>(smem_b);                 // [NP][BM][40]  (2-byte elements: bf16 or fp16)
+    __bf16 *Bs = As + NP * BM * kSplitLd;                           // [NP][BN][40]
+    float sa = 1.0f, sw = 1.0f, unscale = 1.0f;
+    if constexpr (F16) {
+        unsigned mb = 0;
+        for (int i = 0; i < n_a_max; ++i) mb = max(mb, a_max[i]);
+        sa = pow2_scale_for(mb, 0);
+        sw = pow2_scale_for(*w_max, 0);
+        unscale = 1.0f / (sa * sw);
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int fi = lane & 31, fg = lane >> 5;
-    const int n0 = blockIdx.y * BN;
+    // 1-D grid, nbx row walkers x nby column blocks: the column blocks of one row tile get work-group ids 8 apart -- the same
+    // XCD (ids go round the 8 XCDs), dispatched back to back -- so that the A tile comes out of HBM once and out of that XCD's
+    // L2 for the others (with the plain (x, y) grid every column block re-read it from HBM: 2 x 269 MB at 100k nodes)
+    int bx, by;
+    {
+        const int id = blockIdx.x;
+        if ((nbx & 7) == 0) {
+            const int g = id / (8 * nby), r = id % (8 * nby);
+            bx = g * 8 + (r & 7);
+            by = r >> 3;
+        } else {
+            bx = id % nbx;
+            by = id / nbx;
+        }
+    }
+    const int n0 = by * BN;
     const int ktiles = in_dim / kBK;
     const int64_t row_tiles = (n + BM - 1) / BM;
 
@@ -315,25 +346,39 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(
                     x[e] = bn_apply1(x[e], in_stat[k + e], in_stat[in_dim + k + e], in_stat[2 * in_dim + k + e],
                                      in_stat[3 * in_dim + k + e]);
             }
-            bf16x8 hi, mid, lo;
-            split3(x, hi, mid, lo);
-            *reinterpret_cast<bf16x8 *>(As + (0 * BM + r) * kSplitLd + 8 * o) = hi;
-            *reinterpret_cast<bf16x8 *>(As + (1 * BM + r) * kSplitLd + 8 * o) = mid;
-            *reinterpret_cast<bf16x8 *>(As + (2 * BM + r) * kSplitLd + 8 * o) = lo;
+            if constexpr (F16) {
+                f16x8 hi, lo;
+                split2_f16(x, sa, hi, lo);
+                *reinterpret_cast<f16x8 *>(As + (0 * BM + r) * kSplitLd + 8 * o) = hi;
+                *reinterpret_cast<f16x8 *>(As + (1 * BM + r) * kSplitLd + 8 * o) = lo;
+            } else {
+                bf16x8 hi, mid, lo;
+                split3(x, hi, mid, lo);
+                *reinterpret_cast<bf16x8 *>(As + (0 * BM + r) * kSplitLd + 8 * o) = hi;
+                *reinterpret_cast<bf16x8 *>(As + (1 * BM + r) * kSplitLd + 8 * o) = mid;
+                *reinterpret_cast<bf16x8 *>(As + (2 * BM + r) * kSplitLd + 8 * o) = lo;
+            }
         }
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
             const int item = tid + 256 * j, r = item >> 2, o = item & 3;
             const float x[8] = {rb[j][0].x, rb[j][0].y, rb[j][0].z, rb[j][0].w, rb[j][1].x, rb[j][1].y, rb[j][1].z, rb[j][1].w};
-            bf16x8 hi, mid, lo;
-            split3(x, hi, mid, lo);
-            *reinterpret_cast<bf16x8 *>(Bs + (0 * BN + r) * kSplitLd + 8 * o) = hi;
-            *reinterpret_cast<bf16x8 *>(Bs + (1 * BN + r) * kSplitLd + 8 * o) = mid;
-            *reinterpret_cast<bf16x8 *>(Bs + (2 * BN + r) * kSplitLd + 8 * o) = lo;
+            if constexpr (F16) {
+                f16x8 hi, lo;
+                split2_f16(x, sw, hi, lo);
+                *reinterpret_cast<f16x8 *>(Bs + (0 * BN + r) * kSplitLd + 8 * o) = hi;
+                *reinterpret_cast<f16x8 *>(Bs + (1 * BN + r) * kSplitLd + 8 * o) = lo;
+            } else {
+                bf16x8 hi, mid, lo;
+                split3(x, hi, mid, lo);
+                *reinterpret_cast<bf16x8 *>(Bs + (0 * BN + r) * kSplitLd + 8 * o) = hi;
+                *reinterpret_cast<bf16x8 *>(Bs + (1 * BN + r) * kSplitLd + 8 * o) = mid;
+                *reinterpret_cast<bf16x8 *>(Bs + (2 * BN + r) * kSplitLd + 8 * o) = lo;
+            }
         }
     };
 
-    for (int64_t rt = blockIdx.x; rt < row_tiles; rt += gridDim.x) {
+    for (int64_t rt = bx; rt < row_tiles; rt += nbx) {
         const int64_t m0 = rt * BM;
         f32x16 acc[TM][2];
 #pragma unroll
@@ -350,17 +395,17 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(
             if (kt + 1 < ktiles) load_tiles(m0, kt + 1);          // lands while the MFMAs run
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {                      // two 16-wide k blocks per tile
-                bf16x8 af[TM][3], bfr[2][3];
+                bf16x8 af[TM][NP], bfr[2][NP];
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
+                    for (int pl = 0; pl < NP; ++pl)
                         af[tm][pl] = *reinterpret_cast<const bf16x8 *>(
                             As + (pl * BM + (wm * TM + tm) * 32 + fi) * kSplitLd + kb * 16 + 8 * fg);
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
+                    for (int pl = 0; pl < NP; ++pl)
                         bfr[tn][pl] = *reinterpret_cast<const bf16x8 *>(
                             Bs + (pl * BN + wn * 64 + tn * 32 + fi) * kSplitLd + kb * 16 + 8 * fg);
 #pragma unroll
@@ -368,9 +413,18 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(
 #pragma unroll
                     for (int tn = 0; tn < 2; ++tn) {
                         f32x16 c = acc[tm][tn];
+                        if constexpr (F16) {
+                            const f16x8 ah = __builtin_bit_cast(f16x8, af[tm][0]), al = __builtin_bit_cast(f16x8, af[tm][NP - 1]);
+                            const f16x8 bh = __builtin_bit_cast(f16x8, bfr[tn][0]), bl = __builtin_bit_cast(f16x8, bfr[tn][NP - 1]);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);   // lo . hi
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);   // hi . lo
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);   // hi . hi
+                            acc[tm][tn] = c;
+                            continue;
+                        }
                         // smallest terms first
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][2], bfr[tn][0], c, 0, 0, 0);   // lo . hi
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][0], bfr[tn][2], c, 0, 0, 0);   // hi . lo
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][NP - 1], bfr[tn][0], c, 0, 0, 0);   // lo . hi
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][0], bfr[tn][NP - 1], c, 0, 0, 0);   // hi . lo
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][1], bfr[tn][1], c, 0, 0, 0);   // mid . mid
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][1], bfr[tn][0], c, 0, 0, 0);   // mid . hi
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][0], bfr[tn][1], c, 0, 0, 0);   // hi . mid
@@ -396,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(
                 for (int r = 0; r < 16; ++r) {
                     const int64_t row = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fg;
                     if (col_ok && row < n) {
-                        const float v = act_apply(acc[tm][tn][r] + b, act);
+                        const float v = act_apply(F16 ? fmaf(acc[tm][tn][r], unscale, b) : acc[tm][tn][r] + b, act);
                         out[row * ldo + col] = v;
                         csum[tn] += (double)v;
                         csq[tn] += (double)v * (double)v;
@@ -424,24 +478,26 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(
                 double tot = 0.0;
 #pragma unroll
                 for (int m = 0; m < WM; ++m) tot += red[(m * 2 + which) * BN + cl];
-                bn_partial[(int64_t)blockIdx.x * 2 * out_dim + (int64_t)which * out_dim + col] = tot;
+                bn_partial[(int64_t)bx * 2 * out_dim + (int64_t)which * out_dim + col] = tot;
             }
         }
     }
 }
 
-template <int TM, int WN>
+template <int TM, int WN, bool F16 = false>
 static void launch_dense_split(int blocks_x, hipStream_t s, const float *a, int64_t lda, int64_t akb, int kps,
                                const float *in_stat, const float *w, const float *b, int64_t n, int in_dim, int out_dim,
-                               int act, float *out, int64_t ldo, double *bn_partial) {
+                               int act, float *out, int64_t ldo, double *bn_partial, const unsigned *a_max = nullptr,
+                               int n_a_max = 0, const unsigned *w_max = nullptr) {
     constexpr int BM = (4 / WN) * TM * 32, BN = WN * 64;
-    size_t lds = (size_t)3 * (BM + BN) * kSplitLd * 2;
+    size_t lds = (size_t)(F16 ? 2 : 3) * (BM + BN) * kSplitLd * 2;
     const size_t red = (size_t)(4 / WN) * 2 * BN * sizeof(double);
     if (red > lds) lds = red;
     static LdsOptIn site;
-    if (lds > 64 * 1024) (void)opt_in_dynamic_lds(dense_split_kernel<TM, WN>, 160 * 1024 - 256, site);
-    dense_split_kernel<TM, WN><<<dim3(blocks_x, (out_dim + BN - 1) / BN), 256, lds, s>>>(
-        a, lda, akb, kps, in_stat, w, b, n, in_dim, out_dim, act, out, ldo, bn_partial);
+    if (lds > 64 * 1024) (void)opt_in_dynamic_lds(dense_split_kernel<TM, WN, F16>, 160 * 1024 - 256, site);
+    const int nby = (out_dim + BN - 1) / BN;
+    dense_split_kernel<TM, WN, F16><<<blocks_x * nby, 256, lds, s>>>(
+        a, lda, akb, kps, in_stat, w, b, n, in_dim, out_dim, act, out, ldo, bn_partial, a_max, n_a_max, w_max, blocks_x, nby);
 }
 
 template <int NT, bool FAST>
@@ -462,7 +518,8 @@ using namespace tgnn;
 
 static int dense_act_impl(const float *a, int64_t lda, int64_t a_kblock_stride, int kps, const float *in_stat,
                           const float *w, const float *b, int64_t n_rows, int32_t in_dim, int32_t out_dim, int32_t act,
-                          float *out, int64_t ldo, double *bn_partial, int32_t *n_partials_host, tgnn_stream_t stream) {
+                          float *out, int64_t ldo, double *bn_partial, int32_t *n_partials_host, tgnn_stream_t stream,
+                          const unsigned *a_max = nullptr, int n_a_max = 0, const unsigned *w_max = nullptr) {
     TGNN_CHECK_ARG(n_rows >= 0 && in_dim >= 1 && out_dim >= 1, "shape");
     TGNN_CHECK_ARG(act >= TGNN_ACT_NONE && act <= TGNN_ACT_SIGMOID, "activation");
     if (n_rows == 0) {
@@ -497,10 +554,20 @@ static int dense_act_impl(const float *a, int64_t lda, int64_t a_kblock_stride, 
         //  per CU -- runs 672 -> 256 in 449 us against 281 us: the kernel lives on a second block covering the first one's
         //  two barriers per k-tile)
         constexpr int small_rows = 16384;
+        const bool f16 = a_max && w_max && n_a_max >= 1 && !in_stat;
         if (out_dim > 64 && n_rows > small_rows) {
             const int bx = row_blocks(128);
-            launch_dense_split<2, 2>(bx, s, a, lda, a_kblock_stride, kps, in_stat, w, b, n_rows, in_dim, out_dim, act, out, ldo,
-                                     bn_partial);
+            if (f16)
+                launch_dense_split<2, 2, true>(bx, s, a, lda, a_kblock_stride, kps, in_stat, w, b, n_rows, in_dim, out_dim, act,
+                                               out, ldo, bn_partial, a_max, n_a_max, w_max);
+            else
+                launch_dense_split<2, 2>(bx, s, a, lda, a_kblock_stride, kps, in_stat, w, b, n_rows, in_dim, out_dim, act, out, ldo,
+                                         bn_partial);
+            if (n_partials_host) *n_partials_host = bx;
+        } else if (f16) {
+            const int bx = row_blocks(128);
+            launch_dense_split<1, 1, true>(bx, s, a, lda, a_kblock_stride, kps, in_stat, w, b, n_rows, in_dim, out_dim, act, out,
+                                           ldo, bn_partial, a_max, n_a_max, w_max);
             if (n_partials_host) *n_partials_host = bx;
         } else {
             const int bx = row_blocks(128);
@@ -559,4 +626,32 @@ extern "C" int tgnn_dense_act_slots_fwd(const float *a, int32_t slot_width, int6
                    "slot-major input: slot width must be a multiple of 32 that divides in_dim");
     return dense_act_impl(a, slot_width, slot_stride, slot_width / 32, in_stat, w, b, n_rows, in_dim, out_dim, act, out, ldo,
                           bn_partial, n_partials_host, stream);
+}
+
+namespace tgnn {
+// tgnn_dense_act_slots_fwd with the operands' bounds (forward.hip: the first Linear of the final MLP over the skip buffer)
+int dense_act_slots_bounded(const float *a, int32_t slot_width, int64_t slot_stride, const float *w, const float *b,
+                            int64_t n_rows, int32_t in_dim, int32_t out_dim, int32_t act, float *out, int64_t ldo,
+                            double *bn_partial, int32_t *n_partials_host, const unsigned *a_max, int n_a_max,
+                            const unsigned *w_max, hipStream_t s) {
+    return dense_act_impl(a, slot_width, slot_stride, slot_width / 32, nullptr, w, b, n_rows, in_dim, out_dim, act, out, ldo,
+                          bn_partial, n_partials_host, s, a_max, n_a_max, w_max);
+}
+}  // namespace tgnn
+
+extern "C" int tgnn_dense_act_slots_f16_fwd(const float *a, int32_t slot_width, int64_t slot_stride, const float *w, const float *b,
+                                            int64_t n_rows, int32_t in_dim, int32_t out_dim, int32_t act, float *out, int64_t ldo,
+                                            uint32_t *bounds_scratch, double *bn_partial, int32_t *n_partials_host,
+                                            tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
+    TGNN_CHECK_ARG(slot_width == 32 && in_dim % 32 == 0 && in_dim >= 32 && out_dim >= 64 && n_rows >= 1, "shape");
+    TGNN_CHECK_ARG(a && w && b && out && bounds_scratch, "null pointer");
+    TGNN_CHECK_ARG(slot_stride % 8 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)w % 16) == 0, "alignment");
+    const int n_slots = in_dim / 32;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TGNN_CHECK_HIP(hipMemsetAsync(bounds_scratch, 0, (size_t)(n_slots + 1) * sizeof(uint32_t), s));
+    for (int k = 0; k < n_slots; ++k) launch_absmax(a + (int64_t)k * slot_stride, n_rows * 32, bounds_scratch + k, s);
+    launch_absmax(w, (int64_t)in_dim * out_dim, bounds_scratch + n_slots, s);
+    return dense_act_slots_bounded(a, slot_width, slot_stride, w, b, n_rows, in_dim, out_dim, act, out, ldo, bn_partial,
+                                   n_partials_host, bounds_scratch, n_slots, bounds_scratch + n_slots, s);
 }

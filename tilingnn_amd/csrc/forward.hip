@@ -80,6 +80,7 @@ struct Workspace {
     float *small_pack;            // small-layout kernel: per-layer parameter packs, its partial rows, its barrier counter
     double *small_part, *small_part_wide, *small_runstat;
     unsigned *small_ctr;
+    unsigned *bounds;            // [0, D]: max |middle[k]| as float bits; [D + 1, 2 D]: max |root_i|; [2 D + 1]: max |final W_0|
     float *stat1, *stat2[2], *stat_i[2], *stat_f[4];
     size_t bytes;
 };
@@ -123,6 +124,7 @@ struct Prof {
 };
 
 static const int kFinalDims[4] = {256, 128, 64, 0};  // TilinGNN.py:46 hidden_layer_dims; [3] = C
+static std::atomic<int> g_split_f16{1};              // tgnn_set_split_precision
 
 // n = rows this device computes; nr >= n = rows of the buffers that are GATHERED from (owned rows, then halo rows
 // of other shards; nr == n on a single device)
@@ -149,6 +151,7 @@ static Workspace carve(const tgnn_model_dims &d, int64_t n, int64_t nr, int32_t 
     w.small_part_wide = cv.take<double>((size_t)2 * 256 * 512);
     w.small_runstat = cv.take<double>((size_t)D * 128);
     w.small_ctr = cv.take<unsigned>(64);
+    w.bounds = cv.take<unsigned>(2 * kMaxDepth + 8);
     w.stat1 = cv.take<float>(4 * c);
     w.stat2[0] = cv.take<float>(4 * c);
     w.stat2[1] = cv.take<float>(4 * c);
@@ -164,6 +167,10 @@ static Workspace carve(const tgnn_model_dims &d, int64_t n, int64_t nr, int32_t 
 using namespace tgnn;
 
 extern "C" int tgnn_version(void) { return TGNN_VERSION; }
+extern "C" int32_t tgnn_set_split_precision(int32_t mode) {
+    if (mode != 0 && mode != 1) return g_split_f16.load();
+    return g_split_f16.exchange(mode);
+}
 extern "C" const char *tgnn_last_error(void) { return g_err; }
 
 extern "C" int32_t tgnn_param_count(const tgnn_model_dims *dims) {
@@ -341,6 +348,23 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     // finished blocks: its init MLP runs beside them
     unsigned *weights_done = (small_teams == 2 && s2 && weights_on_side) ? w.small_ctr + 16 : nullptr;
     if (weights_done) TGNN_CHECK_HIP(hipMemsetAsync(weights_done, 0, 4, s));
+    const int64_t cat_w_floats = (int64_t)c * (D + 1) * kFinalDims[0];
+    // fp16-pair operands (3 matrix terms instead of the 6 of bf16 x 3) wherever a bound of the operand is at hand: the kernels
+    // that write a slot of the skip buffer leave its largest magnitude (w.bounds), one launch up front those of the root
+    // matrices and of the final MLP's first Linear.  General schedule, train-mode BatchNorm; needs the layout's largest
+    // in-degree.  Sharded: with one all-to-all per layer every shard merges its own AND its halo rows itself, so the bound it
+    // leaves covers every row its NNConv gathers (the shards' scales may differ -- powers of two, taken off again: each
+    // shard's results are as accurate as a single device's); the all-reduce + all-to-all scheme stays on bf16 x 3.
+    const bool fused_shard = sh && sh->send_idx_fused && sh->recv_idx_fused && sh->world >= 1 && c == 32;
+    const bool f16 = g_split_f16 && tiled && (!sh || fused_shard) && !small_teams && !use_running_stats &&
+                     graph->nn_max_in_degree >= 1 && D <= kMaxDepth && (cat_w_floats % 4) == 0;
+    unsigned *slot_max = f16 ? w.bounds : nullptr, *root_max = f16 ? w.bounds + D + 1 : nullptr,
+             *dense_max = f16 ? w.bounds + 2 * D + 1 : nullptr;
+    if (f16) {
+        const float *roots[kMaxDepth];
+        for (int i = 0; i < D; ++i) roots[i] = P.f(P.layer(i) + 6);
+        launch_forward_scales(w.bounds, 2 * D + 2, roots, D, root_max, P.f(P.fin(0)), cat_w_floats, dense_max, s);   // (before the fork: both chains see the zeroed words)
+    }
     if (s2 && weights_on_side) {
         TGNN_CHECK_HIP(hipEventRecord(ev[kEvFork], s));     // everything the caller queued on `stream` so far
         TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[kEvFork], 0));
@@ -357,7 +381,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         }
         prof.begin(0);
         launch_edge_weight_table_batched(adj_edge_attr, graph->type_rep_edge, T, fe, layers, D, c, w.wtab, tiled ? roots : nullptr,
-                                         tiled ? w.wimg : nullptr, sw, weights_done);
+                                         tiled ? w.wimg : nullptr, sw, weights_done, root_max);
         prof.end();
     }
     if (small_teams) launch_small_pack(P, D, w.small_pack, w.small_ctr, s);   // on the main stream: it has nothing else to do yet
@@ -384,9 +408,10 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     prof.end();
     TGNN_TRY(finalize1(w.partf, np1, c, P.bn(P.init(1) + 2), w.stat_i[1]));
     prof.begin(1);
-    TGNN_TRY(tgnn_bn_apply(w.a1, c, w.stat_i[1], n, c, w.mid, c, s));  // middle[0] = brch_1 = brch_2 (:55,58)
+    launch_bn_apply(w.a1, c, w.stat_i[1], n, c, w.mid, c, slot_max, s);   // middle[0] = brch_1 = brch_2 (:55,58)
     prof.end();
     TGNN_TRY(exchange(0, nullptr, nullptr));
+    if (f16 && n_halo > 0) launch_absmax(w.mid + (size_t)n * c, n_halo * c, slot_max, s);   // (the halo rows of middle[0])
 
     // ---- main loop (TilinGNN.py:59-71)
     const bool run_stats = update_running || use_running_stats;
@@ -396,7 +421,6 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     };
     // CollConv (:63): input = BN_{i-1}(a2_{i-1}) folded into the gather; layer 0 reads middle[0]
     // one all-to-all per layer instead of all-reduce + all-to-all (see tgnn_shard in tgnn.h)
-    const bool fused_shard = sh && sh->send_idx_fused && sh->recv_idx_fused && sh->world >= 1 && c == 32;
     if (fused_shard) TGNN_CHECK_ARG(sh->rank >= 0 && sh->rank < sh->world && sh->world <= 64, "shard rank / world (<= 64)");
     auto gin_layer = [&](int i, hipStream_t gs) -> int {
         const int b = P.layer(i);
@@ -447,8 +471,9 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         prof.begin(2);
         if (tiled) {
             TGNN_TRY(launch_nnconv_cols(h1, c, graph->nn_tile_col_ptr, graph->nn_col_meta, graph->nn_col_src,
-                                        w.wimg + (size_t)i * (T + 1) * kWtType, T, P.f(b + 7), n, TGNN_ACT_LEAKY_RELU,
-                                        w.a1, w.part1, &np1, s));
+                                        w.wimg + (size_t)i * (T + 1) * (f16 ? kWtTypeF16 : kWtType), T, P.f(b + 7), n,
+                                        TGNN_ACT_LEAKY_RELU, w.a1, w.part1, &np1, s, f16 ? slot_max + i : nullptr,
+                                        f16 ? root_max + i : nullptr, graph->nn_max_in_degree));
         } else {
             TGNN_TRY(tgnn_nnconv_mean_fwd(h1, c, graph->adj_rowptr, graph->adj_src, graph->adj_type,
                                       w.wtab + (size_t)i * T * c * c, T, P.f(b + 6), P.f(b + 7), n, c,
@@ -483,8 +508,12 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
             //  the merge, not behind it)
             if (s2) TGNN_CHECK_HIP(hipEventRecord(ev[1 + kMaxDepth + i], s));
             const float *resid_f = i >= 2 ? w.mid + (size_t)(i - 2) * nr * c : nullptr;
-            TGNN_TRY(tgnn_merge_fwd(w.a1, w.stat1, w.a2[i & 1], w.stat2[i & 1], resid_f, nr, c,
-                                    w.mid + (size_t)(i + 1) * nr * c, nullptr, s));
+            if (f16)
+                launch_merge(w.a1, w.stat1, w.a2[i & 1], w.stat2[i & 1], resid_f, nr, c, w.mid + (size_t)(i + 1) * nr * c, nullptr,
+                             slot_max + i + 1, s);
+            else
+                TGNN_TRY(tgnn_merge_fwd(w.a1, w.stat1, w.a2[i & 1], w.stat2[i & 1], resid_f, nr, c,
+                                        w.mid + (size_t)(i + 1) * nr * c, nullptr, s));
             continue;
         }
         // Few partial rows (small layouts): merge derives the first BatchNorm's record from them itself -- one launch
@@ -522,7 +551,10 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         prof.begin(5);
         if (fused_bn1) {
             launch_merge_bn1(w.a1, bn_job(w.part1, np1, P.bn(b + 8), w.stat1), n, eps, momentum, w.a2[i & 1],
-                             w.stat2[i & 1], resid, n, w.mid + (size_t)(i + 1) * nr * c, s);
+                             w.stat2[i & 1], resid, n, w.mid + (size_t)(i + 1) * nr * c, s, f16 ? slot_max + i + 1 : nullptr);
+        } else if (f16) {
+            launch_merge(w.a1, w.stat1, w.a2[i & 1], w.stat2[i & 1], resid, n, c, w.mid + (size_t)(i + 1) * nr * c, nullptr,
+                         slot_max + i + 1, s);
         } else {
             TGNN_TRY(tgnn_merge_fwd(w.a1, w.stat1, w.a2[i & 1], w.stat2[i & 1], resid, n, c,
                                     w.mid + (size_t)(i + 1) * nr * c, nullptr, s));
@@ -542,8 +574,12 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         if (l == 0) {
             TGNN_CHECK_ARG(c % 32 == 0, "final MLP over the slot-major buffer needs a network_width that is a multiple of 32");
             prof.begin(6);
-            TGNN_TRY(tgnn_dense_act_slots_fwd(w.mid, c, (int64_t)nr * c, nullptr, P.f(pi), P.f(pi + 1), n, cat_dim, fdim[1],
-                                              TGNN_ACT_LEAKY_RELU, fbuf[0], fdim[1], w.partf, &np1, s));
+            if (f16)
+                TGNN_TRY(dense_act_slots_bounded(w.mid, c, (int64_t)nr * c, P.f(pi), P.f(pi + 1), n, cat_dim, fdim[1],
+                                                 TGNN_ACT_LEAKY_RELU, fbuf[0], fdim[1], w.partf, &np1, slot_max, D + 1, dense_max, s));
+            else
+                TGNN_TRY(tgnn_dense_act_slots_fwd(w.mid, c, (int64_t)nr * c, nullptr, P.f(pi), P.f(pi + 1), n, cat_dim, fdim[1],
+                                                  TGNN_ACT_LEAKY_RELU, fbuf[0], fdim[1], w.partf, &np1, s));
             prof.end();
         } else {
             prof.begin(6);

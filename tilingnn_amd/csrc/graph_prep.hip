@@ -1141,8 +1141,20 @@ extern "C" int tgnn_graph_prep_small(const int64_t *adj_edge_index, int64_t n_ad
 
 /* ---- any size: the same preparation as one call that queues every launch itself (no host round trip in the middle: the
  *      column structure reads the type count from the device) ------------------------------------------------------------- */
-__global__ void prep_result_kernel(const int *__restrict__ col_rowptr, int64_t n, int *__restrict__ result) {
-    result[3] = col_rowptr[n];
+// result[3] = collision edges kept; result[4] = the largest adjacency in-degree (the small-layout kernel's limit, the bound of
+// the fp16-pair NNConv operands)
+__global__ __launch_bounds__(256) void prep_result_kernel(const int *__restrict__ col_rowptr, const int *__restrict__ adj_rowptr,
+                                                          int64_t n, int *__restrict__ result) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) result[3] = col_rowptr[n];
+    int md = 0;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256)
+        md = max(md, adj_rowptr[r + 1] - adj_rowptr[r]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) md = max(md, __shfl_xor(md, d, 64));
+    __shared__ int wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = md;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(result + 4, max(max(wm[0], wm[1]), max(wm[2], wm[3])));
 }
 
 extern "C" size_t tgnn_graph_prep_workspace_bytes(int64_t n_nodes, int64_t n_adj_edges, int64_t n_col_edges, int32_t fe) {
@@ -1182,7 +1194,10 @@ extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edge
         rc = tgnn_gather_i32(edge_type, n_adj_edges, adj_eid, n_adj_edges, adj_type, stream);
         if (rc != TGNN_OK) return rc;
     }
-    prep_result_kernel<<<1, 1, 0, s>>>(col_rowptr, n_nodes, result);
+    {
+        int64_t rb = (n_nodes + 1023) / 1024;
+        prep_result_kernel<<<(unsigned)(rb > 256 ? 256 : rb), 256, 0, s>>>(col_rowptr, adj_rowptr, n_nodes, result);
+    }
     // column structure with the type count read on the device
     const int64_t nt16 = (n_nodes + kColTileRows - 1) / kColTileRows;
     Carver cc(ws_col, col_b);

@@ -49,15 +49,31 @@ __device__ __forceinline__ void weight_image_put(__bf16 *dst, int r, float x) {
     dst[2 * kWtPlane * 2 + at] = (__bf16)r2;
 }
 
+// the fp16-pair image's slot: the same fragment order, two planes (hi, lo) of the weight times the layer's power of two
+__device__ __forceinline__ void weight_image_put_f16(_Float16 *dst, int r, float xs) {
+    const int k = r >> 5, o = r & 31;
+    const _Float16 h = (_Float16)xs;
+    const int at = (((o >> 4) * 4 + (k >> 3)) * 16 + (o & 15)) * 8 + (k & 7);
+    dst[at] = h;
+    dst[kWtPlane * 2 + at] = (_Float16)(xs - (float)h);
+}
+
 __global__ __launch_bounds__(256) void edge_weight_table_kernel(
     const float *__restrict__ edge_attr, const int *__restrict__ type_rep_edge, int fe, EdgeMlpLayers layers, int cc,
-    float *__restrict__ wtab_all, int n_types, RootPtrs roots, float *__restrict__ wimg_all, unsigned *__restrict__ done_ctr) {
+    float *__restrict__ wtab_all, int n_types, RootPtrs roots, float *__restrict__ wimg_all, unsigned *__restrict__ done_ctr,
+    const unsigned *__restrict__ root_max) {
     // wimg_all != NULL (width 32): the block also writes its type's slice of the matrix-core operand image, and one more
     // block per layer (blockIdx.x == n_types) the root matrix's -- no second launch on the way to the first NNConv
-    __bf16 *img = wimg_all ? reinterpret_cast<__bf16 *>(wimg_all + ((int64_t)blockIdx.y * (n_types + 1) + blockIdx.x) * kWtType) : nullptr;
+    // root_max != NULL: fp16-pair images (two planes, scaled), else bf16 x 3
+    const bool f16 = root_max != nullptr;
+    const float wscale = f16 ? nnconv_weight_scale(root_max[blockIdx.y]) : 1.0f;
+    const int64_t img_at = ((int64_t)blockIdx.y * (n_types + 1) + blockIdx.x) * (f16 ? kWtTypeF16 : kWtType);
+    __bf16 *img = wimg_all ? reinterpret_cast<__bf16 *>(wimg_all + img_at) : nullptr;
+    _Float16 *img16 = reinterpret_cast<_Float16 *>(img);
     if ((int)blockIdx.x == n_types) {
         const float *src = roots.p[blockIdx.y];
-        for (int r = threadIdx.x; r < 1024; r += 256) weight_image_put(img, r, src[r]);
+        if (f16) for (int r = threadIdx.x; r < 1024; r += 256) weight_image_put_f16(img16, r, src[r] * wscale);
+        else for (int r = threadIdx.x; r < 1024; r += 256) weight_image_put(img, r, src[r]);
         if (done_ctr) {                                     // (a consumer on another stream counts the finished blocks)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's stores are in L2 before thread 0 writes L2 back
             __syncthreads();
@@ -105,7 +121,10 @@ __global__ __launch_bounds__(256) void edge_weight_table_kernel(
         }
         const float v = sigmoidf_(acc);
         wtab[(int64_t)t * cc + j] = v;
-        if (img) weight_image_put(img, j, v);
+        if (img) {
+            if (f16) weight_image_put_f16(img16, j, v * wscale);
+            else weight_image_put(img, j, v);
+        }
     }
     if (done_ctr) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -325,9 +344,16 @@ __global__ __launch_bounds__(kNNThreads) void nnconv32_lds_kernel(
 // element k & 7.  grid = (T+1, layers); done once per forward so that every NNConv block fills its LDS with a
 // straight coalesced 16-byte copy.
 __global__ __launch_bounds__(256) void nnconv_weight_image_kernel(const float *__restrict__ wtab_all, RootPtrs roots,
-                                                                  int n_types, float *__restrict__ wimg_all) {
+                                                                  int n_types, float *__restrict__ wimg_all,
+                                                                  const unsigned *__restrict__ root_max) {
     const int t = blockIdx.x, layer = blockIdx.y;
     const float *src = t < n_types ? wtab_all + ((int64_t)layer * n_types + t) * 1024 : roots.p[layer];
+    if (root_max) {                                           // fp16-pair image
+        const float wscale = nnconv_weight_scale(root_max[layer]);
+        _Float16 *dst = reinterpret_cast<_Float16 *>(wimg_all + ((int64_t)layer * (n_types + 1) + t) * kWtTypeF16);
+        for (int r = threadIdx.x; r < 1024; r += 256) weight_image_put_f16(dst, r, src[r] * wscale);
+        return;
+    }
     __bf16 *dst = reinterpret_cast<__bf16 *>(wimg_all + ((int64_t)layer * (n_types + 1) + t) * kWtType);
     for (int r = threadIdx.x; r < 1024; r += 256) weight_image_put(dst, r, src[r]);
 }
@@ -393,13 +419,42 @@ constexpr size_t kMaxDynLds = 160 * 1024 - 256;
 
 void launch_edge_weight_table_batched(const float *edge_attr, const int *type_rep_edge, int n_types, int fe,
                                       const EdgeMlpLayers &layers, int depth, int c, float *wtab, const float *const *roots,
-                                      float *wimg_all, hipStream_t s, unsigned *done_ctr) {
+                                      float *wimg_all, hipStream_t s, unsigned *done_ctr, const unsigned *root_max) {
     RootPtrs rp{};
     const bool image = wimg_all && roots && c == 32;
     if (image)
         for (int i = 0; i < depth; ++i) rp.p[i] = roots[i];
     edge_weight_table_kernel<<<dim3(n_types + (image ? 1 : 0), depth), 256, 0, s>>>(edge_attr, type_rep_edge, fe, layers, c * c, wtab,
-                                                                                  n_types, rp, image ? wimg_all : nullptr, done_ctr);
+                                                                                  n_types, rp, image ? wimg_all : nullptr, done_ctr,
+                                                                                  image ? root_max : nullptr);
+}
+
+// words [0, n_zero) = 0; then block b < depth: max |roots[b]| -> root_max[b]; the other blocks: their share of dense_w -> *dense_max
+__global__ __launch_bounds__(256) void forward_scales_kernel(RootPtrs roots, int depth, unsigned *__restrict__ root_max,
+                                                             const float *__restrict__ dense_w, int64_t dense_n4,
+                                                             unsigned *__restrict__ dense_max) {
+    float m = 0.f;
+    unsigned *dst;
+    if ((int)blockIdx.x < depth) {
+        const float4 v = reinterpret_cast<const float4 *>(roots.p[blockIdx.x])[threadIdx.x];   // 1024 floats
+        m = absmax4(m, v);
+        dst = root_max + blockIdx.x;
+    } else {
+        const int nb = gridDim.x - depth, b = blockIdx.x - depth;
+        for (int64_t i = (int64_t)b * 256 + threadIdx.x; i < dense_n4; i += (int64_t)nb * 256)
+            m = absmax4(m, reinterpret_cast<const float4 *>(dense_w)[i]);
+        dst = dense_max;
+    }
+    absmax_flush(m, dst);
+}
+void launch_forward_scales(unsigned *words, int n_words, const float *const *roots, int depth, unsigned *root_max,
+                           const float *dense_w, int64_t dense_n, unsigned *dense_max, hipStream_t s) {
+    (void)hipMemsetAsync(words, 0, (size_t)n_words * sizeof(unsigned), s);
+    RootPtrs rp{};
+    for (int i = 0; i < depth; ++i) rp.p[i] = roots[i];
+    const int dense_blocks = dense_w ? 32 : 0;
+    if (depth + dense_blocks > 0)
+        forward_scales_kernel<<<depth + dense_blocks, 256, 0, s>>>(rp, depth, root_max, dense_w, dense_n / 4, dense_max);
 }
 
 }  // namespace tgnn
@@ -467,10 +522,10 @@ extern "C" int tgnn_nnconv_mean_fwd(const float *h, int64_t ldh, const int32_t *
 
 namespace tgnn {
 void launch_nnconv_weight_image(const float *wtab_all, const float *const *roots, int n_types, int depth,
-                                float *wimg_all, hipStream_t s) {
+                                float *wimg_all, hipStream_t s, const unsigned *root_max) {
     RootPtrs rp{};
     for (int i = 0; i < depth; ++i) rp.p[i] = roots[i];
-    nnconv_weight_image_kernel<<<dim3(n_types + 1, depth), 256, 0, s>>>(wtab_all, rp, n_types, wimg_all);
+    nnconv_weight_image_kernel<<<dim3(n_types + 1, depth), 256, 0, s>>>(wtab_all, rp, n_types, wimg_all, root_max);
 }
 }  // namespace tgnn
 

@@ -27,6 +27,7 @@ namespace tgnn {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = tgnn_f16x8;
 
 #ifdef TGNN_TIMING
 __device__ unsigned long long g_col_timing[512 * 8 * 8];
@@ -38,14 +39,24 @@ __device__ unsigned long long g_col_timing[512 * 8 * 8];
 constexpr int kColMetaFirst = 1 << 8, kColMetaLast = 1 << 9, kColMetaEnd = 1 << 10, kColMetaSkip = 1 << 11;
 constexpr int kColStage = 16 * 20;         // floats of the per-wave BN staging tile: [16 rows][16 cols], row stride 20
 
-template <int DEPTH, int WAVES, int OCC>
+// F16: the 3-term fp16-pair split instead of the 6-term bf16 x 3 one (tgnn_common.h: split2_f16).  The summed source rows
+// are multiplied by the power of two sx that keeps max_in_degree * max |h| below 2^15 (h_max: the bound the producer of h
+// left as float bits), the image's weights by nnconv_weight_scale(max |root|); both come off again with the 1 / deg.
+template <int DEPTH, int WAVES, int OCC, bool F16>
 __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
     const float *__restrict__ h, int64_t ldh, const int *__restrict__ tile_col_ptr, const int *__restrict__ col_meta,
     const int *__restrict__ col_src, const float *__restrict__ wimg, int n_types, const float *__restrict__ bias,
-    int64_t n, int act, float *__restrict__ out, double *__restrict__ bn_partial) {
+    int64_t n, int act, float *__restrict__ out, double *__restrict__ bn_partial, const unsigned *__restrict__ h_max,
+    const unsigned *__restrict__ root_max, int deg_log2) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *wl = lds;                                        // [(T+1)][3 planes][2 M blocks][16][4] x 8 bf16
-    float *stage = lds + (n_types + 1) * kWtType;           // [WAVES][16][20]
+    constexpr int kTy = F16 ? kWtTypeF16 : kWtType;         // floats of one type's image
+    float *wl = lds;                                        // [(T+1)][3 (2) planes][2 M blocks][16][4] x 8 bf16 (fp16)
+    float *stage = lds + (n_types + 1) * kTy;               // [WAVES][16][20]
+    float sx = 1.0f, unscale = 1.0f;
+    if (F16) {
+        sx = pow2_scale_for(*h_max, deg_log2);
+        unscale = 1.0f / (sx * nnconv_weight_scale(*root_max));   // (powers of two: exact)
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fj = lane & 15, fq = lane >> 4;
     constexpr int kThreads = WAVES * 64;
@@ -57,7 +68,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 #endif
     {   // weight image: straight copy, all loads of a thread issued before the first LDS store
-        const int n4 = (n_types + 1) * kWtType / 4;
+        const int n4 = (n_types + 1) * kTy / 4;
         for (int i = tid; i < n4; i += 4 * kThreads) {
             float4 v[4];
 #pragma unroll
@@ -161,6 +172,19 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
             // Matrix and vector time ADD on this chip, so the matrix cycles saved pay for the 44 split instructions.
             const bool root = t == n_types;                  // wave-uniform
             const float scale = root ? (s >= 0 ? __int_as_float(s) : 0.f) : 1.0f;   // root column: max(deg, 1) in the source slot
+            constexpr int kPl = kWtPlane / 4;                // 16-byte fragments per plane
+            if constexpr (F16) {
+                f16x8 xh, xl;
+                split2_f16(af, scale * sx, xh, xl);
+                const f16x8 *wp = reinterpret_cast<const f16x8 *>(wl + t * kTy) + lane;      // lane order: conflict-free
+                const f16x8 h0 = wp[0], h1 = wp[64], l0 = wp[kPl], l1 = wp[kPl + 64];
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(l0, xh, d0, 0, 0, 0);   // lo . hi
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(l1, xh, d1, 0, 0, 0);
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, xl, d0, 0, 0, 0);   // hi . lo
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, xl, d1, 0, 0, 0);
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, xh, d0, 0, 0, 0);   // hi . hi
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, xh, d1, 0, 0, 0);
+            } else {
             bf16x8 xh, xm, xl;
             {
                 float as[8];
@@ -169,7 +193,6 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
                 split3_trunc(as, xh, xm, xl);
             }
             const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(wl + t * kWtType) + lane;   // lane order: conflict-free
-            constexpr int kPl = kWtPlane / 4;                // 16-byte fragments per plane
             const bf16x8 h0 = wp[0], h1 = wp[64], m0 = wp[kPl], m1 = wp[kPl + 64], l0 = wp[2 * kPl], l1 = wp[2 * kPl + 64];
 #ifdef TGNN_ABL_NOMFMA
             d0[0] += (float)h0[0] * af[0]; d1[0] += (float)h1[0] * af[0];
@@ -187,11 +210,12 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
             d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0, xh, d0, 0, 0, 0);   // hi . hi
             d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, xh, d1, 0, 0, 0);
 #endif
+            }
         }
         TGNN_CT(2)
         if (mu & kColMetaEnd) {
             // lane (fj, fq): row fj of the tile, channels 4 fq .. 4 fq + 3 (de0/dr0) and 16 + the same (de1/dr1)
-            const float inv = valid ? 1.0f / __int_as_float(s) : 0.f;   // root column (always the last): max(deg, 1)
+            const float inv = valid ? unscale / __int_as_float(s) : 0.f;   // root column (always the last): max(deg, 1)
             const int64_t v = ctile * 16 + fj;
             float4 o0, o1;
             o0.x = fmaf(d0[0], inv, bias0.x); o0.y = fmaf(d0[1], inv, bias0.y);
@@ -303,20 +327,21 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
 #endif
 }
 
-static size_t cols_lds_bytes(int n_types, int waves) {
-    size_t a = ((size_t)(n_types + 1) * kWtType + (size_t)waves * kColStage) * sizeof(float);
+static size_t cols_lds_bytes(int n_types, int waves, bool f16 = false) {
+    size_t a = ((size_t)(n_types + 1) * (f16 ? kWtTypeF16 : kWtType) + (size_t)waves * kColStage) * sizeof(float);
     const size_t b = (size_t)waves * 64 * 4 * sizeof(double);
     return a > b ? a : b;
 }
 
 constexpr size_t kColsMaxLds = 160 * 1024 - 256;
 
-template <int DEPTH, int WAVES, int OCC>
+template <int DEPTH, int WAVES, int OCC, bool F16 = false>
 static int launch_cols_t(const float *h, int64_t ldh, const int32_t *tile_col_ptr, const int32_t *col_meta,
                          const int32_t *col_src, const float *wimg, int32_t n_types, const float *bias,
                          int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
-                         int blocks_per_cu, hipStream_t s) {
-    auto kern = nnconv32_cols_kernel<DEPTH, WAVES, OCC>;
+                         int blocks_per_cu, hipStream_t s, const unsigned *h_max = nullptr, const unsigned *root_max = nullptr,
+                         int deg_log2 = 0) {
+    auto kern = nnconv32_cols_kernel<DEPTH, WAVES, OCC, F16>;
     // the opt-in to > 64 KB of dynamic LDS is a per-device attribute of the function: set once per device (idempotent)
     static LdsOptIn site;
     TGNN_CHECK_HIP(opt_in_dynamic_lds(kern, (int)kColsMaxLds, site));
@@ -336,8 +361,8 @@ static int launch_cols_t(const float *h, int64_t ldh, const int32_t *tile_col_pt
     if (blocks > cap) blocks = cap;
     if (blocks >= 8) blocks &= ~7;
     if (blocks < 1) blocks = 1;
-    kern<<<(unsigned)blocks, WAVES * 64, cols_lds_bytes(n_types, WAVES), s>>>(
-        h, ldh, tile_col_ptr, col_meta, col_src, wimg, n_types, bias, n_nodes, act, out, bn_partial);
+    kern<<<(unsigned)blocks, WAVES * 64, cols_lds_bytes(n_types, WAVES, F16), s>>>(
+        h, ldh, tile_col_ptr, col_meta, col_src, wimg, n_types, bias, n_nodes, act, out, bn_partial, h_max, root_max, deg_log2);
     if (n_partials_host) *n_partials_host = (int32_t)blocks;
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
@@ -346,7 +371,15 @@ static int launch_cols_t(const float *h, int64_t ldh, const int32_t *tile_col_pt
 int launch_nnconv_cols(const float *h, int64_t ldh, const int32_t *tile_col_ptr, const int32_t *col_meta,
                        const int32_t *col_src, const float *wimg, int32_t n_types, const float *bias,
                        int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
-                       hipStream_t s) {
+                       hipStream_t s, const unsigned *h_max, const unsigned *root_max, int max_in_degree) {
+    if (h_max && root_max && max_in_degree >= 1) {
+        int deg_log2 = 0;
+        while ((1 << deg_log2) < max_in_degree) ++deg_log2;
+        // (always one 16-wave block per CU: two 8-wave blocks per CU -- they would fit, the fp16 image is 4 KB per type -- spread
+        //  over ALL CUs and leave none to the collision chain's 1-block kernels: BatchNorm finalize 7.8 -> 15.2 us, rocprof)
+        return launch_cols_t<4, 16, 4, true>(h, ldh, tile_col_ptr, col_meta, col_src, wimg, n_types, bias, n_nodes, act, out,
+                                             bn_partial, n_partials_host, 1, s, h_max, root_max, deg_log2);
+    }
     // 16 waves per CU either way: two 8-wave blocks when two 6 KB-per-type weight images fit the LDS (T <= 11), else
     // one 16-wave block.  Measured with the fp32 kernel at N = 100k, T = 13 (us): <depth 4, 16 waves/CU> 55.7 |
     // <16, 8> 66.0 | <8, 8> 64.9 | <16, 4> 85.2 | <32, 4> 90.2
@@ -391,4 +424,31 @@ extern "C" int tgnn_nnconv_mean_cols_fwd(const float *h, int64_t ldh, const int3
     launch_nnconv_weight_image(wtab, &root, n_types, 1, wimg_scratch, s);
     return launch_nnconv_cols(h, ldh, tile_col_ptr, col_meta, col_src, wimg_scratch, n_types, bias, n_nodes, act, out,
                               bn_partial, n_partials_host, s);
+}
+
+extern "C" int tgnn_nnconv_mean_cols_f16_fwd(const float *h, int64_t ldh, int64_t n_src_rows, const int32_t *tile_col_ptr,
+                                             const int32_t *col_meta, const int32_t *col_src, const float *wtab,
+                                             int32_t n_types, const float *root, const float *bias, int64_t n_nodes,
+                                             int32_t max_in_degree, int32_t act, float *out, float *wimg_scratch,
+                                             uint32_t *bounds_scratch, double *bn_partial, int32_t *n_partials_host,
+                                             tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
+    TGNN_CHECK_ARG(n_nodes >= 1 && n_src_rows >= n_nodes && max_in_degree >= 1, "shape");
+    TGNN_CHECK_ARG(act == TGNN_ACT_NONE || act == TGNN_ACT_LEAKY_RELU, "activation");
+    TGNN_CHECK_ARG(h && tile_col_ptr && col_meta && col_src && root && bias && out && wimg_scratch && bounds_scratch, "null pointer");
+    TGNN_CHECK_ARG(n_types == 0 || wtab, "null weight table");
+    TGNN_CHECK_ARG(ldh == 32 && ((uintptr_t)h % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)bias % 16) == 0 &&
+                       ((uintptr_t)wimg_scratch % 16) == 0 && ((uintptr_t)root % 16) == 0, "alignment / packed rows");
+    if (n_types > tgnn_nnconv_cols_max_types()) {
+        set_error("tgnn_nnconv_mean_cols_f16_fwd: %d edge types do not fit the LDS weight image (max %d)", n_types,
+                  tgnn_nnconv_cols_max_types());
+        return TGNN_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // bounds: [0] = max |h| over every row that can be gathered, [1] = max |root|
+    launch_forward_scales(bounds_scratch, 2, &root, 1, bounds_scratch + 1, nullptr, 0, nullptr, s);
+    launch_absmax(h, n_src_rows * 32, bounds_scratch, s);
+    launch_nnconv_weight_image(wtab, &root, n_types, 1, wimg_scratch, s, bounds_scratch + 1);
+    return launch_nnconv_cols(h, ldh, tile_col_ptr, col_meta, col_src, wimg_scratch, n_types, bias, n_nodes, act, out,
+                              bn_partial, n_partials_host, s, bounds_scratch, bounds_scratch + 1, max_in_degree);
 }

@@ -604,9 +604,7 @@ __global__ void absmax_kernel(const float *__restrict__ h, int64_t n4, unsigned 
         const float4 v = reinterpret_cast<const float4 *>(h)[i];
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
-#pragma unroll
-    for (int dl = 1; dl < 64; dl <<= 1) m = fmaxf(m, __shfl_xor(m, dl, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));
+    absmax_flush(m, out_bits);
 }
 __device__ __forceinline__ float st_scale_for(unsigned max_bits) {
     const int e = (int)(max_bits >> 23) & 0xff;              // biased exponent of the largest |h|
@@ -635,6 +633,14 @@ __global__ void split16_kernel(const float *__restrict__ h, int64_t n_rows, cons
         dst[g] = hi;
         dst[4 + g] = lo;
     }
+}
+
+void launch_absmax(const float *h, int64_t n_floats, unsigned *max_bits, hipStream_t s) {
+    const int64_t n4 = n_floats / 4;
+    if (n4 <= 0) return;
+    int64_t g = (n4 + 255) / 256;
+    if (g > 512) g = 512;
+    absmax_kernel<<<(unsigned)g, 256, 0, s>>>(h, n4, max_bits);
 }
 
 int launch_nnconv_split16(const float *h, int64_t n_rows, void *hs, float *scale2, unsigned *max_bits, hipStream_t s) {

@@ -160,6 +160,61 @@ __device__ __forceinline__ void split3_trunc(const float (&x)[8], tgnn_bf16x8 &h
     lo = __builtin_bit_cast(tgnn_bf16x8, pl);
 }
 
+// ------------------------------------------------------------------------------------------
+// fp16 x 2 split precision (the 3-term alternative to bf16 x 3 where a bound on the operand's magnitude is at hand): with a
+// power-of-two scale s such that |s x| < 2^15,   hi = RN16(s x),  lo = RN16(s x - hi)   hold s x to 2^-22 relative (fp16
+// subnormals: 2^-25 absolute, i.e. 2^-39 of the scaled maximum), and  hi.hi + hi.lo + lo.hi  is the product to the same
+// 2^-22 -- three matrix instructions instead of six, 24 vector instructions per 8 elements instead of 44.
+// The bound travels as the BIT PATTERN of max |x| (atomicMax on unsigned: the order of non-negative floats), written by the
+// kernel that produced x.
+// ------------------------------------------------------------------------------------------
+using tgnn_f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+__device__ __forceinline__ void split2_f16(const float (&x)[8], float s, tgnn_f16x8 &hi, tgnn_f16x8 &lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float a = x[j] * s;
+        // the product as ONE fp32 value: left to itself hipcc folds the multiply into the conversions (v_fma_mix) in one place and
+        // not in the other, and where s is not a power of two (the NNConv root column: deg * 2^k) the two roundings of "hi"
+        // then differ by an fp16 ulp now and then -- lo belongs to another hi, 2^-11 off (measured: 5e-5 instead of 2e-7)
+        asm volatile("" : "+v"(a));
+        hi[j] = (_Float16)a;
+        lo[j] = (_Float16)(a - (float)hi[j]);                 // the difference is exact
+    }
+}
+// the power of two s with  s * bound * 2^extra_log2 < 2^15,  bound given as float bits (0, inf, nan -> 1)
+__device__ __host__ __forceinline__ float pow2_scale_for(unsigned bound_bits, int extra_log2) {
+    const int e = (int)((bound_bits >> 23) & 0xffu);         // bound < 2^(e - 126)
+    if (e == 0 || e == 255) return 1.0f;
+    int se = 127 + 15 - (e - 126) - extra_log2;              // biased exponent of s
+    se = se < 1 ? 1 : (se > 254 ? 254 : se);
+    const unsigned b = (unsigned)se << 23;
+    float f;
+    __builtin_memcpy(&f, &b, 4);
+    return f;
+}
+// max of |x| over the BLOCK into a device word holding float bits (nothing when out == NULL; every thread of the block calls).
+// Same-address atomics cost ~5 ns each at the L2 and the waves of an element-wise kernel all finish together: one atomic per
+// wavefront made a 256-block merge 25 us slower, so the block folds its waves through LDS first and thread 0 sends one
+// (fire and forget: reading the word first to skip the atomic put a second L2 round trip on the tail of every block).
+__device__ __forceinline__ void absmax_flush(float m, unsigned *out) {
+    if (!out) return;                                         // (uniform)
+    __shared__ float wave_max[16];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = (blockDim.x + 63) >> 6;
+    if (lane == 0) wave_max[wave] = m;
+    __syncthreads();
+    if (wave == 0) {
+        m = lane < n_waves ? wave_max[lane] : 0.f;
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+        if (lane == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+    }
+}
+__device__ __forceinline__ float absmax4(float m, const float4 &v) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+
 // Number of persistent blocks for a row-parallel producer: also the number of BN partial rows.
 static inline int producer_blocks(int64_t n_rows, int rows_per_block) {
     int64_t nb = (n_rows + rows_per_block - 1) / rows_per_block;
@@ -209,7 +264,13 @@ void launch_bn_finalize(const BnJobs &jobs, int n_jobs, int mode, int f, int64_t
 // merge (width 32) that derives the first BatchNorm's record from its partial rows itself (mode-0 semantics of
 // bn_finalize incl. running-stat update, bit-identical statistics); bn_merge.hip
 void launch_merge_bn1(const float *a1, const BnJob &j1, int64_t n_total, float eps, float momentum, const float *a2,
-                      const float *stat2, const float *resid, int64_t n_nodes, float *out, hipStream_t s);
+                      const float *stat2, const float *resid, int64_t n_nodes, float *out, hipStream_t s,
+                      unsigned *absmax_out = nullptr);
+// tgnn_merge_fwd / tgnn_bn_apply with the optional bound output (largest |out| as float bits, atomicMax into a zeroed word)
+void launch_merge(const float *a1, const float *stat1, const float *a2, const float *stat2, const float *resid, int64_t n_nodes,
+                  int c, float *out, float *h2_out, unsigned *absmax_out, hipStream_t s);
+void launch_bn_apply(const float *v, int64_t ldv, const float *stat, int64_t n_rows, int f, float *out, int64_t ldo,
+                     unsigned *absmax_out, hipStream_t s);
 // sharded forward, one all-to-all per layer (width 32): pack halo rows of both branches + local BN sums, unpack, add
 // the shards' sums in rank order; bn_merge.hip
 void launch_shard_pack(const float *a1, const float *a2, const int *idx, int64_t n_rows, const double *sums, float *out,
@@ -238,16 +299,29 @@ struct EdgeMlpLayers {
 // roots + wimg_all given (width 32): the same launch also writes the NNConv operand images [(T+1)][kWtType] of all layers
 void launch_edge_weight_table_batched(const float *edge_attr, const int *type_rep_edge, int n_types, int fe,
                                       const EdgeMlpLayers &layers, int depth, int c, float *wtab, const float *const *roots,
-                                      float *wimg_all, hipStream_t s, unsigned *done_ctr = nullptr);
+                                      float *wimg_all, hipStream_t s, unsigned *done_ctr = nullptr,
+                                      const unsigned *root_max = nullptr);
+// root_max (device, [depth] words = max |root_i| as float bits, forward_scales below): the images are fp16-pair images
+// [(T+1)][kWtTypeF16] instead.
+// Bounds of a forward's fp16-pair operands in one launch behind a memset: words [0, n_zero) = 0 (the slots' maxima, filled by the
+// producers), root_max[i] = max |roots[i]|, *dense_max = max |dense_w[0 .. dense_n)|
+void launch_forward_scales(unsigned *words, int n_zero, const float *const *roots, int depth, unsigned *root_max,
+                           const float *dense_w, int64_t dense_n, unsigned *dense_max, hipStream_t s);
 // NNConv B-operand weight images [(T+1)][1152] for `depth` layers (roots[i] = layer i's root matrix); nnconv.hip
+// (root_max given -- [depth] words, max |root_i| as float bits: fp16-pair images [(T+1)][kWtTypeF16] instead)
 void launch_nnconv_weight_image(const float *wtab_all, const float *const *roots, int n_types, int depth,
-                                float *wimg_all, hipStream_t s);
+                                float *wimg_all, hipStream_t s, const unsigned *root_max = nullptr);
+// h_max + root_max given (device words, float bits: max |h|, max |root|) with max_in_degree >= 1: wimg is an fp16-pair image and
+// the kernel runs the 3-term fp16 split (operands scaled by powers of two from the bounds); else the bf16 x 3 image / split
 int launch_nnconv_cols(const float *h, int64_t ldh, const int32_t *tile_col_ptr, const int32_t *col_meta,
                        const int32_t *col_src, const float *wimg, int32_t n_types, const float *bias,
                        int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
-                       hipStream_t s);
+                       hipStream_t s, const unsigned *h_max = nullptr, const unsigned *root_max = nullptr,
+                       int max_in_degree = 0);
 // the stream NNConv kernel (nnconv_stream.hip) over rows pre-split into fp16 pairs (launch_nnconv_split16: hs [rows][128 B],
 // hs_scale {s, 1/s}); wtab = one layer's [T][32][32] table; reserve_cus CUs stay free
+// largest |h[0 .. n_floats)| (n_floats % 4 == 0) as float bits, atomicMax into *max_bits; nnconv_stream.hip
+void launch_absmax(const float *h, int64_t n_floats, unsigned *max_bits, hipStream_t s);
 int launch_nnconv_split16(const float *h, int64_t n_rows, void *hs, float *scale2, unsigned *max_bits, hipStream_t s);
 int launch_nnconv_stream(const void *hs, const float *hs_scale, int64_t n_src_rows, const int32_t *tile_ent_ptr,
                          const uint32_t *ent_src, const uint32_t *rowlist, const uint32_t *info, const float *inv_deg,
@@ -259,6 +333,12 @@ int nnconv_stream_build_gated(const int32_t *rowptr, const int32_t *col_src, con
                               int32_t n_types, const int32_t *n_types_dev, const int32_t *gate, int32_t *tile_ent_ptr,
                               uint32_t *ent_src, uint32_t *rowlist, uint32_t *info, float *inv_deg, int32_t *result, void *ws,
                               hipStream_t s);
+// tgnn_dense_act_slots_fwd (no input BatchNorm) with bounds of both operands: a_max[0 .. n_a_max) / w_max = max |a| per slot /
+// max |w| as float bits (device) -> the fp16-pair kernel (dense.hip: dense_split_kernel<.., F16>); dense.hip
+int dense_act_slots_bounded(const float *a, int32_t slot_width, int64_t slot_stride, const float *w, const float *b,
+                            int64_t n_rows, int32_t in_dim, int32_t out_dim, int32_t act, float *out, int64_t ldo,
+                            double *bn_partial, int32_t *n_partials_host, const unsigned *a_max, int n_a_max,
+                            const unsigned *w_max, hipStream_t s);
 // the MLP half of tgnn_gin_fwd (width 32) behind tgnn_gin_aggregate; gin.hip
 int launch_gin32_mlp(const float *z, const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
                      const float *b3, int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
@@ -283,4 +363,16 @@ int launch_forward_small(const tgnn_model_dims *d, const Params &P, const float 
 // (conflict-free: SQ_LDS_BANK_CONFLICT 2.3e6 -> 2.3e5 per launch against the [i][g] order of round 1); 6144 B per type
 constexpr int kWtPlane = 2 * 64 * 4;       // floats (16-byte fragments x 4) per plane
 constexpr int kWtType = 3 * kWtPlane;      // floats per type
+// fp16-pair image (layouts whose largest in-degree is known, single device): [plane 2 (hi, lo)] of the same fragment order,
+// every weight multiplied by the layer's power of two nnconv_weight_scale(max |root|) first; 4096 B per type
+constexpr int kWtTypeF16 = 2 * kWtPlane;
+__device__ __host__ __forceinline__ float nnconv_weight_scale(unsigned root_max_bits) {
+    // the edge-MLP weights are sigmoids (< 1), the root matrix is a free parameter: one scale for both (they share accumulators)
+    float m;
+    __builtin_memcpy(&m, &root_max_bits, 4);
+    m = m > 1.0f ? m : 1.0f;
+    unsigned b;
+    __builtin_memcpy(&b, &m, 4);
+    return pow2_scale_for(b, 0);
+}
 }  // namespace tgnn

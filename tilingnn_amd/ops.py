@@ -308,8 +308,8 @@ def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col
     # (measured at 100k nodes: the collision CSR on a stream of its own beside the adjacency side changes nothing, 0.425 vs
     #  0.427 ms -- the ~38 launches of a preparation are bound by the host's launch path and by returning atomics, not by
     #  idle CUs)
-    # largest adjacency in-degree: only the small-layout kernel asks for it
-    if 0 < n_nodes <= _small_prep_limits()[0]:
+    # largest adjacency in-degree: the small-layout kernel's limit and the bound of the fp16-pair NNConv operands
+    if n_nodes > 0:
         max_deg = (a_rowptr[1:n_nodes + 1] - a_rowptr[:n_nodes]).max().reshape(1).to(torch.int32)
     else:
         max_deg = torch.zeros_like(n_types)
@@ -351,11 +351,12 @@ def edge_weight_table(edge_attr: Tensor, graph: PreparedGraph, w1, b1, w2, b2, w
 
 def nnconv_mean(h: Tensor, graph: PreparedGraph, wtab: Tensor, root: Tensor, bias: Tensor, act: int = ACT_NONE,
                 partials: Optional[Tensor] = None, force_csr_kernel: bool = False,
-                kernel: Optional[str] = None) -> Tuple[Tensor, int]:
+                kernel: Optional[str] = None, max_in_degree: int = 0) -> Tuple[Tensor, int]:
     """NNConv mean: the stream kernel when the graph carries the stream structure (width 32, <= 15 edge types, layouts
     above the small-layout limit), else the matrix-core column kernel when it carries the column structure, else the CSR /
     LDS-weight-table kernel (any type count that fits LDS) or the generic one.  kernel: None = that order, "stream" /
-    "cols" pin one (tests, A/B timing)."""
+    "cols" pin one (tests, A/B timing); "cols_f16" = the column kernel with the fp16 x 2 split as tgnn_forward runs it
+    (max_in_degree: the bound to scale by, default the layout's)."""
     h = _f32c(h, "x")
     c = int(h.shape[1])
     n = graph.n_nodes                      # destination rows; x may carry extra (halo) rows behind them
@@ -376,6 +377,15 @@ def nnconv_mean(h: Tensor, graph: PreparedGraph, wtab: Tensor, root: Tensor, bia
                                               ptr(st.info), ptr(st.inv_deg), ptr(wt), graph.n_types, ptr(_f32c(root, "root")),
                                               ptr(_f32c(bias, "bias")), n, c, act, ptr(out), ptr(split), ptr(partials),
                                               C.byref(npart), _stream(h)))
+    elif kernel == "cols_f16":
+        if tl is None or c != 32:
+            raise ValueError("the fp16-pair column kernel needs the column structure and width 32")
+        wimg = torch.empty(lib.tgnn_nnconv_weight_image_floats(graph.n_types), dtype=torch.float32, device=h.device)
+        bounds = torch.empty(2, dtype=torch.int32, device=h.device)
+        check(lib.tgnn_nnconv_mean_cols_f16_fwd(ptr(h), c, int(h.shape[0]), ptr(tl.tile_col_ptr), ptr(tl.col_meta), ptr(tl.col_src),
+                                                ptr(wt), graph.n_types, ptr(_f32c(root, "root")), ptr(_f32c(bias, "bias")), n,
+                                                max_in_degree if max_in_degree else graph.max_in_degree, act, ptr(out), ptr(wimg),
+                                                ptr(bounds), ptr(partials), C.byref(npart), _stream(h)))
     elif tl is not None and c == 32 and not force_csr_kernel and int(h.shape[0]) * c * 4 < 2 ** 31:
         wimg = torch.empty(lib.tgnn_nnconv_weight_image_floats(graph.n_types), dtype=torch.float32, device=h.device)
         check(lib.tgnn_nnconv_mean_cols_fwd(ptr(h), c, ptr(tl.tile_col_ptr), ptr(tl.col_meta), ptr(tl.col_src), ptr(wt),
@@ -407,10 +417,11 @@ def gin(a: Tensor, graph: PreparedGraph, eps: Tensor, w1, b1, w2, b2, w3, b3, ac
 
 
 def dense_act(a: Tensor, weight: Tensor, bias: Tensor, act: int, in_stat: Optional[Tensor] = None,
-              partials: Optional[Tensor] = None, slot_major: bool = False) -> Tuple[Tensor, int]:
+              partials: Optional[Tensor] = None, slot_major: bool = False, f16_split: bool = False) -> Tuple[Tensor, int]:
     """act(BN_in(a) @ weight.T + bias) for a row-major [N, in] matrix, or (slot_major) for the
     [S, N, C] skip-connection buffer read as the concatenation of its S slots (torch.cat never happens; C a
-    multiple of 32)."""
+    multiple of 32).  f16_split (slot-major, C = 32, no input BatchNorm, >= 64 outputs): the fp16 x 2 split kernel as
+    tgnn_forward runs it."""
     a = _f32c(a, "x")
     if slot_major:
         if a.dim() != 3 or a.shape[2] % 32 != 0:
@@ -422,6 +433,13 @@ def dense_act(a: Tensor, weight: Tensor, bias: Tensor, act: int, in_stat: Option
             raise ValueError(f"Linear expects in_dim {int(weight.shape[1])}, got {k}")      # layers/util.py:16
         out = torch.empty(n, m, dtype=torch.float32, device=a.device)
         npart = C.c_int32(0)
+        if f16_split:
+            if in_stat is not None or cw != 32:
+                raise ValueError("the fp16-pair dense kernel takes 32-channel slots and no input BatchNorm")
+            bounds = torch.empty(int(a.shape[0]) + 1, dtype=torch.int32, device=a.device)
+            check(lib.tgnn_dense_act_slots_f16_fwd(ptr(a), cw, n * cw, ptr(_f32c(weight, "weight")), ptr(_f32c(bias, "bias")), n, k, m,
+                                                   act, ptr(out), m, ptr(bounds), ptr(partials), C.byref(npart), _stream(a)))
+            return out, npart.value
         check(lib.tgnn_dense_act_slots_fwd(ptr(a), cw, n * cw, ptr(in_stat), ptr(_f32c(weight, "weight")),
                                            ptr(_f32c(bias, "bias")), n, k, m, act, ptr(out), m, ptr(partials),
                                            C.byref(npart), _stream(a)))
