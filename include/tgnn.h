@@ -445,6 +445,10 @@ int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edges, const fl
                     int32_t *col_src, int32_t *col_eid, int32_t *tile_col_ptr, int32_t *col_meta, int32_t *col_slot_src,
                     int32_t *st_tile_ent_ptr, uint32_t *st_ent_src, uint32_t *st_rowlist, uint32_t *st_info, float *st_inv_deg,
                     void *ws, size_t ws_bytes, int32_t *result, tgnn_stream_t stream);
+/* (tests) tgnn_graph_prep builds both CSRs through buckets of 512 destination rows sorted in LDS; a bucket with more than `cap`
+ * edges (default and maximum 15 360) takes a slow in-place path.  Sets the threshold (negative: only queries); returns the
+ * previous one. */
+int32_t tgnn_debug_set_csr_bucket_cap(int32_t cap);
 
 /* The same forward with a hipEvent pair around every launch (on `stream`, where the kernels run);
  * synchronises, then ADDS the elapsed milliseconds and launch counts per kernel class into the

@@ -69,6 +69,36 @@ def test_larger_layouts_one_call(dev, monkeypatch, n, ea, ec, t, seed):
     _same(ref, got)
 
 
+def test_buckets_that_do_not_fit_lds_take_the_slow_path(dev, monkeypatch):
+    """tgnn_graph_prep sorts the edges of 512 destination rows at a time in LDS; with the threshold lowered every bucket of this
+    layout goes the in-place way -- same arrays."""
+    from tilingnn_amd import _lib
+    from tilingnn_amd.synth import make_super_graph
+    n = 6000
+    sg = make_super_graph(n, 60000, 75000, tile_count=2, n_edge_types=13, seed=11)
+    x, adj, attr, col, _ = sg.to_torch(dev)
+    before = _lib.lib.tgnn_debug_set_csr_bucket_cap(100)
+    try:
+        _same(*_both(n, adj, attr, col, monkeypatch))
+    finally:
+        _lib.lib.tgnn_debug_set_csr_bucket_cap(before)
+
+
+def test_skewed_in_degrees(dev, monkeypatch):
+    """A few rows that collect thousands of edges each (buckets far above the average), rows without any, self loops in the
+    collision set."""
+    n = 9000
+    rng = np.random.default_rng(5)
+    hubs = rng.integers(0, n, size=6)
+    dst = np.concatenate([rng.integers(0, n, size=60000), np.repeat(hubs, 5000)])
+    src = rng.integers(0, n, size=dst.size)
+    adj = torch.tensor(np.stack([src, dst]), device=dev)
+    col = torch.tensor(np.stack([rng.integers(0, n, size=50000), np.concatenate([rng.integers(0, 64, size=30000),
+                                                                                 rng.integers(0, n, size=20000)])]), device=dev)
+    attr = torch.tensor(rng.integers(0, 2, size=(dst.size, 3)).astype(np.float32), device=dev)
+    _same(*_both(n, adj, attr, col, monkeypatch))
+
+
 def test_self_loops_isolated_rows_and_signed_zeros(dev, monkeypatch):
     n = 40
     rng = np.random.default_rng(0)

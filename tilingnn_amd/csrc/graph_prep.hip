@@ -6,6 +6,8 @@
 // tiling/tile_graph.py:206-207) and PyG's MessagePassing.propagate scatters messages to
 // edge_index[1].  Here the scatter becomes a gather: rows of a destination-sorted CSR, built once
 // per layout and reused by all 20 layers of both branches.
+#include <atomic>
+
 #include "tgnn_common.h"
 
 namespace tgnn {
@@ -844,9 +846,229 @@ static inline uint32_t dedup_table_size(int64_t e) {
     return cap;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Both CSRs of a layout in four kernels and no device-scope returning atomic (tgnn_graph_prep).
+//
+// tgnn_csr_build ranks every edge inside its row with a returning atomicAdd on a global counter; those are served by the
+// memory side of the fabric on this chip (~50 us per 1.25 M), and the pass is followed by a scan, a scatter and a per-row sort:
+// seven launches and ~120 us per edge set at 100k nodes.  Here the edges go through BUCKETS of 512 destination rows:
+//   1. bk_hist:    every block counts its contiguous share of the edges per bucket in LDS          -> hist[set][bucket][block]
+//   2. one exclusive scan over all of hist (both sets): where each (bucket, block) cell's edges go
+//   3. bk_scatter: the same blocks hand their edges out to the cells (LDS counters) as records (edge number, source, row in
+//                  bucket); order inside a cell: whatever the LDS atomics give
+//   4. bk_rows:    one block per bucket counts its rows, scans them (-> rowptr), places the records by row in LDS and sorts
+//                  every row by edge number -- the original order, the one the reference's scatter sees and tgnn_csr_build
+//                  restores -- then writes col_src / col_eid of the bucket in one coalesced sweep.
+// Both edge sets ride in the same launches (blockIdx.y).  Bit-identical to tgnn_csr_build (tests/test_graph_prep_small.py).
+// A bucket with more edges than the LDS arrays hold (very skewed in-degrees) takes a slow in-place path.
+// ------------------------------------------------------------------------------------------
+constexpr int kBkLog = 9, kBkRows = 1 << kBkLog, kBkMaxBuckets = 4096, kBkThreads = 1024;
+constexpr int kBkCap = 15360;                        // records of a bucket sorted in LDS: 2 x 4 B each = 120 KB
+struct BkSet {
+    const int64_t *ei;                               // [2][e]
+    int64_t e;
+    int drop_self;
+    int *rowptr, *col_src, *col_eid, *err_flag;
+    int *rec_eid, *rec_src;
+    unsigned short *rec_row;
+};
+struct BkArgs {
+    BkSet set[2];
+    int64_t n, n_src;
+    int nb, nblk;                                    // buckets, edge blocks
+    int cap;                                         // <= kBkCap (tests lower it to reach the slow path)
+    int *hist;                                       // [2][nb][nblk] + 1
+};
+
+__global__ __launch_bounds__(kBkThreads) void bk_hist_kernel(BkArgs A) {
+    extern __shared__ int bk_h[];
+    const BkSet S = A.set[blockIdx.y];
+    const int tid = threadIdx.x, blk = blockIdx.x;
+    for (int b = tid; b < A.nb; b += kBkThreads) bk_h[b] = 0;
+    __syncthreads();
+    const int64_t i0 = S.e * blk / A.nblk, i1 = S.e * (blk + 1) / A.nblk;
+    for (int64_t i = i0 + tid; i < i1; i += kBkThreads) {
+        const int64_t s = S.ei[i], d = S.ei[S.e + i];
+        if (s < 0 || s >= A.n_src || d < 0 || d >= A.n) {
+            if (S.err_flag) *S.err_flag = 1;
+        } else if (!(S.drop_self && s == d)) {
+            atomicAdd(&bk_h[d >> kBkLog], 1);
+        }
+    }
+    __syncthreads();
+    for (int b = tid; b < A.nb; b += kBkThreads) A.hist[((int64_t)blockIdx.y * A.nb + b) * A.nblk + blk] = bk_h[b];
+    if (blk == 0 && blockIdx.y == 1 && tid == 0) A.hist[(int64_t)2 * A.nb * A.nblk] = 0;
+}
+
+__global__ __launch_bounds__(kBkThreads) void bk_scatter_kernel(BkArgs A) {
+    extern __shared__ int bk_h[];
+    const BkSet S = A.set[blockIdx.y];
+    const int tid = threadIdx.x, blk = blockIdx.x;
+    const int base = A.hist[(int64_t)blockIdx.y * A.nb * A.nblk];             // where this set's records start in the scan
+    for (int b = tid; b < A.nb; b += kBkThreads) bk_h[b] = A.hist[((int64_t)blockIdx.y * A.nb + b) * A.nblk + blk] - base;
+    __syncthreads();
+    const int64_t i0 = S.e * blk / A.nblk, i1 = S.e * (blk + 1) / A.nblk;
+    for (int64_t i = i0 + tid; i < i1; i += kBkThreads) {
+        const int64_t s = S.ei[i], d = S.ei[S.e + i];
+        if (s < 0 || s >= A.n_src || d < 0 || d >= A.n || (S.drop_self && s == d)) continue;
+        const int k = atomicAdd(&bk_h[d >> kBkLog], 1);
+        S.rec_eid[k] = (int)i;
+        S.rec_src[k] = (int)s;
+        S.rec_row[k] = (unsigned short)(d & (kBkRows - 1));
+    }
+}
+
+__global__ __launch_bounds__(kBkThreads) void bk_rows_kernel(BkArgs A) {
+    extern __shared__ int bk_l[];
+    int *cnt = bk_l, *off = bk_l + kBkRows, *wtot = off + kBkRows + 1, *key_s = wtot + 16, *val_s = key_s + kBkCap;
+    const BkSet S = A.set[blockIdx.y];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int base = A.hist[(int64_t)blockIdx.y * A.nb * A.nblk];
+    const int lo = A.hist[((int64_t)blockIdx.y * A.nb + b) * A.nblk] - base;
+    const int hi = A.hist[((int64_t)blockIdx.y * A.nb + b + 1) * A.nblk] - base;   // (the next set's start / the total behind the last)
+    const int m = hi - lo;
+    const bool in_lds = m <= A.cap;                                           // uniform
+    if (tid < kBkRows) cnt[tid] = 0;
+    __syncthreads();
+    // rows' counts
+    if (in_lds) {
+        for (int j = tid; j < m; j += kBkThreads) atomicAdd(&cnt[S.rec_row[lo + j]], 1);
+    } else if (tid < kBkRows) {
+        int c = 0;
+        for (int j = 0; j < m; ++j) c += S.rec_row[lo + j] == tid ? 1 : 0;
+        cnt[tid] = c;
+    }
+    __syncthreads();
+    // exclusive scan of the 512 counts (8 waves)
+    int mine = 0, incl = 0;
+    if (tid < kBkRows) {
+        mine = cnt[tid];
+        incl = wave_inclusive_scan(mine);
+        if ((tid & 63) == 63) wtot[tid >> 6] = incl;
+    }
+    __syncthreads();
+    if (tid < kBkRows) {
+        int woff = 0;
+        for (int w = 0; w < (tid >> 6); ++w) woff += wtot[w];
+        off[tid] = woff + incl - mine;
+        if (tid == kBkRows - 1) off[kBkRows] = woff + incl;
+        const int64_t row = (int64_t)b * kBkRows + tid;
+        if (row < A.n) S.rowptr[row] = lo + off[tid];
+        cnt[tid] = 0;
+    }
+    if (b == A.nb - 1 && tid == 0) S.rowptr[A.n] = hi;
+    __syncthreads();
+    if (in_lds) {
+        for (int j = tid; j < m; j += kBkThreads) {
+            const int r = S.rec_row[lo + j];
+            const int at = off[r] + atomicAdd(&cnt[r], 1);
+            key_s[at] = S.rec_eid[lo + j];
+            val_s[at] = S.rec_src[lo + j];
+        }
+        __syncthreads();
+        if (tid < kBkRows) {                                                   // every row back into edge order
+            const int rb = off[tid], re = off[tid + 1];
+            for (int i = rb + 1; i < re; ++i) {
+                const int key = key_s[i], val = val_s[i];
+                int j = i - 1;
+                while (j >= rb && key_s[j] > key) {
+                    key_s[j + 1] = key_s[j];
+                    val_s[j + 1] = val_s[j];
+                    --j;
+                }
+                key_s[j + 1] = key;
+                val_s[j + 1] = val;
+            }
+        }
+        __syncthreads();
+        for (int j = tid; j < m; j += kBkThreads) {
+            S.col_eid[lo + j] = key_s[j];
+            S.col_src[lo + j] = val_s[j];
+        }
+    } else if (tid < kBkRows) {
+        // too many edges for the LDS arrays: every row's thread walks the bucket's records itself (they lie in the order of the
+        // scatter's atomics; the walk writes them by increasing edge number only after a sort in place)
+        int *ke = S.col_eid + lo + off[tid], *ks = S.col_src + lo + off[tid];
+        int c = 0;
+        for (int j = 0; j < m; ++j)
+            if (S.rec_row[lo + j] == tid) {
+                ke[c] = S.rec_eid[lo + j];
+                ks[c] = S.rec_src[lo + j];
+                ++c;
+            }
+        for (int i = 1; i < c; ++i) {
+            const int key = ke[i], val = ks[i];
+            int j = i - 1;
+            while (j >= 0 && ke[j] > key) {
+                ke[j + 1] = ke[j];
+                ks[j + 1] = ks[j];
+                --j;
+            }
+            ke[j + 1] = key;
+            ks[j + 1] = val;
+        }
+    }
+}
+
+static std::atomic<int> g_bk_cap{kBkCap};
+static int bk_blocks(int64_t e_max) {
+    int64_t nblk = (e_max + 8191) / 8192;
+    return (int)(nblk < 1 ? 1 : (nblk > 256 ? 256 : nblk));
+}
+static size_t bk_workspace_bytes(int64_t n, int64_t ea, int64_t ec) {
+    const int64_t nb = (n + kBkRows - 1) / kBkRows, nblk = bk_blocks(ea > ec ? ea : ec), cells = 2 * nb * nblk + 1;
+    return align_up((size_t)cells * 4, 256) + scan_ws_ints(cells) * 4 + align_up((size_t)(ea > 0 ? ea : 1) * 10, 256) +
+           align_up((size_t)(ec > 0 ? ec : 1) * 10, 256) + 2048;
+}
+static bool bk_fits(int64_t n) { return (n + kBkRows - 1) / kBkRows <= kBkMaxBuckets; }
+
+// adjacency set -> (rowptr / col_src / col_eid / err) a, collision set (self loops dropped) -> c
+static int csr_build_pair_bucketed(const int64_t *adj_ei, int64_t ea, const int64_t *col_ei, int64_t ec, int64_t n, int64_t n_src,
+                                   int *a_rowptr, int *a_src, int *a_eid, int *a_err, int *c_rowptr, int *c_src, int *c_eid,
+                                   int *c_err, void *ws, size_t ws_bytes, hipStream_t s) {
+    BkArgs A{};
+    A.n = n; A.n_src = n_src;
+    A.nb = (int)((n + kBkRows - 1) / kBkRows);
+    A.nblk = bk_blocks(ea > ec ? ea : ec);
+    A.cap = g_bk_cap.load();
+    const int64_t cells = (int64_t)2 * A.nb * A.nblk + 1;
+    Carver cv(ws, ws_bytes);
+    A.hist = cv.take<int>(cells);
+    int *scan_ws = cv.take<int>(scan_ws_ints(cells));
+    const int64_t es[2] = {ea, ec};
+    for (int k = 0; k < 2; ++k) {
+        const int64_t e1 = es[k] > 0 ? es[k] : 1;
+        unsigned char *rec = cv.take<unsigned char>((size_t)e1 * 10);
+        A.set[k].rec_eid = reinterpret_cast<int *>(rec);
+        A.set[k].rec_src = reinterpret_cast<int *>(rec + (size_t)e1 * 4);
+        A.set[k].rec_row = reinterpret_cast<unsigned short *>(rec + (size_t)e1 * 8);
+    }
+    A.set[0].ei = adj_ei; A.set[0].e = ea; A.set[0].drop_self = 0;
+    A.set[0].rowptr = a_rowptr; A.set[0].col_src = a_src; A.set[0].col_eid = a_eid; A.set[0].err_flag = a_err;
+    A.set[1].ei = col_ei; A.set[1].e = ec; A.set[1].drop_self = 1;
+    A.set[1].rowptr = c_rowptr; A.set[1].col_src = c_src; A.set[1].col_eid = c_eid; A.set[1].err_flag = c_err;
+    const size_t lds_h = (size_t)A.nb * sizeof(int);
+    bk_hist_kernel<<<dim3(A.nblk, 2), kBkThreads, lds_h, s>>>(A);
+    exclusive_scan_i32(A.hist, A.hist, cells, scan_ws, s);
+    bk_scatter_kernel<<<dim3(A.nblk, 2), kBkThreads, lds_h, s>>>(A);
+    const size_t lds_r = (size_t)(2 * kBkRows + 1 + 16 + 2 * kBkCap) * sizeof(int);
+    static LdsOptIn site;
+    TGNN_CHECK_HIP(opt_in_dynamic_lds(bk_rows_kernel, (int)lds_r, site));
+    bk_rows_kernel<<<dim3(A.nb, 2), kBkThreads, lds_r, s>>>(A);
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}
+
 }  // namespace tgnn
 
 using namespace tgnn;
+
+extern "C" int32_t tgnn_debug_set_csr_bucket_cap(int32_t cap) {
+    const int prev = g_bk_cap.load();
+    if (cap >= 0) g_bk_cap.store(cap > kBkCap ? kBkCap : cap);
+    return prev;
+}
 
 extern "C" size_t tgnn_csr_workspace_bytes(int64_t n_nodes, int64_t n_edges) {
     return align_up((size_t)(n_nodes + 1) * 4, 256) + align_up((size_t)(n_edges > 0 ? n_edges : 1) * 4, 256) +
@@ -1159,7 +1381,8 @@ __global__ __launch_bounds__(256) void prep_result_kernel(const int *__restrict_
 
 extern "C" size_t tgnn_graph_prep_workspace_bytes(int64_t n_nodes, int64_t n_adj_edges, int64_t n_col_edges, int32_t fe) {
     const int64_t emax = n_adj_edges > n_col_edges ? n_adj_edges : n_col_edges;
-    return align_up(tgnn_csr_workspace_bytes(n_nodes, emax), 256) + align_up(tgnn_edge_dedup_workspace_bytes(n_adj_edges, fe), 256) +
+    return align_up(tgnn_csr_workspace_bytes(n_nodes, emax), 256) + align_up(bk_workspace_bytes(n_nodes, n_adj_edges, n_col_edges), 256) +
+           align_up(tgnn_edge_dedup_workspace_bytes(n_adj_edges, fe), 256) +
            align_up(tgnn_nnconv_cols_workspace_bytes(n_nodes), 256) + align_up(tgnn_nnconv_stream_scan_ws_bytes(n_nodes), 256) + 1024;
 }
 
@@ -1184,10 +1407,20 @@ extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edge
                  col_b = tgnn_nnconv_cols_workspace_bytes(n_nodes);
     void *ws_csr = cv.take<unsigned char>(csr_b), *ws_dd = cv.take<unsigned char>(dd_b), *ws_col = cv.take<unsigned char>(col_b);
     TGNN_CHECK_HIP(hipMemsetAsync(result, 0, 32 * sizeof(int32_t), s));
-    int rc = tgnn_csr_build(adj_edge_index, n_adj_edges, n_nodes, n_nodes, 0, adj_rowptr, adj_src, adj_eid, result + 1, ws_csr, csr_b, stream);
-    if (rc != TGNN_OK) return rc;
-    rc = tgnn_csr_build(col_edge_index, n_col_edges, n_nodes, n_nodes, 1, col_rowptr, col_src, col_eid, result + 2, ws_csr, csr_b, stream);
-    if (rc != TGNN_OK) return rc;
+    int rc;
+    if (bk_fits(n_nodes) && n_adj_edges < (int64_t(1) << 31) - 1 && n_col_edges < (int64_t(1) << 31) - 1) {
+        // both CSRs through 512-row buckets: four kernels + one scan, no device-scope returning atomic
+        const size_t bk_b = bk_workspace_bytes(n_nodes, n_adj_edges, n_col_edges);
+        void *ws_bk = cv.take<unsigned char>(bk_b);
+        rc = csr_build_pair_bucketed(adj_edge_index, n_adj_edges, col_edge_index, n_col_edges, n_nodes, n_nodes, adj_rowptr, adj_src,
+                                     adj_eid, result + 1, col_rowptr, col_src, col_eid, result + 2, ws_bk, bk_b, s);
+        if (rc != TGNN_OK) return rc;
+    } else {
+        rc = tgnn_csr_build(adj_edge_index, n_adj_edges, n_nodes, n_nodes, 0, adj_rowptr, adj_src, adj_eid, result + 1, ws_csr, csr_b, stream);
+        if (rc != TGNN_OK) return rc;
+        rc = tgnn_csr_build(col_edge_index, n_col_edges, n_nodes, n_nodes, 1, col_rowptr, col_src, col_eid, result + 2, ws_csr, csr_b, stream);
+        if (rc != TGNN_OK) return rc;
+    }
     rc = tgnn_edge_type_dedup(adj_edge_attr, n_adj_edges, fe, edge_type, type_rep_edge, result + 0, ws_dd, dd_b, stream);
     if (rc != TGNN_OK) return rc;
     if (n_adj_edges > 0) {
