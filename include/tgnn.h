@@ -435,7 +435,9 @@ int tgnn_graph_prep_small(const int64_t *adj_edge_index, int64_t n_adj_edges, co
                           int32_t *col_slot_src, int32_t *tmp, int32_t *result, uint32_t *counters, tgnn_stream_t stream);
 
 /* The same at any size: one call that queues every launch of the preparation itself (no host round trip in the middle:
- * the column structure reads the type count from the device).  result [32] as above (word 6 stays 0).  The five
+ * the column structure reads the type count from the device).  result [32] as above; word 6 = 1: the layout has more than
+ * 4 096 distinct attribute rows -- more than the one-block numbering of the types takes: edge_type / adj_type / the column
+ * structure hold nothing usable, the caller goes through the separate calls (tgnn_edge_type_dedup has no such limit).  The five
  * st_* arrays (all or none; sized as for tgnn_nnconv_stream_build) also receive the NNConv stream structure: result[8..10] =
  * that call's result words. */
 size_t tgnn_graph_prep_workspace_bytes(int64_t n_nodes, int64_t n_adj_edges, int64_t n_col_edges, int32_t fe);

@@ -131,3 +131,20 @@ def test_many_distinct_rows_fall_back(dev, monkeypatch):
     ref, got = _both(n, adj, attr, col, monkeypatch)
     assert got.n_types == e and got.cols is None
     _same(ref, got)
+
+
+def test_many_distinct_rows_fall_back_above_the_small_limit(dev, monkeypatch):
+    """tgnn_graph_prep numbers the edge types from a list of at most 4 096 distinct rows; beyond that it reports the fallback
+    and prepare_graph goes through the separate calls."""
+    n, e = 6000, 30000
+    rng = np.random.default_rng(2)
+    adj = torch.tensor(rng.integers(0, n, size=(2, e)), device=dev)
+    col = torch.tensor(rng.integers(0, n, size=(2, 5000)), device=dev)
+    attr = torch.tensor(rng.normal(size=(e, 3)).astype(np.float32), device=dev)     # every row distinct
+    ref, got = _both(n, adj, attr, col, monkeypatch)
+    assert got.n_types == e and got.cols is None
+    _same(ref, got)
+    attr2 = torch.tensor(rng.integers(0, 16, size=(e, 3)).astype(np.float32), device=dev)   # 4 096 distinct rows at most: taken
+    ref, got = _both(n, adj, attr2, col, monkeypatch)
+    assert got.n_types <= 4096 and got.n_types > 1000
+    _same(ref, got)

@@ -7,6 +7,7 @@
 // edge_index[1].  Here the scatter becomes a gather: rows of a destination-sorted CSR, built once
 // per layout and reused by all 20 layers of both branches.
 #include <atomic>
+#include <mutex>
 
 #include "tgnn_common.h"
 
@@ -76,9 +77,39 @@ static size_t scan_ws_ints(int64_t n) {
     return total + 128;
 }
 
+// short arrays (<= 32 768 entries): one block, one launch instead of three (each ~5 us of mostly launch latency)
+constexpr int kScanOneThreads = 1024, kScanOneMax = kScanOneThreads * 32;
+__global__ __launch_bounds__(kScanOneThreads) void scan_one_block_kernel(const int *in, int *out, int n) {   // may alias
+    __shared__ int wave_tot[kScanOneThreads / 64];
+    const int tid = threadIdx.x;
+    const int per = (n + kScanOneThreads - 1) / kScanOneThreads;            // <= 32 consecutive entries per thread
+    const int b = tid * per, e = min(b + per, n);
+    int v[32];
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        v[k] = (k < per && b + k < e) ? in[b + k] : 0;
+        sum += v[k];
+    }
+    const int incl = wave_inclusive_scan(sum);
+    if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int w = 0; w < (tid >> 6); ++w) run += wave_tot[w];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        if (k < per && b + k < e) out[b + k] = run;
+        run += v[k];
+    }
+}
+
 // exclusive scan; `in` and `out` may alias.  ws holds scan_ws_ints(n) ints.
 static void exclusive_scan_i32(const int *in, int *out, int64_t n, int *ws, hipStream_t s) {
     if (n <= 0) return;
+    if (n <= kScanOneMax) {
+        scan_one_block_kernel<<<1, kScanOneThreads, 0, s>>>(in, out, (int)n);
+        return;
+    }
     const int64_t nb = (n + kScanTile - 1) / kScanTile;
     int *sums = ws;
     int *sums_scan = ws + align_up((size_t)nb, 64);
@@ -206,10 +237,15 @@ __device__ __forceinline__ bool rows_equal(const float *__restrict__ attr, int f
 // a dozen per block on real layouts -- then probe the global table.  A flat version in which all 1e6 edges
 // probed the global table spent 220-280 us hammering 13 hot slots.
 constexpr int kDedupRows = 256;
+constexpr int kDedupListMax = 4096;                      // distinct rows the list-based numbering of tgnn_graph_prep takes
 constexpr int kDedupLocal = 512;                       // LDS table slots (>= 2 x rows: never full)
 __global__ __launch_bounds__(kDedupRows) void dedup_insert_kernel(const float *__restrict__ attr, int64_t e, int fe,
                                                                   int *__restrict__ table, uint32_t mask,
-                                                                  int *__restrict__ slot_of_edge) {
+                                                                  int *__restrict__ slot_of_edge,
+                                                                  int *__restrict__ rep_cnt = nullptr,
+                                                                  int *__restrict__ rep_slots = nullptr) {
+    // rep_cnt / rep_slots (tgnn_graph_prep): every slot is put on a list by the thread that claims it -- one entry per distinct
+    // row content; *rep_cnt starts at -1 (it lies behind the table, in the same 0xFF fill)
     extern __shared__ uint32_t rows_s[];                 // [256][ld], ld = fe | 1 (odd: conflict-free per-thread rows)
     __shared__ int ltab[kDedupLocal];
     __shared__ int lslot[kDedupRows];                    // global slot found by each block representative
@@ -218,9 +254,16 @@ __global__ __launch_bounds__(kDedupRows) void dedup_insert_kernel(const float *_
         const int64_t n_here = e - base < kDedupRows ? e - base : kDedupRows;
         const int64_t total = n_here * fe;
         __syncthreads();
-        for (int64_t k = tid; k < total; k += kDedupRows) {
-            const int r = (int)(k / fe), c = (int)(k - (int64_t)r * fe);
-            rows_s[r * ld + c] = canon_bits(attr[base * fe + k]);
+        {   // (row, column) of element k = tid + 256 j advance by (256 / fe, 256 % fe): no division per element
+            const int step_r = kDedupRows / fe, step_c = kDedupRows % fe;
+            int r = tid / fe, c = tid % fe;
+            const float *src = attr + base * fe;
+            for (int k = tid; k < (int)total; k += kDedupRows) {
+                rows_s[r * ld + c] = canon_bits(src[k]);
+                r += step_r;
+                c += step_c;
+                if (c >= fe) { c -= fe; ++r; }
+            }
         }
         ltab[tid] = -1;
         ltab[tid + kDedupRows] = -1;
@@ -244,11 +287,11 @@ __global__ __launch_bounds__(kDedupRows) void dedup_insert_kernel(const float *_
                     cur = prev;
                 }
                 bool same = cur == tid;
-                if (!same) {
-                    same = true;
+                if (!same) {                                         // (no early exit: the reads go out back to back)
                     const uint32_t *other = rows_s + cur * ld;
-                    for (int k = 0; k < fe; ++k)
-                        if (other[k] != mine[k]) { same = false; break; }
+                    uint32_t diff = 0;
+                    for (int k = 0; k < fe; ++k) diff |= other[k] ^ mine[k];
+                    same = diff == 0;
                 }
                 if (same) {
                     if (tid < cur) atomicMin(&ltab[sl], tid);
@@ -266,15 +309,24 @@ __global__ __launch_bounds__(kDedupRows) void dedup_insert_kernel(const float *_
                 int cur = __hip_atomic_load(&table[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (cur < 0) {
                     const int prev = atomicCAS(&table[slot], -1, (int)i);
-                    if (prev < 0) break;  // claimed the slot
+                    if (prev < 0) {       // claimed the slot
+                        if (rep_cnt) {
+                            const int k = atomicAdd(rep_cnt, 1) + 1;
+                            if (k < kDedupListMax) rep_slots[k] = (int)slot;
+                        }
+                        break;
+                    }
                     cur = prev;
                 }
                 bool same = cur == (int)i;
                 if (!same) {
-                    same = true;
-                    const float *other = attr + (int64_t)cur * fe;        // a handful of hot rows: L1 / L2 hits
-                    for (int k = 0; k < fe; ++k)
-                        if (canon_bits(other[k]) != mine[k]) { same = false; break; }
+                    // a handful of hot rows: L1 / L2 hits -- all fe loads in flight at once (with an early exit they were a chain of
+                    // fe round trips per probing thread, and this level is the latency of every block)
+                    const float *other = attr + (int64_t)cur * fe;
+                    uint32_t diff = 0;
+#pragma unroll 8
+                    for (int k = 0; k < fe; ++k) diff |= canon_bits(other[k]) ^ mine[k];
+                    same = diff == 0;
                 }
                 if (same) {
                     if ((int)i < cur) atomicMin(&table[slot], (int)i);     // the representative only ever decreases
@@ -291,7 +343,8 @@ __global__ __launch_bounds__(kDedupRows) void dedup_insert_kernel(const float *_
 
 // Wide rows (Fe > 60: the staged tile would not fit 64 KB of LDS): every thread reads its row from HBM.
 __global__ void dedup_insert_direct_kernel(const float *__restrict__ attr, int64_t e, int fe, int *__restrict__ table,
-                                           uint32_t mask, int *__restrict__ slot_of_edge) {
+                                           uint32_t mask, int *__restrict__ slot_of_edge, int *__restrict__ rep_cnt = nullptr,
+                                           int *__restrict__ rep_slots = nullptr) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) {
         uint64_t h = 0xCBF29CE484222325ull;
         for (int k = 0; k < fe; ++k) h = mix64(h, canon_bits(attr[i * fe + k]));
@@ -300,7 +353,13 @@ __global__ void dedup_insert_direct_kernel(const float *__restrict__ attr, int64
             int cur = __hip_atomic_load(&table[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (cur < 0) {
                 const int prev = atomicCAS(&table[slot], -1, (int)i);
-                if (prev < 0) break;
+                if (prev < 0) {
+                    if (rep_cnt) {
+                        const int k = atomicAdd(rep_cnt, 1) + 1;
+                        if (k < kDedupListMax) rep_slots[k] = (int)slot;
+                    }
+                    break;
+                }
                 cur = prev;
             }
             if (cur == (int)i || rows_equal(attr, fe, cur, i)) {
@@ -322,14 +381,43 @@ __global__ void dedup_mark_first_kernel(const int *__restrict__ table, const int
 // first_rank = exclusive scan of is_first
 __global__ void dedup_assign_kernel(const int *__restrict__ table, const int *__restrict__ slot_of_edge,
                                     const int *__restrict__ first_rank, int64_t e, int *__restrict__ edge_type,
-                                    int *__restrict__ type_rep_edge, int *__restrict__ n_types) {
+                                    int *__restrict__ type_rep_edge, int *__restrict__ n_types,
+                                    const int *__restrict__ skip_flag = nullptr) {
+    // n_types == NULL: the count was written by dedup_rank_kernel; *skip_flag set: too many distinct rows for that kernel's
+    // list, first_rank holds nothing (the caller falls back)
+    if (skip_flag && *skip_flag) return;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) {
         const int rep = table[slot_of_edge[i]];
         const int t = first_rank[rep];
         edge_type[i] = t;
         if (rep == (int)i) type_rep_edge[t] = (int)i;
-        if (i == e - 1) *n_types = first_rank[i] + (rep == (int)i ? 1 : 0);
+        if (n_types && i == e - 1) *n_types = first_rank[i] + (rep == (int)i ? 1 : 0);
     }
+}
+
+// The list-based numbering (tgnn_graph_prep): type id of a distinct row = rank of its first edge among the first edges of all
+// distinct rows -- what the mark / scan / assign sequence computes with a scan over all E edges, here from the <= 4 096 list
+// entries in one block.  More entries than the list holds: *fallback = 1 (nothing else is written).
+__global__ __launch_bounds__(1024) void dedup_rank_kernel(const int *__restrict__ table, const int *__restrict__ rep_cnt,
+                                                          const int *__restrict__ rep_slots, int *__restrict__ first_rank,
+                                                          int *__restrict__ type_rep_edge, int *__restrict__ n_types,
+                                                          int *__restrict__ fallback) {
+    __shared__ int reps[kDedupListMax];
+    const int cnt = *rep_cnt + 1;
+    if (cnt > kDedupListMax) {
+        if (threadIdx.x == 0) { *fallback = 1; *n_types = cnt; }
+        return;
+    }
+    for (int k = threadIdx.x; k < cnt; k += 1024) reps[k] = table[rep_slots[k]];
+    __syncthreads();
+    for (int k = threadIdx.x; k < cnt; k += 1024) {
+        const int mine = reps[k];
+        int rank = 0;
+        for (int j = 0; j < cnt; ++j) rank += reps[j] < mine ? 1 : 0;
+        first_rank[mine] = rank;
+        type_rep_edge[rank] = mine;
+    }
+    if (threadIdx.x == 0) *n_types = cnt;
 }
 
 __global__ void gather_i32_kernel(const int *__restrict__ src, int64_t n_src, const int *__restrict__ idx,
@@ -357,11 +445,28 @@ __global__ __launch_bounds__(64) void nnconv_col_kernel(const int *__restrict__ 
                                                         const int *__restrict__ tile_col_ptr,   // FILL
                                                         int *__restrict__ col_meta, int *__restrict__ col_slot_src,
                                                         const int *__restrict__ n_types_dev = nullptr, int max_types = kMaxColTypes,
-                                                        int *__restrict__ built_flag = nullptr) {
+                                                        int *__restrict__ built_flag = nullptr,
+                                                        const int *__restrict__ edge_type = nullptr,
+                                                        const int *__restrict__ col_eid = nullptr,
+                                                        int *__restrict__ col_type_out = nullptr) {
     // n_types_dev: the count is still on the device (tgnn_graph_prep queues the whole preparation without a host round trip);
     // more types than the structure / the matrix-core kernel take: nothing is built, *built_flag stays 0
     const int n_types = n_types_dev ? *n_types_dev : n_types_host;
-    if (n_types > max_types || n_types > kMaxColTypes) return;
+    if (!FILL && col_type_out) {
+        // tgnn_graph_prep: the types in CSR order (col_type_out = what col_type points to) are gathered here, every row by its
+        // own thread, instead of by a launch of their own in front of this one
+        const int64_t row0 = (int64_t)blockIdx.x * 64 + threadIdx.x;
+        if (row0 < n)
+            for (int e = rowptr[row0]; e < rowptr[row0 + 1]; ++e) col_type_out[e] = edge_type[col_eid[e]];
+    }
+    if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) tile_cols[(n + kColTileRows - 1) / kColTileRows] = 0;   // (the scan's last entry)
+    if (n_types > max_types || n_types > kMaxColTypes) {
+        if (!FILL) {                                          // (the scan behind this launch reads every entry)
+            const int64_t tile0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 4);
+            if ((threadIdx.x & 15) == 0 && tile0 < (n + kColTileRows - 1) / kColTileRows) tile_cols[tile0] = 0;
+        }
+        return;
+    }
     if (built_flag && blockIdx.x == 0 && threadIdx.x == 0) *built_flag = 1;
     __shared__ int cnt[64][kMaxColTypes + 1];    // +1: odd stride, the per-row walks hit distinct banks
     __shared__ int maxm[4][kMaxColTypes];
@@ -373,7 +478,11 @@ __global__ __launch_bounds__(64) void nnconv_col_kernel(const int *__restrict__ 
     for (int t = 0; t < n_types; ++t) cnt[tid][t] = 0;
     int e0 = 0, e1 = 0;
     if (row < n) { e0 = rowptr[row]; e1 = rowptr[row + 1]; }
-    for (int e = e0; e < e1; ++e) cnt[tid][col_type[e]]++;
+    if (!FILL && col_type_out) {
+        for (int e = e0; e < e1; ++e) cnt[tid][col_type_out[e]]++;          // (this thread's own stores above)
+    } else {
+        for (int e = e0; e < e1; ++e) cnt[tid][col_type[e]]++;
+    }
     __syncthreads();
     for (int t = i; t < n_types; t += 16) {
         int m = 0;
@@ -863,8 +972,10 @@ static inline uint32_t dedup_table_size(int64_t e) {
 // Both edge sets ride in the same launches (blockIdx.y).  Bit-identical to tgnn_csr_build (tests/test_graph_prep_small.py).
 // A bucket with more edges than the LDS arrays hold (very skewed in-degrees) takes a slow in-place path.
 // ------------------------------------------------------------------------------------------
-constexpr int kBkLog = 9, kBkRows = 1 << kBkLog, kBkMaxBuckets = 4096, kBkThreads = 1024;
-constexpr int kBkCap = 15360;                        // records of a bucket sorted in LDS: 2 x 4 B each = 120 KB
+// (256 rows and 60 KB of LDS per bucket -- two blocks per CU -- where the average in-degree allows it; else 512 rows)
+constexpr int kBkLogMax = 9, kBkRows = 1 << kBkLogMax, kBkMaxBuckets = 4096, kBkThreads = 1024;
+constexpr int kBkCap = 15360;                        // records of a bucket sorted in LDS: 10 B each = 150 KB (512 rows)
+constexpr int kBkCapHalf = 7168;                     // ... 70 KB (256 rows)
 struct BkSet {
     const int64_t *ei;                               // [2][e]
     int64_t e;
@@ -872,12 +983,15 @@ struct BkSet {
     int *rowptr, *col_src, *col_eid, *err_flag;
     int *rec_eid, *rec_src;
     unsigned short *rec_row;
+    int *total_out, *max_deg_out;                    // (optional) edges kept; largest in-degree (atomicMax into a zeroed word)
 };
 struct BkArgs {
     BkSet set[2];
     int64_t n, n_src;
     int nb, nblk;                                    // buckets, edge blocks
-    int cap;                                         // <= kBkCap (tests lower it to reach the slow path)
+    int lg;                                          // log2 of the rows per bucket: 8 or 9
+    int cap;                                         // <= cap_lds (tests lower it to reach the slow path)
+    int cap_lds;                                     // records the LDS arrays of bk_rows hold: kBkCap / kBkCapHalf
     int *hist;                                       // [2][nb][nblk] + 1
 };
 
@@ -893,7 +1007,7 @@ __global__ __launch_bounds__(kBkThreads) void bk_hist_kernel(BkArgs A) {
         if (s < 0 || s >= A.n_src || d < 0 || d >= A.n) {
             if (S.err_flag) *S.err_flag = 1;
         } else if (!(S.drop_self && s == d)) {
-            atomicAdd(&bk_h[d >> kBkLog], 1);
+            atomicAdd(&bk_h[d >> A.lg], 1);
         }
     }
     __syncthreads();
@@ -901,27 +1015,90 @@ __global__ __launch_bounds__(kBkThreads) void bk_hist_kernel(BkArgs A) {
     if (blk == 0 && blockIdx.y == 1 && tid == 0) A.hist[(int64_t)2 * A.nb * A.nblk] = 0;
 }
 
+// The records of a (bucket, block) cell leave the block as ONE contiguous run: the block first sorts its edges by bucket in LDS
+// (8 192 at a time: local ranks from LDS counters, a scan over the buckets), then every thread writes consecutive records.
+// (Handing every edge straight to its global slot cost 48 us at 100k nodes: 6.7 M scattered 2- and 4-byte stores.)
+constexpr int kBkChunk = kBkThreads * 8;
 __global__ __launch_bounds__(kBkThreads) void bk_scatter_kernel(BkArgs A) {
     extern __shared__ int bk_h[];
+    int *cur = bk_h, *lcnt = cur + A.nb, *lstart = lcnt + A.nb, *wtot = lstart + A.nb;   // [nb] each, [16]
+    int *l_eid = wtot + 16, *l_src = l_eid + kBkChunk;
+    unsigned short *l_row = reinterpret_cast<unsigned short *>(l_src + kBkChunk), *l_bkt = l_row + kBkChunk;
     const BkSet S = A.set[blockIdx.y];
     const int tid = threadIdx.x, blk = blockIdx.x;
     const int base = A.hist[(int64_t)blockIdx.y * A.nb * A.nblk];             // where this set's records start in the scan
-    for (int b = tid; b < A.nb; b += kBkThreads) bk_h[b] = A.hist[((int64_t)blockIdx.y * A.nb + b) * A.nblk + blk] - base;
-    __syncthreads();
+    for (int b = tid; b < A.nb; b += kBkThreads) cur[b] = A.hist[((int64_t)blockIdx.y * A.nb + b) * A.nblk + blk] - base;
     const int64_t i0 = S.e * blk / A.nblk, i1 = S.e * (blk + 1) / A.nblk;
-    for (int64_t i = i0 + tid; i < i1; i += kBkThreads) {
-        const int64_t s = S.ei[i], d = S.ei[S.e + i];
-        if (s < 0 || s >= A.n_src || d < 0 || d >= A.n || (S.drop_self && s == d)) continue;
-        const int k = atomicAdd(&bk_h[d >> kBkLog], 1);
-        S.rec_eid[k] = (int)i;
-        S.rec_src[k] = (int)s;
-        S.rec_row[k] = (unsigned short)(d & (kBkRows - 1));
+    const int per = (A.nb + kBkThreads - 1) / kBkThreads;                     // buckets per thread in the scan (<= 4)
+    for (int64_t c0 = i0; c0 < i1; c0 += kBkChunk) {
+        for (int b = tid; b < A.nb; b += kBkThreads) lcnt[b] = 0;
+        __syncthreads();
+        int e_b[8], e_r[8], e_s[8], e_row[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t i = c0 + tid + (int64_t)u * kBkThreads;
+            e_b[u] = -1;
+            if (i < i1) {
+                const int64_t sv = S.ei[i], d = S.ei[S.e + i];
+                if (!(sv < 0 || sv >= A.n_src || d < 0 || d >= A.n || (S.drop_self && sv == d))) {
+                    e_b[u] = (int)(d >> A.lg);
+                    e_row[u] = (int)(d & ((1 << A.lg) - 1));
+                    e_s[u] = (int)sv;
+                    e_r[u] = atomicAdd(&lcnt[e_b[u]], 1);
+                }
+            }
+        }
+        __syncthreads();
+        {   // exclusive scan of lcnt over the buckets: thread t owns buckets [t per, (t + 1) per)
+            int mine = 0;
+            for (int q = 0; q < per; ++q) {
+                const int b = tid * per + q;
+                mine += b < A.nb ? lcnt[b] : 0;
+            }
+            const int incl = wave_inclusive_scan(mine);
+            if ((tid & 63) == 63) wtot[tid >> 6] = incl;
+            __syncthreads();
+            int run = incl - mine;
+            for (int w = 0; w < (tid >> 6); ++w) run += wtot[w];
+            for (int q = 0; q < per; ++q) {
+                const int b = tid * per + q;
+                if (b < A.nb) {
+                    lstart[b] = run;
+                    run += lcnt[b];
+                }
+            }
+        }
+        __syncthreads();
+        int total = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e_b[u] >= 0) {
+                const int at = lstart[e_b[u]] + e_r[u];
+                l_eid[at] = (int)(c0 + tid + (int64_t)u * kBkThreads);
+                l_src[at] = e_s[u];
+                l_row[at] = (unsigned short)e_row[u];
+                l_bkt[at] = (unsigned short)e_b[u];
+            }
+        total = lstart[A.nb - 1] + lcnt[A.nb - 1];
+        __syncthreads();
+        for (int j = tid; j < total; j += kBkThreads) {
+            const int b = l_bkt[j];
+            const int g = cur[b] + (j - lstart[b]);
+            S.rec_eid[g] = l_eid[j];
+            S.rec_src[g] = l_src[j];
+            S.rec_row[g] = l_row[j];
+        }
+        __syncthreads();
+        for (int b = tid; b < A.nb; b += kBkThreads) cur[b] += lcnt[b];
+        // (the next round's first barrier orders these updates before its reads)
     }
 }
 
 __global__ __launch_bounds__(kBkThreads) void bk_rows_kernel(BkArgs A) {
     extern __shared__ int bk_l[];
-    int *cnt = bk_l, *off = bk_l + kBkRows, *wtot = off + kBkRows + 1, *key_s = wtot + 16, *val_s = key_s + kBkCap;
+    const int rows = 1 << A.lg;
+    int *cnt = bk_l, *off = bk_l + rows, *wtot = off + rows + 1, *key_s = wtot + 16, *val_s = key_s + A.cap_lds;
+    unsigned short *row_s = reinterpret_cast<unsigned short *>(val_s + A.cap_lds);
     const BkSet S = A.set[blockIdx.y];
     const int tid = threadIdx.x, b = blockIdx.x;
     const int base = A.hist[(int64_t)blockIdx.y * A.nb * A.nblk];
@@ -929,12 +1106,12 @@ __global__ __launch_bounds__(kBkThreads) void bk_rows_kernel(BkArgs A) {
     const int hi = A.hist[((int64_t)blockIdx.y * A.nb + b + 1) * A.nblk] - base;   // (the next set's start / the total behind the last)
     const int m = hi - lo;
     const bool in_lds = m <= A.cap;                                           // uniform
-    if (tid < kBkRows) cnt[tid] = 0;
+    if (tid < rows) cnt[tid] = 0;
     __syncthreads();
     // rows' counts
     if (in_lds) {
         for (int j = tid; j < m; j += kBkThreads) atomicAdd(&cnt[S.rec_row[lo + j]], 1);
-    } else if (tid < kBkRows) {
+    } else if (tid < rows) {
         int c = 0;
         for (int j = 0; j < m; ++j) c += S.rec_row[lo + j] == tid ? 1 : 0;
         cnt[tid] = c;
@@ -942,51 +1119,57 @@ __global__ __launch_bounds__(kBkThreads) void bk_rows_kernel(BkArgs A) {
     __syncthreads();
     // exclusive scan of the 512 counts (8 waves)
     int mine = 0, incl = 0;
-    if (tid < kBkRows) {
+    if (tid < rows) {
         mine = cnt[tid];
         incl = wave_inclusive_scan(mine);
         if ((tid & 63) == 63) wtot[tid >> 6] = incl;
     }
     __syncthreads();
-    if (tid < kBkRows) {
+    if (tid < rows) {
         int woff = 0;
         for (int w = 0; w < (tid >> 6); ++w) woff += wtot[w];
         off[tid] = woff + incl - mine;
-        if (tid == kBkRows - 1) off[kBkRows] = woff + incl;
-        const int64_t row = (int64_t)b * kBkRows + tid;
+        if (tid == rows - 1) off[rows] = woff + incl;
+        const int64_t row = (int64_t)b * rows + tid;
         if (row < A.n) S.rowptr[row] = lo + off[tid];
         cnt[tid] = 0;
     }
-    if (b == A.nb - 1 && tid == 0) S.rowptr[A.n] = hi;
+    if (b == A.nb - 1 && tid == 0) {
+        S.rowptr[A.n] = hi;
+        if (S.total_out) *S.total_out = hi;
+    }
+    if (S.max_deg_out && tid < rows) {                                        // (whole waves: rows is a multiple of 64)
+        int md = mine;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) md = max(md, __shfl_xor(md, d, 64));
+        if ((tid & 63) == 0) wtot[8 + (tid >> 6)] = md;
+    }
     __syncthreads();
+    if (S.max_deg_out && tid == 0) {
+        int md = 0;
+        for (int w = 0; w < (rows >> 6); ++w) md = max(md, wtot[8 + w]);
+        if (md > 0) atomicMax(S.max_deg_out, md);
+    }
     if (in_lds) {
         for (int j = tid; j < m; j += kBkThreads) {
             const int r = S.rec_row[lo + j];
             const int at = off[r] + atomicAdd(&cnt[r], 1);
             key_s[at] = S.rec_eid[lo + j];
             val_s[at] = S.rec_src[lo + j];
+            row_s[at] = (unsigned short)r;
         }
         __syncthreads();
-        if (tid < kBkRows) {                                                   // every row back into edge order
-            const int rb = off[tid], re = off[tid + 1];
-            for (int i = rb + 1; i < re; ++i) {
-                const int key = key_s[i], val = val_s[i];
-                int j = i - 1;
-                while (j >= rb && key_s[j] > key) {
-                    key_s[j + 1] = key_s[j];
-                    val_s[j + 1] = val_s[j];
-                    --j;
-                }
-                key_s[j + 1] = key;
-                val_s[j + 1] = val;
-            }
-        }
-        __syncthreads();
+        // every row back into edge order: a record's place in its row = how many of the row's records carry a smaller edge
+        // number -- one thread per RECORD, independent LDS reads (an insertion sort by one thread per row was a chain of
+        // dependent LDS round trips as long as the longest row of the wave: 16 of this kernel's 30 us)
         for (int j = tid; j < m; j += kBkThreads) {
-            S.col_eid[lo + j] = key_s[j];
-            S.col_src[lo + j] = val_s[j];
+            const int r = row_s[j], rb = off[r], re = off[r + 1], key = key_s[j];
+            int rank = 0;
+            for (int q = rb; q < re; ++q) rank += key_s[q] < key ? 1 : 0;
+            S.col_eid[lo + rb + rank] = key;
+            S.col_src[lo + rb + rank] = val_s[j];
         }
-    } else if (tid < kBkRows) {
+    } else if (tid < rows) {
         // too many edges for the LDS arrays: every row's thread walks the bucket's records itself (they lie in the order of the
         // scatter's atomics; the walk writes them by increasing edge number only after a sort in place)
         int *ke = S.col_eid + lo + off[tid], *ks = S.col_src + lo + off[tid];
@@ -1012,12 +1195,37 @@ __global__ __launch_bounds__(kBkThreads) void bk_rows_kernel(BkArgs A) {
 }
 
 static std::atomic<int> g_bk_cap{kBkCap};
+// the preparation's side stream and its fork / join events: per device the stream, per calling thread and device the events
+// (two threads preparing layouts on one device share the stream -- work of both is ordered on it, never wrong, at worst serial)
+static int prep_side_stream(hipStream_t *st, hipEvent_t *fork, hipEvent_t *join) {
+    static std::mutex mu;
+    static hipStream_t streams[64] = {};
+    static thread_local hipEvent_t events[64][2] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return TGNN_ERR_INVALID_ARG;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!streams[dev] && hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess) return TGNN_ERR_INVALID_ARG;
+    }
+    if (!events[dev][0])
+        for (int k = 0; k < 2; ++k)
+            if (hipEventCreateWithFlags(&events[dev][k], hipEventDisableTiming) != hipSuccess) return TGNN_ERR_INVALID_ARG;
+    *st = streams[dev];
+    *fork = events[dev][0];
+    *join = events[dev][1];
+    return TGNN_OK;
+}
+
 static int bk_blocks(int64_t e_max) {
     int64_t nblk = (e_max + 8191) / 8192;
     return (int)(nblk < 1 ? 1 : (nblk > 256 ? 256 : nblk));
 }
+static int bk_log_rows(int64_t n, int64_t e_max) {   // 256-row buckets when they stay within the table sizes and ~half their LDS
+    return (n <= (int64_t)256 * kBkMaxBuckets && e_max * 256 <= (int64_t)3584 * (n > 0 ? n : 1)) ? 8 : 9;
+}
 static size_t bk_workspace_bytes(int64_t n, int64_t ea, int64_t ec) {
-    const int64_t nb = (n + kBkRows - 1) / kBkRows, nblk = bk_blocks(ea > ec ? ea : ec), cells = 2 * nb * nblk + 1;
+    const int64_t rows = (int64_t)1 << bk_log_rows(n, ea > ec ? ea : ec);
+    const int64_t nb = (n + rows - 1) / rows, nblk = bk_blocks(ea > ec ? ea : ec), cells = 2 * nb * nblk + 1;
     return align_up((size_t)cells * 4, 256) + scan_ws_ints(cells) * 4 + align_up((size_t)(ea > 0 ? ea : 1) * 10, 256) +
            align_up((size_t)(ec > 0 ? ec : 1) * 10, 256) + 2048;
 }
@@ -1026,12 +1234,14 @@ static bool bk_fits(int64_t n) { return (n + kBkRows - 1) / kBkRows <= kBkMaxBuc
 // adjacency set -> (rowptr / col_src / col_eid / err) a, collision set (self loops dropped) -> c
 static int csr_build_pair_bucketed(const int64_t *adj_ei, int64_t ea, const int64_t *col_ei, int64_t ec, int64_t n, int64_t n_src,
                                    int *a_rowptr, int *a_src, int *a_eid, int *a_err, int *c_rowptr, int *c_src, int *c_eid,
-                                   int *c_err, void *ws, size_t ws_bytes, hipStream_t s) {
+                                   int *c_err, int *a_max_deg, int *c_total, void *ws, size_t ws_bytes, hipStream_t s) {
     BkArgs A{};
     A.n = n; A.n_src = n_src;
-    A.nb = (int)((n + kBkRows - 1) / kBkRows);
+    A.lg = bk_log_rows(n, ea > ec ? ea : ec);
+    A.nb = (int)((n + ((int64_t)1 << A.lg) - 1) >> A.lg);
     A.nblk = bk_blocks(ea > ec ? ea : ec);
-    A.cap = g_bk_cap.load();
+    A.cap_lds = A.lg == 8 ? kBkCapHalf : kBkCap;
+    A.cap = g_bk_cap.load() < A.cap_lds ? g_bk_cap.load() : A.cap_lds;
     const int64_t cells = (int64_t)2 * A.nb * A.nblk + 1;
     Carver cv(ws, ws_bytes);
     A.hist = cv.take<int>(cells);
@@ -1048,13 +1258,18 @@ static int csr_build_pair_bucketed(const int64_t *adj_ei, int64_t ea, const int6
     A.set[0].rowptr = a_rowptr; A.set[0].col_src = a_src; A.set[0].col_eid = a_eid; A.set[0].err_flag = a_err;
     A.set[1].ei = col_ei; A.set[1].e = ec; A.set[1].drop_self = 1;
     A.set[1].rowptr = c_rowptr; A.set[1].col_src = c_src; A.set[1].col_eid = c_eid; A.set[1].err_flag = c_err;
+    A.set[0].max_deg_out = a_max_deg;
+    A.set[1].total_out = c_total;
     const size_t lds_h = (size_t)A.nb * sizeof(int);
     bk_hist_kernel<<<dim3(A.nblk, 2), kBkThreads, lds_h, s>>>(A);
     exclusive_scan_i32(A.hist, A.hist, cells, scan_ws, s);
-    bk_scatter_kernel<<<dim3(A.nblk, 2), kBkThreads, lds_h, s>>>(A);
-    const size_t lds_r = (size_t)(2 * kBkRows + 1 + 16 + 2 * kBkCap) * sizeof(int);
+    const size_t lds_s = (size_t)(3 * A.nb + 16 + 2 * kBkChunk) * sizeof(int) + (size_t)2 * kBkChunk * sizeof(unsigned short);
+    static LdsOptIn site_s;
+    TGNN_CHECK_HIP(opt_in_dynamic_lds(bk_scatter_kernel, (int)(160 * 1024 - 256), site_s));
+    bk_scatter_kernel<<<dim3(A.nblk, 2), kBkThreads, lds_s, s>>>(A);
+    const size_t lds_r = (size_t)(2 * (1 << A.lg) + 1 + 16 + 2 * A.cap_lds) * sizeof(int) + (size_t)A.cap_lds * sizeof(unsigned short);
     static LdsOptIn site;
-    TGNN_CHECK_HIP(opt_in_dynamic_lds(bk_rows_kernel, (int)lds_r, site));
+    TGNN_CHECK_HIP(opt_in_dynamic_lds(bk_rows_kernel, (int)(160 * 1024 - 256), site));
     bk_rows_kernel<<<dim3(A.nb, 2), kBkThreads, lds_r, s>>>(A);
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
@@ -1109,7 +1324,32 @@ extern "C" int tgnn_csr_build(const int64_t *edge_index, int64_t n_edges, int64_
 extern "C" size_t tgnn_edge_dedup_workspace_bytes(int64_t n_edges, int32_t fe) {
     (void)fe;
     return (size_t)dedup_table_size(n_edges) * 4 + align_up((size_t)n_edges * 4, 256) * 2 +
-           scan_ws_ints(n_edges) * 4 + 2048;
+           scan_ws_ints(n_edges) * 4 + 2048 + (size_t)(kDedupListMax + 64) * 4 + 512;
+}
+
+// tgnn_edge_type_dedup for tgnn_graph_prep: four launches instead of eight (fill, insert, rank, assign); *fallback = 1 (and
+// nothing usable in edge_type) when the layout has more than kDedupListMax distinct attribute rows
+static int edge_type_dedup_listed(const float *edge_attr, int64_t n_edges, int32_t fe, int32_t *edge_type, int32_t *type_rep_edge,
+                                  int32_t *n_types, int32_t *fallback, void *ws, size_t ws_bytes, hipStream_t s) {
+    (void)ws_bytes;
+    Carver cv(ws, ws_bytes);
+    const uint32_t cap = dedup_table_size(n_edges);
+    int *table = cv.take<int>(cap + 64);                 // + the list counter (table[cap]): one fill for both
+    int *slot_of_edge = cv.take<int>(n_edges);
+    int *first_rank = cv.take<int>(n_edges);
+    int *rep_slots = cv.take<int>(kDedupListMax);
+    TGNN_CHECK_HIP(hipMemsetAsync(table, 0xFF, (size_t)(cap + 64) * 4, s));
+    if (fe <= 60)
+        dedup_insert_kernel<<<grid_for(n_edges, kDedupRows), kDedupRows, (size_t)kDedupRows * (fe | 1) * 4, s>>>(
+            edge_attr, n_edges, fe, table, cap - 1, slot_of_edge, table + cap, rep_slots);
+    else
+        dedup_insert_direct_kernel<<<grid_for(n_edges), 256, 0, s>>>(edge_attr, n_edges, fe, table, cap - 1, slot_of_edge, table + cap,
+                                                                     rep_slots);
+    dedup_rank_kernel<<<1, 1024, 0, s>>>(table, table + cap, rep_slots, first_rank, type_rep_edge, n_types, fallback);
+    dedup_assign_kernel<<<grid_for(n_edges), 256, 0, s>>>(table, slot_of_edge, first_rank, n_edges, edge_type, type_rep_edge,
+                                                          nullptr, fallback);
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
 }
 
 extern "C" int tgnn_edge_type_dedup(const float *edge_attr, int64_t n_edges, int32_t fe, int32_t *edge_type,
@@ -1407,27 +1647,45 @@ extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edge
                  col_b = tgnn_nnconv_cols_workspace_bytes(n_nodes);
     void *ws_csr = cv.take<unsigned char>(csr_b), *ws_dd = cv.take<unsigned char>(dd_b), *ws_col = cv.take<unsigned char>(col_b);
     TGNN_CHECK_HIP(hipMemsetAsync(result, 0, 32 * sizeof(int32_t), s));
+    // The edge-type de-duplication reads only the attribute rows, the CSRs only the index arrays: two independent chains of
+    // ~85 and ~125 us at 100k nodes, neither of which fills the chip (few-block scans, one block per 8 192 edges) -- the first
+    // one runs on a side stream of the library's own (one per device, created once) between a fork and a join event
+    hipStream_t s_side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    if (n_adj_edges > 0 && prep_side_stream(&s_side, &ev_fork, &ev_join) == TGNN_OK) {
+        TGNN_CHECK_HIP(hipEventRecord(ev_fork, s));
+        TGNN_CHECK_HIP(hipStreamWaitEvent(s_side, ev_fork, 0));
+    } else {
+        s_side = nullptr;
+    }
     int rc;
+    bool bucketed = false;
+    if (s_side) {
+        rc = edge_type_dedup_listed(adj_edge_attr, n_adj_edges, fe, edge_type, type_rep_edge, result + 0, result + 6, ws_dd, dd_b, s_side);
+        if (rc != TGNN_OK) return rc;
+        TGNN_CHECK_HIP(hipEventRecord(ev_join, s_side));
+    }
     if (bk_fits(n_nodes) && n_adj_edges < (int64_t(1) << 31) - 1 && n_col_edges < (int64_t(1) << 31) - 1) {
         // both CSRs through 512-row buckets: four kernels + one scan, no device-scope returning atomic
         const size_t bk_b = bk_workspace_bytes(n_nodes, n_adj_edges, n_col_edges);
         void *ws_bk = cv.take<unsigned char>(bk_b);
         rc = csr_build_pair_bucketed(adj_edge_index, n_adj_edges, col_edge_index, n_col_edges, n_nodes, n_nodes, adj_rowptr, adj_src,
-                                     adj_eid, result + 1, col_rowptr, col_src, col_eid, result + 2, ws_bk, bk_b, s);
+                                     adj_eid, result + 1, col_rowptr, col_src, col_eid, result + 2, result + 4, result + 3, ws_bk, bk_b, s);
         if (rc != TGNN_OK) return rc;
+        bucketed = true;
     } else {
         rc = tgnn_csr_build(adj_edge_index, n_adj_edges, n_nodes, n_nodes, 0, adj_rowptr, adj_src, adj_eid, result + 1, ws_csr, csr_b, stream);
         if (rc != TGNN_OK) return rc;
         rc = tgnn_csr_build(col_edge_index, n_col_edges, n_nodes, n_nodes, 1, col_rowptr, col_src, col_eid, result + 2, ws_csr, csr_b, stream);
         if (rc != TGNN_OK) return rc;
     }
-    rc = tgnn_edge_type_dedup(adj_edge_attr, n_adj_edges, fe, edge_type, type_rep_edge, result + 0, ws_dd, dd_b, stream);
-    if (rc != TGNN_OK) return rc;
-    if (n_adj_edges > 0) {
-        rc = tgnn_gather_i32(edge_type, n_adj_edges, adj_eid, n_adj_edges, adj_type, stream);
+    if (s_side) {
+        TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev_join, 0));
+    } else {
+        rc = tgnn_edge_type_dedup(adj_edge_attr, n_adj_edges, fe, edge_type, type_rep_edge, result + 0, ws_dd, dd_b, stream);
         if (rc != TGNN_OK) return rc;
     }
-    {
+    if (!bucketed) {                                          // (the bucketed builder leaves result[3], result[4] itself)
         int64_t rb = (n_nodes + 1023) / 1024;
         prep_result_kernel<<<(unsigned)(rb > 256 ? 256 : rb), 256, 0, s>>>(col_rowptr, adj_rowptr, n_nodes, result);
     }
@@ -1436,11 +1694,12 @@ extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edge
     Carver cc(ws_col, col_b);
     int *tile_cols = cc.take<int>(nt16 + 1);
     int *scan_ws = cc.take<int>(scan_ws_ints(nt16 + 1));
-    TGNN_CHECK_HIP(hipMemsetAsync(tile_cols, 0, (size_t)(nt16 + 1) * 4, s));
     const unsigned blocks = (unsigned)((n_nodes + 63) / 64);
     const int max_types = tgnn_nnconv_cols_max_types();
+    // (the first pass also gathers the types into CSR order -- adj_type -- and writes every entry the scan reads)
     nnconv_col_kernel<false><<<blocks, 64, 0, s>>>(adj_rowptr, adj_src, adj_type, n_nodes, 0, tile_cols, nullptr, nullptr, nullptr,
-                                                   result + 0, max_types, nullptr);
+                                                   result + 0, max_types, nullptr, n_adj_edges > 0 ? edge_type : nullptr, adj_eid,
+                                                   n_adj_edges > 0 ? adj_type : nullptr);
     exclusive_scan_i32(tile_cols, tile_col_ptr, nt16 + 1, scan_ws, s);
     nnconv_col_kernel<true><<<blocks, 64, 0, s>>>(adj_rowptr, adj_src, adj_type, n_nodes, 0, nullptr, tile_col_ptr, col_meta,
                                                   col_slot_src, result + 0, max_types, result + 5);
