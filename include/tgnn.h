@@ -352,9 +352,11 @@ int tgnn_backward(const tgnn_model_dims *dims, const void *const *params_host, v
 /* ---- the same forward for ONE SHARD of a node-range partition (one process per GPU) -------------------------
  * This device owns rows [0, n_own) of a layout whose buffers carry n_rows - n_own halo rows of other shards behind
  * them: `graph` is built with n_nodes = n_own destinations and sources in [0, n_rows) (tgnn_csr_build's
- * n_src_nodes), `x` has n_own rows.  Per layer the library needs two collectives, which stay with the caller
- * (torch.distributed / RCCL in tilingnn_amd/dist.py): it enqueues its kernels on `stream`, calls back on the
- * host, and continues; a callback must enqueue its collective on `stream` or order it with `stream`.
+ * n_src_nodes), `x` has n_own rows.  Per layer the library needs two collectives.  Either it issues them itself over RCCL
+ * (rccl_comm below: ncclSend / ncclRecv groups and ncclAllReduce on the kernels' stream, no host code in the loop), or they
+ * stay with the caller as callbacks (torch.distributed in tilingnn_amd/dist.py, thread-simulated ranks in the tests): the
+ * library enqueues its kernels, calls back on the host, and continues; a callback must enqueue its collective on the
+ * stream it is handed or order it with that stream.
  *   allreduce_f64(ctx, sum_buf, count, stream): sum_buf[0..count) <- sum over all shards      (BatchNorm sums)
  *   alltoall_rows(ctx, send_buf, recv_buf, row_floats, extra_rows, stream): send_buf holds n_send rows of row_floats floats
  *       (the owned rows listed in send_idx, grouped by destination shard); recv_buf must receive the n_rows - n_own
@@ -382,10 +384,32 @@ typedef struct tgnn_shard {
     int32_t world, rank;            /* fused mode */
     const int32_t *send_idx_fused;  /* device, may be NULL = plain mode */
     const int32_t *recv_idx_fused;  /* device */
-    tgnn_stream_t side_stream;      /* may be NULL.  Not NULL (and != stream): the collision branch of a layer runs on it beside
-                                     * the adjacency branch, as in tgnn_forward; the two meet before the layer's exchange.  The
-                                     * callbacks are still only ever handed `stream`. */
+    tgnn_stream_t side_stream;      /* may be NULL.  Not NULL (and != stream), fused mode: SPLIT exchange -- the collision branch
+                                     * of a layer (GIN, then an all-to-all of its own: halo rows of that branch + its BatchNorm
+                                     * sums, C floats per row) runs on it, ahead of the adjacency branch's chain (NNConv, its
+                                     * all-to-all, merge) on `stream`: two all-to-alls per layer, each handed the stream it belongs
+                                     * to and its halves of send_buf / recv_buf.  Plain mode: only the neighbourhood sum of the
+                                     * collision branch runs there. */
+    /* Collectives issued by the library (RCCL, csrc/rccl_comm.hip) instead of through the callbacks: comm from
+     * tgnn_rccl_comm_create (NULL: the callbacks are used and must be given); comm_side (may be NULL = comm) carries the side
+     * stream's all-to-alls -- a communicator of its own lets the two chains' collectives overlap; send_counts / recv_counts
+     * (host, [world]): rows sent to / received from every peer in one exchange, without the extra rows. */
+    void *rccl_comm, *rccl_comm_side;
+    const int64_t *send_counts, *recv_counts;
 } tgnn_shard;
+
+/* RCCL communicators for tgnn_shard.rccl_comm.  RCCL is looked up at run time (librccl.so.1, the copy already in the process
+ * if there is one): tgnn_rccl_available() = 0 when it cannot be found.  One rank calls tgnn_rccl_unique_id (id_out:
+ * tgnn_rccl_unique_id_bytes() = 128 bytes) and hands the bytes to the others (any channel: torch.distributed broadcast,
+ * MPI, a file); then EVERY rank calls tgnn_rccl_comm_create (a collective; the calling thread's current device is the
+ * communicator's). */
+int32_t tgnn_rccl_available(void);
+size_t tgnn_rccl_unique_id_bytes(void);
+int tgnn_rccl_unique_id(void *id_out);
+int tgnn_rccl_comm_create(const void *unique_id, int32_t rank, int32_t world, void **comm_out);
+int tgnn_rccl_comm_destroy(void *comm);
+/* out2[0] / out2[1]: all-to-alls / all-reduces this process has issued through its communicators so far (reporting) */
+void tgnn_rccl_counters(int64_t *out2);
 size_t tgnn_forward_sharded_workspace_bytes(const tgnn_model_dims *dims, int64_t n_own, int64_t n_rows,
                                             int32_t n_types);
 int tgnn_forward_sharded(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
@@ -439,11 +463,12 @@ int tgnn_graph_prep_small(const int64_t *adj_edge_index, int64_t n_adj_edges, co
  * 4 096 distinct attribute rows -- more than the one-block numbering of the types takes: edge_type / adj_type / the column
  * structure hold nothing usable, the caller goes through the separate calls (tgnn_edge_type_dedup has no such limit).  The five
  * st_* arrays (all or none; sized as for tgnn_nnconv_stream_build) also receive the NNConv stream structure: result[8..10] =
- * that call's result words. */
+ * that call's result words.  n_src_nodes >= n_nodes: sources may index rows behind the n_nodes destinations (the halo rows of a
+ * shard, as in tgnn_csr_build); n_nodes on a single device. */
 size_t tgnn_graph_prep_workspace_bytes(int64_t n_nodes, int64_t n_adj_edges, int64_t n_col_edges, int32_t fe);
 int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edges, const float *adj_edge_attr, int32_t fe,
-                    const int64_t *col_edge_index, int64_t n_col_edges, int64_t n_nodes, int32_t *adj_rowptr, int32_t *adj_src,
-                    int32_t *adj_eid, int32_t *adj_type, int32_t *edge_type, int32_t *type_rep_edge, int32_t *col_rowptr,
+                    const int64_t *col_edge_index, int64_t n_col_edges, int64_t n_nodes, int64_t n_src_nodes, int32_t *adj_rowptr,
+                    int32_t *adj_src, int32_t *adj_eid, int32_t *adj_type, int32_t *edge_type, int32_t *type_rep_edge, int32_t *col_rowptr,
                     int32_t *col_src, int32_t *col_eid, int32_t *tile_col_ptr, int32_t *col_meta, int32_t *col_slot_src,
                     int32_t *st_tile_ent_ptr, uint32_t *st_ent_src, uint32_t *st_rowlist, uint32_t *st_info, float *st_inv_deg,
                     void *ws, size_t ws_bytes, int32_t *result, tgnn_stream_t stream);

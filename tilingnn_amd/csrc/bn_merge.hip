@@ -558,6 +558,59 @@ __global__ __launch_bounds__(1024) void shard_unpack_finalize_kernel(const float
     }
 }
 
+// The same for ONE branch (split exchange: the collision branch's rows and sums travel on the side stream as soon as its GIN
+// is through, the adjacency branch's behind the NNConv -- forward.hip): rows of 32 floats, 4 sums rows = 64 doubles per peer.
+__global__ __launch_bounds__(1024) void shard_pack1_kernel(const float *__restrict__ a, const int *__restrict__ idx,
+                                                           int64_t n_rows, BnJob job, float *__restrict__ out) {
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0) {
+        __shared__ double red[1024];
+        __shared__ double tot[64];
+        bn_sums_from_partials_1024(job, 64, red, tot);
+        if (tid < 64) job.sums[tid] = tot[tid];
+        const float *tf = reinterpret_cast<const float *>(tot);
+        for (int64_t r = tid >> 5; r < n_rows; r += 32) {
+            const int id = idx[r];
+            if (id < 0) out[r * 32 + (tid & 31)] = tf[(-1 - id) * 32 + (tid & 31)];
+        }
+        return;
+    }
+    const int64_t total = n_rows * 32;
+    for (int64_t i = (int64_t)(blockIdx.x - 1) * 1024 + tid; i < total; i += (int64_t)(gridDim.x - 1) * 1024) {
+        const int id = idx[i >> 5];
+        if (id >= 0) out[i] = a[(int64_t)id * 32 + (i & 31)];
+    }
+}
+__global__ __launch_bounds__(1024) void shard_unpack1_kernel(const float *__restrict__ in, const int *__restrict__ idx,
+                                                             int64_t n_rows, int64_t n_own, float *__restrict__ a, BnJob job,
+                                                             int world, int rank, int64_t n_total, float eps, float momentum) {
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0) {
+        __shared__ int pos[4 * 64];
+        __shared__ double tot[64];
+        for (int64_t r = tid; r < n_rows; r += 1024) {
+            const int id = idx[r];
+            if (id < 0 && -1 - id < 4 * 64) pos[-1 - id] = (int)r;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int k = tid >> 4, jj = tid & 15;            // sums row k of a peer holds doubles 16 k .. 16 k + 15
+            double t = 0.0;
+            for (int p = 0; p < world; ++p)
+                t += p == rank ? job.sums[tid] : reinterpret_cast<const double *>(in + (int64_t)pos[4 * p + k] * 32)[jj];
+            tot[tid] = t;
+        }
+        __syncthreads();
+        bn_record_from_sums(job, tot, 32, n_total, eps, momentum);
+        return;
+    }
+    const int64_t total = n_rows * 32;
+    for (int64_t i = (int64_t)(blockIdx.x - 1) * 1024 + tid; i < total; i += (int64_t)(gridDim.x - 1) * 1024) {
+        const int id = idx[i >> 5];
+        if (id >= 0) a[(n_own + id) * 32 + (i & 31)] = in[i];
+    }
+}
+
 static inline unsigned shard_copy_blocks(int64_t n_rows) {
     int64_t b = (n_rows * 64 + 1023) / 1024;
     if (b < 1) b = 1;
@@ -573,6 +626,15 @@ void launch_shard_unpack_finalize(const float *in, const int *idx, int64_t n_row
                                   hipStream_t s) {
     shard_unpack_finalize_kernel<<<1 + shard_copy_blocks(n_rows), 1024, 0, s>>>(in, idx, n_rows, n_own, a1, a2, jobs, world,
                                                                                 rank, n_total, eps, momentum);
+}
+
+void launch_shard_pack1(const float *a, const int *idx, int64_t n_rows, const BnJob &job, float *out, hipStream_t s) {
+    shard_pack1_kernel<<<1 + shard_copy_blocks((n_rows + 1) / 2), 1024, 0, s>>>(a, idx, n_rows, job, out);
+}
+void launch_shard_unpack1(const float *in, const int *idx, int64_t n_rows, int64_t n_own, float *a, const BnJob &job, int world,
+                          int rank, int64_t n_total, float eps, float momentum, hipStream_t s) {
+    shard_unpack1_kernel<<<1 + shard_copy_blocks((n_rows + 1) / 2), 1024, 0, s>>>(in, idx, n_rows, n_own, a, job, world, rank,
+                                                                                 n_total, eps, momentum);
 }
 
 void launch_shard_pack(const float *a1, const float *a2, const int *idx, int64_t n_rows, const double *sums, float *out,

@@ -231,8 +231,9 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     if (sh) {
         TGNN_CHECK_ARG(sh->n_own == n && nr >= n && n_total >= n, "shard row counts");
         TGNN_CHECK_ARG(!use_running_stats, "sharded forward runs in train mode");
-        TGNN_CHECK_ARG(sh->allreduce_f64 && sh->alltoall_rows && sh->sum_buf && sh->send_buf && sh->recv_buf,
-                       "shard callbacks / buffers");
+        TGNN_CHECK_ARG(sh->sum_buf && sh->send_buf && sh->recv_buf, "shard buffers");
+        TGNN_CHECK_ARG(sh->rccl_comm ? (sh->send_counts && sh->recv_counts && sh->world >= 1 && sh->world <= 64)
+                                     : (sh->allreduce_f64 && sh->alltoall_rows), "shard communicator / callbacks");
         TGNN_CHECK_ARG(sh->n_send == 0 || sh->send_idx, "send_idx");
     }
     Workspace w = carve(*dims, n, nr, graph->n_types, ws, ws_bytes);
@@ -287,6 +288,26 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
 
     // BatchNorm statistics from the producers' partial rows.  Sharded: partials -> local sums (mode 1) -> all-reduce
     // over the shards (caller's callback; both BatchNorms of a layer travel in one message) -> stat record (mode 2).
+    // the two collectives: RCCL calls of the library's own when the shard carries a communicator, else the caller's callbacks
+    auto allreduce = [&](double *buf, int64_t count, hipStream_t st) -> int {
+        if (sh->rccl_comm) return rccl_allreduce_f64(sh->rccl_comm, buf, count, st);
+        if (sh->allreduce_f64(sh->ctx, buf, count, st) != 0) {
+            set_error("tgnn_forward_sharded: the all-reduce callback failed");
+            return TGNN_ERR_INVALID_ARG;
+        }
+        return TGNN_OK;
+    };
+    auto alltoall = [&](const float *send, float *recv, int row_floats, int extra_rows, hipStream_t st) -> int {
+        if (sh->rccl_comm) {
+            void *comm = (st != s && sh->rccl_comm_side) ? sh->rccl_comm_side : sh->rccl_comm;
+            return rccl_alltoall_rows(comm, send, recv, sh->send_counts, sh->recv_counts, sh->world, row_floats, extra_rows, st);
+        }
+        if (sh->alltoall_rows(sh->ctx, send, recv, row_floats, extra_rows, st) != 0) {
+            set_error("tgnn_forward_sharded: the all-to-all callback failed");
+            return TGNN_ERR_INVALID_ARG;
+        }
+        return TGNN_OK;
+    };
     auto finalize_jobs = [&](BnJobs jobs, int nj, int f) -> int {
         if (nj == 0) return TGNN_OK;
         if (!sh) {
@@ -297,10 +318,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         }
         for (int j = 0; j < nj; ++j) jobs.job[j].sums = sh->sum_buf + (size_t)j * 2 * f;
         launch_bn_finalize(jobs, nj, 1, f, n_total, eps, momentum, s);
-        if (sh->allreduce_f64(sh->ctx, sh->sum_buf, (int64_t)nj * 2 * f, stream) != 0) {
-            set_error("tgnn_forward_sharded: the all-reduce callback failed");
-            return TGNN_ERR_INVALID_ARG;
-        }
+        TGNN_TRY(allreduce(sh->sum_buf, (int64_t)nj * 2 * f, s));
         launch_bn_finalize(jobs, nj, 2, f, n_total, eps, momentum, s);
         return TGNN_OK;
     };
@@ -322,10 +340,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
             TGNN_TRY(tgnn_rows_gather(slot_rows, c, sh->send_idx, sh->n_send, c, sh->send_buf, rf, s));
             if (a2_own) TGNN_TRY(tgnn_rows_gather(a2_own, c, sh->send_idx, sh->n_send, c, sh->send_buf + c, rf, s));
         }
-        if (sh->alltoall_rows(sh->ctx, sh->send_buf, sh->recv_buf, rf, 0, stream) != 0) {
-            set_error("tgnn_forward_sharded: the all-to-all callback failed");
-            return TGNN_ERR_INVALID_ARG;
-        }
+        TGNN_TRY(alltoall(sh->send_buf, sh->recv_buf, rf, 0, s));
         if (n_halo > 0) {
             TGNN_CHECK_HIP(hipMemcpy2DAsync(slot_rows + (size_t)n * c, (size_t)c * 4, sh->recv_buf, (size_t)rf * 4,
                                             (size_t)c * 4, (size_t)n_halo, hipMemcpyDeviceToDevice, s));
@@ -422,6 +437,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     // CollConv (:63): input = BN_{i-1}(a2_{i-1}) folded into the gather; layer 0 reads middle[0]
     // one all-to-all per layer instead of all-reduce + all-to-all (see tgnn_shard in tgnn.h)
     if (fused_shard) TGNN_CHECK_ARG(sh->rank >= 0 && sh->rank < sh->world && sh->world <= 64, "shard rank / world (<= 64)");
+    const bool split = fused_shard && s2 != nullptr;       // one exchange per branch and layer, the collision branch's on the side stream
     auto gin_layer = [&](int i, hipStream_t gs) -> int {
         const int b = P.layer(i);
         const float *gin_in = i == 0 ? w.mid : w.a2[(i - 1) & 1];
@@ -453,7 +469,24 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
             // (sharded: the halo rows and the statistics GIN_i reads arrive with the exchange of layer i-1, so the chain cannot run
             //  ahead; only the HBM-bound neighbourhood sum goes beside the merge / NNConv -- the MLP, which finds no CU beside an
             //  NNConv block, follows on the main stream: 52 us beside the NNConv against 19 us behind it, measured)
-            if (sh) {
+            if (sh && split) {
+                // split exchange: the whole collision branch of layer i -- GIN, then ITS OWN all-to-all (halo rows of a2 + the
+                // BatchNorm sums, 32 floats per row) and the statistics -- on the side stream: it needs nothing of the adjacency
+                // branch, so the chain runs ahead of the NNConv / merge chain as it does on a single device, held back only by
+                // the two-deep buffers (a2[i & 1] / stat2[i & 1] were last read by merge_{i-2})
+                if (i >= 2) TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[1 + kMaxDepth + i - 2], 0));
+                TGNN_TRY(gin_layer(i, s2));
+                if (i + 1 < D) {
+                    BnJob j2 = bn_job(w.part2, np2, P.bn(b + 20), w.stat2[i & 1]);
+                    j2.sums = sh->sum_buf + 64;
+                    const int64_t n_out = sh->n_send + 4 * (int64_t)sh->world, n_in = n_halo + 4 * (int64_t)sh->world;
+                    float *sb2 = sh->send_buf + (size_t)n_out * c, *rb2 = sh->recv_buf + (size_t)n_in * c;
+                    launch_shard_pack1(w.a2[i & 1], sh->send_idx_fused, n_out, j2, sb2, s2);
+                    TGNN_TRY(alltoall(sb2, rb2, c, 4, s2));
+                    launch_shard_unpack1(rb2, sh->recv_idx_fused, n_in, n, w.a2[i & 1], j2, sh->world, sh->rank, n_total, eps,
+                                         momentum, s2);
+                }
+            } else if (sh) {
                 if (i >= 1) TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[1 + kMaxDepth + i - 1], 0));
                 const float *gin_in = i == 0 ? w.mid : w.a2[(i - 1) & 1];
                 TGNN_TRY(tgnn_gin_aggregate(gin_in, c, i == 0 ? nullptr : w.stat2[(i - 1) & 1], graph->col_rowptr, graph->col_src,
@@ -480,6 +513,26 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
                                       TGNN_ACT_LEAKY_RELU, w.a1, w.part1, &np1, s));
         }
         prof.end();
+        if (split && i + 1 < D) {
+            // ---- sharded, split exchange: this chain carries the adjacency branch only (rows of a1 + its BatchNorm sums); the
+            //      collision branch's half arrived (or is arriving) on the side stream
+            BnJob j1 = bn_job(w.part1, np1, P.bn(b + 8), w.stat1);
+            j1.sums = sh->sum_buf;
+            const int64_t n_out = sh->n_send + 4 * (int64_t)sh->world, n_in = n_halo + 4 * (int64_t)sh->world;
+            launch_shard_pack1(w.a1, sh->send_idx_fused, n_out, j1, sh->send_buf, s);
+            TGNN_TRY(alltoall(sh->send_buf, sh->recv_buf, c, 4, s));
+            launch_shard_unpack1(sh->recv_buf, sh->recv_idx_fused, n_in, n, w.a1, j1, sh->world, sh->rank, n_total, eps, momentum, s);
+            TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[1 + i], 0));
+            const float *resid_f = i >= 2 ? w.mid + (size_t)(i - 2) * nr * c : nullptr;
+            if (f16)
+                launch_merge(w.a1, w.stat1, w.a2[i & 1], w.stat2[i & 1], resid_f, nr, c, w.mid + (size_t)(i + 1) * nr * c, nullptr,
+                             slot_max + i + 1, s);
+            else
+                TGNN_TRY(tgnn_merge_fwd(w.a1, w.stat1, w.a2[i & 1], w.stat2[i & 1], resid_f, nr, c,
+                                        w.mid + (size_t)(i + 1) * nr * c, nullptr, s));
+            TGNN_CHECK_HIP(hipEventRecord(ev[1 + kMaxDepth + i], s));       // (a2[i & 1] / stat2[i & 1] are free for GIN_{i+2})
+            continue;
+        }
         if (fused_shard && i + 1 < D) {
             // ---- sharded, fused: local sums -> ONE all-to-all (raw halo rows of both branches + the sums) -> the sums of
             //      all shards added in rank order -> statistics -> merge of the own AND the halo rows
@@ -498,10 +551,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
             jobs.job[1].sums = own + 64;
             const int64_t n_out = sh->n_send + 4 * (int64_t)sh->world, n_in = n_halo + 4 * (int64_t)sh->world;
             launch_shard_pack_sums(w.a1, w.a2[i & 1], sh->send_idx_fused, n_out, jobs, sh->send_buf, s);
-            if (sh->alltoall_rows(sh->ctx, sh->send_buf, sh->recv_buf, 2 * c, 4, stream) != 0) {
-                set_error("tgnn_forward_sharded: the all-to-all callback failed");
-                return TGNN_ERR_INVALID_ARG;
-            }
+            TGNN_TRY(alltoall(sh->send_buf, sh->recv_buf, 2 * c, 4, s));
             launch_shard_unpack_finalize(sh->recv_buf, sh->recv_idx_fused, n_in, n, w.a1, w.a2[i & 1], jobs, sh->world,
                                          sh->rank, n_total, eps, momentum, s);
             // (what the next GIN reads -- the collision rows incl. halo and their statistics -- is complete here: it starts beside
@@ -525,8 +575,9 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         const bool fused_bn1 = c == 32 && !use_running_stats && !sh && np1 <= fuse_rows;
         if (s2 && sh) {
             TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[1 + i], 0));
-            TGNN_TRY(launch_gin32_mlp(w.t0, P.f(b + 14), P.f(b + 15), P.f(b + 16), P.f(b + 17), P.f(b + 18), P.f(b + 19), n,
-                                      TGNN_ACT_LEAKY_RELU, w.a2[i & 1], w.part2, &np2, s));
+            if (!split)
+                TGNN_TRY(launch_gin32_mlp(w.t0, P.f(b + 14), P.f(b + 15), P.f(b + 16), P.f(b + 17), P.f(b + 18), P.f(b + 19), n,
+                                          TGNN_ACT_LEAKY_RELU, w.a2[i & 1], w.part2, &np2, s));
             BnJobs jobs{};
             jobs.job[0] = bn_job(w.part1, np1, P.bn(b + 8), w.stat1);
             jobs.job[1] = bn_job(w.part2, np2, P.bn(b + 20), w.stat2[i & 1]);

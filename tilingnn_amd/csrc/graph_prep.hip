@@ -1627,14 +1627,16 @@ extern "C" size_t tgnn_graph_prep_workspace_bytes(int64_t n_nodes, int64_t n_adj
 }
 
 extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edges, const float *adj_edge_attr, int32_t fe,
-                               const int64_t *col_edge_index, int64_t n_col_edges, int64_t n_nodes, int32_t *adj_rowptr,
-                               int32_t *adj_src, int32_t *adj_eid, int32_t *adj_type, int32_t *edge_type, int32_t *type_rep_edge,
+                               const int64_t *col_edge_index, int64_t n_col_edges, int64_t n_nodes, int64_t n_src_nodes,
+                               int32_t *adj_rowptr, int32_t *adj_src, int32_t *adj_eid, int32_t *adj_type, int32_t *edge_type,
+                               int32_t *type_rep_edge,
                                int32_t *col_rowptr, int32_t *col_src, int32_t *col_eid, int32_t *tile_col_ptr, int32_t *col_meta,
                                int32_t *col_slot_src, int32_t *st_tile_ent_ptr, uint32_t *st_ent_src, uint32_t *st_rowlist,
                                uint32_t *st_info, float *st_inv_deg, void *ws, size_t ws_bytes, int32_t *result,
                                tgnn_stream_t stream) {
     DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_nodes >= 1 && fe >= 1 && n_adj_edges >= 0 && n_col_edges >= 0, "shape");
+    TGNN_CHECK_ARG(n_src_nodes >= n_nodes && n_src_nodes < (1ll << 31) - 1, "n_src_nodes must be >= n_nodes and fit int32");
     TGNN_CHECK_ARG(adj_rowptr && col_rowptr && tile_col_ptr && col_meta && col_slot_src && result, "null pointer");
     if (!ws || ws_bytes < tgnn_graph_prep_workspace_bytes(n_nodes, n_adj_edges, n_col_edges, fe)) {
         set_error("tgnn_graph_prep: workspace too small");
@@ -1669,14 +1671,14 @@ extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edge
         // both CSRs through 512-row buckets: four kernels + one scan, no device-scope returning atomic
         const size_t bk_b = bk_workspace_bytes(n_nodes, n_adj_edges, n_col_edges);
         void *ws_bk = cv.take<unsigned char>(bk_b);
-        rc = csr_build_pair_bucketed(adj_edge_index, n_adj_edges, col_edge_index, n_col_edges, n_nodes, n_nodes, adj_rowptr, adj_src,
+        rc = csr_build_pair_bucketed(adj_edge_index, n_adj_edges, col_edge_index, n_col_edges, n_nodes, n_src_nodes, adj_rowptr, adj_src,
                                      adj_eid, result + 1, col_rowptr, col_src, col_eid, result + 2, result + 4, result + 3, ws_bk, bk_b, s);
         if (rc != TGNN_OK) return rc;
         bucketed = true;
     } else {
-        rc = tgnn_csr_build(adj_edge_index, n_adj_edges, n_nodes, n_nodes, 0, adj_rowptr, adj_src, adj_eid, result + 1, ws_csr, csr_b, stream);
+        rc = tgnn_csr_build(adj_edge_index, n_adj_edges, n_nodes, n_src_nodes, 0, adj_rowptr, adj_src, adj_eid, result + 1, ws_csr, csr_b, stream);
         if (rc != TGNN_OK) return rc;
-        rc = tgnn_csr_build(col_edge_index, n_col_edges, n_nodes, n_nodes, 1, col_rowptr, col_src, col_eid, result + 2, ws_csr, csr_b, stream);
+        rc = tgnn_csr_build(col_edge_index, n_col_edges, n_nodes, n_src_nodes, 1, col_rowptr, col_src, col_eid, result + 2, ws_csr, csr_b, stream);
         if (rc != TGNN_OK) return rc;
     }
     if (s_side) {

@@ -283,6 +283,14 @@ void launch_shard_sum_peers(const double *peer_sums, const double *own, int worl
 // adds the shards' sums in rank order and writes both records (jobs.job[k].stat, running statistics).  world <= 64.
 void launch_shard_pack_sums(const float *a1, const float *a2, const int *idx, int64_t n_rows, const BnJobs &jobs, float *out,
                             hipStream_t s);
+// collectives over RCCL on stream s (rccl_comm.hip); comm from tgnn_rccl_comm_create
+int rccl_alltoall_rows(void *comm, const float *send, float *recv, const int64_t *send_counts, const int64_t *recv_counts,
+                       int world, int32_t row_floats, int32_t extra_rows, hipStream_t s);
+int rccl_allreduce_f64(void *comm, double *buf, int64_t count, hipStream_t s);
+// one branch at a time (rows of 32 floats; 4 sums rows = 64 doubles per peer): the split exchange of forward.hip
+void launch_shard_pack1(const float *a, const int *idx, int64_t n_rows, const BnJob &job, float *out, hipStream_t s);
+void launch_shard_unpack1(const float *in, const int *idx, int64_t n_rows, int64_t n_own, float *a, const BnJob &job, int world,
+                          int rank, int64_t n_total, float eps, float momentum, hipStream_t s);
 void launch_shard_unpack_finalize(const float *in, const int *idx, int64_t n_rows, int64_t n_own, float *a1, float *a2,
                                   const BnJobs &jobs, int world, int rank, int64_t n_total, float eps, float momentum,
                                   hipStream_t s);

@@ -355,7 +355,7 @@ class FusedShardForward:
     the local BatchNorm sums to every peer (27 collectives per forward); fused=False: all-reduce of the sums, then
     all-to-all of the merged rows (47)."""
 
-    def __init__(self, net, shard: Shard, device, comm, inputs=None, fused: bool = True):
+    def __init__(self, net, shard: Shard, device, comm, inputs=None, fused: bool = True, rccl: "LibraryRccl" = None):
         import ctypes as C
         from . import _lib, ops
         self._C, self._lib, self._ops = C, _lib, ops
@@ -372,6 +372,9 @@ class FusedShardForward:
         self.send_buf = torch.zeros(max(self.n_send + 4 * world, 1) * 2 * c, dtype=torch.float32, device=self.dev)
         self.recv_buf = torch.zeros(max(self.n_halo + 4 * world, 1) * 2 * c, dtype=torch.float32, device=self.dev)
         self._error = None
+        # rccl given: the library issues the collectives itself (csrc/rccl_comm.hip) -- `comm` is then only the fallback
+        self.rccl = rccl
+        self._counts = ((C.c_int64 * world)(*self.send_splits), (C.c_int64 * world)(*self.recv_splits))
         # fused layers (one all-to-all per layer, include/tgnn.h): per peer its rows, then 4 rows of BatchNorm sums
         send_ext, recv_ext, halo_at = [], [], 0
         for p_ in range(world):
@@ -391,22 +394,39 @@ class FusedShardForward:
         self.send_idx_fused = torch.from_numpy(np.concatenate(send_ext)).to(self.dev)
         self.recv_idx_fused = torch.from_numpy(np.concatenate(recv_ext)).to(self.dev)
 
-        def allreduce_cb(_ctx, _buf, count, _stream):
+        self._ext_streams = {}
+
+        def on_stream(stream_ptr):
+            """The collective goes onto the stream the library names (the side stream for the collision branch's exchange)."""
+            import contextlib
+            if not stream_ptr or self.dev.type != "cuda":
+                return contextlib.nullcontext()
+            st = self._ext_streams.get(stream_ptr)
+            if st is None:
+                st = self._ext_streams[stream_ptr] = torch.cuda.ExternalStream(stream_ptr, device=self.dev)
+            return torch.cuda.stream(st)
+
+        def allreduce_cb(_ctx, _buf, count, stream_ptr):
             try:
-                self.comm.allreduce(self.sum_buf[:count])
+                with on_stream(stream_ptr):
+                    self.comm.allreduce(self.sum_buf[:count])
                 return 0
             except BaseException as exc:                      # never let an exception cross the C frame
                 self._error = exc
                 return 1
 
-        def alltoall_cb(_ctx, _send, _recv, row_floats, extra_rows, _stream):
+        def alltoall_cb(_ctx, send_ptr, recv_ptr, row_floats, extra_rows, stream_ptr):
             try:
                 n_out = self.n_send + extra_rows * self.shard.world
                 n_in = self.n_halo + extra_rows * self.shard.world
-                send = self.send_buf[: n_out * row_floats].view(n_out, row_floats)
-                recv = self.recv_buf[: n_in * row_floats].view(n_in, row_floats)
-                self.comm.alltoall(send, [k + extra_rows for k in self.send_splits], recv,
-                                   [k + extra_rows for k in self.recv_splits])
+                # (the split exchange hands over the second halves of the two buffers for the collision branch)
+                so = (send_ptr - self.send_buf.data_ptr()) // 4 if send_ptr else 0
+                ro = (recv_ptr - self.recv_buf.data_ptr()) // 4 if recv_ptr else 0
+                send = self.send_buf[so: so + n_out * row_floats].view(n_out, row_floats)
+                recv = self.recv_buf[ro: ro + n_in * row_floats].view(n_in, row_floats)
+                with on_stream(stream_ptr):
+                    self.comm.alltoall(send, [k + extra_rows for k in self.send_splits], recv,
+                                       [k + extra_rows for k in self.recv_splits])
                 return 0
             except BaseException as exc:
                 self._error = exc
@@ -429,7 +449,9 @@ class FusedShardForward:
                               self._cbs[0], self._cbs[1], None, sh.world, sh.rank,
                               self.send_idx_fused.data_ptr() if self.fused else None,
                               self.recv_idx_fused.data_ptr() if self.fused else None,
-                              _lib.side_stream(self.dev) if self.two_streams else None)
+                              _lib.side_stream(self.dev) if self.two_streams else None,
+                              self.rccl.comm if self.rccl else None, self.rccl.comm_side if self.rccl else None,
+                              C.cast(self._counts[0], C.c_void_p), C.cast(self._counts[1], C.c_void_p))
         g = graph.c_struct()
         self._error = None
         rc = _lib.lib.tgnn_forward_sharded(C.byref(dims), table, ops.ptr(inp["x"]), ops.ptr(inp["attr"]), C.byref(g),
@@ -439,6 +461,54 @@ class FusedShardForward:
             raise self._error
         _lib.check(rc)
         return probs
+
+
+class LibraryRccl:
+    """Two RCCL communicators of the library's own (csrc/rccl_comm.hip: main chain / side stream) for FusedShardForward.  Every
+    rank of the torch.distributed job constructs one (a collective): rank 0 draws the unique ids, torch.distributed carries
+    the 128 bytes to the others -- its only part; the forward's collectives then never touch Python."""
+
+    def __init__(self, device, group=None):
+        import ctypes as C
+        import torch.distributed as dist
+        from . import _lib
+        self._lib, self._C = _lib, C
+        # The forward's side stream must exist BEFORE the communicators: HIP hands its (by default 4) hardware queues to streams
+        # round robin in creation order, RCCL creates streams of its own, and a side stream created behind them came to share
+        # the main stream's queue -- the two chains then ran strictly one after the other (rocprof: every kernel on one queue)
+        _lib.side_stream(torch.device(device))
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        nbytes = int(_lib.lib.tgnn_rccl_unique_id_bytes())
+        ids = [None, None]
+        if rank == 0:
+            for k in range(2):
+                buf = (C.c_ubyte * nbytes)()
+                _lib.check(_lib.lib.tgnn_rccl_unique_id(buf))
+                ids[k] = bytes(buf)
+        dist.broadcast_object_list(ids, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        handles = []
+        with torch.cuda.device(device):
+            for k in range(2):
+                h = C.c_void_p()
+                buf = (C.c_ubyte * nbytes).from_buffer_copy(ids[k])
+                _lib.check(_lib.lib.tgnn_rccl_comm_create(buf, rank, world, C.byref(h)))
+                handles.append(h)
+        self.comm, self.comm_side = handles
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def counters():
+        import ctypes as C
+        from . import _lib
+        out = (C.c_int64 * 2)()
+        _lib.lib.tgnn_rccl_counters(out)
+        return int(out[0]), int(out[1])
+
+    def close(self):
+        for h in (self.comm, self.comm_side):
+            if h:
+                self._lib.lib.tgnn_rccl_comm_destroy(h)
+        self.comm = self.comm_side = None
 
 
 class TorchDistCollectives:
@@ -513,14 +583,32 @@ class ShardedTilinGNN:
         self.inputs = self.backend.upload(shard)          # resident in HBM before any timed step
         self.program = None
         self.collectives = TorchDistCollectives(group)
-        self.fused = FusedShardForward(net, shard, device, self.collectives, inputs=self.inputs)
+        # the collectives of the fused forward: issued by the library over RCCL communicators of its own (default where the
+        # job runs on "nccl" = RCCL and librccl is found; TGNN_LIBRARY_RCCL=0: host callbacks into torch.distributed) -- and
+        # then with the split exchange (the collision branch's all-to-all on the side stream)
+        import os
+        import torch.distributed as dist
+        from . import _lib
+        self.rccl = None
+        if (torch.device(device).type == "cuda" and dist.get_backend(group) == "nccl" and _lib.lib.tgnn_rccl_available()
+                and os.environ.get("TGNN_LIBRARY_RCCL", "1") == "1"):
+            self.rccl = LibraryRccl(device, group)
+        self.fused = FusedShardForward(net, shard, device, self.collectives, inputs=self.inputs, rccl=self.rccl)
+        self.fused.two_streams = self.rccl is not None
+        self._rccl0 = LibraryRccl.counters() if self.rccl else (0, 0)
         self.steps = 0
 
     @property
     def collectives_per_forward(self):
-        """{all_to_all, all_reduce} issued through torch.distributed per fused forward (counted, not assumed)."""
+        """{all_to_all, all_reduce} issued per fused forward (counted, not assumed): by the library's RCCL calls or through
+        torch.distributed."""
         k = max(self.steps, 1)
-        return {"all_to_all_single": self.collectives.n_alltoall / k, "all_reduce": self.collectives.n_allreduce / k}
+        if self.rccl:
+            a2a, ar = LibraryRccl.counters()
+            return {"all_to_all_single": (a2a - self._rccl0[0]) / k, "all_reduce": (ar - self._rccl0[1]) / k,
+                    "issued_by": "library (ncclSend / ncclRecv groups, ncclAllReduce)"}
+        return {"all_to_all_single": self.collectives.n_alltoall / k, "all_reduce": self.collectives.n_allreduce / k,
+                "issued_by": "torch.distributed (host callbacks)"}
 
     def step(self, fused: bool = True) -> Tensor:
         """One forward of this rank's shard, graph preparation included (as in the 1-GPU benchmark).

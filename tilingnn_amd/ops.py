@@ -238,7 +238,8 @@ def _small_prep_counters(dev, _cache={}):
 SMALL_PREP = True      # one library call per layout (up to 4 096 nodes: one launch, tgnn_graph_prep_small); False: the separate calls
 
 
-def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, small: bool) -> Optional[PreparedGraph]:
+def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, small: bool,
+                         n_src_nodes: Optional[int] = None) -> Optional[PreparedGraph]:
     """prepare_graph as ONE library call + the one sync: `small`: tgnn_graph_prep_small (one launch); else tgnn_graph_prep
     (the launches of the separate calls, queued by the library without a host round trip).  None = fall back."""
     ea, ec = int(adj.shape[1]), int(col.shape[1])
@@ -265,7 +266,7 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
     v = [buf[o:o + sz] for o, sz in zip(offs, sizes)]
     (a_rowptr, a_src, a_eid, adj_type, edge_type, rep, c_rowptr, c_src, c_eid, tile_col_ptr, col_meta, col_slot_src, res, tmp,
      st_ptr, st_src, st_rl, st_info, st_inv) = v
-    head = (ptr(adj), ea, ptr(attr), fe, ptr(col), ec, n_nodes, ptr(a_rowptr), ptr(a_src), ptr(a_eid), ptr(adj_type), ptr(edge_type),
+    head = (ptr(adj), ea, ptr(attr), fe, ptr(col), ec, n_nodes) + (() if small else (n_src_nodes or n_nodes,)) + (ptr(a_rowptr), ptr(a_src), ptr(a_eid), ptr(adj_type), ptr(edge_type),
             ptr(rep), ptr(c_rowptr), ptr(c_src), ptr(c_eid), ptr(tile_col_ptr), ptr(col_meta), ptr(col_slot_src))
     if small:
         check(lib.tgnn_graph_prep_small(*head, ptr(tmp), ptr(res), ptr(_small_prep_counters(dev)), _stream(adj)))
@@ -295,9 +296,10 @@ def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col
     ea, ec = int(adj.shape[1]), int(col.shape[1])
     if adj_e_features.shape[0] != ea:
         raise ValueError(f"adj_e_features has {adj_e_features.shape[0]} rows for {ea} edges")
-    if SMALL_PREP and tile_width == 32 and n_src_nodes is None and columns in (None, True) and COLS_MIN_NODES == 0 and n_nodes >= 1:
-        small = n_nodes <= _small_prep_limits()[0] and max(ea, ec) <= _small_prep_limits()[1]
-        g = _prepare_graph_fused(n_nodes, adj, adj_e_features, col, small)
+    if SMALL_PREP and tile_width == 32 and columns in (None, True) and COLS_MIN_NODES == 0 and n_nodes >= 1:
+        # (a shard's layout -- sources behind the destination rows -- goes through the any-size call)
+        small = n_src_nodes is None and n_nodes <= _small_prep_limits()[0] and max(ea, ec) <= _small_prep_limits()[1]
+        g = _prepare_graph_fused(n_nodes, adj, adj_e_features, col, small, n_src_nodes)
         if g is not None:
             return g
     a_rowptr, a_src, a_eid, a_err = build_csr(adj, n_nodes, False, n_src_nodes)
