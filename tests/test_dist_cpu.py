@@ -55,7 +55,10 @@ def _graph(kind):
     if kind == "labyrinth":
         g = load_labyrinth_graph()
         return g["x"].astype(np.float64), g["adj"], g["adj_attr"].astype(np.float64), g["col"]
-    sg = make_super_graph(3000, 24000, 30000, tile_count=2, n_edge_types=13, seed=5)
+    if kind == "config4_20k":      # BASELINE configs[3] (500k nodes, 6M + 7.5M edges, two tile classes) at 1 / 25 of its size
+        sg = make_super_graph(20000, 240000, 300000, tile_count=2, n_edge_types=13, seed=7)
+    else:
+        sg = make_super_graph(3000, 24000, 30000, tile_count=2, n_edge_types=13, seed=5)
     return sg.node_feature, sg.align_edge_index, sg.align_edge_features, sg.collide_edge_index
 
 
@@ -104,11 +107,51 @@ def test_sharded_forward_equals_oracle_forward(world):
     assert float((got - want).abs().max()) < 1e-9
 
 
-def test_two_process_gloo_run_matches_oracle(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_rounds_of_local_compaction_equal_the_oracle_sub_layouts(world):
+    """The greedy loop scores, every round, the sub-layout of the still unlabelled nodes (reference: util/algorithms.py:18-62,
+    tiling/brick_layout.py:248-286).  Sharded, every rank cuts its shard of that sub-layout out of its shard of the round
+    before (dist.compact_shard: mask -> local compact -> halo-list rebuild).  Three rounds with shrinking alive sets: the
+    sharded forward over the compacted shards equals the oracle's forward over oracle.greedy_oracle.compute_sub_layout."""
+    from oracle import greedy_oracle as go
+    x, adj, attr, col = _graph("synthetic")
+    n = x.shape[0]
+    depth, width, fe, fx = 3, 32, attr.shape[1], x.shape[1]
+    sd = make_state_dict(fe, depth, width, 1, fx, seed=4)
+    net = _param_holder(sd, depth, width, fe, fx)
+    shards = [tdist.make_shard(x, adj, attr, col, r, world) for r in range(world)]
+    rng = np.random.default_rng(9)
+    alive_orig = np.ones(n, dtype=bool)                     # over the ORIGINAL numbering (what the oracle cuts from)
+    dummy = np.zeros((col.shape[1], 1))
+    for keep in (0.7, 0.6, 0.3):
+        ids_before = np.flatnonzero(alive_orig)
+        alive_orig &= rng.uniform(size=n) < keep
+        if keep == 0.6:
+            alive_orig[: n // world] = False                # a rank left without a single node
+        alive_rel = alive_orig[ids_before]                  # over the numbering of the round before (what the ranks hold)
+        shards = [tdist.compact_shard(s, alive_rel) for s in shards]
+        tdist.LocalSimComm.setup(shards)
+        assert sum(s.n_own for s in shards) == int(alive_orig.sum()) and all(s.n_total == int(alive_orig.sum()) for s in shards)
+        sub = go.compute_sub_layout(x, adj, attr, col, dummy, np.flatnonzero(alive_orig))
+        for s in shards:                                    # the shard's rows ARE the sub-layout's rows of its range
+            np.testing.assert_array_equal(s.x, sub[0][s.lo:s.lo + s.n_own])
+        be = OracleBackend()
+        got = torch.cat(tdist.LocalSimComm.run([tdist.ShardProgram(net, s, be, update_running=False) for s in shards]))
+        with torch.no_grad():
+            want, _ = orc.tilingnn_forward(orc.cast_sd(sd, torch.float64), torch.from_numpy(sub[0]), torch.from_numpy(sub[1]),
+                                           torch.from_numpy(sub[2]), torch.from_numpy(sub[3]))
+        assert got.shape == want.shape and float((got - want).abs().max()) < 1e-9
+
+
+@pytest.mark.parametrize("kind,dedup", [("labyrinth", False), ("config4_20k", True)])
+def test_two_process_gloo_run_matches_oracle(tmp_path, kind, dedup):
     """Real torch.distributed ranks (gloo, world_size 2) through TorchDistComm: setup all-to-all of the halo id
-    lists, 21 halo exchanges and 26 BN all-reduces of a depth-20 forward."""
+    lists, 21 halo exchanges and 26 BN all-reduces of a depth-20 forward -- on the labyrinth layout and on a layout of
+    BASELINE configs[3]'s shape (20 000 nodes, 12 + 15 edges per node; there the edge MLP runs on the distinct attribute rows
+    only, on both sides: oracle.nnconv_mean_dedup, pinned to the port)."""
     script = tmp_path / "rank.py"
     script.write_text(f'''
+KIND, DEDUP = {kind!r}, {dedup!r}
 import sys, os, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, {REPO!r})
 from oracle import tilingnn_oracle as orc
@@ -118,13 +161,15 @@ from tilingnn_amd import dist as tdist
 from tilingnn_amd.weights import make_state_dict
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-x, adj, attr, col = _graph("labyrinth")
+x, adj, attr, col = _graph(KIND)
+if DEDUP:
+    orc.nnconv_mean = orc.nnconv_mean_dedup
 sd = make_state_dict(attr.shape[1], 20, 32, 1, x.shape[1], seed=0)
 net = _param_holder(sd, 20, 32, attr.shape[1], x.shape[1])
 shard = tdist.make_shard(x, adj, attr, col, rank, world)
 comm = tdist.TorchDistComm()
 comm.setup(shard)
-probs = comm.run(tdist.ShardProgram(net, shard, OracleBackend(), update_running=False))
+probs = comm.run(tdist.ShardProgram(net, shard, OracleBackend(dedup_rows=DEDUP), update_running=False))
 gathered = [torch.empty(tdist.node_range(x.shape[0], r, world)[1] - tdist.node_range(x.shape[0], r, world)[0], 1,
                         dtype=torch.float64) for r in range(world)]
 dist.all_gather(gathered, probs.contiguous())

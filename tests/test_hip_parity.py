@@ -655,8 +655,10 @@ def test_sharded_hip_path_matches_unsharded(dev, world, general_schedule, bf16x3
             assert float((a[k + ".running_var"] - b[k + ".running_var"]).abs().max()) < 1e-5
 
 
-@pytest.mark.parametrize("world,one_collective", [(1, True), (2, True), (4, True), (3, True), (2, False), (4, False)])
-def test_fused_sharded_forward_matches_unsharded(dev, world, one_collective, general_schedule):
+@pytest.mark.parametrize("world,one_collective,split", [(1, True, False), (2, True, False), (4, True, False), (3, True, False),
+                                                        (2, False, False), (4, False, False), (2, True, True), (4, True, True),
+                                                        (3, True, True)])
+def test_fused_sharded_forward_matches_unsharded(dev, world, one_collective, split, general_schedule):
     """tgnn_forward_sharded (the whole shard schedule in one library call, collectives through callbacks): P
     virtual ranks = P threads on this one GPU (ThreadSimCollectives) against the unsharded forward; both collective
     schemes: one all-to-all per layer carrying raw halo rows + BatchNorm sums (default) and all-reduce + all-to-all;
@@ -676,6 +678,8 @@ def test_fused_sharded_forward_matches_unsharded(dev, world, one_collective, gen
         hub = tdist.ThreadSimCollectives.Hub(world)
         runners = [tdist.FusedShardForward(nets[r], shards[r], dev, tdist.ThreadSimCollectives(hub, r), fused=one_collective)
                    for r in range(world)]
+        for rn in runners:       # split: one all-to-all per BRANCH and layer, the collision branch's chain on the side stream
+            rn.two_streams = split
         parts, errors = [None] * world, []
 
         def work(r):
@@ -707,10 +711,77 @@ def test_fused_sharded_forward_matches_unsharded(dev, world, one_collective, gen
             assert float((a[k + ".running_mean"] - b[k + ".running_mean"]).abs().max()) < 1e-5
 
 
+def test_sharded_greedy_rounds_score_like_the_single_gpu_loop(dev, general_schedule):
+    """The assembly loop (reference: util/algorithms.py:18-62) on a layout that stays SHARDED: the product's single-GPU loop
+    runs (tilingnn_amd.util.algorithms.solve_by_probablistic_greedy: device compaction + forward per round); beside its first
+    rounds four thread-simulated ranks cut their shards of the same sub-layout locally (dist.compact_shard: mask -> local
+    compact -> halo-list rebuild, send lists exchanged again) and score it with tgnn_forward_sharded (split exchange):
+    the gathered probabilities equal the single-GPU round's."""
+    import threading
+    from tilingnn_amd import dist as tdist
+    from tilingnn_amd.solver.ml_solver.ml_solver import LayoutArrays, ML_Solver
+    from tilingnn_amd.synth import make_super_graph
+    from tilingnn_amd.util.algorithms import solve_by_probablistic_greedy
+    world, n = 4, 6000
+    sg = make_super_graph(n, 60000, 75000, tile_count=2, n_edge_types=13, seed=21)
+    net, _ = make_net(dev, depth=5)
+    nets = [make_net(dev, depth=5)[0] for _ in range(world)]
+    layout = LayoutArrays(sg.node_feature, sg.align_edge_index, sg.align_edge_features, sg.collide_edge_index,
+                          np.zeros((sg.collide_edge_index.shape[1], 1), dtype=np.float32))
+    solver = ML_Solver(None, dev, None, net, num_prob_maps=1)
+    state = {"shards": [tdist.make_shard(sg.node_feature, sg.align_edge_index, sg.align_edge_features, sg.collide_edge_index, r,
+                                         world) for r in range(world)],
+             "ids": np.arange(n), "round": 0, "errs": []}
+
+    def on_round(sub):
+        if state["round"] >= 4:
+            return
+        ids = sub.inverse_index.cpu().numpy()                      # original ids of this round's nodes, ascending
+        if state["round"] > 0:                                    # every rank: its shard of the sub-layout from the one before
+            alive_rel = np.isin(state["ids"], ids)
+            state["shards"] = [tdist.compact_shard(s, alive_rel) for s in state["shards"]]
+        state["ids"] = ids
+        shards = state["shards"]
+        assert sum(s.n_own for s in shards) == ids.shape[0] and all(s.n_own > 0 for s in shards)
+        tdist.LocalSimComm.setup(shards)
+        hub = tdist.ThreadSimCollectives.Hub(world)
+        runners = [tdist.FusedShardForward(nets[r], shards[r], dev, tdist.ThreadSimCollectives(hub, r)) for r in range(world)]
+        parts, errors = [None] * world, []
+
+        def work(r):
+            try:
+                torch.cuda.set_device(dev)
+                runners[r].two_streams = True
+                parts[r] = runners[r].step()
+            except BaseException as exc:
+                errors.append(exc)
+                hub.barrier.abort()
+        threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=120)
+        assert not errors, errors
+        torch.cuda.synchronize()
+        got = torch.cat(parts)
+        want = net(x=sub.node_feature, adj_e_index=sub.align_edge_index, adj_e_features=sub.align_edge_features,
+                   col_e_idx=sub.collide_edge_index)[0]
+        err = float((got - want).abs().max())
+        print(f"round {state['round']}: {ids.shape[0]} nodes alive, max |sharded - single| = {err:.2e}")
+        state["errs"].append(err)
+        state["round"] += 1
+
+    np.random.seed(3)
+    selection, _, order = solve_by_probablistic_greedy(solver, layout, score_fn=lambda *a, **k: 0.0, on_round=on_round)
+    assert state["round"] >= 3 and max(state["errs"]) < 1e-5, state["errs"]
+    assert selection.sum() == len(order) > 0
+
+
 @pytest.mark.parametrize("one_collective", [True, False])
 def test_sharded_forward_with_the_collision_branch_on_a_side_stream(dev, one_collective, general_schedule):
-    """tgnn_shard.side_stream: a layer's collision branch beside its adjacency branch (off by default: measured slower).  Same
-    kernels, same order of every sum: the same bits as on one stream."""
+    """tgnn_shard.side_stream: the collision branch on a stream of its own -- with one all-to-all per layer only its
+    neighbourhood sum, in the fused mode the SPLIT exchange (the branch's GIN, its own all-to-all and statistics run ahead of the
+    adjacency chain; what the RCCL path runs by default).  Same kernels, same order of every sum: the same bits as on one stream."""
     from tilingnn_amd import dist as tdist
     from tilingnn_amd.synth import make_super_graph
     sg = make_super_graph(6000, 60000, 75000, tile_count=2, n_edge_types=13, seed=8)

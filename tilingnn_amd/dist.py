@@ -50,20 +50,28 @@ class Shard:
     adj_attr: np.ndarray
     col: np.ndarray                # [2, Ec_loc] int64, local ids
     send_ids: Optional[List[np.ndarray]] = None   # owned LOCAL row ids every peer needs (filled by setup)
+    bounds: Optional[np.ndarray] = None           # [world + 1] first global id of every rank's range (None: the even split of
+                                                  # node_range; set by compact_shard, whose ranges follow the surviving nodes)
 
     @property
     def n_rows(self) -> int:
         return self.n_own + int(self.halo_ids.shape[0])
 
 
-def node_range(n_total: int, rank: int, world: int):
+def node_range(n_total: int, rank: int, world: int, bounds: Optional[np.ndarray] = None):
+    if bounds is not None:
+        return int(bounds[rank]), int(bounds[rank + 1])
     return n_total * rank // world, n_total * (rank + 1) // world
 
 
-def owner_of(ids: np.ndarray, n_total: int, world: int) -> np.ndarray:
+def even_bounds(n_total: int, world: int) -> np.ndarray:
+    return np.array([n_total * r // world for r in range(world + 1)], dtype=np.int64)
+
+
+def owner_of(ids: np.ndarray, n_total: int, world: int, bounds: Optional[np.ndarray] = None) -> np.ndarray:
     """Rank owning each global node id (inverse of node_range)."""
-    bounds = np.array([n_total * r // world for r in range(1, world + 1)], dtype=np.int64)
-    return np.searchsorted(bounds, ids, side="right")
+    ends = np.asarray(bounds[1:] if bounds is not None else even_bounds(n_total, world)[1:], dtype=np.int64)
+    return np.searchsorted(ends, ids, side="right")
 
 
 def make_shard(node_feature: np.ndarray, adj: np.ndarray, adj_attr: np.ndarray, col: np.ndarray, rank: int,
@@ -92,16 +100,58 @@ def make_shard(node_feature: np.ndarray, adj: np.ndarray, adj_attr: np.ndarray, 
                  adj_attr[keep_a], localise(c))
 
 
-def exchange_send_lists(shards_halo_ids: Sequence[np.ndarray], n_total: int, world: int) -> List[List[np.ndarray]]:
+def exchange_send_lists(shards_halo_ids: Sequence[np.ndarray], n_total: int, world: int,
+                        bounds: Optional[np.ndarray] = None) -> List[List[np.ndarray]]:
     """send_ids[r][p] = LOCAL owned row ids of rank r that rank p holds in its halo (what the setup
     all-to-all of id lists produces on real ranks)."""
     out = [[np.empty(0, dtype=np.int64) for _ in range(world)] for _ in range(world)]
     for p, ids in enumerate(shards_halo_ids):
-        owners = owner_of(ids, n_total, world)
+        owners = owner_of(ids, n_total, world, bounds)
         for r in range(world):
             sel = ids[owners == r]
-            out[r][p] = sel - node_range(n_total, r, world)[0]
+            out[r][p] = sel - node_range(n_total, r, world, bounds)[0]
     return out
+
+
+def compact_shard(shard: Shard, alive: np.ndarray) -> Shard:
+    """A greedy round later (the reference's util/algorithms.py:18-62 scores, every round, the sub-layout of the still
+    unlabelled nodes: tiling/brick_layout.py:248-286): this rank's shard of that sub-layout, cut LOCALLY from its shard of the
+    round before -- mask -> local compact -> halo-list rebuild -- with no gather of the layout anywhere.
+      alive: bool [shard.n_total] over the CURRENT global numbering (every rank holds it: the acceptance sweep is a host
+      loop over the gathered probabilities).
+    The sub-layout's nodes are numbered as compute_sub_layout numbers them (rank among the alive ones), every rank keeps the
+    survivors of its own range (so the ranges stay contiguous: `bounds`), an edge survives iff both ends do, in its old order;
+    the halo = the alive remote sources of the surviving edges.  The communicator's setup must run again (send lists)."""
+    world, rank = shard.world, shard.rank
+    alive = np.asarray(alive, dtype=bool)
+    assert alive.shape[0] == shard.n_total
+    old_bounds = shard.bounds if shard.bounds is not None else even_bounds(shard.n_total, world)
+    prefix = np.concatenate([[0], np.cumsum(alive, dtype=np.int64)])          # new id of node g (if alive) = prefix[g]
+    new_bounds = prefix[old_bounds]
+    lo, hi = int(old_bounds[rank]), int(old_bounds[rank + 1])
+    nlo, nhi = int(new_bounds[rank]), int(new_bounds[rank + 1])
+    gid = np.concatenate([np.arange(lo, hi, dtype=np.int64), shard.halo_ids.astype(np.int64)])   # global id of every local row
+    row_alive = alive[gid]
+    new_gid = prefix[gid]
+
+    def cut(e):
+        keep = row_alive[e[0]] & row_alive[e[1]]
+        return keep, new_gid[e[:, keep]]                                       # surviving edges in NEW global ids
+    keep_a, a = cut(shard.adj)
+    keep_c, c = cut(shard.col)
+    srcs = np.concatenate([a[0], c[0]])
+    remote = np.unique(srcs[(srcs < nlo) | (srcs >= nhi)])
+    owners = np.searchsorted(new_bounds[1:], remote, side="right")
+    recv_counts = [int(np.count_nonzero(owners == r)) for r in range(world)]
+
+    def localise(e):
+        out = np.empty_like(e)
+        out[1] = e[1] - nlo
+        own = (e[0] >= nlo) & (e[0] < nhi)
+        out[0] = np.where(own, e[0] - nlo, (nhi - nlo) + np.searchsorted(remote, e[0]))
+        return out
+    return Shard(rank, world, int(prefix[-1]), nlo, nhi - nlo, remote, recv_counts, shard.x[alive[lo:hi]], localise(a),
+                 shard.adj_attr[keep_a], localise(c), None, new_bounds)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -308,7 +358,7 @@ class LocalSimComm:
 
     @staticmethod
     def setup(shards: Sequence[Shard]) -> None:
-        lists = exchange_send_lists([s.halo_ids for s in shards], shards[0].n_total, shards[0].world)
+        lists = exchange_send_lists([s.halo_ids for s in shards], shards[0].n_total, shards[0].world, shards[0].bounds)
         for r, s in enumerate(shards):
             s.send_ids = lists[r]
 
