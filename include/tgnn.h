@@ -500,6 +500,13 @@ int tgnn_forward_profiled_two_stream(const tgnn_model_dims *dims, const void *co
                                      const float *adj_edge_attr, const tgnn_graph *graph, int32_t update_running,
                                      float *probs, void *ws, size_t ws_bytes, tgnn_stream_t stream, tgnn_stream_t stream2,
                                      float *class_ms_host, int32_t *class_launches_host);
+/* The PRODUCTION forward (tgnn_forward, train mode, two chains when stream2 is given; no event, no profiler) with the column
+ * NNConv launches stamped on the device's wall clock: nnconv_us_host [network_depth] = last block out - first block in of every
+ * layer's launch, microseconds -- the duration a kernel trace reports, measured inside the schedule as it runs (0 where the
+ * layer did not go through the column kernel: small layouts, no column structure).  Synchronises both streams. */
+int tgnn_forward_stamped(const tgnn_model_dims *dims, const void *const *params_host, const float *x, const float *adj_edge_attr,
+                         const tgnn_graph *graph, int32_t update_running, float *probs, void *ws, size_t ws_bytes,
+                         tgnn_stream_t stream, tgnn_stream_t stream2, float *nnconv_us_host);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-GPU helpers: node-range shards exchange boundary rows each layer (RCCL does the moving)

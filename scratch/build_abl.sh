@@ -9,5 +9,5 @@ d=/tmp/abl_$tag; rm -rf $d; mkdir -p $d $REPO/scratch/libs
 cp $REPO/build/csrc/*.o $d/
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DTGNN_ABL_$tag "$@" \
     -c $REPO/tilingnn_amd/csrc/$stem.hip -o $d/$stem.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $REPO/scratch/libs/libtgnn_$tag.so $d/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $REPO/scratch/libs/libtgnn_$tag.so $d/*.o -ldl
 echo built scratch/libs/libtgnn_$tag.so

@@ -93,6 +93,7 @@ struct Prof {
     bool on = false;
     unsigned class_mask = ~0u;       // two-stream mode: only these classes (main-stream kernels) are bracketed
     bool two_stream = false, open = false;
+    unsigned long long *stamps = nullptr;   // tgnn_forward_stamped: [depth][2] device words for the NNConv launches' wall-clock stamps
     void begin(int sl) {
         open = on && ((class_mask >> sl) & 1u);
         if (!open) return;
@@ -506,7 +507,8 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
             TGNN_TRY(launch_nnconv_cols(h1, c, graph->nn_tile_col_ptr, graph->nn_col_meta, graph->nn_col_src,
                                         w.wimg + (size_t)i * (T + 1) * (f16 ? kWtTypeF16 : kWtType), T, P.f(b + 7), n,
                                         TGNN_ACT_LEAKY_RELU, w.a1, w.part1, &np1, s, f16 ? slot_max + i : nullptr,
-                                        f16 ? root_max + i : nullptr, graph->nn_max_in_degree));
+                                        f16 ? root_max + i : nullptr, graph->nn_max_in_degree,
+                                        prof.stamps ? prof.stamps + 2 * i : nullptr));
         } else {
             TGNN_TRY(tgnn_nnconv_mean_fwd(h1, c, graph->adj_rowptr, graph->adj_src, graph->adj_type,
                                       w.wtab + (size_t)i * T * c * c, T, P.f(b + 6), P.f(b + 7), n, c,
@@ -691,6 +693,37 @@ extern "C" int tgnn_forward_profiled(const tgnn_model_dims *dims, const void *co
                                 ws, ws_bytes, stream, nullptr, prof);
     prof.collect(class_ms_host, class_launches_host);
     return rc;
+}
+
+extern "C" int tgnn_forward_stamped(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
+                                    const float *adj_edge_attr, const tgnn_graph *graph, int32_t update_running, float *probs,
+                                    void *ws, size_t ws_bytes, tgnn_stream_t stream, tgnn_stream_t stream2,
+                                    float *nnconv_us_host) {
+    DeviceGuard guard__(stream);
+    TGNN_CHECK_ARG(nnconv_us_host && dims_ok(dims), "arguments");
+    const int D = dims->network_depth;
+    std::vector<unsigned long long> host(2 * (size_t)D);
+    for (int i = 0; i < D; ++i) { host[2 * i] = ~0ull; host[2 * i + 1] = 0ull; }
+    unsigned long long *dev_stamps = nullptr;
+    TGNN_CHECK_HIP(hipMalloc(&dev_stamps, host.size() * sizeof(unsigned long long)));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc = (int)hipMemcpyAsync(dev_stamps, host.data(), host.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, s);
+    if (rc == 0) {
+        Prof prof;
+        prof.stamps = dev_stamps;
+        rc = forward_impl(dims, params_host, x, adj_edge_attr, graph, update_running, 0, probs, ws, ws_bytes, stream, stream2, prof);
+    }
+    (void)hipStreamSynchronize(s);
+    if (stream2) (void)hipStreamSynchronize(static_cast<hipStream_t>(stream2));
+    if (rc == 0) rc = (int)hipMemcpy(host.data(), dev_stamps, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipFree(dev_stamps);
+    if (rc != 0) return rc < 0 ? rc : TGNN_ERR_LAUNCH;
+    int dev = 0, khz = 100000;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev);
+    for (int i = 0; i < D; ++i)
+        nnconv_us_host[i] = host[2 * i + 1] > host[2 * i] ? (float)((double)(host[2 * i + 1] - host[2 * i]) * 1e3 / (double)khz) : 0.f;
+    return TGNN_OK;
 }
 
 extern "C" int tgnn_forward_profiled_two_stream(const tgnn_model_dims *dims, const void *const *params_host, const float *x,

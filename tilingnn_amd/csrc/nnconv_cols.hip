@@ -47,8 +47,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
     const float *__restrict__ h, int64_t ldh, const int *__restrict__ tile_col_ptr, const int *__restrict__ col_meta,
     const int *__restrict__ col_src, const float *__restrict__ wimg, int n_types, const float *__restrict__ bias,
     int64_t n, int act, float *__restrict__ out, double *__restrict__ bn_partial, const unsigned *__restrict__ h_max,
-    const unsigned *__restrict__ root_max, int deg_log2) {
+    const unsigned *__restrict__ root_max, int deg_log2, unsigned long long *__restrict__ stamp) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // stamp (tgnn_forward_stamped): first block in / last block out on the device's wall clock -- the launch's duration as a
+    // kernel trace sees it, measured inside the production schedule without an event or a profiler around it
+    if (stamp && threadIdx.x == 0) atomicMin(stamp, wall_clock64());
     constexpr int kTy = F16 ? kWtTypeF16 : kWtType;         // floats of one type's image
     float *wl = lds;                                        // [(T+1)][3 (2) planes][2 M blocks][16][4] x 8 bf16 (fp16)
     float *stage = lds + (n_types + 1) * kTy;               // [WAVES][16][20]
@@ -320,6 +323,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
             bn_partial[(int64_t)blockIdx.x * 64 + tid] = acc;
         }
     }
+    if (stamp && tid == 0) atomicMax(stamp + 1, wall_clock64());
 #ifdef TGNN_TIMING
     TGNN_CT(7)
     if (lane == 0 && blockIdx.x < 512 && wave < 8)
@@ -340,7 +344,7 @@ static int launch_cols_t(const float *h, int64_t ldh, const int32_t *tile_col_pt
                          const int32_t *col_src, const float *wimg, int32_t n_types, const float *bias,
                          int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
                          int blocks_per_cu, hipStream_t s, const unsigned *h_max = nullptr, const unsigned *root_max = nullptr,
-                         int deg_log2 = 0) {
+                         int deg_log2 = 0, unsigned long long *stamp = nullptr) {
     auto kern = nnconv32_cols_kernel<DEPTH, WAVES, OCC, F16>;
     // the opt-in to > 64 KB of dynamic LDS is a per-device attribute of the function: set once per device (idempotent)
     static LdsOptIn site;
@@ -362,7 +366,7 @@ static int launch_cols_t(const float *h, int64_t ldh, const int32_t *tile_col_pt
     if (blocks >= 8) blocks &= ~7;
     if (blocks < 1) blocks = 1;
     kern<<<(unsigned)blocks, WAVES * 64, cols_lds_bytes(n_types, WAVES, F16), s>>>(
-        h, ldh, tile_col_ptr, col_meta, col_src, wimg, n_types, bias, n_nodes, act, out, bn_partial, h_max, root_max, deg_log2);
+        h, ldh, tile_col_ptr, col_meta, col_src, wimg, n_types, bias, n_nodes, act, out, bn_partial, h_max, root_max, deg_log2, stamp);
     if (n_partials_host) *n_partials_host = (int32_t)blocks;
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
@@ -371,23 +375,24 @@ static int launch_cols_t(const float *h, int64_t ldh, const int32_t *tile_col_pt
 int launch_nnconv_cols(const float *h, int64_t ldh, const int32_t *tile_col_ptr, const int32_t *col_meta,
                        const int32_t *col_src, const float *wimg, int32_t n_types, const float *bias,
                        int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
-                       hipStream_t s, const unsigned *h_max, const unsigned *root_max, int max_in_degree) {
+                       hipStream_t s, const unsigned *h_max, const unsigned *root_max, int max_in_degree,
+                       unsigned long long *stamp) {
     if (h_max && root_max && max_in_degree >= 1) {
         int deg_log2 = 0;
         while ((1 << deg_log2) < max_in_degree) ++deg_log2;
         // (always one 16-wave block per CU: two 8-wave blocks per CU -- they would fit, the fp16 image is 4 KB per type -- spread
         //  over ALL CUs and leave none to the collision chain's 1-block kernels: BatchNorm finalize 7.8 -> 15.2 us, rocprof)
         return launch_cols_t<4, 16, 4, true>(h, ldh, tile_col_ptr, col_meta, col_src, wimg, n_types, bias, n_nodes, act, out,
-                                             bn_partial, n_partials_host, 1, s, h_max, root_max, deg_log2);
+                                             bn_partial, n_partials_host, 1, s, h_max, root_max, deg_log2, stamp);
     }
     // 16 waves per CU either way: two 8-wave blocks when two 6 KB-per-type weight images fit the LDS (T <= 11), else
     // one 16-wave block.  Measured with the fp32 kernel at N = 100k, T = 13 (us): <depth 4, 16 waves/CU> 55.7 |
     // <16, 8> 66.0 | <8, 8> 64.9 | <16, 4> 85.2 | <32, 4> 90.2
     if (cols_lds_bytes(n_types, 8) * 2 <= 160 * 1024)
         return launch_cols_t<4, 8, 4>(h, ldh, tile_col_ptr, col_meta, col_src, wimg, n_types, bias, n_nodes, act, out,
-                                      bn_partial, n_partials_host, 2, s);
+                                      bn_partial, n_partials_host, 2, s, nullptr, nullptr, 0, stamp);
     return launch_cols_t<4, 16, 4>(h, ldh, tile_col_ptr, col_meta, col_src, wimg, n_types, bias, n_nodes, act, out,
-                                   bn_partial, n_partials_host, 1, s);
+                                   bn_partial, n_partials_host, 1, s, nullptr, nullptr, 0, stamp);
 }
 
 }  // namespace tgnn

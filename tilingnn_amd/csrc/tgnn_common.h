@@ -325,7 +325,7 @@ int launch_nnconv_cols(const float *h, int64_t ldh, const int32_t *tile_col_ptr,
                        const int32_t *col_src, const float *wimg, int32_t n_types, const float *bias,
                        int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
                        hipStream_t s, const unsigned *h_max = nullptr, const unsigned *root_max = nullptr,
-                       int max_in_degree = 0);
+                       int max_in_degree = 0, unsigned long long *stamp = nullptr);
 // the stream NNConv kernel (nnconv_stream.hip) over rows pre-split into fp16 pairs (launch_nnconv_split16: hs [rows][128 B],
 // hs_scale {s, 1/s}); wtab = one layer's [T][32][32] table; reserve_cus CUs stay free
 // largest |h[0 .. n_floats)| (n_floats % 4 == 0) as float bits, atomicMax into *max_bits; nnconv_stream.hip
