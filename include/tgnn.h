@@ -500,6 +500,18 @@ int tgnn_forward_profiled_two_stream(const tgnn_model_dims *dims, const void *co
                                      const float *adj_edge_attr, const tgnn_graph *graph, int32_t update_running,
                                      float *probs, void *ws, size_t ws_bytes, tgnn_stream_t stream, tgnn_stream_t stream2,
                                      float *class_ms_host, int32_t *class_launches_host);
+/* K independent layouts -- every one a batch of its own, exactly what K tgnn_forward calls compute -- queued in ONE call:
+ * layout k on streams[k % n_streams] (and the shared side stream stream2).  For small layouts (tgnn_set_small_layout_limit) the
+ * persistent kernels of different streams run side by side when they fit the device together: the reference's crop loop
+ * (Tiling-Shape.py:52-64) hands over layouts of ~1 000 nodes that fill a third of the chip each.  The caller orders `streams`
+ * with its own work before and after.  update_running != 0 with layouts sharing one parameter set: the K updates of the
+ * running statistics race (they do not enter train-mode outputs); pass 0 to leave them untouched.
+ * (HIP maps streams to hardware queues round robin, 4 by default: with GPU_MAX_HW_QUEUES=8 in the environment before the
+ *  runtime starts, three layout streams + the side stream do not share one.) */
+int tgnn_forward_many(const tgnn_model_dims *dims, const void *const *params_host, int32_t n_layouts, const float *const *x,
+                      const float *const *adj_edge_attr, const tgnn_graph *graphs, int32_t update_running,
+                      int32_t use_running_stats, float *const *probs, void *const *ws, const size_t *ws_bytes,
+                      const tgnn_stream_t *streams, int32_t n_streams, tgnn_stream_t stream2);
 /* The PRODUCTION forward (tgnn_forward, train mode, two chains when stream2 is given; no event, no profiler) with the column
  * NNConv launches stamped on the device's wall clock: nnconv_us_host [network_depth] = last block out - first block in of every
  * layer's launch, microseconds -- the duration a kernel trace reports, measured inside the schedule as it runs (0 where the

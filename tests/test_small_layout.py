@@ -306,3 +306,25 @@ def test_uncached_preparation_beside_a_persistent_forward_does_not_deadlock(dev)
     torch.cuda.synchronize()
     for k in range(2):
         assert torch.equal(got[k], want[k])
+
+
+def test_three_layouts_side_by_side_are_their_solo_runs(dev):
+    """TilinGNN.forward_many: K independent layouts (own BatchNorm populations), every one on a stream of its own, the
+    persistent kernels running beside each other when they fit the device together (the reference's crop loop,
+    Tiling-Shape.py:52-64, hands over such layouts one after the other).  Every result is bit-identical to the layout's solo
+    forward; repeated, with the layouts in another order and with more layouts than streams."""
+    from tilingnn_amd.synth import make_super_graph
+    net, _ = make_net(dev, depth=20)
+    g = load_labyrinth_graph()
+    layouts = [tuple(graph_tensors(g, torch.float32, dev)[:4])]
+    for n, seed in ((1100, 3), (900, 4), (1300, 5), (640, 6)):
+        sg = make_super_graph(n, 7 * n, 8 * n, tile_count=2, n_edge_types=13, seed=seed)
+        layouts.append(tuple(sg.to_torch(dev)[:4]))
+    solo = [net(x=l[0], adj_e_index=l[1], adj_e_features=l[2], col_e_idx=l[3])[0].clone() for l in layouts]
+    torch.cuda.synchronize()
+    for order in ([0, 1, 2], [2, 0, 1], [0, 1, 2, 3, 4], [4, 3, 2, 1, 0, 0]):
+        for _ in range(3):
+            outs = net.forward_many([layouts[i] for i in order])
+            torch.cuda.synchronize()
+            for i, o in zip(order, outs):
+                assert torch.equal(o, solo[i]), (order, i)

@@ -660,6 +660,23 @@ extern "C" int tgnn_forward(const tgnn_model_dims *dims, const void *const *para
                         ws_bytes, stream, stream2, prof);
 }
 
+extern "C" int tgnn_forward_many(const tgnn_model_dims *dims, const void *const *params_host, int32_t n_layouts,
+                                 const float *const *x, const float *const *adj_edge_attr, const tgnn_graph *graphs,
+                                 int32_t update_running, int32_t use_running_stats, float *const *probs, void *const *ws,
+                                 const size_t *ws_bytes, const tgnn_stream_t *streams, int32_t n_streams, tgnn_stream_t stream2) {
+    TGNN_CHECK_ARG(n_layouts >= 0 && n_streams >= 1 && x && adj_edge_attr && graphs && probs && ws && ws_bytes && streams,
+                   "arguments");
+    for (int k = 0; k < n_layouts; ++k) {
+        tgnn_stream_t st = streams[k % n_streams];
+        DeviceGuard guard__(st);
+        Prof prof;
+        const int rc = forward_impl(dims, params_host, x[k], adj_edge_attr[k], graphs + k, update_running, use_running_stats,
+                                    probs[k], ws[k], ws_bytes[k], st, stream2, prof);
+        if (rc != TGNN_OK) return rc;
+    }
+    return TGNN_OK;
+}
+
 extern "C" int tgnn_forward_train(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
                                   const float *adj_edge_attr, const tgnn_graph *graph, const tgnn_train_save *keep,
                                   float *probs, void *ws, size_t ws_bytes, tgnn_stream_t stream, tgnn_stream_t stream2) {

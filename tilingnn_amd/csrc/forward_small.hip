@@ -29,6 +29,8 @@
 // steps of 32), i.e. fp32 / fp64 rounding only.  Deterministic: every order is fixed.
 #include <mutex>
 
+#include <vector>
+
 #include "tgnn_common.h"
 
 namespace tgnn {
@@ -1117,17 +1119,47 @@ void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrie
 
 #define TGNN_TRY_SMALL(expr) do { const int rc__ = (expr); if (rc__ != TGNN_OK) return rc__; } while (0)
 
-int spin_kernel_chain(hipStream_t s, void (*launch)(void *ctx, hipStream_t s), void *ctx) {
+// Spin-barrier kernels need all their blocks resident at once; two of them started side by side could each hold part of the CUs
+// and wait for the rest for ever.  Every such launch passes through this per-device gate with the number of CUs it occupies:
+//   * it joins the kernels still in flight when all of them TOGETHER fit the device (`capacity` CUs: small layouts of
+//     different streams then run side by side -- three labyrinth-sized forwards, 79 CUs each, take the time of one);
+//   * else it waits for every one of them (events, whichever streams they are on) and runs behind them.
+// Invariant: the kernels that can be started-and-unfinished at any moment fit the device together -- the last one launched
+// among them either waited for all the others or was admitted because the whole list + itself fits.
+int spin_kernel_chain(hipStream_t s, void (*launch)(void *ctx, hipStream_t s), void *ctx, int cus_needed) {
+    struct InFlight { hipEvent_t ev; int cus; };
+    struct Gate { std::vector<InFlight> live; std::vector<hipEvent_t> pool; };
     static std::mutex mu;
-    static hipEvent_t last_done[64] = {};
+    static Gate gates[64];
     int dev = 0;
     TGNN_CHECK_HIP(hipGetDevice(&dev));
     TGNN_CHECK_ARG(dev >= 0 && dev < 64, "device index");
+    const int capacity = device_cus() - 16;                   // (16 CUs stay free for the pre-pass kernels the forwards wait on)
     std::lock_guard<std::mutex> lock(mu);
-    if (!last_done[dev]) TGNN_CHECK_HIP(hipEventCreateWithFlags(&last_done[dev], hipEventDisableTiming));
-    else TGNN_CHECK_HIP(hipStreamWaitEvent(s, last_done[dev], 0));
+    Gate &g = gates[dev];
+    int used = 0;
+    for (size_t i = 0; i < g.live.size();) {                   // forget what has finished
+        if (hipEventQuery(g.live[i].ev) == hipSuccess) {
+            g.pool.push_back(g.live[i].ev);
+            g.live.erase(g.live.begin() + (long)i);
+        } else {
+            used += g.live[i].cus;
+            ++i;
+        }
+    }
+    (void)hipGetLastError();                                   // (hipEventQuery leaves hipErrorNotReady behind)
+    if (used + cus_needed > capacity || g.live.size() >= 16)
+        for (const InFlight &f : g.live) TGNN_CHECK_HIP(hipStreamWaitEvent(s, f.ev, 0));
+    hipEvent_t ev;
+    if (!g.pool.empty()) {
+        ev = g.pool.back();
+        g.pool.pop_back();
+    } else {
+        TGNN_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
     launch(ctx, s);
-    TGNN_CHECK_HIP(hipEventRecord(last_done[dev], s));
+    TGNN_CHECK_HIP(hipEventRecord(ev, s));
+    g.live.push_back(InFlight{ev, cus_needed});
     return TGNN_OK;
 }
 
@@ -1192,7 +1224,7 @@ int launch_forward_small(const tgnn_model_dims *d, const Params &P, const float 
     TGNN_TRY_SMALL(spin_kernel_chain(s, [](void *c, hipStream_t st) {
         Ctx *x = static_cast<Ctx *>(c);
         forward_layers_small_kernel<<<dim3(x->blocks), dim3(kSmallThreads), x->lds, st>>>(*x->A, *x->R, *x->E);
-    }, &ctx));
+    }, &ctx, blocks));                                         // (one block per CU: the LDS images fill it)
     return TGNN_OK;
 }
 

@@ -1595,7 +1595,7 @@ extern "C" int tgnn_graph_prep_small(const int64_t *adj_edge_index, int64_t n_ad
     const int rc = spin_kernel_chain(s, [](void *c, hipStream_t st) {
         Ctx *x = static_cast<Ctx *>(c);
         graph_prep_small_kernel<<<x->blocks, kSmallPrepThreads, x->lds, st>>>(*x->A);
-    }, &ctx);
+    }, &ctx, (int)blocks);
     if (rc != TGNN_OK) return rc;
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;

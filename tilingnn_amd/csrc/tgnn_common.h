@@ -353,10 +353,11 @@ int launch_gin32_mlp(const float *z, const float *w1, const float *b1, const flo
                      hipStream_t s);
 // Kernels that synchronise their blocks with spin barriers (the persistent small-layout forward, the one-launch small-layout
 // preparation) need ALL their blocks resident; two of them started side by side from different streams or threads could each
-// hold part of the CUs and wait for the rest for ever.  Every such launch goes through this per-device chain: it waits for the
-// spin kernel before it (an event, whichever stream that was on) and leaves its own.  `launch` queues the kernel on `s`.
-// (Stream capture: the shared event makes these launches uncapturable into a HIP graph.)
-int spin_kernel_chain(hipStream_t s, void (*launch)(void *ctx, hipStream_t s), void *ctx);
+// hold part of the CUs and wait for the rest for ever.  Every such launch goes through this per-device gate (forward_small.hip):
+// it runs beside the spin kernels still in flight when all of them together fit the device, else behind them (events,
+// whichever streams they are on).  `launch` queues the kernel on `s`; cus_needed = CUs its blocks occupy.
+// (Stream capture: the shared events make these launches uncapturable into a HIP graph.)
+int spin_kernel_chain(hipStream_t s, void (*launch)(void *ctx, hipStream_t s), void *ctx, int cus_needed);
 // Small layouts: the whole forward behind a pre-pass as one persistent kernel (forward_small.hip).  small_layout_teams:
 // 0 = not eligible (too large, too many edge types for LDS, ...); the packs / images are built per forward.
 int small_layout_teams(const tgnn_model_dims *d, int64_t n_nodes, int n_types, int max_in_degree);

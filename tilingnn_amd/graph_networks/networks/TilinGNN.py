@@ -117,7 +117,57 @@ class TilinGNN(Tracked, nn.Module):
         return state
 
     # ---- forward ----------------------------------------------------------------------------
+    def forward_many(self, layouts, streams: int = 3):
+        """K independent layouts, every one a batch of its own (own BatchNorm statistics: exactly what K forward() calls
+        compute, bit for bit) scored SIDE BY SIDE -- the reference's crop loop (Tiling-Shape.py:52-64) and the first rounds of
+        several greedy solves hand over layouts of ~1 000 nodes that fill a third of the chip each.  layouts: sequence of
+        (x, adj_e_index, adj_e_features, col_e_idx); every layout's preparation and forward are queued on one of `streams`
+        streams of this module's own, the persistent small-layout kernels of different streams run beside each other when
+        they fit the device together (csrc/forward_small.hip: spin_kernel_chain).  Train mode: the running statistics are left
+        untouched (K concurrent updates of the same buffers would race; they do not enter train-mode outputs).
+        Returns the list of probs tensors, ready on the current stream."""
+        table, dev = self._param_table()
+        layouts = list(layouts)
+        bn_train = self.training
+        if (self.autograd and bn_train and torch.is_grad_enabled()) or self.activation_dtype != torch.float32 or not layouts:
+            return [self._forward_one(*l, update_running=False)[0] for l in layouts]
+        cur = torch.cuda.current_stream(dev)
+        pool = self.__dict__.setdefault("_many_streams", {})
+        lanes = pool.get(dev.index)
+        if lanes is None or len(lanes) < streams:
+            lanes = pool[dev.index] = [torch.cuda.Stream(device=dev) for _ in range(streams)]
+        k_n = len(layouts)
+        used = lanes[:min(streams, k_n)]
+        for st in used:
+            st.wait_stream(cur)
+        dims = self._dims()
+        xs, attrs, graphs, outs, wss = [], [], [], [], []
+        for k, (x, adj, attr, col) in enumerate(layouts):
+            n = int(x.shape[0])
+            if x.dim() != 2 or x.shape[1] != self.node_features_dim or attr.dim() != 2 or attr.shape[1] != self.adj_edge_features_dim:
+                raise ValueError("forward_many: layout shapes (see forward)")
+            if bn_train and n < 2:
+                raise ValueError("Expected more than 1 value per channel when training")
+            with torch.cuda.stream(lanes[k % streams]):          # preparation and buffers belong to the layout's stream
+                xf, ea = ops._f32c(x, "x"), ops._f32c(attr, "adj_e_features")
+                graph = _graph_cache.get_full(n, adj, attr, col) if self.cache_graph else ops.prepare_graph(n, adj, attr, col)
+                ws = torch.empty(lib.tgnn_forward_workspace_bytes(C.byref(dims), n, graph.n_types), dtype=torch.uint8, device=dev)
+                probs = torch.empty(n, self.output_dim, dtype=torch.float32, device=dev)
+            probs.record_stream(cur)
+            xs.append(xf); attrs.append(ea); graphs.append(graph); outs.append(probs); wss.append(ws)
+        arr = lambda ts: (C.c_void_p * k_n)(*[t.data_ptr() for t in ts])
+        gs = (_lib.Graph * k_n)(*[g.c_struct() for g in graphs])
+        check(lib.tgnn_forward_many(C.byref(dims), table, k_n, arr(xs), arr(attrs), gs, 0, int(not bn_train), arr(outs), arr(wss),
+                                    (C.c_size_t * k_n)(*[int(w.numel()) for w in wss]),
+                                    (C.c_void_p * len(used))(*[st.cuda_stream for st in used]), len(used), _lib.side_stream(dev)))
+        for st in used:
+            cur.wait_stream(st)
+        return outs
+
     def forward(self, x, adj_e_index, adj_e_features, col_e_idx, col_e_features=None):
+        return self._forward_one(x, adj_e_index, adj_e_features, col_e_idx, col_e_features)
+
+    def _forward_one(self, x, adj_e_index, adj_e_features, col_e_idx, col_e_features=None, update_running=True):
         table, dev = self._param_table()
         for name, t in (("x", x), ("adj_e_index", adj_e_index), ("adj_e_features", adj_e_features),
                         ("col_e_idx", col_e_idx)):
@@ -152,6 +202,6 @@ class TilinGNN(Tracked, nn.Module):
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         probs = torch.empty(n, self.output_dim, dtype=torch.float32, device=dev)
         g = graph.c_struct()
-        check(lib.tgnn_forward(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), int(bn_train), int(not bn_train),
+        check(lib.tgnn_forward(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), int(bn_train and update_running), int(not bn_train),
                                ptr(probs), ptr(ws), ws_bytes, _lib.current_stream(dev), _lib.side_stream(dev)))
         return probs, adj_e_features                                          # TilinGNN.py:78
