@@ -18,10 +18,6 @@ Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, measured with HI
 launch stream in a second instrumented pass) and `cpu_baseline` (the CPU oracle = a port of the
 reference's op sequence, timed on this box's host cores on a bounded sample).
 """
-import os as _os
-# HIP hands its hardware queues to streams round robin, 4 by default; the forward's side stream, RCCL's and torch's streams then
-# come to share queues (a shared queue runs its kernels one after the other): 8 queues, set before the runtime starts
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import argparse
 import ctypes as C
 import json

@@ -506,8 +506,9 @@ int tgnn_forward_profiled_two_stream(const tgnn_model_dims *dims, const void *co
  * (Tiling-Shape.py:52-64) hands over layouts of ~1 000 nodes that fill a third of the chip each.  The caller orders `streams`
  * with its own work before and after.  update_running != 0 with layouts sharing one parameter set: the K updates of the
  * running statistics race (they do not enter train-mode outputs); pass 0 to leave them untouched.
- * (HIP maps streams to hardware queues round robin, 4 by default: with GPU_MAX_HW_QUEUES=8 in the environment before the
- *  runtime starts, three layout streams + the side stream do not share one.) */
+ * (HIP binds streams to its hardware queues -- 4 by default, GPU_MAX_HW_QUEUES -- round robin, and two streams on one queue run
+ *  their kernels one after the other: hand over streams that were seen to overlap; tilingnn_amd._lib.concurrent_streams
+ *  measures that.) */
 int tgnn_forward_many(const tgnn_model_dims *dims, const void *const *params_host, int32_t n_layouts, const float *const *x,
                       const float *const *adj_edge_attr, const tgnn_graph *graphs, int32_t update_running,
                       int32_t use_running_stats, float *const *probs, void *const *ws, const size_t *ws_bytes,

@@ -5,7 +5,6 @@ import json
 import os
 import sys
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # (before the HIP runtime starts: see tilingnn_amd/__init__.py)
 
 import torch
 import torch.distributed as dist

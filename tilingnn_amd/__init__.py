@@ -10,13 +10,7 @@ plus `tilingnn_amd.ops` (torch-tensor front end of the C ABI in include/tgnn.h),
 (seeded synthetic super-graphs).  Importing the GPU-facing parts requires the built
 libtgnn.so; `weights` and `synth` are pure numpy/torch and import anywhere.
 """
-import os as _os
-
 __version__ = "0.1.0"
-# HIP hands its hardware queues to streams round robin, 4 by default; the forward uses a side stream, forward_many three more:
-# with 8 queues they do not share one (a shared queue runs its streams' kernels one after the other).  Read when the HIP
-# runtime starts, i.e. effective if this import comes before the process's first GPU call; set it yourself otherwise.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 _GPU_ATTRS = {"TilinGNN": ("graph_networks.networks.TilinGNN", "TilinGNN"),
               "get_network_prediction": ("graph_networks.network_utils", "get_network_prediction"),

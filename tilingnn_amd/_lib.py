@@ -251,12 +251,65 @@ class pinned_stream:
 
 
 _side_streams = {}
+_stream_lock = threading.Lock()
+_stream_sets = {}         # device index -> streams found to run beside the device's current stream and beside each other
+
+
+def _run_side_by_side(a, b, dev, cycles=400_000) -> bool:
+    """True when a spinning kernel on stream a and one on stream b overlap in time (wall clock of both against one)."""
+    import time
+    import torch
+
+    def wall(streams):
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        for st in streams:
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(cycles)
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t
+    wall([a])                                               # (warm-up: first use of a stream binds it to a hardware queue)
+    wall([b])
+    one = min(wall([a]), wall([a]))
+    both = min(wall([a, b]), wall([a, b]))
+    return both < 1.5 * one
+
+
+def concurrent_streams(device, k: int):
+    """k streams of this package's own that really run beside the device's current stream and beside each other.  HIP binds
+    streams to its hardware queues (4 by default, GPU_MAX_HW_QUEUES) round robin, and two streams on one queue run their kernels
+    strictly one after the other -- which streams collide depends on how many the process (torch, RCCL, ...) created before.
+    Measured, not assumed: candidates are created one at a time and kept when a spinning kernel on them overlaps with one on the
+    current stream and on every stream kept so far (~1 ms per test, once per device).  Fewer than k found: the last ones repeat."""
+    import torch
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    with _stream_lock:
+        return _concurrent_streams_locked(key, k)
+
+
+def _concurrent_streams_locked(key, k):
+    import torch
+    have = _stream_sets.setdefault(key, [])
+    if len(have) < k and not getattr(concurrent_streams, "_exhausted_" + str(key), False):
+        cur = torch.cuda.current_stream(key)
+        tries = 0
+        while len(have) < k and tries < 16:
+            tries += 1
+            cand = torch.cuda.Stream(device=key)
+            if _run_side_by_side(cur, cand, key) and all(_run_side_by_side(h, cand, key) for h in have):
+                have.append(cand)
+        if len(have) < k:
+            setattr(concurrent_streams, "_exhausted_" + str(key), True)
+            if not have:
+                have.append(torch.cuda.Stream(device=key))
+    return [have[min(i, len(have) - 1)] for i in range(k)]
 
 
 def side_stream(device) -> C.c_void_p:
     """Second stream of the forward's two-chain schedule (the collision branch runs free beside the adjacency branch,
-    csrc/forward.hip); one per device, created on first use.  TGNN_TWO_STREAMS=0 returns NULL = everything on the
-    current stream.  Measured at 100k nodes: 4 % faster with the side stream."""
+    csrc/forward.hip); one per device, picked on first use among streams that were MEASURED to run beside the current one
+    (concurrent_streams).  TGNN_TWO_STREAMS=0 returns NULL = everything on the current stream."""
     import torch
     if os.environ.get("TGNN_TWO_STREAMS", "1") == "0":
         return C.c_void_p(None)
@@ -265,7 +318,7 @@ def side_stream(device) -> C.c_void_p:
         key = torch.cuda.current_device()
     st = _side_streams.get(key)
     if st is None:
-        st = _side_streams[key] = torch.cuda.Stream(device=key)
+        st = _side_streams[key] = concurrent_streams(key, 1)[0]
     return C.c_void_p(st.cuda_stream)
 
 

@@ -523,9 +523,9 @@ class LibraryRccl:
         import torch.distributed as dist
         from . import _lib
         self._lib, self._C = _lib, C
-        # The forward's side stream must exist BEFORE the communicators: HIP hands its (by default 4) hardware queues to streams
-        # round robin in creation order, RCCL creates streams of its own, and a side stream created behind them came to share
-        # the main stream's queue -- the two chains then ran strictly one after the other (rocprof: every kernel on one queue)
+        # The forward's side stream is picked (and bound to its hardware queue) BEFORE the communicators exist: RCCL creates
+        # streams of its own, and a side stream that came to share the main stream's queue made the two chains run strictly
+        # one after the other (rocprof: every kernel on one queue).  _lib.side_stream measures what it picks.
         _lib.side_stream(torch.device(device))
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         nbytes = int(_lib.lib.tgnn_rccl_unique_id_bytes())

@@ -132,10 +132,8 @@ class TilinGNN(Tracked, nn.Module):
         if (self.autograd and bn_train and torch.is_grad_enabled()) or self.activation_dtype != torch.float32 or not layouts:
             return [self._forward_one(*l, update_running=False)[0] for l in layouts]
         cur = torch.cuda.current_stream(dev)
-        pool = self.__dict__.setdefault("_many_streams", {})
-        lanes = pool.get(dev.index)
-        if lanes is None or len(lanes) < streams:
-            lanes = pool[dev.index] = [torch.cuda.Stream(device=dev) for _ in range(streams)]
+        _lib.side_stream(dev)                                  # (the first of the measured set: the forward's side stream)
+        lanes = _lib.concurrent_streams(dev, streams + 1)[1:]    # streams measured to run beside each other and the side stream
         k_n = len(layouts)
         used = lanes[:min(streams, k_n)]
         for st in used:
