@@ -359,6 +359,9 @@ def test_trainer_loop_on_layout_files(tmp_path):
         trainer.train(solver, opt, batch_size=4)
 
 
+SEED_RATIO_MAX = 8.0
+
+
 def test_training_step_with_many_edge_types():
     """25 distinct edge-attribute rows: more than the matrix-core NNConv kernel's weight image holds, so the forward of the
     step runs on the CSR / LDS-table kernel; the adjoints (type sums with 26 slots) must not care.  Depth 2, so that float32
@@ -396,7 +399,13 @@ def test_training_step_with_many_edge_types():
         floor = float(np.median(list(err32.values())))
         errs = {k: _rel(p.grad, ref_grads[k]) for k, p in net.named_parameters()}
         assert set(errs) == set(err32)
-        assert max(errs.values()) < 0.2, max(errs.items(), key=lambda kv: kv[1])          # a wrong adjoint is off by O(1)
+        seed_ratio = max(errs.values()) / (max(err32.values()) + 2.5e-6)
+        print(f"seed {seed}: worst parameter ours {max(errs.values()):.2e}, float32 oracle's worst {max(err32.values()):.2e} "
+              f"(ratio {seed_ratio:.1f}), float32 oracle's median {floor:.2e}")
+        # per seed: our worst parameter against the float32 oracle's OWN worst parameter of the same seed (the yardstick moves
+        # with the seed's conditioning, the gate moves with it) -- an adjoint regression of a few per cent on any parameter in
+        # any seed fails; a wrong adjoint is off by O(1)
+        assert seed_ratio < SEED_RATIO_MAX and max(errs.values()) < 0.05, max(errs.items(), key=lambda kv: kv[1])
         worst.append(max(e / (max(err32[k], floor) + 2.5e-6) for k, e in errs.items()))
     print("worst parameter, ours / float32 oracle, per seed:", [f"{w:.1f}" for w in worst])
     assert sorted(worst)[1] <= 4.0

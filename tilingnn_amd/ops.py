@@ -255,7 +255,9 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
         (int(lib.tgnn_graph_prep_workspace_bytes(n_nodes, ea, ec, fe)) + 3) // 4 + 64
     want_stream = not small and STREAM_NNCONV and n_nodes < 2 ** 24
     st_cap = int(lib.tgnn_nnconv_stream_max_entries(n_nodes, ea)) if want_stream else 0
-    sizes = [n_nodes + 1, e1, e1, e1, e1, e1, n_nodes + 1, c1, c1, ntiles + 1, cap, cap * 16, 32, ws_ints,
+    # the persistent outputs share ONE long-lived allocation; the scratch (CSR / de-dup tables, scan workspaces) and the result
+    # words are tensors of their own, freed after the read-back -- a cached graph does not pin hundreds of MB of scratch
+    sizes = [n_nodes + 1, e1, e1, e1, e1, e1, n_nodes + 1, c1, c1, ntiles + 1, cap, cap * 16,
              (ntiles + 1) if want_stream else 0, st_cap, (st_cap // 2 + 64) if want_stream else 0,
              ntiles * 64 if want_stream else 0, ntiles * 16 if want_stream else 0]
     offs, at = [], 0
@@ -264,8 +266,10 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
         at += (sz + 63) // 64 * 64                     # 256-byte aligned pieces of ONE allocation
     buf = torch.empty(at, dtype=torch.int32, device=dev)
     v = [buf[o:o + sz] for o, sz in zip(offs, sizes)]
-    (a_rowptr, a_src, a_eid, adj_type, edge_type, rep, c_rowptr, c_src, c_eid, tile_col_ptr, col_meta, col_slot_src, res, tmp,
+    (a_rowptr, a_src, a_eid, adj_type, edge_type, rep, c_rowptr, c_src, c_eid, tile_col_ptr, col_meta, col_slot_src,
      st_ptr, st_src, st_rl, st_info, st_inv) = v
+    res = torch.empty(32, dtype=torch.int32, device=dev)
+    tmp = torch.empty(ws_ints, dtype=torch.int32, device=dev)
     head = (ptr(adj), ea, ptr(attr), fe, ptr(col), ec, n_nodes) + (() if small else (n_src_nodes or n_nodes,)) + (ptr(a_rowptr), ptr(a_src), ptr(a_eid), ptr(adj_type), ptr(edge_type),
             ptr(rep), ptr(c_rowptr), ptr(c_src), ptr(c_eid), ptr(tile_col_ptr), ptr(col_meta), ptr(col_slot_src))
     if small:
