@@ -123,7 +123,9 @@ class TilinGNN(Tracked, nn.Module):
         several greedy solves hand over layouts of ~1 000 nodes that fill a third of the chip each.  layouts: sequence of
         (x, adj_e_index, adj_e_features, col_e_idx); every layout's preparation and forward are queued on one of `streams`
         streams of this module's own, the persistent small-layout kernels of different streams run beside each other when
-        they fit the device together (csrc/forward_small.hip: spin_kernel_chain).  Train mode: the running statistics are left
+        they fit the device together (csrc/forward_small.hip: spin_kernel_chain).  More than two layouts at a time need more
+        than HIP's default 4 hardware queues (current + side + K layout streams): GPU_MAX_HW_QUEUES=8 in the environment before
+        the process's first GPU call; the streams used are measured to overlap (_lib.concurrent_streams).  Train mode: the running statistics are left
         untouched (K concurrent updates of the same buffers would race; they do not enter train-mode outputs).
         Returns the list of probs tensors, ready on the current stream."""
         table, dev = self._param_table()
