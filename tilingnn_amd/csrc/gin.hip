@@ -126,21 +126,6 @@ __device__ __forceinline__ f32x4 gin_mma6(const bf16x8 *wpl, int plane_stride, c
     return acc;
 }
 
-// Layers 2 and 3 take SIGMOIDS as input (bounded by 1): they run the 3-term fp16-pair split (tgnn_common.h: split2_f16) with the
-// fixed scale 2^14 for the activations and the power of two of max |W| (found while the block builds its weight images) for
-// the weights -- 24 + 24 matrix instructions become 12 + 12, 44 split instructions per 8 values become 24.  The biases enter
-// the accumulators multiplied by the same powers of two, which come off inside the sigmoid's exponent.  Layer 1's input (the
-// neighbourhood sum) has no bound at hand: bf16 x 3.
-using f16x8 = tgnn_f16x8;
-__device__ __forceinline__ f32x4 gin_mma3(const f16x8 &wh, const f16x8 &wl, const f16x8 &xh, const f16x8 &xl, f32x4 acc) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc, 0, 0, 0);   // lo . hi
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc, 0, 0, 0);   // hi . lo
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc, 0, 0, 0);   // hi . hi
-    return acc;
-}
-// sigmoid(u v) with c = -u log2(e): the scale of the fp16-pair accumulators comes off in the exponent's own multiply
-__device__ __forceinline__ float sigmoid_scaled(float v, float c) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * c)); }
-
 // (2 waves per SIMD on purpose: the compiler then keeps all 30 weight fragments in registers, 232 VGPRs; with
 //  16 waves per block and 128 VGPRs the same code spills: 59.6 us)
 __global__ __launch_bounds__(kMlpThreads, 2) void gin32_mlp_kernel(
@@ -149,9 +134,8 @@ __global__ __launch_bounds__(kMlpThreads, 2) void gin32_mlp_kernel(
     const float *__restrict__ b3, int64_t n, int act, float *__restrict__ out, double *__restrict__ bn_partial) {
     // weight images: [plane 3][M block][i 16][q 4] x bf16x8 -- the A fragment of lane (i, q) is one ds_read_b128
     __shared__ bf16x8 W1s[3 * 2 * 64];          // K = 32 (natural order 8 q + e: Z comes straight from memory)
-    __shared__ f16x8 W2s[2 * 4 * 64];           // fp16 pairs (hi, lo planes), K = 32 in kf order
-    __shared__ f16x8 W3s[2 * 2 * 2 * 64];       // [plane][M block][K step][..], K = 64 in kf order
-    __shared__ unsigned wmax_s[2];              // max |w2|, max |w3| as float bits
+    __shared__ bf16x8 W2s[3 * 4 * 64];          // K = 32 in kf order
+    __shared__ bf16x8 W3s[3 * 2 * 2 * 64];      // [plane][M block][K step][..], K = 64 in kf order
     __shared__ __attribute__((aligned(16))) float Bs[128];   // b1 | b2 | b3
     __shared__ double red[kMlpWaves * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -189,26 +173,12 @@ __global__ __launch_bounds__(kMlpThreads, 2) void gin32_mlp_kernel(
         for (int e = 0; e < 8; ++e) x[e] = w1[(16 * mb + ii) * 32 + 8 * q + e];
         gin_split3(x, W1s[(0 * 2 + mb) * 64 + ii * 4 + q], W1s[(1 * 2 + mb) * 64 + ii * 4 + q], W1s[(2 * 2 + mb) * 64 + ii * 4 + q]);
     }
-    // layers 2 / 3: the weights' bounds first (2 048 values each: threads 0-255 / 256-511 take 8), then the scaled fp16-pair images
-    if (tid < 2) wmax_s[tid] = 0u;
-    __syncthreads();
-    {
-        const float *wsrc = tid < 256 ? w2 + 8 * tid : w3 + 8 * (tid - 256);
-        const float4 u0 = reinterpret_cast<const float4 *>(wsrc)[0], u1 = reinterpret_cast<const float4 *>(wsrc)[1];
-        float m = absmax4(absmax4(0.f, u0), u1);
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
-        if (lane == 0) atomicMax(&wmax_s[tid < 256 ? 0 : 1], __float_as_uint(m));
-    }
-    __syncthreads();
-    const float sw2 = pow2_scale_for(wmax_s[0], 0), sw3 = pow2_scale_for(wmax_s[1], 0);
-    constexpr float kActScale = 16384.0f;                   // sigmoids < 1 -> below 2^14
     for (int i = tid; i < 4 * 64; i += kMlpThreads) {
         const int mb = i >> 6, ii = (i >> 2) & 15, q = i & 3;
         float x[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = w2[(16 * mb + ii) * 32 + gin_kf(q, e)];
-        split2_f16(x, sw2, W2s[(0 * 4 + mb) * 64 + ii * 4 + q], W2s[(1 * 4 + mb) * 64 + ii * 4 + q]);
+        gin_split3(x, W2s[(0 * 4 + mb) * 64 + ii * 4 + q], W2s[(1 * 4 + mb) * 64 + ii * 4 + q], W2s[(2 * 4 + mb) * 64 + ii * 4 + q]);
     }
     for (int i = tid; i < 4 * 64; i += kMlpThreads) {       // item = (M block, K step, i, q)
         const int mb = i >> 7, ks = (i >> 6) & 1, ii = (i >> 2) & 15, q = i & 3;
@@ -216,33 +186,20 @@ __global__ __launch_bounds__(kMlpThreads, 2) void gin32_mlp_kernel(
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = w3[(16 * mb + ii) * 64 + 32 * ks + gin_kf(q, e)];
         const int o = (mb * 2 + ks) * 64 + ii * 4 + q;
-        split2_f16(x, sw3, W3s[0 * 256 + o], W3s[1 * 256 + o]);
+        gin_split3(x, W3s[0 * 256 + o], W3s[1 * 256 + o], W3s[2 * 256 + o]);
     }
-    // biases of layers 2 / 3 in the accumulators' scale (powers of two: exact)
     if (tid < 32) Bs[tid] = b1[tid];
-    else if (tid < 96) Bs[tid] = b2[tid - 32] * (kActScale * sw2);
-    else if (tid < 128) Bs[tid] = b3[tid - 96] * (kActScale * sw3);
+    else if (tid < 96) Bs[tid] = b2[tid - 32];
+    else if (tid < 128) Bs[tid] = b3[tid - 96];
     __syncthreads();
-    const float u2 = 1.0f / (kActScale * sw2), u3 = 1.0f / (kActScale * sw3), c2 = -1.4426950408889634f * u2;
 
     // this lane's accumulator registers hold features 16 mb + 4 q + r: bias vectors in that order
     auto bias4 = [&](int base, int mb) {
         const float4 t = *reinterpret_cast<const float4 *>(Bs + base + 16 * mb + 4 * fq);
         return f32x4{t.x, t.y, t.z, t.w};
     };
-    const bf16x8 *w1p = W1s + fn * 4 + fq;
-    const f16x8 *w2p = W2s + fn * 4 + fq, *w3p = W3s + fn * 4 + fq;
+    const bf16x8 *w1p = W1s + fn * 4 + fq, *w2p = W2s + fn * 4 + fq, *w3p = W3s + fn * 4 + fq;
     double cs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cq[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // BN sums of this lane's 8 output features
-    // the weight fragments of layers 2 / 3 stay in registers for the whole tile loop (16 x 4 registers; read explicitly here:
-    // left to itself the compiler re-reads them from LDS for every tile)
-    f16x8 w2h[4], w2l[4], w3h[4], w3l[4];
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-        w2h[mb] = w2p[mb * 64];
-        w2l[mb] = w2p[4 * 64 + mb * 64];
-        w3h[mb] = w3p[mb * 64];                             // mb here = M block * 2 + K step
-        w3l[mb] = w3p[256 + mb * 64];
-    }
 
     for (int64_t tile = t0; tile < t1; ++tile) {
         bf16x8 xb[3];
@@ -254,29 +211,25 @@ __global__ __launch_bounds__(kMlpThreads, 2) void gin32_mlp_kernel(
         // ---- layer 1: 2 M blocks
         f32x4 h1a = gin_mma6(w1p + 0 * 64, 2 * 64, xb, bias4(0, 0));
         f32x4 h1b = gin_mma6(w1p + 1 * 64, 2 * 64, xb, bias4(0, 1));
-        f16x8 xh, xl;
         {
             const float x[8] = {sigmoidf_(h1a[0]), sigmoidf_(h1a[1]), sigmoidf_(h1a[2]), sigmoidf_(h1a[3]),
                                 sigmoidf_(h1b[0]), sigmoidf_(h1b[1]), sigmoidf_(h1b[2]), sigmoidf_(h1b[3])};
-            split2_f16(x, kActScale, xh, xl);
+            gin_split3(x, xb[0], xb[1], xb[2]);
         }
-        // ---- layer 2: 4 M blocks (fp16 pairs; accumulators in the scale 2^14 sw2)
+        // ---- layer 2: 4 M blocks
         f32x4 h2[4];
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) h2[mb] = gin_mma3(w2h[mb], w2l[mb], xh, xl, bias4(32, mb));
-        // ---- layer 3: 2 M blocks x 2 K steps (scale 2^14 sw3)
+        for (int mb = 0; mb < 4; ++mb) h2[mb] = gin_mma6(w2p + mb * 64, 4 * 64, xb, bias4(32, mb));
+        // ---- layer 3: 2 M blocks x 2 K steps
         f32x4 o0 = bias4(96, 0), o1 = bias4(96, 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const float x[8] = {sigmoid_scaled(h2[2 * ks][0], c2), sigmoid_scaled(h2[2 * ks][1], c2), sigmoid_scaled(h2[2 * ks][2], c2),
-                                sigmoid_scaled(h2[2 * ks][3], c2), sigmoid_scaled(h2[2 * ks + 1][0], c2), sigmoid_scaled(h2[2 * ks + 1][1], c2),
-                                sigmoid_scaled(h2[2 * ks + 1][2], c2), sigmoid_scaled(h2[2 * ks + 1][3], c2)};
-            split2_f16(x, kActScale, xh, xl);
-            o0 = gin_mma3(w3h[0 * 2 + ks], w3l[0 * 2 + ks], xh, xl, o0);
-            o1 = gin_mma3(w3h[1 * 2 + ks], w3l[1 * 2 + ks], xh, xl, o1);
+            const float x[8] = {sigmoidf_(h2[2 * ks][0]), sigmoidf_(h2[2 * ks][1]), sigmoidf_(h2[2 * ks][2]), sigmoidf_(h2[2 * ks][3]),
+                                sigmoidf_(h2[2 * ks + 1][0]), sigmoidf_(h2[2 * ks + 1][1]), sigmoidf_(h2[2 * ks + 1][2]), sigmoidf_(h2[2 * ks + 1][3])};
+            gin_split3(x, xb[0], xb[1], xb[2]);
+            o0 = gin_mma6(w3p + (0 * 2 + ks) * 64, 256, xb, o0);
+            o1 = gin_mma6(w3p + (1 * 2 + ks) * 64, 256, xb, o1);
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { o0[r] *= u3; o1[r] *= u3; }
         // ---- epilogue: row fn, features 4 q + r and 16 + 4 q + r
         float4 r0, r1;
         // the OUTPUT sigmoid in full precision (libm expf + IEEE division, ~1.5 ulp instead of the hardware
