@@ -642,7 +642,13 @@ class ShardedTilinGNN:
         self.rccl = None
         if (torch.device(device).type == "cuda" and dist.get_backend(group) == "nccl" and _lib.lib.tgnn_rccl_available()
                 and os.environ.get("TGNN_LIBRARY_RCCL", "1") == "1"):
-            self.rccl = LibraryRccl(device, group)
+            try:
+                self.rccl = LibraryRccl(device, group)
+            except Exception as exc:                           # (no RCCL entry points, communicator creation refused, ...)
+                import warnings
+                warnings.warn(f"tilingnn_amd.dist: library-issued RCCL collectives unavailable ({exc}); "
+                              "falling back to torch.distributed callbacks")
+                self.rccl = None
         self.fused = FusedShardForward(net, shard, device, self.collectives, inputs=self.inputs, rccl=self.rccl)
         self.fused.two_streams = self.rccl is not None
         self._rccl0 = LibraryRccl.counters() if self.rccl else (0, 0)
