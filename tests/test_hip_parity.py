@@ -890,6 +890,44 @@ def test_two_chain_schedule_is_bit_identical_to_one_stream(dev, n_nodes, columns
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
 
 
+def test_stamped_forward_is_the_production_forward(dev, general_schedule):
+    """tgnn_forward_stamped (what bench.py's roofline.avg_launch_us comes from): the production two-stream forward with the column
+    NNConv launches stamped on the device clock -- the same bits as tgnn_forward, one positive duration per layer, and the streams
+    the package hands out for the two chains really overlap."""
+    import ctypes as C
+    from tilingnn_amd import _lib, ops
+    from tilingnn_amd.synth import make_super_graph
+    n = 20000
+    sg = make_super_graph(n, 10 * n, 12 * n, tile_count=2, n_edge_types=13, seed=5)
+    x, adj, adj_attr, col, _ = sg.to_torch(dev)
+    net, _ = make_net(dev)
+    graph = ops.prepare_graph(n, adj, adj_attr, col)
+    dims = net._dims()
+    table, _ = net._param_table()
+    ws_bytes = _lib.lib.tgnn_forward_workspace_bytes(C.byref(dims), n, graph.n_types)
+    g = graph.c_struct()
+    side = _lib.side_stream(dev)
+    assert side.value and side.value != _lib.current_stream(dev).value
+    lanes = _lib.concurrent_streams(dev, 2)
+    assert len(lanes) == 2 and lanes[0].cuda_stream == side.value
+    outs = []
+    us = (C.c_float * 20)()
+    for stamped in (False, True, False):
+        ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
+        probs = torch.empty(n, 1, device=dev)
+        if stamped:
+            _lib.check(_lib.lib.tgnn_forward_stamped(C.byref(dims), table, ops.ptr(x), ops.ptr(adj_attr), C.byref(g), 0, ops.ptr(probs),
+                                                    ops.ptr(ws), ws_bytes, _lib.current_stream(dev), side, us))
+        else:
+            _lib.check(_lib.lib.tgnn_forward(C.byref(dims), table, ops.ptr(x), ops.ptr(adj_attr), C.byref(g), 0, 0, ops.ptr(probs),
+                                            ops.ptr(ws), ws_bytes, _lib.current_stream(dev), side))
+        torch.cuda.synchronize()
+        outs.append(probs.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    durations = [float(v) for v in us]
+    assert all(2.0 < d < 500.0 for d in durations), durations                 # microseconds per launch at 20 000 nodes
+
+
 # ------------------------------------------------------------------------------------------ loss on the predict path
 from tests.test_oracle_vs_reference_golden import LOSS_CASES, _loss_case_inputs   # noqa: E402
 
