@@ -554,7 +554,7 @@ static int dense_act_impl(const float *a, int64_t lda, int64_t a_kblock_stride, 
         //  per CU -- runs 672 -> 256 in 449 us against 281 us: the kernel lives on a second block covering the first one's
         //  two barriers per k-tile)
         constexpr int small_rows = 16384;
-        const bool f16 = a_max && w_max && n_a_max >= 1 && !in_stat;
+        const bool f16 = a_max && w_max && n_a_max >= 1;     // (a_max bounds the input AFTER the BatchNorm applied while staging)
         if (out_dim > 64 && n_rows > small_rows) {
             const int bx = row_blocks(128);
             if (f16)
@@ -629,6 +629,12 @@ extern "C" int tgnn_dense_act_slots_fwd(const float *a, int32_t slot_width, int6
 }
 
 namespace tgnn {
+int dense_act_bounded(const float *a, int64_t lda, int64_t a_kblock_stride, const float *in_stat, const float *w, const float *b,
+                      int64_t n_rows, int32_t in_dim, int32_t out_dim, int32_t act, float *out, int64_t ldo, double *bn_partial,
+                      int32_t *n_partials_host, const unsigned *a_max, int n_a_max, const unsigned *w_max, hipStream_t s) {
+    return dense_act_impl(a, lda, a_kblock_stride, 1, in_stat, w, b, n_rows, in_dim, out_dim, act, out, ldo, bn_partial,
+                          n_partials_host, s, a_max, n_a_max, w_max);
+}
 // tgnn_dense_act_slots_fwd with the operands' bounds (forward.hip: the first Linear of the final MLP over the skip buffer)
 int dense_act_slots_bounded(const float *a, int32_t slot_width, int64_t slot_stride, const float *w, const float *b,
                             int64_t n_rows, int32_t in_dim, int32_t out_dim, int32_t act, float *out, int64_t ldo,

@@ -365,6 +365,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     unsigned *weights_done = (small_teams == 2 && s2 && weights_on_side) ? w.small_ctr + 16 : nullptr;
     if (weights_done) TGNN_CHECK_HIP(hipMemsetAsync(weights_done, 0, 4, s));
     const int64_t cat_w_floats = (int64_t)c * (D + 1) * kFinalDims[0];
+    const int fin_dims[5] = {c * (D + 1), kFinalDims[0], kFinalDims[1], kFinalDims[2], c};   // in / out widths of the final MLP's layers
     // fp16-pair operands (3 matrix terms instead of the 6 of bf16 x 3) wherever a bound of the operand is at hand: the kernels
     // that write a slot of the skip buffer leave its largest magnitude (w.bounds), one launch up front those of the root
     // matrices and of the final MLP's first Linear.  General schedule, train-mode BatchNorm; needs the layout's largest
@@ -379,12 +380,28 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     if (f16) {
         const float *roots[kMaxDepth];
         for (int i = 0; i < D; ++i) roots[i] = P.f(P.layer(i) + 6);
-        launch_forward_scales(w.bounds, 2 * D + 2, roots, D, root_max, P.f(P.fin(0)), cat_w_floats, dense_max, s);   // (before the fork: both chains see the zeroed words)
+        launch_forward_scales(w.bounds, 2 * D + 6, roots, D, root_max, P.f(P.fin(0)), cat_w_floats, dense_max, s);   // (before the fork: both chains see the zeroed words)
     }
     if (s2 && weights_on_side) {
         TGNN_CHECK_HIP(hipEventRecord(ev[kEvFork], s));     // everything the caller queued on `stream` so far
         TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[kEvFork], 0));
         sw = s2;
+    }
+    if (f16) {
+        // the final MLP's layers 1 and 2 (256 -> 128 -> 64): weights' bounds and, from the BatchNorm parameters alone, their inputs'
+        const float *bw[2], *bg[2], *bb[2];
+        int64_t bwn[2];
+        int bf[2];
+        unsigned *bwm[2], *bam[2];
+        for (int l = 1; l <= 2; ++l) {
+            const BnPtrs bp = P.bn(P.fin(l - 1) + 2);
+            bw[l - 1] = P.f(P.fin(l));
+            bwn[l - 1] = (int64_t)fin_dims[l] * fin_dims[l + 1];
+            bg[l - 1] = bp.gamma; bb[l - 1] = bp.beta; bf[l - 1] = fin_dims[l];
+            bwm[l - 1] = w.bounds + 2 * D + 2 + 2 * (l - 1);
+            bam[l - 1] = w.bounds + 2 * D + 3 + 2 * (l - 1);
+        }
+        launch_dense_bounds(2, bw, bwn, bg, bb, bf, bwm, bam, n_total, sw);   // (side stream: off the critical chain; the final MLP is behind every join)
     }
     if (T > 0 || tiled) {
         // edge MLP of every (layer, type) and, for the matrix-core NNConv, its operand images (root = pseudo-type T): one launch
@@ -636,8 +653,13 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
             prof.end();
         } else {
             prof.begin(6);
-            TGNN_TRY(tgnn_dense_act_fwd(fbuf[l - 1], fdim[l], 32, w.stat_f[l - 1], P.f(pi), P.f(pi + 1), n, fdim[l],
-                                        fdim[l + 1], TGNN_ACT_LEAKY_RELU, fbuf[l], fdim[l + 1], w.partf, &np1, s));
+            if (f16 && l <= 2)       // fp16 pairs: the input's bound follows from the producer's BatchNorm parameters (dense_bounds_kernel)
+                TGNN_TRY(dense_act_bounded(fbuf[l - 1], fdim[l], 32, w.stat_f[l - 1], P.f(pi), P.f(pi + 1), n, fdim[l], fdim[l + 1],
+                                           TGNN_ACT_LEAKY_RELU, fbuf[l], fdim[l + 1], w.partf, &np1, w.bounds + 2 * D + 3 + 2 * (l - 1), 1,
+                                           w.bounds + 2 * D + 2 + 2 * (l - 1), s));
+            else
+                TGNN_TRY(tgnn_dense_act_fwd(fbuf[l - 1], fdim[l], 32, w.stat_f[l - 1], P.f(pi), P.f(pi + 1), n, fdim[l],
+                                            fdim[l + 1], TGNN_ACT_LEAKY_RELU, fbuf[l], fdim[l + 1], w.partf, &np1, s));
             prof.end();
         }
         TGNN_TRY(finalize1(w.partf, np1, fdim[l + 1], P.bn(pi + 2), w.stat_f[l]));

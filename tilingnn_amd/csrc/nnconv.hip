@@ -447,6 +447,36 @@ __global__ __launch_bounds__(256) void forward_scales_kernel(RootPtrs roots, int
     }
     absmax_flush(m, dst);
 }
+// Bounds of the final MLP's inner layers (their input is a train-mode BatchNorm's output): block l -> max |W_l| and
+//   max_c ( |gamma_c| sqrt(n) + |beta_c| )  >=  max |BN(v)|   -- Samuelson's inequality: no sample lies further than
+// sqrt(n - 1) standard deviations from the mean of the n samples the BatchNorm normalises with, so the bound needs the
+// PARAMETERS only (loose by a factor ~sqrt(n) / 5: a scaled fp16 pair loses nothing to a loose bound, only to an overflow).
+struct DenseBoundJob {
+    const float *w;
+    int64_t w_n4;
+    const float *gamma, *beta;
+    int f;
+    unsigned *w_max, *a_max;
+};
+struct DenseBoundJobs {
+    DenseBoundJob job[4];
+};
+__global__ __launch_bounds__(256) void dense_bounds_kernel(DenseBoundJobs jobs, float sqrt_n) {
+    const DenseBoundJob j = jobs.job[blockIdx.x];
+    float m = 0.f;
+    for (int64_t i = threadIdx.x; i < j.w_n4; i += 256) m = absmax4(m, reinterpret_cast<const float4 *>(j.w)[i]);
+    absmax_flush(m, j.w_max);
+    float a = 0.f;
+    for (int c = threadIdx.x; c < j.f; c += 256) a = fmaxf(a, fmaf(fabsf(j.gamma[c]), sqrt_n, fabsf(j.beta[c])));
+    absmax_flush(a, j.a_max);
+}
+void launch_dense_bounds(int n_jobs, const float *const *w, const int64_t *w_n, const float *const *gamma, const float *const *beta,
+                         const int *f, unsigned *const *w_max, unsigned *const *a_max, int64_t n_total, hipStream_t s) {
+    DenseBoundJobs jobs{};
+    for (int k = 0; k < n_jobs && k < 4; ++k) jobs.job[k] = DenseBoundJob{w[k], w_n[k] / 4, gamma[k], beta[k], f[k], w_max[k], a_max[k]};
+    dense_bounds_kernel<<<n_jobs, 256, 0, s>>>(jobs, sqrtf((float)n_total) * 1.0001f);
+}
+
 void launch_forward_scales(unsigned *words, int n_words, const float *const *roots, int depth, unsigned *root_max,
                            const float *dense_w, int64_t dense_n, unsigned *dense_max, hipStream_t s) {
     (void)hipMemsetAsync(words, 0, (size_t)n_words * sizeof(unsigned), s);

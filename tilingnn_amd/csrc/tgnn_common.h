@@ -341,6 +341,14 @@ int nnconv_stream_build_gated(const int32_t *rowptr, const int32_t *col_src, con
                               int32_t n_types, const int32_t *n_types_dev, const int32_t *gate, int32_t *tile_ent_ptr,
                               uint32_t *ent_src, uint32_t *rowlist, uint32_t *info, float *inv_deg, int32_t *result, void *ws,
                               hipStream_t s);
+// max |W_k| and a bound of |BN(v)| from the BatchNorm's parameters alone (nnconv.hip: dense_bounds_kernel), atomicMax into
+// zeroed words: what the final MLP's inner layers need to run the fp16-pair kernel on a BatchNorm-on-load input
+void launch_dense_bounds(int n_jobs, const float *const *w, const int64_t *w_n, const float *const *gamma, const float *const *beta,
+                         const int *f, unsigned *const *w_max, unsigned *const *a_max, int64_t n_total, hipStream_t s);
+// tgnn_dense_act_fwd with bounds of both operands (a_max: of the input AFTER in_stat's BatchNorm, if any): dense.hip
+int dense_act_bounded(const float *a, int64_t lda, int64_t a_kblock_stride, const float *in_stat, const float *w, const float *b,
+                      int64_t n_rows, int32_t in_dim, int32_t out_dim, int32_t act, float *out, int64_t ldo, double *bn_partial,
+                      int32_t *n_partials_host, const unsigned *a_max, int n_a_max, const unsigned *w_max, hipStream_t s);
 // tgnn_dense_act_slots_fwd (no input BatchNorm) with bounds of both operands: a_max[0 .. n_a_max) / w_max = max |a| per slot /
 // max |w| as float bits (device) -> the fp16-pair kernel (dense.hip: dense_split_kernel<.., F16>); dense.hip
 int dense_act_slots_bounded(const float *a, int32_t slot_width, int64_t slot_stride, const float *w, const float *b,
