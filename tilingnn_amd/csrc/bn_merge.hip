@@ -467,30 +467,6 @@ __device__ __forceinline__ void bn_sums_from_partials_1024(const BnJob &jb, int 
     __syncthreads();
 }
 
-// threads 0 .. f-1: record + running statistics from the column sums tot[0 .. 2f) over n_total rows (bn_finalize mode 2)
-__device__ __forceinline__ void bn_record_from_sums(const BnJob &jb, const double *tot, int f, int64_t n_total, float eps,
-                                                    float momentum) {
-    const int tid = threadIdx.x;
-    if (tid < f) {
-        const float gamma = jb.gamma[tid], beta = jb.beta[tid];
-        const double inv_n = 1.0 / (double)n_total;
-        const double mean = tot[tid] * inv_n;
-        double var = tot[f + tid] * inv_n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float mh = (float)mean;
-        jb.stat[tid] = mh;
-        jb.stat[f + tid] = (float)(mean - (double)mh);
-        jb.stat[2 * f + tid] = (float)((double)gamma / sqrt(var + (double)eps));
-        jb.stat[3 * f + tid] = beta;
-        if (jb.running_mean) {
-            const double unbiased = n_total > 1 ? var * ((double)n_total / (double)(n_total - 1)) : var;
-            jb.running_mean[tid] = (float)((1.0 - (double)momentum) * (double)jb.running_mean[tid] + (double)momentum * mean);
-            jb.running_var[tid] = (float)((1.0 - (double)momentum) * (double)jb.running_var[tid] + (double)momentum * unbiased);
-        }
-    }
-    if (tid == 0 && jb.num_batches_tracked) *jb.num_batches_tracked += 1;
-}
-
 // jobs.job[0/1].sums: this shard's 2 x 64 sums (128 contiguous doubles), also copied bit for bit into the message's sums
 // rows (idx < 0: floats (-1 - idx) * 64 .. of those 128 doubles).  Width 32.
 __global__ __launch_bounds__(1024) void shard_pack_sums_kernel(const float *__restrict__ a1, const float *__restrict__ a2,

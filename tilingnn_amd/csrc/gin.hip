@@ -131,7 +131,7 @@ __device__ __forceinline__ f32x4 gin_mma6(const bf16x8 *wpl, int plane_stride, c
 __global__ __launch_bounds__(kMlpThreads, 2) void gin32_mlp_kernel(
     const float *__restrict__ z, const float *__restrict__ w1, const float *__restrict__ b1,
     const float *__restrict__ w2, const float *__restrict__ b2, const float *__restrict__ w3,
-    const float *__restrict__ b3, int64_t n, int act, float *__restrict__ out, double *__restrict__ bn_partial) {
+    const float *__restrict__ b3, int64_t n, int act, float *__restrict__ out, double *__restrict__ bn_partial, GinFin fin) {
     // weight images: [plane 3][M block][i 16][q 4] x bf16x8 -- the A fragment of lane (i, q) is one ds_read_b128
     __shared__ bf16x8 W1s[3 * 2 * 64];          // K = 32 (natural order 8 q + e: Z comes straight from memory)
     __shared__ bf16x8 W2s[3 * 4 * 64];          // K = 32 in kf order
@@ -272,10 +272,60 @@ __global__ __launch_bounds__(kMlpThreads, 2) void gin32_mlp_kernel(
             }
         }
         __syncthreads();
+        using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
+        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(bn_partial, 0, (int)0x80000000u, 0x00020000);
+        constexpr int kSc1 = 16;                              // cache policy sc1: agent scope, coherent across the XCDs' L2s
         if (tid < 64) {
             double tot = 0.0;
             for (int w = 0; w < kMlpWaves; ++w) tot += red[w * 64 + tid];
-            bn_partial[(int64_t)blockIdx.x * 64 + tid] = tot;
+            // (a write-through store when another block of THIS launch reads the row; an agent-scope release fence instead would
+            //  write the XCD's whole L2 back -- this kernel's 12.8 MB of output -- once per block: 19 -> 84 us, measured)
+            if (fin.counter)
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, tot), prs, ((uint32_t)blockIdx.x * 64u + (uint32_t)tid) * 8u, 0, kSc1);
+            else
+                bn_partial[(int64_t)blockIdx.x * 64 + tid] = tot;
+        }
+        if (fin.counter) {
+            // the last block to get here writes the BatchNorm's record: bn_finalize_kernel's reduction (16 row groups of the
+            // partial rows in order, then the fixed 16-way fold) with two groups per thread -- the same bits, no launch behind
+            __shared__ unsigned ticket;
+            __shared__ double fred[16 * 64];
+            __shared__ double ftot[64];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this block's row has been written through before its ticket
+            __syncthreads();
+            if (tid == 0) ticket = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (ticket == gridDim.x - 1) {                    // (uniform)
+                const int j = tid & 63, h = tid >> 6;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int g = h + 8 * half;
+                    double acc = 0.0;
+                    const int np = (int)gridDim.x;
+                    int p = g;
+                    for (; p < np; p += 8 * 16) {             // eight coherent loads in flight (rows past the end read as 0)
+                        u32x2 v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int pp = p + u * 16;
+                            v[u] = __builtin_amdgcn_raw_buffer_load_b64(prs, pp < np ? ((uint32_t)pp * 64u + (uint32_t)j) * 8u : 0x80000000u, 0, kSc1);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (p + u * 16 < np) acc += __builtin_bit_cast(double, v[u]);
+                    }
+                    fred[g * 64 + j] = acc;
+                }
+                __syncthreads();
+                if (tid < 64) {
+                    double t = 0.0;
+                    for (int gg = 0; gg < 16; ++gg) t += fred[gg * 64 + tid];
+                    ftot[tid] = t;
+                }
+                __syncthreads();
+                bn_record_from_sums(fin.job, ftot, 32, fin.n_total, fin.eps, fin.momentum);
+                if (tid == 0) __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -338,6 +388,21 @@ __global__ __launch_bounds__(256) void gin_generic_kernel(
 
 using namespace tgnn;
 
+namespace tgnn {
+int gin32_fwd_folded(const float *a, int64_t lda, const float *in_stat, const int32_t *rowptr, const int32_t *col_src, const float *eps,
+                     const float *w1, const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
+                     int64_t n_nodes, int32_t act, float *out, float *z_scratch, double *bn_partial, int32_t *n_partials_host,
+                     const GinFin &fin, hipStream_t s) {
+    if (!(n_nodes >= 1 && lda % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)out % 16) == 0 && z_scratch &&
+          ((uintptr_t)z_scratch % 16) == 0 && bn_partial))
+        return TGNN_ERR_UNSUPPORTED;
+    const int64_t rows_per_xcd = (n_nodes + 7) / 8;
+    const unsigned agg_blocks = (unsigned)(8 * ((rows_per_xcd + 31) / 32));
+    gin32_aggregate_kernel<<<agg_blocks, 256, 0, s>>>(a, lda, in_stat, rowptr, col_src, eps, n_nodes, z_scratch);
+    return launch_gin32_mlp(z_scratch, w1, b1, w2, b2, w3, b3, n_nodes, act, out, bn_partial, n_partials_host, s, &fin);
+}
+}  // namespace tgnn
+
 extern "C" int tgnn_gin_fwd(const float *a, int64_t lda, const float *in_stat, const int32_t *rowptr,
                             const int32_t *col_src, const float *eps, const float *w1, const float *b1,
                             const float *w2, const float *b2, const float *w3, const float *b3, int64_t n_nodes,
@@ -367,7 +432,7 @@ extern "C" int tgnn_gin_fwd(const float *a, int64_t lda, const float *in_stat, c
         if (blocks > cus_minus(reserve)) blocks = cus_minus(reserve);
         if (blocks >= 8) blocks &= ~7;
         gin32_mlp_kernel<<<blocks, kMlpThreads, 0, s>>>(z_scratch, w1, b1, w2, b2, w3, b3, n_nodes, act, out,
-                                                        bn_partial);
+                                                        bn_partial, GinFin{});
     } else {
         blocks = producer_blocks(n_nodes, 4);
         gin_generic_kernel<<<blocks, 256, 0, s>>>(a, lda, in_stat, rowptr, col_src, eps, w1, b1, w2, b2, w3, b3,
@@ -383,12 +448,18 @@ namespace tgnn {
 // halves on different streams
 int launch_gin32_mlp(const float *z, const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
                      const float *b3, int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
-                     hipStream_t s) {
+                     hipStream_t s, const GinFin *fin) {
     int blocks = producer_blocks(n_nodes, 16 * kMlpWaves);
     constexpr int reserve = 32;
     if (blocks > cus_minus(reserve)) blocks = cus_minus(reserve);
     if (blocks >= 8) blocks &= ~7;
-    gin32_mlp_kernel<<<blocks, kMlpThreads, 0, s>>>(z, w1, b1, w2, b2, w3, b3, n_nodes, act, out, bn_partial);
+    GinFin f{};
+    if (fin && bn_partial) {
+        f = *fin;
+        f.job.partials = bn_partial;
+        f.job.n_partials = blocks;
+    }
+    gin32_mlp_kernel<<<blocks, kMlpThreads, 0, s>>>(z, w1, b1, w2, b2, w3, b3, n_nodes, act, out, bn_partial, f);
     if (n_partials_host) *n_partials_host = blocks;
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;

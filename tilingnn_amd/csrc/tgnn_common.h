@@ -258,6 +258,39 @@ struct BnJob {
 struct BnJobs {
     BnJob job[2];
 };
+// threads 0 .. f-1: record + running statistics from the column sums tot[0 .. 2f) over n_total rows (bn_finalize mode 2)
+__device__ __forceinline__ void bn_record_from_sums(const BnJob &jb, const double *tot, int f, int64_t n_total, float eps,
+                                                    float momentum) {
+    const int tid = threadIdx.x;
+    if (tid < f) {
+        const float gamma = jb.gamma[tid], beta = jb.beta[tid];
+        const double inv_n = 1.0 / (double)n_total;
+        const double mean = tot[tid] * inv_n;
+        double var = tot[f + tid] * inv_n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float mh = (float)mean;
+        jb.stat[tid] = mh;
+        jb.stat[f + tid] = (float)(mean - (double)mh);
+        jb.stat[2 * f + tid] = (float)((double)gamma / sqrt(var + (double)eps));
+        jb.stat[3 * f + tid] = beta;
+        if (jb.running_mean) {
+            const double unbiased = n_total > 1 ? var * ((double)n_total / (double)(n_total - 1)) : var;
+            jb.running_mean[tid] = (float)((1.0 - (double)momentum) * (double)jb.running_mean[tid] + (double)momentum * mean);
+            jb.running_var[tid] = (float)((1.0 - (double)momentum) * (double)jb.running_var[tid] + (double)momentum * unbiased);
+        }
+    }
+    if (tid == 0 && jb.num_batches_tracked) *jb.num_batches_tracked += 1;
+}
+
+// The collision branch's BatchNorm record written by the LAST block of the GIN MLP kernel to finish (gin.hip): a ticket counter
+// (zero before the launch, reset by that block) replaces the 1-block finalize launch behind the kernel; the reduction of the
+// partial rows follows bn_finalize_kernel's tree (16 row groups, fixed fold), hence the same bits.
+struct GinFin {
+    unsigned *counter;           // NULL: no folded finalize
+    BnJob job;                   // (n_partials is filled in by the launcher)
+    int64_t n_total;
+    float eps, momentum;
+};
 // one block per job (1 or 2 BatchNorms of the same width finalised by one launch); bn_merge.hip
 void launch_bn_finalize(const BnJobs &jobs, int n_jobs, int mode, int f, int64_t n_total, float eps, float momentum,
                         hipStream_t s);
@@ -358,7 +391,13 @@ int dense_act_slots_bounded(const float *a, int32_t slot_width, int64_t slot_str
 // the MLP half of tgnn_gin_fwd (width 32) behind tgnn_gin_aggregate; gin.hip
 int launch_gin32_mlp(const float *z, const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
                      const float *b3, int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
-                     hipStream_t s);
+                     hipStream_t s, const GinFin *fin = nullptr);
+// tgnn_gin_fwd (width 32 fast path only: returns TGNN_ERR_UNSUPPORTED otherwise) with the BatchNorm finalize folded into the MLP
+// kernel's last block
+int gin32_fwd_folded(const float *a, int64_t lda, const float *in_stat, const int32_t *rowptr, const int32_t *col_src, const float *eps,
+                     const float *w1, const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
+                     int64_t n_nodes, int32_t act, float *out, float *z_scratch, double *bn_partial, int32_t *n_partials_host,
+                     const GinFin &fin, hipStream_t s);
 // Kernels that synchronise their blocks with spin barriers (the persistent small-layout forward, the one-launch small-layout
 // preparation) need ALL their blocks resident; two of them started side by side from different streams or threads could each
 // hold part of the CUs and wait for the rest for ever.  Every such launch goes through this per-device gate (forward_small.hip):
