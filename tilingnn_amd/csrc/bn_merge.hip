@@ -14,46 +14,54 @@
 namespace tgnn {
 
 // mode 0: partials->stat, 1: partials->sums, 2: sums->stat, 3: running stats->stat (eval mode)
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(BnJobs jobs, int mode, int f, int64_t n_total, float eps,
+// One block per (job, SLICE of 32 features): the block reduces the 64 column entries of its slice (32 sums, 32 sums of squares)
+// over all partial rows -- 16 row groups of the rows in order, every thread one batch of independent loads, then the fixed 16-way
+// fold.  For F = 32 that is the whole job (and the tree merge_bn1 / the shard kernels / the GIN kernel's last block repeat:
+// the same bits); a wide BatchNorm (the final MLP's 256 / 128 / 64 features, 512 partial rows of 4 KB) is spread over F / 32
+// blocks instead of one CU reading 2 MB by itself (14 -> 5 us per launch, six launches on the forward's serial tail).
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(BnJobs jobs, int mode, int f, int slices, int64_t n_total, float eps,
                                                            float momentum) {
     __shared__ double red[1024];
-    __shared__ double tot[512];
-    const BnJob jb = jobs.job[blockIdx.x];
+    __shared__ double tot[64];
+    const BnJob jb = jobs.job[blockIdx.x / slices];
+    const int slice = blockIdx.x % slices, f0 = slice * 32, fw = f - f0 < 32 ? f - f0 : 32;
     const int tid = threadIdx.x, two_f = 2 * f;
     // the affine parameters and running buffers are fetched up front: their round trip then overlaps the partial
-    // rows' instead of following it (this 1-block kernel is pure latency)
+    // rows' instead of following it (this kernel is pure latency)
     float pre_gamma = 1.f, pre_beta = 0.f, pre_rm = 0.f, pre_rv = 1.f;
-    if (tid < f && mode != 1) {
-        pre_gamma = jb.gamma[tid];
-        pre_beta = jb.beta[tid];
+    if (tid < fw && mode != 1) {
+        pre_gamma = jb.gamma[f0 + tid];
+        pre_beta = jb.beta[f0 + tid];
         if (jb.running_mean) {
-            pre_rm = jb.running_mean[tid];
-            pre_rv = jb.running_var[tid];
+            pre_rm = jb.running_mean[f0 + tid];
+            pre_rv = jb.running_var[f0 + tid];
         }
     }
     if (mode == 3) {
-        if (tid < f) {
+        if (tid < fw) {
             const double mean = (double)pre_rm;
             const double var = (double)pre_rv;
             const float mh = (float)mean;
-            jb.stat[tid] = mh;
-            jb.stat[f + tid] = (float)(mean - (double)mh);
-            jb.stat[2 * f + tid] = (float)((double)pre_gamma / sqrt(var + (double)eps));
-            jb.stat[3 * f + tid] = pre_beta;
+            jb.stat[f0 + tid] = mh;
+            jb.stat[f + f0 + tid] = (float)(mean - (double)mh);
+            jb.stat[2 * f + f0 + tid] = (float)((double)pre_gamma / sqrt(var + (double)eps));
+            jb.stat[3 * f + f0 + tid] = pre_beta;
         }
         return;
     }
+    // column entry of thread j < 64 of the slice: j < 32 the sum of feature f0 + j, else the sum of squares of feature f0 + j - 32
+    const int j = tid & 63, g = tid >> 6;
+    const bool live = (j & 31) < fw;
+    const int col = (j >> 5) * f + f0 + (j & 31);
     if (mode == 2) {
-        if (tid < two_f) tot[tid] = jb.sums[tid];
+        if (tid < 64) tot[tid] = live ? jb.sums[col] : 0.0;
     } else {
-        const int groups = 1024 / two_f;                     // >= 2 since F <= 256
-        const int j = tid % two_f, g = tid / two_f;
+        constexpr int groups = 16;
         double acc = 0.0;
-        if (g < groups) {
-            // all of a thread's partial rows are fetched before the first add: with <= 512 partial rows and
-            // >= 16 row groups that is one batch of <= 32 independent loads, i.e. ONE L2 round trip instead of
-            // one per row (the plain loop made this 1-block kernel cost 17 us, 8-deep batches 9.4 us)
-            const double *src = jb.partials + j;
+        if (live) {
+            // all of a thread's partial rows are fetched before the first add: with <= 512 partial rows and 16 row groups
+            // that is one batch of <= 32 independent loads, i.e. ONE L2 round trip instead of one per row
+            const double *src = jb.partials + col;
             int p = g;
             for (; p + 31 * groups < jb.n_partials; p += 32 * groups) {
                 double v[32];
@@ -73,32 +81,32 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(BnJobs jobs, int mode
         }
         red[tid] = acc;
         __syncthreads();
-        if (tid < two_f) {
+        if (tid < 64) {
             double t = 0.0;
-            for (int gg = 0; gg < groups; ++gg) t += red[gg * two_f + tid];
+            for (int gg = 0; gg < groups; ++gg) t += red[gg * 64 + tid];
             tot[tid] = t;
-            if (mode == 1) jb.sums[tid] = t;
+            if (mode == 1 && live) jb.sums[col] = t;
         }
         if (mode == 1) return;
     }
     __syncthreads();
-    if (tid < f) {
+    if (tid < fw) {
         const double inv_n = 1.0 / (double)n_total;
         const double mean = tot[tid] * inv_n;
-        double var = tot[f + tid] * inv_n - mean * mean;     // biased; fp64 sums of fp32 data
+        double var = tot[32 + tid] * inv_n - mean * mean;    // biased; fp64 sums of fp32 data
         if (var < 0.0) var = 0.0;
         const float mh = (float)mean;
-        jb.stat[tid] = mh;
-        jb.stat[f + tid] = (float)(mean - (double)mh);
-        jb.stat[2 * f + tid] = (float)((double)pre_gamma / sqrt(var + (double)eps));
-        jb.stat[3 * f + tid] = pre_beta;
+        jb.stat[f0 + tid] = mh;
+        jb.stat[f + f0 + tid] = (float)(mean - (double)mh);
+        jb.stat[2 * f + f0 + tid] = (float)((double)pre_gamma / sqrt(var + (double)eps));
+        jb.stat[3 * f + f0 + tid] = pre_beta;
         if (jb.running_mean) {
             const double unbiased = n_total > 1 ? var * ((double)n_total / (double)(n_total - 1)) : var;
-            jb.running_mean[tid] = (float)((1.0 - (double)momentum) * (double)pre_rm + (double)momentum * mean);
-            jb.running_var[tid] = (float)((1.0 - (double)momentum) * (double)pre_rv + (double)momentum * unbiased);
+            jb.running_mean[f0 + tid] = (float)((1.0 - (double)momentum) * (double)pre_rm + (double)momentum * mean);
+            jb.running_var[f0 + tid] = (float)((1.0 - (double)momentum) * (double)pre_rv + (double)momentum * unbiased);
         }
     }
-    if (tid == 0 && jb.num_batches_tracked) *jb.num_batches_tracked += 1;
+    if (tid == 0 && slice == 0 && jb.num_batches_tracked) *jb.num_batches_tracked += 1;
 }
 
 // absmax_out (optional, here and in the merge kernels): the largest |out| as float bits, by atomicMax into a word the caller
@@ -654,7 +662,8 @@ void launch_bn_apply(const float *v, int64_t ldv, const float *stat, int64_t n_r
 
 void launch_bn_finalize(const BnJobs &jobs, int n_jobs, int mode, int f, int64_t n_total, float eps, float momentum,
                         hipStream_t s) {
-    bn_finalize_kernel<<<n_jobs, 1024, 0, s>>>(jobs, mode, f, n_total, eps, momentum);
+    const int slices = (f + 31) / 32;
+    bn_finalize_kernel<<<n_jobs * slices, 1024, 0, s>>>(jobs, mode, f, slices, n_total, eps, momentum);
 }
 
 }  // namespace tgnn
@@ -676,7 +685,8 @@ extern "C" int tgnn_bn_finalize(int32_t mode, const double *partials, int32_t n_
     TGNN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running stats come in pairs");
     BnJobs jobs{};
     jobs.job[0] = BnJob{partials, n_partials, sums, gamma, beta, running_mean, running_var, num_batches_tracked, stat};
-    bn_finalize_kernel<<<1, 1024, 0, static_cast<hipStream_t>(stream)>>>(jobs, mode, f, n_rows_total, eps, momentum);
+    const int slices = (f + 31) / 32;
+    bn_finalize_kernel<<<slices, 1024, 0, static_cast<hipStream_t>(stream)>>>(jobs, mode, f, slices, n_rows_total, eps, momentum);
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
 }
