@@ -115,6 +115,24 @@ __global__ void bn_apply_kernel(const float *__restrict__ v, int64_t ldv, const 
                                 int f, float *__restrict__ out, int64_t ldo, unsigned *__restrict__ absmax_out) {
     const int64_t total = n * f;
     float am = 0.f;
+    if (f == 32 && ldv == 32 && ldo == 32 && (((uintptr_t)v | (uintptr_t)out | (uintptr_t)stat) & 15) == 0) {
+        // packed rows of 32 (the init MLP's output -> middle[0]): float4 per thread, the record's four float4 in registers
+        const int q = threadIdx.x & 7;                        // (the grid stride is a multiple of 8 float4)
+        const float4 mh = reinterpret_cast<const float4 *>(stat)[q], ml = reinterpret_cast<const float4 *>(stat + 32)[q];
+        const float4 gi = reinterpret_cast<const float4 *>(stat + 64)[q], be = reinterpret_cast<const float4 *>(stat + 96)[q];
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total / 4; i += (int64_t)gridDim.x * blockDim.x) {
+            const float4 x = reinterpret_cast<const float4 *>(v)[i];
+            float4 o;
+            o.x = bn_apply1(x.x, mh.x, ml.x, gi.x, be.x);
+            o.y = bn_apply1(x.y, mh.y, ml.y, gi.y, be.y);
+            o.z = bn_apply1(x.z, mh.z, ml.z, gi.z, be.z);
+            o.w = bn_apply1(x.w, mh.w, ml.w, gi.w, be.w);
+            reinterpret_cast<float4 *>(out)[i] = o;
+            am = absmax4(am, o);
+        }
+        absmax_flush(am, absmax_out);
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / f;
         const int c = (int)(i - r * f);

@@ -516,6 +516,84 @@ static void launch_dense(dim3 grid, hipStream_t s, const float *a, int64_t lda, 
 
 using namespace tgnn;
 
+// ------------------------------------------------------------------------------------------
+// The two ends of the network are too narrow for matrix tiles: the first init layer (Fx = 3 .. 8 inputs -> 32) and the read-out
+// (32 -> 1, sigmoid).  Through the 128-row MFMA kernels they cost 20 us each for 13 MB of traffic (one k-tile, mostly padding,
+// a block-level prologue and epilogue per 128 rows); as plain element-wise kernels they run at memory speed.
+// ------------------------------------------------------------------------------------------
+// out[r] = act( BN(a[r][:]) . w + b ), out_dim == 1: L = in_dim / 4 lanes per row (a power of two <= 64), float4 each, shuffle fold
+template <int L>
+__global__ __launch_bounds__(256) void dense_out1_kernel(const float *__restrict__ a, int64_t lda, const float *__restrict__ in_stat,
+                                                         const float *__restrict__ w, const float *__restrict__ bias, int64_t n,
+                                                         int in_dim, int act, float *__restrict__ out, int64_t ldo) {
+    const int q = threadIdx.x % L;
+    const float4 wv = reinterpret_cast<const float4 *>(w)[q];
+    float4 mh = make_float4(0, 0, 0, 0), ml = mh, gi = make_float4(1, 1, 1, 1), be = mh;
+    if (in_stat) {
+        mh = reinterpret_cast<const float4 *>(in_stat)[q];
+        ml = reinterpret_cast<const float4 *>(in_stat + in_dim)[q];
+        gi = reinterpret_cast<const float4 *>(in_stat + 2 * in_dim)[q];
+        be = reinterpret_cast<const float4 *>(in_stat + 3 * in_dim)[q];
+    }
+    const float b0 = bias[0];
+    constexpr int kRows = 256 / L;
+    for (int64_t r = (int64_t)blockIdx.x * kRows + threadIdx.x / L; r < n; r += (int64_t)gridDim.x * kRows) {
+        const float4 x = *reinterpret_cast<const float4 *>(a + r * lda + 4 * q);
+        float s = bn_apply1(x.x, mh.x, ml.x, gi.x, be.x) * wv.x;
+        s = fmaf(bn_apply1(x.y, mh.y, ml.y, gi.y, be.y), wv.y, s);
+        s = fmaf(bn_apply1(x.z, mh.z, ml.z, gi.z, be.z), wv.z, s);
+        s = fmaf(bn_apply1(x.w, mh.w, ml.w, gi.w, be.w), wv.w, s);
+#pragma unroll
+        for (int d = L / 2; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        if (q == 0) out[r * ldo] = act_apply(s + b0, act);
+    }
+}
+
+// out[r][0..32) = act( a[r][0..in_dim) . W^T + b ), in_dim <= 8, no input BatchNorm; 8 lanes per row, 4 outputs each; fp64 column
+// sums per block (one partial row per block, fixed order: rows of a thread in order, then the threads of a column group in order)
+__global__ __launch_bounds__(256) void dense_in8_kernel(const float *__restrict__ a, int64_t lda, const float *__restrict__ w,
+                                                        const float *__restrict__ bias, int64_t n, int in_dim, int act,
+                                                        float *__restrict__ out, int64_t ldo, double *__restrict__ bn_partial) {
+    __shared__ double red[256 * 8];
+    const int tid = threadIdx.x, q = tid & 7;
+    float wr[4][8];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wr[o][k] = k < in_dim ? w[(4 * q + o) * in_dim + k] : 0.f;
+    const float4 bv = reinterpret_cast<const float4 *>(bias)[q];
+    double cs[4] = {0, 0, 0, 0}, cq[4] = {0, 0, 0, 0};
+    for (int64_t r = (int64_t)blockIdx.x * 32 + (tid >> 3); r < n; r += (int64_t)gridDim.x * 32) {
+        float x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = k < in_dim ? a[r * lda + k] : 0.f;
+        float o4[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o4[o] = fmaf(x[k], wr[o][k], o4[o]);
+            o4[o] = act_apply(o4[o], act);
+            cs[o] += (double)o4[o];
+            cq[o] += (double)o4[o] * (double)o4[o];
+        }
+        *reinterpret_cast<float4 *>(out + r * ldo + 4 * q) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+    }
+    if (bn_partial) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            red[tid * 8 + o] = cs[o];
+            red[tid * 8 + 4 + o] = cq[o];
+        }
+        __syncthreads();
+        if (tid < 64) {                                       // entry = which * 32 + column; column = 4 q + o
+            const int which = tid >> 5, colm = tid & 31, qq = colm >> 2, o = colm & 3;
+            double t = 0.0;
+            for (int g = 0; g < 32; ++g) t += red[(g * 8 + qq) * 8 + which * 4 + o];
+            bn_partial[(int64_t)blockIdx.x * 64 + tid] = t;
+        }
+    }
+}
+
 static int dense_act_impl(const float *a, int64_t lda, int64_t a_kblock_stride, int kps, const float *in_stat,
                           const float *w, const float *b, int64_t n_rows, int32_t in_dim, int32_t out_dim, int32_t act,
                           float *out, int64_t ldo, double *bn_partial, int32_t *n_partials_host, tgnn_stream_t stream,
@@ -532,6 +610,32 @@ static int dense_act_impl(const float *a, int64_t lda, int64_t a_kblock_stride, 
     TGNN_CHECK_ARG(kps >= 1, "K blocks per slot");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int vec_a = (lda % 4 == 0) && (a_kblock_stride % 4 == 0) && ((uintptr_t)a % 16 == 0);
+    // ---- the network's two narrow ends as element-wise kernels (see dense_out1_kernel / dense_in8_kernel)
+    if (out_dim == 1 && !bn_partial && kps == 1 && a_kblock_stride == kBK && vec_a && in_dim >= 4 && in_dim <= 256 &&
+        (in_dim & (in_dim - 1)) == 0 && ((uintptr_t)w % 16 == 0) && (!in_stat || (uintptr_t)in_stat % 16 == 0)) {
+        int64_t nb = (n_rows * (in_dim / 4) + 255) / 256;
+        if (nb > 2048) nb = 2048;
+        const unsigned g = (unsigned)nb;
+        switch (in_dim / 4) {
+            case 1: dense_out1_kernel<1><<<g, 256, 0, s>>>(a, lda, in_stat, w, b, n_rows, in_dim, act, out, ldo); break;
+            case 2: dense_out1_kernel<2><<<g, 256, 0, s>>>(a, lda, in_stat, w, b, n_rows, in_dim, act, out, ldo); break;
+            case 4: dense_out1_kernel<4><<<g, 256, 0, s>>>(a, lda, in_stat, w, b, n_rows, in_dim, act, out, ldo); break;
+            case 8: dense_out1_kernel<8><<<g, 256, 0, s>>>(a, lda, in_stat, w, b, n_rows, in_dim, act, out, ldo); break;
+            case 16: dense_out1_kernel<16><<<g, 256, 0, s>>>(a, lda, in_stat, w, b, n_rows, in_dim, act, out, ldo); break;
+            case 32: dense_out1_kernel<32><<<g, 256, 0, s>>>(a, lda, in_stat, w, b, n_rows, in_dim, act, out, ldo); break;
+            default: dense_out1_kernel<64><<<g, 256, 0, s>>>(a, lda, in_stat, w, b, n_rows, in_dim, act, out, ldo); break;
+        }
+        if (n_partials_host) *n_partials_host = 0;
+        TGNN_CHECK_LAUNCH();
+        return TGNN_OK;
+    }
+    if (in_dim <= 8 && out_dim == 32 && !in_stat && kps == 1 && ldo % 4 == 0 && ((uintptr_t)out % 16 == 0) && ((uintptr_t)b % 16 == 0)) {
+        const int nb = producer_blocks(n_rows, 32 * 8);       // 32 rows per sweep, ~8 sweeps per block; <= TGNN_BN_MAX_PARTIALS
+        dense_in8_kernel<<<nb, 256, 0, s>>>(a, lda, w, b, n_rows, in_dim, act, out, ldo, bn_partial);
+        if (n_partials_host) *n_partials_host = nb;
+        TGNN_CHECK_LAUNCH();
+        return TGNN_OK;
+    }
     const int vec_w = (in_dim % 4 == 0) && ((uintptr_t)w % 16 == 0);
     // one block = one BatchNorm partial row, hence the cap of producer_blocks; a product nobody takes statistics of (the
     // backward's dx = dz . W, the GIN hidden layers it re-derives) gets one block per row tile instead of walking two
