@@ -20,6 +20,7 @@
 // register pipeline (index load -> gather -> consume), across tile boundaries.  D^T = W^T . S^T is computed
 // (operands swapped) so that a lane ends up with 4 consecutive output channels of ONE row: float4 stores.
 #include <atomic>
+#include <type_traits>
 
 #include "tgnn_common.h"
 
@@ -42,7 +43,11 @@ constexpr int kColStage = 16 * 20;         // floats of the per-wave BN staging 
 // F16: the 3-term fp16-pair split instead of the 6-term bf16 x 3 one (tgnn_common.h: split2_f16).  The summed source rows
 // are multiplied by the power of two sx that keeps max_in_degree * max |h| below 2^15 (h_max: the bound the producer of h
 // left as float bits), the image's weights by nnconv_weight_scale(max |root|); both come off again with the 1 / deg.
-template <int DEPTH, int WAVES, int OCC, bool F16>
+// FAST (ldh == 32, packed 128-byte rows): the steady state of the column stream -- every group whose gathers lie before the
+// end of the wave's share -- runs without the masks of the general path: a source word IS the gather offset but for a shift
+// (-1 lands beyond the descriptor's range and loads zeros), the root column's own-row offset is kept in a register and moves
+// on once per tile, the end-of-share tests are gone.  28 instructions per column become 10; same arithmetic, same bits.
+template <int DEPTH, int WAVES, int OCC, bool F16, bool FAST>
 __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
     const float *__restrict__ h, int64_t ldh, const int *__restrict__ tile_col_ptr, const int *__restrict__ col_meta,
     const int *__restrict__ col_src, const float *__restrict__ wimg, int n_types, const float *__restrict__ bias,
@@ -149,14 +154,37 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
         x[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, off + 16u, 0, 0));
         if (root) ++gtile;                                   // wave-uniform
     };
+    // steady state (FAST): see the kernel's header.  own_off: this lane's 32 bytes of its own row of the tile the gather
+    // stage is at (rows past n, last tile: out of range)
+    const uint32_t fq_bytes = (uint32_t)fq * 32u;
+    auto own_off_of = [&](int64_t tile) -> uint32_t {
+        const int64_t r = tile * 16 + fj;
+        return r < n ? (uint32_t)r * 128u + fq_bytes : 0x80000000u;
+    };
+    uint32_t own_off = 0;
+    auto unpack_steady = [&](int u, int s4, int m4, int &s, int &m) {
+        s = __shfl(s4, u * 16 + fj, 64);
+        m = __builtin_amdgcn_readlane(m4, u);
+    };
+    auto issue_gather_steady = [&](int s, int mu, float4 (&x)[2]) {
+        const bool root = (mu & kColMetaEnd) != 0;           // wave-uniform; the root column is the one that ends a tile
+        const uint32_t off = root ? own_off : ((uint32_t)s << 7) + fq_bytes;   // s = -1: 0xffffff80 + .. >= 2 GB, loads zeros
+        x[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, off, 0, 0));
+        x[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, off + 16u, 0, 0));
+        if (root) {
+            ++gtile;
+            own_off = own_off_of(gtile);
+        }
+    };
 
     // ONE accumulator pair: the root block's operand is pre-multiplied by max(deg, 1) (the root column carries it), so
     // that a single 1/deg at the end turns the edge sum into the mean and leaves the root term as it is
     f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;               // D^T tiles: channels 4 fq + r and 16 + 4 fq + r of row fj
     float af[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t ctile = t0;
-    auto consume = [&](int s, int mu, const float4 (&x)[2]) {
-        if (mu & kColMetaSkip) return;                       // wave-uniform
+    auto consume = [&](auto steady, int s, int mu, const float4 (&x)[2]) {
+        if constexpr (!decltype(steady)::value)
+            if (mu & kColMetaSkip) return;                   // wave-uniform (a steady-state column is never a skip)
         const int t = mu & 0xff;
         const bool valid = s >= 0;                           // (empty slots were loaded as zeros)
         const float xv[8] = {x[0].x, x[0].y, x[0].z, x[0].w, x[1].x, x[1].y, x[1].z, x[1].w};
@@ -288,7 +316,26 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
             }
     }
     TGNN_CT(0)
-    for (int base = cbeg; base < cend; base += 4 * G) {
+    int base = cbeg;
+    if constexpr (FAST) {
+        own_off = own_off_of(gtile);
+        for (; base + 8 * G <= cend; base += 4 * G) {        // the groups gathered in this round lie before cend
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                int s4c, m4c;
+                load_group(base + 4 * (2 * G + g), s4c, m4c);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    consume(std::true_type{}, xs[g][u], xm[g][u], x[g][u]);
+                    unpack_steady(u, s4n[g], m4n[g], xs[g][u], xm[g][u]);
+                    issue_gather_steady(xs[g][u], xm[g][u], x[g][u]);
+                }
+                s4n[g] = s4c;
+                m4n[g] = m4c;
+            }
+        }
+    }
+    for (; base < cend; base += 4 * G) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             int s4c, m4c;
@@ -296,7 +343,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
             TGNN_CT(6)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                consume(xs[g][u], xm[g][u], x[g][u]);
+                consume(std::false_type{}, xs[g][u], xm[g][u], x[g][u]);
                 unpack(base + 4 * (G + g), u, s4n[g], m4n[g], xs[g][u], xm[g][u]);
                 TGNN_CT(4)
                 issue_gather(xs[g][u], xm[g][u], x[g][u]);
@@ -345,10 +392,11 @@ static int launch_cols_t(const float *h, int64_t ldh, const int32_t *tile_col_pt
                          int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
                          int blocks_per_cu, hipStream_t s, const unsigned *h_max = nullptr, const unsigned *root_max = nullptr,
                          int deg_log2 = 0, unsigned long long *stamp = nullptr) {
-    auto kern = nnconv32_cols_kernel<DEPTH, WAVES, OCC, F16>;
+    const bool fast = ldh == 32;
+    auto kern = fast ? nnconv32_cols_kernel<DEPTH, WAVES, OCC, F16, true> : nnconv32_cols_kernel<DEPTH, WAVES, OCC, F16, false>;
     // the opt-in to > 64 KB of dynamic LDS is a per-device attribute of the function: set once per device (idempotent)
-    static LdsOptIn site;
-    TGNN_CHECK_HIP(opt_in_dynamic_lds(kern, (int)kColsMaxLds, site));
+    static LdsOptIn site[2];
+    TGNN_CHECK_HIP(opt_in_dynamic_lds(kern, (int)kColsMaxLds, site[fast]));
     const int64_t n_tiles = (n_nodes + 15) / 16;
     // One tile per SIMD before a second wave of a SIMD gets one: a small layout is bound by the latency of a tile, and
     // waves that share a SIMD stretch each other's (matrix and vector issue do not overlap).  Large layouts hit the cap.
