@@ -166,6 +166,7 @@ __global__ __launch_bounds__(kMlpThreads, 2) void gin32_mlp_kernel(
     float4 zin[2];
     load_z(t0 < t1 ? t0 : 0, zin);                          // in flight while the weight images are built
 
+#ifndef TGNN_ABL_GINNOPRO
     for (int i = tid; i < 2 * 64; i += kMlpThreads) {       // item = (M block, i, q): 8 weights
         const int mb = i >> 6, ii = (i >> 2) & 15, q = i & 3;
         float x[8];
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(kMlpThreads, 2) void gin32_mlp_kernel(
         const int o = (mb * 2 + ks) * 64 + ii * 4 + q;
         gin_split3(x, W3s[0 * 256 + o], W3s[1 * 256 + o], W3s[2 * 256 + o]);
     }
+#endif
     if (tid < 32) Bs[tid] = b1[tid];
     else if (tid < 96) Bs[tid] = b2[tid - 32];
     else if (tid < 128) Bs[tid] = b3[tid - 96];
@@ -387,6 +389,11 @@ __global__ __launch_bounds__(256) void gin_generic_kernel(
 }  // namespace tgnn
 
 using namespace tgnn;
+namespace tgnn { std::atomic<int> g_debug_block_cap[2]; }
+extern "C" void tgnn_debug_set_block_caps(int32_t nnconv_blocks, int32_t gin_mlp_blocks) {
+    g_debug_block_cap[0].store(nnconv_blocks);
+    g_debug_block_cap[1].store(gin_mlp_blocks);
+}
 
 namespace tgnn {
 int gin32_fwd_folded(const float *a, int64_t lda, const float *in_stat, const int32_t *rowptr, const int32_t *col_src, const float *eps,
@@ -452,6 +459,7 @@ int launch_gin32_mlp(const float *z, const float *w1, const float *b1, const flo
     int blocks = producer_blocks(n_nodes, 16 * kMlpWaves);
     constexpr int reserve = 32;
     if (blocks > cus_minus(reserve)) blocks = cus_minus(reserve);
+    if (const int dbg = g_debug_block_cap[1].load(); dbg > 0 && blocks > dbg) blocks = dbg;
     if (blocks >= 8) blocks &= ~7;
     GinFin f{};
     if (fin && bn_partial) {

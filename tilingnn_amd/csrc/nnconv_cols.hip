@@ -411,6 +411,7 @@ static int launch_cols_t(const float *h, int64_t ldh, const int32_t *tile_col_pt
     constexpr int reserve = 32;
     const int64_t cap = cus_minus(reserve) * (int64_t)blocks_per_cu;
     if (blocks > cap) blocks = cap;
+    if (const int dbg = g_debug_block_cap[0].load(); dbg > 0 && blocks > dbg) blocks = dbg;
     if (blocks >= 8) blocks &= ~7;
     if (blocks < 1) blocks = 1;
     kern<<<(unsigned)blocks, WAVES * 64, cols_lds_bytes(n_types, WAVES, F16), s>>>(

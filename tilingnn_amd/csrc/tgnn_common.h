@@ -389,6 +389,8 @@ int dense_act_slots_bounded(const float *a, int32_t slot_width, int64_t slot_str
                             double *bn_partial, int32_t *n_partials_host, const unsigned *a_max, int n_a_max,
                             const unsigned *w_max, hipStream_t s);
 // the MLP half of tgnn_gin_fwd (width 32) behind tgnn_gin_aggregate; gin.hip
+// experiment knob (tgnn_debug_set_block_caps): upper bounds of the whole-CU kernels' grids, 0 = the built-in policy
+extern std::atomic<int> g_debug_block_cap[2];   // [0] column NNConv, [1] GIN MLP
 int launch_gin32_mlp(const float *z, const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
                      const float *b3, int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
                      hipStream_t s, const GinFin *fin = nullptr);
