@@ -47,4 +47,6 @@ MASTER_ADDR=127.0.0.1 MASTER_PORT=29577 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout
 timeout 200 python scratch/time_many.py > $O/forward_many.txt 2>&1
 timeout 300 python scratch/time_small.py 300 1254 2500 4096 > $O/small_layout_times.txt 2>&1
 timeout 300 python scratch/time_fwd.py > $O/forward_sizes.txt 2>&1
+
+timeout 200 python scratch/mid_size.py > $O/mid_sizes.txt 2>&1
 ls -la $O

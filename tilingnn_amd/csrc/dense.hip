@@ -365,7 +365,11 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(
             const float x[8] = {rb[j][0].x, rb[j][0].y, rb[j][0].z, rb[j][0].w, rb[j][1].x, rb[j][1].y, rb[j][1].z, rb[j][1].w};
             if constexpr (F16) {
                 f16x8 hi, lo;
+#ifdef TGNN_ABL_BSPLIT
+                hi = __builtin_bit_cast(f16x8, rb[j][0]); lo = __builtin_bit_cast(f16x8, rb[j][1]);   // (timing ablation: a pre-split image)
+#else
                 split2_f16(x, sw, hi, lo);
+#endif
                 *reinterpret_cast<f16x8 *>(Bs + (0 * BN + r) * kSplitLd + 8 * o) = hi;
                 *reinterpret_cast<f16x8 *>(Bs + (1 * BN + r) * kSplitLd + 8 * o) = lo;
             } else {
