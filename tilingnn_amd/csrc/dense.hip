@@ -348,7 +348,11 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(
             }
             if constexpr (F16) {
                 f16x8 hi, lo;
+#ifdef TGNN_ABL_ASPLIT
+                hi = __builtin_bit_cast(f16x8, ra[j][0]); lo = __builtin_bit_cast(f16x8, ra[j][1]);   // (timing ablation: pre-split activations)
+#else
                 split2_f16(x, sa, hi, lo);
+#endif
                 *reinterpret_cast<f16x8 *>(As + (0 * BM + r) * kSplitLd + 8 * o) = hi;
                 *reinterpret_cast<f16x8 *>(As + (1 * BM + r) * kSplitLd + 8 * o) = lo;
             } else {
