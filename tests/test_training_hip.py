@@ -362,9 +362,12 @@ def test_trainer_loop_on_layout_files(tmp_path):
 # Which parameters a float32 run of this ill-conditioned step gets wrong by how much is a lottery of the rounding realisation
 # (scratch/grad_ratio.py, ten seeds, two builds that differ in the summation order of the first layer: the worst per-parameter
 # ratio against the float32 oracle is 0.1 .. 1.3 on seven seeds and 13 .. 114 on the other three -- and WHICH three changes with the
-# build; the float32 oracle's own worst parameter spans 3e-4 .. 8.5e-2 over the seeds).  So the gate is over NINE seeds: the
-# median of the per-seed worst ratios stays below 4, at most four seeds draw a bad realisation, and no seed is off by more than a
-# wrong adjoint would be small (a wrong adjoint is off by O(1) on every seed).
+# build; the float32 oracle's own worst parameter spans 3e-4 .. 8.5e-2 over the seeds).  A seed draws a bad realisation with
+# probability ~0.3, independently of the others and anew with every build.  So the gate is over NINE seeds and asks for what a
+# correct adjoint delivers with probability 0.996 whatever the draw: at least THREE seeds whose worst parameter is within 4 x of
+# the float32 oracle's own error (a rule on the median would fail one build in ten by the draw alone), and no seed off by more
+# than the float32 oracle itself can be.  A wrong adjoint -- a systematic relative error of 1e-3 on one parameter is a ratio of
+# ~1 000 -- is off on EVERY seed and fails both.
 GRAD_SEEDS = (1, 2, 3, 4, 5, 6, 7, 8, 9)
 
 
@@ -407,7 +410,8 @@ def test_training_step_with_many_edge_types():
         assert max(errs.values()) < max(0.06, 2.0 * max(err32.values())), max(errs.items(), key=lambda kv: kv[1])
         worst.append(max(e / (max(err32[k], floor) + 2.5e-6) for k, e in errs.items()))
     print("worst parameter, ours / float32 oracle, per seed:", [f"{w:.1f}" for w in worst])
-    assert float(np.median(worst)) <= 4.0 and sum(w > 8.0 for w in worst) <= 4, worst
+    print(f"median {float(np.median(worst)):.1f}, third best {sorted(worst)[2]:.1f}")
+    assert sorted(worst)[2] <= 4.0, worst
 
 
 @pytest.mark.parametrize("case,fe,depth,seed", [("small", 15, 3, 5), ("tiny", 6, 3, 3), ("laby", 15, 20, 0)])
