@@ -477,7 +477,7 @@ int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edges, const fl
  * previous one. */
 int32_t tgnn_debug_set_csr_bucket_cap(int32_t cap);
 /* (experiments: scratch/block_caps.py, scratch/mid_trace.sh) upper bounds on the grids of the two kernels whose blocks need a CU to
- * themselves -- the column NNConv and the GIN MLP; 0 = the built-in policy (device CUs minus 32 each). */
+ * themselves -- the column NNConv and the GIN MLP (at most the device's CU count); 0 = the built-in policy (device CUs minus 32 each). */
 void tgnn_debug_set_block_caps(int32_t nnconv_blocks, int32_t gin_mlp_blocks);
 
 /* The same forward with a hipEvent pair around every launch (on `stream`, where the kernels run);

@@ -9,7 +9,7 @@ from tilingnn_amd.weights import make_state_dict
 dev = torch.device('cuda:0')
 f = _lib.lib.tgnn_debug_set_block_caps
 net = TilinGNN(15, 20, 32, node_features_dim=3); net.load_state_dict(make_state_dict(15, 20, 32, 1, 3)); net = net.to(dev).train()
-caps = [(0, 0), (128, 128), (160, 96), (96, 160), (128, 96), (112, 112), (64, 64)]
+caps = [(0, 0), (256, 224), (240, 224), (256, 192), (240, 192), (224, 192), (224, 160), (256, 256), (0, 0)]
 for n in [int(a) for a in sys.argv[1:]] or [5000, 10000, 20000, 30000, 50000, 100000]:
     sg = make_super_graph(n, 10 * n, 12 * n + n // 2, tile_count=2, n_edge_types=13, seed=2)
     x, adj, attr, col, _ = sg.to_torch(dev)

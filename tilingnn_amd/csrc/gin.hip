@@ -458,8 +458,9 @@ int launch_gin32_mlp(const float *z, const float *w1, const float *b1, const flo
                      hipStream_t s, const GinFin *fin) {
     int blocks = producer_blocks(n_nodes, 16 * kMlpWaves);
     constexpr int reserve = 32;
-    if (blocks > cus_minus(reserve)) blocks = cus_minus(reserve);
-    if (const int dbg = g_debug_block_cap[1].load(); dbg > 0 && blocks > dbg) blocks = dbg;
+    int cap = cus_minus(reserve);
+    if (const int dbg = g_debug_block_cap[1].load(); dbg > 0) cap = dbg < device_cus() ? dbg : device_cus();
+    if (blocks > cap) blocks = cap;
     if (blocks >= 8) blocks &= ~7;
     GinFin f{};
     if (fin && bn_partial) {

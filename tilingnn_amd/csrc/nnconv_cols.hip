@@ -409,9 +409,9 @@ static int launch_cols_t(const float *h, int64_t ldh, const int32_t *tile_col_pt
     // 1.43 / 1.36 / 1.35 / 1.39, 100 000 nodes 2.29 / 2.27 / 2.23 / 2.25; the isolated kernel at 100k nodes: 45.7 us on
     // 256 CUs, 47.8 on 224 (6 250 tiles are 7 per SIMD either way), 56.5 on 192, 71.6 on 128.
     constexpr int reserve = 32;
-    const int64_t cap = cus_minus(reserve) * (int64_t)blocks_per_cu;
+    int64_t cap = cus_minus(reserve) * (int64_t)blocks_per_cu;
+    if (const int dbg = g_debug_block_cap[0].load(); dbg > 0) cap = (dbg < device_cus() ? dbg : device_cus()) * (int64_t)blocks_per_cu;
     if (blocks > cap) blocks = cap;
-    if (const int dbg = g_debug_block_cap[0].load(); dbg > 0 && blocks > dbg) blocks = dbg;
     if (blocks >= 8) blocks &= ~7;
     if (blocks < 1) blocks = 1;
     kern<<<(unsigned)blocks, WAVES * 64, cols_lds_bytes(n_types, WAVES, F16), s>>>(
