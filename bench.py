@@ -412,6 +412,12 @@ def main():
         roofline["whole_forward"] = {"algorithmic_bytes": forward_bytes(n_total, ea_total, ec_total, n_types_seen),
                                      "frac_of_hbm_peak": forward_bytes(n_total, ea_total, ec_total, n_types_seen)
                                      / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if os.path.exists(prof_file) and (n_total, ea_total, n_types_seen) == (100_000, 1_000_000, 13):
+            with open(prof_file) as fh:
+                q = json.load(fh)
+            if q.get("whole_forward_hbm_bytes_pmc"):      # quoted: HBM bytes of one cached-layout forward by PMC counters
+                roofline["whole_forward"]["traffic"] = q["whole_forward_hbm_bytes_pmc"]
+                roofline["whole_forward"]["traffic_source"] = q.get("whole_forward_hbm_source")
 
     # ---- larger single-GPU layouts (BASELINE configs 4 / 5 are 500k / 2M nodes over 4 / 8 GPUs; here on ONE GPU, drawn
     #      on the device): step time with graph preparation, kernel classes, fractions of the HBM bound per kernel
