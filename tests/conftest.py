@@ -33,8 +33,9 @@ def general_schedule():
 
 @pytest.fixture
 def bf16x3_split():
-    """The single-device general schedule runs its matrix-core kernels with the fp16 x 2 split (tgnn_set_split_precision), the
-    sharded schedule with bf16 x 3: tests that compare the two at rounding level put both on bf16 x 3."""
+    """The single-device general schedule and the fused sharded schedule (one all-to-all per layer) run their matrix-core kernels
+    with the fp16 x 2 split (tgnn_set_split_precision); the per-op entry points, eval mode and the all-reduce + all-to-all sharded
+    scheme run bf16 x 3: tests that compare the two at rounding level put everything on bf16 x 3."""
     from tilingnn_amd import _lib
     before = _lib.lib.tgnn_set_split_precision(0)
     try:

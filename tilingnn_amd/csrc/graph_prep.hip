@@ -1662,10 +1662,20 @@ extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edge
     }
     int rc;
     bool bucketed = false;
+    // an error return between the fork and the join must not leave side-stream work in flight on the caller's buffers (the
+    // Python side frees the scratch as soon as the call raises): the caller's stream waits for whatever was queued there
+    auto bail = [&](int code) {
+        if (s_side && hipEventRecord(ev_join, s_side) == hipSuccess) (void)hipStreamWaitEvent(s, ev_join, 0);
+        return code;
+    };
     if (s_side) {
         rc = edge_type_dedup_listed(adj_edge_attr, n_adj_edges, fe, edge_type, type_rep_edge, result + 0, result + 6, ws_dd, dd_b, s_side);
-        if (rc != TGNN_OK) return rc;
-        TGNN_CHECK_HIP(hipEventRecord(ev_join, s_side));
+        if (rc != TGNN_OK) return bail(rc);
+        if (hipEventRecord(ev_join, s_side) != hipSuccess) {
+            (void)hipStreamSynchronize(s_side);
+            set_error("tgnn_graph_prep: hipEventRecord failed");
+            return TGNN_ERR_LAUNCH;
+        }
     }
     if (bk_fits(n_nodes) && n_adj_edges < (int64_t(1) << 31) - 1 && n_col_edges < (int64_t(1) << 31) - 1) {
         // both CSRs through 512-row buckets: four kernels + one scan, no device-scope returning atomic
@@ -1673,13 +1683,13 @@ extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edge
         void *ws_bk = cv.take<unsigned char>(bk_b);
         rc = csr_build_pair_bucketed(adj_edge_index, n_adj_edges, col_edge_index, n_col_edges, n_nodes, n_src_nodes, adj_rowptr, adj_src,
                                      adj_eid, result + 1, col_rowptr, col_src, col_eid, result + 2, result + 4, result + 3, ws_bk, bk_b, s);
-        if (rc != TGNN_OK) return rc;
+        if (rc != TGNN_OK) return bail(rc);
         bucketed = true;
     } else {
         rc = tgnn_csr_build(adj_edge_index, n_adj_edges, n_nodes, n_src_nodes, 0, adj_rowptr, adj_src, adj_eid, result + 1, ws_csr, csr_b, stream);
-        if (rc != TGNN_OK) return rc;
+        if (rc != TGNN_OK) return bail(rc);
         rc = tgnn_csr_build(col_edge_index, n_col_edges, n_nodes, n_src_nodes, 1, col_rowptr, col_src, col_eid, result + 2, ws_csr, csr_b, stream);
-        if (rc != TGNN_OK) return rc;
+        if (rc != TGNN_OK) return bail(rc);
     }
     if (s_side) {
         TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev_join, 0));

@@ -80,12 +80,20 @@ int rccl_alltoall_rows(void *comm, const float *send, float *recv, const int64_t
     ncclComm_t c = static_cast<ncclComm_t>(comm);
     TGNN_CHECK_RCCL(api, api->GroupStart());
     size_t so = 0, ro = 0;
-    for (int p = 0; p < world; ++p) {
+    // a failure between GroupStart and GroupEnd must not leave the thread's RCCL group open: the library shares the process's
+    // librccl with torch.distributed, whose later collectives on this thread would then be deferred for ever instead of failing
+    ncclResult_t bad = ncclSuccess;
+    for (int p = 0; p < world && bad == ncclSuccess; ++p) {
         const size_t ns = (size_t)(send_counts[p] + extra_rows) * row_floats, nr = (size_t)(recv_counts[p] + extra_rows) * row_floats;
-        if (ns) TGNN_CHECK_RCCL(api, api->Send(send + so, ns, ncclFloat32, p, c, s));
-        if (nr) TGNN_CHECK_RCCL(api, api->Recv(recv + ro, nr, ncclFloat32, p, c, s));
+        if (ns) bad = api->Send(send + so, ns, ncclFloat32, p, c, s);
+        if (nr && bad == ncclSuccess) bad = api->Recv(recv + ro, nr, ncclFloat32, p, c, s);
         so += ns;
         ro += nr;
+    }
+    if (bad != ncclSuccess) {
+        (void)api->GroupEnd();
+        set_error("rccl_alltoall_rows: RCCL: %s", api->GetErrorString(bad));
+        return TGNN_ERR_LAUNCH;
     }
     TGNN_CHECK_RCCL(api, api->GroupEnd());
     g_n_alltoall.fetch_add(1, std::memory_order_relaxed);

@@ -113,6 +113,24 @@ def exchange_send_lists(shards_halo_ids: Sequence[np.ndarray], n_total: int, wor
     return out
 
 
+class EmptyShardError(ValueError):
+    """A rank's node range holds no node (check_no_empty_rank; raised on EVERY rank together)."""
+
+
+def check_no_empty_rank(shard: Shard) -> None:
+    """The HIP forward of a shard needs rows on EVERY rank (train-mode BatchNorm, tgnn_graph_prep and tgnn_forward_sharded take
+    n_nodes >= 1), and a rank that raised alone would leave the others waiting in an all-to-all for ever.  Every rank holds the
+    same `bounds` (compact_shard derives them from the global alive mask), so every rank raises HERE, together, before any
+    collective is issued; callers re-shard the remainder over fewer ranks (solve_sharded) -- a late greedy round of a large
+    layout is a small layout."""
+    b = shard.bounds if shard.bounds is not None else even_bounds(shard.n_total, shard.world)
+    sizes = np.diff(np.asarray(b, dtype=np.int64))
+    if np.any(sizes < 1):
+        empty = [int(r) for r in np.nonzero(sizes < 1)[0]]
+        raise EmptyShardError(f"ranks {empty} own no node of the {shard.n_total}-node layout split over {shard.world} ranks: "
+                              "re-shard over fewer ranks")
+
+
 def compact_shard(shard: Shard, alive: np.ndarray) -> Shard:
     """A greedy round later (the reference's util/algorithms.py:18-62 scores, every round, the sub-layout of the still
     unlabelled nodes: tiling/brick_layout.py:248-286): this rank's shard of that sub-layout, cut LOCALLY from its shard of the
@@ -121,7 +139,9 @@ def compact_shard(shard: Shard, alive: np.ndarray) -> Shard:
       loop over the gathered probabilities).
     The sub-layout's nodes are numbered as compute_sub_layout numbers them (rank among the alive ones), every rank keeps the
     survivors of its own range (so the ranges stay contiguous: `bounds`), an edge survives iff both ends do, in its old order;
-    the halo = the alive remote sources of the surviving edges.  The communicator's setup must run again (send lists)."""
+    the halo = the alive remote sources of the surviving edges.  The communicator's setup must run again (send lists).
+    A range may come out EMPTY (n_own == 0): the Python schedule over a CPU backend runs such a shard, the HIP forward does not
+    (check_no_empty_rank raises on every rank together)."""
     world, rank = shard.world, shard.rank
     alive = np.asarray(alive, dtype=bool)
     assert alive.shape[0] == shard.n_total
@@ -176,6 +196,7 @@ class HipBackend:
 
     def prepare(self, shard: Shard, inputs: Dict[str, Tensor]):
         """Per-forward graph preparation on the device-resident inputs (CSR, edge types, NNConv tiles)."""
+        check_no_empty_rank(shard)
         g = self.ops.prepare_graph(shard.n_own, inputs["adj"], inputs["attr"], inputs["col"], n_src_nodes=shard.n_rows)
         return g, inputs["attr"]
 
@@ -411,6 +432,7 @@ class FusedShardForward:
         self._C, self._lib, self._ops = C, _lib, ops
         self.net, self.shard, self.comm, self.dev = net, shard, comm, torch.device(device)
         assert shard.send_ids is not None, "shard.send_ids not set: run the communicator's setup first"
+        check_no_empty_rank(shard)
         self.inputs = inputs if inputs is not None else HipBackend(device).upload(shard)
         c = net.network_width
         self.n_send = int(self.inputs["send_idx"].shape[0])
