@@ -162,40 +162,28 @@ int tgnn_nnconv_mean_cols_f16_fwd(const float *h, int64_t ldh, int64_t n_src_row
                                   float *out, float *wimg_scratch, uint32_t *bounds_scratch, double *bn_partial,
                                   int32_t *n_partials_host, tgnn_stream_t stream);
 
-/* The same NNConv as a STREAM of gathered rows through an LDS ring (csrc/nnconv_stream.hip; the throughput kernel, production
- * path of tgnn_forward when the graph carries the structure): message, scatter-mean, update in the reference's order.  Two
- * loader waves fetch the source rows of a block's tiles by LDS-DMA -- rows pre-split into fp16 pairs, so that a gathered row
- * is a matrix operand --, eight multiplying waves keep the weight fragments of their edge types in registers and multiply 16
- * edges of one type at a time, two epilogue waves add every destination row's messages in CSR order.  Built from the
- * adjacency CSR + the edge types in CSR order (once per layout):
- *   tile_ent_ptr int32  [ceil(N/16)+1]   entries before every 16-row tile (multiples of 8)
- *   ent          uint32 [tgnn_nnconv_stream_max_entries(N, E)]  entry words (source row << 7 | piece permutation << 4): per
- *                                        tile its edge types in order, the tile's own rows last (root run); inside a type the
- *                                        destination rows ascending, a row's edges in CSR order
- *   rowlist      uint16 [same count]     per tile, row by row: where the messages of the row's edges (CSR order), then of
- *                                        the row itself, sit in the kernel's message ring
- *   info         uint32 [ceil(N/16)][64] per multiplying wave the first entry / length of its two type runs; the rows' list
- *                                        positions
- *   inv_deg      float  [16 ceil(N/16)]  1 / max(in-degree, 1)
- * result (device int32 [4]): most (padded) entries of two consecutive tiles, most entries of one type run, 1 = built.  The
- * kernel takes layouts with n_types <= *max_types, result[0] <= *max_pair_entries, result[1] <= *max_run_entries
- * (tgnn_nnconv_stream_limits); otherwise use the column kernel.  n_types_dev (may be NULL): the type count read from the
- * device instead (tgnn_graph_prep queues the whole preparation without a host round trip).
- * Source rows are dense [n_src_rows][32] floats (row stride 128 bytes) within 2 GB. */
-void tgnn_nnconv_stream_limits(int32_t *max_types, int32_t *max_pair_entries, int32_t *max_run_entries);
-int64_t tgnn_nnconv_stream_max_entries(int64_t n_nodes, int64_t n_edges);
-size_t tgnn_nnconv_stream_scan_ws_bytes(int64_t n_nodes);
-int tgnn_nnconv_stream_build(const int32_t *rowptr, const int32_t *col_src, const int32_t *col_type, int64_t n_nodes,
-                             int32_t n_types, const int32_t *n_types_dev, int32_t *tile_ent_ptr, uint32_t *ent, uint32_t *rowlist,
-                             uint32_t *info, float *inv_deg, int32_t *result, void *ws, size_t ws_bytes, tgnn_stream_t stream);
-int tgnn_nnconv_mean_stream_fwd(const float *h, int64_t n_src_rows, const int32_t *tile_ent_ptr, const uint32_t *ent,
-                                const uint32_t *rowlist, const uint32_t *info, const float *inv_deg, const float *wtab,
-                                int32_t n_types, const float *root, const float *bias, int64_t n_nodes, int32_t c, int32_t act,
-                                float *out, void *split_scratch, double *bn_partial, int32_t *n_partials_host,
-                                tgnn_stream_t stream);
-/* split_scratch: tgnn_nnconv_stream_split_bytes(n_src_rows) bytes, 256-byte aligned: the source rows as fp16 pairs
- * (hi + lo, scaled by a power of two chosen from the largest |h|), which is the form the kernel gathers. */
-size_t tgnn_nnconv_stream_split_bytes(int64_t n_src_rows);
+/* NNConv BATCHES of the mid-size persistent layer loop (csrc/forward_mid.hip; layouts of 4 097 .. tgnn_mid_layout_max_nodes()
+ * nodes run TilinGNN.py:59-71 as ONE kernel).  Built from the type-column structure, once per layout:
+ *   tile_nb int32  [ceil(N/16)]                                            batches of every 16-row tile (<= TGNN_MID_TILE_BATCHES)
+ *   ent     uint32 [ceil(N/16)][TGNN_MID_TILE_BATCHES][TGNN_MID_BATCH_WORDS]  per tile its edge types in order; a batch = up to 32
+ *           in-edges of ONE type: words 0-3 = {type | last-batch-of-the-type << 8, mask of the tile's rows that have an edge of
+ *           the type, 0, 0}, word 4 + 4 o + g = slot o (0..7) of gather instruction g (0..3):
+ *           source row | destination row (0..15) << 20 | add << 24 | valid << 31.  Eight whole 128-byte source rows per gather
+ *           instruction, never two edges of one destination row in one instruction: a row's first edge of a type STORES its
+ *           type-sum slot, further ones (add) read-add-write it, in CSR (= original edge) order.
+ * result (device int32 [2], zeroed by the caller): [0] most batches of a tile, [1] 1 = a tile does not fit (more than
+ * TGNN_MID_TILE_BATCHES batches / 128 columns) or no column structure -- the layout then takes the general schedule.
+ * cols_built_dev (may be NULL): device word, 0 = the column structure was not built (tgnn_graph_prep: result + 5). */
+#define TGNN_MID_BATCH_WORDS 36
+#define TGNN_MID_TILE_BATCHES 18
+int64_t tgnn_mid_entries_words(int64_t n_nodes);
+int tgnn_mid_entries_build(const int32_t *tile_col_ptr, const int32_t *col_meta, const int32_t *col_src, int64_t n_nodes,
+                           const int32_t *cols_built_dev, int32_t *tile_nb, uint32_t *ent, int32_t *result, tgnn_stream_t stream);
+/* Layouts above the small-layout limit and up to this many nodes (default and maximum 65 536; 0 = off) run the layer loop as the
+ * persistent mid-size kernel when the graph carries the batches (nn_mid_*), width 32, train-mode BatchNorm, single device. */
+void tgnn_set_mid_layout_limit(int64_t n_nodes);
+int64_t tgnn_get_mid_layout_limit(void);
+int64_t tgnn_mid_layout_max_nodes(void);
 
 /* GINConv + optional LeakyReLU (coll_conv.py:25-27):
  *   z[v]  = (1+eps) * f(a[v]) + sum_{e: dst_e = v} f(a[src_e]),   f = identity or the BatchNorm
@@ -292,13 +280,9 @@ typedef struct tgnn_graph {
      * with the type count); 0 = unknown.  The small-layout kernel (tgnn_set_small_layout_limit) keeps a row's gather list in
      * registers and runs only when 1 <= nn_max_in_degree <= 31; otherwise the general schedule does. */
     int32_t nn_max_in_degree;
-    /* NNConv stream structure (tgnn_nnconv_stream_build; all NULL => the column kernel runs).  Set only when the layout is
-     * inside tgnn_nnconv_stream_limits. */
-    const int32_t *nn_st_tile_ent_ptr;
-    const uint32_t *nn_st_ent_src;
-    const uint32_t *nn_st_rowlist;
-    const uint32_t *nn_st_info;
-    const float *nn_st_inv_deg;
+    /* NNConv batches of the mid-size persistent layer loop (tgnn_mid_entries_build; both NULL => the general schedule). */
+    const int32_t *nn_mid_tile_nb;
+    const uint32_t *nn_mid_ent;
 } tgnn_graph;
 
 size_t tgnn_forward_workspace_bytes(const tgnn_model_dims *dims, int64_t n_nodes, int32_t n_types);
@@ -427,6 +411,18 @@ int tgnn_forward_sharded(const tgnn_model_dims *dims, const void *const *params_
  * on and re-recorded by every launch, whichever stream it is on) -- state beyond the "idempotent set-up" of the conventions
  * above, and the reason these two calls cannot be captured into a HIP graph. */
 void tgnn_set_small_layout_limit(int64_t n_nodes);
+/* No wait of the persistent kernels (small and mid-size layer loops) spins without bound: a block that has waited for the others
+ * longer than the budget (default 250 000 us; 0 restores the default; returns the previous value) ORs a reason into a device
+ * word and runs on without waiting, so that the launch terminates; the results of that forward are invalid.
+ * tgnn_spin_error_poll synchronises `stream`, reads the word of the stream's device into *code_out (0 = every forward since the
+ * last poll was sound; bits: 1 grid barrier, 2 partial rows, 4 edge weights) and clears it; with a non-zero code
+ * tgnn_last_error() carries the explanation.  What gives up is a kernel whose blocks are not all resident -- another process
+ * or tenant holds compute units: switch the persistent schedules off (limits 0) and run the forward again. */
+int tgnn_spin_error_poll(tgnn_stream_t stream, uint32_t *code_out);
+uint64_t tgnn_set_spin_budget_us(uint64_t us);
+/* test hook: the next n_launches persistent kernels run with their last block absent (it returns at once) -- what a block that
+ * never becomes resident looks like to the others; they must give up after the budget and report through the word above. */
+void tgnn_debug_spin_fault(int32_t n_launches);
 int64_t tgnn_get_small_layout_limit(void);
 
 /* Split precision of the general schedule's matrix-core kernels (NNConv, the final MLP's first Linear).  Both hold the fp32
@@ -461,16 +457,16 @@ int tgnn_graph_prep_small(const int64_t *adj_edge_index, int64_t n_adj_edges, co
 /* The same at any size: one call that queues every launch of the preparation itself (no host round trip in the middle:
  * the column structure reads the type count from the device).  result [32] as above; word 6 = 1: the layout has more than
  * 4 096 distinct attribute rows -- more than the one-block numbering of the types takes: edge_type / adj_type / the column
- * structure hold nothing usable, the caller goes through the separate calls (tgnn_edge_type_dedup has no such limit).  The five
- * st_* arrays (all or none; sized as for tgnn_nnconv_stream_build) also receive the NNConv stream structure: result[8..10] =
- * that call's result words.  n_src_nodes >= n_nodes: sources may index rows behind the n_nodes destinations (the halo rows of a
- * shard, as in tgnn_csr_build); n_nodes on a single device. */
+ * structure hold nothing usable, the caller goes through the separate calls (tgnn_edge_type_dedup has no such limit).  With
+ * mid_tile_nb / mid_ent (both or none; sized as for tgnn_mid_entries_build) the batches of the mid-size layer loop are built
+ * too: result[8..9] = that call's result words.  n_src_nodes >= n_nodes: sources may index rows behind the n_nodes destinations
+ * (the halo rows of a shard, as in tgnn_csr_build); n_nodes on a single device. */
 size_t tgnn_graph_prep_workspace_bytes(int64_t n_nodes, int64_t n_adj_edges, int64_t n_col_edges, int32_t fe);
 int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edges, const float *adj_edge_attr, int32_t fe,
                     const int64_t *col_edge_index, int64_t n_col_edges, int64_t n_nodes, int64_t n_src_nodes, int32_t *adj_rowptr,
                     int32_t *adj_src, int32_t *adj_eid, int32_t *adj_type, int32_t *edge_type, int32_t *type_rep_edge, int32_t *col_rowptr,
                     int32_t *col_src, int32_t *col_eid, int32_t *tile_col_ptr, int32_t *col_meta, int32_t *col_slot_src,
-                    int32_t *st_tile_ent_ptr, uint32_t *st_ent_src, uint32_t *st_rowlist, uint32_t *st_info, float *st_inv_deg,
+                    int32_t *mid_tile_nb, uint32_t *mid_ent,
                     void *ws, size_t ws_bytes, int32_t *result, tgnn_stream_t stream);
 /* (tests) tgnn_graph_prep builds both CSRs through buckets of 512 destination rows sorted in LDS; a bucket with more than `cap`
  * edges (default and maximum 15 360) takes a slow in-place path.  Sets the threshold (negative: only queries); returns the

@@ -19,16 +19,19 @@ def golden_dir():
 
 @pytest.fixture
 def general_schedule():
-    """Layouts of up to 4 096 nodes normally run the layer loop as one persistent kernel (csrc/forward_small.hip), which
-    associates the BatchNorm / tile sums differently than the general launch schedule.  Tests that compare the general
-    schedule's variants bit for bit (two streams vs one, sharded vs unsharded) switch it off."""
+    """Layouts of up to 4 096 nodes normally run the whole forward as one persistent kernel (csrc/forward_small.hip), layouts
+    of up to 65 536 nodes their layer loop (csrc/forward_mid.hip); both associate the BatchNorm / tile sums differently than the
+    general launch schedule.  Tests that compare the general schedule's variants bit for bit (two streams vs one, sharded vs
+    unsharded) switch both off."""
     from tilingnn_amd import _lib
-    before = _lib.lib.tgnn_get_small_layout_limit()
+    before = _lib.lib.tgnn_get_small_layout_limit(), _lib.lib.tgnn_get_mid_layout_limit()
     _lib.lib.tgnn_set_small_layout_limit(0)
+    _lib.lib.tgnn_set_mid_layout_limit(0)
     try:
         yield
     finally:
-        _lib.lib.tgnn_set_small_layout_limit(before)
+        _lib.lib.tgnn_set_small_layout_limit(before[0])
+        _lib.lib.tgnn_set_mid_layout_limit(before[1])
 
 
 @pytest.fixture

@@ -38,6 +38,7 @@ def main():
     ref_net = ref_net.to(dev).train()
     from tilingnn_amd import _lib
     _lib.lib.tgnn_set_small_layout_limit(0)      # the sharded step runs the general schedule's kernels: compare with those
+    _lib.lib.tgnn_set_mid_layout_limit(0)
     x, adj, attr, col, _ = sg.to_torch(dev)
     want = ref_net(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)[0]
     lo = runner.shard.lo

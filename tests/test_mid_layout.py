@@ -1,0 +1,249 @@
+"""Mid-size layouts (4 097 .. 65 536 nodes: BASELINE config 2, greedy rounds of large solves, a rank's share of a strong-scaled
+100 000-node layout): the 20 layers of /root/reference/graph_networks/networks/TilinGNN.py:59-71 as ONE persistent kernel
+(csrc/forward_mid.hip) against the fp64 oracle -- absolute, slot by slot -- and against the general launch schedule."""
+import contextlib
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tilingnn_oracle as orc
+from tests.test_hip_parity import make_net
+from tests.test_small_layout import _forward_with_slots, slot_tol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+@contextlib.contextmanager
+def mid_limit(n):
+    from tilingnn_amd import _lib
+    before = _lib.lib.tgnn_get_mid_layout_limit()
+    _lib.lib.tgnn_set_mid_layout_limit(n)
+    try:
+        yield
+    finally:
+        _lib.lib.tgnn_set_mid_layout_limit(before)
+
+
+def _spin_ok(dev):
+    from tilingnn_amd import _lib
+    code = C.c_uint32(0)
+    _lib.check(_lib.lib.tgnn_spin_error_poll(_lib.current_stream(dev), C.byref(code)))
+    return code.value
+
+
+def _layout(n, dev, seed=5, tile_count=2, types=13, ea_per=10, ec_per=12.5):
+    from tilingnn_amd.synth import make_super_graph
+    sg = make_super_graph(n, int(ea_per * n), int(ec_per * n), tile_count=tile_count, n_edge_types=types, seed=seed)
+    inputs = sg.to_torch(dev)[:4]
+    inputs64 = tuple(t.double() if t.is_floating_point() else t for t in sg.to_torch("cpu"))
+    return inputs, inputs64
+
+
+def test_the_graph_carries_the_batches_and_they_cover_every_edge(dev):
+    """tgnn_mid_entries_build against the column structure it is cut from: per tile and type the multiset of (destination row,
+    source) pairs, the order of a row's edges, the store / add flags, no row twice in one gather instruction."""
+    from tilingnn_amd import ops
+    n = 5000
+    (x, adj, attr, col), _ = _layout(n, dev, seed=2)
+    g = ops.prepare_graph(n, adj, attr, col)
+    assert g.mid is not None and g.cols is not None
+    nb = g.mid.tile_nb.cpu().numpy()
+    ent = g.mid.ent.cpu().numpy().view(np.uint32).reshape(-1, 18, 36)
+    ptr_ = g.cols.tile_col_ptr.cpu().numpy()
+    meta = g.cols.col_meta.cpu().numpy()
+    src = g.cols.col_src.cpu().numpy().reshape(-1, 16)
+    assert nb.max() <= 18 and nb.min() >= 1
+    for tile in list(range(0, 40)) + [len(nb) - 1, len(nb) // 2]:
+        want = {}                                              # type -> per row the sources in column (= CSR) order
+        for c in range(ptr_[tile], ptr_[tile + 1] - 1):
+            t = int(meta[c] & 0xff)
+            for r in range(16):
+                if src[c, r] >= 0:
+                    want.setdefault(t, [[] for _ in range(16)])[r].append(int(src[c, r]))
+        got, types_seen, masks = {}, [], {}
+        for b in range(nb[tile]):
+            hdr = ent[tile, b, :4]
+            t = int(hdr[0] & 0xff)
+            rows = got.setdefault(t, [[] for _ in range(16)])
+            for gi in range(4):
+                seen = set()
+                for o in range(8):
+                    w = int(ent[tile, b, 4 + 4 * o + gi])
+                    if not (w >> 31):
+                        continue
+                    r = (w >> 20) & 15
+                    assert r not in seen                       # never two entries of a row in one instruction
+                    seen.add(r)
+                    assert bool((w >> 24) & 1) == (len(rows[r]) > 0)   # a row's first edge of a type stores, further ones add
+                    rows[r].append(w & 0xfffff)
+            if hdr[0] & 0x100:
+                types_seen.append(t)
+                masks[t] = int(hdr[1])
+        assert types_seen == sorted(want)                       # every type once, in order, closed by a `last` batch
+        for t in want:
+            assert got[t] == want[t]
+            assert masks[t] == sum(1 << r for r in range(16) if want[t][r])
+
+
+@pytest.mark.parametrize("n,depth", [(8000, 1), (8000, 4), (20000, 4), (50000, 4), (4097, 2), (65536, 2)])
+def test_mid_kernel_slots_against_the_fp64_oracle_absolute(dev, n, depth):
+    """Every slot of the skip buffer, free running, against the float64 oracle with the per-class tolerances of
+    tests/test_small_layout.py (slot k: 2e-5 * 4^(k-1)); the general schedule is held to the same numbers beside it."""
+    inputs, inputs64 = _layout(n, dev)
+    from tilingnn_amd import ops
+    assert ops.prepare_graph(n, *inputs[1:]).mid is not None
+    for name, limit in (("persistent", 65536), ("general", 0)):
+        net, sd = make_net(dev, depth=depth)
+        with mid_limit(limit):
+            probs, slots = _forward_with_slots(net, inputs, n, dev)
+        assert _spin_ok(dev) == 0
+        cap = {}
+        with torch.no_grad():
+            want = orc.tilingnn_forward(orc.cast_sd(sd, torch.float64), *inputs64, capture=cap)[0]
+        errs = [orc.rel_max_err(slots[0], cap["init"])] + [orc.rel_max_err(slots[k], cap[f"mid.{k}"]) for k in range(1, depth + 1)]
+        pgap = float((probs.double() - want.cpu()).abs().max())
+        print(f"n {n} depth {depth} {name}: slots " + " ".join(f"{e:.1e}" for e in errs) + f"  max |p - p64| {pgap:.1e}")
+        for k, e in enumerate(errs):
+            assert e < slot_tol(k), (name, k, e, slot_tol(k))
+        assert pgap < 1e-4 * 4 ** (depth - 1)
+    assert True
+
+
+@pytest.mark.parametrize("n", [4100, 10000, 30000])
+def test_mid_kernel_against_the_general_schedule_layer_by_layer(dev, n):
+    """Depth 3: same formulas, other association of the BatchNorm and same-type sums -- rounding only; and it IS another path."""
+    inputs, _ = _layout(n, dev, seed=7)
+    net, _ = make_net(dev, depth=3)
+    with mid_limit(0):
+        p_gen, s_gen = _forward_with_slots(net, inputs, n, dev)
+    p_mid, s_mid = _forward_with_slots(net, inputs, n, dev)
+    assert _spin_ok(dev) == 0
+    assert torch.equal(s_mid[0], s_gen[0])                      # the init MLP is the general schedule's
+    for k in range(1, 4):
+        err = orc.rel_max_err(s_mid[k], s_gen[k].double())
+        print(f"n {n} slot {k}: {err:.2e}")
+        assert err < 2e-5 * (4 ** (k - 1)), (k, err)
+    assert not torch.equal(s_gen[1], s_mid[1])
+    assert float((p_mid - p_gen).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("depth,t,tile_count,out_dim,n,ea_per,ec_per", [(1, 13, 2, 1, 6000, 10, 12.5), (2, 16, 2, 1, 9000, 8, 10),
+                                                                       (6, 3, 4, 3, 7000, 8, 10), (20, 13, 2, 1, 10000, 8, 10),
+                                                                       (3, 1, 2, 1, 5000, 6, 4), (3, 13, 1, 1, 12000, 10, 12.5)])
+def test_mid_kernel_other_shapes(dev, depth, t, tile_count, out_dim, n, ea_per, ec_per):
+    """1 .. 16 edge types, depth 1 .. 20 (BASELINE config 2 itself: 10 000 nodes / 80 000 + 100 000 edges), tile_count 1 / 2 / 4,
+    several probability maps: the probabilities of both schedules."""
+    from tilingnn_amd import TilinGNN
+    from tilingnn_amd.synth import make_super_graph
+    from tilingnn_amd.weights import make_state_dict
+    sg = make_super_graph(n, int(ea_per * n), int(ec_per * n), tile_count=tile_count, n_edge_types=t, seed=depth)
+    x, adj, attr, col, _ = sg.to_torch(dev)
+    fe, fx = int(attr.shape[1]), int(x.shape[1])
+    outs = {}
+    for name, limit in (("general", 0), ("mid", 65536)):
+        net = TilinGNN(adj_edge_features_dim=fe, network_depth=depth, network_width=32, output_dim=out_dim, node_features_dim=fx)
+        net.load_state_dict(make_state_dict(fe, depth, 32, out_dim, fx, seed=3), strict=True)
+        net = net.to(dev).train()
+        with mid_limit(limit):
+            outs[name] = net(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)[0].cpu()
+    assert _spin_ok(dev) == 0
+    assert outs["mid"].shape == (n, out_dim) and bool(torch.isfinite(outs["mid"]).all())
+    err = float((outs["mid"] - outs["general"]).abs().max())
+    print(f"depth {depth} types {t} maps {out_dim}: max |p_mid - p_general| = {err:.2e}")
+    assert err < (2e-5 if depth <= 2 else 2e-3 if depth <= 6 else 1e-1)
+    assert not torch.equal(outs["mid"], outs["general"])
+
+
+def test_layouts_above_the_mid_limit_take_the_general_schedule(dev):
+    inputs, _ = _layout(6000, dev)
+    net, _ = make_net(dev, depth=3)
+    with mid_limit(0):
+        p_gen, s_gen = _forward_with_slots(net, inputs, 6000, dev)
+    with mid_limit(5999):
+        p, s = _forward_with_slots(net, inputs, 6000, dev)
+    assert torch.equal(p, p_gen) and torch.equal(s, s_gen)
+
+
+@pytest.mark.parametrize("n", [8000, 20000, 50000])
+def test_mid_kernel_is_bit_reproducible(dev, n):
+    """Cross-block data moves through sc1 loads / stores, tagged partial rows and a counter barrier without cache maintenance: a
+    stale read would show up as run-to-run differences.  Twelve runs, depth 20."""
+    inputs, _ = _layout(n, dev, seed=11)
+    net, _ = make_net(dev)
+    first = None
+    for _ in range(12):
+        probs, slots = _forward_with_slots(net, inputs, n, dev)
+        if first is None:
+            first = (probs, slots)
+        else:
+            assert torch.equal(first[0], probs) and torch.equal(first[1], slots)
+    assert _spin_ok(dev) == 0
+
+
+def test_mid_kernel_running_statistics_match_the_general_schedule(dev):
+    inputs, _ = _layout(9000, dev, seed=3)
+    sds = []
+    for limit in (0, 65536):
+        net, _ = make_net(dev, depth=4)
+        with mid_limit(limit):
+            _forward_with_slots(net, inputs, 9000, dev, update_running=1)
+        sds.append({k: v.detach().cpu().double() for k, v in net.state_dict().items()})
+    for k in sds[0]:
+        if "running" in k:
+            assert orc.rel_max_err(sds[1][k], sds[0][k]) < 1e-4, k
+        elif k.endswith("num_batches_tracked"):
+            assert int(sds[0][k]) == int(sds[1][k]) == 1, k
+
+
+@pytest.mark.parametrize("n", [2000, 8000])
+def test_a_starved_persistent_kernel_gives_up_and_the_module_falls_back(dev, n):
+    """Bounded spins (csrc/forward_persist.h).  A persistent kernel one of whose blocks never shows up -- what a kernel looks like
+    to its other blocks when another process holds compute units; simulated by the library's test hook -- must TERMINATE after
+    the spin budget, the device's error word must say why, and TilinGNN.forward_checked (the call ML_Solver.predict makes) must
+    come back with the general schedule's result.  Both persistent kernels: 2 000 nodes (forward_small.hip), 8 000 (forward_mid.hip)."""
+    import time
+    import warnings
+    from tilingnn_amd import _lib
+    inputs, _ = _layout(n, dev, seed=9)
+    net, _ = make_net(dev, depth=6)
+    limits = _lib.lib.tgnn_get_small_layout_limit(), _lib.lib.tgnn_get_mid_layout_limit()
+    _lib.lib.tgnn_set_small_layout_limit(0)
+    _lib.lib.tgnn_set_mid_layout_limit(0)
+    want = net(*inputs)[0].clone()
+    _lib.lib.tgnn_set_small_layout_limit(limits[0])
+    _lib.lib.tgnn_set_mid_layout_limit(limits[1])
+    torch.cuda.synchronize()
+    before = _lib.lib.tgnn_set_spin_budget_us(20000)
+    try:
+        _lib.lib.tgnn_debug_spin_fault(1)
+        t0 = time.perf_counter()
+        net(*inputs)
+        torch.cuda.synchronize()                                # (terminates: every wait is bounded)
+        took = time.perf_counter() - t0
+        assert took < 5.0, took
+        code = _spin_ok(dev)
+        assert code != 0
+        assert b"gave up" in _lib.lib.tgnn_last_error()
+        assert _spin_ok(dev) == 0                               # (the poll cleared the word)
+        _lib.lib.tgnn_debug_spin_fault(1)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            got = net.forward_checked(*inputs)[0]
+        assert any("gave up" in str(w.message) for w in caught)
+        assert _lib.lib.tgnn_get_small_layout_limit() == 0 and _lib.lib.tgnn_get_mid_layout_limit() == 0
+    finally:
+        _lib.lib.tgnn_debug_spin_fault(0)
+        _lib.lib.tgnn_set_spin_budget_us(before)
+        _lib.lib.tgnn_set_small_layout_limit(limits[0])
+        _lib.lib.tgnn_set_mid_layout_limit(limits[1])
+    assert torch.equal(got, want)
+    assert _spin_ok(dev) == 0
+    assert torch.equal(net.forward_checked(*inputs)[0].cpu(), net(*inputs)[0].cpu())   # healthy: the persistent schedule's own result

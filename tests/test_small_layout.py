@@ -112,11 +112,14 @@ def test_small_kernel_other_shapes(dev, depth, t, tile_count, out_dim, n):
     assert not torch.equal(outs["small"], outs["general"])
 
 
-def test_layouts_above_the_limit_take_the_general_schedule(dev):
+def test_layouts_above_the_limit_take_the_general_schedule(dev, general_schedule):
+    """4 097 nodes are not the small-layout kernel's (they are the mid-size kernel's, tests/test_mid_layout.py): with that one
+    switched off too (the fixture) the result is the general schedule's whatever the small-layout limit says."""
+    from tilingnn_amd import _lib
     inputs = _synthetic(4097, dev)
     net, _ = make_net(dev, depth=3)
-    with small_limit(0):
-        p_gen, s_gen = _forward_with_slots(net, inputs, 4097, dev)
+    p_gen, s_gen = _forward_with_slots(net, inputs, 4097, dev)
+    _lib.lib.tgnn_set_small_layout_limit(4096)
     p, s = _forward_with_slots(net, inputs, 4097, dev)
     assert torch.equal(p, p_gen) and torch.equal(s, s_gen)
 

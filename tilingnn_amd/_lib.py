@@ -34,8 +34,7 @@ class Graph(C.Structure):
                 ("type_rep_edge", C.c_void_p), ("col_rowptr", C.c_void_p), ("col_src", C.c_void_p),
                 ("nn_tile_col_ptr", C.c_void_p), ("nn_col_meta", C.c_void_p), ("nn_col_src", C.c_void_p),
                 ("nn_max_in_degree", C.c_int32),
-                ("nn_st_tile_ent_ptr", C.c_void_p), ("nn_st_ent_src", C.c_void_p), ("nn_st_rowlist", C.c_void_p), ("nn_st_info", C.c_void_p),
-                ("nn_st_inv_deg", C.c_void_p)]
+                ("nn_mid_tile_nb", C.c_void_p), ("nn_mid_ent", C.c_void_p)]
 
 
 class TrainSave(C.Structure):
@@ -96,12 +95,14 @@ def _load() -> C.CDLL:
         "tgnn_nnconv_weight_image_floats": (sz, [i32]),
         "tgnn_nnconv_mean_cols_fwd": (C.c_int, [p, i64, p, p, p, p, i32, p, p, i64, i32, i32, p, p, p, pi32, p]),
         "tgnn_nnconv_mean_cols_f16_fwd": (C.c_int, [p, i64, i64, p, p, p, p, i32, p, p, i64, i32, i32, p, p, p, p, pi32, p]),
-        "tgnn_nnconv_stream_limits": (None, [pi32, pi32, pi32]),
-        "tgnn_nnconv_stream_max_entries": (i64, [i64, i64]),
-        "tgnn_nnconv_stream_scan_ws_bytes": (sz, [i64]),
-        "tgnn_nnconv_stream_build": (C.c_int, [p, p, p, i64, i32, p, p, p, p, p, p, p, p, sz, p]),
-        "tgnn_nnconv_stream_split_bytes": (sz, [i64]),
-        "tgnn_nnconv_mean_stream_fwd": (C.c_int, [p, i64, p, p, p, p, p, p, i32, p, p, i64, i32, i32, p, p, p, pi32, p]),
+        "tgnn_mid_entries_words": (i64, [i64]),
+        "tgnn_mid_entries_build": (C.c_int, [p, p, p, i64, p, p, p, p, p]),
+        "tgnn_set_mid_layout_limit": (None, [i64]),
+        "tgnn_get_mid_layout_limit": (i64, []),
+        "tgnn_mid_layout_max_nodes": (i64, []),
+        "tgnn_spin_error_poll": (C.c_int, [p, C.POINTER(C.c_uint32)]),
+        "tgnn_set_spin_budget_us": (C.c_uint64, [C.c_uint64]),
+        "tgnn_debug_spin_fault": (None, [i32]),
         "tgnn_gin_fwd": (C.c_int, [p, i64, p, p, p, p, p, p, p, p, p, p, i64, i32, i32, p, p, p, pi32, p]),
         "tgnn_dense_act_fwd": (C.c_int, [p, i64, i64, p, p, p, i64, i32, i32, i32, p, i64, p, pi32, p]),
         "tgnn_dense_act_slots_fwd": (C.c_int, [p, i32, i64, p, p, p, i64, i32, i32, i32, p, i64, p, pi32, p]),
@@ -127,7 +128,7 @@ def _load() -> C.CDLL:
         "tgnn_graph_prep_small_tmp_ints": (sz, [i64, i64, i64]),
         "tgnn_graph_prep_small": (C.c_int, [p, i64, p, i32, p, i64, i64] + [p] * 15 + [p]),
         "tgnn_graph_prep_workspace_bytes": (sz, [i64, i64, i64, i32]),
-        "tgnn_graph_prep": (C.c_int, [p, i64, p, i32, p, i64, i64, i64] + [p] * 18 + [sz, p, p]),
+        "tgnn_graph_prep": (C.c_int, [p, i64, p, i32, p, i64, i64, i64] + [p] * 15 + [sz, p, p]),
         "tgnn_set_small_layout_limit": (None, [i64]),
         "tgnn_get_small_layout_limit": (i64, []),
         "tgnn_set_split_precision": (i32, [i32]),
@@ -195,8 +196,8 @@ EXPORTED_SYMBOLS = (
     "tgnn_edge_dedup_workspace_bytes", "tgnn_edge_type_dedup", "tgnn_gather_i32", "tgnn_edge_weight_table",
     "tgnn_nnconv_mean_fwd", "tgnn_nnconv_cols_max_columns", "tgnn_nnconv_cols_workspace_bytes",
     "tgnn_nnconv_cols_build", "tgnn_nnconv_cols_max_types", "tgnn_nnconv_weight_image_floats", "tgnn_nnconv_mean_cols_fwd", "tgnn_nnconv_mean_cols_f16_fwd",
-    "tgnn_nnconv_stream_limits", "tgnn_nnconv_stream_max_entries", "tgnn_nnconv_stream_scan_ws_bytes", "tgnn_nnconv_stream_build",
-    "tgnn_nnconv_mean_stream_fwd", "tgnn_nnconv_stream_split_bytes", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_dense_act_slots_fwd", "tgnn_dense_act_slots_f16_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
+    "tgnn_mid_entries_words", "tgnn_mid_entries_build", "tgnn_set_mid_layout_limit", "tgnn_get_mid_layout_limit", "tgnn_mid_layout_max_nodes",
+    "tgnn_spin_error_poll", "tgnn_set_spin_budget_us", "tgnn_debug_spin_fault", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_dense_act_slots_fwd", "tgnn_dense_act_slots_f16_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
     "tgnn_merge_fwd", "tgnn_param_count", "tgnn_param_name", "tgnn_forward_workspace_bytes", "tgnn_forward",
     "tgnn_forward_profiled", "tgnn_forward_profiled_two_stream", "tgnn_forward_stamped", "tgnn_forward_many", "tgnn_graph_prep_small_max_nodes", "tgnn_graph_prep_small_max_edges", "tgnn_graph_prep_small_tmp_ints",
     "tgnn_graph_prep_small", "tgnn_graph_prep_workspace_bytes", "tgnn_graph_prep", "tgnn_set_small_layout_limit", "tgnn_get_small_layout_limit", "tgnn_set_split_precision", "tgnn_rccl_available", "tgnn_rccl_unique_id_bytes", "tgnn_rccl_unique_id", "tgnn_rccl_comm_create", "tgnn_rccl_comm_destroy", "tgnn_rccl_counters", "tgnn_debug_set_csr_bucket_cap", "tgnn_debug_set_block_caps", "tgnn_forward_train", "tgnn_backward_workspace_bytes", "tgnn_backward", "tgnn_forward_sharded_workspace_bytes", "tgnn_forward_sharded",

@@ -668,6 +668,23 @@ void launch_merge_bn1(const float *a1, const BnJob &j1, int64_t n_total, float e
     merge_bn1_kernel<<<(unsigned)blocks, 256, 0, s>>>(a1, j1, n_total, eps, momentum, a2, stat2, resid, n4, out, absmax_out);
 }
 
+// largest |h[0 .. n_floats)| (n_floats % 4 == 0) as float bits, atomicMax into *max_bits (a zeroed word or a running bound)
+__global__ void absmax_kernel(const float *__restrict__ h, int64_t n4, unsigned *__restrict__ out_bits) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4 *>(h)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    absmax_flush(m, out_bits);
+}
+void launch_absmax(const float *h, int64_t n_floats, unsigned *max_bits, hipStream_t s) {
+    const int64_t n4 = n_floats / 4;
+    if (n4 <= 0) return;
+    int64_t g = (n4 + 255) / 256;
+    if (g > 512) g = 512;
+    absmax_kernel<<<(unsigned)g, 256, 0, s>>>(h, n4, max_bits);
+}
+
 void launch_merge(const float *a1, const float *stat1, const float *a2, const float *stat2, const float *resid, int64_t n_nodes,
                   int c, float *out, float *h2_out, unsigned *absmax_out, hipStream_t s) {
     const int64_t n4 = n_nodes * c / 4;

@@ -79,6 +79,7 @@ struct Workspace {
     double *part1, *part2, *partf;
     float *small_pack;            // small-layout kernel: per-layer parameter packs, its partial rows, its barrier counter
     double *small_part, *small_part_wide, *small_runstat;
+    double *mid_part;             // mid-size persistent layer loop: tagged partial rows + group sums (forward_mid.hip)
     unsigned *small_ctr;
     unsigned *bounds;            // [0, D]: max |middle[k]| as float bits; [D + 1, 2 D]: max |root_i|; [2 D + 1]: max |final W_0|
     float *stat1, *stat2[2], *stat_i[2], *stat_f[4];
@@ -151,6 +152,7 @@ static Workspace carve(const tgnn_model_dims &d, int64_t n, int64_t nr, int32_t 
     w.small_part = cv.take<double>((size_t)256 * 128);
     w.small_part_wide = cv.take<double>((size_t)2 * 256 * 512);
     w.small_runstat = cv.take<double>((size_t)D * 128);
+    w.mid_part = cv.take<double>(mid_part_doubles());
     w.small_ctr = cv.take<unsigned>(64);
     w.bounds = cv.take<unsigned>(2 * kMaxDepth + 8);
     w.stat1 = cv.take<float>(4 * c);
@@ -418,6 +420,11 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         prof.end();
     }
     if (small_teams) launch_small_pack(P, D, w.small_pack, w.small_ctr, s);   // on the main stream: it has nothing else to do yet
+    // Mid-size layouts (above the small-layout limit, up to 65 536 nodes): the D layers between the init and the final MLP are
+    // ONE persistent kernel carrying both chains (forward_mid.hip) instead of ~5 dependent launches per layer on two streams
+    int mid_blocks = 0;
+    const int mid_k = (f16 && !sh && !keep && !prof.on && nr == n) ? mid_layout_tiles_per_block(dims, graph, n, &mid_blocks) : 0;
+    if (mid_k) launch_small_pack(P, D, w.small_pack, w.small_ctr, s, false);   // parameter vectors + GIN images of the layers
     if (sw != s) TGNN_CHECK_HIP(hipEventRecord(ev[kEvWeights], s2));
     if (small_teams) {
         // init MLP, the layers and the final MLP: one persistent kernel behind the pre-pass
@@ -491,12 +498,16 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         prof.end();
         return TGNN_OK;
     };
-    if (s2) {
+    if (mid_k) {
+        if (sw != s) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[kEvWeights], 0));   // (the images and the bounds of the side stream)
+        TGNN_TRY(launch_forward_mid(dims, P, w.mid, w.a1, w.a2[0], w.a2[1], w.wimg, w.small_pack, graph, w.mid_part, w.small_runstat,
+                                    w.small_ctr, w.bounds, n, mid_k, mid_blocks, update_running, eps, momentum, s));
+    } else if (s2) {
         TGNN_CHECK_HIP(hipEventRecord(ev[0], s));            // middle[0] is complete
         TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[0], 0));
         if (sw != s) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[kEvWeights], 0));
     }
-    for (int i = 0; i < D; ++i) {
+    for (int i = 0; i < (mid_k ? 0 : D); ++i) {
         const int b = P.layer(i);
         if (keep) {                                          // this layer's own buffers (kernels already queued keep theirs)
             w.a1 = keep->a1 + (size_t)i * n * c;

@@ -31,19 +31,9 @@
 
 #include <vector>
 
-#include "tgnn_common.h"
+#include "forward_persist.h"
 
 namespace tgnn {
-
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
-using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
-
-// ---- per-layer parameter pack (floats): small vectors, then the GIN MLP's MFMA weight image -----------------------------
-constexpr int kSpBias = 0, kSpG1 = 32, kSpB1 = 64, kSpG2 = 96, kSpB2 = 128, kSpEps = 160, kSpGinB = 192, kSpGinW = 320;
-constexpr int kSpGinFrags = 3 * 2 * 64 + 3 * 4 * 64 + 3 * 2 * 2 * 64;      // 1920 fragments of 16 bytes
-constexpr int kSpStride = kSpGinW + kSpGinFrags * 4;                       // 8000 floats per layer
 
 struct SmallPackLayer {
     const float *nn_bias, *g1, *b1, *g2, *b2, *eps, *w1, *gb1, *w2, *gb2, *w3, *gb3;
@@ -124,15 +114,6 @@ __global__ __launch_bounds__(256) void small_pack_kernel(SmallPackLayers layers,
 }
 
 // ---- the persistent kernel ------------------------------------------------------------------------------------------------
-struct SmallRun {
-    float *rm1, *rv1;
-    int64_t *nbt1;
-    float *rm2, *rv2;
-    int64_t *nbt2;
-};
-struct SmallRunTab {
-    SmallRun l[kMaxDepth];
-};
 struct SmallArgs {
     float *mid;                  // skip buffer [depth + 1][n][32]; slot 0 filled by the init MLP
     float *a2[2];                // collision branch, pre-BatchNorm rows, two-deep
@@ -145,8 +126,10 @@ struct SmallArgs {
     unsigned *ctr;               // barrier counter (zeroed by small_pack_kernel)
     const unsigned *weights_done;   // NULL, or: blocks of the edge-weight kernel that have finished (the kernel may start before them)
     unsigned weights_target;
+    unsigned *err;               // the device's spin-error word (forward_persist.h: no wait of this kernel spins without bound)
+    unsigned long long spin_budget;
     int64_t n;
-    int n_types, depth, update_running;
+    int n_types, depth, update_running, fault;
     float eps, momentum;
 };
 
@@ -184,9 +167,6 @@ __device__ unsigned long long g_small_timing[32 * 260];
 #define TGNN_ST3_RESET
 #endif
 
-constexpr int kCpSc1 = 16;       // cache-policy bit of the raw buffer builtins: sc1 = agent scope (coherent across the XCDs' L2s)
-constexpr uint32_t kOob = 0x80000000u;   // offset outside the 2 GB window of every descriptor here: the load returns 0
-
 // gathers of rows other blocks wrote in the previous phase
 #ifdef TGNN_SMALL_CACHED
 constexpr int kCpGather = 0;     // through L2: needs the invalidate after barrier 2
@@ -196,25 +176,15 @@ constexpr int kCpGather = kCpSc1;
 __device__ __forceinline__ float4 ld_gather_f4(__amdgpu_buffer_rsrc_t r, uint32_t off) {
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, kCpGather));
 }
-__device__ __forceinline__ float4 ld_sc1_f4(__amdgpu_buffer_rsrc_t r, uint32_t off) {
-    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, kCpSc1));
-}
-__device__ __forceinline__ void st_sc1_f4(__amdgpu_buffer_rsrc_t r, uint32_t off, float4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, kCpSc1);
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void *p) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)0x80000000u, 0x00020000);
-}
-
 // All blocks are resident (small_layout_teams checks the device's capacity).  Stores of this block are acknowledged (vmcnt(0)) before its arrival
 // is published; the data itself is sc1, so no cache maintenance is needed on either side.
-__device__ __forceinline__ void small_grid_barrier(unsigned *ctr, unsigned &target, unsigned nblk) {
+__device__ __forceinline__ void small_grid_barrier(unsigned *ctr, unsigned &target, unsigned nblk, SpinCtx &sp) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     target += nblk;
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        spin_until_ge(ctr, target, sp, kSpinErrBarrier);       // bounded: forward_persist.h
     }
     __syncthreads();
 }
@@ -238,17 +208,6 @@ constexpr int kLdsSpv = 2 * kSpGinW, kLdsNnRed = kNnWaves * 64 * 8, kLdsGinRed =
 constexpr int kGinCached = 16;        // collision neighbours per row whose gather offsets stay in registers
 constexpr int kPfG = 4;               // float4 per thread of the next layer's GIN weight image held across barrier 1
 constexpr int kNnEntries = 32;        // gather entries per row (adjacency in-edges + the root row): in-degree <= 31
-
-__device__ __forceinline__ f32x4 small_mma6(const bf16x8 *wpl, int plane_stride, const bf16x8 (&x)[3], f32x4 acc) {
-    const bf16x8 w0 = wpl[0], w1 = wpl[plane_stride], w2 = wpl[2 * plane_stride];
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, x[0], acc, 0, 0, 0);   // lo . hi
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x[2], acc, 0, 0, 0);   // hi . lo
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x[1], acc, 0, 0, 0);   // mid . mid
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x[0], acc, 0, 0, 0);   // mid . hi
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x[1], acc, 0, 0, 0);   // hi . mid
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x[0], acc, 0, 0, 0);   // hi . hi
-    return acc;
-}
 
 // acc (D^T tile pair) += W_t^T . (a * scale)^T for one run of same-type columns: bf16 x 3 split, six cross terms per M block
 __device__ __forceinline__ void small_run_mma(const float *wl, int t, int lane, const float (&af)[8], float scale, f32x4 &d0,
@@ -369,7 +328,7 @@ __device__ __forceinline__ void small_tile_planes_from_act(const float *act, con
 template <int M>
 __device__ __forceinline__ void small_tile_bn(const float *act, int valid_rows, const SmallDense &L, double *part_wide, double *red,
                                               float *rec, int64_t n_total, float eps, float momentum, int update_running,
-                                              unsigned *ctr, unsigned &target, unsigned nblk, int tid) {
+                                              unsigned *ctr, unsigned &target, unsigned nblk, SpinCtx &sp, int tid) {
     static_assert(M == 32 || M == 64 || M == 128 || M == 256, "width");
     const __amdgpu_buffer_rsrc_t rs = rsrc_of(part_wide);
     if (tid < 2 * M) {
@@ -382,7 +341,7 @@ __device__ __forceinline__ void small_tile_bn(const float *act, int valid_rows, 
         }
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, acc), rs, ((uint32_t)blockIdx.x * 512u + (uint32_t)tid) * 8u, 0, kCpSc1);
     }
-    small_grid_barrier(ctr, target, nblk);
+    small_grid_barrier(ctr, target, nblk, sp);
     {
         constexpr int groups = kSmallThreads / M;              // thread = (column pair, row group): 2 M doubles per row = M pairs
         const int jp = tid % M, g = tid / M;
@@ -433,6 +392,7 @@ __device__ __forceinline__ void small_tile_bn(const float *act, int valid_rows, 
 __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(SmallArgs A, SmallRunTab R, SmallEnds E) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NT = kSmallThreads;
+    if (A.fault && blockIdx.x == gridDim.x - 1) return;         // (test hook: a block that never shows up)
     const int T = A.n_types, D = A.depth;
     const int64_t n = A.n;
     // LDS of the layer loop: GIN weight image | parameter vectors of two layers | NNConv partial products [6][64][8] (phase B:
@@ -457,6 +417,7 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
     const bool row_ok = my_row < n;
     const unsigned nblk = gridDim.x;
     unsigned target = 0;
+    SpinCtx spin{A.err, A.spin_budget, false};
     const size_t slot = (size_t)n * 32;
     const __amdgpu_buffer_rsrc_t part_rs = rsrc_of(A.part);
 #ifdef TGNN_SMALL_TIMING
@@ -499,12 +460,12 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
             dact[r * kDActLd + ch] = leakyf_(acc);
         }
         __syncthreads();
-        small_tile_bn<32>(dact, valid_rows, E.i0, E.part_wide, dred, drec, n, A.eps, A.momentum, A.update_running, A.ctr, target, nblk, tid);
+        small_tile_bn<32>(dact, valid_rows, E.i0, E.part_wide, dred, drec, n, A.eps, A.momentum, A.update_running, A.ctr, target, nblk, spin, tid);
         small_tile_planes_from_act(dact, drec, 32, valid_rows, dx, tid);
         __syncthreads();
         small_tile_dense<1>(E.i1.img, 1, 2, E.i1.bias, dx, dact, tw, lane);
         __syncthreads();
-        small_tile_bn<32>(dact, valid_rows, E.i1, E.part_wide + kPartWideSet, dred, drec, n, A.eps, A.momentum, A.update_running, A.ctr, target, nblk, tid);
+        small_tile_bn<32>(dact, valid_rows, E.i1, E.part_wide + kPartWideSet, dred, drec, n, A.eps, A.momentum, A.update_running, A.ctr, target, nblk, spin, tid);
         if (tid < 128) {
             const int row = tid >> 3, c4 = (tid & 7) * 4;
             if (row < valid_rows) {
@@ -516,7 +477,7 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
                 st_sc1_f4(rsrc_of(A.mid), (uint32_t)(tile * 16 + row) * 128u + (uint32_t)c4 * 4u, o);
             }
         }
-        small_grid_barrier(A.ctr, target, nblk);                 // (also: everybody is done with the LDS of this phase)
+        small_grid_barrier(A.ctr, target, nblk, spin);                 // (also: everybody is done with the LDS of this phase)
     }
     TGNN_SMALL_PREFETCH(0)
 
@@ -607,8 +568,7 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
     if (A.weights_done) {
         // the NNConv operand images come from a kernel on another stream that may still be running (the init MLP above did not
         // need them): wait for its last block, then drop what this CU / XCD caches of other XCDs' lines
-        if (tid == 0)
-            while (__hip_atomic_load(A.weights_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < A.weights_target) __builtin_amdgcn_s_sleep(8);
+        if (tid == 0) spin_until_ge(A.weights_done, A.weights_target, spin, kSpinErrWeights);
         __syncthreads();
         if (tw == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
@@ -861,7 +821,7 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
                                                   kCpSc1);
         }
         TGNN_ST(3)
-        small_grid_barrier(A.ctr, target, nblk);
+        small_grid_barrier(A.ctr, target, nblk, spin);
         TGNN_ST(4)
         // =========================================== phase B ===========================================
         {
@@ -955,7 +915,7 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
         }
         TGNN_ST(6)
         if (layer + 1 < D) {
-            small_grid_barrier(A.ctr, target, nblk);
+            small_grid_barrier(A.ctr, target, nblk, spin);
 #ifdef TGNN_SMALL_CACHED
             if (tw == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop what this CU's L1 / this XCD's L2 hold of other XCDs' rows
             __syncthreads();
@@ -964,8 +924,9 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
         TGNN_ST(7)
     }
 
-    if (blockIdx.x == 0 && A.update_running) {
-        // running statistics of the 2 x depth BatchNorms of the layers (momentum update, num_batches_tracked)
+    if (blockIdx.x == 0 && A.update_running && __hip_atomic_load(A.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        // running statistics of the 2 x depth BatchNorms of the layers (momentum update, num_batches_tracked); not after a
+        // wait that gave up: the parked statistics are garbage then, and the host repeats the forward
         __syncthreads();
         for (int idx = tid; idx < D * 64; idx += NT) {
             const int l = idx >> 6, job = (idx >> 5) & 1, ch = idx & 31;
@@ -1000,22 +961,22 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
         __syncthreads();
         small_tile_dense<2>(E.f[0].img, D + 1, 16, E.f[0].bias, dx, dact, tw, lane);
         __syncthreads();
-        small_tile_bn<256>(dact, valid_rows, E.f[0], E.part_wide, dred, drec, n, A.eps, A.momentum, A.update_running, A.ctr, target, nblk, tid);
+        small_tile_bn<256>(dact, valid_rows, E.f[0], E.part_wide, dred, drec, n, A.eps, A.momentum, A.update_running, A.ctr, target, nblk, spin, tid);
         small_tile_planes_from_act(dact, drec, 256, valid_rows, dx, tid);
         __syncthreads();
         small_tile_dense<1>(E.f[1].img, 8, 8, E.f[1].bias, dx, dact, tw, lane);
         __syncthreads();
-        small_tile_bn<128>(dact, valid_rows, E.f[1], E.part_wide + kPartWideSet, dred, drec, n, A.eps, A.momentum, A.update_running, A.ctr, target, nblk, tid);
+        small_tile_bn<128>(dact, valid_rows, E.f[1], E.part_wide + kPartWideSet, dred, drec, n, A.eps, A.momentum, A.update_running, A.ctr, target, nblk, spin, tid);
         small_tile_planes_from_act(dact, drec, 128, valid_rows, dx, tid);
         __syncthreads();
         small_tile_dense<1>(E.f[2].img, 4, 4, E.f[2].bias, dx, dact, tw, lane);
         __syncthreads();
-        small_tile_bn<64>(dact, valid_rows, E.f[2], E.part_wide, dred, drec, n, A.eps, A.momentum, A.update_running, A.ctr, target, nblk, tid);
+        small_tile_bn<64>(dact, valid_rows, E.f[2], E.part_wide, dred, drec, n, A.eps, A.momentum, A.update_running, A.ctr, target, nblk, spin, tid);
         small_tile_planes_from_act(dact, drec, 64, valid_rows, dx, tid);
         __syncthreads();
         small_tile_dense<1>(E.f[3].img, 2, 2, E.f[3].bias, dx, dact, tw, lane);
         __syncthreads();
-        small_tile_bn<32>(dact, valid_rows, E.f[3], E.part_wide + kPartWideSet, dred, drec, n, A.eps, A.momentum, A.update_running, A.ctr, target, nblk, tid);
+        small_tile_bn<32>(dact, valid_rows, E.f[3], E.part_wide + kPartWideSet, dred, drec, n, A.eps, A.momentum, A.update_running, A.ctr, target, nblk, spin, tid);
         for (int it = tid; it < 16 * E.out_dim; it += NT) {      // final_mlp.1
             const int r = it / E.out_dim, o = it - r * E.out_dim;
             if (r < valid_rows) {
@@ -1034,6 +995,35 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
     if (tid == 0 && blockIdx.x < 260)
         for (int k = 0; k < 8; ++k) g_small_timing[blockIdx.x * 32 + 16 + k] = tacc3[k];
 #endif
+}
+
+// ---- the device's spin-error word (forward_persist.h) ------------------------------------------------------------------
+// 4 bytes of device memory per device, allocated on first use, zero; the spin kernels OR a reason into it when a wait runs out
+// of its budget, tgnn_spin_error_poll reads and clears it.
+static std::atomic<unsigned long long> g_spin_budget{kSpinBudgetTicksDefault};
+unsigned long long spin_budget_ticks() { return g_spin_budget.load(std::memory_order_relaxed); }
+static std::atomic<int> g_spin_fault{0};
+int spin_take_fault() {
+    int v = g_spin_fault.load(std::memory_order_relaxed);
+    while (v > 0 && !g_spin_fault.compare_exchange_weak(v, v - 1)) {}
+    return v > 0 ? 1 : 0;
+}
+unsigned *spin_error_word() {
+    static std::mutex mu;
+    static unsigned *word[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!word[dev]) {
+        unsigned *p = nullptr;
+        if (hipMalloc(&p, 256) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, 256) != hipSuccess) {
+            (void)hipFree(p);
+            return nullptr;
+        }
+        word[dev] = p;
+    }
+    return word[dev];
 }
 
 static size_t small_lds_bytes(int n_types, int depth) {
@@ -1093,7 +1083,7 @@ size_t small_pack_floats(int depth) {
 
 // Per-forward pre-pass (side stream): parameter packs + GIN images of the layers, MFMA images of the dense layers; re-arms
 // the barrier counter
-void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrier_ctr, hipStream_t s) {
+void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrier_ctr, hipStream_t s, bool dense_images) {
     size_t off[5];
     small_image_floats(depth, off);
     float *img = pack + (size_t)depth * kSpStride;
@@ -1111,9 +1101,9 @@ void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrie
             L.l[k] = SmallPackLayer{P.f(b + 7), P.f(b + 8), P.f(b + 9), P.f(b + 20), P.f(b + 21), P.f(b + 13),
                                     P.f(b + 14), P.f(b + 15), P.f(b + 16), P.f(b + 17), P.f(b + 18), P.f(b + 19)};
         }
-        const bool first = lo == 0;                             // the dense images ride along with the first chunk
+        const bool first = lo == 0 && dense_images;             // the dense images ride along with the first chunk
         small_pack_kernel<<<dim3(first ? 64 : 1, nl + (first ? 5 : 0)), 256, 0, s>>>(L, nl, pack + (size_t)lo * kSpStride,
-                                                                                     first ? barrier_ctr : nullptr, J);
+                                                                                     lo == 0 ? barrier_ctr : nullptr, J);
     }
 }
 
@@ -1191,6 +1181,13 @@ int launch_forward_small(const tgnn_model_dims *d, const Params &P, const float 
     A.update_running = update_running;
     A.eps = eps;
     A.momentum = momentum;
+    A.err = spin_error_word();
+    A.spin_budget = spin_budget_ticks();
+    A.fault = spin_take_fault();
+    if (!A.err) {
+        set_error("tgnn_forward: the spin-error word of the device could not be allocated");
+        return TGNN_ERR_LAUNCH;
+    }
     SmallRunTab R{};
     for (int i = 0; i < depth; ++i) {
         const BnPtrs b1 = P.bn(P.layer(i) + 8), b2 = P.bn(P.layer(i) + 20);
@@ -1235,5 +1232,30 @@ extern "C" int tgnn_debug_small_timing(unsigned long long *out, int n_blocks) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tgnn::g_small_timing), (size_t)n_blocks * 32 * sizeof(unsigned long long));
 }
 #endif
+extern "C" int tgnn_spin_error_poll(tgnn_stream_t stream, uint32_t *code_out) {
+    tgnn::DeviceGuard guard__(stream);
+    TGNN_CHECK_ARG(code_out, "null pointer");
+    unsigned *w = tgnn::spin_error_word();
+    if (!w) {
+        tgnn::set_error("tgnn_spin_error_poll: no error word on this device");
+        return TGNN_ERR_LAUNCH;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned host = 0;
+    TGNN_CHECK_HIP(hipMemcpyAsync(&host, w, 4, hipMemcpyDeviceToHost, s));
+    TGNN_CHECK_HIP(hipStreamSynchronize(s));
+    if (host) TGNN_CHECK_HIP(hipMemsetAsync(w, 0, 4, s));
+    *code_out = host;
+    if (host)
+        tgnn::set_error("a persistent forward kernel gave up waiting for its other blocks (reason bits %u: 1 grid barrier, 2 partial "
+                        "rows, 4 edge weights): another process or tenant holds compute units; the results of that forward are "
+                        "invalid -- run the general schedule (tgnn_set_small_layout_limit(0), tgnn_set_mid_layout_limit(0))", host);
+    return TGNN_OK;
+}
+extern "C" void tgnn_debug_spin_fault(int32_t n_launches) { tgnn::g_spin_fault.store(n_launches > 0 ? n_launches : 0); }
+extern "C" uint64_t tgnn_set_spin_budget_us(uint64_t us) {
+    const unsigned long long ticks = us * 100ull;             // wall_clock64: 100 MHz
+    return tgnn::g_spin_budget.exchange(ticks ? ticks : tgnn::kSpinBudgetTicksDefault) / 100ull;
+}
 extern "C" void tgnn_set_small_layout_limit(int64_t n_nodes) { tgnn::g_small_limit.store(n_nodes < 0 ? 0 : n_nodes); }
 extern "C" int64_t tgnn_get_small_layout_limit(void) { return tgnn::g_small_limit.load(); }

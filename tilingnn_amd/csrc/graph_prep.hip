@@ -1623,7 +1623,7 @@ extern "C" size_t tgnn_graph_prep_workspace_bytes(int64_t n_nodes, int64_t n_adj
     const int64_t emax = n_adj_edges > n_col_edges ? n_adj_edges : n_col_edges;
     return align_up(tgnn_csr_workspace_bytes(n_nodes, emax), 256) + align_up(bk_workspace_bytes(n_nodes, n_adj_edges, n_col_edges), 256) +
            align_up(tgnn_edge_dedup_workspace_bytes(n_adj_edges, fe), 256) +
-           align_up(tgnn_nnconv_cols_workspace_bytes(n_nodes), 256) + align_up(tgnn_nnconv_stream_scan_ws_bytes(n_nodes), 256) + 1024;
+           align_up(tgnn_nnconv_cols_workspace_bytes(n_nodes), 256) + 1024;
 }
 
 extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edges, const float *adj_edge_attr, int32_t fe,
@@ -1631,9 +1631,8 @@ extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edge
                                int32_t *adj_rowptr, int32_t *adj_src, int32_t *adj_eid, int32_t *adj_type, int32_t *edge_type,
                                int32_t *type_rep_edge,
                                int32_t *col_rowptr, int32_t *col_src, int32_t *col_eid, int32_t *tile_col_ptr, int32_t *col_meta,
-                               int32_t *col_slot_src, int32_t *st_tile_ent_ptr, uint32_t *st_ent_src, uint32_t *st_rowlist,
-                               uint32_t *st_info, float *st_inv_deg, void *ws, size_t ws_bytes, int32_t *result,
-                               tgnn_stream_t stream) {
+                               int32_t *col_slot_src, int32_t *mid_tile_nb, uint32_t *mid_ent, void *ws, size_t ws_bytes,
+                               int32_t *result, tgnn_stream_t stream) {
     DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_nodes >= 1 && fe >= 1 && n_adj_edges >= 0 && n_col_edges >= 0, "shape");
     TGNN_CHECK_ARG(n_src_nodes >= n_nodes && n_src_nodes < (1ll << 31) - 1, "n_src_nodes must be >= n_nodes and fit int32");
@@ -1716,12 +1715,9 @@ extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edge
     nnconv_col_kernel<true><<<blocks, 64, 0, s>>>(adj_rowptr, adj_src, adj_type, n_nodes, 0, nullptr, tile_col_ptr, col_meta,
                                                   col_slot_src, result + 0, max_types, result + 5);
     TGNN_CHECK_LAUNCH();
-    if (st_tile_ent_ptr && st_ent_src && st_rowlist && st_info && st_inv_deg && n_nodes < (int64_t(1) << 24)) {
-        // the stream structure of the throughput NNConv kernel (nnconv_stream.hip; the type count is read on the device);
-        // result[8..10] = most entries of two consecutive tiles, most entries of one type run of a tile, 1 = built
-        void *ws_st = cv.take<unsigned char>(tgnn_nnconv_stream_scan_ws_bytes(n_nodes));
-        rc = nnconv_stream_build_gated(adj_rowptr, adj_src, adj_type, n_nodes, 0, result + 0, nullptr, st_tile_ent_ptr,
-                                       st_ent_src, st_rowlist, st_info, st_inv_deg, result + 8, ws_st, s);
+    if (mid_tile_nb && mid_ent) {
+        // the batches of the mid-size persistent layer loop (forward_mid.hip), straight from the columns; result[8..9]
+        rc = tgnn_mid_entries_build(tile_col_ptr, col_meta, col_slot_src, n_nodes, result + 5, mid_tile_nb, mid_ent, result + 8, stream);
         if (rc != TGNN_OK) return rc;
     }
     return TGNN_OK;

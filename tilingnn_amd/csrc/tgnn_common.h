@@ -359,21 +359,8 @@ int launch_nnconv_cols(const float *h, int64_t ldh, const int32_t *tile_col_ptr,
                        int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
                        hipStream_t s, const unsigned *h_max = nullptr, const unsigned *root_max = nullptr,
                        int max_in_degree = 0, unsigned long long *stamp = nullptr);
-// the stream NNConv kernel (nnconv_stream.hip) over rows pre-split into fp16 pairs (launch_nnconv_split16: hs [rows][128 B],
-// hs_scale {s, 1/s}); wtab = one layer's [T][32][32] table; reserve_cus CUs stay free
-// largest |h[0 .. n_floats)| (n_floats % 4 == 0) as float bits, atomicMax into *max_bits; nnconv_stream.hip
+// largest |h[0 .. n_floats)| (n_floats % 4 == 0) as float bits, atomicMax into *max_bits; bn_merge.hip
 void launch_absmax(const float *h, int64_t n_floats, unsigned *max_bits, hipStream_t s);
-int launch_nnconv_split16(const float *h, int64_t n_rows, void *hs, float *scale2, unsigned *max_bits, hipStream_t s);
-int launch_nnconv_stream(const void *hs, const float *hs_scale, int64_t n_src_rows, const int32_t *tile_ent_ptr,
-                         const uint32_t *ent_src, const uint32_t *rowlist, const uint32_t *info, const float *inv_deg,
-                         const float *wtab, const float *root, int32_t n_types, const float *bias, int64_t n_nodes, int32_t act,
-                         float *out, double *bn_partial, int32_t *n_partials_host, int reserve_cus, hipStream_t s);
-// queues the stream structure's three launches (from the adjacency CSR + edge types in CSR order); gate (may be NULL):
-// device word, nothing is built while it is 0
-int nnconv_stream_build_gated(const int32_t *rowptr, const int32_t *col_src, const int32_t *col_type, int64_t n_nodes,
-                              int32_t n_types, const int32_t *n_types_dev, const int32_t *gate, int32_t *tile_ent_ptr,
-                              uint32_t *ent_src, uint32_t *rowlist, uint32_t *info, float *inv_deg, int32_t *result, void *ws,
-                              hipStream_t s);
 // max |W_k| and a bound of |BN(v)| from the BatchNorm's parameters alone (nnconv.hip: dense_bounds_kernel), atomicMax into
 // zeroed words: what the final MLP's inner layers need to run the fp16-pair kernel on a BatchNorm-on-load input
 void launch_dense_bounds(int n_jobs, const float *const *w, const int64_t *w_n, const float *const *gamma, const float *const *beta,
@@ -411,11 +398,19 @@ int spin_kernel_chain(hipStream_t s, void (*launch)(void *ctx, hipStream_t s), v
 // 0 = not eligible (too large, too many edge types for LDS, ...); the packs / images are built per forward.
 int small_layout_teams(const tgnn_model_dims *d, int64_t n_nodes, int n_types, int max_in_degree);
 size_t small_pack_floats(int depth);
-void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrier_ctr, hipStream_t s);
+void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrier_ctr, hipStream_t s, bool dense_images = true);
 int launch_forward_small(const tgnn_model_dims *d, const Params &P, const float *x, float *probs, float *mid, float *a2_0,
                          float *a2_1, const float *wimg, float *pack, const tgnn_graph *graph, double *part, double *part_wide,
                          double *runstat, unsigned *ctr, const unsigned *weights_done, unsigned weights_target, int64_t n,
                          int update_running, float eps, float momentum, hipStream_t s);
+// Mid-size layouts (up to 65 536 nodes): the 20 layers as ONE persistent kernel between the general schedule's init and final
+// MLP (forward_mid.hip).  mid_layout_tiles_per_block: 0 = not eligible; the pack (GIN images + parameter vectors) is
+// launch_small_pack's, the NNConv images are the fp16-pair ones of launch_edge_weight_table_batched.
+int mid_layout_tiles_per_block(const tgnn_model_dims *d, const tgnn_graph *g, int64_t n_nodes, int *blocks_out);
+size_t mid_part_doubles();
+int launch_forward_mid(const tgnn_model_dims *d, const Params &P, float *mid, float *a1, float *a2_0, float *a2_1, const float *wimg,
+                       const float *pack, const tgnn_graph *graph, double *part, double *runstat, unsigned *ctr, unsigned *bounds,
+                       int64_t n, int tiles_per_block, int blocks, int update_running, float eps, float momentum, hipStream_t s);
 // MFMA weight image of the column NNConv, per type: [plane 3 (hi, mid, lo)][M block 2][g 4][i 16] x 8 bf16 --
 // the A fragment of lane 16 g + i for one (plane, M block) is one 16-byte read, a wavefront reads 1 KB in lane order
 // (conflict-free: SQ_LDS_BANK_CONFLICT 2.3e6 -> 2.3e5 per launch against the [i][g] order of round 1); 6144 B per type

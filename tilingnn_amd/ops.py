@@ -72,17 +72,16 @@ class PreparedGraph:
     col_eid: Tensor
     cols: Optional["NNConvColumns"] = None     # matrix-core NNConv column structure (None: CSR kernel is used)
     max_in_degree: int = 0                     # largest adjacency in-degree (0 = not known: no small-layout kernel)
-    stream: Optional["NNConvStream"] = None    # gathered-row stream of the throughput NNConv kernel (None: column kernel)
+    mid: Optional["NNConvBatches"] = None      # NNConv batches of the mid-size persistent layer loop (None: general schedule)
 
     def c_struct(self) -> _lib.Graph:
-        t, st = self.cols, self.stream
+        t, st = self.cols, self.mid
         return _lib.Graph(self.n_nodes, self.n_adj_edges, self.n_col_edges, self.n_types,
                           self.adj_rowptr.data_ptr(), self.adj_src.data_ptr(), self.adj_type.data_ptr(),
                           self.type_rep_edge.data_ptr(), self.col_rowptr.data_ptr(), self.col_src.data_ptr(),
                           *((t.tile_col_ptr.data_ptr(), t.col_meta.data_ptr(), t.col_src.data_ptr())
                             if t is not None else (None,) * 3), self.max_in_degree,
-                          *((st.tile_ent_ptr.data_ptr(), st.ent_src.data_ptr(), st.rowlist.data_ptr(), st.info.data_ptr(),
-                             st.inv_deg.data_ptr()) if st is not None else (None,) * 5))
+                          *((st.tile_nb.data_ptr(), st.ent.data_ptr()) if st is not None else (None,) * 2))
 
 
 @dataclass
@@ -94,56 +93,29 @@ class NNConvColumns:
 
 
 @dataclass
-class NNConvStream:
-    """Gathered-row stream of the throughput NNConv kernel (tgnn_nnconv_stream_build, include/tgnn.h)."""
-    tile_ent_ptr: Tensor      # int32 [ceil(N/16) + 1]
-    ent_src: Tensor           # int32 (uint32 bits) [cap]: entry words
-    rowlist: Tensor           # int32 (pairs of uint16) [cap / 2]: message-ring slots of every row's edges + itself
-    info: Tensor              # int32 (uint32 bits) [ceil(N/16) * 64]
-    inv_deg: Tensor           # float32 [16 * ceil(N/16)]
+class NNConvBatches:
+    """Per 16-row tile its in-edges packed by edge type for the mid-size persistent layer loop (tgnn_mid_entries_build,
+    include/tgnn.h; csrc/forward_mid.hip)."""
+    tile_nb: Tensor           # int32 [ceil(N/16)]
+    ent: Tensor               # int32 (uint32 bits) [ceil(N/16) * 18 * 36]
 
 
-# The stream kernel (csrc/nnconv_stream.hip) is an EXPERIMENT kept for its measurements (DESIGN.md section 13): parity-tested,
-# 38 us at 100k nodes against the column kernel's 44, and it wants its input rows pre-split -- not worth the switch.  Opt in
-# with TGNN_STREAM_NNCONV=1 (prepare_graph then also builds its structure) or per call with nnconv_mean(kernel="stream").
-STREAM_NNCONV = os.environ.get("TGNN_STREAM_NNCONV", "0") == "1"
+def mid_layout_range() -> Tuple[int, int]:
+    """(lo, hi]: node counts whose layer loop runs as the mid-size persistent kernel (layouts of up to 4 096 nodes belong to the
+    small-layout kernel, or to the general schedule when that one is switched off)."""
+    return 4096, int(lib.tgnn_get_mid_layout_limit())
 
 
-def stream_limits(_cache=[]):
-    if not _cache:
-        a, b, c = C.c_int32(0), C.c_int32(0), C.c_int32(0)
-        lib.tgnn_nnconv_stream_limits(C.byref(a), C.byref(b), C.byref(c))
-        _cache.append((a.value, b.value, c.value))
-    return _cache[0]
-
-
-def stream_fits(n_types: int, max_pair_entries: int, max_run_entries: int, built: int, n_src_rows: int) -> bool:
-    lim = stream_limits()
-    return bool(built and n_types <= lim[0] and max_pair_entries <= lim[1] and max_run_entries <= lim[2]
-                and n_src_rows < 2 ** 24)
-
-
-def build_nnconv_stream(n_nodes: int, n_edges: int, n_types: int, rowptr: Tensor, col_src: Tensor, col_type: Tensor,
-                        n_src_rows: Optional[int] = None) -> Optional[NNConvStream]:
-    """The stream structure from the adjacency CSR + edge types in CSR order (synchronises: the layout's largest tile and
-    the most same-type in-edges of a row decide whether the kernel takes it).  None when it does not."""
-    if n_types > stream_limits()[0] or n_nodes >= 2 ** 24:
-        return None
-    dev = rowptr.device
+def build_nnconv_batches(n_nodes: int, cols: "NNConvColumns") -> Optional[NNConvBatches]:
+    """The batches from the column structure (synchronises: a tile that does not fit sends the layout to the general schedule)."""
+    dev = cols.tile_col_ptr.device
     ntiles = (n_nodes + 15) // 16
-    cap = int(lib.tgnn_nnconv_stream_max_entries(n_nodes, n_edges))
-    st = NNConvStream(torch.empty(ntiles + 1, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.int32, device=dev),
-                      torch.empty(cap // 2 + 64, dtype=torch.int32, device=dev),
-                      torch.empty(ntiles * 64, dtype=torch.int32, device=dev),
-                      torch.empty(ntiles * 16, dtype=torch.float32, device=dev))
-    res = torch.zeros(4, dtype=torch.int32, device=dev)
-    ws_bytes = int(lib.tgnn_nnconv_stream_scan_ws_bytes(n_nodes))
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    check(lib.tgnn_nnconv_stream_build(ptr(rowptr), ptr(col_src), ptr(col_type), n_nodes, n_types, None, ptr(st.tile_ent_ptr),
-                                       ptr(st.ent_src), ptr(st.rowlist), ptr(st.info), ptr(st.inv_deg), ptr(res), ptr(ws), ws_bytes,
-                                       _stream(rowptr)))
-    host = res.cpu().tolist()
-    return st if stream_fits(n_types, host[0], host[1], host[2], n_src_rows or n_nodes) else None
+    mid = NNConvBatches(torch.empty(ntiles, dtype=torch.int32, device=dev),
+                        torch.empty(int(lib.tgnn_mid_entries_words(n_nodes)), dtype=torch.int32, device=dev))
+    res = torch.zeros(2, dtype=torch.int32, device=dev)
+    check(lib.tgnn_mid_entries_build(ptr(cols.tile_col_ptr), ptr(cols.col_meta), ptr(cols.col_src), n_nodes, None, ptr(mid.tile_nb),
+                                     ptr(mid.ent), ptr(res), _stream(cols.tile_col_ptr)))
+    return mid if res.cpu().tolist()[1] == 0 else None
 
 
 def build_nnconv_columns(n_nodes: int, n_edges: int, n_types: int, rowptr: Tensor, col_src: Tensor,
@@ -253,13 +225,13 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
     fe = int(attr.shape[1])
     ws_ints = int(lib.tgnn_graph_prep_small_tmp_ints(n_nodes, ea, ec)) if small else \
         (int(lib.tgnn_graph_prep_workspace_bytes(n_nodes, ea, ec, fe)) + 3) // 4 + 64
-    want_stream = not small and STREAM_NNCONV and n_nodes < 2 ** 24
-    st_cap = int(lib.tgnn_nnconv_stream_max_entries(n_nodes, ea)) if want_stream else 0
+    lo_mid, hi_mid = mid_layout_range()
+    want_mid = not small and n_src_nodes is None and lo_mid < n_nodes <= hi_mid
+    mid_words = int(lib.tgnn_mid_entries_words(n_nodes)) if want_mid else 0
     # the persistent outputs share ONE long-lived allocation; the scratch (CSR / de-dup tables, scan workspaces) and the result
     # words are tensors of their own, freed after the read-back -- a cached graph does not pin hundreds of MB of scratch
     sizes = [n_nodes + 1, e1, e1, e1, e1, e1, n_nodes + 1, c1, c1, ntiles + 1, cap, cap * 16,
-             (ntiles + 1) if want_stream else 0, st_cap, (st_cap // 2 + 64) if want_stream else 0,
-             ntiles * 64 if want_stream else 0, ntiles * 16 if want_stream else 0]
+             ntiles if want_mid else 0, mid_words]
     offs, at = [], 0
     for sz in sizes:
         offs.append(at)
@@ -267,7 +239,7 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
     buf = torch.empty(at, dtype=torch.int32, device=dev)
     v = [buf[o:o + sz] for o, sz in zip(offs, sizes)]
     (a_rowptr, a_src, a_eid, adj_type, edge_type, rep, c_rowptr, c_src, c_eid, tile_col_ptr, col_meta, col_slot_src,
-     st_ptr, st_src, st_rl, st_info, st_inv) = v
+     mid_nb, mid_ent) = v
     res = torch.empty(32, dtype=torch.int32, device=dev)
     tmp = torch.empty(ws_ints, dtype=torch.int32, device=dev)
     head = (ptr(adj), ea, ptr(attr), fe, ptr(col), ec, n_nodes) + (() if small else (n_src_nodes or n_nodes,)) + (ptr(a_rowptr), ptr(a_src), ptr(a_eid), ptr(adj_type), ptr(edge_type),
@@ -275,19 +247,17 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
     if small:
         check(lib.tgnn_graph_prep_small(*head, ptr(tmp), ptr(res), ptr(_small_prep_counters(dev)), _stream(adj)))
     else:
-        st_args = (ptr(st_ptr), ptr(st_src), ptr(st_rl), ptr(st_info), ptr(st_inv)) if want_stream else (None,) * 5
-        check(lib.tgnn_graph_prep(*head, *st_args, ptr(tmp), ws_ints * 4, ptr(res), _stream(adj)))
+        mid_args = (ptr(mid_nb), ptr(mid_ent)) if want_mid else (None,) * 2
+        check(lib.tgnn_graph_prep(*head, *mid_args, ptr(tmp), ws_ints * 4, ptr(res), _stream(adj)))
     host = res[:12].cpu().tolist()                                               # the one sync
     if host[1] or host[2]:
         raise IndexError(f"edge index out of range [0, {n_nodes}) in {'adj_e_index' if host[1] else 'col_e_idx'}")
     if host[6]:
         return None
     cols = NNConvColumns(tile_col_ptr, col_meta, col_slot_src) if host[5] else None
-    stream = None
-    if want_stream and cols is not None and stream_fits(int(host[0]), host[8], host[9], host[10], n_nodes):
-        stream = NNConvStream(st_ptr, st_src, st_rl, st_info, st_inv.view(torch.float32))
+    mid = NNConvBatches(mid_nb, mid_ent) if want_mid and cols is not None and host[9] == 0 else None
     return PreparedGraph(n_nodes, ea, int(host[3]), int(host[0]), a_rowptr, a_src, a_eid, adj_type, edge_type, rep,
-                         c_rowptr, c_src, c_eid, cols, int(host[4]), stream)
+                         c_rowptr, c_src, c_eid, cols, int(host[4]), mid)
 
 
 def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col_e_idx: Tensor,
@@ -327,11 +297,12 @@ def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col
     if columns is None:
         columns = n_nodes > COLS_MIN_NODES
     cols = build_nnconv_columns(n_nodes, ea, n_types, a_rowptr, a_src, adj_type) if tile_width == 32 and columns else None
-    stream = None
-    if STREAM_NNCONV and cols is not None and n_nodes > _small_prep_limits()[0]:
-        stream = build_nnconv_stream(n_nodes, ea, n_types, a_rowptr, a_src, adj_type, n_src_nodes)
+    mid = None
+    lo_mid, hi_mid = mid_layout_range()
+    if cols is not None and n_src_nodes is None and lo_mid < n_nodes <= hi_mid:
+        mid = build_nnconv_batches(n_nodes, cols)
     return PreparedGraph(n_nodes, ea, int(host[3]), n_types, a_rowptr, a_src, a_eid, adj_type, edge_type, rep,
-                         c_rowptr, c_src, c_eid, cols, int(host[4]), stream)
+                         c_rowptr, c_src, c_eid, cols, int(host[4]), mid)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -358,11 +329,10 @@ def edge_weight_table(edge_attr: Tensor, graph: PreparedGraph, w1, b1, w2, b2, w
 def nnconv_mean(h: Tensor, graph: PreparedGraph, wtab: Tensor, root: Tensor, bias: Tensor, act: int = ACT_NONE,
                 partials: Optional[Tensor] = None, force_csr_kernel: bool = False,
                 kernel: Optional[str] = None, max_in_degree: int = 0) -> Tuple[Tensor, int]:
-    """NNConv mean: the stream kernel when the graph carries the stream structure (width 32, <= 15 edge types, layouts
-    above the small-layout limit), else the matrix-core column kernel when it carries the column structure, else the CSR /
-    LDS-weight-table kernel (any type count that fits LDS) or the generic one.  kernel: None = that order, "stream" /
-    "cols" pin one (tests, A/B timing); "cols_f16" = the column kernel with the fp16 x 2 split as tgnn_forward runs it
-    (max_in_degree: the bound to scale by, default the layout's)."""
+    """NNConv mean: the matrix-core column kernel when the graph carries the column structure, else the CSR /
+    LDS-weight-table kernel (any type count that fits LDS) or the generic one.  kernel: None = that order; "cols_f16" = the
+    column kernel with the fp16 x 2 split as tgnn_forward runs it (max_in_degree: the bound to scale by, default the
+    layout's)."""
     h = _f32c(h, "x")
     c = int(h.shape[1])
     n = graph.n_nodes                      # destination rows; x may carry extra (halo) rows behind them
@@ -374,16 +344,7 @@ def nnconv_mean(h: Tensor, graph: PreparedGraph, wtab: Tensor, root: Tensor, bia
     npart = C.c_int32(0)
     wt = _f32c(wtab, "wtab")
     tl = graph.cols
-    st = graph.stream if kernel in (None, "stream") else None
-    if kernel == "stream" and st is None:
-        raise ValueError("the graph carries no stream structure")
-    if st is not None and c == 32 and not force_csr_kernel and int(h.shape[0]) < 2 ** 24:
-        split = torch.empty(lib.tgnn_nnconv_stream_split_bytes(int(h.shape[0])), dtype=torch.uint8, device=h.device)
-        check(lib.tgnn_nnconv_mean_stream_fwd(ptr(h), int(h.shape[0]), ptr(st.tile_ent_ptr), ptr(st.ent_src), ptr(st.rowlist),
-                                              ptr(st.info), ptr(st.inv_deg), ptr(wt), graph.n_types, ptr(_f32c(root, "root")),
-                                              ptr(_f32c(bias, "bias")), n, c, act, ptr(out), ptr(split), ptr(partials),
-                                              C.byref(npart), _stream(h)))
-    elif kernel == "cols_f16":
+    if kernel == "cols_f16":
         if tl is None or c != 32:
             raise ValueError("the fp16-pair column kernel needs the column structure and width 32")
         wimg = torch.empty(lib.tgnn_nnconv_weight_image_floats(graph.n_types), dtype=torch.float32, device=h.device)

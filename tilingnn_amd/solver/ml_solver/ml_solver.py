@@ -65,8 +65,11 @@ class ML_Solver:
         else:
             x, adj_edge_index, adj_edge_features, collide_edge_index, collide_edge_features = \
                 brick_layout.get_data_as_torch_tensor(self.device)
-            predictions, *_ = self.network(x=x, adj_e_index=adj_edge_index, adj_e_features=adj_edge_features,
-                                           col_e_idx=collide_edge_index, col_e_features=collide_edge_features)
+            # the reference's call (ml_solver.py:39-43); tilingnn_amd.TilinGNN also checks the health word of its persistent
+            # kernels here (forward_checked: the probabilities travel to the host below anyway)
+            run = getattr(self.network, "forward_checked", None) or self.network
+            predictions, *_ = run(x=x, adj_e_index=adj_edge_index, adj_e_features=adj_edge_features,
+                                  col_e_idx=collide_edge_index, col_e_features=collide_edge_features)
         best_map_index = self._best_prob_map(predictions, brick_layout)
         return predictions[:, best_map_index].detach().cpu().numpy()
 
