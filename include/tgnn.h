@@ -168,19 +168,22 @@ int tgnn_nnconv_mean_cols_f16_fwd(const float *h, int64_t ldh, int64_t n_src_row
  *   ent     uint32 [ceil(N/16)][TGNN_MID_TILE_BATCHES][TGNN_MID_BATCH_WORDS]  per tile its edge types in order; a batch = up to 32
  *           in-edges of ONE type: words 0-3 = {type | last-batch-of-the-type << 8, mask of the tile's rows that have an edge of
  *           the type, 0, 0}, word 4 + 4 o + g = slot o (0..7) of gather instruction g (0..3):
- *           source row | destination row (0..15) << 20 | add << 24 | valid << 31.  Eight whole 128-byte source rows per gather
+ *           source row (24 bits) | destination row (0..15) << 25 | add << 30; an empty slot is 0x21000000 (source 0x1000000 = none,
+ *           destination 16 = the kernel's spare row).  Eight whole 128-byte source rows per gather
  *           instruction, never two edges of one destination row in one instruction: a row's first edge of a type STORES its
  *           type-sum slot, further ones (add) read-add-write it, in CSR (= original edge) order.
  * result (device int32 [2], zeroed by the caller): [0] most batches of a tile, [1] 1 = a tile does not fit (more than
- * TGNN_MID_TILE_BATCHES batches / 128 columns) or no column structure -- the layout then takes the general schedule.
+ * TGNN_MID_TILE_BATCHES batches / 64 columns) or no column structure -- the layout then takes the general schedule.
  * cols_built_dev (may be NULL): device word, 0 = the column structure was not built (tgnn_graph_prep: result + 5). */
 #define TGNN_MID_BATCH_WORDS 36
-#define TGNN_MID_TILE_BATCHES 18
+#define TGNN_MID_TILE_BATCHES 24
 int64_t tgnn_mid_entries_words(int64_t n_nodes);
 int tgnn_mid_entries_build(const int32_t *tile_col_ptr, const int32_t *col_meta, const int32_t *col_src, int64_t n_nodes,
                            const int32_t *cols_built_dev, int32_t *tile_nb, uint32_t *ent, int32_t *result, tgnn_stream_t stream);
-/* Layouts above the small-layout limit and up to this many nodes (default and maximum 65 536; 0 = off) run the layer loop as the
+/* Layouts of more than 4 096 and up to this many nodes (default 32 768, maximum 65 536; 0 = off) run the layer loop as the
  * persistent mid-size kernel when the graph carries the batches (nn_mid_*), width 32, train-mode BatchNorm, single device. */
+/* Forwards queued so far by this process on {the general launch schedule, the small-layout kernel, the mid-size kernel}. */
+void tgnn_forward_path_counts(int64_t *out3);
 void tgnn_set_mid_layout_limit(int64_t n_nodes);
 int64_t tgnn_get_mid_layout_limit(void);
 int64_t tgnn_mid_layout_max_nodes(void);

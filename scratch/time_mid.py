@@ -2,6 +2,7 @@
 import sys, time, torch
 sys.path.insert(0, ".")
 from tilingnn_amd import TilinGNN, _lib
+from tilingnn_amd.graph_networks import _graph_cache
 from tilingnn_amd.synth import make_super_graph
 from tilingnn_amd.weights import make_state_dict
 dev = torch.device("cuda:0")
@@ -16,6 +17,7 @@ for n in sizes:
     out = {}
     for name, limit in (("general", 0), ("mid", 65536)):
         _lib.lib.tgnn_set_mid_layout_limit(limit)
+        _graph_cache.clear()
         for cache in (True, False):
             net.cache_graph = cache
             for _ in range(5):

@@ -97,6 +97,7 @@ def _load() -> C.CDLL:
         "tgnn_nnconv_mean_cols_f16_fwd": (C.c_int, [p, i64, i64, p, p, p, p, i32, p, p, i64, i32, i32, p, p, p, p, pi32, p]),
         "tgnn_mid_entries_words": (i64, [i64]),
         "tgnn_mid_entries_build": (C.c_int, [p, p, p, i64, p, p, p, p, p]),
+        "tgnn_forward_path_counts": (None, [p]),
         "tgnn_set_mid_layout_limit": (None, [i64]),
         "tgnn_get_mid_layout_limit": (i64, []),
         "tgnn_mid_layout_max_nodes": (i64, []),
@@ -196,7 +197,7 @@ EXPORTED_SYMBOLS = (
     "tgnn_edge_dedup_workspace_bytes", "tgnn_edge_type_dedup", "tgnn_gather_i32", "tgnn_edge_weight_table",
     "tgnn_nnconv_mean_fwd", "tgnn_nnconv_cols_max_columns", "tgnn_nnconv_cols_workspace_bytes",
     "tgnn_nnconv_cols_build", "tgnn_nnconv_cols_max_types", "tgnn_nnconv_weight_image_floats", "tgnn_nnconv_mean_cols_fwd", "tgnn_nnconv_mean_cols_f16_fwd",
-    "tgnn_mid_entries_words", "tgnn_mid_entries_build", "tgnn_set_mid_layout_limit", "tgnn_get_mid_layout_limit", "tgnn_mid_layout_max_nodes",
+    "tgnn_mid_entries_words", "tgnn_mid_entries_build", "tgnn_forward_path_counts", "tgnn_set_mid_layout_limit", "tgnn_get_mid_layout_limit", "tgnn_mid_layout_max_nodes",
     "tgnn_spin_error_poll", "tgnn_set_spin_budget_us", "tgnn_debug_spin_fault", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_dense_act_slots_fwd", "tgnn_dense_act_slots_f16_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
     "tgnn_merge_fwd", "tgnn_param_count", "tgnn_param_name", "tgnn_forward_workspace_bytes", "tgnn_forward",
     "tgnn_forward_profiled", "tgnn_forward_profiled_two_stream", "tgnn_forward_stamped", "tgnn_forward_many", "tgnn_graph_prep_small_max_nodes", "tgnn_graph_prep_small_max_edges", "tgnn_graph_prep_small_tmp_ints",
@@ -209,6 +210,13 @@ EXPORTED_SYMBOLS = (
     "tgnn_nnconv_type_sum", "tgnn_csr_degree", "tgnn_unsupervised_loss_bwd",
     "tgnn_f32_to_bf16", "tgnn_nnconv64_image_elems", "tgnn_nnconv64_bf16_fwd", "tgnn_gin64_bf16_fwd", "tgnn_collconv64_bf16_fwd", "tgnn_merge_bf16_fwd",
     "tgnn_dense_bf16_slots_fwd", "tgnn_forward_bf16_workspace_bytes", "tgnn_forward_bf16")
+
+
+def forward_path_counts():
+    """(general schedule, small-layout kernel, mid-size kernel): forwards queued so far by this process."""
+    out = (C.c_int64 * 3)()
+    lib.tgnn_forward_path_counts(out)
+    return tuple(int(v) for v in out)
 
 
 def check(rc: int) -> None:

@@ -127,6 +127,7 @@ struct Prof {
 
 static const int kFinalDims[4] = {256, 128, 64, 0};  // TilinGNN.py:46 hidden_layer_dims; [3] = C
 static std::atomic<int> g_split_f16{1};              // tgnn_set_split_precision
+static std::atomic<int64_t> g_path_count[3];          // forwards queued on the general schedule / small-layout kernel / mid-size kernel
 
 // n = rows this device computes; nr >= n = rows of the buffers that are GATHERED from (owned rows, then halo rows
 // of other shards; nr == n on a single device)
@@ -175,6 +176,10 @@ extern "C" int32_t tgnn_set_split_precision(int32_t mode) {
     return g_split_f16.exchange(mode);
 }
 extern "C" const char *tgnn_last_error(void) { return g_err; }
+extern "C" void tgnn_forward_path_counts(int64_t *out3) {
+    if (!out3) return;
+    for (int k = 0; k < 3; ++k) out3[k] = g_path_count[k].load(std::memory_order_relaxed);
+}
 
 extern "C" int32_t tgnn_param_count(const tgnn_model_dims *dims) {
     if (!dims_ok(dims)) return -1;
@@ -424,8 +429,10 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     // ONE persistent kernel carrying both chains (forward_mid.hip) instead of ~5 dependent launches per layer on two streams
     int mid_blocks = 0;
     const int mid_k = (f16 && !sh && !keep && !prof.on && nr == n) ? mid_layout_tiles_per_block(dims, graph, n, &mid_blocks) : 0;
-    if (mid_k) launch_small_pack(P, D, w.small_pack, w.small_ctr, s, false);   // parameter vectors + GIN images of the layers
+    // (parameter vectors + GIN images of the layers; the same launch clears the barrier counter and the tagged partial rows)
+    if (mid_k) launch_small_pack(P, D, w.small_pack, w.small_ctr, s, false, w.mid_part, mid_part_doubles() * sizeof(double));
     if (sw != s) TGNN_CHECK_HIP(hipEventRecord(ev[kEvWeights], s2));
+    g_path_count[small_teams ? 1 : mid_k ? 2 : 0].fetch_add(1, std::memory_order_relaxed);
     if (small_teams) {
         // init MLP, the layers and the final MLP: one persistent kernel behind the pre-pass
         if (sw != s && !weights_done) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[kEvWeights], 0));
@@ -471,7 +478,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
 #else
     const bool fold_fin2 = c == 32 && !sh && !use_running_stats;
 #endif
-    if (fold_fin2) TGNN_CHECK_HIP(hipMemsetAsync(w.small_ctr + 32, 0, sizeof(unsigned), s));   // (before ev[0]: the side chain sees it)
+    if (fold_fin2 && !mid_k) TGNN_CHECK_HIP(hipMemsetAsync(w.small_ctr + 32, 0, sizeof(unsigned), s));   // (before ev[0]: the side chain sees it)
     auto gin_layer = [&](int i, hipStream_t gs) -> int {
         const int b = P.layer(i);
         const float *gin_in = i == 0 ? w.mid : w.a2[(i - 1) & 1];

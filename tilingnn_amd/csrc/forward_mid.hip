@@ -43,11 +43,24 @@ namespace tgnn {
 using f16x8 = tgnn_f16x8;
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-constexpr int kMidThreads = 1024, kMidWaves = 16, kMidNnWaves = 8, kMidGinWaves = 12;
+constexpr int kMidThreads = 512, kMidWaves = 8;   // 2 waves per SIMD, 256 registers a lane: a wave hides its own latency (deep gather queues)
 constexpr int kMidBatchWords = TGNN_MID_BATCH_WORDS, kMidTileBatches = TGNN_MID_TILE_BATCHES;
-constexpr int kMidEntWords = kMidBatchWords * kMidTileBatches;     // 648 words per tile
+constexpr int kMidEntWords = kMidBatchWords * kMidTileBatches;     // 864 words per tile
+constexpr uint32_t kMidEmptyEntry = 0x01000000u | (16u << 25);      // no source row, destination = the spare row
+constexpr int kMidPf = 4;                                          // gather batches in flight per wave
+constexpr int kMidEntLds = kMidEntWords + 2 * kMidPf * kMidBatchWords;   // a wave's batches in LDS + the empty ones behind them (the unrolled loop runs up to kPf - 1 past the end and issues kPf ahead)
 constexpr int kMidMaxTilesPerBlock = 16;
 constexpr int kMidColFirst = 1 << 8;
+constexpr int kMidTileFloats = 17 * 36;                           // a wave's tile (see mid_chunk) incl. the row empty batch slots store to
+
+#ifdef TGNN_MID_TIMING
+// phase timers (scratch builds only): wall_clock64 ticks (100 MHz) summed over the layers; per block [0..15] thread 0's phases,
+// [16 + w] wave w's time inside its NNConv items, [32 + w] inside its GIN items
+__device__ unsigned long long g_mid_timing[256 * 64];
+#define TGNN_MT(slot) { const unsigned long long now_ = wall_clock64(); if (tid == 0) tacc[slot] += now_ - tlast; tlast = now_; }
+#else
+#define TGNN_MT(slot)
+#endif
 
 struct MidArgs {
     float *mid;                  // skip buffer [depth + 1][n][32]; slot 0 filled by the init MLP
@@ -66,13 +79,15 @@ struct MidArgs {
     unsigned *err;
     unsigned long long spin_budget;
     int64_t n;
-    int n_types, depth, update_running, tiles_per_block, deg_log2, fault;
+    int n_types, depth, update_running, tiles_per_block, deg_log2, fault, nn_split;
     float eps, momentum;
 };
 
-// ---- wave tile in LDS: [16 rows][8 chunks of 16 bytes], chunk c of row r at position c ^ (r & 7): whole-row writes (8 lanes a row),
-//      matrix-layout reads (lane (n, q): chunks 2 q, 2 q + 1 of row n) and column walks are all bank-conflict free
-__device__ __forceinline__ int mid_chunk(int row, int c) { return row * 32 + ((c ^ (row & 7)) << 2); }   // float index
+// ---- wave tile in LDS: [17 rows][36 floats]: rows of 32 floats padded to 144 bytes (a matrix-layout read -- lane (n, q): floats
+//      8 q .. 8 q + 7 of row n -- then meets at most 2-way bank conflicts, whole-row writes and column walks none), row 16 = where
+//      the empty slots of a gather batch store.  An address is one multiply-add of the row number.
+constexpr int kMidRowFloats = 36;
+__device__ __forceinline__ int mid_chunk(int row, int c) { return row * kMidRowFloats + (c << 2); }   // float index of 16-byte chunk c
 
 // ---- one tagged double: the low two mantissa bits carry the generation
 __device__ __forceinline__ u32x2 mid_tag(double v, unsigned tag) {
@@ -114,27 +129,29 @@ struct MidNn {
     int n_types;
 };
 
-__device__ __forceinline__ void mid_nnconv_tile(const MidNn &N, const MidArgs &A, int64_t tile, int nb, const float *bias,
-                                                int lane, double &bn_acc) {
+// The wave's share of a tile's type runs (all of them, or every W-th when W waves share the tile; the root run belongs to share 0):
+// d0 / d1 = its partial D^T tiles (channels 4 fq + r and 16 + 4 fq + r of row fj), before the 1 / deg.
+__device__ __forceinline__ void mid_nnconv_partial(const MidNn &N, const MidArgs &A, int64_t tile, int nb, bool with_root, int lane,
+                                                   f32x4 &d0, f32x4 &d1) {
     const int fj = lane & 15, fq = lane >> 4, go = lane >> 3, gp = lane & 7;
-    const int64_t n = A.n;
     const uint32_t gp16 = (uint32_t)gp * 16u;
-    // the tile's own rows in the matrix layout (root run) and their in-degrees: requested first, used last
+    // the tile's own rows in the matrix layout (root run): requested first ...
     const int64_t my_row = tile * 16 + fj;
-    const bool row_ok = my_row < n;
+    const bool row_ok = my_row < A.n && with_root;
     const uint32_t own_off = row_ok ? (uint32_t)my_row * 128u + (uint32_t)fq * 32u : kOob;
     const float4 own0 = ld_sc1_f4(N.h_rs, own_off), own1 = ld_sc1_f4(N.h_rs, own_off == kOob ? kOob : own_off + 16u);
     int deg_i = 0;
     if (row_ok) deg_i = A.adj_rowptr[my_row + 1] - A.adj_rowptr[my_row];
     const float degf = row_ok ? (float)(deg_i > 0 ? deg_i : 1) : 0.f;
 
-    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;                 // D^T tiles: channels 4 fq + r and 16 + 4 fq + r of row fj
+    d0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    d1 = d0;
     constexpr int kPl = kWtPlane / 4;                            // 16-byte fragments per plane
     auto run_mma = [&](const float (&af)[8], float scale, int t) {
-        f16x8 xh, xl;
-        split2_f16(af, scale, xh, xl);
         const f16x8 *wp = reinterpret_cast<const f16x8 *>(N.wl + t * kWtTypeF16) + lane;
         const f16x8 h0 = wp[0], h1 = wp[64], l0 = wp[kPl], l1 = wp[kPl + 64];
+        f16x8 xh, xl;
+        split2_f16(af, scale, xh, xl);
         d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(l0, xh, d0, 0, 0, 0);   // lo . hi
         d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(l1, xh, d1, 0, 0, 0);
         d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, xl, d0, 0, 0, 0);   // hi . lo
@@ -143,40 +160,41 @@ __device__ __forceinline__ void mid_nnconv_tile(const MidNn &N, const MidArgs &A
         d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, xh, d1, 0, 0, 0);
     };
 
-    // batches: the gathers of batch b + 1 are in flight while batch b is scattered into the tile and multiplied
-    u32x4 ew = {0u, 0u, 0u, 0u};                                 // this lane's four entry words of the batch in flight
-    f32x4 x[4];
-    auto issue = [&](int b) {
-        const bool live = b < nb;                                // (wave-uniform; no load sits behind a branch)
-        const int bb = live ? b : 0;
-        ew = *reinterpret_cast<const u32x4 *>(N.ebuf + bb * kMidBatchWords + 4 + go * 4);
+    // Batches: the gathers of kPf batches are in flight while one is scattered into the tile and multiplied -- a wave works on its
+    // tile alone, so what hides the latency of a gather is its own queue.  Register slots are static (the loop is unrolled by
+    // kPf); nothing is loaded behind a branch (hipcc would drain the queue at the join): past the last batch the offsets are out
+    // of range and fetch nothing.  A batch's entry words and header travel in registers from the issue to the scatter.
+    constexpr int kPf = kMidPf;
+    f32x4 x[kPf][4];
+    u32x4 ews[kPf];
+    uint32_t hdr0[kPf], hdr1[kPf];
+    // entry word: source row (bits 0-23; 0x1000000 = none: shifted by 7 that is an offset out of the window, nothing is fetched) |
+    // destination row << 25 (16 = the tile's spare row, for empty slots) | add << 30 -- one instruction each for the gather offset,
+    // the row and the LDS address.  The buffer holds kPf empty batches behind the tile's last one: no end test anywhere.
+    auto issue = [&](f32x4 (&xs)[4], u32x4 &ew, uint32_t &h0, uint32_t &h1, int b) {
+        const uint32_t *bp = N.ebuf + b * kMidBatchWords;
+        ew = *reinterpret_cast<const u32x4 *>(bp + 4 + go * 4);
+        const u32x2 hh = *reinterpret_cast<const u32x2 *>(bp);
+        h0 = __builtin_amdgcn_readfirstlane(hh[0]);
+        h1 = __builtin_amdgcn_readfirstlane(hh[1]);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const uint32_t w = live ? ew[g] : 0u;
-            ew[g] = w;
-            x[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                 N.h_rs, (w >> 31) ? ((w & 0xfffffu) << 7) + gp16 : kOob, 0, kCpSc1));
-        }
+        for (int g = 0; g < 4; ++g)
+            xs[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(N.h_rs, (ew[g] << 7) | gp16, 0, kCpSc1));
     };
-    issue(0);
-    for (int b = 0; b < nb; ++b) {
-        const uint32_t hdr0 = __builtin_amdgcn_readfirstlane(N.ebuf[b * kMidBatchWords]);
-        const uint32_t hdr1 = __builtin_amdgcn_readfirstlane(N.ebuf[b * kMidBatchWords + 1]);
+    auto consume = [&](const f32x4 (&xs)[4], const u32x4 &ew, uint32_t h0, uint32_t h1) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const uint32_t w = ew[g];
-            const bool valid = (w >> 31) != 0u, add = ((w >> 24) & 1u) != 0u;
-            const int row = (int)((w >> 20) & 15u);
-            f32x4 *dst = reinterpret_cast<f32x4 *>(N.tbuf + mid_chunk(row, gp));
-            f32x4 v = x[g];
-            if (__any(valid && add)) {                            // (wave-uniform) a further edge of the same type: read-add-write
+            const bool add = ((w >> 30) & 1u) != 0u;
+            f32x4 *dst = reinterpret_cast<f32x4 *>(N.tbuf + ((w >> 25) & 31u) * kMidRowFloats + 4 * gp);
+            f32x4 v = xs[g];
+            if (__any(add)) {                                     // (wave-uniform) a further edge of the same type: read-add-write
                 const f32x4 old = *dst;
                 if (add) v = v + old;
             }
-            if (valid) *dst = v;
+            *dst = v;
         }
-        issue(b + 1);
-        if (hdr0 & 0x100u) {                                      // last batch of its type run: S_t is complete
+        if (h0 & 0x100u) {                                        // last batch of its type run: S_t is complete
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -184,18 +202,38 @@ __device__ __forceinline__ void mid_nnconv_tile(const MidNn &N, const MidArgs &A
             const f32x4 s1 = *reinterpret_cast<const f32x4 *>(N.tbuf + mid_chunk(fj, 2 * fq + 1));
             const float af[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
             // rows without an edge of this type hold whatever the run before left there: their operand is zeroed by the scale
-            const float scale = ((hdr1 >> fj) & 1u) ? N.sx : 0.f;
-            run_mma(af, scale, (int)(hdr0 & 0xffu));
+            const float scale = ((h1 >> fj) & 1u) ? N.sx : 0.f;
+            run_mma(af, scale, (int)(h0 & 0xffu));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();                      // (the next run's stores come after these reads)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-    }
-    {   // root run: the row itself, pre-multiplied by max(deg, 1)
+    };
+#pragma unroll
+    for (int u = 0; u < kPf; ++u) issue(x[u], ews[u], hdr0[u], hdr1[u], u);
+    if (with_root) {   // ... root run first (its rows were requested ahead of the batches): the row itself times max(deg, 1)
         const float af[8] = {own0.x, own0.y, own0.z, own0.w, own1.x, own1.y, own1.z, own1.w};
         run_mma(af, degf * N.sx, N.n_types);
     }
-    // epilogue: mean + root + bias, LeakyReLU; rows past n are zero
+    for (int b0 = 0; b0 < nb; b0 += kPf) {                        // (batches nb .. are empty ones: harmless to scatter)
+#pragma unroll
+        for (int u = 0; u < kPf; ++u) {
+            consume(x[u], ews[u], hdr0[u], hdr1[u]);
+            issue(x[u], ews[u], hdr0[u], hdr1[u], b0 + u + kPf);
+        }
+    }
+}
+
+// mean + root + bias, LeakyReLU of a finished tile (d0 / d1: the sums over all type runs and the root run); rows past n are zero;
+// the rows go to a1, their BatchNorm column sums (fp64) into bn_acc
+__device__ __forceinline__ void mid_nnconv_finish(const MidNn &N, const MidArgs &A, int64_t tile, const float *bias, int lane,
+                                                  const f32x4 &d0, const f32x4 &d1, double &bn_acc) {
+    const int fj = lane & 15, fq = lane >> 4;
+    const int64_t my_row = tile * 16 + fj;
+    const bool row_ok = my_row < A.n;
+    int deg_i = 0;
+    if (row_ok) deg_i = A.adj_rowptr[my_row + 1] - A.adj_rowptr[my_row];
+    const float degf = (float)(deg_i > 0 ? deg_i : 1);
     const float inv = row_ok ? N.unscale / degf : 0.f;
     const float4 bias0 = *reinterpret_cast<const float4 *>(bias + 4 * fq), bias1 = *reinterpret_cast<const float4 *>(bias + 16 + 4 * fq);
     f32x4 o0, o1;
@@ -204,6 +242,9 @@ __device__ __forceinline__ void mid_nnconv_tile(const MidNn &N, const MidArgs &A
     o1[0] = leakyf_(fmaf(d1[0], inv, bias1.x)); o1[1] = leakyf_(fmaf(d1[1], inv, bias1.y));
     o1[2] = leakyf_(fmaf(d1[2], inv, bias1.z)); o1[3] = leakyf_(fmaf(d1[3], inv, bias1.w));
     if (!row_ok) o0 = o1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     *reinterpret_cast<f32x4 *>(N.tbuf + mid_chunk(fj, fq)) = o0;
     *reinterpret_cast<f32x4 *>(N.tbuf + mid_chunk(fj, 4 + fq)) = o1;
     const __amdgpu_buffer_rsrc_t o_rs = rsrc_of(A.a1);
@@ -243,7 +284,9 @@ __device__ __forceinline__ void mid_gin_tile(const MidArgs &A, int64_t tile, int
     const float4 gv = use_stat ? *reinterpret_cast<const float4 *>(st2 + 64 + 4 * gp) : one4;
     const float4 bv = use_stat ? *reinterpret_cast<const float4 *>(st2 + 96 + 4 * gp) : zero4;
     const float one_eps = sp[kSpEps];
-    // neighbourhood sums: lane (go, gp) walks the rows 8 h + go (h = 0, 1), piece gp; 8 neighbours of both rows in flight
+    // neighbourhood sums: lane (go, gp) walks the rows 8 h + go (h = 0, 1), piece gp.  A row's 8 lanes fetch 8 consecutive
+    // neighbour indices with ONE load (the next 8 while the rows of these fly) and hand them round by lane permutes; 8 source
+    // rows of both destination rows are in flight per step: ~3 memory round trips per 16 neighbours instead of one per 4
     int beg[2], deg[2];
     float4 selfv[2], acc[2];
 #pragma unroll
@@ -255,30 +298,42 @@ __device__ __forceinline__ void mid_gin_tile(const MidArgs &A, int64_t tile, int
         selfv[h] = ld_sc1_f4(a_rs, ok ? (uint32_t)row * 128u + (uint32_t)gp * 16u : kOob);
         acc[h] = zero4;
     }
-    constexpr int kG = 4;                                         // neighbours of each of the two rows in flight (registers: 128 per lane)
-    for (int k0 = 0; __any(k0 < deg[0] || k0 < deg[1]); k0 += kG) {
-        uint32_t off[2][kG];
+    int maxdeg = deg[0] > deg[1] ? deg[0] : deg[1];
+#pragma unroll
+    for (int d = 32; d >= 8; d >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, d, 64));
+    maxdeg = __builtin_amdgcn_readfirstlane(maxdeg);
+    auto load_idx = [&](int k0, int (&idx)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const bool in = k0 + gp < deg[h];
+            const int v = A.col_nbr[in ? beg[h] + k0 + gp : 0];
+            idx[h] = in ? v : -1;
+        }
+    };
+    int idx[2], idx_next[2];
+    load_idx(0, idx);
+    for (int k0 = 0; k0 < maxdeg; k0 += 8) {
+        load_idx(k0 + 8, idx_next);                               // (past the longest row: nothing is fetched)
+        float4 y[2][8];
+        bool has[2][8];
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int k = 0; k < kG; ++k) {
-                const bool in = k0 + k < deg[h];
-                const int nb = A.col_nbr[in ? beg[h] + k0 + k : 0];
-                off[h][k] = in ? (uint32_t)nb * 128u + (uint32_t)gp * 16u : kOob;
+            for (int k = 0; k < 8; ++k) {
+                const int nbk = __shfl(idx[h], (lane & ~7) | k, 64);
+                has[h][k] = nbk >= 0;
+                y[h][k] = ld_sc1_f4(a_rs, nbk >= 0 ? (uint32_t)nbk * 128u + (uint32_t)gp * 16u : kOob);
             }
-        float4 y[2][kG];
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int k = 0; k < kG; ++k) y[h][k] = ld_sc1_f4(a_rs, off[h][k]);
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int k = 0; k < kG; ++k)
-                if (off[h][k] != kOob) {
+            for (int k = 0; k < 8; ++k)
+                if (has[h][k]) {
                     acc[h].x += (y[h][k].x - mhi.x) - mlo.x; acc[h].y += (y[h][k].y - mhi.y) - mlo.y;
                     acc[h].z += (y[h][k].z - mhi.z) - mlo.z; acc[h].w += (y[h][k].w - mhi.w) - mlo.w;
                 }
+        idx[0] = idx_next[0];
+        idx[1] = idx_next[1];
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -363,11 +418,11 @@ __device__ __forceinline__ void mid_gin_tile(const MidArgs &A, int64_t tile, int
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// global -> LDS by DMA: `chunks` KB starting at src, round the waves [w0, w0 + nw) of the block; 1 KB per wave-level instruction
-__device__ __forceinline__ void mid_dma(const float *src, float *dst_lds, int bytes, int wave, int lane, int w0, int nw) {
-    if (wave < w0 || wave >= w0 + nw) return;
-    const int chunks = bytes >> 10;                               // (multiples of 1 KB)
-    for (int c = wave - w0; c < chunks; c += nw)
+// global -> LDS by DMA: `bytes` (a multiple of 1 KB) starting at src, shared out round the block's waves; 1 KB per wave-level
+// instruction, no register in between
+__device__ __forceinline__ void mid_dma(const float *src, float *dst_lds, int bytes, int wave, int lane) {
+    const int chunks = bytes >> 10;
+    for (int c = wave; c < chunks; c += kMidWaves)
         __builtin_amdgcn_global_load_lds(src + c * 256 + lane * 4, (lds_void_t *)(dst_lds + c * 256), 16, 0, 0);
 }
 
@@ -376,20 +431,23 @@ __global__ __launch_bounds__(kMidThreads) void forward_layers_mid_kernel(MidArgs
     if (A.fault && blockIdx.x == gridDim.x - 1) return;         // (test hook: a block that never shows up)
     const int T = A.n_types, D = A.depth;
     const int64_t n = A.n;
-    // LDS: NNConv image | GIN image | 16 wave tiles [16][32] (the all-reduce's two fold arrays alias them) | batches of the 8
-    //      NNConv waves' tiles | BatchNorm records [2][4][32] | all-reduce totals [128] doubles | scratch words
+    // LDS: NNConv image | GIN image | 8 wave tiles [16][32] (the all-reduce's fold array [16][128] doubles aliases them) | batches of
+    //      the waves' tiles | BatchNorm records [2][4][32] | all-reduce totals [128] doubles | scratch words | the waves' BatchNorm sums
     float *wl = lds;
     float *gw = wl + (T + 1) * kWtTypeF16;
     float *tiles = gw + kSpGinFrags * 4;
-    uint32_t *ents = reinterpret_cast<uint32_t *>(tiles + kMidWaves * 512);
-    float *st = reinterpret_cast<float *>(ents + kMidNnWaves * kMidEntWords);
+    uint32_t *ents = reinterpret_cast<uint32_t *>(tiles + kMidWaves * kMidTileFloats);
+    float *st = reinterpret_cast<float *>(ents + kMidWaves * kMidEntLds);
     double *tot = reinterpret_cast<double *>(st + 256);
     float *scr = reinterpret_cast<float *>(tot + 128);            // [32]
-    double *red1 = reinterpret_cast<double *>(tiles), *red2 = red1 + 16 * 128;
+    double *bnred = reinterpret_cast<double *>(scr + 32);         // [8 waves][128]: the waves' BatchNorm sums of the layer (NOT in the tiles:
+                                                                  //  a share's partial product may still be read there by share 0)
+    double *red = reinterpret_cast<double *>(tiles);
+    static_assert(kMidWaves * kMidTileFloats * 4 >= 16 * 128 * 8, "the fold array fits the wave tiles");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float *tbuf = tiles + wave * 512;
-    uint32_t *ebuf = ents + (wave & (kMidNnWaves - 1)) * kMidEntWords;
+    float *tbuf = tiles + wave * kMidTileFloats;
+    uint32_t *ebuf = ents + wave * kMidEntLds;
     const int64_t n_tiles = (n + 15) / 16;
     const int K = A.tiles_per_block;
     const int64_t tile0 = (int64_t)blockIdx.x * K;
@@ -398,45 +456,78 @@ __global__ __launch_bounds__(kMidThreads) void forward_layers_mid_kernel(MidArgs
     const size_t slot = (size_t)n * 32;
     SpinCtx spin{A.err, A.spin_budget, false};
     unsigned b_target = 0;
-    const bool ent_resident = K <= kMidNnWaves;                  // one tile per NNConv wave: its batches stay in LDS for all layers
+    const bool ent_resident = K <= kMidWaves;                    // one tile per wave: its batches stay in LDS for all layers
     double bn1 = 0.0, bn2 = 0.0;                                  // this wave's BatchNorm sums of the layer: lane = (channel, sum | sumsq)
+#ifdef TGNN_MID_TIMING
+    unsigned long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = wall_clock64(), t_nn = 0, t_gin = 0;
+#endif
 
-    auto load_entries = [&](int64_t tile, int nb) {
+    // W waves share a tile's type runs when the block has fewer tiles than waves (W = 8 / K rounded down to a power of two): run r
+    // belongs to share r % W; the shares' partial products meet through the tiles.  W == 1: a wave owns whole tiles (k, k + 8, ..)
+    const int W = A.nn_split, my_part = wave & (W - 1);
+    const int my_k = W > 1 ? wave / W : wave;                     // W > 1: THE tile of this wave (if < kb)
+    // the batches of `tile` that belong to share `part` of W, compacted into this wave's buffer; returns their number
+    auto load_entries = [&](int64_t tile, int part) -> int {
+        const int nb_all = __builtin_amdgcn_readfirstlane(A.tile_nb[tile]);
         const uint32_t *src = A.ent + (size_t)tile * kMidEntWords;
-        for (int w4 = lane; w4 < nb * (kMidBatchWords / 4); w4 += 64)
-            reinterpret_cast<u32x4 *>(ebuf)[w4] = reinterpret_cast<const u32x4 *>(src)[w4];
+        int cnt = nb_all;
+        if (W == 1) {
+            for (int w4 = lane; w4 < nb_all * (kMidBatchWords / 4); w4 += 64)
+                reinterpret_cast<u32x4 *>(ebuf)[w4] = reinterpret_cast<const u32x4 *>(src)[w4];
+        } else {
+            // lane b looks at batch b's header: its run = the number of `last` flags in front of it
+            const uint32_t h = lane < nb_all ? src[lane * kMidBatchWords] : 0u;
+            const unsigned long long lastm = __ballot((h & 0x100u) != 0u);
+            const int run = __popcll(lastm & ((1ull << lane) - 1ull));
+            const unsigned long long minem = __ballot(lane < nb_all && (run & (W - 1)) == part);
+            cnt = 0;
+            for (unsigned long long m = minem; m; m &= m - 1ull, ++cnt) {
+                const int b = __builtin_ctzll(m);
+                if (lane < kMidBatchWords) ebuf[cnt * kMidBatchWords + lane] = src[b * kMidBatchWords + lane];
+            }
+        }
+        // the empty batches behind the last one: header 0 (no `last` flag), every slot = no source, spare row
+        for (int w = lane; w < 2 * kMidPf * kMidBatchWords; w += 64)
+            ebuf[cnt * kMidBatchWords + w] = (w % kMidBatchWords) < 4 ? 0u : kMidEmptyEntry;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        return cnt;
     };
     auto gin_items = [&](int layer) {
-        if (wave >= kMidGinWaves) return;
         const float *src = layer == 0 ? A.mid : A.a2[(layer - 1) & 1];
         const float *sp = A.pack + (size_t)layer * kSpStride;
-        for (int k = wave; k < kb; k += kMidGinWaves)
+#ifdef TGNN_MID_TIMING
+        const unsigned long long tg0 = wall_clock64();
+#endif
+        for (int k = wave; k < kb; k += kMidWaves)
             mid_gin_tile(A, tile0 + k, layer, src, A.a2[layer & 1], gw, sp, st + 128, tbuf, lane, bn2);
+#ifdef TGNN_MID_TIMING
+        t_gin += wall_clock64() - tg0;
+#endif
     };
 
     // ---- prologue: images of layer 0, the batches of one-tile waves, the zeroed tiles; then GIN_0 (reads slot 0, no statistics)
-    mid_dma(A.wimg, wl, (T + 1) * kWtTypeF16 * 4, wave, lane, 0, 8);
-    mid_dma(A.pack + kSpGinW, gw, kSpGinFrags * 16, wave, lane, 8, 8);
-    for (int i = lane; i < 128; i += 64) reinterpret_cast<f32x4 *>(tbuf)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mid_dma(A.wimg, wl, (T + 1) * kWtTypeF16 * 4, wave, lane);
+    mid_dma(A.pack + kSpGinW, gw, kSpGinFrags * 16, wave, lane);
+    for (int i = lane; i < kMidTileFloats / 4; i += 64) reinterpret_cast<f32x4 *>(tbuf)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     int nb_res = 0;
-    if (ent_resident && wave < kMidNnWaves && wave < kb) {
-        nb_res = __builtin_amdgcn_readfirstlane(A.tile_nb[tile0 + wave]);
-        load_entries(tile0 + wave, nb_res);
-    }
+    if (ent_resident && my_k < kb) nb_res = load_entries(tile0 + my_k, my_part);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     gin_items(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                              // GIN_0 is through with the GIN image
+    if (D > 1) mid_dma(A.pack + (size_t)kSpStride + kSpGinW, gw, kSpGinFrags * 16, wave, lane);
 
     for (int layer = 0; layer < D; ++layer) {
         const float *sp = A.pack + (size_t)layer * kSpStride;
-        __syncthreads();                                          // GIN_layer is through with the GIN image
-        // the GIN image of the next layer (used in this layer's barrier shadow): by the waves that have no NNConv item
-        if (layer + 1 < D) mid_dma(A.pack + (size_t)(layer + 1) * kSpStride + kSpGinW, gw, kSpGinFrags * 16, wave, lane, 8, 8);
+        TGNN_MT(0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the images brought in during the barrier's shadow have landed)
+        __syncthreads();
+        TGNN_MT(1)
         // =========================================== NNConv_layer ===========================================
-        if (wave < kMidNnWaves && wave < kb) {
+        if (my_k < kb) {
             MidNn N;
             N.wl = wl;
             N.tbuf = tbuf;
@@ -450,65 +541,124 @@ __global__ __launch_bounds__(kMidThreads) void forward_layers_mid_kernel(MidArgs
                 N.sx = pow2_scale_for(hmax, A.deg_log2);
                 N.unscale = 1.0f / (N.sx * nnconv_weight_scale(rmax));   // (powers of two: exact)
             }
-            for (int k = wave; k < kb; k += kMidNnWaves) {
-                int nb = nb_res;
-                if (!ent_resident) {
-                    nb = __builtin_amdgcn_readfirstlane(A.tile_nb[tile0 + k]);
-                    load_entries(tile0 + k, nb);
+#ifdef TGNN_MID_TIMING
+            const unsigned long long tn0 = wall_clock64();
+#endif
+            f32x4 d0, d1;
+            if (W == 1) {
+                for (int k = wave; k < kb; k += kMidWaves) {
+                    const int nb = ent_resident ? nb_res : load_entries(tile0 + k, 0);
+                    mid_nnconv_partial(N, A, tile0 + k, nb, true, lane, d0, d1);
+                    mid_nnconv_finish(N, A, tile0 + k, sp + kSpBias, lane, d0, d1, bn1);
                 }
-                mid_nnconv_tile(N, A, tile0 + k, nb, sp + kSpBias, lane, bn1);
+            } else {
+                mid_nnconv_partial(N, A, tile0 + my_k, nb_res, my_part == 0, lane, d0, d1);
+                if (my_part != 0) {                               // a share's partial product waits in its tile for share 0
+                    const int fj = lane & 15, fq = lane >> 4;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    *reinterpret_cast<f32x4 *>(tbuf + mid_chunk(fj, fq)) = d0;
+                    *reinterpret_cast<f32x4 *>(tbuf + mid_chunk(fj, 4 + fq)) = d1;
+                }
             }
+#ifdef TGNN_MID_TIMING
+            t_nn += wall_clock64() - tn0;
+#endif
+            if (W > 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __syncthreads();                                  // (W is the same for every wave of every block)
+                if (my_part == 0) {
+                    const int fj = lane & 15, fq = lane >> 4;
+                    for (int j = 1; j < W; ++j) {                 // shares in order
+                        const float *pt = tiles + (wave + j) * kMidTileFloats;
+                        const f32x4 p0 = *reinterpret_cast<const f32x4 *>(pt + mid_chunk(fj, fq));
+                        const f32x4 p1 = *reinterpret_cast<const f32x4 *>(pt + mid_chunk(fj, 4 + fq));
+                        d0 = d0 + p0;
+                        d1 = d1 + p1;
+                    }
+                    mid_nnconv_finish(N, A, tile0 + my_k, sp + kSpBias, lane, d0, d1, bn1);
+                }
+            }
+        } else if (W > 1) {
+            __syncthreads();                                      // (the shares' hand-over above)
         }
+        TGNN_MT(2)
         // =========================================== [R] BatchNorm sums of the layer ===========================================
         // the wave's sums -> its tile; the block's 128 sums (waves in order) -> tagged partial row
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the a1 / a2 rows of this block are written)
-        reinterpret_cast<double *>(tbuf)[lane] = bn1;
-        reinterpret_cast<double *>(tbuf)[64 + lane] = bn2;
+        bnred[wave * 128 + lane] = bn1;
+        bnred[wave * 128 + 64 + lane] = bn2;
         bn1 = bn2 = 0.0;
         __syncthreads();
+        TGNN_MT(3)
+        // the merge's operands (own rows of a1, a2 and the residual slot; complete: the stores above were waited for) are
+        // requested NOW, so that their round trip runs beside the all-reduce's instead of behind it
+        const __amdgpu_buffer_rsrc_t a1_rs = rsrc_of(A.a1), a2_rs = rsrc_of(A.a2[layer & 1]);
+        const __amdgpu_buffer_rsrc_t r_rs = rsrc_of(A.mid + (size_t)(layer >= 2 ? layer - 2 : 0) * slot);
+        constexpr int kMergeItems = (kMidMaxTilesPerBlock * 128 + kMidThreads - 1) / kMidThreads;   // 4
+        float4 mg1[kMergeItems], mg2[kMergeItems], mgr[kMergeItems];
+        uint32_t mgoff[kMergeItems];
+#pragma unroll
+        for (int j = 0; j < kMergeItems; ++j) {
+            const int idx = tid + j * kMidThreads;
+            const int64_t r = tile0 * 16 + (idx >> 3);
+            mgoff[j] = (idx < kb * 128 && r < n) ? (uint32_t)r * 128u + (uint32_t)(tid & 7) * 16u : kOob;
+            mg1[j] = ld_sc1_f4(a1_rs, mgoff[j]);
+            mg2[j] = ld_sc1_f4(a2_rs, mgoff[j]);
+            mgr[j] = ld_sc1_f4(r_rs, layer >= 2 ? mgoff[j] : kOob);
+        }
         const unsigned tag = 1u + ((unsigned)(layer >> 1) & 1u);
         const size_t par = (size_t)(layer & 1) * nblk;
         const __amdgpu_buffer_rsrc_t p_rs = rsrc_of(A.part + par * 128), g_rs = rsrc_of(A.gpart + par * 128);
-        double blocksum = 0.0;
         if (tid < 128) {
+            double blocksum = 0.0;
 #pragma unroll
-            for (int w = 0; w < kMidWaves; ++w) blocksum += reinterpret_cast<const double *>(tiles + w * 512)[tid];
+            for (int w = 0; w < kMidWaves; ++w) blocksum += bnred[w * 128 + tid];
             __builtin_amdgcn_raw_buffer_store_b64(mid_tag(blocksum, tag), p_rs, (blk * 128u + (uint32_t)tid) * 8u, 0, kCpSc1);
         }
-        __syncthreads();                                          // (the tiles are free: the fold arrays alias them)
-        // the NNConv image of the next layer: the last waves bring it in while the sums travel (everybody is through with this one)
-        if (layer + 1 < D) mid_dma(A.wimg + (size_t)(layer + 1) * (T + 1) * kWtTypeF16, wl, (T + 1) * kWtTypeF16 * 4, wave, lane, 12, 4);
+        __syncthreads();                                          // (the tiles are free: the fold array aliases them)
         {
+            // thread = (pair of doubles jp, rows r and r + 8): two polls in flight
             const int jp = tid & 63, r = tid >> 6;
             // level 1: the 16 blocks of this block's group, rows in order
             const unsigned gbase = blk & ~15u;
-            double x0, x1;
+            double x0, x1, y0, y1;
             mid_poll_pair(p_rs, gbase + r < nblk ? (int64_t)(gbase + r) : -1, jp, tag, x0, x1, spin);
-            red1[r * 128 + 2 * jp] = x0;
-            red1[r * 128 + 2 * jp + 1] = x1;
+            mid_poll_pair(p_rs, gbase + r + 8 < nblk ? (int64_t)(gbase + r + 8) : -1, jp, tag, y0, y1, spin);
+            red[r * 128 + 2 * jp] = x0;
+            red[r * 128 + 2 * jp + 1] = x1;
+            red[(r + 8) * 128 + 2 * jp] = y0;
+            red[(r + 8) * 128 + 2 * jp + 1] = y1;
             __syncthreads();
+            TGNN_MT(4)
             if (tid < 128) {
                 double s = 0.0;
 #pragma unroll
-                for (int rr = 0; rr < 16; ++rr) s += red1[rr * 128 + tid];
+                for (int rr = 0; rr < 16; ++rr) s += red[rr * 128 + tid];
                 __builtin_amdgcn_raw_buffer_store_b64(mid_tag(s, tag), g_rs, (blk * 128u + (uint32_t)tid) * 8u, 0, kCpSc1);
             }
             // level 2: one copy of every group's sum (all copies carry the same bits), groups in order
             const unsigned n_groups = (nblk + 15u) >> 4;
-            int64_t grow = -1;
-            if ((unsigned)r < n_groups) {
-                const unsigned gsize = nblk - 16u * (unsigned)r < 16u ? nblk - 16u * (unsigned)r : 16u;
+            auto group_row = [&](unsigned g) -> int64_t {
+                if (g >= n_groups) return -1;
+                const unsigned gsize = nblk - 16u * g < 16u ? nblk - 16u * g : 16u;
                 const unsigned member = (blk & 15u) < gsize ? (blk & 15u) : gsize - 1u;
-                grow = (int64_t)(16u * (unsigned)r + member);
-            }
-            mid_poll_pair(g_rs, grow, jp, tag, x0, x1, spin);
-            red2[r * 128 + 2 * jp] = x0;
-            red2[r * 128 + 2 * jp + 1] = x1;
+                return (int64_t)(16u * g + member);
+            };
+            mid_poll_pair(g_rs, group_row((unsigned)r), jp, tag, x0, x1, spin);
+            mid_poll_pair(g_rs, group_row((unsigned)r + 8u), jp, tag, y0, y1, spin);
+            __syncthreads();                                      // (level 1's sums have been read)
+            red[r * 128 + 2 * jp] = x0;
+            red[r * 128 + 2 * jp + 1] = x1;
+            red[(r + 8) * 128 + 2 * jp] = y0;
+            red[(r + 8) * 128 + 2 * jp + 1] = y1;
             __syncthreads();
+            TGNN_MT(5)
             if (tid < 128) {
                 double s = 0.0;
 #pragma unroll
-                for (int rr = 0; rr < 16; ++rr) s += red2[rr * 128 + tid];
+                for (int rr = 0; rr < 16; ++rr) s += red[rr * 128 + tid];
                 tot[tid] = s;
             }
             __syncthreads();
@@ -533,31 +683,28 @@ __global__ __launch_bounds__(kMidThreads) void forward_layers_mid_kernel(MidArgs
             }
             __syncthreads();
         }
+        TGNN_MT(6)
         // =========================================== merge (TilinGNN.py:64-71) ===========================================
         // slot layer + 1 = BN1(a1) * BN2(a2) (+ slot layer - 2), own rows; the slot's largest magnitude for the next NNConv's scale
         {
-            const __amdgpu_buffer_rsrc_t a1_rs = rsrc_of(A.a1), a2_rs = rsrc_of(A.a2[layer & 1]);
             const __amdgpu_buffer_rsrc_t o_rs = rsrc_of(A.mid + (size_t)(layer + 1) * slot);
-            const __amdgpu_buffer_rsrc_t r_rs = rsrc_of(A.mid + (size_t)(layer >= 2 ? layer - 2 : 0) * slot);
             const int c4 = (tid & 7) * 4;
             const float4 m1h = *reinterpret_cast<const float4 *>(st + c4), m1l = *reinterpret_cast<const float4 *>(st + 32 + c4);
             const float4 g1 = *reinterpret_cast<const float4 *>(st + 64 + c4), b1 = *reinterpret_cast<const float4 *>(st + 96 + c4);
             const float4 m2h = *reinterpret_cast<const float4 *>(st + 128 + c4), m2l = *reinterpret_cast<const float4 *>(st + 160 + c4);
             const float4 g2 = *reinterpret_cast<const float4 *>(st + 192 + c4), b2 = *reinterpret_cast<const float4 *>(st + 224 + c4);
             float mx = 0.f;
-            for (int idx = tid; idx < kb * 128; idx += kMidThreads) {
-                const int64_t r = tile0 * 16 + (idx >> 3);
-                const uint32_t off = r < n ? (uint32_t)r * 128u + (uint32_t)c4 * 4u : kOob;
-                const float4 x1 = ld_sc1_f4(a1_rs, off), x2 = ld_sc1_f4(a2_rs, off);
-                const float4 rs4 = ld_sc1_f4(r_rs, layer >= 2 ? off : kOob);
+#pragma unroll
+            for (int j = 0; j < kMergeItems; ++j) {
+                const float4 x1 = mg1[j], x2 = mg2[j], rs4 = mgr[j];
                 float4 o;
                 o.x = bn_apply1(x1.x, m1h.x, m1l.x, g1.x, b1.x) * bn_apply1(x2.x, m2h.x, m2l.x, g2.x, b2.x) + rs4.x;
                 o.y = bn_apply1(x1.y, m1h.y, m1l.y, g1.y, b1.y) * bn_apply1(x2.y, m2h.y, m2l.y, g2.y, b2.y) + rs4.y;
                 o.z = bn_apply1(x1.z, m1h.z, m1l.z, g1.z, b1.z) * bn_apply1(x2.z, m2h.z, m2l.z, g2.z, b2.z) + rs4.z;
                 o.w = bn_apply1(x1.w, m1h.w, m1l.w, g1.w, b1.w) * bn_apply1(x2.w, m2h.w, m2l.w, g2.w, b2.w) + rs4.w;
-                if (off != kOob) {
+                if (mgoff[j] != kOob) {
                     mx = absmax4(mx, o);
-                    st_sc1_f4(o_rs, off, o);
+                    st_sc1_f4(o_rs, mgoff[j], o);
                 }
             }
 #pragma unroll
@@ -565,10 +712,12 @@ __global__ __launch_bounds__(kMidThreads) void forward_layers_mid_kernel(MidArgs
             if (lane == 0) scr[wave] = mx;
         }
         // =========================================== [B] arrive; GIN_{layer + 1} in the shadow; wait ===========================================
+        TGNN_MT(7)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
+        TGNN_MT(8)
         b_target += nblk;
-        if (tid == 0) {
+        if (tid == kMidThreads - 64) {                            // (the last wave: it is the one least likely to hold a GIN item)
             float m = scr[0];
 #pragma unroll
             for (int w = 1; w < kMidWaves; ++w) m = fmaxf(m, scr[w]);
@@ -577,12 +726,31 @@ __global__ __launch_bounds__(kMidThreads) void forward_layers_mid_kernel(MidArgs
             __hip_atomic_fetch_add(A.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (layer + 1 < D) {
-            for (int i = lane; i < 128; i += 64) reinterpret_cast<f32x4 *>(tbuf)[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // (the fold left doubles there)
+            // in the barrier's shadow: the collision branch of the next layer, then the images the next phases need (the next
+            // layer's NNConv image -- everybody is through with this one -- and its successor's GIN image)
+            for (int i = lane; i < kMidTileFloats / 4; i += 64) reinterpret_cast<f32x4 *>(tbuf)[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // (the fold left doubles there)
+            TGNN_MT(9)
             gin_items(layer + 1);
-            if (tid == 0) spin_until_ge(A.ctr, b_target, spin, kSpinErrBarrier);
+            TGNN_MT(10)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();                                      // GIN_{layer + 1} is through with the GIN image
+            mid_dma(A.wimg + (size_t)(layer + 1) * (T + 1) * kWtTypeF16, wl, (T + 1) * kWtTypeF16 * 4, wave, lane);
+            if (layer + 2 < D) mid_dma(A.pack + (size_t)(layer + 2) * kSpStride + kSpGinW, gw, kSpGinFrags * 16, wave, lane);
+            if (tid == kMidThreads - 64) spin_until_ge(A.ctr, b_target, spin, kSpinErrBarrier);
+            TGNN_MT(11)
         }
     }
     // (no barrier behind the last merge: the final MLP is the next launch)
+#ifdef TGNN_MID_TIMING
+    if (blockIdx.x < 256) {
+        if (tid == 0)
+            for (int k = 0; k < 16; ++k) g_mid_timing[blockIdx.x * 64 + k] = tacc[k];
+        if (lane == 0) {
+            g_mid_timing[blockIdx.x * 64 + 16 + wave] = t_nn;
+            g_mid_timing[blockIdx.x * 64 + 32 + wave] = t_gin;
+        }
+    }
+#endif
 
     if (blockIdx.x == 0 && A.update_running && __hip_atomic_load(A.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
         // running statistics of the 2 x depth BatchNorms of the layers (momentum update, num_batches_tracked); not after a
@@ -601,12 +769,15 @@ __global__ __launch_bounds__(kMidThreads) void forward_layers_mid_kernel(MidArgs
 }
 
 static size_t mid_lds_bytes(int n_types) {
-    return ((size_t)(n_types + 1) * kWtTypeF16 + (size_t)kSpGinFrags * 4 + (size_t)kMidWaves * 512 + (size_t)kMidNnWaves * kMidEntWords + 256 +
-            256 + 32) * sizeof(float);
+    return ((size_t)(n_types + 1) * kWtTypeF16 + (size_t)kSpGinFrags * 4 + (size_t)kMidWaves * kMidTileFloats + (size_t)kMidWaves * kMidEntLds + 256 +
+            256 + 32 + (size_t)kMidWaves * 256) * sizeof(float);
 }
 constexpr size_t kMidMaxLds = 160 * 1024 - 256;
 
-static std::atomic<int64_t> g_mid_limit{65536};
+// default: up to 8 tiles per block on a 256-CU device (the waves of a block then hold one tile each); beyond that the kernel still
+// runs (tiles in rounds, tgnn_set_mid_layout_limit up to 65 536) but the general schedule is faster (measured: 40 000 nodes 1.13 vs
+// 1.05 ms, 50 000: 1.28 vs 1.20; 32 000: 0.82 vs 0.97, 10 000: 0.61 vs 0.77)
+static std::atomic<int64_t> g_mid_limit{32768};
 static std::atomic<int> g_mid_blocks_cap{0};                      // experiments: upper bound of the grid (0 = one block per CU)
 
 // > 0: tiles per block of the persistent layer loop for this layout; 0: not eligible (the general schedule runs)
@@ -623,9 +794,9 @@ int mid_layout_tiles_per_block(const tgnn_model_dims *d, const tgnn_graph *g, in
     if (cap == 0) {
         static LdsOptIn site;
         int per_cu = 0;
-        if (opt_in_dynamic_lds(forward_layers_mid_kernel, (int)kMidMaxLds, site) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, forward_layers_mid_kernel, kMidThreads, kMidMaxLds) != hipSuccess)
-            return 0;
+        const hipError_t e1 = opt_in_dynamic_lds(forward_layers_mid_kernel, (int)kMidMaxLds, site);
+        const hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, forward_layers_mid_kernel, kMidThreads, kMidMaxLds);
+        if (e1 != hipSuccess || e2 != hipSuccess) return 0;
         cap = per_cu > 0 ? device_cus() : -1;                     // one 16-wave block with the whole LDS per CU
         capacity[dev].store(cap, std::memory_order_release);
     }
@@ -633,7 +804,14 @@ int mid_layout_tiles_per_block(const tgnn_model_dims *d, const tgnn_graph *g, in
     int max_blocks = cap;
     if (const int dbg = g_mid_blocks_cap.load(std::memory_order_relaxed); dbg > 0 && dbg < max_blocks) max_blocks = dbg;
     const int64_t n_tiles = (n_nodes + 15) / 16;
-    const int64_t k = (n_tiles + max_blocks - 1) / max_blocks;
+    int64_t k = (n_tiles + max_blocks - 1) / max_blocks;
+    // a power of two up to 8 tiles per block: the waves of a block then share its tiles evenly (8 / k waves per tile), and fewer
+    // blocks make the all-reduce and the barrier cheaper; beyond 8 the waves take their tiles in rounds
+    for (int64_t p2 = 1; p2 <= 8; p2 *= 2)
+        if (k <= p2) {
+            k = p2;
+            break;
+        }
     if (k > kMidMaxTilesPerBlock) return 0;
     *blocks_out = (int)((n_tiles + k - 1) / k);
     return (int)k;
@@ -674,6 +852,7 @@ int launch_forward_mid(const tgnn_model_dims *d, const Params &P, float *mid, fl
     A.depth = depth;
     A.update_running = update_running;
     A.tiles_per_block = tiles_per_block;
+    A.nn_split = tiles_per_block <= 1 ? 8 : tiles_per_block <= 2 ? 4 : tiles_per_block <= 4 ? 2 : 1;
     int deg_log2 = 0;
     while ((1 << deg_log2) < graph->nn_max_in_degree) ++deg_log2;
     A.deg_log2 = deg_log2;
@@ -687,9 +866,8 @@ int launch_forward_mid(const tgnn_model_dims *d, const Params &P, float *mid, fl
     TGNN_CHECK_ARG(blocks >= 1 && blocks <= 256, "blocks of the persistent layer loop");
     static LdsOptIn site;
     TGNN_CHECK_HIP(opt_in_dynamic_lds(forward_layers_mid_kernel, (int)kMidMaxLds, site));
-    // the tagged rows of both parities carry no valid tag before the launch (tag 0 is never used)
-    TGNN_CHECK_HIP(hipMemsetAsync(part, 0, mid_part_doubles() * sizeof(double), s));
-    TGNN_CHECK_HIP(hipMemsetAsync(ctr, 0, sizeof(unsigned), s));
+    // (the tagged rows of both parities carry no valid tag -- tag 0 is never used -- and the counter is zero: launch_small_pack,
+    //  queued on this stream in front of the init MLP, cleared them)
     struct Ctx { MidArgs *A; SmallRunTab *R; int blocks; size_t lds; } ctx{&A, &R, blocks, mid_lds_bytes(graph->n_types)};
     const int rc = spin_kernel_chain(s, [](void *c, hipStream_t st) {
         Ctx *x = static_cast<Ctx *>(c);
@@ -702,99 +880,112 @@ int launch_forward_mid(const tgnn_model_dims *d, const Params &P, float *mid, fl
 
 // ------------------------------------------------------------------------------------------------------------------------------------
 // The NNConv batches of the mid-size kernel, from the type-column structure (graph_prep.hip: column (t, r) = the r-th in-edge of
-// type t of each of the tile's 16 rows).  Per tile and type run: the run's entries -- column by column, i.e. a row's edges in CSR
-// order -- packed 8 to a gather instruction, 4 instructions to a batch, never two entries of one row in one instruction (a row's
-// second edge of a type is a read-add-write of the slot its first edge stored); a run of more than 32 entries continues in
-// further batches, the last one carries the `last` flag and the mask of rows that have an edge of the type.
+// type t of each of the tile's 16 rows, i.e. a column holds at most one edge per row and a row's edges of a type sit in
+// consecutive columns in CSR order).  Per tile and type run the columns are laid one behind the other into gather
+// instructions of 8 entries; a column starts a NEW instruction when one of its rows already has an entry in the one being
+// filled: no instruction then holds two entries of a row, and a row's r-th edge of the type comes in a later instruction than
+// its (r - 1)-th -- it read-add-writes the type-sum slot the first one stored.  4 instructions make a batch; a run of more than 32 slots continues in further batches, the last one carries the
+// `last` flag and the mask of rows that have an edge of the type (= the rows of the run's first column).
 //   batch = [type | last << 8, row mask, 0, 0 | 32 entry words: slot o (0..7) of instruction g (0..3) at 4 + 4 o + g]
-//   entry = source row | destination row << 20 | add << 24 | valid << 31
-// One block of one wave per tile: the columns come in coalesced, thread 0 packs in LDS, the batches go out coalesced.
+//   entry = source row (24 bits; 0x1000000: none) | destination row << 25 (16: none) | add << 30
+// One wave packs FOUR tiles, 16 lanes (= the 16 rows) each: a column is one ballot + one prefix count.
 // ------------------------------------------------------------------------------------------------------------------------------------
-constexpr int kMidBuildMaxCols = 128;
+constexpr int kMidBuildMaxCols = 64;
 
 __global__ __launch_bounds__(64) void mid_entries_kernel(const int *__restrict__ tile_col_ptr, const int *__restrict__ col_meta,
                                                          const int *__restrict__ col_src, int64_t n_tiles,
                                                          const int *__restrict__ cols_built, int *__restrict__ tile_nb,
                                                          uint32_t *__restrict__ ent, int *__restrict__ result) {
-    __shared__ int s_src[kMidBuildMaxCols * 16];
-    __shared__ int s_meta[kMidBuildMaxCols];
-    __shared__ uint32_t s_out[kMidEntWords];
-    __shared__ int s_nb;
-    const int tid = threadIdx.x;
-    const int64_t tile = blockIdx.x;
-    if (tile >= n_tiles) return;
+    __shared__ int s_src[4][kMidBuildMaxCols * 16];
+    __shared__ int s_meta[4][kMidBuildMaxCols];
+    __shared__ uint32_t s_out[4][kMidEntWords];
+    const int tid = threadIdx.x, q = tid >> 4, i = tid & 15;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + q;
+    const bool live = tile < n_tiles;
     if (cols_built && *cols_built == 0) {                         // no column structure (too many edge types): nothing to pack
-        if (tid == 0) {
-            tile_nb[tile] = 0;
-            if (tile == 0) result[1] = 1;
-        }
+        if (live && i == 0) tile_nb[tile] = 0;
+        if (tid == 0 && blockIdx.x == 0) result[1] = 1;
         return;
     }
-    const int c0 = tile_col_ptr[tile], c1 = tile_col_ptr[tile + 1];
-    const int nc = c1 - c0 - 1;                                   // edge columns (the last column of a tile is the root column)
-    if (nc > kMidBuildMaxCols) {
-        if (tid == 0) {
-            tile_nb[tile] = 0;
-            result[1] = 1;                                        // overflow: the layout is not for this kernel
-        }
-        return;
+    int c0 = 0, nc = 0;
+    if (live) {
+        c0 = tile_col_ptr[tile];
+        nc = tile_col_ptr[tile + 1] - c0 - 1;                     // edge columns (the last column of a tile is the root column)
     }
-    for (int i = tid; i < nc * 16; i += 64) s_src[i] = col_src[(int64_t)c0 * 16 + i];
-    for (int i = tid; i < nc; i += 64) s_meta[i] = col_meta[c0 + i];
-    for (int i = tid; i < kMidEntWords; i += 64) s_out[i] = 0u;
+    bool over = nc > kMidBuildMaxCols;
+    if (over) nc = 0;
+    for (int w = i; w < nc * 16; w += 16) s_src[q][w] = col_src[(int64_t)c0 * 16 + w];
+    for (int w = i; w < nc; w += 16) s_meta[q][w] = col_meta[c0 + w];
+    for (int w = i; w < kMidEntWords; w += 16) s_out[q][w] = (w % kMidBatchWords) < 4 ? 0u : kMidEmptyEntry;
     __syncthreads();
-    if (tid == 0) {
-        int nb = 0, pos = 0, type = -1;
-        unsigned mask = 0;
-        int rowgrp[16];
-        bool open = false, overflow = false;
-        auto close = [&](bool last) {
-            if (nb < kMidTileBatches) {
-                s_out[nb * kMidBatchWords] = (unsigned)type | (last ? 0x100u : 0u);
-                s_out[nb * kMidBatchWords + 1] = mask;
-            } else {
-                overflow = true;
-            }
-            ++nb;
-            pos = 0;
-            for (int i = 0; i < 16; ++i) rowgrp[i] = -1;
-        };
-        for (int i = 0; i < 16; ++i) rowgrp[i] = -1;
-        for (int k = 0; k < nc; ++k) {
-            const int m = s_meta[k];
-            if (m & kMidColFirst) {
-                if (open) close(true);
-                type = m & 0xff;
-                mask = 0;
-                open = true;
-            }
-            const bool add = !(m & kMidColFirst);
-            for (int i = 0; i < 16; ++i) {
-                const int sv = s_src[k * 16 + i];
-                if (sv < 0) continue;
-                if (rowgrp[i] == (pos >> 3)) pos = ((pos >> 3) + 1) * 8;      // this row already has an entry in the instruction
-                if (pos >= 32) close(false);
-                if (nb < kMidTileBatches)
-                    s_out[nb * kMidBatchWords + 4 + 4 * (pos & 7) + (pos >> 3)] =
-                        ((unsigned)sv & 0xfffffu) | ((unsigned)i << 20) | (add ? 1u << 24 : 0u) | 0x80000000u;
-                rowgrp[i] = pos >> 3;
-                ++pos;
-                mask |= 1u << i;
-            }
+    int ncmax = nc;
+#pragma unroll
+    for (int d = 32; d >= 16; d >>= 1) ncmax = max(ncmax, __shfl_xor(ncmax, d, 64));
+    // state of this quarter's tile (the same in its 16 lanes): batches closed so far, slots used / type / rows of the open run,
+    // rows that already have an entry in the gather instruction being filled
+    int nb = 0, rpos = 0, type = 0;
+    unsigned runmask = 0, gmask = 0;
+    bool open = false;
+    auto close_run = [&]() {
+        const int nbr = rpos > 0 ? (rpos + 31) >> 5 : 1;
+        if (i == 0)
+            for (int b = 0; b < nbr; ++b)
+                if (nb + b < kMidTileBatches) {
+                    s_out[q][(nb + b) * kMidBatchWords] = (unsigned)type | (b == nbr - 1 ? 0x100u : 0u);
+                    s_out[q][(nb + b) * kMidBatchWords + 1] = runmask;
+                }
+        nb += nbr;
+        rpos = 0;
+        gmask = 0;
+    };
+    for (int k = 0; k < ncmax; ++k) {
+        const bool act = k < nc;
+        const int sv = act ? s_src[q][k * 16 + i] : -1;
+        const bool valid = sv >= 0;
+        const unsigned bal = (unsigned)(__ballot(valid) >> (16 * q)) & 0xffffu;
+        const int m = act ? s_meta[q][k] : 0;
+        const bool first = (m & kMidColFirst) != 0;
+        if (first) {
+            if (open) close_run();
+            type = m & 0xff;
+            runmask = bal;
+            open = true;
         }
-        if (open) close(true);
-        if (overflow) {
-            nb = 0;
-            result[1] = 1;
+        // a column joins the instruction being filled when none of its rows is in it yet and it fits; else it starts a new one (a
+        // column of more than 8 entries runs on into the next instruction: its rows are all different)
+        const int cnt = __popc(bal), fill = rpos & 7;
+        if (fill != 0 && ((gmask & bal) != 0u || fill + cnt > 8)) {
+            rpos = (rpos + 7) & ~7;
+            gmask = 0;
         }
-        if (nb > result[0]) atomicMax(result, nb);
-        s_nb = nb;
-        tile_nb[tile] = nb;
+        const int p = rpos + __popc(bal & ((1u << i) - 1u));
+        if (valid) {
+            const int b = nb + (p >> 5), pp = p & 31;
+            if (b < kMidTileBatches)
+                s_out[q][b * kMidBatchWords + 4 + 4 * (pp & 7) + (pp >> 3)] =
+                    ((unsigned)sv & 0xffffffu) | ((unsigned)i << 25) | (first ? 0u : 1u << 30);
+        }
+        const int end = rpos + cnt, lastg = (end - 1) >> 3;
+        const unsigned in_last = (unsigned)(__ballot(valid && (p >> 3) == lastg) >> (16 * q)) & 0xffffu;
+        if (cnt > 0) {
+            gmask = (rpos >> 3) == lastg ? (gmask | in_last) : in_last;
+            if ((end & 7) == 0) gmask = 0;
+            rpos = end;
+        }
     }
+    if (open) close_run();
+    if (nb > kMidTileBatches) over = true;
+    if (over) nb = 0;
     __syncthreads();
-    const int words = s_nb * kMidBatchWords;
-    uint32_t *dst = ent + (size_t)tile * kMidEntWords;
-    for (int i = tid; i < words; i += 64) dst[i] = s_out[i];
+    if (live) {
+        if (i == 0) {
+            tile_nb[tile] = nb;
+            if (over) result[1] = 1;                              // the layout is not for this kernel
+            else if (nb > result[0]) atomicMax(result, nb);
+        }
+        uint32_t *dst = ent + (size_t)tile * kMidEntWords;
+        for (int w = i; w < nb * kMidBatchWords; w += 16) dst[w] = s_out[q][w];
+    }
 }
 
 }  // namespace tgnn
@@ -810,12 +1001,17 @@ extern "C" int tgnn_mid_entries_build(const int32_t *tile_col_ptr, const int32_t
     TGNN_CHECK_ARG(n_nodes >= 1 && n_nodes < (1 << 20), "n_nodes (source rows are 20-bit)");
     TGNN_CHECK_ARG(tile_col_ptr && col_meta && col_src && tile_nb && ent && result, "null pointer");
     const int64_t n_tiles = (n_nodes + 15) / 16;
-    mid_entries_kernel<<<(unsigned)n_tiles, 64, 0, static_cast<hipStream_t>(stream)>>>(tile_col_ptr, col_meta, col_src, n_tiles,
-                                                                                       cols_built_dev, tile_nb, ent, result);
+    mid_entries_kernel<<<(unsigned)((n_tiles + 3) / 4), 64, 0, static_cast<hipStream_t>(stream)>>>(tile_col_ptr, col_meta, col_src, n_tiles,
+                                                                                                   cols_built_dev, tile_nb, ent, result);
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
 }
 
+#ifdef TGNN_MID_TIMING
+extern "C" int tgnn_debug_mid_timing(unsigned long long *out, int n_blocks) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tgnn::g_mid_timing), (size_t)n_blocks * 64 * sizeof(unsigned long long));
+}
+#endif
 extern "C" void tgnn_set_mid_layout_limit(int64_t n_nodes) { g_mid_limit.store(n_nodes < 0 ? 0 : n_nodes); }
 extern "C" int64_t tgnn_get_mid_layout_limit(void) { return g_mid_limit.load(); }
 extern "C" int64_t tgnn_mid_layout_max_nodes(void) { return 65536; }

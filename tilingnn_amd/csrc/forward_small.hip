@@ -56,8 +56,12 @@ struct SmallImageJobs {
 // The per-forward pre-pass of the persistent kernel, one launch: blockIdx.y < n_layers: the parameter pack of that layer
 // (block x = 0; it also re-arms the barrier counter); above: the MFMA image of one dense layer, one thread per (mb, ks, lane)
 __global__ __launch_bounds__(256) void small_pack_kernel(SmallPackLayers layers, int n_layers, float *__restrict__ pack,
-                                                         unsigned *__restrict__ barrier_ctr, SmallImageJobs jobs) {
+                                                         unsigned *__restrict__ barrier_ctr, SmallImageJobs jobs,
+                                                         u32x4 *__restrict__ zero, int64_t zero_n) {
     const int tid = threadIdx.x;
+    // (the mid-size kernel's tagged partial rows must carry no valid tag before its launch: the layers' blocks clear them)
+    if (zero && (int)blockIdx.y < n_layers && blockIdx.x == 0)
+        for (int64_t i = (int64_t)blockIdx.y * 256 + tid; i < zero_n; i += (int64_t)n_layers * 256) zero[i] = u32x4{0u, 0u, 0u, 0u};
     if ((int)blockIdx.y >= n_layers) {
         const SmallImageJob J = jobs.j[blockIdx.y - n_layers];
         const int ksteps = J.k / 32, items = (J.m / 16) * ksteps * 64;
@@ -1083,7 +1087,8 @@ size_t small_pack_floats(int depth) {
 
 // Per-forward pre-pass (side stream): parameter packs + GIN images of the layers, MFMA images of the dense layers; re-arms
 // the barrier counter
-void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrier_ctr, hipStream_t s, bool dense_images) {
+void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrier_ctr, hipStream_t s, bool dense_images, void *zero,
+                       size_t zero_bytes) {
     size_t off[5];
     small_image_floats(depth, off);
     float *img = pack + (size_t)depth * kSpStride;
@@ -1103,7 +1108,8 @@ void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrie
         }
         const bool first = lo == 0 && dense_images;             // the dense images ride along with the first chunk
         small_pack_kernel<<<dim3(first ? 64 : 1, nl + (first ? 5 : 0)), 256, 0, s>>>(L, nl, pack + (size_t)lo * kSpStride,
-                                                                                     lo == 0 ? barrier_ctr : nullptr, J);
+                                                                                     lo == 0 ? barrier_ctr : nullptr, J,
+                                                                                     lo == 0 ? static_cast<u32x4 *>(zero) : nullptr, (int64_t)(zero_bytes / 16));
     }
 }
 

@@ -398,7 +398,9 @@ int spin_kernel_chain(hipStream_t s, void (*launch)(void *ctx, hipStream_t s), v
 // 0 = not eligible (too large, too many edge types for LDS, ...); the packs / images are built per forward.
 int small_layout_teams(const tgnn_model_dims *d, int64_t n_nodes, int n_types, int max_in_degree);
 size_t small_pack_floats(int depth);
-void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrier_ctr, hipStream_t s, bool dense_images = true);
+// zero / zero_bytes (a multiple of 16): memory the same launch clears (the mid-size kernel's tagged partial rows)
+void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrier_ctr, hipStream_t s, bool dense_images = true,
+                       void *zero = nullptr, size_t zero_bytes = 0);
 int launch_forward_small(const tgnn_model_dims *d, const Params &P, const float *x, float *probs, float *mid, float *a2_0,
                          float *a2_1, const float *wimg, float *pack, const tgnn_graph *graph, double *part, double *part_wide,
                          double *runstat, unsigned *ctr, const unsigned *weights_done, unsigned weights_target, int64_t n,

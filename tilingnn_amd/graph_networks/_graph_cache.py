@@ -45,7 +45,8 @@ def clear():
 
 def get_full(n_nodes, adj_e_index, adj_e_features, col_e_idx):
     ts = (adj_e_index, adj_e_features, col_e_idx)
-    return _lookup(("full", n_nodes) + _key(*ts), ts,
+    # (what a prepared graph carries depends on the size range of the mid-size persistent kernel: part of the key)
+    return _lookup(("full", n_nodes, ops.mid_layout_range()) + _key(*ts), ts,
                    lambda: ops.prepare_graph(n_nodes, adj_e_index, adj_e_features, col_e_idx))
 
 

@@ -97,7 +97,7 @@ class NNConvBatches:
     """Per 16-row tile its in-edges packed by edge type for the mid-size persistent layer loop (tgnn_mid_entries_build,
     include/tgnn.h; csrc/forward_mid.hip)."""
     tile_nb: Tensor           # int32 [ceil(N/16)]
-    ent: Tensor               # int32 (uint32 bits) [ceil(N/16) * 18 * 36]
+    ent: Tensor               # int32 (uint32 bits) [ceil(N/16) * 24 * 36]
 
 
 def mid_layout_range() -> Tuple[int, int]:
