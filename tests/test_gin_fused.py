@@ -1,0 +1,92 @@
+"""GINConv's neighbourhood sum and MLP as ONE kernel on the general schedule's inference forward (csrc/gin.hip:
+gin32_fused_kernel; /root/reference/graph_networks/layers/coll_conv.py:24-27) against the two-kernel form it replaces: the same
+arithmetic in the same order -- the CollConv rows must agree bit for bit; only the BatchNorm sums are associated differently."""
+import contextlib
+import ctypes as C
+
+import pytest
+import torch
+
+from oracle import tilingnn_oracle as orc
+from tests.test_hip_parity import make_net
+from tests.test_mid_layout import _layout
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+@contextlib.contextmanager
+def gin_fused(on):
+    from tilingnn_amd import _lib
+    before = _lib.lib.tgnn_set_gin_fused(int(on))
+    try:
+        yield
+    finally:
+        _lib.lib.tgnn_set_gin_fused(before)
+
+
+def _run(net, inputs, n, dev):
+    """-> (probs, slots, a2 of the LAST layer's parity-0 / parity-1 buffers): the workspace's first carves (csrc/forward.hip)."""
+    from tilingnn_amd import _lib, ops
+    x, adj, attr, col = inputs
+    graph = ops.prepare_graph(n, adj, attr, col)
+    dims = net._dims()
+    table, _ = net._param_table()
+    ws_bytes = _lib.lib.tgnn_forward_workspace_bytes(C.byref(dims), n, graph.n_types)
+    ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
+    probs = torch.empty(n, 1, device=dev)
+    g = graph.c_struct()
+    _lib.check(_lib.lib.tgnn_forward(C.byref(dims), table, ops.ptr(x), ops.ptr(attr), C.byref(g), 0, 0, ops.ptr(probs), ops.ptr(ws), ws_bytes,
+                                    _lib.current_stream(dev), _lib.side_stream(dev)))
+    torch.cuda.synchronize()
+    f = ws.view(torch.float32)
+    d = net.network_depth
+    al = lambda k: (k + 63) // 64 * 64
+    o = al((d + 1) * n * 32)
+    o = al(o + n * 32)                                          # a1
+    a2 = [f[o:o + n * 32].view(n, 32).clone().cpu(), f[al(o + n * 32):al(o + n * 32) + n * 32].view(n, 32).clone().cpu()]
+    slots = f[:(d + 1) * n * 32].view(d + 1, n, 32).clone().cpu()
+    return probs.cpu(), slots, a2
+
+
+@pytest.mark.parametrize("n", [6000, 33000, 100000])
+def test_fused_gin_rows_equal_the_two_kernel_form(dev, n, general_schedule):
+    inputs, inputs64 = _layout(n, dev, seed=3)
+    net, sd = make_net(dev, depth=2)
+    with gin_fused(False):
+        p0, s0, a0 = _run(net, inputs, n, dev)
+    with gin_fused(True):
+        p1, s1, a1 = _run(net, inputs, n, dev)
+    assert torch.equal(a0[0], a1[0])                            # CollConv_0 (reads slot 0, no folded BatchNorm): bit for bit
+    # CollConv_1 folds BatchNorm_0's record in: the record's sums are associated differently (fp64), so rounding level only
+    assert orc.rel_max_err(a1[1], a0[1].double()) < 1e-5
+    assert orc.rel_max_err(s1[2], s0[2].double()) < 1e-4
+    cap = {}
+    with torch.no_grad():
+        want = orc.tilingnn_forward(orc.cast_sd(sd, torch.float64), *inputs64, capture=cap)[0]
+    for k in (1, 2):
+        assert orc.rel_max_err(s1[k], cap[f"mid.{k}"]) < 2e-5 * 4 ** (k - 1)
+    assert float((p1.double() - want).abs().max()) < 4e-4
+
+
+def test_fused_gin_forward_is_bit_reproducible_and_keeps_the_running_statistics(dev, general_schedule):
+    n = 20000
+    inputs, _ = _layout(n, dev, seed=4)
+    sds = []
+    for on in (False, True):
+        net, _ = make_net(dev, depth=4)
+        with gin_fused(on):
+            outs = [net(*inputs)[0].clone() for _ in range(4)]
+        torch.cuda.synchronize()
+        assert all(torch.equal(outs[0], o) for o in outs[1:])
+        sds.append({k: v.detach().cpu().double() for k, v in net.state_dict().items()})
+    for k in sds[0]:
+        if "running" in k:
+            assert orc.rel_max_err(sds[1][k], sds[0][k]) < 1e-4, k
+        elif k.endswith("num_batches_tracked"):
+            assert int(sds[0][k]) == int(sds[1][k]) == 4, k

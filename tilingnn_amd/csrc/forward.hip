@@ -493,7 +493,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
             prof.begin(3);
             const int rc = gin32_fwd_folded(gin_in, c, gin_stat, graph->col_rowptr, graph->col_src, P.f(b + 13), P.f(b + 14), P.f(b + 15),
                                             P.f(b + 16), P.f(b + 17), P.f(b + 18), P.f(b + 19), n, TGNN_ACT_LEAKY_RELU, w.a2[i & 1],
-                                            w.t0, w.part2, &np2, fin, gs);
+                                            w.t0, w.part2, &np2, fin, gs, keep != nullptr);
             prof.end();
             if (rc != TGNN_ERR_UNSUPPORTED) return rc;
             return TGNN_ERR_UNSUPPORTED;                       // (the workspace is aligned: cannot happen)

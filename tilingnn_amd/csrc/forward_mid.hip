@@ -51,7 +51,6 @@ constexpr int kMidPf = 4;                                          // gather bat
 constexpr int kMidEntLds = kMidEntWords + 2 * kMidPf * kMidBatchWords;   // a wave's batches in LDS + the empty ones behind them (the unrolled loop runs up to kPf - 1 past the end and issues kPf ahead)
 constexpr int kMidMaxTilesPerBlock = 16;
 constexpr int kMidColFirst = 1 << 8;
-constexpr int kMidTileFloats = 17 * 36;                           // a wave's tile (see mid_chunk) incl. the row empty batch slots store to
 
 #ifdef TGNN_MID_TIMING
 // phase timers (scratch builds only): wall_clock64 ticks (100 MHz) summed over the layers; per block [0..15] thread 0's phases,
@@ -82,12 +81,6 @@ struct MidArgs {
     int n_types, depth, update_running, tiles_per_block, deg_log2, fault, nn_split;
     float eps, momentum;
 };
-
-// ---- wave tile in LDS: [17 rows][36 floats]: rows of 32 floats padded to 144 bytes (a matrix-layout read -- lane (n, q): floats
-//      8 q .. 8 q + 7 of row n -- then meets at most 2-way bank conflicts, whole-row writes and column walks none), row 16 = where
-//      the empty slots of a gather batch store.  An address is one multiply-add of the row number.
-constexpr int kMidRowFloats = 36;
-__device__ __forceinline__ int mid_chunk(int row, int c) { return row * kMidRowFloats + (c << 2); }   // float index of 16-byte chunk c
 
 // ---- one tagged double: the low two mantissa bits carry the generation
 __device__ __forceinline__ u32x2 mid_tag(double v, unsigned tag) {
@@ -270,154 +263,6 @@ __device__ __forceinline__ void mid_nnconv_finish(const MidNn &N, const MidArgs 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// ---- CollConv of one 16-row tile on one wave ------------------------------------------------------------------------------------
-__device__ __forceinline__ void mid_gin_tile(const MidArgs &A, int64_t tile, int layer, const float *src, float *dst, const float *gw,
-                                             const float *sp, const float *st2, float *tbuf, int lane, double &bn_acc) {
-    const int fj = lane & 15, fq = lane >> 4, go = lane >> 3, gp = lane & 7;
-    const int64_t n = A.n;
-    const __amdgpu_buffer_rsrc_t a_rs = rsrc_of(src);
-    const bool use_stat = layer > 0;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
-    // x = BatchNorm of the previous layer's pre-BN rows, folded into the sum as in gin32_aggregate_kernel (gin.hip)
-    const float4 mhi = use_stat ? *reinterpret_cast<const float4 *>(st2 + 4 * gp) : zero4;
-    const float4 mlo = use_stat ? *reinterpret_cast<const float4 *>(st2 + 32 + 4 * gp) : zero4;
-    const float4 gv = use_stat ? *reinterpret_cast<const float4 *>(st2 + 64 + 4 * gp) : one4;
-    const float4 bv = use_stat ? *reinterpret_cast<const float4 *>(st2 + 96 + 4 * gp) : zero4;
-    const float one_eps = sp[kSpEps];
-    // neighbourhood sums: lane (go, gp) walks the rows 8 h + go (h = 0, 1), piece gp.  A row's 8 lanes fetch 8 consecutive
-    // neighbour indices with ONE load (the next 8 while the rows of these fly) and hand them round by lane permutes; 8 source
-    // rows of both destination rows are in flight per step: ~3 memory round trips per 16 neighbours instead of one per 4
-    int beg[2], deg[2];
-    float4 selfv[2], acc[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int64_t row = tile * 16 + 8 * h + go;
-        const bool ok = row < n;
-        beg[h] = ok ? A.col_rowptr[row] : 0;
-        deg[h] = ok ? A.col_rowptr[row + 1] - beg[h] : 0;
-        selfv[h] = ld_sc1_f4(a_rs, ok ? (uint32_t)row * 128u + (uint32_t)gp * 16u : kOob);
-        acc[h] = zero4;
-    }
-    int maxdeg = deg[0] > deg[1] ? deg[0] : deg[1];
-#pragma unroll
-    for (int d = 32; d >= 8; d >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, d, 64));
-    maxdeg = __builtin_amdgcn_readfirstlane(maxdeg);
-    auto load_idx = [&](int k0, int (&idx)[2]) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const bool in = k0 + gp < deg[h];
-            const int v = A.col_nbr[in ? beg[h] + k0 + gp : 0];
-            idx[h] = in ? v : -1;
-        }
-    };
-    int idx[2], idx_next[2];
-    load_idx(0, idx);
-    for (int k0 = 0; k0 < maxdeg; k0 += 8) {
-        load_idx(k0 + 8, idx_next);                               // (past the longest row: nothing is fetched)
-        float4 y[2][8];
-        bool has[2][8];
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int nbk = __shfl(idx[h], (lane & ~7) | k, 64);
-                has[h][k] = nbk >= 0;
-                y[h][k] = ld_sc1_f4(a_rs, nbk >= 0 ? (uint32_t)nbk * 128u + (uint32_t)gp * 16u : kOob);
-            }
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (has[h][k]) {
-                    acc[h].x += (y[h][k].x - mhi.x) - mlo.x; acc[h].y += (y[h][k].y - mhi.y) - mlo.y;
-                    acc[h].z += (y[h][k].z - mhi.z) - mlo.z; acc[h].w += (y[h][k].w - mhi.w) - mlo.w;
-                }
-        idx[0] = idx_next[0];
-        idx[1] = idx_next[1];
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const float kb = one_eps + (float)deg[h];
-        f32x4 z4;
-        z4[0] = fmaf(gv.x, fmaf(one_eps, (selfv[h].x - mhi.x) - mlo.x, acc[h].x), kb * bv.x);
-        z4[1] = fmaf(gv.y, fmaf(one_eps, (selfv[h].y - mhi.y) - mlo.y, acc[h].y), kb * bv.y);
-        z4[2] = fmaf(gv.z, fmaf(one_eps, (selfv[h].z - mhi.z) - mlo.z, acc[h].z), kb * bv.z);
-        z4[3] = fmaf(gv.w, fmaf(one_eps, (selfv[h].w - mhi.w) - mlo.w, acc[h].w), kb * bv.w);
-        *reinterpret_cast<f32x4 *>(tbuf + mid_chunk(8 * h + go, gp)) = z4;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // matrix layout: lane (n = fj, q = fq) holds floats 8 q .. 8 q + 7 of tile row n
-    float z[8];
-    {
-        const f32x4 za = *reinterpret_cast<const f32x4 *>(tbuf + mid_chunk(fj, 2 * fq));
-        const f32x4 zb = *reinterpret_cast<const f32x4 *>(tbuf + mid_chunk(fj, 2 * fq + 1));
-        z[0] = za[0]; z[1] = za[1]; z[2] = za[2]; z[3] = za[3]; z[4] = zb[0]; z[5] = zb[1]; z[6] = zb[2]; z[7] = zb[3];
-    }
-    const bf16x8 *W1s = reinterpret_cast<const bf16x8 *>(gw), *W2s = W1s + 3 * 2 * 64, *W3s = W2s + 3 * 4 * 64;
-    const float *Bs = sp + kSpGinB;
-    auto bias4 = [&](int base, int mb) {
-        const float4 t = *reinterpret_cast<const float4 *>(Bs + base + 16 * mb + 4 * fq);
-        return f32x4{t.x, t.y, t.z, t.w};
-    };
-    const bf16x8 *w1p = W1s + fj * 4 + fq, *w2p = W2s + fj * 4 + fq, *w3p = W3s + fj * 4 + fq;
-    bf16x8 xb[3];
-    split3_trunc(z, xb[0], xb[1], xb[2]);
-    f32x4 h1a = small_mma6(w1p + 0 * 64, 2 * 64, xb, bias4(0, 0));
-    f32x4 h1b = small_mma6(w1p + 1 * 64, 2 * 64, xb, bias4(0, 1));
-    {
-        const float x[8] = {sigmoidf_(h1a[0]), sigmoidf_(h1a[1]), sigmoidf_(h1a[2]), sigmoidf_(h1a[3]),
-                            sigmoidf_(h1b[0]), sigmoidf_(h1b[1]), sigmoidf_(h1b[2]), sigmoidf_(h1b[3])};
-        split3_trunc(x, xb[0], xb[1], xb[2]);
-    }
-    f32x4 h2[4];
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) h2[mb] = small_mma6(w2p + mb * 64, 4 * 64, xb, bias4(32, mb));
-    f32x4 o0 = bias4(96, 0), o1 = bias4(96, 1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        const float x[8] = {sigmoidf_(h2[2 * ks][0]), sigmoidf_(h2[2 * ks][1]), sigmoidf_(h2[2 * ks][2]), sigmoidf_(h2[2 * ks][3]),
-                            sigmoidf_(h2[2 * ks + 1][0]), sigmoidf_(h2[2 * ks + 1][1]), sigmoidf_(h2[2 * ks + 1][2]), sigmoidf_(h2[2 * ks + 1][3])};
-        split3_trunc(x, xb[0], xb[1], xb[2]);
-        o0 = small_mma6(w3p + (0 * 2 + ks) * 64, 256, xb, o0);
-        o1 = small_mma6(w3p + (1 * 2 + ks) * 64, 256, xb, o1);
-    }
-    auto sig_out = [](float v) { return 1.0f / (1.0f + expf(-v)); };     // full precision, as gin32_mlp_kernel
-    const int64_t my_row = tile * 16 + fj;
-    const bool row_ok = my_row < n;
-    f32x4 r0, r1;
-    r0[0] = leakyf_(sig_out(o0[0])); r0[1] = leakyf_(sig_out(o0[1])); r0[2] = leakyf_(sig_out(o0[2])); r0[3] = leakyf_(sig_out(o0[3]));
-    r1[0] = leakyf_(sig_out(o1[0])); r1[1] = leakyf_(sig_out(o1[1])); r1[2] = leakyf_(sig_out(o1[2])); r1[3] = leakyf_(sig_out(o1[3]));
-    if (!row_ok) r0 = r1 = f32x4{0.f, 0.f, 0.f, 0.f};
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();                              // (everybody has read z)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    *reinterpret_cast<f32x4 *>(tbuf + mid_chunk(fj, fq)) = r0;
-    *reinterpret_cast<f32x4 *>(tbuf + mid_chunk(fj, 4 + fq)) = r1;
-    const __amdgpu_buffer_rsrc_t o_rs = rsrc_of(dst);
-    const uint32_t o_off = row_ok ? (uint32_t)my_row * 128u + (uint32_t)fq * 16u : kOob;
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r0), o_rs, o_off, 0, kCpSc1);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r1), o_rs, o_off == kOob ? kOob : o_off + 64u, 0, kCpSc1);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    {
-        const int ch = lane & 31;
-        const bool sq = lane >= 32;
-        double acc2 = 0.0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const double v = (double)tbuf[mid_chunk(r, ch >> 2) + (ch & 3)];
-            acc2 += sq ? v * v : v;
-        }
-        bn_acc += acc2;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // global -> LDS by DMA: `bytes` (a multiple of 1 KB) starting at src, shared out round the block's waves; 1 KB per wave-level
 // instruction, no register in between
 __device__ __forceinline__ void mid_dma(const float *src, float *dst_lds, int bytes, int wave, int lane) {
@@ -501,7 +346,7 @@ __global__ __launch_bounds__(kMidThreads) void forward_layers_mid_kernel(MidArgs
         const unsigned long long tg0 = wall_clock64();
 #endif
         for (int k = wave; k < kb; k += kMidWaves)
-            mid_gin_tile(A, tile0 + k, layer, src, A.a2[layer & 1], gw, sp, st + 128, tbuf, lane, bn2);
+            gin_tile<kCpSc1>(GinGraph{A.col_rowptr, A.col_nbr, A.n}, tile0 + k, layer > 0, src, A.a2[layer & 1], gw, sp, st + 128, tbuf, lane, bn2);
 #ifdef TGNN_MID_TIMING
         t_gin += wall_clock64() - tg0;
 #endif

@@ -23,7 +23,7 @@
 //  butterfly is serial.  See DESIGN.md section 5.)
 #include <stdlib.h>
 
-#include "tgnn_common.h"
+#include "forward_persist.h"
 
 namespace tgnn {
 
@@ -332,6 +332,155 @@ __global__ __launch_bounds__(kMlpThreads, 2) void gin32_mlp_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The two kernels above as ONE (packed 128-byte rows): z never travels through HBM (25.6 MB written and read again per layer at
+// 100 000 nodes: a fifth of the forward's excess traffic) and the layer costs one launch instead of two.
+// A block = 16 waves in 4 TEAMS, one per SIMD: an MLP wave and three GATHER waves.  A gather wave sums the neighbourhoods of its
+// tiles (every third tile of the team's share) -- whole 128-byte rows, 8 source rows of 2 x 8 destination rows per step,
+// gin_tile_gather -- and hands z over through a ring of LDS tiles; the MLP wave takes the tiles from the ring in order, in the
+// matrix layout, and runs gin_tile_mlp (forward_persist.h: the 32 -> 32 -> 64 -> 32 sigmoid MLP on bf16 x 3 fragments of an LDS
+// image, the arithmetic of gin32_mlp_kernel, same bits).  The memory-bound and the matrix-bound half of the layer overlap instead
+// of following each other, and twelve gather waves per CU keep its L2 -> L1 fill path (the bound of this op) busy (tried first:
+// every wave gathers, then multiplies -- the sum of both, 63 us per layer inside the forward against 31 + 29 for the two kernels;
+// then one streaming gather wave per MLP wave: 65 us, a wave's chain of dependent round trips per tile is too long).  BatchNorm partial row and the folded finalize (GinFin) as in gin32_mlp_kernel.
+// ------------------------------------------------------------------------------------------
+constexpr int kFusedWaves = 16, kFusedThreads = kFusedWaves * 64, kFusedGatherPerPair = 3, kFusedRing = 2 * kFusedGatherPerPair;
+constexpr int kFusedLdsFloats = kSpGinFrags * 4 + kSpGinW + 128 + 4 * kMidTileFloats + 4 * kFusedRing * kMidTileFloats + 64;
+constexpr size_t kFusedLdsBytes = (size_t)kFusedLdsFloats * 4 + (size_t)(4 * 64 + 16 * 64 + 64) * 8;
+
+__global__ __launch_bounds__(kFusedThreads) void gin32_fused_kernel(
+    const float *__restrict__ a, const float *__restrict__ in_stat, const int *__restrict__ rowptr, const int *__restrict__ col_src,
+    const float *__restrict__ eps_p, const float *__restrict__ w1, const float *__restrict__ b1, const float *__restrict__ w2,
+    const float *__restrict__ b2, const float *__restrict__ w3, const float *__restrict__ b3, int64_t n, float *__restrict__ out,
+    double *__restrict__ bn_partial, GinFin fin) {
+    extern __shared__ __attribute__((aligned(16))) float fl[];
+    float *gw = fl;                                               // [W1 | W2 | W3] images, small_pack_kernel's layout
+    float *spl = gw + kSpGinFrags * 4;                            // parameter vectors: 1 + eps, the three biases
+    float *st2 = spl + kSpGinW;                                   // the producer's BatchNorm record
+    float *tiles = st2 + 128;                                     // the MLP waves' own tiles
+    float *rings = tiles + 4 * kMidTileFloats;                    // [team][slot] hand-over tiles
+    volatile int *flags = reinterpret_cast<volatile int *>(rings + 4 * kFusedRing * kMidTileFloats);   // [team][slot]: tiles handed over / taken
+    double *red = reinterpret_cast<double *>(fl + kFusedLdsFloats);   // [4][64]
+    double *fred = red + 4 * 64, *ftot = fred + 16 * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    bf16x8 *W1s = reinterpret_cast<bf16x8 *>(gw), *W2s = W1s + 3 * 2 * 64, *W3s = W2s + 3 * 4 * 64;
+    for (int i = tid; i < 2 * 64; i += kFusedThreads) {     // item = (M block, i, q): 8 weights
+        const int mb = i >> 6, ii = (i >> 2) & 15, q = i & 3;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = w1[(16 * mb + ii) * 32 + 8 * q + e];
+        gin_split3(x, W1s[(0 * 2 + mb) * 64 + ii * 4 + q], W1s[(1 * 2 + mb) * 64 + ii * 4 + q], W1s[(2 * 2 + mb) * 64 + ii * 4 + q]);
+    }
+    for (int i = tid; i < 4 * 64; i += kFusedThreads) {
+        const int mb = i >> 6, ii = (i >> 2) & 15, q = i & 3;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = w2[(16 * mb + ii) * 32 + gin_kf(q, e)];
+        gin_split3(x, W2s[(0 * 4 + mb) * 64 + ii * 4 + q], W2s[(1 * 4 + mb) * 64 + ii * 4 + q], W2s[(2 * 4 + mb) * 64 + ii * 4 + q]);
+    }
+    for (int i = tid; i < 4 * 64; i += kFusedThreads) {     // item = (M block, K step, i, q)
+        const int mb = i >> 7, ks = (i >> 6) & 1, ii = (i >> 2) & 15, q = i & 3;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = w3[(16 * mb + ii) * 64 + 32 * ks + gin_kf(q, e)];
+        const int o = (mb * 2 + ks) * 64 + ii * 4 + q;
+        gin_split3(x, W3s[0 * 256 + o], W3s[1 * 256 + o], W3s[2 * 256 + o]);
+    }
+    if (tid < 32) spl[kSpGinB + tid] = b1[tid];
+    else if (tid < 96) spl[kSpGinB + tid] = b2[tid - 32];
+    else if (tid < 128) spl[kSpGinB + tid] = b3[tid - 96];
+    if (tid == 128) spl[kSpEps] = 1.0f + eps_p[0];
+    if (tid >= 256 && tid < 384) st2[tid - 256] = in_stat ? in_stat[tid - 256] : 0.f;
+    if (tid >= 384 && tid < 384 + 8 * kFusedRing) flags[tid - 384] = 0;
+    for (int i = tid; i < 4 * kMidTileFloats; i += kFusedThreads) tiles[i] = 0.f;
+    __syncthreads();
+
+    // the tile share of a team (= of a SIMD): as gin32_mlp_kernel shares the tiles out over the SIMD slots of the grid
+    const int64_t n_tiles = (n + 15) / 16;
+    const int nblk = gridDim.x, team = wave & 3, role = wave >> 2;   // role 0: the MLP wave, 1 .. 3: gather waves
+    int64_t blk = blockIdx.x;
+    if (nblk >= 8 && (nblk & 7) == 0) blk = (int64_t)(blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    const int64_t slot = blk * 4 + team, n_slots = (int64_t)nblk * 4;
+    const int64_t t0 = n_tiles * slot / n_slots, t1 = n_tiles * (slot + 1) / n_slots;
+    const GinGraph G{rowptr, col_src, n};
+    float *ring = rings + team * kFusedRing * kMidTileFloats;
+    // ring slot s: ready[s] = 1 + the number of the last tile handed over there, taken[s] = 1 + the number of the last tile read
+    volatile int *ready = flags + 2 * kFusedRing * team, *taken = ready + kFusedRing;
+    double bn = 0.0;
+    if (role > 0) {
+        for (int64_t i = role - 1; t0 + i < t1; i += kFusedGatherPerPair) {
+            const int s = (int)(i % kFusedRing);
+            while (i >= kFusedRing && taken[s] < (int)(i - kFusedRing) + 1) __builtin_amdgcn_s_sleep(1);   // the slot's last tile has been read
+            gin_tile_gather<0>(G, t0 + i, in_stat != nullptr, a, spl, st2, ring + s * kMidTileFloats, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) ready[s] = (int)i + 1;
+        }
+    } else {
+        float *tbuf = tiles + team * kMidTileFloats;
+        for (int64_t i = 0; t0 + i < t1; ++i) {
+            const int s = (int)(i % kFusedRing);
+            while (ready[s] < (int)i + 1) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            gin_tile_mlp<0>(G, t0 + i, out, gw, spl, ring + s * kMidTileFloats, tbuf, lane, bn, taken + s, (int)i + 1);
+        }
+    }
+
+    if (bn_partial) {
+        if (role == 0) red[team * 64 + lane] = bn;           // lane = (channel, sum | sum of squares): the partial row's order
+        __syncthreads();
+        using u32x2_ = __attribute__((ext_vector_type(2))) unsigned int;
+        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(bn_partial, 0, (int)0x80000000u, 0x00020000);
+        if (tid < 64) {
+            double tot = 0.0;
+            for (int w = 0; w < 4; ++w) tot += red[w * 64 + tid];
+            if (fin.counter)
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, tot), prs, ((uint32_t)blockIdx.x * 64u + (uint32_t)tid) * 8u, 0, kCpSc1);
+            else
+                bn_partial[(int64_t)blockIdx.x * 64 + tid] = tot;
+        }
+        if (fin.counter) {                                    // the last block writes the BatchNorm's record (see gin32_mlp_kernel)
+            __shared__ unsigned ticket;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) ticket = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (ticket == gridDim.x - 1) {                    // (uniform)
+                const int j = tid & 63, h = tid >> 6;
+                if (tid < 512) {                              // (the 8 waves of bn_finalize_kernel's tree)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int g = h + 8 * half;
+                        double acc = 0.0;
+                        const int np = (int)gridDim.x;
+                        for (int p = g; p < np; p += 8 * 16) {
+                            u32x2_ v[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const int pp = p + u * 16;
+                                v[u] = __builtin_amdgcn_raw_buffer_load_b64(prs, pp < np ? ((uint32_t)pp * 64u + (uint32_t)j) * 8u : 0x80000000u, 0, kCpSc1);
+                            }
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                if (p + u * 16 < np) acc += __builtin_bit_cast(double, v[u]);
+                        }
+                        fred[g * 64 + j] = acc;
+                    }
+                }
+                __syncthreads();
+                if (tid < 64) {
+                    double t = 0.0;
+                    for (int gg = 0; gg < 16; ++gg) t += fred[gg * 64 + tid];
+                    ftot[tid] = t;
+                }
+                __syncthreads();
+                bn_record_from_sums(fin.job, ftot, 32, fin.n_total, fin.eps, fin.momentum);
+                if (tid == 0) __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
 // Generic fallback (any C <= 256): one wave per row, everything through LDS / L2.
 __global__ __launch_bounds__(256) void gin_generic_kernel(
     const float *__restrict__ a, int64_t lda, const float *__restrict__ in_stat, const int *__restrict__ rowptr,
@@ -389,7 +538,8 @@ __global__ __launch_bounds__(256) void gin_generic_kernel(
 }  // namespace tgnn
 
 using namespace tgnn;
-namespace tgnn { std::atomic<int> g_debug_block_cap[2]; }
+namespace tgnn { std::atomic<int> g_debug_block_cap[2]; static std::atomic<int> g_gin_fused{1}; }
+extern "C" int32_t tgnn_set_gin_fused(int32_t on) { return tgnn::g_gin_fused.exchange(on ? 1 : 0); }
 extern "C" void tgnn_debug_set_block_caps(int32_t nnconv_blocks, int32_t gin_mlp_blocks) {
     g_debug_block_cap[0].store(nnconv_blocks);
     g_debug_block_cap[1].store(gin_mlp_blocks);
@@ -399,10 +549,28 @@ namespace tgnn {
 int gin32_fwd_folded(const float *a, int64_t lda, const float *in_stat, const int32_t *rowptr, const int32_t *col_src, const float *eps,
                      const float *w1, const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
                      int64_t n_nodes, int32_t act, float *out, float *z_scratch, double *bn_partial, int32_t *n_partials_host,
-                     const GinFin &fin, hipStream_t s) {
+                     const GinFin &fin, hipStream_t s, bool need_z) {
     if (!(n_nodes >= 1 && lda % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)out % 16) == 0 && z_scratch &&
           ((uintptr_t)z_scratch % 16) == 0 && bn_partial))
         return TGNN_ERR_UNSUPPORTED;
+    if (!need_z && lda == 32 && act == TGNN_ACT_LEAKY_RELU && g_gin_fused.load(std::memory_order_relaxed) && n_nodes * 128 < (int64_t(1) << 31)) {
+        // one launch, no z round trip (gin32_fused_kernel)
+        int blocks = producer_blocks(n_nodes, 16 * kMlpWaves);
+        constexpr int reserve = 32;
+        int cap = cus_minus(reserve);
+        if (const int dbg = g_debug_block_cap[1].load(); dbg > 0) cap = dbg < device_cus() ? dbg : device_cus();
+        if (blocks > cap) blocks = cap;
+        if (blocks >= 8) blocks &= ~7;
+        GinFin f = fin;
+        f.job.partials = bn_partial;
+        f.job.n_partials = blocks;
+        static LdsOptIn site;
+        TGNN_CHECK_HIP(opt_in_dynamic_lds(gin32_fused_kernel, (int)kFusedLdsBytes, site));
+        gin32_fused_kernel<<<blocks, kFusedThreads, kFusedLdsBytes, s>>>(a, in_stat, rowptr, col_src, eps, w1, b1, w2, b2, w3, b3, n_nodes, out, bn_partial, f);
+        if (n_partials_host) *n_partials_host = blocks;
+        TGNN_CHECK_LAUNCH();
+        return TGNN_OK;
+    }
     const int64_t rows_per_xcd = (n_nodes + 7) / 8;
     const unsigned agg_blocks = (unsigned)(8 * ((rows_per_xcd + 31) / 32));
     gin32_aggregate_kernel<<<agg_blocks, 256, 0, s>>>(a, lda, in_stat, rowptr, col_src, eps, n_nodes, z_scratch);

@@ -386,7 +386,9 @@ int launch_gin32_mlp(const float *z, const float *w1, const float *b1, const flo
 int gin32_fwd_folded(const float *a, int64_t lda, const float *in_stat, const int32_t *rowptr, const int32_t *col_src, const float *eps,
                      const float *w1, const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
                      int64_t n_nodes, int32_t act, float *out, float *z_scratch, double *bn_partial, int32_t *n_partials_host,
-                     const GinFin &fin, hipStream_t s);
+                     const GinFin &fin, hipStream_t s, bool need_z = true);
+// need_z = false (nobody reads the aggregate z afterwards; packed rows, LeakyReLU): aggregate and MLP as ONE kernel, z_scratch
+// is not written (gin.hip: gin32_fused_kernel; tgnn_set_gin_fused(0) keeps the two-kernel form)
 // Kernels that synchronise their blocks with spin barriers (the persistent small-layout forward, the one-launch small-layout
 // preparation) need ALL their blocks resident; two of them started side by side from different streams or threads could each
 // hold part of the CUs and wait for the rest for ever.  Every such launch goes through this per-device gate (forward_small.hip):
