@@ -439,9 +439,10 @@ int64_t tgnn_get_small_layout_limit(void);
  *      sharded scheme and the per-op entry points stay on bf16 x 3.
  * Process-wide; returns the previous mode (any other argument: only queries). */
 int32_t tgnn_set_split_precision(int32_t mode);
-/* 1 (default): tgnn_forward runs GINConv's neighbourhood sum and MLP as ONE kernel on single-device inference forwards (the
- * aggregate never travels through HBM); 0: the two kernels of tgnn_gin_fwd.  Same arithmetic.  Returns the previous setting. */
-int32_t tgnn_set_gin_fused(int32_t on);
+/* GINConv's neighbourhood sum and MLP as ONE kernel on single-device inference forwards (the aggregate never travels through
+ * HBM; csrc/gin.hip: gin32_fused_kernel): 0 never (the two kernels of tgnn_gin_fwd), 1 (default) for layouts of 200 000 nodes and
+ * more -- where it is faster --, 2 always.  Same arithmetic, the CollConv rows are bit-identical.  Returns the previous mode. */
+int32_t tgnn_set_gin_fused(int32_t mode);
 
 /* Small layouts (<= tgnn_graph_prep_small_max_nodes() nodes, <= ..._max_edges() edges per set): everything above --
  * tgnn_csr_build of both edge sets (self loops dropped from the collision set), tgnn_edge_type_dedup, the types in CSR

@@ -13,7 +13,7 @@ for n in (100000, 300000):
     net.load_state_dict(make_state_dict(15, 20, 32, 1, 3, seed=0), strict=True)
     net = net.to(dev).train()
     for on in (0, 1):
-        _lib.lib.tgnn_set_gin_fused(on)
+        _lib.lib.tgnn_set_gin_fused(2 * on)
         bench.profiled_classes(net, x, adj, attr, col, 3)
         cls, _ = bench.profiled_classes(net, x, adj, attr, col, 10)
         print(n, "fused" if on else "two kernels", {k: round(v["ms_per_forward"] / max(1, v["launches_per_forward"]) * 1e3, 1) for k, v in cls.items() if k in ("nnconv", "gin", "merge")}, flush=True)

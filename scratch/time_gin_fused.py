@@ -14,7 +14,7 @@ for n in [int(a) for a in sys.argv[1:]] or [20000, 50000, 100000, 300000]:
     res = {}
     for rep in range(2):
         for on in (0, 1):
-            _lib.lib.tgnn_set_gin_fused(on)
+            _lib.lib.tgnn_set_gin_fused(2 * on)
             for _ in range(5):
                 net(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)
             torch.cuda.synchronize()

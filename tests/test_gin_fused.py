@@ -23,7 +23,7 @@ def dev():
 @contextlib.contextmanager
 def gin_fused(on):
     from tilingnn_amd import _lib
-    before = _lib.lib.tgnn_set_gin_fused(int(on))
+    before = _lib.lib.tgnn_set_gin_fused(2 if on else 0)      # (2: at every size; the default switches by size)
     try:
         yield
     finally:

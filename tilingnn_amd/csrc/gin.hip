@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void gin_generic_kernel(
 
 using namespace tgnn;
 namespace tgnn { std::atomic<int> g_debug_block_cap[2]; static std::atomic<int> g_gin_fused{1}; }
-extern "C" int32_t tgnn_set_gin_fused(int32_t on) { return tgnn::g_gin_fused.exchange(on ? 1 : 0); }
+extern "C" int32_t tgnn_set_gin_fused(int32_t mode) { return tgnn::g_gin_fused.exchange(mode < 0 ? 0 : (mode > 2 ? 2 : mode)); }
 extern "C" void tgnn_debug_set_block_caps(int32_t nnconv_blocks, int32_t gin_mlp_blocks) {
     g_debug_block_cap[0].store(nnconv_blocks);
     g_debug_block_cap[1].store(gin_mlp_blocks);
@@ -553,7 +553,14 @@ int gin32_fwd_folded(const float *a, int64_t lda, const float *in_stat, const in
     if (!(n_nodes >= 1 && lda % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)out % 16) == 0 && z_scratch &&
           ((uintptr_t)z_scratch % 16) == 0 && bn_partial))
         return TGNN_ERR_UNSUPPORTED;
-    if (!need_z && lda == 32 && act == TGNN_ACT_LEAKY_RELU && g_gin_fused.load(std::memory_order_relaxed) && n_nodes * 128 < (int64_t(1) << 31)) {
+    // Measured, cached-layout forward, two kernels / fused: 20 000 nodes 0.880 / 0.916 ms, 100 000: 1.78 / 1.85, 300 000: 4.53 / 4.39;
+    // the op alone (events, single stream) 43.6 / 38.1 us at 100 000 nodes, 94.0 / 83.3 at 300 000.  Inside the two-chain forward both
+    // forms cost ~62 us of wall clock per layer at 100 000 nodes (the chains take the CUs in turns); the fused form wins where the
+    // layer is long enough for its z traffic (25.6 MB per 100 000 nodes) to matter: from kGinFusedMinNodes on
+    constexpr int64_t kGinFusedMinNodes = 200000;
+    const int fused_mode = g_gin_fused.load(std::memory_order_relaxed);   // 0 never, 1 by size, 2 always
+    if (!need_z && lda == 32 && act == TGNN_ACT_LEAKY_RELU && (fused_mode == 2 || (fused_mode == 1 && n_nodes >= kGinFusedMinNodes)) &&
+        n_nodes * 128 < (int64_t(1) << 31)) {
         // one launch, no z round trip (gin32_fused_kernel)
         int blocks = producer_blocks(n_nodes, 16 * kMlpWaves);
         constexpr int reserve = 32;
