@@ -500,6 +500,14 @@ def test_full_size_layers_against_the_fp64_oracle(dev, big):
             "gconv": orc.rel_max_err(l1(h.to(dev), adj, adj_attr)[0].cpu(), want_g),
             "gin": orc.rel_max_err(l2.ginConv(h.to(dev), col).cpu(), want_gin),
             "cconv": orc.rel_max_err(l2(h.to(dev), col)[0].cpu(), want_c)}
+    # the kernel tgnn_forward RUNS at this size -- the column NNConv on the fp16-pair split -- as its own op (the layer call
+    # above goes through the bf16 x 3 per-op entry point)
+    from tilingnn_amd import ops
+    from tilingnn_amd.graph_networks import _graph_cache
+    graph = _graph_cache.get_adj(100_000, adj, adj_attr)
+    wtab = ops.edge_weight_table(adj_attr, graph, *l1.nnConv._edge_mlp_params(), 32)
+    errs["nnconv_f16_pair"] = orc.rel_max_err(ops.nnconv_mean(h.to(dev), graph, wtab, l1.nnConv.root, l1.nnConv.bias,
+                                                               kernel="cols_f16")[0].cpu(), want_nn)
     cat = torch.randn(100_000, 672, generator=gen)
     with torch.no_grad():
         want_f = orc.final_mlp(cat.double(), sd64)
