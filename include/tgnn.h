@@ -546,6 +546,23 @@ int tgnn_sublayout_compact(const int32_t *alive, int64_t n_nodes, const float *x
                            int64_t *adj_out, float *adj_attr_out, int64_t *col_out, int64_t *counts_out,
                            int32_t *err_flag, void *ws, size_t ws_bytes, tgnn_stream_t stream);
 
+/* ---- one round of the greedy assembly loop's acceptance, batched on the device (csrc/greedy.hip; the DOCUMENTED SUBSTITUTE of
+ * the sequential sweep of util/algorithms.py:41-54 for large layouts -- not bit-compatible with the reference's RNG stream, see
+ * the file's header; tilingnn_amd.util.algorithms keeps the reference's sweep on the host as the default).
+ *   prob [n_sub] (stride ld_prob floats): this round's probabilities of the sub-layout's nodes; inverse [n_sub] (may be NULL =
+ *   identity): sub-layout node -> original node; col_edge_index [2][n_col_edges]: the sub-layout's collision edges (both
+ *   directions, sub-layout numbering); round >= 1; prob_saved [N] doubles over ORIGINAL nodes (1.0 before round 1): the running
+ *   geometric mean of :33-34, updated; alive [N] int32: cleared for accepted nodes and their collision neighbours;
+ *   selected_round [N] int32: set to `round` for accepted nodes; *n_selected (device int64) += accepted; *err_flag set on an edge
+ *   end outside [0, n_sub).  A node is accepted when it precedes all its neighbours in the reference's visiting order (larger
+ *   running mean first, smaller number on ties) and exp(p - 1) > u, u = uniform(seed, round, original node) -- counter based,
+ *   reproducible.  No two accepted nodes collide. */
+size_t tgnn_greedy_round_workspace_bytes(int64_t n_sub);
+int tgnn_greedy_round(const float *prob, int64_t ld_prob, const int64_t *inverse, int64_t n_sub, const int64_t *col_edge_index,
+                      int64_t n_col_edges, int32_t round, uint64_t seed, double *prob_saved, int32_t *alive,
+                      int32_t *selected_round, int64_t *n_selected, int32_t *err_flag, void *ws, size_t ws_bytes,
+                      tgnn_stream_t stream);
+
 /* ---- the loss on the predict path -------------------------------------------------
  * Losses.calculate_unsupervised_loss (solver/ml_solver/losses.py:48-116), evaluated by ML_Solver.predict through
  * get_best_prob_map (ml_solver.py:46,133-136): for every probability map m (column of probs [N, n_maps])

@@ -51,6 +51,10 @@ class ML_Solver:
         self.num_prob_maps = num_prob_maps
         self._greedy_solver = greedy_solver
         self._score_fn = score_fn                               # (selection, layout) -> float; default: Losses.solution_score
+        # None (default): solve() runs the reference's sweep with numpy's RNG stream (seeded parity) at every size; a node count:
+        # layouts at least that large take tilingnn_amd.util.algorithms.solve_by_device_greedy (batched acceptance on the GPU)
+        self.device_greedy_min_nodes = None
+        self.device_greedy_seed = 0
 
     @staticmethod
     def _no_edges(index) -> bool:
@@ -72,6 +76,18 @@ class ML_Solver:
                                   col_e_idx=collide_edge_index, col_e_features=collide_edge_features)
         best_map_index = self._best_prob_map(predictions, brick_layout)
         return predictions[:, best_map_index].detach().cpu().numpy()
+
+    def predict_on_device(self, brick_layout):
+        """predict() for a layout that lives on the GPU, the probabilities staying there: [N] float32 on self.device (the loop of
+        tilingnn_amd.util.algorithms.solve_by_device_greedy feeds them straight into the acceptance kernels)."""
+        if self._no_edges(brick_layout.collide_edge_index) or self._no_edges(brick_layout.align_edge_index):
+            return torch.ones(brick_layout.node_feature.shape[0], dtype=torch.float32, device=self.device)     # ml_solver.py:31-32
+        x, adj_edge_index, adj_edge_features, collide_edge_index, collide_edge_features = \
+            brick_layout.get_data_as_torch_tensor(self.device)
+        run = getattr(self.network, "forward_checked", None) or self.network
+        predictions, *_ = run(x=x, adj_e_index=adj_edge_index, adj_e_features=adj_edge_features,
+                              col_e_idx=collide_edge_index, col_e_features=collide_edge_features)
+        return predictions[:, self._best_prob_map(predictions, brick_layout)].detach().contiguous()
 
     def _best_prob_map(self, predictions, brick_layout):
         """get_best_prob_map (ml_solver.py:133-136): argsort of the per-map unsupervised loss.
@@ -104,8 +120,14 @@ class ML_Solver:
         on the GPU; score = Losses.solution_score when the layout carries its complete graph and super-contour area, or
         `score_fn`, else None); `greedy_solver=` swaps in another one, e.g. the reference's own."""
         if self._greedy_solver is None:
-            from ...util.algorithms import solve_by_probablistic_greedy
-            output_solution, score, predict_order = solve_by_probablistic_greedy(self, brick_layout, score_fn=self._score_fn)
+            from ...util.algorithms import solve_by_device_greedy, solve_by_probablistic_greedy
+            n_nodes = int(brick_layout.node_feature.shape[0])
+            if self.device_greedy_min_nodes is not None and n_nodes >= self.device_greedy_min_nodes:
+                # large layouts: the acceptance batched on the device (a documented substitute of the sequential sweep)
+                output_solution, score, predict_order = solve_by_device_greedy(self, brick_layout, seed=self.device_greedy_seed,
+                                                                               score_fn=self._score_fn)
+            else:
+                output_solution, score, predict_order = solve_by_probablistic_greedy(self, brick_layout, score_fn=self._score_fn)
         else:
             output_solution, score, predict_order = self._greedy_solver(self, brick_layout)
         output_layout = deepcopy(brick_layout)

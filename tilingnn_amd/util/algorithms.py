@@ -136,6 +136,53 @@ def solve_by_probablistic_greedy(ml_solver, origin_layout, score_fn=None, on_rou
     return selection, score, order
 
 
+def solve_by_device_greedy(ml_solver, origin_layout, seed=0, score_fn=None, on_round=None, max_rounds=100000):
+    """The assembly loop with the acceptance BATCHED on the device (csrc/greedy.hip: tgnn_greedy_round) -- the documented
+    substitute of the reference's sequential sweep (algorithms.py:41-54) for large layouts (BASELINE config 5: "batched greedy
+    selection"): per round every node that precedes all its unlabelled collision neighbours in the reference's visiting order
+    and passes the reference's test exp(p - 1) > u is accepted at once, u from a counter-based generator keyed by (seed, round,
+    node).  NOT the reference's RNG stream -- `solve_by_probablistic_greedy` stays the default where seeded parity matters --
+    but the same invariants: a collision-free selection, maximal when the loop ends, the same running geometric mean of the
+    probabilities (:33-34).  O(log N) rounds of {compaction, forward, four small launches}; nothing but one count per round
+    travels to the host.  Same return values: (selection, score, predict_order); the order = by round, then by node number."""
+    device = ml_solver.device
+    origin = origin_layout if isinstance(origin_layout, DeviceLayout) else DeviceLayout.upload(origin_layout, device)
+    dev = origin.node_feature.device
+    n = int(origin.node_feature.shape[0])
+    builder = SubLayoutBuilder(origin)
+    alive = torch.ones(n, dtype=torch.int32, device=dev)
+    selected = torch.zeros(n, dtype=torch.int32, device=dev)
+    saved = torch.ones(n, dtype=torch.float64, device=dev)
+    tail = torch.zeros(2, dtype=torch.int64, device=dev)        # accepted so far | error flag
+    ws_bytes = int(lib.tgnn_greedy_round_workspace_bytes(n))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    rounds = 0
+    while True:
+        sub = builder.build(alive)                              # (one sync: the sub-layout's sizes)
+        n2 = int(sub.node_feature.shape[0])
+        if n2 == 0:
+            break
+        rounds += 1
+        if rounds > max_rounds:
+            raise RuntimeError(f"solve_by_device_greedy: {n2} nodes still unlabelled after {max_rounds} rounds")
+        if on_round is not None:
+            on_round(sub)
+        probs = ml_solver.predict_on_device(sub)                # [n2] float32 on the device
+        ec2 = int(sub.collide_edge_index.shape[1])
+        check(lib.tgnn_greedy_round(ptr(probs), 1, ptr(sub.inverse_index), n2, ptr(sub.collide_edge_index) if ec2 else None, ec2,
+                                    rounds, int(seed) & (2 ** 64 - 1), ptr(saved), ptr(alive), ptr(selected), ptr(tail[:1]),
+                                    ptr(tail[1:].view(torch.int32)[:1]), ptr(ws), ws_bytes, _lib.current_stream(dev)))
+    sel_round = selected.cpu().numpy()
+    if int(tail[1].item()):
+        raise IndexError("collision edge index out of range in a sub-layout")
+    selection = (sel_round > 0).astype(np.float64)
+    picked = np.flatnonzero(sel_round > 0)
+    order = [int(v) for v in picked[np.lexsort((picked, sel_round[picked]))]]
+    score = create_score(selection, origin_layout, score_fn, device)
+    solve_by_device_greedy.last_rounds = rounds
+    return selection, score, order
+
+
 def create_score(selection, origin_layout, score_fn=None, device=None):
     """The score half of `create_solution` (algorithms.py:210-220)."""
     if score_fn is not None:
