@@ -546,6 +546,15 @@ int tgnn_sublayout_compact(const int32_t *alive, int64_t n_nodes, const float *x
                            int64_t *adj_out, float *adj_attr_out, int64_t *col_out, int64_t *counts_out,
                            int32_t *err_flag, void *ws, size_t ws_bytes, tgnn_stream_t stream);
 
+/* A node-range SHARD's rows of the next greedy round (tilingnn_amd.dist.compact_shard_device): alive_local [n_rows] = 1 for the
+ * owned rows (0 .. n_own - 1) that are still unlabelled and for the halo rows (n_own ..) that are unlabelled AND still the source
+ * of an edge whose destination is unlabelled too; tgnn_sublayout_compact over the shard's local row space with that mask then IS
+ * the shard of the sub-layout.  alive_global [N] over the current global numbering, gid [n_rows] the global number of every local
+ * row, edge indices [2][E] in local numbering.  *err_flag is set on an edge end outside [0, n_rows). */
+int tgnn_shard_alive_rows(const int32_t *alive_global, const int64_t *gid, int64_t n_own, int64_t n_rows,
+                          const int64_t *adj_edge_index, int64_t n_adj_edges, const int64_t *col_edge_index, int64_t n_col_edges,
+                          int32_t *alive_local, int32_t *err_flag, tgnn_stream_t stream);
+
 /* ---- one round of the greedy assembly loop's acceptance, batched on the device (csrc/greedy.hip; the DOCUMENTED SUBSTITUTE of
  * the sequential sweep of util/algorithms.py:41-54 for large layouts -- not bit-compatible with the reference's RNG stream, see
  * the file's header; tilingnn_amd.util.algorithms keeps the reference's sweep on the host as the default).

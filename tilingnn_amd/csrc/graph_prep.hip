@@ -1545,6 +1545,43 @@ extern "C" int tgnn_sublayout_compact(const int32_t *alive, int64_t n_nodes, con
     return TGNN_OK;
 }
 
+/* ---- a SHARD's rows of the next greedy round (tilingnn_amd.dist.compact_shard_device): the owned rows that are still
+ *      unlabelled, and of the halo rows those that are unlabelled AND still the source of an edge whose two ends are -- the halo
+ *      list of the round before shrinks with the layout.  alive_global over the current global numbering, gid [n_rows] = global
+ *      number of every local row (owned rows first), edges in local numbering (destinations are owned rows). */
+__global__ void shard_alive_own_kernel(const int *__restrict__ alive_global, const int64_t *__restrict__ gid, int64_t n_own,
+                                       int64_t n_rows, int *__restrict__ alive_local) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += (int64_t)gridDim.x * blockDim.x)
+        alive_local[i] = i < n_own ? (alive_global[gid[i]] != 0) : 0;
+}
+__global__ void shard_alive_halo_kernel(const int *__restrict__ alive_global, const int64_t *__restrict__ gid, int64_t n_own,
+                                        int64_t n_rows, const int64_t *__restrict__ ei, int64_t e, int *__restrict__ alive_local,
+                                        int *__restrict__ err_flag) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < e; k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t src = ei[k], dst = ei[e + k];
+        if (src < 0 || src >= n_rows || dst < 0 || dst >= n_rows) { *err_flag = 1; continue; }
+        if (src >= n_own && alive_global[gid[src]] != 0 && alive_global[gid[dst]] != 0) alive_local[src] = 1;   // (every writer stores 1)
+    }
+}
+extern "C" int tgnn_shard_alive_rows(const int32_t *alive_global, const int64_t *gid, int64_t n_own, int64_t n_rows,
+                                     const int64_t *adj_edge_index, int64_t n_adj_edges, const int64_t *col_edge_index,
+                                     int64_t n_col_edges, int32_t *alive_local, int32_t *err_flag, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
+    TGNN_CHECK_ARG(n_own >= 0 && n_rows >= n_own && n_rows >= 1 && n_adj_edges >= 0 && n_col_edges >= 0, "shape");
+    TGNN_CHECK_ARG(alive_global && gid && alive_local && err_flag, "null pointer");
+    TGNN_CHECK_ARG((n_adj_edges == 0 || adj_edge_index) && (n_col_edges == 0 || col_edge_index), "null edge index");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    shard_alive_own_kernel<<<grid_for(n_rows), 256, 0, s>>>(alive_global, gid, n_own, n_rows, alive_local);
+    if (n_adj_edges > 0)
+        shard_alive_halo_kernel<<<grid_for(n_adj_edges), 256, 0, s>>>(alive_global, gid, n_own, n_rows, adj_edge_index, n_adj_edges,
+                                                                     alive_local, err_flag);
+    if (n_col_edges > 0)
+        shard_alive_halo_kernel<<<grid_for(n_col_edges), 256, 0, s>>>(alive_global, gid, n_own, n_rows, col_edge_index, n_col_edges,
+                                                                     alive_local, err_flag);
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}
+
 /* ---- small layouts: everything tgnn_forward needs of a layout in one launch -------------------------------------------- */
 extern "C" int64_t tgnn_graph_prep_small_max_nodes(void) { return kSmallPrepMaxNodes; }
 extern "C" int64_t tgnn_graph_prep_small_max_edges(void) { return (int64_t)kSmallPrepMaxBlocks * kSmallPrepLocal; }

@@ -174,6 +174,72 @@ def compact_shard(shard: Shard, alive: np.ndarray) -> Shard:
                  shard.adj_attr[keep_a], localise(c), None, new_bounds)
 
 
+def compact_shard_device(shard: Shard, inputs: Dict[str, Tensor], alive) -> "tuple[Shard, Dict[str, Tensor]]":
+    """compact_shard with the shard's arrays where they live -- in HBM (`inputs` = HipBackend.upload(shard) or the result of an
+    earlier call): the same sub-layout shard, bit for bit, cut by the device (csrc/graph_prep.hip: tgnn_shard_alive_rows marks the
+    surviving owned rows and the halo rows that are still somebody's source, tgnn_sublayout_compact -- the kernel of the
+    single-GPU loop -- re-indexes rows and edges over the shard's local row space).  The host does what is O(world) or O(halo):
+    the ranges' new bounds from the alive mask it holds anyway, the new halo list (global numbers) for the send-list exchange.
+    One read-back: the three counts + the surviving halo rows.  Returns (shard', inputs'); shard'.x / .adj / .col stay None (the
+    data is inputs'); the communicator's setup must run again and inputs'["send_idx"] be rebuilt (refresh_send_idx)."""
+    import ctypes as C
+    from . import _lib
+    lib, check, ptr = _lib.lib, _lib.check, _lib.ptr
+    world, rank = shard.world, shard.rank
+    alive_h = np.asarray(alive.cpu().numpy() if torch.is_tensor(alive) else alive).astype(bool)
+    assert alive_h.shape[0] == shard.n_total
+    dev = inputs["x"].device
+    old_bounds = shard.bounds if shard.bounds is not None else even_bounds(shard.n_total, world)
+    prefix = np.concatenate([[0], np.cumsum(alive_h, dtype=np.int64)])
+    new_bounds = prefix[old_bounds]
+    lo, hi = int(old_bounds[rank]), int(old_bounds[rank + 1])
+    nlo, nhi = int(new_bounds[rank]), int(new_bounds[rank + 1])
+    n_own, n_rows = shard.n_own, shard.n_rows
+    n_halo = n_rows - n_own
+    x, adj, attr, col = inputs["x"], inputs["adj"], inputs["attr"], inputs["col"]
+    fx = int(x.shape[1])
+    ea, ec, fe = int(adj.shape[1]), int(col.shape[1]), int(attr.shape[1]) if attr.numel() else 1
+    stream = _lib.current_stream(dev)
+    alive_d = (alive if torch.is_tensor(alive) and alive.is_cuda else torch.from_numpy(alive_h.astype(np.int32)).to(dev)).to(torch.int32)
+    gid = torch.cat([torch.arange(lo, hi, dtype=torch.int64, device=dev),
+                     torch.from_numpy(np.ascontiguousarray(shard.halo_ids, dtype=np.int64)).to(dev)])
+    alive_local = torch.empty(max(n_rows, 1), dtype=torch.int32, device=dev)
+    tail = torch.zeros(4, dtype=torch.int64, device=dev)        # counts [3] | error flag
+    err = tail[3:].view(torch.int32)[:1]
+    check(lib.tgnn_shard_alive_rows(ptr(alive_d), ptr(gid), n_own, n_rows, ptr(adj) if ea else None, ea, ptr(col) if ec else None, ec,
+                                    ptr(alive_local), ptr(err), stream))
+    x_pad = torch.cat([x, torch.zeros(n_halo, fx, dtype=torch.float32, device=dev)]) if n_halo else x
+    x_out = torch.empty(n_rows, fx, dtype=torch.float32, device=dev)
+    inverse = torch.empty(n_rows, dtype=torch.int64, device=dev)
+    adj_out = torch.empty(2 * max(ea, 1), dtype=torch.int64, device=dev)
+    attr_out = torch.empty(max(ea, 1) * fe, dtype=torch.float32, device=dev)
+    col_out = torch.empty(2 * max(ec, 1), dtype=torch.int64, device=dev)
+    ws_bytes = int(lib.tgnn_sublayout_workspace_bytes(n_rows, ea, ec))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    check(lib.tgnn_sublayout_compact(ptr(alive_local), n_rows, ptr(x_pad), fx, ptr(adj) if ea else None, ea, ptr(attr) if ea else None, fe,
+                                     ptr(col) if ec else None, ec, ptr(x_out), ptr(inverse), ptr(adj_out), ptr(attr_out), ptr(col_out),
+                                     ptr(tail[:3]), ptr(err), ptr(ws), ws_bytes, stream))
+    n_own2 = nhi - nlo
+    rows2, ea2, ec2, bad = tail.cpu().tolist()                  # the one sync
+    if bad:
+        raise IndexError("edge index out of range in the shard")
+    kept_halo = inverse[n_own2:rows2].cpu().numpy() - n_own     # old halo slots that survive, ascending
+    halo_ids2 = prefix[np.asarray(shard.halo_ids, dtype=np.int64)[kept_halo]] if rows2 > n_own2 else np.empty(0, dtype=np.int64)
+    owners = np.searchsorted(new_bounds[1:], halo_ids2, side="right")
+    recv_counts = [int(np.count_nonzero(owners == r)) for r in range(world)]
+    new = Shard(rank, world, int(prefix[-1]), nlo, n_own2, halo_ids2, recv_counts, None, None, None, None, None, new_bounds)
+    new_inputs = {"x": x_out[:n_own2], "adj": adj_out[:2 * ea2].view(2, ea2), "attr": attr_out[:ea2 * fe].view(ea2, fe),
+                  "col": col_out[:2 * ec2].view(2, ec2), "send_idx": torch.empty(0, dtype=torch.int32, device=dev)}
+    return new, new_inputs
+
+
+def refresh_send_idx(shard: Shard, inputs: Dict[str, Tensor]) -> None:
+    """inputs["send_idx"] from shard.send_ids (after the communicator's setup ran on a compacted shard)."""
+    send = shard.send_ids if shard.send_ids is not None else []
+    flat = np.concatenate(send) if len(send) else np.empty(0)
+    inputs["send_idx"] = torch.from_numpy(np.ascontiguousarray(flat)).to(torch.int32).to(inputs["x"].device)
+
+
 # ----------------------------------------------------------------------------------------------
 # compute backends
 # ----------------------------------------------------------------------------------------------
@@ -600,6 +666,18 @@ class TorchDistCollectives:
         self.dist.all_to_all_single(recv, send, output_split_sizes=recv_splits, input_split_sizes=send_splits,
                                     group=self.group)
 
+    def allgather(self, t: Tensor) -> List[Tensor]:
+        """Every rank's 1-d tensor (lengths may differ), in rank order."""
+        dist, world = self.dist, self.dist.get_world_size(self.group)
+        lens = torch.zeros(world, dtype=torch.int64, device=t.device)
+        dist.all_gather_into_tensor(lens, torch.tensor([t.numel()], dtype=torch.int64, device=t.device), group=self.group)
+        lens = lens.cpu().tolist()
+        pad = torch.zeros(max(lens), dtype=t.dtype, device=t.device)
+        pad[: t.numel()] = t.reshape(-1)
+        out = torch.empty(world * max(lens), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, pad, group=self.group)
+        return [out[r * max(lens): r * max(lens) + lens[r]] for r in range(world)]
+
 
 class ThreadSimCollectives:
     """P virtual ranks = P Python threads on ONE device and ONE stream (tests): a collective is a rendezvous on a
@@ -625,6 +703,24 @@ class ThreadSimCollectives:
         hub.barrier.wait()
         t.copy_(hub.total)
         hub.barrier.wait()
+
+    def setup(self, shard: Shard) -> None:
+        """The send-list exchange of TorchDistComm.setup among the thread-simulated ranks: every rank posts its halo list and
+        picks, from every peer's list, the rows it owns."""
+        hub = self.hub
+        hub.slots[self.rank] = np.asarray(shard.halo_ids, dtype=np.int64)
+        hub.barrier.wait()
+        lo, hi = node_range(shard.n_total, shard.rank, shard.world, shard.bounds)
+        shard.send_ids = [ids[(ids >= lo) & (ids < hi)] - lo for ids in hub.slots]
+        hub.barrier.wait()
+
+    def allgather(self, t: Tensor) -> List[Tensor]:
+        hub = self.hub
+        hub.slots[self.rank] = t
+        hub.barrier.wait()
+        out = [s.clone() for s in hub.slots]
+        hub.barrier.wait()
+        return out
 
     def alltoall(self, send: Tensor, send_splits, recv: Tensor, recv_splits) -> None:
         hub = self.hub
@@ -696,3 +792,68 @@ class ShardedTilinGNN:
             return self.fused.step()
         self.program = ShardProgram(self.net, self.shard, self.backend, inputs=self.inputs)
         return self.comm.run(self.program)
+
+
+# ----------------------------------------------------------------------------------------------
+# the greedy assembly loop on a layout that stays sharded
+# ----------------------------------------------------------------------------------------------
+def solve_sharded(net, shard: Shard, device, collectives, setup, collide_edge_index: np.ndarray, rccl: "LibraryRccl" = None,
+                  min_nodes_per_rank: int = 64, on_round=None, uniform=None):
+    """`solve_by_probablistic_greedy` (/root/reference/util/algorithms.py:18-62) for ONE RANK of a node-range sharded layout:
+    per round   shard of the unlabelled sub-layout (compact_shard_device: cut locally, on the device)  ->  send lists
+    (`setup(shard)`: the communicator's exchange of halo id lists)  ->  score (FusedShardForward: tgnn_forward_sharded)  ->
+    all ranks' probabilities gathered (`collectives.allgather`)  ->  the reference's acceptance sweep, run by EVERY rank on the
+    same probabilities with the same numpy seed, hence the same decisions everywhere (tilingnn_amd.util.algorithms.HostSweep; it
+    needs the layout's collision edge list `collide_edge_index` [2, Ec] in ORIGINAL numbering on every rank's host)  ->  alive mask.
+    The empty-edge early-out of ML_Solver.predict (ml_solver.py:31-32: no collision or no adjacency edge left -> every remaining
+    tile gets probability 1) is taken when the sub-layout has none on ANY rank (an all-gathered count).
+    When the sub-layout has shrunk below world * min_nodes_per_rank nodes, or a rank's range has emptied, the loop stops
+    sharding: it returns with `sweep.unlabelled` non-empty and the caller finishes the few remaining rounds on one device
+    (finish_on_one_device).  Returns (sweep, rounds): sweep.selection / .order / .unlabelled over the original numbering."""
+    from .util.algorithms import HostSweep
+    world = shard.world
+    n = shard.n_total
+    sweep = HostSweep(n, collide_edge_index, uniform)
+    inputs = HipBackend(device).upload(shard)
+    ids = np.arange(n)
+    rounds = 0
+    while sweep.unlabelled.any():
+        sizes = np.diff(np.asarray(shard.bounds if shard.bounds is not None else even_bounds(shard.n_total, world)))
+        if shard.n_total < world * min_nodes_per_rank or np.any(sizes < 2):
+            break                                               # (every rank sees the same bounds: a collective decision)
+        counts = collectives.allgather(torch.tensor([float(inputs["adj"].shape[1]), float(inputs["col"].shape[1])], device=device))
+        tot = torch.stack(list(counts)).sum(0).cpu().tolist()
+        if tot[0] == 0 or tot[1] == 0:
+            prob = np.ones(shard.n_total)                        # ml_solver.py:31-32
+        else:
+            fwd = FusedShardForward(net, shard, device, collectives, inputs=inputs, rccl=rccl)
+            fwd.two_streams = rccl is not None
+            own = fwd.step()[:, 0].contiguous()
+            prob = torch.cat([p.reshape(-1) for p in collectives.allgather(own)]).cpu().numpy()
+        if on_round is not None:
+            on_round(ids, prob)
+        killed = sweep.round(ids, prob)
+        rounds += 1
+        new_ids = sweep.ids()
+        if new_ids.size == 0:
+            break
+        alive_rel = np.isin(ids, new_ids, assume_unique=True)
+        shard, inputs = compact_shard_device(shard, inputs, alive_rel)
+        setup(shard)
+        refresh_send_idx(shard, inputs)
+        ids = new_ids
+    return sweep, rounds
+
+
+def finish_on_one_device(ml_solver, origin_layout, sweep):
+    """The tail of a sharded solve: the rounds that are left once the sub-layout is too small to shard, on one device -- the
+    single-GPU loop of tilingnn_amd.util.algorithms continued from `sweep`'s state (same RNG stream, same decisions on every rank
+    that runs it)."""
+    from .util.algorithms import DeviceLayout, SubLayoutBuilder
+    origin = origin_layout if isinstance(origin_layout, DeviceLayout) else DeviceLayout.upload(origin_layout, ml_solver.device)
+    builder = SubLayoutBuilder(origin)
+    dev = origin.node_feature.device
+    while sweep.unlabelled.any():
+        alive = torch.from_numpy(sweep.unlabelled.astype(np.int32)).to(dev)
+        sweep.round(sweep.ids(), ml_solver.predict(builder.build(alive)))
+    return sweep

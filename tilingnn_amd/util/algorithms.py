@@ -89,51 +89,75 @@ class SubLayoutBuilder:
                             self.col_out[:2 * ec2].view(2, ec2), self.inverse[:n2])
 
 
+class HostSweep:
+    """The state and the acceptance sweep of the reference's loop (algorithms.py:23-54), over the ORIGINAL node numbering: the
+    running geometric mean of the probabilities (:33-34), the descending walk that stops at the first node labelled in this
+    round (:41-48), the test against numpy's global RNG stream (:51), label_collision_neighbor (:196-207).  Shared by the
+    single-GPU loop below and by tilingnn_amd.dist.solve_sharded (every rank runs the same sweep on the gathered probabilities
+    with the same seed, so every rank takes the same decisions)."""
+
+    def __init__(self, n: int, collide_edge_index: np.ndarray, uniform=None):
+        # uniform: the draw of :51; default numpy's GLOBAL stream, as the reference (np.random.RandomState(seed).uniform gives the
+        # stream np.random.seed(seed) would: what thread-simulated ranks, which share one interpreter, use instead)
+        self.uniform = uniform if uniform is not None else np.random.uniform
+        col = np.asarray(collide_edge_index).reshape(2, -1)
+        self.n, self.has_col = n, bool(col.size)
+        if self.has_col:                                        # collision neighbours in edge order (algorithms.py:199)
+            by_src = np.argsort(col[0], kind="stable")
+            self.starts = np.searchsorted(col[0][by_src], np.arange(n + 1))
+            self.nbr = col[1][by_src]
+        self.prob_saved = np.ones(n)                            # SelectionSolution.unlabelled_nodes (:285)
+        self.unlabelled = np.ones(n, dtype=bool)
+        self.selection = np.zeros(n)
+        self.order = []
+        self.round_cnt = 1
+
+    def ids(self) -> np.ndarray:
+        return np.flatnonzero(self.unlabelled)
+
+    def round(self, ids: np.ndarray, prob) -> list:
+        """One round: `prob` = the network's probabilities of the nodes `ids` (ascending original numbers).  Returns the original
+        numbers of the nodes labelled in this round (selected ones and their collision neighbours)."""
+        prob = np.asarray(prob, dtype=np.float64).reshape(-1)
+        prob_per_node = np.power(np.power(self.prob_saved[ids], self.round_cnt - 1) * prob, 1 / self.round_cnt)     # (:33-34)
+        self.prob_saved[ids] = prob_per_node
+        unlabelled, killed = self.unlabelled, []
+        for idx in np.argsort(-prob_per_node):                  # (:41)
+            origin_idx = ids[idx]
+            if not unlabelled[origin_idx]:                      # (:47-48)
+                break
+            if np.exp((prob_per_node[idx] - 1) * 1.0) > self.uniform():     # (:51)
+                unlabelled[origin_idx] = False
+                self.selection[origin_idx] = 1
+                self.order.append(int(origin_idx))
+                killed.append(origin_idx)
+                if self.has_col:                                # label_collision_neighbor (:196-207)
+                    for v in self.nbr[self.starts[origin_idx]:self.starts[origin_idx + 1]]:
+                        if unlabelled[v]:
+                            unlabelled[v] = False
+                            killed.append(v)
+        self.round_cnt += 1
+        return killed
+
+
 def solve_by_probablistic_greedy(ml_solver, origin_layout, score_fn=None, on_round=None):
     """algorithms.py:18-62.  `origin_layout`: BrickLayout-like numpy arrays (uploaded once) or a DeviceLayout."""
     device = ml_solver.device
     origin = origin_layout if isinstance(origin_layout, DeviceLayout) else DeviceLayout.upload(origin_layout, device)
     n = int(origin.node_feature.shape[0])
-    col_host = origin.collide_edge_index.cpu().numpy()
-    if col_host.size:                                           # collision neighbours in edge order (algorithms.py:199)
-        by_src = np.argsort(col_host[0], kind="stable")
-        starts = np.searchsorted(col_host[0][by_src], np.arange(n + 1))
-        nbr = col_host[1][by_src]
+    sweep = HostSweep(n, origin.collide_edge_index.cpu().numpy())
     builder = SubLayoutBuilder(origin)
-    prob_saved = np.ones(n)                                     # SelectionSolution.unlabelled_nodes (:285)
-    unlabelled = np.ones(n, dtype=bool)
     alive_dev = torch.ones(n, dtype=torch.int32, device=origin.node_feature.device)
-    selection = np.zeros(n)
-    order = []
-    round_cnt = 1
-    while unlabelled.any():
+    while sweep.unlabelled.any():
         temp_layout = builder.build(alive_dev)
-        ids = np.flatnonzero(unlabelled)                        # == temp_layout.inverse_index (kept on the device)
+        ids = sweep.ids()                                       # == temp_layout.inverse_index (kept on the device)
         if on_round is not None:
             on_round(temp_layout)
-        prob = np.asarray(ml_solver.predict(temp_layout), dtype=np.float64).reshape(-1)
-        prob_per_node = np.power(np.power(prob_saved[ids], round_cnt - 1) * prob, 1 / round_cnt)     # (:33-34)
-        prob_saved[ids] = prob_per_node
-        killed = []
-        for idx in np.argsort(-prob_per_node):                  # (:41)
-            origin_idx = ids[idx]
-            if not unlabelled[origin_idx]:                      # (:47-48)
-                break
-            if np.exp((prob_per_node[idx] - 1) * 1.0) > np.random.uniform():     # (:51)
-                unlabelled[origin_idx] = False
-                selection[origin_idx] = 1
-                order.append(int(origin_idx))
-                killed.append(origin_idx)
-                if col_host.size:                               # label_collision_neighbor (:196-207)
-                    for v in nbr[starts[origin_idx]:starts[origin_idx + 1]]:
-                        if unlabelled[v]:
-                            unlabelled[v] = False
-                            killed.append(v)
+        killed = sweep.round(ids, ml_solver.predict(temp_layout))
         if killed:
             alive_dev[torch.from_numpy(np.asarray(killed, dtype=np.int64)).to(alive_dev.device)] = 0
-        round_cnt += 1
-    score = create_score(selection, origin_layout, score_fn, device)
-    return selection, score, order
+    score = create_score(sweep.selection, origin_layout, score_fn, device)
+    return sweep.selection, score, sweep.order
 
 
 def solve_by_device_greedy(ml_solver, origin_layout, seed=0, score_fn=None, on_round=None, max_rounds=100000):
