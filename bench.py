@@ -268,6 +268,11 @@ def main():
     ap.add_argument("--no-extra-sizes", action="store_true", help="skip the 500k / 2M-node single-GPU lines")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the sharded (RCCL) schedule even at world size 1 (exercises the multi-GPU code path)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default, the driver's mode): the workload PER GPU is fixed; strong: the TOTAL is fixed and split over the ranks")
+    ap.add_argument("--config", choices=["headline", "4", "5"], default="headline",
+                    help="headline: 100k nodes / 1M + 1.25M edges; 4 / 5: SURVEY 8d's fixed totals (500k / 6M + 7.5M, tile_count 2, seed 3; "
+                         "2M / 20M + 25M, tile_count 1, seed 4) -- meant for --scaling strong over 4 / 8 GPUs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -300,10 +305,17 @@ def main():
     from tilingnn_amd.weights import make_state_dict
 
     scale = args.nodes_per_gpu / NODES_PER_GPU
-    n_total = args.nodes_per_gpu * world
-    ea_total, ec_total = int(ADJ_PER_GPU * scale) * world, int(COL_PER_GPU * scale) * world
-    sg = make_super_graph(n_total, ea_total, ec_total, tile_count=TILE_COUNT, n_edge_types=N_TYPES, seed=2)
-    fe, fx = 2 + N_TYPES, TILE_COUNT + 1
+    # the workload: (nodes, adjacency edges, collision edges) of ONE unit, tile_count, seed; weak scaling: one unit per GPU,
+    # strong scaling: one unit in all, node-range sharded over the ranks
+    unit = {"headline": (args.nodes_per_gpu, int(ADJ_PER_GPU * scale), int(COL_PER_GPU * scale), TILE_COUNT, 2),
+            "4": (500_000, 6_000_000, 7_500_000, 2, 3), "5": (2_000_000, 20_000_000, 25_000_000, 1, 4)}[args.config]
+    mult = world if args.scaling == "weak" else 1
+    n_total, ea_total, ec_total = unit[0] * mult, unit[1] * mult, unit[2] * mult
+    tile_count = unit[3]
+    if args.config != "headline":
+        args.no_extra_sizes = args.no_train_step = True            # (the side measurements belong to the headline workload)
+    sg = make_super_graph(n_total, ea_total, ec_total, tile_count=tile_count, n_edge_types=N_TYPES, seed=unit[4])
+    fe, fx = 2 + N_TYPES, tile_count + 1
     net = TilinGNN(adj_edge_features_dim=fe, network_depth=DEPTH, network_width=WIDTH, node_features_dim=fx)
     net.load_state_dict(make_state_dict(fe, DEPTH, WIDTH, 1, fx, seed=0), strict=True)
     net = net.to(dev).train()               # inference in train mode, as ml_solver.py:131 leaves it
@@ -483,7 +495,7 @@ def main():
                    "value": n3 / (res3["ms_per_step"] * 1e-3), "cached_layout_ms": res3["cached_layout_ms"],
                    "whole_forward": {"algorithmic_bytes": b3, "frac_of_hbm_peak": b3 / (res3["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
                    "nnconv_algorithmic_bytes_per_launch": nnconv_bytes(n3, ea3, N_TYPES, c=64, s=2),
-                   "profile": "profiles/r02_config3_kernel_stats.txt (rocprofv3 --kernel-trace --stats of scratch/time_config3.py), "
+                   "profile": "profiles/r04_config3_kernel_stats.txt (rocprofv3 --kernel-trace --stats of scratch/run_config3_only.py), "
                               "profiles/r02_config3_pmc.txt (HBM / MFMA counters of nnconv64_bf16_cols_kernel)"}
         del net3, x3, adj3, attr3, col3
         torch.cuda.empty_cache()
@@ -675,11 +687,13 @@ def main():
             "timing": {"value_from": "median step time (event spacing over the K timed steps, max over ranks)",
                        "ms_per_step_median": median_ms, "ms_per_step_mean": mean_ms, "value_mean": n_total / (mean_ms * 1e-3),
                        "ms_per_step_min": per_step_ms[0], "ms_per_step_max": per_step_ms[-1]},
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"TilinGNN.forward on a seeded banded super-graph: {args.nodes_per_gpu} nodes / "
-                                   f"{int(ADJ_PER_GPU * scale)} adjacency edges / {int(COL_PER_GPU * scale)} collision edges "
-                                   f"per GPU, 30-60-90 (tile_count 2), T=13 edge types, width 32, depth 20, "
-                                   f"train-mode BatchNorm, graph prep included",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"TilinGNN.forward on a seeded banded super-graph: {unit[0]} nodes / "
+                                   f"{unit[1]} adjacency edges / {unit[2]} collision edges "
+                                   f"{'per GPU' if args.scaling == 'weak' else 'IN ALL (strong scaling: split over the ranks)'}, "
+                                   f"tile_count {tile_count}, T=13 edge types, width 32, depth 20, "
+                                   f"train-mode BatchNorm, graph prep included"
+                                   + ("" if args.config == "headline" else f" (BASELINE config {args.config}, SURVEY 8d)"),
                        "n_nodes": n_total, "n_adj_edges": ea_total, "n_col_edges": ec_total,
                        "parallelism": "single GPU" if not sharded else f"node-range shards x{world}, one all-to-all per layer (halo rows + BN sums) over RCCL"},
             "roofline": roofline,

@@ -700,13 +700,15 @@ int tgnn_gin64_bf16_fwd(const void *a_bf16, const float *in_stat, const int32_t 
                         const float *w3, const float *b3, int64_t n_nodes, int32_t act, void *out_bf16,
                         void *z_scratch_bf16, double *bn_partial, int32_t *n_partials_host, tgnn_stream_t stream);
 /* CollConv.forward (coll_conv.py:24-30) incl. its train-mode BatchNorm, the OUTPUT stored as bf16 (the pre-BatchNorm sigmoid
- * columns vary by ~5e-3: 16-bit storage in front of the BatchNorm would destroy them).  Two passes over the MLP (statistics,
- * then normalise + store).  stat_scratch: 4 x 64 floats (the record); bn_partial: TGNN_BN_MAX_PARTIALS x 128 doubles. */
+ * columns vary by ~5e-3: 16-bit storage in front of the BatchNorm would destroy them).  One pass over the MLP leaves the
+ * statistics and the fp32 rows in pre_scratch_f32 [N][64]; an element-wise pass normalises, rounds and stores.  stat_scratch:
+ * 4 x 64 floats (the record); bn_partial: TGNN_BN_MAX_PARTIALS x 128 doubles. */
 int tgnn_collconv64_bf16_fwd(const void *h2_in_bf16, const int32_t *rowptr, const int32_t *col_src, const float *eps,
                              const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
                              const float *b3, const float *gamma, const float *beta, float *running_mean,
                              float *running_var, int64_t *num_batches_tracked, int64_t n_nodes, void *out_bf16,
-                             void *z_scratch_bf16, float *stat_scratch, double *bn_partial, tgnn_stream_t stream);
+                             void *z_scratch_bf16, float *pre_scratch_f32, float *stat_scratch, double *bn_partial,
+                             tgnn_stream_t stream);
 /* stat2 == NULL: a2 holds BN2's output already (tgnn_collconv64_bf16_fwd) */
 int tgnn_merge_bf16_fwd(const void *a1_bf16, const float *stat1, const void *a2_bf16, const float *stat2,
                         const void *resid_bf16, int64_t n_nodes, int32_t c, void *out_bf16, tgnn_stream_t stream);

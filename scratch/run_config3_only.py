@@ -1,7 +1,7 @@
 """Five bf16-storage forwards at BASELINE config 3 (100k / 1M / 1.25M, tile_count 4, width 64), cached layout: the process
 rocprofv3 --pmc passes are taken on."""
 import sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tilingnn_amd import TilinGNN
 from tilingnn_amd.synth import make_super_graph
 from tilingnn_amd.weights import make_state_dict

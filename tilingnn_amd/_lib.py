@@ -181,7 +181,7 @@ def _load() -> C.CDLL:
         "tgnn_nnconv64_image_elems": (sz, [i32]),
         "tgnn_nnconv64_bf16_fwd": (C.c_int, [p, i64, p, p, p, p, i32, p, p, i64, i32, p, p, p, pi32, p]),
         "tgnn_gin64_bf16_fwd": (C.c_int, [p, p, p, p, p, p, p, p, p, p, p, i64, i32, p, p, p, pi32, p]),
-        "tgnn_collconv64_bf16_fwd": (C.c_int, [p, p, p, p, p, p, p, p, p, p, p, p, p, p, p, i64, p, p, p, p, p]),
+        "tgnn_collconv64_bf16_fwd": (C.c_int, [p, p, p, p, p, p, p, p, p, p, p, p, p, p, p, i64, p, p, p, p, p, p]),
         "tgnn_merge_bf16_fwd": (C.c_int, [p, p, p, p, p, i64, i32, p, p]),
         "tgnn_dense_bf16_slots_fwd": (C.c_int, [p, i64, i32, p, p, i64, i32, i32, p, p, p, pi32, p]),
         "tgnn_forward_bf16_workspace_bytes": (sz, [C.POINTER(ModelDims), i64, i32]),

@@ -46,6 +46,26 @@ __global__ void bn_apply_bf16_kernel(const float *__restrict__ v, const float *_
     }
 }
 
+// the same for 64 columns, 8 per thread (a thread keeps its columns: the grid stride is a multiple of 64), the record through
+// registers: BatchNorm of the collision branch applied to the fp32 rows its MLP left (gin64_bf16_mlp_kernel<3>)
+__global__ __launch_bounds__(256) void bn_apply64_bf16_kernel(const float *__restrict__ v, const float *__restrict__ stat, int64_t n8,
+                                                              __bf16 *__restrict__ out) {
+    const int c0 = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % 8) * 8;
+    float mh[8], ml[8], g[8], b[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        mh[k] = stat[c0 + k]; ml[k] = stat[kC + c0 + k]; g[k] = stat[2 * kC + c0 + k]; b[k] = stat[3 * kC + c0 + k];
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const float4 x0 = reinterpret_cast<const float4 *>(v)[2 * i], x1 = reinterpret_cast<const float4 *>(v)[2 * i + 1];
+        const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (__bf16)bn_apply1(x[k], mh[k], ml[k], g[k], b[k]);
+        reinterpret_cast<bf16x8 *>(out)[i] = o;
+    }
+}
+
 __global__ void f32_to_bf16_kernel(const float *__restrict__ v, int64_t total, __bf16 *__restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = (__bf16)v[i];
@@ -118,7 +138,7 @@ template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, 4) void nnconv64_bf16_cols_kernel(
     const __bf16 *__restrict__ h, uint32_t h_bytes, const int *__restrict__ tile_col_ptr, const int *__restrict__ col_meta,
     const int *__restrict__ col_src, const __bf16 *__restrict__ wimg, int n_types, const float *__restrict__ bias,
-    int64_t n, int act, __bf16 *__restrict__ out, double *__restrict__ bn_partial) {
+    int64_t n, int act, __bf16 *__restrict__ out, double *__restrict__ bn_partial, GinFin fin) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *wl = lds;                                        // [(T+1)][8 fragments][64 lanes] x 16 B
     float *bias_s = lds + (n_types + 1) * kW64Floats;       // [64]
@@ -285,21 +305,25 @@ __global__ __launch_bounds__(WAVES * 64, 4) void nnconv64_bf16_cols_kernel(
             for (int w = 0; w < WAVES; ++w)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc += red[((int64_t)w * 64 + q * 16 + j) * 8 + which * 4 + mb];
-            bn_partial[(int64_t)blockIdx.x * 128 + tid] = acc;
+            if (fin.counter) st_partial_sc1(bn_partial, (int64_t)blockIdx.x * 128 + tid, acc);
+            else bn_partial[(int64_t)blockIdx.x * 128 + tid] = acc;
         }
+        // [r4] the BatchNorm's record by the last block to finish instead of a 1-block launch behind the kernel (6.7 us on the chain)
+        if (fin.counter) bn_fold_finish<kC>(fin, bn_partial, red + (size_t)WAVES * 64 * 8);
     }
 }
 
 static size_t nnconv64_lds_bytes(int n_types, int waves) {
     const size_t a = ((size_t)(n_types + 1) * kW64Floats + kC + (size_t)waves * kStage64) * sizeof(float);
-    const size_t b = (size_t)waves * 64 * 8 * sizeof(double);
+    const size_t b = (size_t)waves * 64 * 8 * sizeof(double) + bn_fold_scratch_bytes(kC);
     return a > b ? a : b;
 }
 constexpr size_t kMaxLds64 = 160 * 1024 - 256;
 
 static int launch_nnconv64(const __bf16 *h, int64_t n_src_rows, const int32_t *tile_col_ptr, const int32_t *col_meta,
                            const int32_t *col_src, const __bf16 *wimg, int32_t n_types, const float *bias, int64_t n_nodes,
-                           int32_t act, __bf16 *out, double *bn_partial, int32_t *n_partials_host, hipStream_t s) {
+                           int32_t act, __bf16 *out, double *bn_partial, int32_t *n_partials_host, hipStream_t s,
+                           const GinFin *fin = nullptr) {
     constexpr int WAVES = 16;
     auto kern = nnconv64_bf16_cols_kernel<WAVES>;
     static LdsOptIn site;
@@ -310,8 +334,14 @@ static int launch_nnconv64(const __bf16 *h, int64_t n_src_rows, const int32_t *t
     if (blocks > cap) blocks = cap;
     if (blocks >= 8) blocks &= ~(int64_t)7;
     if (blocks < 1) blocks = 1;
+    GinFin f{};
+    if (fin && bn_partial) {
+        f = *fin;
+        f.job.partials = bn_partial;
+        f.job.n_partials = (int)blocks;
+    }
     kern<<<(unsigned)blocks, WAVES * 64, nnconv64_lds_bytes(n_types, WAVES), s>>>(
-        h, (uint32_t)(n_src_rows * 128), tile_col_ptr, col_meta, col_src, wimg, n_types, bias, n_nodes, act, out, bn_partial);
+        h, (uint32_t)(n_src_rows * 128), tile_col_ptr, col_meta, col_src, wimg, n_types, bias, n_nodes, act, out, bn_partial, f);
     if (n_partials_host) *n_partials_host = (int32_t)blocks;
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
@@ -380,7 +410,9 @@ __global__ __launch_bounds__(256) void gin64_bf16_aggregate_kernel(
 // three cross terms, fp32 accumulation; the input z is bf16 already: two terms), and (2) what is STORED is the
 // BatchNorm's OUTPUT (unit variance: bf16's relative precision is harmless there), which takes two passes over the MLP
 // because the statistics are global: MODE 1 = statistics of the fp32 outputs only, MODE 2 = recompute, normalise with the
-// finished record, round, store.  MODE 0 = the GINConv seam by itself (pre-BatchNorm output rounded to bf16 + its sums).
+// finished record, round, store; MODE 3 [r4] = statistics AND the fp32 outputs kept in a scratch array, so that a light
+// element-wise pass (bn_apply64_bf16_kernel: same formula on the same fp32 values, the same bits) replaces the second MLP pass
+// (41 us per layer on what had become the forward's critical chain; the scratch costs 25.6 MB written + read per 100 000 nodes).  MODE 0 = the GINConv seam by itself (pre-BatchNorm output rounded to bf16 + its sums).
 constexpr int kMlp64Waves = 8, kMlp64Threads = kMlp64Waves * 64;
 __device__ __forceinline__ int kf64(int q, int e) { return e < 4 ? 4 * q + e : 16 + 4 * q + (e - 4); }
 __device__ __forceinline__ void split2(const float (&x)[8], bf16x8 &hi, bf16x8 &lo) {
@@ -396,7 +428,7 @@ __global__ __launch_bounds__(kMlp64Threads, 2) void gin64_bf16_mlp_kernel(
     const __bf16 *__restrict__ z, const float *__restrict__ w1, const float *__restrict__ b1,
     const float *__restrict__ w2, const float *__restrict__ b2, const float *__restrict__ w3,
     const float *__restrict__ b3, int64_t n, int act, const float *__restrict__ out_stat, __bf16 *__restrict__ out,
-    double *__restrict__ bn_partial) {
+    double *__restrict__ bn_partial, float *__restrict__ out32 = nullptr, GinFin fin = GinFin{}) {
     __shared__ bf16x8 W1s[2][2 * 2 * 64];       // [plane hi / lo][M block 2][K chunk 2][lane]   K natural (Z comes from memory)
     __shared__ bf16x8 W2s[2][4 * 64];           // [plane][M block 4][lane]                      K = 32 in kf order
     __shared__ bf16x8 W3s[2][4 * 2 * 64];       // [plane][M block 4][K chunk 2][lane]           K = 64 in kf order per chunk
@@ -510,13 +542,18 @@ __global__ __launch_bounds__(kMlp64Threads, 2) void gin64_bf16_mlp_kernel(
                     v = bn_apply1(v, St[c], St[kC + c], St[2 * kC + c], St[3 * kC + c]);
                 }
                 ob[r] = (__bf16)v;
+                if (MODE == 3) o[r] = v;
                 if (MODE != 2 && valid) {
                     const double dv = MODE == 0 ? (double)(float)ob[r] : (double)v;
                     cs[4 * mb + r] += dv;
                     cq[4 * mb + r] += dv * dv;
                 }
             }
-            if (MODE != 1 && valid) *reinterpret_cast<bf16x4 *>(out + row * kC + 16 * mb + 4 * fq) = ob;
+            if (MODE == 3) {
+                if (valid) *reinterpret_cast<f32x4 *>(out32 + row * kC + 16 * mb + 4 * fq) = o;   // the fp32 rows the BatchNorm is applied to
+            } else if (MODE != 1 && valid) {
+                *reinterpret_cast<bf16x4 *>(out + row * kC + 16 * mb + 4 * fq) = ob;
+            }
         }
     }
     if (MODE != 2 && bn_partial) {
@@ -539,7 +576,12 @@ __global__ __launch_bounds__(kMlp64Threads, 2) void gin64_bf16_mlp_kernel(
         if (tid < 128) {
             double tot = 0.0;
             for (int w = 0; w < kMlp64Waves; ++w) tot += red[w * 128 + tid];
-            bn_partial[(int64_t)blockIdx.x * 128 + tid] = tot;
+            if (MODE == 3 && fin.counter) st_partial_sc1(bn_partial, (int64_t)blockIdx.x * 128 + tid, tot);
+            else bn_partial[(int64_t)blockIdx.x * 128 + tid] = tot;
+        }
+        if (MODE == 3 && fin.counter) {                       // the record by the last block to finish (tgnn_common.h)
+            __shared__ __attribute__((aligned(16))) unsigned char fold[bn_fold_scratch_bytes(kC)];
+            bn_fold_finish<kC>(fin, bn_partial, reinterpret_cast<double *>(fold));
         }
     }
 }
@@ -672,7 +714,8 @@ __global__ __launch_bounds__(kDbThreads) void dense_bf16_slots_kernel(const __bf
 // ------------------------------------------------------------------------------------------ workspace of the forward
 struct Ws64 {
     __bf16 *mid, *a1, *a2[2], *z, *wimg, *wfin;
-    float *t0, *ainit, *f1, *f2, *f3, *f4, *wtab;
+    float *t0, *ainit, *f1, *f2, *f3, *f4, *wtab, *pre32;
+    unsigned *ctr;                                            // [0], [16]: the folded finalizes' tickets (bn_fold_finish)
     double *part1, *part2, *partf;
     float *stat1, *stat2[2], *stat_i[2], *stat_f[4];
     size_t bytes;
@@ -688,6 +731,8 @@ static Ws64 carve64(const tgnn_model_dims &d, int64_t n, int32_t n_types, void *
     w.z = cv.take<__bf16>((size_t)n * kC);
     w.wimg = cv.take<__bf16>((size_t)D * (n_types + 1) * kC * kC);
     w.wfin = cv.take<__bf16>((size_t)256 * kC * (D + 1));
+    w.pre32 = cv.take<float>((size_t)n * kC);
+    w.ctr = cv.take<unsigned>(64);
     w.t0 = cv.take<float>((size_t)n * kC);
     w.ainit = cv.take<float>((size_t)n * kC);
     w.f1 = cv.take<float>((size_t)n * 256);
@@ -785,18 +830,27 @@ static int gin64_launch(const __bf16 *a, const float *in_stat, const int32_t *ro
 static int collconv64_launch(const __bf16 *h2_in, const int32_t *rowptr, const int32_t *col_src, const float *eps,
                              const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
                              const float *b3, const BnJob &bn, int64_t n, int64_t n_total, float bn_eps, float momentum,
-                             __bf16 *out, __bf16 *z, double *bn_partial, hipStream_t s) {
+                             __bf16 *out, __bf16 *z, float *pre32, double *bn_partial, hipStream_t s, unsigned *fold_counter = nullptr) {
     gin64_bf16_aggregate_kernel<<<gin64_agg_blocks(n), 256, 0, s>>>(h2_in, nullptr, rowptr, col_src, eps, n, z);
     const int blocks = gin64_mlp_blocks(n);
-    gin64_bf16_mlp_kernel<1><<<blocks, kMlp64Threads, 0, s>>>(z, w1, b1, w2, b2, w3, b3, n, TGNN_ACT_LEAKY_RELU, nullptr, nullptr,
-                                                             bn_partial);
-    BnJobs jobs{};
-    jobs.job[0] = bn;
-    jobs.job[0].partials = bn_partial;
-    jobs.job[0].n_partials = blocks;
-    launch_bn_finalize(jobs, 1, 0, kC, n_total, bn_eps, momentum, s);
-    gin64_bf16_mlp_kernel<2><<<blocks, kMlp64Threads, 0, s>>>(z, w1, b1, w2, b2, w3, b3, n, TGNN_ACT_LEAKY_RELU, bn.stat, out,
-                                                             nullptr);
+    // one pass over the MLP: statistics + the fp32 rows (pre32); the BatchNorm is applied to those by an element-wise pass.
+    // fold_counter (a zeroed device word): the record is written by the MLP kernel's last block, no finalize launch
+    GinFin fin{};
+    fin.counter = fold_counter;
+    fin.job = bn;
+    fin.job.partials = bn_partial;
+    fin.job.n_partials = blocks;
+    fin.n_total = n_total;
+    fin.eps = bn_eps;
+    fin.momentum = momentum;
+    gin64_bf16_mlp_kernel<3><<<blocks, kMlp64Threads, 0, s>>>(z, w1, b1, w2, b2, w3, b3, n, TGNN_ACT_LEAKY_RELU, nullptr, nullptr,
+                                                             bn_partial, pre32, fin);
+    if (!fold_counter) {
+        BnJobs jobs{};
+        jobs.job[0] = fin.job;
+        launch_bn_finalize(jobs, 1, 0, kC, n_total, bn_eps, momentum, s);
+    }
+    bn_apply64_bf16_kernel<<<ew_grid64(n * kC / 8), 256, 0, s>>>(pre32, bn.stat, n * kC / 8, out);
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
 }
@@ -820,15 +874,16 @@ extern "C" int tgnn_collconv64_bf16_fwd(const void *h2_in_bf16, const int32_t *r
                                         const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
                                         const float *b3, const float *gamma, const float *beta, float *running_mean,
                                         float *running_var, int64_t *num_batches_tracked, int64_t n_nodes, void *out_bf16,
-                                        void *z_scratch_bf16, float *stat_scratch, double *bn_partial, tgnn_stream_t stream) {
+                                        void *z_scratch_bf16, float *pre_scratch_f32, float *stat_scratch, double *bn_partial,
+                                        tgnn_stream_t stream) {
     DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_nodes >= 2, "train-mode BatchNorm needs more than one row");
     TGNN_CHECK_ARG(h2_in_bf16 && rowptr && eps && w1 && b1 && w2 && b2 && w3 && b3 && gamma && beta && out_bf16 && z_scratch_bf16 &&
-                       stat_scratch && bn_partial, "null pointer");
+                       pre_scratch_f32 && stat_scratch && bn_partial, "null pointer");
     TGNN_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running stats come in pairs");
     const BnJob bn{nullptr, 0, nullptr, gamma, beta, running_mean, running_var, num_batches_tracked, stat_scratch};
     return collconv64_launch(static_cast<const __bf16 *>(h2_in_bf16), rowptr, col_src, eps, w1, b1, w2, b2, w3, b3, bn, n_nodes,
-                             n_nodes, 1e-5f, 0.1f, static_cast<__bf16 *>(out_bf16), static_cast<__bf16 *>(z_scratch_bf16),
+                             n_nodes, 1e-5f, 0.1f, static_cast<__bf16 *>(out_bf16), static_cast<__bf16 *>(z_scratch_bf16), pre_scratch_f32,
                              bn_partial, static_cast<hipStream_t>(stream));
 }
 
@@ -956,6 +1011,7 @@ extern "C" int tgnn_forward_bf16(const tgnn_model_dims *dims, const void *const 
     finalize1(w.partf, np1, kC, P.bn(P.init(1) + 2), w.stat_i[1]);
     bn_apply_bf16_kernel<<<ew_grid64(n * kC), 256, 0, s>>>(w.ainit, w.stat_i[1], n, kC, w.mid);
     // ---- main loop.  a2[i & 1] holds h2_i = the collision branch's BatchNorm OUTPUT (stored normalised, see the MLP kernel)
+    TGNN_CHECK_HIP(hipMemsetAsync(w.ctr, 0, 64 * sizeof(unsigned), s));
     if (s2) {
         TGNN_CHECK_HIP(hipEventRecord(ev[0], s));
         TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[0], 0));
@@ -968,14 +1024,17 @@ extern "C" int tgnn_forward_bf16(const tgnn_model_dims *dims, const void *const 
         if (s2 && i >= 2) TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[1 + kMaxDepth + i - 2], 0));   // a2[i & 1] was read by merge_{i-2}
         TGNN_TRY64(collconv64_launch(h2_in, graph->col_rowptr, graph->col_src, P.f(b + 13), P.f(b + 14), P.f(b + 15), P.f(b + 16),
                                      P.f(b + 17), P.f(b + 18), P.f(b + 19), bn_job(nullptr, 0, P.bn(b + 20), w.stat2[i & 1]), n, n,
-                                     eps, momentum, w.a2[i & 1], w.z, w.part2, sc));
+                                     eps, momentum, w.a2[i & 1], w.z, w.pre32, w.part2, sc, w.ctr));
         if (s2) TGNN_CHECK_HIP(hipEventRecord(ev[1 + i], s2));
+        GinFin fin1{};
+        fin1.counter = w.ctr + 16;
+        fin1.job = bn_job(nullptr, 0, P.bn(b + 8), w.stat1);
+        fin1.n_total = n;
+        fin1.eps = eps;
+        fin1.momentum = momentum;
         TGNN_TRY64(launch_nnconv64(h1, n, graph->nn_tile_col_ptr, graph->nn_col_meta, graph->nn_col_src,
                                    w.wimg + (size_t)i * (T + 1) * kC * kC, T, P.f(b + 7), n, TGNN_ACT_LEAKY_RELU, w.a1, w.part1,
-                                   &np1, s));
-        BnJobs jobs{};
-        jobs.job[0] = bn_job(w.part1, np1, P.bn(b + 8), w.stat1);
-        launch_bn_finalize(jobs, 1, 0, kC, n, eps, momentum, s);
+                                   &np1, s, &fin1));
         if (s2) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[1 + i], 0));
         const __bf16 *resid = i >= 2 ? w.mid + (size_t)(i - 2) * n * kC : nullptr;
         merge_bf16_kernel<<<ew_grid64(n * kC / 8), 256, 8 * kC * sizeof(float), s>>>(w.a1, w.stat1, w.a2[i & 1], nullptr, resid, n * kC / 8, kC,

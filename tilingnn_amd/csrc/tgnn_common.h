@@ -291,6 +291,55 @@ struct GinFin {
     int64_t n_total;
     float eps, momentum;
 };
+// The same for any producer whose blocks leave one partial row of 2 F doubles each (F <= blockDim.x): called by ALL threads of
+// every block after the block's row has been stored with st_partial_sc1 (write-through: another block reads it).  scratch =
+// (16 + 1) * 2 F doubles of LDS + one word behind them.  bn_finalize_kernel's tree, the same bits.
+__device__ __forceinline__ void st_partial_sc1(double *bn_partial, int64_t idx, double v) {
+    using u32x2_ = __attribute__((ext_vector_type(2))) unsigned int;
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(bn_partial, 0, (int)0x80000000u, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, v), prs, (uint32_t)idx * 8u, 0, 16);
+}
+constexpr size_t bn_fold_scratch_bytes(int f) { return (size_t)17 * 2 * f * sizeof(double) + 16; }
+template <int F>
+__device__ __forceinline__ void bn_fold_finish(const GinFin &fin, double *bn_partial, double *scratch) {
+    using u32x2_ = __attribute__((ext_vector_type(2))) unsigned int;
+    constexpr int kRow = 2 * F;
+    double *fred = scratch, *ftot = scratch + 16 * kRow;
+    unsigned *ticket = reinterpret_cast<unsigned *>(ftot + kRow);
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this block's row has been written through before its ticket
+    __syncthreads();
+    if (tid == 0) *ticket = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*ticket != gridDim.x - 1) return;                    // (uniform)
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(bn_partial, 0, (int)0x80000000u, 0x00020000);
+    const int np = (int)gridDim.x;
+    for (int item = tid; item < 16 * kRow; item += nthr) {
+        const int j = item % kRow, g = item / kRow;
+        double acc = 0.0;
+        for (int p = g; p < np; p += 8 * 16) {               // eight coherent loads in flight (rows past the end fetch nothing)
+            u32x2_ v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int pp = p + u * 16;
+                v[u] = __builtin_amdgcn_raw_buffer_load_b64(prs, pp < np ? ((uint32_t)pp * (uint32_t)kRow + (uint32_t)j) * 8u : 0x80000000u, 0, 16);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (p + u * 16 < np) acc += __builtin_bit_cast(double, v[u]);
+        }
+        fred[g * kRow + j] = acc;
+    }
+    __syncthreads();
+    for (int j = tid; j < kRow; j += nthr) {
+        double t = 0.0;
+        for (int gg = 0; gg < 16; ++gg) t += fred[gg * kRow + j];
+        ftot[j] = t;
+    }
+    __syncthreads();
+    bn_record_from_sums(fin.job, ftot, F, fin.n_total, fin.eps, fin.momentum);
+    if (tid == 0) __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // one block per job (1 or 2 BatchNorms of the same width finalised by one launch); bn_merge.hip
 void launch_bn_finalize(const BnJobs &jobs, int n_jobs, int mode, int f, int64_t n_total, float eps, float momentum,
                         hipStream_t s);

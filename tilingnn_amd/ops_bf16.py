@@ -75,12 +75,14 @@ def gin64(a: Tensor, graph: ops.PreparedGraph, eps: Tensor, w1, b1, w2, b2, w3, 
 
 def collconv64(h2: Tensor, graph: ops.PreparedGraph, eps: Tensor, w1, b1, w2, b2, w3, b3, bn: torch.nn.BatchNorm1d,
                update_running: bool = True) -> Tensor:
-    """CollConv.forward incl. its train-mode BatchNorm -> the normalised output, bf16 [N, 64] (two passes over the MLP)."""
+    """CollConv.forward incl. its train-mode BatchNorm -> the normalised output, bf16 [N, 64] (one pass over the MLP leaves the
+    statistics and the fp32 rows; an element-wise pass normalises and rounds them)."""
     h2 = _bf16c(h2, "x")
     n = graph.n_nodes
     dev = h2.device
     out = torch.empty(n, WIDTH, dtype=torch.bfloat16, device=dev)
     z = torch.empty(n, WIDTH, dtype=torch.bfloat16, device=dev)
+    pre = torch.empty(n, WIDTH, dtype=torch.float32, device=dev)
     stat = torch.empty(4 * WIDTH, dtype=torch.float32, device=dev)
     parts = ops.new_partials(WIDTH, dev)
     ps = [ops._f32c(p, "gin parameter") for p in (eps, w1, b1, w2, b2, w3, b3)]
@@ -88,7 +90,7 @@ def collconv64(h2: Tensor, graph: ops.PreparedGraph, eps: Tensor, w1, b1, w2, b2
     check(lib.tgnn_collconv64_bf16_fwd(ptr(h2), ptr(graph.col_rowptr), ptr(graph.col_src), *[ptr(p) for p in ps],
                                        ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean if upd else None),
                                        ptr(bn.running_var if upd else None), ptr(bn.num_batches_tracked if upd else None), n,
-                                       ptr(out), ptr(z), ptr(stat), ptr(parts), _lib.current_stream(dev)))
+                                       ptr(out), ptr(z), ptr(pre), ptr(stat), ptr(parts), _lib.current_stream(dev)))
     return out
 
 
