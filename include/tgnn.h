@@ -219,10 +219,13 @@ int tgnn_dense_act_slots_fwd(const float *a, int32_t slot_width, int64_t slot_st
                              tgnn_stream_t stream);
 /* The same (no input BatchNorm, slots of 32 channels with packed rows, out_dim >= 64) with the fp16 x 2 split as tgnn_forward runs
  * it (tgnn_set_split_precision), as one op for tests: the bounds tgnn_forward gets from the kernels that fill the slots are
- * computed here into bounds_scratch (in_dim / 32 + 1 words of device scratch). */
+ * computed here into bounds_scratch (in_dim / 32 + 1 words of device scratch).  wimg_scratch (4 * in_dim * out_dim bytes of
+ * device scratch, 16-byte aligned; out_dim 64 / 128 / 256): the rows-per-wave kernel tgnn_forward runs on the final MLP (W as
+ * a pre-split operand image, every wave 32 rows x all columns); NULL: the block-tile kernel. */
 int tgnn_dense_act_slots_f16_fwd(const float *a, int32_t slot_width, int64_t slot_stride, const float *w, const float *b,
                                  int64_t n_rows, int32_t in_dim, int32_t out_dim, int32_t act, float *out, int64_t ldo,
-                                 uint32_t *bounds_scratch, double *bn_partial, int32_t *n_partials_host, tgnn_stream_t stream);
+                                 uint32_t *bounds_scratch, void *wimg_scratch, double *bn_partial, int32_t *n_partials_host,
+                                 tgnn_stream_t stream);
 
 /* Train-mode BatchNorm1d statistics (fact 2 of SURVEY.md: the reference never leaves train mode).
  * mode 0: partials -> stat (+ running stats)      single GPU

@@ -9,7 +9,7 @@ import csv,glob
 f=glob.glob("$out/**/*kernel_stats.csv",recursive=True)
 if not f: print(open("$out/log.txt").read()[-2000:]); raise SystemExit
 with open("$out/stats.txt","w") as o:
-    for r in list(csv.DictReader(open(f[0])))[:14]:
+    for r in list(csv.DictReader(open(f[0])))[:18]:
         line=f'{r["Name"][:70].ljust(70)} calls {r["Calls"]:>5} avg_us {float(r["AverageNs"])/1e3:8.1f} pct {r["Percentage"]}'
         print(line); o.write(line+"\n")
 PY

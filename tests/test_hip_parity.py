@@ -848,6 +848,26 @@ def test_fp16_pair_split_kernels_hold_fp32_accuracy_across_magnitudes(dev, scale
         got, _ = ops.dense_act(mid, w, b, ops.ACT_NONE, slot_major=True, f16_split=True)
         want = mid.double().permute(1, 0, 2).reshape(n, 672) @ w.double().t() + b.double()
         assert orc.rel_max_err(got.cpu(), want.cpu()) < 2e-6, n
+    # the rows-per-wave kernel the forward takes from 49 152 rows on (W as a pre-split operand image, every wave 32 rows x all
+    # columns): same gate, the same bits as the block-tile kernel (same order of matrix instructions per output), the same sums
+    n = 60001
+    mid = (torch.randn(21, n, 32, generator=gen) * scale_a)
+    mid[3] *= torch.randn(n, 32, generator=gen).abs() * 4
+    mid = mid.to(dev)
+    for m in (256, 128, 64):
+        w = (torch.randn(m, 672, generator=gen) * scale_w / 672 ** 0.5).to(dev)
+        b = (torch.randn(m, generator=gen) * scale_a * scale_w).to(dev)
+        p_rows, p_tile = ops.new_partials(m, dev), ops.new_partials(m, dev)
+        got, np_rows = ops.dense_act(mid, w, b, ops.ACT_LEAKY_RELU, slot_major=True, f16_split=True, partials=p_rows)
+        ref, np_tile = ops.dense_act(mid, w, b, ops.ACT_LEAKY_RELU, slot_major=True, f16_split="tile", partials=p_tile)
+        want = torch.nn.functional.leaky_relu(mid.double().permute(1, 0, 2).reshape(n, 672) @ w.double().t() + b.double())
+        assert orc.rel_max_err(got.cpu(), want.cpu()) < 2e-6, m
+        assert torch.equal(got, ref), m
+        s_rows = p_rows[:np_rows * 2 * m].view(np_rows, 2 * m).sum(0)
+        s_tile = p_tile[:np_tile * 2 * m].view(np_tile, 2 * m).sum(0)
+        assert torch.allclose(s_rows, s_tile, rtol=1e-12, atol=0), m
+        want_sums = torch.cat([want.sum(0), (want * want).sum(0)])
+        assert torch.allclose(s_rows.cpu(), want_sums.cpu(), rtol=1e-5, atol=1e-5 * float(want.abs().max()) * n), m
     n = 6000
     sg = make_super_graph(n, 10 * n, 12 * n, tile_count=2, n_edge_types=13, seed=3)
     x, adj, adj_attr, col, _ = sg.to_torch(dev)

@@ -107,7 +107,7 @@ def _load() -> C.CDLL:
         "tgnn_gin_fwd": (C.c_int, [p, i64, p, p, p, p, p, p, p, p, p, p, i64, i32, i32, p, p, p, pi32, p]),
         "tgnn_dense_act_fwd": (C.c_int, [p, i64, i64, p, p, p, i64, i32, i32, i32, p, i64, p, pi32, p]),
         "tgnn_dense_act_slots_fwd": (C.c_int, [p, i32, i64, p, p, p, i64, i32, i32, i32, p, i64, p, pi32, p]),
-        "tgnn_dense_act_slots_f16_fwd": (C.c_int, [p, i32, i64, p, p, i64, i32, i32, i32, p, i64, p, p, pi32, p]),
+        "tgnn_dense_act_slots_f16_fwd": (C.c_int, [p, i32, i64, p, p, i64, i32, i32, i32, p, i64, p, p, p, pi32, p]),
         "tgnn_bn_finalize": (C.c_int, [i32, p, i32, p, i32, i64, p, p, f32, f32, p, p, p, p, p]),
         "tgnn_bn_apply": (C.c_int, [p, i64, p, i64, i32, p, i64, p]),
         "tgnn_merge_fwd": (C.c_int, [p, p, p, p, p, i64, i32, p, p, p]),

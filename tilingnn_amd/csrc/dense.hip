@@ -492,6 +492,214 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// [r4] fp16-pair Linear for MANY rows and out_dim = 32 TN <= 256 (the final MLP's 672 -> 256 -> 128 -> 64): every wave owns
+// 32 rows x ALL output columns.
+//  * A never goes through LDS: lane (i, g) of the v_mfma_f32_32x32x16_f16 A operand needs k = 8 g .. 8 g + 7 of row i -- 32
+//    bytes of the fp32 row, read straight from memory two k-tiles ahead and split ONCE (dense_split_kernel splits every A
+//    tile once per column block and once more per barrier-separated stage; its two barriers per k-tile with the loads of a
+//    single k-tile in flight left the matrix pipe idle 3/4 of the time: 188 us against 41 us of fp16 matrix work).
+//  * W comes as a pre-split operand image in fragment order (dense_f16_image_kernel, once per forward: [k-tile][kb][tn][plane]
+//    [lane] x 16 B), copied through registers into a double-buffered LDS tile -- ONE barrier per k-tile, conflict-free
+//    ds_read_b128, no split work on it.
+//  * MFMA order per accumulator as in dense_split_kernel<.., true> (lo.hi, hi.lo, hi.hi over k ascending): the same bits.
+// Persistent over 128-row tiles, one BatchNorm partial row per block (column sums kept in 2 x TN / 2 doubles per lane).
+// ------------------------------------------------------------------------------------------
+using u32x4_ = __attribute__((ext_vector_type(4))) unsigned int;
+using f32x4_ = __attribute__((ext_vector_type(4))) float;
+typedef __attribute__((address_space(3))) void lds_void_t;
+constexpr int kRowsThreads = 256;
+__global__ __launch_bounds__(256) void dense_f16_image_kernel(const float *__restrict__ w, int in_dim, int tn_count,
+                                                              const unsigned *__restrict__ w_max, u32x4_ *__restrict__ wimg) {
+    const int ktiles = in_dim / kBK;
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= ktiles * 2 * tn_count * 64) return;
+    const int lane = item & 63, t = item >> 6, tn = t % tn_count, kb = (t / tn_count) & 1, kt = t / (2 * tn_count);
+    const int col = tn * 32 + (lane & 31), k0 = kt * kBK + kb * 16 + 8 * (lane >> 5);
+    const float sw = pow2_scale_for(*w_max, 0);
+    const float4 *p = reinterpret_cast<const float4 *>(w + (int64_t)col * in_dim + k0);
+    const float4 x0 = p[0], x1 = p[1];
+    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    f16x8 hi, lo;
+    split2_f16(x, sw, hi, lo);
+    const int64_t o = ((int64_t)(kt * 2 + kb) * tn_count + tn) * 128 + lane;
+    wimg[o] = __builtin_bit_cast(u32x4_, hi);
+    wimg[o + 64] = __builtin_bit_cast(u32x4_, lo);
+}
+
+template <int TN, bool STAT>
+__global__ __launch_bounds__(kRowsThreads, 2) void dense_f16_rows_kernel(
+    const float *__restrict__ a, int64_t lda, int64_t a_kb_stride, int kps, const float *__restrict__ in_stat,
+    const u32x4_ *__restrict__ wimg, const float *__restrict__ bias, int64_t n, int in_dim, int act, float *__restrict__ out,
+    int64_t ldo, double *__restrict__ bn_partial, const unsigned *__restrict__ a_max, int n_a_max,
+    const unsigned *__restrict__ w_max) {
+    constexpr int N = 32 * TN, TNH = TN / 2;
+    constexpr int kTileVec = 2 * TN * 2 * 64;                 // 16-byte pieces of one k-tile of the image
+    constexpr int RB = kTileVec / kRowsThreads;               // ... per thread
+    __shared__ __attribute__((aligned(1024))) u32x4_ Bs0[kTileVec];
+    __shared__ __attribute__((aligned(1024))) u32x4_ Bs1[kTileVec];
+    extern __shared__ __attribute__((aligned(16))) float st[];    // [4][in_dim] (STAT)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 31, fg = lane >> 5;
+    const int ktiles = in_dim / kBK;
+    float sa, unscale;
+    {
+        unsigned mb = 0;
+        for (int i = lane; i < n_a_max; i += 64) mb = max(mb, a_max[i]);   // (one round trip, not one per slot)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, d, 64));
+        sa = pow2_scale_for(mb, 0);
+        unscale = 1.0f / (sa * pow2_scale_for(*w_max, 0));
+    }
+    if (STAT) {
+        for (int i = tid; i < 4 * in_dim; i += kRowsThreads) st[i] = in_stat[i];
+    }
+    const int64_t row_tiles = (n + 127) / 128;
+    // BatchNorm sums of the block: thread t keeps entries t and t + 256 of the row [sum N | sum of squares N], added up tile by
+    // tile from the waves' column sums (through the LDS tile the last k-step does not read)
+    double bsum[2] = {0.0, 0.0};
+    double *red = reinterpret_cast<double *>((ktiles & 1) ? Bs1 : Bs0);   // [wave][2][N]
+    static_assert((size_t)4 * 2 * N * sizeof(double) <= sizeof(Bs0), "the reduction array lives in one tile");
+    const bool leaky = act == TGNN_ACT_LEAKY_RELU;
+
+    for (int64_t rt = blockIdx.x; rt < row_tiles; rt += gridDim.x) {
+        const int64_t m0 = rt * 128 + wave * 32;
+        int64_t row = m0 + fi;
+        row = row < n ? row : n - 1;
+        const float *arow = a + row * lda + 8 * fg;
+        auto load_a = [&](int kt, float4 (&r)[4]) {
+            const float4 *p = reinterpret_cast<const float4 *>(arow + a_kblock_offset(kt, kps, a_kb_stride));
+            r[0] = p[0]; r[1] = p[1]; r[2] = p[4]; r[3] = p[5];        // k = 8 g .. + 7 and 16 + 8 g .. + 7
+        };
+        // image k-tile -> LDS by DMA, 1 KB per wave-level instruction, no register in between
+        auto dma_b = [&](int kt, u32x4_ *dst) {
+            const u32x4_ *p = wimg + (int64_t)kt * kTileVec + tid;
+#pragma unroll
+            for (int j = 0; j < RB; ++j)
+                __builtin_amdgcn_global_load_lds(p + kRowsThreads * j, (lds_void_t *)(dst + kRowsThreads * j + wave * 64), 16, 0, 0);
+        };
+        f32x16 acc[TN];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tn][r] = 0.f;
+        float4 abuf0[4], abuf1[4];                            // A(kt) of even / odd k-tiles: no copies between them
+        load_a(0, abuf0);
+        __syncthreads();                                      // the previous row tile's last reads of the tiles (and st's fill) are over
+        dma_b(0, Bs0);
+        // One k-tile: A(kt) -> fp16 pairs; tile kt has landed (the fence of __syncthreads waits for the copy); the next tile's copy
+        // and A rows are issued and land while this tile is multiplied.  (Everything compiler-visible: hand-counted vmcnt /
+        // lgkmcnt with inline-asm loads -- A two tiles ahead, B fragments four steps ahead, accumulators interleaved -- measured
+        // the same 155-160 us and hipcc copies asm-loaded registers at control-flow merges before the data has landed.)
+        auto step = [&](int kt, const u32x4_ *bcur, u32x4_ *bnxt, const float4 (&acur)[4], float4 (&anxt)[4]) {
+            f16x8 ah[2], al[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                float x[8] = {acur[2 * kb].x, acur[2 * kb].y, acur[2 * kb].z, acur[2 * kb].w,
+                              acur[2 * kb + 1].x, acur[2 * kb + 1].y, acur[2 * kb + 1].z, acur[2 * kb + 1].w};
+                if (STAT) {
+                    const int k = kt * kBK + kb * 16 + 8 * fg;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        x[e] = bn_apply1(x[e], st[k + e], st[in_dim + k + e], st[2 * in_dim + k + e], st[3 * in_dim + k + e]);
+                }
+                split2_f16(x, sa, ah[kb], al[kb]);
+            }
+            __syncthreads();                                  // tile kt is complete, the other one is free
+            if (kt + 1 < ktiles) {
+                dma_b(kt + 1, bnxt);
+                load_a(kt + 1, anxt);
+            }
+            const u32x4_ *bt = bcur + lane;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const f16x8 bh = __builtin_bit_cast(f16x8, bt[(kb * TN + tn) * 128]);
+                    const f16x8 bl = __builtin_bit_cast(f16x8, bt[(kb * TN + tn) * 128 + 64]);
+                    f32x16 c = acc[tn];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kb], bh, c, 0, 0, 0);   // lo . hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kb], bl, c, 0, 0, 0);   // hi . lo
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kb], bh, c, 0, 0, 0);   // hi . hi
+                    acc[tn] = c;
+                }
+        };
+        for (int kt = 0; kt < ktiles; kt += 2) {
+            step(kt, Bs0, Bs1, abuf0, abuf1);
+            if (kt + 1 < ktiles) step(kt + 1, Bs1, Bs0, abuf1, abuf0);
+        }
+        // ---- epilogue (C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5))
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = tn * 32 + fi;
+            const float b = bias[col];
+            double s_ = 0.0, q_ = 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t orow = m0 + (r & 3) + 8 * (r >> 2) + 4 * fg;
+                if (orow < n) {
+                    const float u = fmaf(acc[tn][r], unscale, b);
+                    const float v = leaky ? (u >= 0.f ? u : u * kLeakySlope) : act_apply(u, act);
+                    out[orow * ldo + col] = v;
+                    s_ += (double)v;
+                    q_ += (double)v * (double)v;
+                }
+            }
+            s_ += __shfl_xor(s_, 32, 64);
+            q_ += __shfl_xor(q_, 32, 64);
+            if (bn_partial && (tn / TNH) == fg) {             // (lanes < 32 write the columns of tn < TN / 2, the others the rest)
+                red[(wave * 2 + 0) * N + col] = s_;
+                red[(wave * 2 + 1) * N + col] = q_;
+            }
+        }
+        if (bn_partial) {
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = tid + kRowsThreads * h;
+                if (i < 2 * N) {
+                    const int which = i / N, cl = i % N;
+                    double tot = 0.0;
+#pragma unroll
+                    for (int wv = 0; wv < 4; ++wv) tot += red[(wv * 2 + which) * N + cl];
+                    bsum[h] += tot;
+                }
+            }
+        }
+    }
+
+    if (bn_partial) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = tid + kRowsThreads * h;
+            if (i < 2 * N) bn_partial[(int64_t)blockIdx.x * 2 * N + i] = bsum[h];
+        }
+    }
+}
+
+static size_t dense_f16_image_bytes(int in_dim, int out_dim) { return (size_t)in_dim * out_dim * 4; }
+
+template <int TN>
+static int launch_dense_f16_rows(hipStream_t s, const float *a, int64_t lda, int64_t akb, int kps, const float *in_stat,
+                                 const void *wimg, const float *b, int64_t n, int in_dim, int act, float *out, int64_t ldo,
+                                 double *bn_partial, const unsigned *a_max, int n_a_max, const unsigned *w_max) {
+    const size_t lds = in_stat ? (size_t)4 * in_dim * sizeof(float) : 0;     // (dynamic part: the BatchNorm record)
+    int blocks = producer_blocks(n, 128);
+    const int cap = 2 * device_cus();
+    if (blocks > cap) blocks = cap;
+    const u32x4_ *img = static_cast<const u32x4_ *>(wimg);
+    if (in_stat) {
+        static LdsOptIn site;
+        if (TN == 8) (void)opt_in_dynamic_lds(dense_f16_rows_kernel<TN, true>, (int)lds, site);
+        dense_f16_rows_kernel<TN, true><<<blocks, kRowsThreads, lds, s>>>(a, lda, akb, kps, in_stat, img, b, n, in_dim, act, out, ldo,
+                                                                         bn_partial, a_max, n_a_max, w_max);
+    } else {
+        dense_f16_rows_kernel<TN, false><<<blocks, kRowsThreads, lds, s>>>(a, lda, akb, kps, nullptr, img, b, n, in_dim, act, out, ldo,
+                                                                          bn_partial, a_max, n_a_max, w_max);
+    }
+    return blocks;
+}
+
 template <int TM, int WN, bool F16 = false>
 static void launch_dense_split(int blocks_x, hipStream_t s, const float *a, int64_t lda, int64_t akb, int kps,
                                const float *in_stat, const float *w, const float *b, int64_t n, int in_dim, int out_dim,
@@ -605,7 +813,8 @@ __global__ __launch_bounds__(256) void dense_in8_kernel(const float *__restrict_
 static int dense_act_impl(const float *a, int64_t lda, int64_t a_kblock_stride, int kps, const float *in_stat,
                           const float *w, const float *b, int64_t n_rows, int32_t in_dim, int32_t out_dim, int32_t act,
                           float *out, int64_t ldo, double *bn_partial, int32_t *n_partials_host, tgnn_stream_t stream,
-                          const unsigned *a_max = nullptr, int n_a_max = 0, const unsigned *w_max = nullptr) {
+                          const unsigned *a_max = nullptr, int n_a_max = 0, const unsigned *w_max = nullptr,
+                          const void *wimg = nullptr) {
     TGNN_CHECK_ARG(n_rows >= 0 && in_dim >= 1 && out_dim >= 1, "shape");
     TGNN_CHECK_ARG(act >= TGNN_ACT_NONE && act <= TGNN_ACT_SIGMOID, "activation");
     if (n_rows == 0) {
@@ -667,6 +876,26 @@ static int dense_act_impl(const float *a, int64_t lda, int64_t a_kblock_stride, 
         //  two barriers per k-tile)
         constexpr int small_rows = 16384;
         const bool f16 = a_max && w_max && n_a_max >= 1;     // (a_max bounds the input AFTER the BatchNorm applied while staging)
+        // the operand image of W is at hand (dense_f16_image_build) and every output column fits one wave's accumulators:
+        // rows-per-wave kernel (dense_f16_rows_kernel)
+        // (measured, 672 -> 256: 54 / 59 / 158 / 393 us at 10 000 / 32 000 / 100 000 / 300 000 rows against 34 / 56 / 177 / 446 for the
+        //  block-tile kernels; inside the forward at 100 000 rows 166 + 58 + 28 us for the three layers against 197 + 72 + 36)
+        if (f16 && wimg && n_rows >= kDenseRowsKernelMin && (out_dim == 64 || out_dim == 128 || out_dim == 256) &&
+            ((uintptr_t)wimg % 16) == 0 && (!in_stat || in_dim <= 1024)) {
+            int nb;
+            if (out_dim == 256)
+                nb = launch_dense_f16_rows<8>(s, a, lda, a_kblock_stride, kps, in_stat, wimg, b, n_rows, in_dim, act, out, ldo, bn_partial,
+                                              a_max, n_a_max, w_max);
+            else if (out_dim == 128)
+                nb = launch_dense_f16_rows<4>(s, a, lda, a_kblock_stride, kps, in_stat, wimg, b, n_rows, in_dim, act, out, ldo, bn_partial,
+                                              a_max, n_a_max, w_max);
+            else
+                nb = launch_dense_f16_rows<2>(s, a, lda, a_kblock_stride, kps, in_stat, wimg, b, n_rows, in_dim, act, out, ldo, bn_partial,
+                                              a_max, n_a_max, w_max);
+            if (n_partials_host) *n_partials_host = nb;
+            TGNN_CHECK_LAUNCH();
+            return TGNN_OK;
+        }
         if (out_dim > 64 && n_rows > small_rows) {
             const int bx = row_blocks(128);
             if (f16)
@@ -743,24 +972,34 @@ extern "C" int tgnn_dense_act_slots_fwd(const float *a, int32_t slot_width, int6
 namespace tgnn {
 int dense_act_bounded(const float *a, int64_t lda, int64_t a_kblock_stride, const float *in_stat, const float *w, const float *b,
                       int64_t n_rows, int32_t in_dim, int32_t out_dim, int32_t act, float *out, int64_t ldo, double *bn_partial,
-                      int32_t *n_partials_host, const unsigned *a_max, int n_a_max, const unsigned *w_max, hipStream_t s) {
+                      int32_t *n_partials_host, const unsigned *a_max, int n_a_max, const unsigned *w_max, hipStream_t s,
+                      const void *wimg) {
     return dense_act_impl(a, lda, a_kblock_stride, 1, in_stat, w, b, n_rows, in_dim, out_dim, act, out, ldo, bn_partial,
-                          n_partials_host, s, a_max, n_a_max, w_max);
+                          n_partials_host, s, a_max, n_a_max, w_max, wimg);
+}
+size_t dense_f16_image_size(int in_dim, int out_dim) { return align_up(dense_f16_image_bytes(in_dim, out_dim), 256); }
+// W [out_dim][in_dim] -> the fp16-pair operand image dense_f16_rows_kernel reads (scaled by w_max's power of two)
+int dense_f16_image_build(const float *w, int in_dim, int out_dim, const unsigned *w_max, void *wimg, hipStream_t s) {
+    if (in_dim % kBK || out_dim % 32 || ((uintptr_t)w % 16) || ((uintptr_t)wimg % 16)) return TGNN_ERR_UNSUPPORTED;
+    const int items = (in_dim / kBK) * 2 * (out_dim / 32) * 64;
+    dense_f16_image_kernel<<<(items + 255) / 256, 256, 0, s>>>(w, in_dim, out_dim / 32, w_max, static_cast<u32x4_ *>(wimg));
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
 }
 // tgnn_dense_act_slots_fwd with the operands' bounds (forward.hip: the first Linear of the final MLP over the skip buffer)
 int dense_act_slots_bounded(const float *a, int32_t slot_width, int64_t slot_stride, const float *w, const float *b,
                             int64_t n_rows, int32_t in_dim, int32_t out_dim, int32_t act, float *out, int64_t ldo,
                             double *bn_partial, int32_t *n_partials_host, const unsigned *a_max, int n_a_max,
-                            const unsigned *w_max, hipStream_t s) {
+                            const unsigned *w_max, hipStream_t s, const void *wimg) {
     return dense_act_impl(a, slot_width, slot_stride, slot_width / 32, nullptr, w, b, n_rows, in_dim, out_dim, act, out, ldo,
-                          bn_partial, n_partials_host, s, a_max, n_a_max, w_max);
+                          bn_partial, n_partials_host, s, a_max, n_a_max, w_max, wimg);
 }
 }  // namespace tgnn
 
 extern "C" int tgnn_dense_act_slots_f16_fwd(const float *a, int32_t slot_width, int64_t slot_stride, const float *w, const float *b,
                                             int64_t n_rows, int32_t in_dim, int32_t out_dim, int32_t act, float *out, int64_t ldo,
-                                            uint32_t *bounds_scratch, double *bn_partial, int32_t *n_partials_host,
-                                            tgnn_stream_t stream) {
+                                            uint32_t *bounds_scratch, void *wimg_scratch, double *bn_partial,
+                                            int32_t *n_partials_host, tgnn_stream_t stream) {
     DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(slot_width == 32 && in_dim % 32 == 0 && in_dim >= 32 && out_dim >= 64 && n_rows >= 1, "shape");
     TGNN_CHECK_ARG(a && w && b && out && bounds_scratch, "null pointer");
@@ -770,6 +1009,11 @@ extern "C" int tgnn_dense_act_slots_f16_fwd(const float *a, int32_t slot_width, 
     TGNN_CHECK_HIP(hipMemsetAsync(bounds_scratch, 0, (size_t)(n_slots + 1) * sizeof(uint32_t), s));
     for (int k = 0; k < n_slots; ++k) launch_absmax(a + (int64_t)k * slot_stride, n_rows * 32, bounds_scratch + k, s);
     launch_absmax(w, (int64_t)in_dim * out_dim, bounds_scratch + n_slots, s);
+    if (wimg_scratch) {
+        TGNN_CHECK_ARG(out_dim == 64 || out_dim == 128 || out_dim == 256, "the rows kernel takes out_dim 64 / 128 / 256");
+        const int rc = dense_f16_image_build(w, in_dim, out_dim, bounds_scratch + n_slots, wimg_scratch, s);
+        if (rc != TGNN_OK) return rc;
+    }
     return dense_act_slots_bounded(a, slot_width, slot_stride, w, b, n_rows, in_dim, out_dim, act, out, ldo, bn_partial,
-                                   n_partials_host, bounds_scratch, n_slots, bounds_scratch + n_slots, s);
+                                   n_partials_host, bounds_scratch, n_slots, bounds_scratch + n_slots, s, wimg_scratch);
 }

@@ -81,6 +81,7 @@ struct Workspace {
     double *small_part, *small_part_wide, *small_runstat;
     double *mid_part;             // mid-size persistent layer loop: tagged partial rows + group sums (forward_mid.hip)
     unsigned *small_ctr;
+    void *dimg[3];                 // fp16-pair operand images of the final MLP's first three Linears (dense_f16_image_build)
     unsigned *bounds;            // [0, D]: max |middle[k]| as float bits; [D + 1, 2 D]: max |root_i|; [2 D + 1]: max |final W_0|
     float *stat1, *stat2[2], *stat_i[2], *stat_f[4];
     size_t bytes;
@@ -156,6 +157,10 @@ static Workspace carve(const tgnn_model_dims &d, int64_t n, int64_t nr, int32_t 
     w.mid_part = cv.take<double>(mid_part_doubles());
     w.small_ctr = cv.take<unsigned>(64);
     w.bounds = cv.take<unsigned>(2 * kMaxDepth + 8);
+    {
+        const int fd[4] = {c * (D + 1), kFinalDims[0], kFinalDims[1], kFinalDims[2]};
+        for (int l = 0; l < 3; ++l) w.dimg[l] = cv.take<unsigned char>(dense_f16_image_size(fd[l], fd[l + 1]));
+    }
     w.stat1 = cv.take<float>(4 * c);
     w.stat2[0] = cv.take<float>(4 * c);
     w.stat2[1] = cv.take<float>(4 * c);
@@ -394,6 +399,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[kEvFork], 0));
         sw = s2;
     }
+    bool dimg_ok[3] = {false, false, false};
     if (f16) {
         // the final MLP's layers 1 and 2 (256 -> 128 -> 64): weights' bounds and, from the BatchNorm parameters alone, their inputs'
         const float *bw[2], *bg[2], *bb[2];
@@ -409,6 +415,11 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
             bam[l - 1] = w.bounds + 2 * D + 3 + 2 * (l - 1);
         }
         launch_dense_bounds(2, bw, bwn, bg, bb, bf, bwm, bam, n_total, sw);   // (side stream: off the critical chain; the final MLP is behind every join)
+        // the three Linears' operand images for the rows-per-wave kernel (dense.hip), behind their weights' bounds on the same stream
+        for (int l = 0; l < 3; ++l) {
+            const unsigned *wm = l == 0 ? dense_max : w.bounds + 2 * D + 2 + 2 * (l - 1);
+            dimg_ok[l] = c == 32 && n >= kDenseRowsKernelMin && dense_f16_image_build(P.f(P.fin(l)), fin_dims[l], fin_dims[l + 1], wm, w.dimg[l], sw) == TGNN_OK;
+        }
     }
     if (T > 0 || tiled) {
         // edge MLP of every (layer, type) and, for the matrix-core NNConv, its operand images (root = pseudo-type T): one launch
@@ -690,7 +701,8 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
             prof.begin(6);
             if (f16)
                 TGNN_TRY(dense_act_slots_bounded(w.mid, c, (int64_t)nr * c, P.f(pi), P.f(pi + 1), n, cat_dim, fdim[1],
-                                                 TGNN_ACT_LEAKY_RELU, fbuf[0], fdim[1], w.partf, &np1, slot_max, D + 1, dense_max, s));
+                                                 TGNN_ACT_LEAKY_RELU, fbuf[0], fdim[1], w.partf, &np1, slot_max, D + 1, dense_max, s,
+                                                 dimg_ok[0] ? w.dimg[0] : nullptr));
             else
                 TGNN_TRY(tgnn_dense_act_slots_fwd(w.mid, c, (int64_t)nr * c, nullptr, P.f(pi), P.f(pi + 1), n, cat_dim, fdim[1],
                                                   TGNN_ACT_LEAKY_RELU, fbuf[0], fdim[1], w.partf, &np1, s));
@@ -700,7 +712,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
             if (f16 && l <= 2)       // fp16 pairs: the input's bound follows from the producer's BatchNorm parameters (dense_bounds_kernel)
                 TGNN_TRY(dense_act_bounded(fbuf[l - 1], fdim[l], 32, w.stat_f[l - 1], P.f(pi), P.f(pi + 1), n, fdim[l], fdim[l + 1],
                                            TGNN_ACT_LEAKY_RELU, fbuf[l], fdim[l + 1], w.partf, &np1, w.bounds + 2 * D + 3 + 2 * (l - 1), 1,
-                                           w.bounds + 2 * D + 2 + 2 * (l - 1), s));
+                                           w.bounds + 2 * D + 2 + 2 * (l - 1), s, dimg_ok[l] ? w.dimg[l] : nullptr));
             else
                 TGNN_TRY(tgnn_dense_act_fwd(fbuf[l - 1], fdim[l], 32, w.stat_f[l - 1], P.f(pi), P.f(pi + 1), n, fdim[l],
                                             fdim[l + 1], TGNN_ACT_LEAKY_RELU, fbuf[l], fdim[l + 1], w.partf, &np1, s));

@@ -417,13 +417,19 @@ void launch_dense_bounds(int n_jobs, const float *const *w, const int64_t *w_n, 
 // tgnn_dense_act_fwd with bounds of both operands (a_max: of the input AFTER in_stat's BatchNorm, if any): dense.hip
 int dense_act_bounded(const float *a, int64_t lda, int64_t a_kblock_stride, const float *in_stat, const float *w, const float *b,
                       int64_t n_rows, int32_t in_dim, int32_t out_dim, int32_t act, float *out, int64_t ldo, double *bn_partial,
-                      int32_t *n_partials_host, const unsigned *a_max, int n_a_max, const unsigned *w_max, hipStream_t s);
+                      int32_t *n_partials_host, const unsigned *a_max, int n_a_max, const unsigned *w_max, hipStream_t s,
+                      const void *wimg = nullptr);
+// the fp16-pair operand image of a Linear's W [out_dim][in_dim] (out_dim 64 / 128 / 256, in_dim % 32 == 0) that routes
+// dense_act_bounded / dense_act_slots_bounded to the rows-per-wave kernel (dense.hip: dense_f16_rows_kernel)
+constexpr int64_t kDenseRowsKernelMin = 49152;       // rows from which that kernel is taken (below: the block-tile kernels win)
+size_t dense_f16_image_size(int in_dim, int out_dim);
+int dense_f16_image_build(const float *w, int in_dim, int out_dim, const unsigned *w_max, void *wimg, hipStream_t s);
 // tgnn_dense_act_slots_fwd (no input BatchNorm) with bounds of both operands: a_max[0 .. n_a_max) / w_max = max |a| per slot /
 // max |w| as float bits (device) -> the fp16-pair kernel (dense.hip: dense_split_kernel<.., F16>); dense.hip
 int dense_act_slots_bounded(const float *a, int32_t slot_width, int64_t slot_stride, const float *w, const float *b,
                             int64_t n_rows, int32_t in_dim, int32_t out_dim, int32_t act, float *out, int64_t ldo,
                             double *bn_partial, int32_t *n_partials_host, const unsigned *a_max, int n_a_max,
-                            const unsigned *w_max, hipStream_t s);
+                            const unsigned *w_max, hipStream_t s, const void *wimg = nullptr);
 // the MLP half of tgnn_gin_fwd (width 32) behind tgnn_gin_aggregate; gin.hip
 // experiment knob (tgnn_debug_set_block_caps): upper bounds of the whole-CU kernels' grids, 0 = the built-in policy
 extern std::atomic<int> g_debug_block_cap[2];   // [0] column NNConv, [1] GIN MLP

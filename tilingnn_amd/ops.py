@@ -404,8 +404,11 @@ def dense_act(a: Tensor, weight: Tensor, bias: Tensor, act: int, in_stat: Option
             if in_stat is not None or cw != 32:
                 raise ValueError("the fp16-pair dense kernel takes 32-channel slots and no input BatchNorm")
             bounds = torch.empty(int(a.shape[0]) + 1, dtype=torch.int32, device=a.device)
+            # the rows-per-wave kernel (what tgnn_forward runs on the final MLP) where its shape fits; f16_split="tile": the block-tile one
+            # (the library takes the rows kernel from 49 152 rows on; below that wimg is built and ignored)
+            wimg = torch.empty(k * m, dtype=torch.float32, device=a.device) if (f16_split != "tile" and m in (64, 128, 256)) else None
             check(lib.tgnn_dense_act_slots_f16_fwd(ptr(a), cw, n * cw, ptr(_f32c(weight, "weight")), ptr(_f32c(bias, "bias")), n, k, m,
-                                                   act, ptr(out), m, ptr(bounds), ptr(partials), C.byref(npart), _stream(a)))
+                                                   act, ptr(out), m, ptr(bounds), ptr(wimg), ptr(partials), C.byref(npart), _stream(a)))
             return out, npart.value
         check(lib.tgnn_dense_act_slots_fwd(ptr(a), cw, n * cw, ptr(in_stat), ptr(_f32c(weight, "weight")),
                                            ptr(_f32c(bias, "bias")), n, k, m, act, ptr(out), m, ptr(partials),
