@@ -47,6 +47,9 @@ constexpr int kColStage = 16 * 20;         // floats of the per-wave BN staging 
 // end of the wave's share -- runs without the masks of the general path: a source word IS the gather offset but for a shift
 // (-1 lands beyond the descriptor's range and loads zeros), the root column's own-row offset is kept in a register and moves
 // on once per tile, the end-of-share tests are gone.  28 instructions per column become 10; same arithmetic, same bits.
+#ifdef TGNN_ABL_BLOCKTIMES
+__device__ unsigned long long g_blk_times[2][256];
+#endif
 template <int DEPTH, int WAVES, int OCC, bool F16, bool FAST>
 __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
     const float *__restrict__ h, int64_t ldh, const int *__restrict__ tile_col_ptr, const int *__restrict__ col_meta,
@@ -57,6 +60,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
     // stamp (tgnn_forward_stamped): first block in / last block out on the device's wall clock -- the launch's duration as a
     // kernel trace sees it, measured inside the production schedule without an event or a profiler around it
     if (stamp && threadIdx.x == 0) atomicMin(stamp, wall_clock64());
+#ifdef TGNN_ABL_BLOCKTIMES
+    if (threadIdx.x == 0 && blockIdx.x < 256) g_blk_times[0][blockIdx.x] = wall_clock64();   // (experiment: when do the blocks start?)
+#endif
     constexpr int kTy = F16 ? kWtTypeF16 : kWtType;         // floats of one type's image
     float *wl = lds;                                        // [(T+1)][3 (2) planes][2 M blocks][16][4] x 8 bf16 (fp16)
     float *stage = lds + (n_types + 1) * kTy;               // [WAVES][16][20]
@@ -371,6 +377,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_cols_kernel(
         }
     }
     if (stamp && tid == 0) atomicMax(stamp + 1, wall_clock64());
+#ifdef TGNN_ABL_BLOCKTIMES
+    if (tid == 0 && blockIdx.x < 256) g_blk_times[1][blockIdx.x] = wall_clock64();
+#endif
 #ifdef TGNN_TIMING
     TGNN_CT(7)
     if (lane == 0 && blockIdx.x < 512 && wave < 8)
@@ -430,7 +439,8 @@ int launch_nnconv_cols(const float *h, int64_t ldh, const int32_t *tile_col_ptr,
         int deg_log2 = 0;
         while ((1 << deg_log2) < max_in_degree) ++deg_log2;
         // (always one 16-wave block per CU: two 8-wave blocks per CU -- they would fit, the fp16 image is 4 KB per type -- spread
-        //  over ALL CUs and leave none to the collision chain's 1-block kernels: BatchNorm finalize 7.8 -> 15.2 us, rocprof)
+        //  over ALL CUs and leave none to the collision chain's 1-block kernels: BatchNorm finalize 7.8 -> 15.2 us, rocprof;
+        //  [r4] measured again now that that chain has no 1-block kernel left: cached forward 1.89 -> 2.16 ms at 100 000 nodes)
         return launch_cols_t<4, 16, 4, true>(h, ldh, tile_col_ptr, col_meta, col_src, wimg, n_types, bias, n_nodes, act, out,
                                              bn_partial, n_partials_host, 1, s, h_max, root_max, deg_log2, stamp);
     }
@@ -506,3 +516,9 @@ extern "C" int tgnn_nnconv_mean_cols_f16_fwd(const float *h, int64_t ldh, int64_
     return launch_nnconv_cols(h, ldh, tile_col_ptr, col_meta, col_src, wimg_scratch, n_types, bias, n_nodes, act, out,
                               bn_partial, n_partials_host, s, bounds_scratch, bounds_scratch + 1, max_in_degree);
 }
+
+#ifdef TGNN_ABL_BLOCKTIMES
+extern "C" int tgnn_debug_block_times(unsigned long long *host512) {
+    return (int)hipMemcpyFromSymbol(host512, HIP_SYMBOL(tgnn::g_blk_times), sizeof(unsigned long long) * 512);
+}
+#endif
