@@ -270,3 +270,28 @@ def test_library_forward_is_the_composition_of_its_ops(dev, depth):
     d = float((got - want).abs().max())
     print(f"depth {depth}: max |library - composition| = {d:.3e}")
     assert torch.equal(got, want)
+
+@pytest.mark.gpu
+def test_final_linear_rows_kernel(dev):
+    """[r4] From 49 152 rows on the first final Linear runs on the rows-per-wave kernel (W as a bf16 operand image, every wave 32 rows x
+    all 256 columns): fp64 gate, BatchNorm sums of what was stored, and the same bits as the block-tile kernel row by row (the same
+    rows through a call below the threshold)."""
+    from tilingnn_amd import ops, ops_bf16
+    n, s = 60001, 21
+    gen = torch.Generator().manual_seed(6)
+    mid = bf(torch.randn(s, n, W, generator=gen)).to(dev).bfloat16().contiguous()
+    w = (torch.randn(256, s * W, generator=gen) / (s * W) ** 0.5).to(dev)
+    b = torch.randn(256, generator=gen).to(dev)
+    parts = ops.new_partials(256, dev)
+    got, npart = ops_bf16.dense_slots(mid, w, b, ops.ACT_LEAKY_RELU, parts)
+    cat = torch.cat(list(mid.float()), dim=1).double()
+    want = torch.nn.functional.leaky_relu(cat @ w.double().t() + b.double())
+    assert orc.rel_max_err(got.cpu(), want.cpu()) < TOL_BF16
+    sm, sq = sums_from(parts, npart, 256)
+    gd = got.double().cpu()
+    assert float((sm - gd.sum(0)).abs().max()) < 1e-9 * float(gd.abs().sum(0).max())
+    assert float((sq - (gd * gd).sum(0)).abs().max()) < 1e-9 * float((gd * gd).sum(0).max())
+    m = 40000
+    ref, _ = ops_bf16.dense_slots(mid[:, :m].contiguous(), w, b, ops.ACT_LEAKY_RELU, ops.new_partials(256, dev))
+    assert torch.equal(got[:m], ref)
+

@@ -711,6 +711,126 @@ __global__ __launch_bounds__(kDbThreads) void dense_bf16_slots_kernel(const __bf
     }
 }
 
+// ------------------------------------------------------------------------------------------ first final Linear, many rows
+// [r4] The rows-per-wave form of dense.hip's dense_f16_rows_kernel for the bf16 skip buffer (no split: one matrix term): 4 waves x
+// 32 rows x all 256 output columns; A fragments straight from memory (lane (i, g): 8 consecutive bf16 of row i), one slot (64 k)
+// ahead; W as a bf16 operand image in fragment order ([slot][kb 4][tn 8][lane] x 16 B, dense_bf16_image_kernel) copied by DMA
+// into a double-buffered 32 KB LDS tile, one barrier per slot.  k ascending per output as in dense_bf16_slots_kernel: same bits.
+using u32x4_ = __attribute__((ext_vector_type(4))) unsigned int;
+typedef __attribute__((address_space(3))) void lds_void64_t;
+constexpr int kBrThreads = 256, kBrTileVec = 4 * 8 * 64, kBrRB = kBrTileVec / kBrThreads;
+constexpr int64_t kBf16RowsKernelMin = 49152;
+
+__global__ __launch_bounds__(256) void dense_bf16_image_kernel(const float *__restrict__ w, int n_slots, u32x4_ *__restrict__ wimg) {
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= n_slots * kBrTileVec) return;
+    const int lane = item & 63, tn = (item >> 6) & 7, kb = (item >> 9) & 3, sl = item >> 11;
+    const int col = tn * 32 + (lane & 31), k0 = sl * kDbK + kb * 16 + 8 * (lane >> 5);
+    const float4 *p = reinterpret_cast<const float4 *>(w + (int64_t)col * n_slots * kDbK + k0);
+    const float4 x0 = p[0], x1 = p[1];
+    bf16x8 o;
+    o[0] = (__bf16)x0.x; o[1] = (__bf16)x0.y; o[2] = (__bf16)x0.z; o[3] = (__bf16)x0.w;
+    o[4] = (__bf16)x1.x; o[5] = (__bf16)x1.y; o[6] = (__bf16)x1.z; o[7] = (__bf16)x1.w;
+    wimg[item] = __builtin_bit_cast(u32x4_, o);
+}
+
+__global__ __launch_bounds__(kBrThreads, 2) void dense_bf16_rows_kernel(const __bf16 *__restrict__ a, int64_t slot_stride, int n_slots,
+                                                                       const u32x4_ *__restrict__ wimg, const float *__restrict__ bias,
+                                                                       int64_t n, int act, float *__restrict__ out,
+                                                                       double *__restrict__ bn_partial) {
+    constexpr int N = 256, TN = 8, TNH = 4;
+    __shared__ __attribute__((aligned(1024))) u32x4_ Bs0[kBrTileVec];
+    __shared__ __attribute__((aligned(1024))) u32x4_ Bs1[kBrTileVec];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 31, fg = lane >> 5;
+    const int64_t row_tiles = (n + 127) / 128;
+    double bsum[2] = {0.0, 0.0};                              // entries tid and tid + 256 of the block's row [sum 256 | sum of squares 256]
+    double *red = reinterpret_cast<double *>((n_slots & 1) ? Bs1 : Bs0);   // [wave][2][N]: the tile the last step does not read
+    const bool leaky = act == TGNN_ACT_LEAKY_RELU;
+    for (int64_t rt = blockIdx.x; rt < row_tiles; rt += gridDim.x) {
+        const int64_t m0 = rt * 128 + wave * 32;
+        int64_t row = m0 + fi;
+        row = row < n ? row : n - 1;
+        const __bf16 *arow = a + row * kDbK + 8 * fg;
+        auto load_a = [&](int sl, bf16x8 (&r)[4]) {
+            const __bf16 *p = arow + (int64_t)sl * slot_stride;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) r[kb] = *reinterpret_cast<const bf16x8 *>(p + 16 * kb);
+        };
+        auto dma_b = [&](int sl, u32x4_ *dst) {
+            const u32x4_ *p = wimg + (int64_t)sl * kBrTileVec + tid;
+#pragma unroll
+            for (int j = 0; j < kBrRB; ++j)
+                __builtin_amdgcn_global_load_lds(p + kBrThreads * j, (lds_void64_t *)(dst + kBrThreads * j + wave * 64), 16, 0, 0);
+        };
+        f32x16 acc[TN];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tn][r] = 0.f;
+        bf16x8 abuf0[4], abuf1[4];
+        load_a(0, abuf0);
+        __syncthreads();                                      // the previous row tile's last reads of the tiles are over
+        dma_b(0, Bs0);
+        auto step = [&](int sl, const u32x4_ *bcur, u32x4_ *bnxt, const bf16x8 (&acur)[4], bf16x8 (&anxt)[4]) {
+            __syncthreads();                                  // tile sl is complete (the barrier's fence waits for the copy), the other free
+            if (sl + 1 < n_slots) {
+                dma_b(sl + 1, bnxt);
+                load_a(sl + 1, anxt);
+            }
+            const u32x4_ *bt = bcur + lane;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[kb], __builtin_bit_cast(bf16x8, bt[(kb * TN + tn) * 64]), acc[tn], 0, 0, 0);
+        };
+        for (int sl = 0; sl < n_slots; sl += 2) {
+            step(sl, Bs0, Bs1, abuf0, abuf1);
+            if (sl + 1 < n_slots) step(sl + 1, Bs1, Bs0, abuf1, abuf0);
+        }
+        // ---- epilogue (C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5))
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = tn * 32 + fi;
+            const float b = bias[col];
+            double s_ = 0.0, q_ = 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t orow = m0 + (r & 3) + 8 * (r >> 2) + 4 * fg;
+                if (orow < n) {
+                    const float u = acc[tn][r] + b;
+                    const float v = leaky ? (u >= 0.f ? u : u * kLeakySlope) : act_apply(u, act);
+                    out[orow * N + col] = v;
+                    s_ += (double)v;
+                    q_ += (double)v * (double)v;
+                }
+            }
+            s_ += __shfl_xor(s_, 32, 64);
+            q_ += __shfl_xor(q_, 32, 64);
+            if (bn_partial && (tn / TNH) == fg) {
+                red[(wave * 2 + 0) * N + col] = s_;
+                red[(wave * 2 + 1) * N + col] = q_;
+            }
+        }
+        if (bn_partial) {
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = tid + kBrThreads * h, which = i / N, cl = i % N;
+                double tot = 0.0;
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) tot += red[(wv * 2 + which) * N + cl];
+                bsum[h] += tot;
+            }
+        }
+    }
+    if (bn_partial) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) bn_partial[(int64_t)blockIdx.x * 2 * N + tid + kBrThreads * h] = bsum[h];
+    }
+}
+
 // ------------------------------------------------------------------------------------------ workspace of the forward
 struct Ws64 {
     __bf16 *mid, *a1, *a2[2], *z, *wimg, *wfin;
@@ -914,6 +1034,30 @@ static int dense_bf16_slots_launch(const __bf16 *a, int64_t slot_stride, int n_s
     return TGNN_OK;
 }
 
+// fp32 W -> bf16 (row-major for the block-tile kernel, fragment order for the rows kernel) into wb_scratch, then the product.
+// Measured at 100 000 rows x 21 slots -> 256: block-tile kernel 150 us, rows kernel 125 us (inside the config-3 forward; its A rows are one slot ahead only -- the barrier drains them: latency, not issue, bounds it).
+static int dense_bf16_slots_from_f32(const __bf16 *a, int64_t slot_stride, int n_slots, const float *w, const float *bias, int64_t n,
+                                     int out_dim, int act, float *out, void *wb_scratch, double *bn_partial, int32_t *n_partials_host,
+                                     hipStream_t s) {
+    if (out_dim == 256 && n >= kBf16RowsKernelMin && ((uintptr_t)w % 16) == 0 && ((uintptr_t)wb_scratch % 16) == 0) {
+        const int items = n_slots * kBrTileVec;
+        dense_bf16_image_kernel<<<(items + 255) / 256, 256, 0, s>>>(w, n_slots, static_cast<u32x4_ *>(wb_scratch));
+        int64_t blocks = (n + 127) / 128;
+        const int64_t cap = 2 * (int64_t)device_cus();
+        if (blocks > cap) blocks = cap;
+        if (blocks > TGNN_BN_MAX_PARTIALS) blocks = TGNN_BN_MAX_PARTIALS;
+        dense_bf16_rows_kernel<<<(unsigned)blocks, kBrThreads, 0, s>>>(a, slot_stride, n_slots, static_cast<const u32x4_ *>(wb_scratch), bias,
+                                                                      n, act, out, bn_partial);
+        if (n_partials_host) *n_partials_host = (int32_t)blocks;
+        TGNN_CHECK_LAUNCH();
+        return TGNN_OK;
+    }
+    const int64_t wn = (int64_t)out_dim * kDbK * n_slots;
+    f32_to_bf16_kernel<<<ew_grid64(wn), 256, 0, s>>>(w, wn, static_cast<__bf16 *>(wb_scratch));
+    return dense_bf16_slots_launch(a, slot_stride, n_slots, static_cast<const __bf16 *>(wb_scratch), bias, n, out_dim, act, out, bn_partial,
+                                   n_partials_host, s);
+}
+
 /* act(cat . w^T + b) over the slot-major bf16 skip buffer [n_slots][n_rows][64]; w fp32 [out_dim][64 n_slots] is rounded to
  * bf16 into wb_scratch (out_dim * 64 * n_slots bf16) first. */
 extern "C" int tgnn_dense_bf16_slots_fwd(const void *a_bf16, int64_t slot_stride, int32_t n_slots, const float *w,
@@ -923,10 +1067,8 @@ extern "C" int tgnn_dense_bf16_slots_fwd(const void *a_bf16, int64_t slot_stride
     TGNN_CHECK_ARG(n_rows >= 1 && n_slots >= 1 && out_dim >= 1 && out_dim <= 256, "shape");
     TGNN_CHECK_ARG(a_bf16 && w && b && out && wb_scratch && slot_stride >= n_rows * kC, "null pointer / stride");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int64_t wn = (int64_t)out_dim * kC * n_slots;
-    f32_to_bf16_kernel<<<ew_grid64(wn), 256, 0, s>>>(w, wn, static_cast<__bf16 *>(wb_scratch));
-    return dense_bf16_slots_launch(static_cast<const __bf16 *>(a_bf16), slot_stride, n_slots, static_cast<const __bf16 *>(wb_scratch),
-                                   b, n_rows, out_dim, act, out, bn_partial, n_partials_host, s);
+    return dense_bf16_slots_from_f32(static_cast<const __bf16 *>(a_bf16), slot_stride, n_slots, w, b, n_rows, out_dim, act, out, wb_scratch,
+                                     bn_partial, n_partials_host, s);
 }
 
 // ------------------------------------------------------------------------------------------ the whole forward
@@ -1044,10 +1186,8 @@ extern "C" int tgnn_forward_bf16(const tgnn_model_dims *dims, const void *const 
     // ---- final MLP: the first Linear reads the bf16 skip buffer in place, the rest runs on the fp32 dense kernels
     {
         const int pi = P.fin(0);
-        const int64_t wn = (int64_t)256 * kC * (D + 1);
-        f32_to_bf16_kernel<<<ew_grid64(wn), 256, 0, s>>>(P.f(pi), wn, w.wfin);
-        TGNN_TRY64(dense_bf16_slots_launch(w.mid, (int64_t)n * kC, D + 1, w.wfin, P.f(pi + 1), n, 256, TGNN_ACT_LEAKY_RELU, w.f1,
-                                           w.partf, &np1, s));
+        TGNN_TRY64(dense_bf16_slots_from_f32(w.mid, (int64_t)n * kC, D + 1, P.f(pi), P.f(pi + 1), n, 256, TGNN_ACT_LEAKY_RELU, w.f1, w.wfin,
+                                             w.partf, &np1, s));
         finalize1(w.partf, np1, 256, P.bn(pi + 2), w.stat_f[0]);
     }
     float *fbuf[4] = {w.f1, w.f2, w.f3, w.f4};
