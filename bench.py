@@ -652,6 +652,28 @@ def main():
             go.compute_sub_layout(xh, ah, aah, ch, cah, np.flatnonzero(alive_h))
             sub_info["cpu_numpy_us"] = (time.perf_counter() - t3) * 1e6
 
+    # ---- a whole greedy solve of the headline layout with the acceptance step on the device (csrc/greedy.hip: the documented
+    #      substitute for the reference's sequential host sweep): forwards of the shrinking sub-layouts, compaction and
+    #      acceptance per round, nothing but three counts per round on the host
+    if sub_info is not None and not args.no_extra_sizes:
+        from tilingnn_amd.solver.ml_solver.ml_solver import ML_Solver
+        from tilingnn_amd.util import algorithms as alg
+        cg = net.cache_graph
+        net.cache_graph = False
+        solver = ML_Solver(None, dev, None, net, num_prob_maps=1)
+        lay = alg.DeviceLayout(x, adj, adj_attr, col)
+        alg.solve_by_device_greedy(solver, lay, seed=1)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        sel, _, _ = alg.solve_by_device_greedy(solver, lay, seed=1)
+        torch.cuda.synchronize()
+        sub_info["device_greedy_solve"] = {"ms": (time.perf_counter() - t2) * 1e3, "rounds": int(alg.solve_by_device_greedy.last_rounds),
+                                           "tiles_selected": int(sel.sum()), "n_nodes": int(n_total),
+                                           "what": "solve_by_device_greedy: every round a forward of the remaining sub-layout; the "
+                                                   "reference's host sweep takes 244 rounds / 0.62 s at this size "
+                                                   "(profiles/r04_greedy_solve.txt)"}
+        net.cache_graph = cg
+
     # ---- one training step at the same shape: forward keeping activations, loss, backward through the
     #      adjoint kernels, Adam (torch's, the caller's optimizer in the reference: network_train.py)
     train_info = None
