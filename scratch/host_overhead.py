@@ -23,3 +23,25 @@ for cached in (True, False):
     for _ in range(200): net(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)
     pr.disable(); torch.cuda.synchronize()
     st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(12); print("\n".join(st.getvalue().splitlines()[:24]))
+
+# ---- where the host time goes: python before the library call | the call | python after
+import tilingnn_amd.graph_networks.networks.TilinGNN as mod
+real = mod.lib.tgnn_forward
+marks = []
+class Wrap:
+    def __call__(self, *a):
+        t0 = time.perf_counter(); r = real(*a); marks.append((t0, time.perf_counter())); return r
+mod.lib.tgnn_forward = Wrap()
+net.cache_graph = True
+for _ in range(5): net(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)
+torch.cuda.synchronize()
+pre, call, post, e2e = [], [], [], []
+for _ in range(50):
+    torch.cuda.synchronize(); marks.clear(); t0 = time.perf_counter()
+    net(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)
+    t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    a, b = marks[-1]
+    pre.append((a - t0) * 1e6); call.append((b - a) * 1e6); post.append((t1 - b) * 1e6); e2e.append((t2 - t0) * 1e6)
+med = lambda v: sorted(v)[len(v) // 2]
+print(f"cached forward at {n} nodes: python before the library call {med(pre):.0f} us | the call {med(call):.0f} us | python after {med(post):.0f} us | "
+      f"call entry -> results on the device {med(e2e):.0f} us")

@@ -76,15 +76,26 @@ class TilinGNN(Tracked, nn.Module):
 
     # ---- host-side table of device pointers -------------------------------------------------
     def _dims(self):
-        return _lib.ModelDims(self.node_features_dim, self.adj_edge_features_dim, self.network_width,
-                              self.network_depth, self.output_dim)
+        key = (self.node_features_dim, self.adj_edge_features_dim, self.network_width, self.network_depth, self.output_dim)
+        hit = self.__dict__.get("_tgnn_dims")
+        if hit is None or hit[0] != key:
+            hit = self.__dict__["_tgnn_dims"] = (key, _lib.ModelDims(*key))
+        return hit[1]
 
-    def _param_table(self):
+    def _param_table(self, verify: bool = True):
+        """(table, device).  verify=False: the cached table without the pointer comparison (~25 us for 400 entries) -- the
+        caller runs `_param_table_stale()` AFTER it has queued its work and repeats the work if that says so; the cache holds
+        the storages the table points into, so a stale pointer still points into live memory."""
         cache = self.__dict__.get("_tgnn_table")
         if cache is not None and cache[0] == _tracking.epoch():
             # the epoch covers attribute assignment, _apply and load_state_dict; storage swaps underneath a live
-            # Parameter (`p.data = t`, torch.utils.swap_tensors) show up as a changed data_ptr (~25 us for 400 entries)
-            if tuple(map(torch.Tensor.data_ptr, cache[3])) == cache[4]:
+            # Parameter (`p.data = t`, torch.utils.swap_tensors) show up as a changed data_ptr
+            if verify:
+                if tuple(map(torch.Tensor.data_ptr, cache[3])) == cache[4]:
+                    return cache[1], cache[2]
+            elif tuple(map(torch.Tensor.data_ptr, cache[6])) == cache[7]:
+                # (what the kernels WRITE -- the running statistics -- is compared up front even then: a stale read comes out of
+                #  memory the cache keeps alive and is repeated, a stale write would land in a buffer somebody else may own)
                 return cache[1], cache[2]
         dims = self._dims()
         sd = dict(self.named_parameters())
@@ -108,12 +119,23 @@ class TilinGNN(Tracked, nn.Module):
                 raise ValueError("all parameters must live on one device")
             table[i] = t.data_ptr()
             keep.append(t)
-        self.__dict__["_tgnn_table"] = (_tracking.epoch(), table, dev, keep, tuple(t.data_ptr() for t in keep))
+        written = [t for name, t in zip(names, keep) if name.endswith(("running_mean", "running_var", "num_batches_tracked"))]
+        self.__dict__["_tgnn_table"] = (_tracking.epoch(), table, dev, keep, tuple(t.data_ptr() for t in keep),
+                                        [t.untyped_storage() for t in keep], written, tuple(t.data_ptr() for t in written))
         return table, dev
+
+    def _param_table_stale(self) -> bool:
+        """True when a parameter's storage was swapped underneath the cached table (the cache is dropped)."""
+        cache = self.__dict__.get("_tgnn_table")
+        if cache is None or cache[0] != _tracking.epoch() or tuple(map(torch.Tensor.data_ptr, cache[3])) != cache[4]:
+            self.__dict__.pop("_tgnn_table", None)
+            return True
+        return False
 
     def __getstate__(self):                      # copy.deepcopy(network) (ml_solver.py:26) and pickling
         state = self.__dict__.copy()
         state.pop("_tgnn_table", None)
+        state.pop("_tgnn_dims", None)
         return state
 
     # ---- forward ----------------------------------------------------------------------------
@@ -189,7 +211,10 @@ class TilinGNN(Tracked, nn.Module):
         return out
 
     def _forward_one(self, x, adj_e_index, adj_e_features, col_e_idx, col_e_features=None, update_running=True):
-        table, dev = self._param_table()
+        fast = (self.activation_dtype == torch.float32 and not (self.autograd and self.training and torch.is_grad_enabled()))
+        # (the inference forward checks the cached pointer table AFTER it has queued its kernels: 25 us less in front of the
+        #  first launch; a stale table -- `p.data = t` under a live Parameter -- is rebuilt and the forward repeated)
+        table, dev = self._param_table(verify=not fast)
         for name, t in (("x", x), ("adj_e_index", adj_e_index), ("adj_e_features", adj_e_features),
                         ("col_e_idx", col_e_idx)):
             if t.device != dev:
@@ -225,4 +250,8 @@ class TilinGNN(Tracked, nn.Module):
         g = graph.c_struct()
         check(lib.tgnn_forward(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), int(bn_train and update_running), int(not bn_train),
                                ptr(probs), ptr(ws), ws_bytes, _lib.current_stream(dev), _lib.side_stream(dev)))
+        if self._param_table_stale():                                         # (see the top: checked behind the launches)
+            table, dev = self._param_table()
+            check(lib.tgnn_forward(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), int(bn_train and update_running),
+                                   int(not bn_train), ptr(probs), ptr(ws), ws_bytes, _lib.current_stream(dev), _lib.side_stream(dev)))
         return probs, adj_e_features                                          # TilinGNN.py:78

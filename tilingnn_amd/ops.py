@@ -75,6 +75,12 @@ class PreparedGraph:
     mid: Optional["NNConvBatches"] = None      # NNConv batches of the mid-size persistent layer loop (None: general schedule)
 
     def c_struct(self) -> _lib.Graph:
+        hit = self.__dict__.get("_c_struct")          # (the tensors of a prepared graph are never replaced)
+        if hit is None:
+            hit = self.__dict__["_c_struct"] = self._build_c_struct()
+        return hit
+
+    def _build_c_struct(self) -> _lib.Graph:
         t, st = self.cols, self.mid
         return _lib.Graph(self.n_nodes, self.n_adj_edges, self.n_col_edges, self.n_types,
                           self.adj_rowptr.data_ptr(), self.adj_src.data_ptr(), self.adj_type.data_ptr(),
