@@ -37,10 +37,19 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 void exclusive_scan_i32_shared(const int *in, int *out, int64_t n, int *ws, hipStream_t s);   // graph_prep.hip
 size_t scan_ws_ints_shared(int64_t n);
 
-// col_word: bits 0-15 occupancy mask | 16-20 type | 21-25 type of the NEXT run (on a run's first column: what the kernel
-// prefetches) | 26-27 chunks of the entry stream this column needs beyond the column before it | 28 last column of its tile
-// (the root column) | 29 first column of its type run
-constexpr unsigned kPsEnd = 1u << 28, kPsFirst = 1u << 29;
+// col_word: bits 0-15 occupancy mask | 16-19 type (the root column: T) | 20-23 type of the run BEHIND this column's run (what
+// the kernel fetches ahead; behind a tile's root run: the next tile's first run) | 24-25 chunks of the entry stream this column
+// needs beyond the column before it | 26-31 ring position of its first entry (its absolute entry number mod kPsRingEnt)
+#ifndef TGNN_PS_WAVES
+#define TGNN_PS_WAVES 12
+#endif
+#ifndef TGNN_PS_RING
+#define TGNN_PS_RING 6
+#endif
+constexpr int kPsWaves = TGNN_PS_WAVES;
+constexpr int kPsRing = TGNN_PS_RING;      // chunks of a wave's ring: chunk k of the stream lives in ring chunk k % kPsRing
+constexpr int kPsRingEnt = kPsRing * 8;    // (<= 64: the ring position has 6 bits in a column word)
+static_assert(kPsRingEnt <= 64 && kPsRing >= 4 && kPsRing <= 8, "ring size");
 
 // ------------------------------------------------------------------------------------------
 // structure: from the type columns of tgnn_nnconv_cols_build (graph_prep.hip)
@@ -82,18 +91,15 @@ __global__ __launch_bounds__(64) void ps_fill_kernel(const int *__restrict__ til
         const int cnt = __popc(m);
         if (valid) ent_src[e0 + pos + __popc(m & ((1u << i) - 1u))] = root ? (int)row : s;
         if (in && i == 0) {
-            unsigned w = m | ((unsigned)(meta & 0x1f) << 16);
+            unsigned w = m | ((unsigned)(meta & 0xf) << 16);
             const int need = (pos + cnt - 1) >> 3, before = (pos - 1) >> 3;       // (arithmetic shifts: -1 in front of the tile's first chunk)
-            w |= (unsigned)(need - before) << 26;
-            if (root) w |= kPsEnd;
-            if (meta & (1 << 8)) {
-                w |= kPsFirst;
-                int c2 = c + 1;
-                while (c2 < c1 && !(col_meta[c2] & (1 << 8))) ++c2;
-                // (behind the root run: the first run of the next tile -- the wave goes on there, or stops and never uses it)
-                const int nt = (c2 < c1 || tile + 1 < n_tiles) ? (col_meta[c2] & 0x1f) : 0;
-                w |= (unsigned)nt << 21;
-            }
+            w |= (unsigned)(need - before) << 24;
+            w |= (unsigned)((e0 + pos) % kPsRingEnt) << 26;
+            int c2 = c + 1;
+            while (c2 < c1 && !(col_meta[c2] & (1 << 8))) ++c2;
+            // (behind the root run: the first run of the next tile -- the wave goes on there, or stops and never uses it)
+            const int nt = (c2 < c1 || tile + 1 < n_tiles) ? (col_meta[c2] & 0xf) : 0;
+            w |= (unsigned)nt << 20;
             col_word[c] = w;
         }
         pos += cnt;
@@ -147,36 +153,33 @@ __device__ __forceinline__ T ps_lds_ld(unsigned addr) {
     return *reinterpret_cast<const __attribute__((address_space(3))) T *>((uintptr_t)addr);
 }
 // LDS-DMA by hand (hipcc drains vmcnt(0) in front of every LDS read behind a DMA it knows of): 64 lanes x 16 (4) bytes from
-// base + this lane's offset to lds_dst + 16 (4) * lane; counted on vmcnt, waited for by ps_wait_after
+// base + this lane's offset to lds_dst + 16 (4) * lane; counted on vmcnt, waited for with ps_wait_vmcnt
 __device__ __forceinline__ void ps_dma16(const void *base, unsigned voff, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds_dst) : "memory", "m0");
 }
 __device__ __forceinline__ void ps_dma4(const void *base, unsigned voff, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(base), "s"(lds_dst) : "memory", "m0");
 }
 
 constexpr int kPsStage = 16 * 20;           // floats of the per-wave BatchNorm staging tile (nnconv_cols.hip)
 
 struct PsLds {
-    unsigned zero, idx, ring, stage, total;
+    unsigned zero, idx, cw, ring, stage, total;
 };
-__host__ __device__ inline PsLds ps_lds_map(int n_types, int waves, int ring_chunks) {
+__host__ __device__ inline PsLds ps_lds_map(int n_types, int waves) {
     PsLds m;
     m.zero = (unsigned)(n_types + 1) * kWtTypeF16 * 4u;      // 128 bytes of zeros behind the weight image
     m.idx = m.zero + 256u;                                   // [waves][2][64] entry words
-    m.ring = (m.idx + (unsigned)waves * 512u + 1023u) & ~1023u;
-    m.stage = m.ring + (unsigned)waves * (unsigned)ring_chunks * 1024u;
+    m.cw = m.idx + (unsigned)waves * 512u;                   // [waves][2][64] column words
+    m.ring = (m.cw + (unsigned)waves * 512u + 1023u) & ~1023u;
+    m.stage = m.ring + (unsigned)waves * kPsRing * 1024u;
     m.total = m.stage + (unsigned)waves * kPsStage * 4u;
     const unsigned red = (unsigned)waves * 64u * 4u * 8u;    // the block's BatchNorm fold (aliases the image at the end)
     if (m.total < red) m.total = red;
     return m;
 }
 
-template <int WAVES, int RING>
+template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void nnconv32_ps_kernel(
     const void *__restrict__ hs, const int *__restrict__ tile_col_ptr, const unsigned *__restrict__ col_word,
     const int *__restrict__ tile_ent_ptr, const int *__restrict__ ent_src, const float *__restrict__ wimg, int n_types,
@@ -186,11 +189,10 @@ __global__ __launch_bounds__(WAVES * 64) void nnconv32_ps_kernel(
     // LOOK chunks are in flight beyond the last chunk of the column whose operands are being read (a column spans <= 3 chunks).
     // LOOK <= 5: the wait of the column before a batch's first chunk then also covers that batch's entry words (issued >= 8
     // chunks earlier, at most 3 + LOOK of them younger than what that wait covered)
-    constexpr int LOOK = RING - 3;
-    constexpr int kRingEnt = RING * 8;
-    static_assert(RING >= 4 && LOOK <= 5 && WAVES % 4 == 0, "shape");
+    constexpr int LOOK = kPsRing - 3;
+    static_assert(LOOK >= 1 && LOOK <= 5 && WAVES % 4 == 0, "shape");
     if (stamp && threadIdx.x == 0) atomicMin(stamp, wall_clock64());
-    const PsLds L = ps_lds_map(n_types, WAVES, RING);
+    const PsLds L = ps_lds_map(n_types, WAVES);
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_t *)lds_raw;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fj = lane & 15, fq = lane >> 4;
@@ -235,171 +237,167 @@ __global__ __launch_bounds__(WAVES * 64) void nnconv32_ps_kernel(
     __syncthreads();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // nothing of the compiler's is in flight when the hand-counted DMAs start
 
-    // ---- the loader half: chunks of 8 entries, their source rows named by entry words that arrive 64 at a time (two slots).
-    // Every column asks for the chunks it needs beyond its predecessor's, so exactly LOOK chunk DMAs are younger than a
-    // column's last chunk when its operands are read: ONE constant wait.  (The loader runs up to LOOK chunks past the end of
-    // the wave's stream: rows of the next wave's tiles or the slack's row 0, fetched and never read.)
-    const unsigned ring0 = lds0 + L.ring + (unsigned)wave * RING * 1024u;
+    // ---- the loader half: chunks of 8 entries (chunk k -> ring chunk k % kPsRing), their source rows named by entry words
+    // that arrive 64 at a time (two slots).  Every column asks for the chunks it needs beyond its predecessor's, so exactly
+    // LOOK chunk DMAs are younger than a column's last chunk when its operands are read: ONE constant wait.  (The loader runs
+    // up to LOOK chunks past the end of the wave's stream: rows of the next wave's tiles or the slack's row 0, never read.)
+    const unsigned ring0 = lds0 + L.ring + (unsigned)wave * kPsRing * 1024u;
+    const unsigned ring_end = ring0 + kPsRing * 1024u;
     const unsigned idx0 = lds0 + L.idx + (unsigned)wave * 512u;
+    const unsigned cw0 = lds0 + L.cw + (unsigned)wave * 512u;
+#ifdef TGNN_ABL_PSNOROT
+    const unsigned dma_piece = (unsigned)(lane & 7) << 4;
+#else
     const unsigned dma_piece = (unsigned)(((lane & 7) - (lane >> 3)) & 7) << 4;
-    const unsigned idx_lane = idx0 + ((unsigned)(lane >> 3) << 2);
-    int csub = 0, cbatch = 0;                                // the next chunk: number inside its batch of 8, the batch
-    unsigned ring_dst = ring0;                               // ... and its place in the ring
-    unsigned src_next = 0;                                   // its entry word (read one chunk ahead)
-    auto idx_dma = [&](int b) {                              // entry words [8 k0 + 64 b, + 64)
-        ps_dma4(ent_src, (unsigned)(((k0 << 3) + (b << 6) + lane) << 2), idx0 + (unsigned)(b & 1) * 256u);
+#endif
+    unsigned kpos = 0;                                       // chunks asked for so far (the next chunk's number in the wave's stream)
+    unsigned ring_dst = ring0 + (unsigned)(k0 % kPsRing) * 1024u;   // ... its place in the ring
+    const unsigned idx_lane = idx0 + ((unsigned)(lane >> 3) << 2);  // entry words: one per 8 lanes, two slots of 64 = 16 chunks
+    unsigned src_next = 0;                                   // the next chunk's entry word (read one chunk ahead)
+    auto idx_dma = [&](unsigned b) {                         // entry words [8 k0 + 64 b, + 64)
+        ps_dma4(ent_src, (unsigned)(((k0 << 3) + (int)(b << 6) + lane) << 2), idx0 + (b & 1u) * 256u);
+    };
+    auto cw_dma = [&](unsigned b) {                          // column words [cbeg + 64 b, + 64)
+        ps_dma4(col_word, (unsigned)((cbeg + (int)(b << 6) + lane) << 2), cw0 + (b & 1u) * 256u);
     };
     auto issue_chunk = [&]() {
-        const unsigned src = src_next;
-        ps_dma16(hs, (src << 7) + dma_piece, ring_dst);
-        ring_dst = ring_dst + 1024u == ring0 + RING * 1024u ? ring0 : ring_dst + 1024u;
-        ++csub;
-        if (csub == 8) {                                     // the next chunk opens batch cbatch + 1 (landed: see LOOK above);
-            csub = 0;                                        // the slot of the batch just finished takes the one behind it
-            ++cbatch;
-            idx_dma(cbatch + 1);
-        }
-        src_next = ps_lds_ld<unsigned>(idx_lane + (unsigned)(cbatch & 1) * 256u + (unsigned)csub * 32u);
+#ifndef TGNN_ABL_PSNODMA
+        ps_dma16(hs, (src_next << 7) + dma_piece, ring_dst);
+#endif
+        ring_dst += 1024u;
+        ring_dst = ring_dst == ring_end ? ring0 : ring_dst;
+        ++kpos;
+        // the next chunk opens a batch (landed: see LOOK above): the slot of the batch just finished takes the one behind it
+        if ((kpos & 7u) == 0u) idx_dma((kpos >> 3) + 1u);
+        src_next = ps_lds_ld<unsigned>(idx_lane + ((kpos & 15u) << 5));
     };
+
+    const unsigned lt_mask = (1u << fj) - 1u;
+    const unsigned zero_addr = lds0 + L.zero;
+    const unsigned w_lane = lds0 + (unsigned)lane * 16u;
+    const unsigned piece0 = (unsigned)fq << 4;
+
+    // ---- the column stream.  Outer loop: tiles; inner loop: a tile's edge columns, one per turn, the accumulators touched in ONE
+    //      place (hipcc keeps them where they are).  Column words come 64 per DMA into two slots and are read one column ahead
+    //      (every lane the same address); a column's six operands -- this lane's two pieces of its entry, the four fragments of
+    //      its type -- are read from LDS side by side.
     if (cbeg < cend) {
+        const unsigned t_bits = (unsigned)n_types << 16;
         idx_dma(0);
         idx_dma(1);
+        cw_dma(0);
+        cw_dma(1);
         ps_wait_vmcnt<0>();
         src_next = ps_lds_ld<unsigned>(idx_lane);
 #pragma unroll
         for (int i = 0; i < LOOK; ++i) issue_chunk();
-    }
-
-    // ---- the multiplying half
-    const unsigned lt_mask = (1u << fj) - 1u;
-    const unsigned zero_addr = lds0 + L.zero;
-    const unsigned w_lane = lds0 + (unsigned)lane * 16u;
-    // D^T tiles (channels 4 fq + r and 16 + 4 fq + r of row fj): the edge sum's hi.hi terms / its two small terms / the root term
-    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0, e0 = d0, e1 = d0, r0 = d0, r1 = d0;
-    f16x8 wh0, wh1, wl0, wl1;                                // the current type's fragments ...
-    u32x4 nh0 = {}, nh1 = {}, nl0 = {}, nl1 = {};            // ... and the next run's, on their way from the image
-    auto weights_fetch = [&](int type) {
-        const unsigned wa = w_lane + (unsigned)type * (kWtTypeF16 * 4u);
-        nh0 = ps_lds_ld<u32x4>(wa);
-        nh1 = ps_lds_ld<u32x4>(wa + 1024u);
-        nl0 = ps_lds_ld<u32x4>(wa + 2048u);
-        nl1 = ps_lds_ld<u32x4>(wa + 3072u);
-    };
-    auto weights_take = [&](unsigned w) {                    // column w opens a run: its fragments were asked for at the run before
-        wh0 = __builtin_bit_cast(f16x8, nh0); wh1 = __builtin_bit_cast(f16x8, nh1);
-        wl0 = __builtin_bit_cast(f16x8, nl0); wl1 = __builtin_bit_cast(f16x8, nl1);
-        weights_fetch((int)((w >> 21) & 0x1fu));
-    };
-    int pos_mod = 0;                                         // first entry of the next column, in the ring
-    unsigned degcnt = 0;
-    int64_t ctile = t0;
-    // stage A of a column: its chunks, the one wait, this lane's two operand pieces (an empty slot: zeros)
-    auto operands = [&](unsigned w, u32x4 &xh, u32x4 &xl, unsigned &valid) {
-        const unsigned mask = w & 0xffffu;
-        const int n_new = (int)((w >> 26) & 3u);
-        for (int i = 0; i < n_new; ++i) issue_chunk();
-        valid = (mask >> fj) & 1u;
-        unsigned q = (unsigned)pos_mod + (unsigned)__builtin_popcount(mask & lt_mask);
-        q = min(q, q - (unsigned)kRingEnt);                  // (wraps: q < 2 ring sizes)
-        const unsigned piece = ((unsigned)fq + q) & 7u;
-        unsigned addr = ring0 + (q << 7) + (piece << 4);
-        addr = valid ? addr : zero_addr;
-        ps_wait_vmcnt<LOOK>();
-        xh = ps_lds_ld<u32x4>(addr);
-        xl = ps_lds_ld<u32x4>(addr ^ 64u);
-        pos_mod += __builtin_popcount(mask);
-        if (w & kPsEnd) pos_mod = (pos_mod + 7) & ~7;        // the next tile's entries start on a chunk boundary
-        pos_mod = pos_mod >= kRingEnt ? pos_mod - kRingEnt : pos_mod;
-    };
-    // stage B: the products; the root column also ends its tile
-    auto multiply = [&](unsigned w, const u32x4 &xh_, const u32x4 &xl_, unsigned valid) {
-        const f16x8 xh = __builtin_bit_cast(f16x8, xh_), xl = __builtin_bit_cast(f16x8, xl_);
-        degcnt += valid;
-        if (!(w & kPsEnd)) {
-            e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl0, xh, e0, 0, 0, 0);   // lo . hi
-            e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl1, xh, e1, 0, 0, 0);
-            d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh0, xh, d0, 0, 0, 0);   // hi . hi
-            d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh1, xh, d1, 0, 0, 0);
-            e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh0, xl, e0, 0, 0, 0);   // hi . lo
-            e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh1, xl, e1, 0, 0, 0);
-            return;
-        }
-        r0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl0, xh, r0, 0, 0, 0);
-        r1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl1, xh, r1, 0, 0, 0);
-        r0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh0, xl, r0, 0, 0, 0);
-        r1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh1, xl, r1, 0, 0, 0);
-        r0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh0, xh, r0, 0, 0, 0);
-        r1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh1, xh, r1, 0, 0, 0);
-        const unsigned deg = degcnt - valid;                 // (the root column's own slot is not an edge)
-        const float inv = unscale / (float)(deg > 0u ? deg : 1u);
-        const int64_t v = ctile * 16 + fj;
-        float4 o0, o1;
-        o0.x = fmaf(d0[0] + e0[0], inv, fmaf(r0[0], unscale, bias0.x)); o0.y = fmaf(d0[1] + e0[1], inv, fmaf(r0[1], unscale, bias0.y));
-        o0.z = fmaf(d0[2] + e0[2], inv, fmaf(r0[2], unscale, bias0.z)); o0.w = fmaf(d0[3] + e0[3], inv, fmaf(r0[3], unscale, bias0.w));
-        o1.x = fmaf(d1[0] + e1[0], inv, fmaf(r1[0], unscale, bias1.x)); o1.y = fmaf(d1[1] + e1[1], inv, fmaf(r1[1], unscale, bias1.y));
-        o1.z = fmaf(d1[2] + e1[2], inv, fmaf(r1[2], unscale, bias1.z)); o1.w = fmaf(d1[3] + e1[3], inv, fmaf(r1[3], unscale, bias1.w));
-        if (act == TGNN_ACT_LEAKY_RELU) {
-            o0.x = leakyf_(o0.x); o0.y = leakyf_(o0.y); o0.z = leakyf_(o0.z); o0.w = leakyf_(o0.w);
-            o1.x = leakyf_(o1.x); o1.y = leakyf_(o1.y); o1.z = leakyf_(o1.z); o1.w = leakyf_(o1.w);
-        }
-        if (valid) {
-            *reinterpret_cast<float4 *>(out + v * 32 + 4 * fq) = o0;
-            *reinterpret_cast<float4 *>(out + v * 32 + 16 + 4 * fq) = o1;
-        }
-        if (bn_partial) {
-            // column sums in fp64: transpose through the wave's own LDS tile, one 16-channel half at a time (nnconv_cols.hip)
-            auto half_sums = [&](float4 o, double &sum, double &sq) {
-                o.x = valid ? o.x : 0.f; o.y = valid ? o.y : 0.f;
-                o.z = valid ? o.z : 0.f; o.w = valid ? o.w : 0.f;
-                *reinterpret_cast<float4 *>(stg + fj * 20 + 4 * fq) = o;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double val = (double)stg[(4 * fq + r) * 20 + fj];
-                    sum += val;
-                    sq += val * val;
+        unsigned cpos = 0;                                   // columns taken so far
+        unsigned w_next_v = ps_lds_ld<unsigned>(cw0);
+        const unsigned n_cols = (unsigned)(cend - cbeg);
+        int64_t ctile = t0;
+#pragma unroll 1
+        while (cpos < n_cols) {
+            // D^T tiles (channels 4 fq + r and 16 + 4 fq + r of row fj): the edge sum's hi.hi terms / its two small terms
+            f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0, e0 = d0, e1 = d0;
+            unsigned degcnt = 0, valid;
+            f16x8 wh0, wh1, wl0, wl1, xh, xl;
+#pragma unroll 1
+            for (;;) {
+                const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)w_next_v);
+                ++cpos;
+                // (two words into a batch the slot of the batch before it is free and takes the batch behind this one; the word
+                //  read now was asked for >= 62 columns earlier: landed long ago)
+                if ((cpos & 63u) == 2u && cpos > 64u) cw_dma((cpos >> 6) + 1u);
+                w_next_v = ps_lds_ld<unsigned>(cw0 + ((cpos & 127u) << 2));
+                // the column's chunks
+                const unsigned n_new = (w >> 24) & 3u;
+                if (n_new > 0u) {
+                    issue_chunk();
+                    if (n_new > 1u) {
+                        issue_chunk();
+                        if (n_new > 2u) issue_chunk();
+                    }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            };
-            half_sums(o0, bs[0], bq[0]);
-            half_sums(o1, bs[1], bq[1]);
-        }
-        d0 = f32x4{0.f, 0.f, 0.f, 0.f};
-        d1 = d0; e0 = d0; e1 = d0; r0 = d0; r1 = d0;
-        degcnt = 0;
-        ++ctile;
-    };
-
-    // ---- the column stream, four column words per scalar load; column j + 1's operands are asked for before column j is
-    //      multiplied, the fragments of a run one run ahead
-    if (cbeg < cend) {
-        auto word = [&](int c) -> unsigned { return c < cend ? col_word[c] : 0u; };
-        unsigned wa[4] = {word(cbeg), word(cbeg + 1), word(cbeg + 2), word(cbeg + 3)};
-        weights_fetch((int)((wa[0] >> 16) & 0x1fu));          // (a wave starts on a tile's first column: the first of a run)
-        u32x4 xh, xl;
-        unsigned valid;
-        operands(wa[0], xh, xl, valid);
-        weights_take(wa[0]);
-        for (int c = cbeg; c < cend; c += 4) {
-            const unsigned wb[4] = {word(c + 4), word(c + 5), word(c + 6), word(c + 7)};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (c + u >= cend) break;                    // (uniform)
-                const unsigned w = wa[u], wn = u < 3 ? wa[u + 1] : wb[0];
-                u32x4 yh = {}, yl = {};
-                unsigned vn = 0;
-                const bool more = c + u + 1 < cend;
-                if (more) operands(wn, yh, yl, vn);
-                multiply(w, xh, xl, valid);
-                if (more && (wn & kPsFirst)) weights_take(wn);
-                xh = yh; xl = yl; valid = vn;
+                // this lane's entry: ring position of the column's first entry + the filled slots below this lane's
+                valid = (w >> fj) & 1u;
+                unsigned q = (unsigned)__builtin_popcount(w & lt_mask) + (w >> 26);
+                if constexpr ((kPsRingEnt & (kPsRingEnt - 1)) == 0) q &= (unsigned)(kPsRingEnt - 1);
+                else q = min(q, q - (unsigned)kPsRingEnt);   // (q < 2 ring sizes)
+                unsigned addr = ring0 + (q << 7) + (((q << 4) + piece0) & 0x70u);
+                addr = valid ? addr : zero_addr;
+                const unsigned wa = w_lane + ((w >> 4) & 0xf000u);          // type * 4096 bytes
+#ifndef TGNN_ABL_PSNOWAIT
+                ps_wait_vmcnt<LOOK>();
+#endif
+#ifdef TGNN_ABL_PSNOLDS
+                xh = __builtin_bit_cast(f16x8, u32x4{addr, addr, addr, addr}); xl = xh;
+#else
+                xh = __builtin_bit_cast(f16x8, ps_lds_ld<u32x4>(addr));
+                xl = __builtin_bit_cast(f16x8, ps_lds_ld<u32x4>(addr ^ 64u));
+#endif
+                wh0 = __builtin_bit_cast(f16x8, ps_lds_ld<u32x4>(wa));
+                wh1 = __builtin_bit_cast(f16x8, ps_lds_ld<u32x4>(wa + 1024u));
+                wl0 = __builtin_bit_cast(f16x8, ps_lds_ld<u32x4>(wa + 2048u));
+                wl1 = __builtin_bit_cast(f16x8, ps_lds_ld<u32x4>(wa + 3072u));
+                if ((w & 0xf0000u) == t_bits) break;         // (scalar) the root column: behind the loop
+                degcnt += valid;
+#ifdef TGNN_ABL_PSNOMUL
+                e0[0] += (float)xh[0] * (float)wl0[0] + (float)xl[1] * (float)wh1[0] + (float)wh0[0] * (float)wl1[2];
+#else
+                e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl0, xh, e0, 0, 0, 0);   // lo . hi
+                e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl1, xh, e1, 0, 0, 0);
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh0, xh, d0, 0, 0, 0);   // hi . hi
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh1, xh, d1, 0, 0, 0);
+                e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh0, xl, e0, 0, 0, 0);   // hi . lo
+                e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh1, xl, e1, 0, 0, 0);
+#endif
             }
+            // ---- the root column ends the tile
+            f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
+            r0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl0, xh, r0, 0, 0, 0);
+            r1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl1, xh, r1, 0, 0, 0);
+            r0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh0, xl, r0, 0, 0, 0);
+            r1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh1, xl, r1, 0, 0, 0);
+            r0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh0, xh, r0, 0, 0, 0);
+            r1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh1, xh, r1, 0, 0, 0);
+            const float inv = unscale / (float)(degcnt > 0u ? degcnt : 1u);
+            const int64_t v = ctile * 16 + fj;
+            float4 o0, o1;
+            o0.x = fmaf(d0[0] + e0[0], inv, fmaf(r0[0], unscale, bias0.x)); o0.y = fmaf(d0[1] + e0[1], inv, fmaf(r0[1], unscale, bias0.y));
+            o0.z = fmaf(d0[2] + e0[2], inv, fmaf(r0[2], unscale, bias0.z)); o0.w = fmaf(d0[3] + e0[3], inv, fmaf(r0[3], unscale, bias0.w));
+            o1.x = fmaf(d1[0] + e1[0], inv, fmaf(r1[0], unscale, bias1.x)); o1.y = fmaf(d1[1] + e1[1], inv, fmaf(r1[1], unscale, bias1.y));
+            o1.z = fmaf(d1[2] + e1[2], inv, fmaf(r1[2], unscale, bias1.z)); o1.w = fmaf(d1[3] + e1[3], inv, fmaf(r1[3], unscale, bias1.w));
+            if (act == TGNN_ACT_LEAKY_RELU) {
+                o0.x = leakyf_(o0.x); o0.y = leakyf_(o0.y); o0.z = leakyf_(o0.z); o0.w = leakyf_(o0.w);
+                o1.x = leakyf_(o1.x); o1.y = leakyf_(o1.y); o1.z = leakyf_(o1.z); o1.w = leakyf_(o1.w);
+            }
+            if (valid) {
+                *reinterpret_cast<float4 *>(out + v * 32 + 4 * fq) = o0;
+                *reinterpret_cast<float4 *>(out + v * 32 + 16 + 4 * fq) = o1;
+            }
+            if (bn_partial) {
+                // column sums in fp64: transpose through the wave's own LDS tile, one 16-channel half at a time (nnconv_cols.hip)
+                auto half_sums = [&](float4 o, double &sum, double &sq) {
+                    o.x = valid ? o.x : 0.f; o.y = valid ? o.y : 0.f;
+                    o.z = valid ? o.z : 0.f; o.w = valid ? o.w : 0.f;
+                    *reinterpret_cast<float4 *>(stg + fj * 20 + 4 * fq) = o;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-            for (int u = 0; u < 4; ++u) wa[u] = wb[u];
+                    for (int r = 0; r < 4; ++r) {
+                        const double val = (double)stg[(4 * fq + r) * 20 + fj];
+                        sum += val;
+                        sq += val * val;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                };
+                half_sums(o0, bs[0], bq[0]);
+                half_sums(o1, bs[1], bq[1]);
+            }
+            ++ctile;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (nothing of this wave's is still on its way into the LDS that is reused below)
@@ -423,17 +421,10 @@ __global__ __launch_bounds__(WAVES * 64) void nnconv32_ps_kernel(
     if (stamp && tid == 0) atomicMax(stamp + 1, wall_clock64());
 }
 
-#ifndef TGNN_PS_WAVES
-#define TGNN_PS_WAVES 12
-#endif
-#ifndef TGNN_PS_RING
-#define TGNN_PS_RING 6
-#endif
-
 int32_t nnconv_ps_max_types() {
     // the largest T whose LDS map fits
     int t = 0;
-    while (ps_lds_map(t + 1, TGNN_PS_WAVES, TGNN_PS_RING).total <= 160u * 1024u - 256u) ++t;
+    while (t < 15 && ps_lds_map(t + 1, kPsWaves).total <= 160u * 1024u - 256u) ++t;   // (a column word has 4 bits for the type, the root's included)
     return t;
 }
 
@@ -441,11 +432,11 @@ int launch_nnconv_ps(const void *hs, const int32_t *tile_col_ptr, const uint32_t
                      const int32_t *ent_src, const float *wimg, int32_t n_types, const float *bias, int64_t n_nodes, int32_t act,
                      float *out, double *bn_partial, int32_t *n_partials_host, const float *h_scale, const unsigned *root_max,
                      hipStream_t s, unsigned long long *stamp) {
-    constexpr int WAVES = TGNN_PS_WAVES, RING = TGNN_PS_RING;
-    auto kern = nnconv32_ps_kernel<WAVES, RING>;
+    constexpr int WAVES = kPsWaves;
+    auto kern = nnconv32_ps_kernel<WAVES>;
     static LdsOptIn site;
     TGNN_CHECK_HIP(opt_in_dynamic_lds(kern, 160 * 1024, site));
-    const PsLds L = ps_lds_map(n_types, WAVES, RING);
+    const PsLds L = ps_lds_map(n_types, WAVES);
     if (L.total > 160u * 1024u) {
         set_error("launch_nnconv_ps: %d edge types do not fit the LDS map", n_types);
         return TGNN_ERR_UNSUPPORTED;
