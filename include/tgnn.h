@@ -475,6 +475,10 @@ int32_t tgnn_set_split_precision(int32_t mode);
  * HBM; csrc/gin.hip: gin32_fused_kernel): 0 never (the two kernels of tgnn_gin_fwd), 1 (default) for layouts of 200 000 nodes and
  * more -- where it is faster --, 2 always.  Same arithmetic, the CollConv rows are bit-identical.  Returns the previous mode. */
 int32_t tgnn_set_gin_fused(int32_t mode);
+/* The collision branch's MLP inside tgnn_forward / tgnn_forward_sharded (inference): 1 = layers 2 and 3 on fp16 pairs
+ * (three matrix terms; their inputs are sigmoids), 16 waves per block (csrc/gin.hip: gin32_mlp16_kernel); 0 (default: the
+ * forward measured no faster with it, csrc/gin.hip) = the bf16 x 3 kernel the training forward and tgnn_gin_fwd run.  Returns the previous setting. */
+int32_t tgnn_set_gin_mlp_f16(int32_t on);
 
 /* Small layouts (<= tgnn_graph_prep_small_max_nodes() nodes, <= ..._max_edges() edges per set): everything above --
  * tgnn_csr_build of both edge sets (self loops dropped from the collision set), tgnn_edge_type_dedup, the types in CSR

@@ -1,0 +1,18 @@
+#!/bin/bash
+# scratch/abl_any.sh <tag> <kernel-substring> <script+args> -- <libtags...>: rocprofv3 average of one kernel for the default library and builds
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+tag=$1; kn=$2; shift 2
+cmd=()
+while [ "$1" != "--" ]; do cmd+=("$1"); shift; done; shift
+mkdir -p gpurun_out/$tag
+for lt in default "$@"; do
+  if [ $lt = default ]; then unset TGNN_LIB_PATH; else export TGNN_LIB_PATH=$GRAFT_REPO_ROOT/scratch/libs/libtgnn_$lt.so; fi
+  rm -rf /tmp/abl_$lt
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abl_$lt -o t -- python "${cmd[@]}" > /tmp/abl_$lt.log 2>&1
+  f=$(find /tmp/abl_$lt -name "*kernel_stats.csv" | head -1)
+  python - <<PY | tee -a gpurun_out/$tag/abl.txt
+import csv
+rows=[r for r in csv.DictReader(open("$f")) if "$kn" in r["Name"]]
+for r in rows: print("$lt".ljust(12), r["Name"][:44], "calls", r["Calls"], "avg_us %.1f min %.1f" % (float(r["AverageNs"])/1e3, float(r["MinNs"])/1e3))
+PY
+done

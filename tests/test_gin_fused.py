@@ -62,7 +62,9 @@ def test_fused_gin_rows_equal_the_two_kernel_form(dev, n, general_schedule):
         p0, s0, a0 = _run(net, inputs, n, dev)
     with gin_fused(True):
         p1, s1, a1 = _run(net, inputs, n, dev)
-    assert torch.equal(a0[0], a1[0])                            # CollConv_0 (reads slot 0, no folded BatchNorm): bit for bit
+    # CollConv_0 (reads slot 0, no folded BatchNorm): the same neighbourhood sums; the fused kernel's MLP is the bf16 x 3 one, the
+    # two-kernel form's the fp16-pair one of the inference forward [r5]: rounding level (both ~1e-7 of the fp64 oracle)
+    assert orc.rel_max_err(a1[0], a0[0].double()) < 1e-6
     # CollConv_1 folds BatchNorm_0's record in: the record's sums are associated differently (fp64), so rounding level only
     assert orc.rel_max_err(a1[1], a0[1].double()) < 1e-5
     assert orc.rel_max_err(s1[2], s0[2].double()) < 1e-4
@@ -90,3 +92,40 @@ def test_fused_gin_forward_is_bit_reproducible_and_keeps_the_running_statistics(
             assert orc.rel_max_err(sds[1][k], sds[0][k]) < 1e-4, k
         elif k.endswith("num_batches_tracked"):
             assert int(sds[0][k]) == int(sds[1][k]) == 4, k
+
+
+@contextlib.contextmanager
+def gin_mlp_f16(on):
+    from tilingnn_amd import _lib
+    before = _lib.lib.tgnn_set_gin_mlp_f16(1 if on else 0)
+    try:
+        yield
+    finally:
+        _lib.lib.tgnn_set_gin_mlp_f16(before)
+
+
+@pytest.mark.parametrize("n", [6000, 40000, 100000])
+def test_inference_gin_mlp_on_fp16_pairs_against_the_oracle(dev, n, general_schedule):
+    """[r5] csrc/gin.hip: gin32_mlp16_kernel -- layers 2 / 3 of GINConv's MLP on fp16 pairs (their inputs are sigmoids), the output
+    sigmoid on a two-part exponent: the raw CollConv rows of layer 0 against the fp64 oracle (north_star's 1e-5; measured ~1e-7),
+    against the bf16 x 3 kernel it replaces in the inference forward, and bit-repeatable."""
+    inputs, inputs64 = _layout(n, dev, seed=5)
+    net, sd = make_net(dev, depth=2)
+    with gin_fused(False):
+        with gin_mlp_f16(True):
+            p1, s1, a1 = _run(net, inputs, n, dev)
+            p1b, s1b, a1b = _run(net, inputs, n, dev)
+        with gin_mlp_f16(False):
+            p0, s0, a0 = _run(net, inputs, n, dev)
+    assert torch.equal(a1[0], a1b[0]) and torch.equal(p1, p1b)
+    assert not torch.equal(a1[0], a0[0])                         # (it IS the other kernel)
+    cap = {}
+    with torch.no_grad():
+        want = orc.tilingnn_forward(orc.cast_sd(sd, torch.float64), *inputs64, capture=cap)[0]
+    gin0 = torch.nn.functional.leaky_relu(cap["gin.0"])          # a2 holds LeakyReLU(GINConv) before its BatchNorm
+    e1, e0 = orc.rel_max_err(a1[0], gin0), orc.rel_max_err(a0[0], gin0)
+    print(f"n {n}: GINConv_0 vs fp64: fp16-pair kernel {e1:.2e}, bf16 x 3 kernel {e0:.2e}")
+    assert e1 < 1e-6 and e0 < 1e-6
+    for k in (1, 2):
+        assert orc.rel_max_err(s1[k], cap[f"mid.{k}"]) < 2e-5 * 4 ** (k - 1)
+    assert float((p1.double() - want).abs().max()) < 4e-4

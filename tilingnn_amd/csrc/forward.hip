@@ -613,7 +613,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
             if (s2) {
                 TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[1 + i], 0));
                 TGNN_TRY(launch_gin32_mlp(w.t0, P.f(b + 14), P.f(b + 15), P.f(b + 16), P.f(b + 17), P.f(b + 18), P.f(b + 19), n,
-                                          TGNN_ACT_LEAKY_RELU, w.a2[i & 1], w.part2, &np2, s));
+                                          TGNN_ACT_LEAKY_RELU, w.a2[i & 1], w.part2, &np2, s, nullptr, true));
             } else {
                 TGNN_TRY(gin_layer(i, s));
             }
@@ -651,7 +651,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
             TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[1 + i], 0));
             if (!split)
                 TGNN_TRY(launch_gin32_mlp(w.t0, P.f(b + 14), P.f(b + 15), P.f(b + 16), P.f(b + 17), P.f(b + 18), P.f(b + 19), n,
-                                          TGNN_ACT_LEAKY_RELU, w.a2[i & 1], w.part2, &np2, s));
+                                          TGNN_ACT_LEAKY_RELU, w.a2[i & 1], w.part2, &np2, s, nullptr, true));
             BnJobs jobs{};
             jobs.job[0] = bn_job(w.part1, np1, P.bn(b + 8), w.stat1);
             jobs.job[1] = bn_job(w.part2, np2, P.bn(b + 20), w.stat2[i & 1]);

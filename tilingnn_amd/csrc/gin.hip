@@ -333,6 +333,236 @@ __global__ __launch_bounds__(kMlpThreads, 2) void gin32_mlp_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// The same MLP for the inference forward ([r5]; the kernel above stays for the training forward, whose adjoint tests pin its
+// bits, and for layouts the checks below exclude).  What its counters said (profiles/r05_pmc_gin_mlp.txt): 675 vector
+// instructions per 16-row tile against 60 matrix instructions, two waves per SIMD parked 40 % of their cycles -- it runs at the
+// speed of its vector stream, and 40 % of that stream was the libm sigmoid of the output.  Here:
+//   * layers 2 and 3 take their inputs -- sigmoids, in (0, 1) -- as fp16 PAIRS (tgnn_common.h: split2_f16) against weight images
+//     scaled by a power of two (max |W| from the block's own prologue): 3 matrix terms instead of 6, 24 instead of 36 split
+//     instructions per 8 values; the scale comes off inside the sigmoid's exponent (acc = s (W x + b); sigma(acc / s));
+//     layer 1 (its input, the neighbourhood sum, has no bound at hand) stays on bf16 x 3.  36 matrix instructions per tile.
+//   * the output sigmoid keeps its accuracy at a third of the instructions: exp2 on a two-part product (the rounding of
+//     v log2 e is what costs accuracy at |v| ~ 10), one Newton step on the hardware reciprocal; LeakyReLU behind a sigmoid is the
+//     identity and is not executed.
+//   * weight fragments come out of the LDS image per tile instead of living in 120 registers: 16 waves per block (4 per SIMD)
+//     cover each other's waits.
+// ------------------------------------------------------------------------------------------
+extern std::atomic<int> g_gin_mlp16;     // tgnn_set_gin_mlp_f16 (default off: see the note below)
+#ifndef TGNN_GIN16_WAVES
+#define TGNN_GIN16_WAVES 8
+#endif
+constexpr int kMlp16Waves = TGNN_GIN16_WAVES, kMlp16Threads = kMlp16Waves * 64;
+using f16x8g = tgnn_f16x8;
+
+// 1 / (1 + exp(-v)), ~1.5 ulp: t = -v log2 e as th + tl, e = 2^th (1 + tl ln 2), r = 1 / (1 + e) refined once
+__device__ __forceinline__ float gin_sigmoid_out(float v) {
+    constexpr float kL2eH = 1.44269502162933349609375f, kL2eL = 1.925963033500011e-8f, kLn2 = 0.693147182464599609375f;
+    const float nv = -fmaxf(v, -87.0f);                       // (e stays finite: the result there is < 2e-38 either way)
+    const float th = nv * kL2eH;
+    const float tl = fmaf(nv, kL2eH, -th) + nv * kL2eL;
+    const float eh = __builtin_amdgcn_exp2f(th);
+    const float e = fmaf(eh, tl * kLn2, eh);
+    const float d = 1.0f + e;
+    float r = __builtin_amdgcn_rcpf(d);
+    r = fmaf(fmaf(-d, r, 1.0f), r, r);
+    return r;
+}
+
+__global__ __launch_bounds__(kMlp16Threads) void gin32_mlp16_kernel(
+    const float *__restrict__ z, const float *__restrict__ w1, const float *__restrict__ b1,
+    const float *__restrict__ w2, const float *__restrict__ b2, const float *__restrict__ w3,
+    const float *__restrict__ b3, int64_t n, float *__restrict__ out, double *__restrict__ bn_partial, GinFin fin) {
+    // weight images: W1 [plane 3][M block 2][i 16][q 4] x bf16x8; W2 [plane 2][M block 4][..] x f16x8 (K in kf order);
+    // W3 [plane 2][M block 2][K step 2][..] x f16x8
+    __shared__ bf16x8 W1s[3 * 2 * 64];
+    __shared__ f16x8g W2s[2 * 4 * 64];
+    __shared__ f16x8g W3s[2 * 2 * 2 * 64];
+    __shared__ __attribute__((aligned(16))) float Bs[128];   // b1 | s2 b2 | s3 b3
+    __shared__ float wmax[2][kMlp16Waves];
+    __shared__ double red[kMlp16Waves * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fn = lane & 15, fq = lane >> 4;
+
+    const int64_t n_tiles = (n + 15) / 16;
+    const int nblk = gridDim.x;
+    int64_t blk = blockIdx.x;
+    if (nblk >= 8 && (nblk & 7) == 0) blk = (int64_t)(blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    const int64_t slot = blk * 4 + (wave & 3), n_slots = (int64_t)nblk * 4;
+    const int64_t q0 = n_tiles * slot / n_slots, q1 = n_tiles * (slot + 1) / n_slots;
+    constexpr int kSubs = kMlp16Waves / 4;
+    const int sub = wave >> 2;
+    const int64_t t0 = q0 + (q1 - q0) * sub / kSubs, t1 = q0 + (q1 - q0) * (sub + 1) / kSubs;
+
+    auto load_z = [&](int64_t tile, float4 (&zin)[2]) {
+        int64_t zr = tile * 16 + fn;                        // clamped, unconditional: rows >= n are masked at the store
+        zr = zr < n ? zr : n - 1;
+        const float4 *pz = reinterpret_cast<const float4 *>(z + zr * 32 + 8 * fq);
+        zin[0] = pz[0];
+        zin[1] = pz[1];
+    };
+    float4 zin[2];
+    load_z(t0 < t1 ? t0 : 0, zin);                          // in flight while the weight images are built
+
+    // ---- the scales of the fp16 images: max |W2|, max |W3| over the block (2 048 weights each)
+    {
+        float m2 = 0.f, m3 = 0.f;
+        for (int i = tid; i < 2048; i += kMlp16Threads) {
+            m2 = fmaxf(m2, fabsf(w2[i]));
+            m3 = fmaxf(m3, fabsf(w3[i]));
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            m2 = fmaxf(m2, __shfl_xor(m2, d, 64));
+            m3 = fmaxf(m3, __shfl_xor(m3, d, 64));
+        }
+        if (lane == 0) { wmax[0][wave] = m2; wmax[1][wave] = m3; }
+    }
+    __syncthreads();
+    float s2, s3;
+    {
+        float m2 = 0.f, m3 = 0.f;
+#pragma unroll
+        for (int w = 0; w < kMlp16Waves; ++w) { m2 = fmaxf(m2, wmax[0][w]); m3 = fmaxf(m3, wmax[1][w]); }
+        s2 = pow2_scale_for(__float_as_uint(m2), 0);         // s |w| < 2^15 (0, inf, nan: 1)
+        s3 = pow2_scale_for(__float_as_uint(m3), 0);
+    }
+    for (int i = tid; i < 2 * 64; i += kMlp16Threads) {     // item = (M block, i, q): 8 weights
+        const int mb = i >> 6, ii = (i >> 2) & 15, q = i & 3;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = w1[(16 * mb + ii) * 32 + 8 * q + e];
+        gin_split3(x, W1s[(0 * 2 + mb) * 64 + ii * 4 + q], W1s[(1 * 2 + mb) * 64 + ii * 4 + q], W1s[(2 * 2 + mb) * 64 + ii * 4 + q]);
+    }
+    for (int i = tid; i < 4 * 64; i += kMlp16Threads) {
+        const int mb = i >> 6, ii = (i >> 2) & 15, q = i & 3;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = w2[(16 * mb + ii) * 32 + gin_kf(q, e)];
+        split2_f16(x, s2, W2s[(0 * 4 + mb) * 64 + ii * 4 + q], W2s[(1 * 4 + mb) * 64 + ii * 4 + q]);
+    }
+    for (int i = tid; i < 4 * 64; i += kMlp16Threads) {     // item = (M block, K step, i, q)
+        const int mb = i >> 7, ks = (i >> 6) & 1, ii = (i >> 2) & 15, q = i & 3;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = w3[(16 * mb + ii) * 64 + 32 * ks + gin_kf(q, e)];
+        const int o = (mb * 2 + ks) * 64 + ii * 4 + q;
+        split2_f16(x, s3, W3s[0 * 256 + o], W3s[1 * 256 + o]);
+    }
+    if (tid < 32) Bs[tid] = b1[tid];
+    else if (tid < 96) Bs[tid] = s2 * b2[tid - 32];
+    else if (tid < 128) Bs[tid] = s3 * b3[tid - 96];
+    __syncthreads();
+
+    auto bias4 = [&](int base, int mb) {
+        const float4 t = *reinterpret_cast<const float4 *>(Bs + base + 16 * mb + 4 * fq);
+        return f32x4{t.x, t.y, t.z, t.w};
+    };
+    const bf16x8 *w1p = W1s + fn * 4 + fq;
+    const f16x8g *w2p = W2s + fn * 4 + fq, *w3p = W3s + fn * 4 + fq;
+    // sigma(acc / s) = 1 / (1 + 2^(acc * c)),  c = -log2 e / s  (s a power of two: exact)
+    const float c2 = -1.44269504088896340736f / s2, inv3 = 1.0f / s3;
+    auto sig2 = [&](float a) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a * c2)); };
+    // acc += W . X over one K step of 32, fp16 pairs: three cross terms, smallest first
+    auto mma3 = [&](const f16x8g *wpl, int plane_stride, const f16x8g &xh, const f16x8g &xl, f32x4 acc) {
+        const f16x8g wh = wpl[0], wl = wpl[plane_stride];
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc, 0, 0, 0);   // lo . hi
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc, 0, 0, 0);   // hi . lo
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc, 0, 0, 0);   // hi . hi
+        return acc;
+    };
+    double cs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cq[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // BN sums of this lane's 8 output features
+
+#ifdef TGNN_ABL_G16NOTILE
+    for (int64_t tile = t0; tile < t0; ++tile) {
+#else
+    for (int64_t tile = t0; tile < t1; ++tile) {
+#endif
+        asm volatile("" ::: "memory");                       // (the fragments are re-read from the image every tile: no 88 registers of them)
+        bf16x8 xb[3];
+        {
+            const float x[8] = {zin[0].x, zin[0].y, zin[0].z, zin[0].w, zin[1].x, zin[1].y, zin[1].z, zin[1].w};
+            gin_split3(x, xb[0], xb[1], xb[2]);
+        }
+        load_z(tile + 1 < t1 ? tile + 1 : tile, zin);
+        // ---- layer 1 (bf16 x 3): 2 M blocks
+        const f32x4 h1a = gin_mma6(w1p + 0 * 64, 2 * 64, xb, bias4(0, 0));
+        const f32x4 h1b = gin_mma6(w1p + 1 * 64, 2 * 64, xb, bias4(0, 1));
+        f16x8g xh, xl;
+        {
+            const float x[8] = {sigmoidf_(h1a[0]), sigmoidf_(h1a[1]), sigmoidf_(h1a[2]), sigmoidf_(h1a[3]),
+                                sigmoidf_(h1b[0]), sigmoidf_(h1b[1]), sigmoidf_(h1b[2]), sigmoidf_(h1b[3])};
+            split2_f16(x, 1.0f, xh, xl);
+        }
+        // ---- layer 2 (fp16 pairs): 4 M blocks
+        f32x4 h2[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) h2[mb] = mma3(w2p + mb * 64, 4 * 64, xh, xl, bias4(32, mb));
+        // ---- layer 3 (fp16 pairs): 2 M blocks x 2 K steps
+        f32x4 o0 = bias4(96, 0), o1 = bias4(96, 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float x[8] = {sig2(h2[2 * ks][0]), sig2(h2[2 * ks][1]), sig2(h2[2 * ks][2]), sig2(h2[2 * ks][3]),
+                                sig2(h2[2 * ks + 1][0]), sig2(h2[2 * ks + 1][1]), sig2(h2[2 * ks + 1][2]), sig2(h2[2 * ks + 1][3])};
+            split2_f16(x, 1.0f, xh, xl);
+            o0 = mma3(w3p + (0 * 2 + ks) * 64, 256, xh, xl, o0);
+            o1 = mma3(w3p + (1 * 2 + ks) * 64, 256, xh, xl, o1);
+        }
+        // ---- epilogue: row fn, features 4 q + r and 16 + 4 q + r.  (The BatchNorm behind this kernel divides columns that vary
+        //      by ~1 % of their value: every ulp here is ~100 ulp there -- hence the careful sigmoid.  LeakyReLU of a sigmoid: identity.)
+        float4 r0, r1;
+        r0.x = gin_sigmoid_out(o0[0] * inv3); r0.y = gin_sigmoid_out(o0[1] * inv3); r0.z = gin_sigmoid_out(o0[2] * inv3); r0.w = gin_sigmoid_out(o0[3] * inv3);
+        r1.x = gin_sigmoid_out(o1[0] * inv3); r1.y = gin_sigmoid_out(o1[1] * inv3); r1.z = gin_sigmoid_out(o1[2] * inv3); r1.w = gin_sigmoid_out(o1[3] * inv3);
+        const int64_t row = tile * 16 + fn;
+        if (row < n) {
+            *reinterpret_cast<float4 *>(out + row * 32 + 4 * fq) = r0;
+            *reinterpret_cast<float4 *>(out + row * 32 + 16 + 4 * fq) = r1;
+            const float v[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                cs[e] += (double)v[e];
+                cq[e] += (double)v[e] * (double)v[e];
+            }
+        }
+    }
+    if (bn_partial) {
+        // lanes of one 16-lane row hold the same 8 features: fold the 16 batch rows (fixed butterfly), then the waves
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int d = 1; d <= 8; d <<= 1) {
+                cs[e] += __shfl_xor(cs[e], d, 64);
+                cq[e] += __shfl_xor(cq[e], d, 64);
+            }
+        if (fn == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int feat = (e < 4 ? 0 : 16) + 4 * fq + (e & 3);
+                red[wave * 64 + feat] = cs[e];
+                red[wave * 64 + 32 + feat] = cq[e];
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            double tot = 0.0;
+            for (int w = 0; w < kMlp16Waves; ++w) tot += red[w * 64 + tid];
+            // (written through when another block of THIS launch reads the row: see gin32_mlp_kernel)
+            if (fin.counter) st_partial_sc1(bn_partial, (int64_t)blockIdx.x * 64 + tid, tot);
+            else bn_partial[(int64_t)blockIdx.x * 64 + tid] = tot;
+        }
+#ifndef TGNN_ABL_G16NOFOLD
+        if (fin.counter) {
+            // the last block to get here writes the BatchNorm's record (tgnn_common.h: bn_fold_finish -- bn_finalize_kernel's tree)
+            __shared__ __attribute__((aligned(16))) unsigned char fold_scratch[bn_fold_scratch_bytes(32)];
+            GinFin f = fin;
+            f.job.partials = bn_partial;
+            f.job.n_partials = (int)gridDim.x;
+            bn_fold_finish<32>(f, bn_partial, reinterpret_cast<double *>(fold_scratch));
+        }
+#endif
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // The two kernels above as ONE (packed 128-byte rows): z never travels through HBM (25.6 MB written and read again per layer at
 // 100 000 nodes: a fifth of the forward's excess traffic) and the layer costs one launch instead of two.
 // A block = 16 waves in 4 TEAMS, one per SIMD: an MLP wave and three GATHER waves.  A gather wave sums the neighbourhoods of its
@@ -538,7 +768,8 @@ __global__ __launch_bounds__(256) void gin_generic_kernel(
 }  // namespace tgnn
 
 using namespace tgnn;
-namespace tgnn { std::atomic<int> g_debug_block_cap[2]; static std::atomic<int> g_gin_fused{1}; }
+namespace tgnn { std::atomic<int> g_debug_block_cap[2]; static std::atomic<int> g_gin_fused{1}; std::atomic<int> g_gin_mlp16{0}; }
+extern "C" int32_t tgnn_set_gin_mlp_f16(int32_t on) { return tgnn::g_gin_mlp16.exchange(on ? 1 : 0); }
 extern "C" int32_t tgnn_set_gin_fused(int32_t mode) { return tgnn::g_gin_fused.exchange(mode < 0 ? 0 : (mode > 2 ? 2 : mode)); }
 extern "C" void tgnn_debug_set_block_caps(int32_t nnconv_blocks, int32_t gin_mlp_blocks) {
     g_debug_block_cap[0].store(nnconv_blocks);
@@ -581,7 +812,7 @@ int gin32_fwd_folded(const float *a, int64_t lda, const float *in_stat, const in
     const int64_t rows_per_xcd = (n_nodes + 7) / 8;
     const unsigned agg_blocks = (unsigned)(8 * ((rows_per_xcd + 31) / 32));
     gin32_aggregate_kernel<<<agg_blocks, 256, 0, s>>>(a, lda, in_stat, rowptr, col_src, eps, n_nodes, z_scratch);
-    return launch_gin32_mlp(z_scratch, w1, b1, w2, b2, w3, b3, n_nodes, act, out, bn_partial, n_partials_host, s, &fin);
+    return launch_gin32_mlp(z_scratch, w1, b1, w2, b2, w3, b3, n_nodes, act, out, bn_partial, n_partials_host, s, &fin, !need_z);
 }
 }  // namespace tgnn
 
@@ -630,7 +861,22 @@ namespace tgnn {
 // halves on different streams
 int launch_gin32_mlp(const float *z, const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
                      const float *b3, int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
-                     hipStream_t s, const GinFin *fin) {
+                     hipStream_t s, const GinFin *fin, bool inference) {
+    if (inference && act == TGNN_ACT_LEAKY_RELU && g_gin_mlp16.load(std::memory_order_relaxed)) {
+        // the inference forward's kernel (gin32_mlp16_kernel): fp16 pairs in layers 2 / 3, 16 waves per block
+        int blocks = producer_blocks(n_nodes, 16 * kMlp16Waves);
+        constexpr int reserve = 32;
+        int cap = cus_minus(reserve);
+        if (const int dbg = g_debug_block_cap[1].load(); dbg > 0) cap = dbg < device_cus() ? dbg : device_cus();
+        if (blocks > cap) blocks = cap;
+        if (blocks >= 8) blocks &= ~7;
+        GinFin f{};
+        if (fin && bn_partial) f = *fin;
+        gin32_mlp16_kernel<<<blocks, kMlp16Threads, 0, s>>>(z, w1, b1, w2, b2, w3, b3, n_nodes, out, bn_partial, f);
+        if (n_partials_host) *n_partials_host = blocks;
+        TGNN_CHECK_LAUNCH();
+        return TGNN_OK;
+    }
     int blocks = producer_blocks(n_nodes, 16 * kMlpWaves);
     constexpr int reserve = 32;
     int cap = cus_minus(reserve);

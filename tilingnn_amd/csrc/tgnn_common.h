@@ -443,9 +443,10 @@ int dense_act_slots_bounded(const float *a, int32_t slot_width, int64_t slot_str
 // the MLP half of tgnn_gin_fwd (width 32) behind tgnn_gin_aggregate; gin.hip
 // experiment knob (tgnn_debug_set_block_caps): upper bounds of the whole-CU kernels' grids, 0 = the built-in policy
 extern std::atomic<int> g_debug_block_cap[2];   // [0] column NNConv, [1] GIN MLP
+// inference: the forward's fp16-pair kernel (gin32_mlp16_kernel) instead of the bf16 x 3 one the training forward keeps
 int launch_gin32_mlp(const float *z, const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
                      const float *b3, int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
-                     hipStream_t s, const GinFin *fin = nullptr);
+                     hipStream_t s, const GinFin *fin = nullptr, bool inference = false);
 // tgnn_gin_fwd (width 32 fast path only: returns TGNN_ERR_UNSUPPORTED otherwise) with the BatchNorm finalize folded into the MLP
 // kernel's last block
 int gin32_fwd_folded(const float *a, int64_t lda, const float *in_stat, const int32_t *rowptr, const int32_t *col_src, const float *eps,
