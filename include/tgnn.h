@@ -162,35 +162,6 @@ int tgnn_nnconv_mean_cols_f16_fwd(const float *h, int64_t ldh, int64_t n_src_row
                                   float *out, float *wimg_scratch, uint32_t *bounds_scratch, double *bn_partial,
                                   int32_t *n_partials_host, tgnn_stream_t stream);
 
-/* The column NNConv on PRE-SPLIT source rows streamed through LDS (csrc/nnconv_ps.hip; the kernel tgnn_forward runs on layouts
- * above the mid-size limit): same product as tgnn_nnconv_mean_cols_fwd (edge_conv.py:24-27 over PyG NNConv, aggr="mean"), but
- *   - the source rows arrive as fp16 pairs -- row = hi[32] | lo[32] halves (128 bytes) of s * h, s a power of two with
- *     s * max |h| < 2^15 (tgnn_rows_split16; inside tgnn_forward the kernels that produce h leave this copy themselves);
- *   - per 16-row tile the source rows of all its columns form a dense ENTRY stream (column after column, a column's filled
- *     slots in row order, the tile's own rows -- the root column -- last; padded to a multiple of 8 entries), fetched as whole
- *     128-byte rows by LDS-DMA; a column is a 16-bit occupancy mask and goes to the matrix pipe on its own.
- * Structure (from the type columns, once per layout):
- *   tile_ent_ptr int32 [ceil(N/16)+1]  first entry of every tile (multiples of 8)
- *   col_word     uint32 [n_cols]       occupancy mask (bits 0-15) | type << 16 | 1 << 24 on a tile's last (root) column
- *   ent_src      int32 [tgnn_nnconv_ps_max_entries(N, E)]  source rows
- * At most tgnn_nnconv_ps_max_types() edge types; N_src * 128 < 2^31. */
-int32_t tgnn_nnconv_ps_max_types(void);
-int64_t tgnn_nnconv_ps_max_entries(int64_t n_nodes, int64_t n_edges);
-size_t tgnn_nnconv_ps_workspace_bytes(int64_t n_nodes);
-int tgnn_nnconv_ps_build(const int32_t *rowptr, const int32_t *tile_col_ptr, const int32_t *col_meta, const int32_t *col_src,
-                         int64_t n_nodes, int32_t *tile_ent_ptr, uint32_t *col_word, int32_t *ent_src, void *ws, size_t ws_bytes,
-                         tgnn_stream_t stream);
-/* hs [n_rows][128 bytes] = the fp16 pairs of s * h (h packed rows of 32 floats), *scale_out = s; max_bits_scratch: one word. */
-int tgnn_rows_split16(const float *h, int64_t n_rows, uint32_t *max_bits_scratch, void *hs, float *scale_out,
-                      tgnn_stream_t stream);
-/* One op for tests: split of h (n_src_rows >= n_nodes packed rows) into hs_scratch (n_src_rows * 128 bytes, 128-byte aligned),
- * weight image (wimg_scratch: tgnn_nnconv_weight_image_floats(T) floats), bounds (bounds_scratch: 4 words), then the kernel. */
-int tgnn_nnconv_mean_ps_fwd(const float *h, int64_t n_src_rows, const int32_t *tile_col_ptr, const uint32_t *col_word,
-                            const int32_t *tile_ent_ptr, const int32_t *ent_src, const float *wtab, int32_t n_types,
-                            const float *root, const float *bias, int64_t n_nodes, int32_t act, float *out, float *wimg_scratch,
-                            void *hs_scratch, uint32_t *bounds_scratch, double *bn_partial, int32_t *n_partials_host,
-                            tgnn_stream_t stream);
-
 /* NNConv BATCHES of the mid-size persistent layer loop (csrc/forward_mid.hip; layouts of 4 097 .. tgnn_mid_layout_max_nodes()
  * nodes run TilinGNN.py:59-71 as ONE kernel).  Built from the type-column structure, once per layout:
  *   tile_nb int32  [ceil(N/16)]                                            batches of every 16-row tile (<= TGNN_MID_TILE_BATCHES)

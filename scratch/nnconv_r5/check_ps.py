@@ -5,6 +5,7 @@ sys.path.insert(0, '.')
 from tilingnn_amd import ops
 from tilingnn_amd.synth import make_super_graph
 
+KERN = os.environ.get("PS_KERN", "cols_ps")
 dev = torch.device('cuda:0')
 
 
@@ -33,7 +34,7 @@ def run(n, ea, T=13, time_it=True):
     bias = torch.randn(32, device=dev)
     part = ops.new_partials(32, dev)
     part2 = ops.new_partials(32, dev)
-    o_ps, np_ps = ops.nnconv_mean(h, g, wtab, root, bias, ops.ACT_LEAKY_RELU, part, kernel="ps")
+    o_ps, np_ps = ops.nnconv_mean(h, g, wtab, root, bias, ops.ACT_LEAKY_RELU, part, kernel=KERN)
     o_c, np_c = ops.nnconv_mean(h, g, wtab, root, bias, ops.ACT_LEAKY_RELU, part2, kernel="cols_f16")
     torch.cuda.synchronize()
     want = ref64(h, adj, g.edge_type, wtab, root, bias, n)
@@ -45,11 +46,11 @@ def run(n, ea, T=13, time_it=True):
     e_bn = float(((s_ps.reshape(-1) - s_ref).abs() / s_ref.abs().clamp(min=1)).max())
     print(f"n={n} ea={ea} T={g.n_types}: max-norm rel err vs fp64: ps {e_ps:.2e}  cols_f16 {e_c:.2e}   bn sums rel {e_bn:.2e}  finite {bool(torch.isfinite(o_ps).all())}")
     # repeatability
-    o2, _ = ops.nnconv_mean(h, g, wtab, root, bias, ops.ACT_LEAKY_RELU, part, kernel="ps")
+    o2, _ = ops.nnconv_mean(h, g, wtab, root, bias, ops.ACT_LEAKY_RELU, part, kernel=KERN)
     print("  bit-repeatable:", bool(torch.equal(o_ps, o2)))
     if not time_it:
         return
-    for kern in ("ps", "cols_f16"):
+    for kern in ("cols_ps", "ps", "cols_f16"):
         for _ in range(5):
             ops.nnconv_mean(h, g, wtab, root, bias, ops.ACT_LEAKY_RELU, part, kernel=kern)
         torch.cuda.synchronize()

@@ -472,11 +472,7 @@ __global__ __launch_bounds__(kMlp16Threads) void gin32_mlp16_kernel(
     };
     double cs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cq[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // BN sums of this lane's 8 output features
 
-#ifdef TGNN_ABL_G16NOTILE
-    for (int64_t tile = t0; tile < t0; ++tile) {
-#else
     for (int64_t tile = t0; tile < t1; ++tile) {
-#endif
         asm volatile("" ::: "memory");                       // (the fragments are re-read from the image every tile: no 88 registers of them)
         bf16x8 xb[3];
         {
@@ -549,7 +545,6 @@ __global__ __launch_bounds__(kMlp16Threads) void gin32_mlp16_kernel(
             if (fin.counter) st_partial_sc1(bn_partial, (int64_t)blockIdx.x * 64 + tid, tot);
             else bn_partial[(int64_t)blockIdx.x * 64 + tid] = tot;
         }
-#ifndef TGNN_ABL_G16NOFOLD
         if (fin.counter) {
             // the last block to get here writes the BatchNorm's record (tgnn_common.h: bn_fold_finish -- bn_finalize_kernel's tree)
             __shared__ __attribute__((aligned(16))) unsigned char fold_scratch[bn_fold_scratch_bytes(32)];
@@ -558,7 +553,6 @@ __global__ __launch_bounds__(kMlp16Threads) void gin32_mlp16_kernel(
             f.job.n_partials = (int)gridDim.x;
             bn_fold_finish<32>(f, bn_partial, reinterpret_cast<double *>(fold_scratch));
         }
-#endif
     }
 }
 

@@ -522,3 +522,4 @@ extern "C" int tgnn_debug_block_times(unsigned long long *host512) {
     return (int)hipMemcpyFromSymbol(host512, HIP_SYMBOL(tgnn::g_blk_times), sizeof(unsigned long long) * 512);
 }
 #endif
+

@@ -408,16 +408,6 @@ int launch_nnconv_cols(const float *h, int64_t ldh, const int32_t *tile_col_ptr,
                        int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
                        hipStream_t s, const unsigned *h_max = nullptr, const unsigned *root_max = nullptr,
                        int max_in_degree = 0, unsigned long long *stamp = nullptr);
-// the same product on pre-split rows streamed through LDS (nnconv_ps.hip): hs = fp16-pair rows of *h_scale * h
-int launch_nnconv_ps(const void *hs, const int32_t *tile_col_ptr, const uint32_t *col_word, const int32_t *tile_ent_ptr,
-                     const int32_t *ent_src, const float *wimg, int32_t n_types, const float *bias, int64_t n_nodes, int32_t act,
-                     float *out, double *bn_partial, int32_t *n_partials_host, const float *h_scale, const unsigned *root_max,
-                     hipStream_t s, unsigned long long *stamp = nullptr);
-int launch_nnconv_ps_build(const int32_t *rowptr, const int32_t *tile_col_ptr, const int32_t *col_meta, const int32_t *col_src,
-                           int64_t n_nodes, int32_t *tile_ent_ptr, uint32_t *col_word, int32_t *ent_src, int *scan_ws,
-                           hipStream_t s);
-void launch_rows_split16(const float *h, int64_t n_rows, const unsigned *h_max, void *hs, float *scale_out, hipStream_t s);
-int32_t nnconv_ps_max_types();
 // largest |h[0 .. n_floats)| (n_floats % 4 == 0) as float bits, atomicMax into *max_bits; bn_merge.hip
 void launch_absmax(const float *h, int64_t n_floats, unsigned *max_bits, hipStream_t s);
 // max |W_k| and a bound of |BN(v)| from the BatchNorm's parameters alone (nnconv.hip: dense_bounds_kernel), atomicMax into

@@ -99,38 +99,6 @@ class NNConvColumns:
 
 
 @dataclass
-class NNConvStream:
-    """Per 16-row tile the dense entry stream of its type columns for the LDS-streaming NNConv kernel (tgnn_nnconv_ps_build,
-    include/tgnn.h; csrc/nnconv_ps.hip)."""
-    tile_ent_ptr: Tensor      # int32 [ceil(N/16) + 1]
-    col_word: Tensor          # int32 (uint32 bits) [cap]
-    ent_src: Tensor           # int32 [tgnn_nnconv_ps_max_entries]
-
-
-def build_nnconv_stream(graph: "PreparedGraph") -> Optional["NNConvStream"]:
-    """The entry stream from the column structure (asynchronous); None when the layout carries no columns or too many types."""
-    hit = graph.__dict__.get("_ps_stream")
-    if hit is not None:
-        return hit
-    cols = graph.cols
-    if cols is None or graph.n_types > lib.tgnn_nnconv_ps_max_types():
-        return None
-    dev = cols.tile_col_ptr.device
-    n = graph.n_nodes
-    ntiles = (n + 15) // 16
-    st = NNConvStream(torch.empty(ntiles + 1, dtype=torch.int32, device=dev),
-                      torch.empty(int(cols.col_meta.shape[0]), dtype=torch.int32, device=dev),
-                      torch.empty(int(lib.tgnn_nnconv_ps_max_entries(n, graph.n_adj_edges)), dtype=torch.int32, device=dev))
-    ws_bytes = lib.tgnn_nnconv_ps_workspace_bytes(n)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    check(lib.tgnn_nnconv_ps_build(ptr(graph.adj_rowptr), ptr(cols.tile_col_ptr), ptr(cols.col_meta), ptr(cols.col_src), n,
-                                   ptr(st.tile_ent_ptr), ptr(st.col_word), ptr(st.ent_src), ptr(ws), ws_bytes,
-                                   _stream(cols.tile_col_ptr)))
-    graph.__dict__["_ps_stream"] = st
-    return st
-
-
-@dataclass
 class NNConvBatches:
     """Per 16-row tile its in-edges packed by edge type for the mid-size persistent layer loop (tgnn_mid_entries_build,
     include/tgnn.h; csrc/forward_mid.hip)."""
@@ -407,17 +375,6 @@ def nnconv_mean(h: Tensor, graph: PreparedGraph, wtab: Tensor, root: Tensor, bia
                                                 ptr(wt), graph.n_types, ptr(_f32c(root, "root")), ptr(_f32c(bias, "bias")), n,
                                                 max_in_degree if max_in_degree else graph.max_in_degree, act, ptr(out), ptr(wimg),
                                                 ptr(bounds), ptr(partials), C.byref(npart), _stream(h)))
-    elif kernel == "ps":
-        st = build_nnconv_stream(graph)
-        if st is None or c != 32:
-            raise ValueError("the LDS-streaming column kernel needs the column structure and width 32")
-        wimg = torch.empty(lib.tgnn_nnconv_weight_image_floats(graph.n_types), dtype=torch.float32, device=h.device)
-        bounds = torch.empty(4, dtype=torch.int32, device=h.device)
-        hs = torch.empty(int(h.shape[0]) * 32, dtype=torch.float32, device=h.device)
-        check(lib.tgnn_nnconv_mean_ps_fwd(ptr(h), int(h.shape[0]), ptr(tl.tile_col_ptr), ptr(st.col_word), ptr(st.tile_ent_ptr),
-                                          ptr(st.ent_src), ptr(wt), graph.n_types, ptr(_f32c(root, "root")), ptr(_f32c(bias, "bias")),
-                                          n, act, ptr(out), ptr(wimg), ptr(hs), ptr(bounds), ptr(partials), C.byref(npart),
-                                          _stream(h)))
     elif tl is not None and c == 32 and not force_csr_kernel and int(h.shape[0]) * c * 4 < 2 ** 31:
         wimg = torch.empty(lib.tgnn_nnconv_weight_image_floats(graph.n_types), dtype=torch.float32, device=h.device)
         check(lib.tgnn_nnconv_mean_cols_fwd(ptr(h), c, ptr(tl.tile_col_ptr), ptr(tl.col_meta), ptr(tl.col_src), ptr(wt),
