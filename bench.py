@@ -233,6 +233,21 @@ def stamped_nnconv_us(net, x, adj, adj_attr, col, steps):
     return (tot / cnt, cnt) if cnt else None
 
 
+def gather_ceiling(dev, n_rows=100_000):
+    """The measured ceiling the two gather kernels run against (csrc/ubench.hip; profiles/r05_gather_ceiling.txt,
+    r05_nnconv_study.txt): GB/s of 128-byte row gathers from a cache-resident table, per access shape, on THIS device."""
+    from tilingnn_amd._lib import check, lib, ptr
+    table = torch.zeros(n_rows * 32, dtype=torch.float32, device=dev)
+    sink = torch.empty(256 * 1024, dtype=torch.float32, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    out = {}
+    for name, shape in (("nnconv_lane_map_16rows_x_64B", 0), ("whole_rows_8lanes_x_16B", 1)):
+        rate = C.c_double(0.0)
+        check(lib.tgnn_ubench_row_gather(shape, ptr(table), n_rows, ptr(sink), 400, 3, C.byref(rate), stream))
+        out[name] = rate.value * 128.0 / 1e9
+    return out
+
+
 def kernel_roofline(class_ms, n, ea, ec, n_types):
     """`roofline` of the NNConv column kernel (the path's scatter-add) + the GIN pair and merge, all against the HBM
     bound with SURVEY 8d's algorithmic bytes; `achieved` = bytes / the average launch duration of the events above."""
@@ -257,6 +272,55 @@ def kernel_roofline(class_ms, n, ea, ec, n_types):
     return out
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher around it: N ranks of this script through torch.distributed.run (one per
+    GPU, rendezvous on 127.0.0.1, a free port), their stdout -- rank 0's ONE JSON line -- passed through.  Fails loudly, and
+    before anything is started, when fewer than N GPUs are visible; a run that outlives --launch-timeout is killed as a whole."""
+    import signal
+    import socket
+    import subprocess
+    n = int(args.gpus)
+    if not args.launcher_selftest:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            print(f"bench.py: --gpus {n} needs {n} visible GPUs, this node shows {have}", file=sys.stderr)
+            return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    argv = [a for a in sys.argv[1:] if a != "--spawn"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return proc.wait(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        print(f"bench.py: the {n}-rank run did not finish within {args.launch_timeout:.0f} s: killed", file=sys.stderr)
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        proc.wait()
+        return 3
+
+
+def launcher_selftest(rank: int, world: int) -> None:
+    """The launcher's own path without a GPU: gloo rendezvous, one all-reduce on the CPU, rank 0 reports how many ranks it saw."""
+    import datetime
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29547")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    ones = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(ones)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "ranks_seen": int(ones.item()), "n_gpus": world}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -273,15 +337,28 @@ def main():
     ap.add_argument("--config", choices=["headline", "4", "5"], default="headline",
                     help="headline: 100k nodes / 1M + 1.25M edges; 4 / 5: SURVEY 8d's fixed totals (500k / 6M + 7.5M, tile_count 2, seed 3; "
                          "2M / 20M + 25M, tile_count 1, seed 4) -- meant for --scaling strong over 4 / 8 GPUs")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the N ranks through torch.distributed.run from here even for N = 1 (N > 1 without WORLD_SIZE in the "
+                         "environment does so by itself)")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="the launcher alone: every rank joins a gloo group on the CPU, all-reduces a one, rank 0 prints "
+                         '{"launcher_selftest": true, "ranks_seen": N}; needs no GPU')
+    ap.add_argument("--launch-timeout", type=float, default=1800.0, help="seconds after which a self-launched run is killed")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run with N ranks")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks for --gpus N "
+                         "(or leave WORLD_SIZE unset: bench.py then starts them itself)")
+    if args.launcher_selftest:
+        return launcher_selftest(rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -339,6 +416,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    ranks_seen = 1
+    if sharded:
+        import torch.distributed as dist
+        ones = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(ones)                                # (every rank that actually joined adds its one)
+        ranks_seen = int(ones.item())
+
     for _ in range(args.warmup):
         step()
     barrier()
@@ -392,6 +476,29 @@ def main():
         stamped = stamped_nnconv_us(net, x, adj, adj_attr, col, args.steps)
         infwd = in_forward_classes(net, x, adj, adj_attr, col, args.steps)
         roofline["single_stream"] = {k: roofline[k] for k in ("avg_launch_us", "achieved", "frac", "timing")}
+        # the bound this formulation REALLY has: neither kernel moves HBM bytes at its limit -- both gather
+        # 128-byte rows out of L2 through the CU's vector-memory path, whose ceiling is measured here, per access shape
+        try:
+            ceil = gather_ceiling(dev)
+            t_ss = roofline["single_stream"]["avg_launch_us"] * 1e-6
+            nn_rows_bytes = (ea_total + n_total) * 128           # every in-edge's source row + the tile's own rows (root term)
+            roofline["gather_bound"] = {
+                "what": "rows gathered per launch x 128 B / the chip-wide row-gather rate of the kernel's own access shape, measured on "
+                        "this device by tgnn_ubench_row_gather (cache-resident 12.8 MB table, band-local rows, 16 waves per CU)",
+                "bytes": nn_rows_bytes, "peak_GBs": ceil["nnconv_lane_map_16rows_x_64B"],
+                "floor_us": nn_rows_bytes / (ceil["nnconv_lane_map_16rows_x_64B"] * 1e9) * 1e6,
+                "frac_single_stream": nn_rows_bytes / t_ss / 1e9 / ceil["nnconv_lane_map_16rows_x_64B"],
+                "whole_row_peak_GBs": ceil["whole_rows_8lanes_x_16B"],
+                "note": "the floor assumes every gather instruction full; at the benchmark's column fill (29 % outside the root column) the "
+                        "instruction floor of the 70 gathers of a tile puts the path at ~27 us per launch (profiles/r05_nnconv_study.txt): "
+                        "the kernel runs at ~0.8 of THAT"}
+            gk = roofline["gin_kernel"]
+            gin_rows_bytes = (ec_total + n_total) * 128
+            gk["gather_bound"] = {"bytes": gin_rows_bytes, "peak_GBs": ceil["whole_rows_8lanes_x_16B"],
+                                  "floor_us": gin_rows_bytes / (ceil["whole_rows_8lanes_x_16B"] * 1e9) * 1e6,
+                                  "what": "gin32_aggregate_kernel's neighbourhood rows (whole-row gathers) against the same measured ceiling"}
+        except Exception as exc:                                  # (an older library without the helper)
+            roofline["gather_bound"] = {"error": str(exc)}
         if stamped:
             t_in = stamped[0] * 1e-6
             roofline.update({"avg_launch_us": stamped[0], "achieved": roofline["algorithmic_bytes_per_launch"] / t_in / 1e9,
@@ -399,6 +506,9 @@ def main():
                              "timing": f"device wall clock stamped by the kernel's first and last block INSIDE the production "
                                        f"two-stream forward of this run (tgnn_forward_stamped, {stamped[1]} launches): the "
                                        f"duration a kernel trace reports, no event or profiler in the schedule"})
+        if stamped and "peak_GBs" in roofline.get("gather_bound", {}):
+            gb = roofline["gather_bound"]
+            gb["frac"] = gb["bytes"] / (stamped[0] * 1e-6) / 1e9 / gb["peak_GBs"]   # in the production forward, like roofline.frac
         if infwd and infwd["nnconv"]["launches_per_forward"]:
             t_ev = infwd["nnconv"]["ms_per_forward"] / infwd["nnconv"]["launches_per_forward"] * 1e-3
             roofline["in_forward_events"] = {"avg_launch_us": t_ev * 1e6, "frac": roofline["algorithmic_bytes_per_launch"] / t_ev / 1e9 / HBM_PEAK_GBS,
@@ -755,7 +865,7 @@ def main():
             line["config3_width64_bf16"] = config3
         if sharded:
             import torch.distributed as dist
-            line["collectives"] = {"backend": dist.get_backend(), "ranks_seen": dist.get_world_size(),
+            line["collectives"] = {"backend": dist.get_backend(), "ranks_seen": ranks_seen,
                                    "per_forward": shard_runner.collectives_per_forward}
         if not args.no_cpu_baseline and world == 1:           # the CPU leg is a 1-GPU (rank 0, N = 1) measurement
             line["cpu_baseline"] = cpu_baseline()

@@ -45,6 +45,7 @@ extern "C" {
 #define TGNN_ERR_LAUNCH (-3)      /* HIP launch / runtime failure */
 #define TGNN_ERR_UNSUPPORTED (-4) /* shape outside what the kernels are built for */
 #define TGNN_ERR_BAD_GRAPH (-5)   /* edge index out of [0, N) */
+#define TGNN_ERR_STALE_RESULT (-6) /* an EARLIER forward's persistent kernel gave up and nobody collected it: see tgnn_spin_error_poll */
 
 /* activation codes (torch.nn.LeakyReLU() slope 0.01 / torch.nn.Sigmoid()) */
 #define TGNN_ACT_NONE 0
@@ -161,6 +162,13 @@ int tgnn_nnconv_mean_cols_f16_fwd(const float *h, int64_t ldh, int64_t n_src_row
                                   const float *root, const float *bias, int64_t n_nodes, int32_t max_in_degree, int32_t act,
                                   float *out, float *wimg_scratch, uint32_t *bounds_scratch, double *bn_partial,
                                   int32_t *n_partials_host, tgnn_stream_t stream);
+
+/* Measurement helper of bench.py (roofline.gather_bound; csrc/ubench.hip): rows of 128 bytes gathered per second by one launch
+ * over every CU from an L2 / Infinity-Cache resident table of n_rows x 128 bytes (>= 8192 rows), band-local random rows, best of
+ * `reps` launches of `iters` x 8 gather steps per wave.  shape 0 = the column NNConv's lane map (16 rows x 64 bytes per
+ * instruction), 1 = whole rows (8 lanes x 16 bytes: the GIN aggregate's).  sink: 256 x 1024 floats.  Synchronises the stream. */
+int tgnn_ubench_row_gather(int32_t shape, const float *table, int64_t n_rows, float *sink, int32_t iters, int32_t reps,
+                           double *rows_per_s_out, tgnn_stream_t stream);
 
 /* NNConv BATCHES of the mid-size persistent layer loop (csrc/forward_mid.hip; layouts of 4 097 .. tgnn_mid_layout_max_nodes()
  * nodes run TilinGNN.py:59-71 as ONE kernel).  Built from the type-column structure, once per layout:
@@ -423,12 +431,15 @@ void tgnn_set_small_layout_limit(int64_t n_nodes);
  * tgnn_spin_error_poll synchronises `stream`, reads the word of the stream's device into *code_out (0 = every forward since the
  * last poll was sound; bits: 1 grid barrier, 2 partial rows, 4 edge weights) and clears it; with a non-zero code
  * tgnn_last_error() carries the explanation.  What gives up is a kernel whose blocks are not all resident -- another process
- * or tenant holds compute units: switch the persistent schedules off (limits 0) and run the forward again. */
+ * or tenant holds compute units: run the forward again (the poll has switched the persistent schedules off for a while:
+ * tgnn_persist_fallback). */
 int tgnn_spin_error_poll(tgnn_stream_t stream, uint32_t *code_out);
 uint64_t tgnn_set_spin_budget_us(uint64_t us);
-/* test hook: the next n_launches persistent kernels run with their last block absent (it returns at once) -- what a block that
- * never becomes resident looks like to the others; they must give up after the budget and report through the word above. */
-void tgnn_debug_spin_fault(int32_t n_launches);
+/* The persistent schedules (small and mid-size layer loops) are off for the next n_forwards forwards of this process, then come
+ * back by themselves (0: back now).  tgnn_spin_error_poll opens such a window (256 forwards) when it finds a failure, and so does
+ * any forward entry point that finds one nobody collected -- it then returns TGNN_ERR_STALE_RESULT (the word cleared, the message
+ * set): the results of the EARLIER forward that failed, and of persistent forwards queued behind it, are invalid. */
+void tgnn_persist_fallback(int64_t n_forwards);
 int64_t tgnn_get_small_layout_limit(void);
 
 /* Split precision of the general schedule's matrix-core kernels (NNConv, the final MLP's first Linear).  Both hold the fp32
@@ -482,6 +493,9 @@ int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edges, const fl
                     int32_t *col_src, int32_t *col_eid, int32_t *tile_col_ptr, int32_t *col_meta, int32_t *col_slot_src,
                     int32_t *mid_tile_nb, uint32_t *mid_ent,
                     void *ws, size_t ws_bytes, int32_t *result, tgnn_stream_t stream);
+#ifdef TGNN_DEBUG
+/* ---- test / experiment hooks: only in libtgnn_debug.so (make -C tilingnn_amd/csrc debug: the same sources with -DTGNN_DEBUG); the
+ *      production library does not export them ---- */
 /* (tests) tgnn_graph_prep builds both CSRs through buckets of 512 destination rows sorted in LDS; a bucket with more than `cap`
  * edges (default and maximum 15 360) takes a slow in-place path.  Sets the threshold (negative: only queries); returns the
  * previous one. */
@@ -489,6 +503,10 @@ int32_t tgnn_debug_set_csr_bucket_cap(int32_t cap);
 /* (experiments: scratch/block_caps.py, scratch/mid_trace.sh) upper bounds on the grids of the two kernels whose blocks need a CU to
  * themselves -- the column NNConv and the GIN MLP (at most the device's CU count); 0 = the built-in policy (device CUs minus 32 each). */
 void tgnn_debug_set_block_caps(int32_t nnconv_blocks, int32_t gin_mlp_blocks);
+/* the next n_launches persistent kernels run with their last block absent (it returns at once) -- what a block that never
+ * becomes resident looks like to the others; they must give up after the budget and report through the spin-error word. */
+void tgnn_debug_spin_fault(int32_t n_launches);
+#endif
 
 /* The same forward with a hipEvent pair around every launch (on `stream`, where the kernels run);
  * synchronises, then ADDS the elapsed milliseconds and launch counts per kernel class into the

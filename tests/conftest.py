@@ -45,3 +45,23 @@ def bf16x3_split():
         yield
     finally:
         _lib.lib.tgnn_set_split_precision(before)
+
+
+@pytest.fixture
+def debug_hooks(request):
+    """Tests that need the tgnn_debug_* hooks: the production library does not export them.  Inside the debug build
+    (TGNN_LIB_PATH = tilingnn_amd/libtgnn_debug.so) the fixture is False and the test runs; inside the production library the SAME
+    test is run in a subprocess against the debug build, its verdict is asserted, and the fixture is True (the test returns)."""
+    import os
+    import subprocess
+    import sys
+    from tilingnn_amd import _lib
+    if _lib.has_debug_hooks():
+        return False
+    assert os.path.exists(_lib.DEBUG_LIB_PATH), f"{_lib.DEBUG_LIB_PATH} is missing: make -C tilingnn_amd/csrc debug"
+    env = dict(os.environ, TGNN_LIB_PATH=_lib.DEBUG_LIB_PATH)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", request.node.nodeid, "-x", "-q", "-p", "no:cacheprovider"], cwd=repo, env=env,
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, "under libtgnn_debug.so:\n" + r.stdout[-3000:] + r.stderr[-1000:]
+    return True

@@ -15,6 +15,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_functions():
     text = open(os.path.join(REPO, "include", "tgnn.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"#ifdef TGNN_DEBUG.*?#endif", "", text, flags=re.S)       # the test hooks of libtgnn_debug.so
     return sorted(set(re.findall(r"\b(tgnn_[a-z0-9_]+)\s*\(", text)))
 
 
@@ -26,6 +27,9 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_lib.lib, name), f"{name} is declared in include/tgnn.h but not exported by libtgnn.so"
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared, "ctypes binding table and header disagree"
     assert _lib.lib.tgnn_version() == 100
+    # the production library carries no test hook (they live in libtgnn_debug.so: make -C tilingnn_amd/csrc debug)
+    if not os.environ.get("TGNN_LIB_PATH"):
+        assert not any(hasattr(_lib.lib, n) for n in ("tgnn_debug_spin_fault", "tgnn_debug_set_csr_bucket_cap", "tgnn_debug_set_block_caps"))
 
 
 def test_param_table_names_are_the_reference_state_dict_keys():

@@ -220,22 +220,26 @@ def test_mid_kernel_running_statistics_match_the_general_schedule(dev):
 
 
 @pytest.mark.parametrize("n", [2000, 8000])
-def test_a_starved_persistent_kernel_gives_up_and_the_module_falls_back(dev, n):
+def test_a_starved_persistent_kernel_gives_up_and_the_module_falls_back(dev, n, debug_hooks):
     """Bounded spins (csrc/forward_persist.h).  A persistent kernel one of whose blocks never shows up -- what a kernel looks like
-    to its other blocks when another process holds compute units; simulated by the library's test hook -- must TERMINATE after
-    the spin budget, the device's error word must say why, and TilinGNN.forward_checked (the call ML_Solver.predict makes) must
-    come back with the general schedule's result.  Both persistent kernels: 2 000 nodes (forward_small.hip), 8 000 (forward_mid.hip)."""
+    to its other blocks when another process holds compute units; simulated by the debug library's test hook -- must TERMINATE
+    after the spin budget, the device's error word must say why, and
+      * TilinGNN.forward_checked (the call ML_Solver.predict makes) must come back with the general schedule's result, the
+        persistent schedules off for a WINDOW of forwards (tgnn_persist_fallback) and back afterwards [r5];
+      * a failure nobody polled for must be loud at the NEXT forward of any kind (TGNN_ERR_STALE_RESULT) instead of poisoning
+        every later persistent kernel silently [r5: ADVICE r4].
+    Both persistent kernels: 2 000 nodes (forward_small.hip), 8 000 (forward_mid.hip)."""
+    if debug_hooks:
+        return                                                  # (ran against libtgnn_debug.so in a subprocess)
     import time
     import warnings
     from tilingnn_amd import _lib
     inputs, _ = _layout(n, dev, seed=9)
     net, _ = make_net(dev, depth=6)
-    limits = _lib.lib.tgnn_get_small_layout_limit(), _lib.lib.tgnn_get_mid_layout_limit()
-    _lib.lib.tgnn_set_small_layout_limit(0)
-    _lib.lib.tgnn_set_mid_layout_limit(0)
+    path = 1 if n <= 4096 else 2                               # index into tgnn_forward_path_counts: small / mid
+    _lib.lib.tgnn_persist_fallback(1 << 40)                    # the general schedule's result
     want = net(*inputs)[0].clone()
-    _lib.lib.tgnn_set_small_layout_limit(limits[0])
-    _lib.lib.tgnn_set_mid_layout_limit(limits[1])
+    _lib.lib.tgnn_persist_fallback(0)
     torch.cuda.synchronize()
     before = _lib.lib.tgnn_set_spin_budget_us(20000)
     try:
@@ -249,17 +253,41 @@ def test_a_starved_persistent_kernel_gives_up_and_the_module_falls_back(dev, n):
         assert code != 0
         assert b"gave up" in _lib.lib.tgnn_last_error()
         assert _spin_ok(dev) == 0                               # (the poll cleared the word)
+        # ... and opened the fallback window: the next forwards take the general schedule, then the persistent one is back
+        c0 = _lib.forward_path_counts()
+        net(*inputs)
+        c1 = _lib.forward_path_counts()
+        assert c1[0] - c0[0] == 1 and c1[path] == c0[path]
+        _lib.lib.tgnn_persist_fallback(0)
+        net(*inputs)
+        c2 = _lib.forward_path_counts()
+        assert c2[path] - c1[path] == 1
+        assert _spin_ok(dev) == 0
+        _lib.lib.tgnn_persist_fallback(0)
+        # forward_checked: warning, the general schedule's result, window open
         _lib.lib.tgnn_debug_spin_fault(1)
         with warnings.catch_warnings(record=True) as caught:
             warnings.simplefilter("always")
             got = net.forward_checked(*inputs)[0]
         assert any("gave up" in str(w.message) for w in caught)
-        assert _lib.lib.tgnn_get_small_layout_limit() == 0 and _lib.lib.tgnn_get_mid_layout_limit() == 0
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+        c3 = _lib.forward_path_counts()
+        net(*inputs)
+        assert _lib.forward_path_counts()[path] == c3[path]     # still inside the window
+        _lib.lib.tgnn_persist_fallback(0)
+        # a failure NOBODY polls for: plain forward(); the next forward of any kind raises, the one after it is sound again
+        _lib.lib.tgnn_debug_spin_fault(1)
+        net(*inputs)
+        torch.cuda.synchronize()
+        with pytest.raises(_lib.TgnnError, match="EARLIER call gave up"):
+            net(*inputs)
+        again = net(*inputs)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(again, want) and _spin_ok(dev) == 0   # (inside the window the stale failure opened: the general schedule)
     finally:
         _lib.lib.tgnn_debug_spin_fault(0)
         _lib.lib.tgnn_set_spin_budget_us(before)
-        _lib.lib.tgnn_set_small_layout_limit(limits[0])
-        _lib.lib.tgnn_set_mid_layout_limit(limits[1])
-    assert torch.equal(got, want)
+        _lib.lib.tgnn_persist_fallback(0)
     assert _spin_ok(dev) == 0
     assert torch.equal(net.forward_checked(*inputs)[0].cpu(), net(*inputs)[0].cpu())   # healthy: the persistent schedule's own result

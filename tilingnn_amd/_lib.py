@@ -95,6 +95,7 @@ def _load() -> C.CDLL:
         "tgnn_nnconv_weight_image_floats": (sz, [i32]),
         "tgnn_nnconv_mean_cols_fwd": (C.c_int, [p, i64, p, p, p, p, i32, p, p, i64, i32, i32, p, p, p, pi32, p]),
         "tgnn_nnconv_mean_cols_f16_fwd": (C.c_int, [p, i64, i64, p, p, p, p, i32, p, p, i64, i32, i32, p, p, p, p, pi32, p]),
+        "tgnn_ubench_row_gather": (C.c_int, [i32, p, i64, p, i32, i32, C.POINTER(C.c_double), p]),
         "tgnn_mid_entries_words": (i64, [i64]),
         "tgnn_mid_entries_build": (C.c_int, [p, p, p, i64, p, p, p, p, p]),
         "tgnn_forward_path_counts": (None, [p]),
@@ -103,7 +104,7 @@ def _load() -> C.CDLL:
         "tgnn_mid_layout_max_nodes": (i64, []),
         "tgnn_spin_error_poll": (C.c_int, [p, C.POINTER(C.c_uint32)]),
         "tgnn_set_spin_budget_us": (C.c_uint64, [C.c_uint64]),
-        "tgnn_debug_spin_fault": (None, [i32]),
+        "tgnn_persist_fallback": (None, [i64]),
         "tgnn_gin_fwd": (C.c_int, [p, i64, p, p, p, p, p, p, p, p, p, p, i64, i32, i32, p, p, p, pi32, p]),
         "tgnn_dense_act_fwd": (C.c_int, [p, i64, i64, p, p, p, i64, i32, i32, i32, p, i64, p, pi32, p]),
         "tgnn_dense_act_slots_fwd": (C.c_int, [p, i32, i64, p, p, p, i64, i32, i32, i32, p, i64, p, pi32, p]),
@@ -144,8 +145,6 @@ def _load() -> C.CDLL:
         "tgnn_rccl_comm_create": (C.c_int, [p, i32, i32, C.POINTER(C.c_void_p)]),
         "tgnn_rccl_comm_destroy": (C.c_int, [p]),
         "tgnn_rccl_counters": (None, [p]),
-        "tgnn_debug_set_csr_bucket_cap": (i32, [i32]),
-        "tgnn_debug_set_block_caps": (None, [i32, i32]),
         "tgnn_forward_profiled": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), p, p, C.POINTER(Graph), i32,
                                             i32, p, p, sz, p, C.POINTER(C.c_float), pi32]),
         "tgnn_forward_many": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), i32, p, p, p, i32, i32, p, p, p, p, i32, p]),
@@ -193,7 +192,23 @@ def _load() -> C.CDLL:
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)      # AttributeError here = header / library mismatch
         fn.restype, fn.argtypes = res, args
+    # test / experiment hooks: exported by libtgnn_debug.so only (make -C tilingnn_amd/csrc debug; TGNN_LIB_PATH selects it)
+    for name, (res, args) in {"tgnn_debug_spin_fault": (None, [i32]), "tgnn_debug_set_csr_bucket_cap": (i32, [i32]),
+                              "tgnn_debug_set_block_caps": (None, [i32, i32])}.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            continue
+        fn.restype, fn.argtypes = res, args
     return lib
+
+
+DEBUG_LIB_PATH = os.path.join(_HERE, "libtgnn_debug.so")
+
+
+def has_debug_hooks() -> bool:
+    """True inside the debug build of the library (the tgnn_debug_* test hooks exist)."""
+    return hasattr(lib, "tgnn_debug_spin_fault")
 
 
 lib = _load()
@@ -202,11 +217,11 @@ EXPORTED_SYMBOLS = (
     "tgnn_edge_dedup_workspace_bytes", "tgnn_edge_type_dedup", "tgnn_gather_i32", "tgnn_edge_weight_table",
     "tgnn_nnconv_mean_fwd", "tgnn_nnconv_cols_max_columns", "tgnn_nnconv_cols_workspace_bytes",
     "tgnn_nnconv_cols_build", "tgnn_nnconv_cols_max_types", "tgnn_nnconv_weight_image_floats", "tgnn_nnconv_mean_cols_fwd", "tgnn_nnconv_mean_cols_f16_fwd",
-    "tgnn_mid_entries_words", "tgnn_mid_entries_build", "tgnn_forward_path_counts", "tgnn_set_mid_layout_limit", "tgnn_get_mid_layout_limit", "tgnn_mid_layout_max_nodes",
-    "tgnn_spin_error_poll", "tgnn_set_spin_budget_us", "tgnn_debug_spin_fault", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_dense_act_slots_fwd", "tgnn_dense_act_slots_f16_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
+    "tgnn_ubench_row_gather", "tgnn_mid_entries_words", "tgnn_mid_entries_build", "tgnn_forward_path_counts", "tgnn_set_mid_layout_limit", "tgnn_get_mid_layout_limit", "tgnn_mid_layout_max_nodes",
+    "tgnn_spin_error_poll", "tgnn_set_spin_budget_us", "tgnn_persist_fallback", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_dense_act_slots_fwd", "tgnn_dense_act_slots_f16_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
     "tgnn_merge_fwd", "tgnn_param_count", "tgnn_param_name", "tgnn_forward_workspace_bytes", "tgnn_forward",
     "tgnn_forward_profiled", "tgnn_forward_profiled_two_stream", "tgnn_forward_stamped", "tgnn_forward_many", "tgnn_graph_prep_small_max_nodes", "tgnn_graph_prep_small_max_edges", "tgnn_graph_prep_small_tmp_ints",
-    "tgnn_graph_prep_small", "tgnn_graph_prep_workspace_bytes", "tgnn_graph_prep", "tgnn_set_small_layout_limit", "tgnn_get_small_layout_limit", "tgnn_set_split_precision", "tgnn_set_gin_fused", "tgnn_set_gin_mlp_f16", "tgnn_rccl_available", "tgnn_rccl_unique_id_bytes", "tgnn_rccl_unique_id", "tgnn_rccl_comm_create", "tgnn_rccl_comm_destroy", "tgnn_rccl_counters", "tgnn_debug_set_csr_bucket_cap", "tgnn_debug_set_block_caps", "tgnn_forward_train", "tgnn_backward_workspace_bytes", "tgnn_backward", "tgnn_forward_sharded_workspace_bytes", "tgnn_forward_sharded",
+    "tgnn_graph_prep_small", "tgnn_graph_prep_workspace_bytes", "tgnn_graph_prep", "tgnn_set_small_layout_limit", "tgnn_get_small_layout_limit", "tgnn_set_split_precision", "tgnn_set_gin_fused", "tgnn_set_gin_mlp_f16", "tgnn_rccl_available", "tgnn_rccl_unique_id_bytes", "tgnn_rccl_unique_id", "tgnn_rccl_comm_create", "tgnn_rccl_comm_destroy", "tgnn_rccl_counters", "tgnn_forward_train", "tgnn_backward_workspace_bytes", "tgnn_backward", "tgnn_forward_sharded_workspace_bytes", "tgnn_forward_sharded",
     "tgnn_rows_gather", "tgnn_rows_scatter", "tgnn_unsupervised_loss_workspace_bytes", "tgnn_unsupervised_loss", "tgnn_solution_score_sums",
     "tgnn_sublayout_workspace_bytes", "tgnn_sublayout_compact", "tgnn_greedy_round_workspace_bytes", "tgnn_greedy_round", "tgnn_shard_alive_rows",
     "tgnn_transpose", "tgnn_swap_leading", "tgnn_gin_aggregate", "tgnn_sigmoid_bwd", "tgnn_add_into", "tgnn_reduce_workspace_bytes", "tgnn_colsum",
@@ -267,27 +282,41 @@ class pinned_stream:
 
 _side_streams = {}
 _stream_lock = threading.Lock()
+_stream_retry_at = {}     # device index -> monotonic time before which a short search is not repeated
 _stream_sets = {}         # device index -> streams found to run beside the device's current stream and beside each other
 
 
-def _run_side_by_side(a, b, dev, cycles=400_000) -> bool:
-    """True when a spinning kernel on stream a and one on stream b overlap in time (wall clock of both against one)."""
-    import time
+def _run_side_by_side(a, b, dev, cycles=400_000, reps=3) -> bool:
+    """True when a spinning kernel on stream a and one on stream b overlap in time.  Timed on the DEVICE (events on the two
+    streams; the minimum of a few repetitions), so that a busy host -- a loaded box, a Python thread holding the GIL between the
+    two launches -- cannot make two concurrent queues look like colliding ones."""
     import torch
 
-    def wall(streams):
-        torch.cuda.synchronize(dev)
-        t = time.perf_counter()
-        for st in streams:
-            with torch.cuda.stream(st):
+    def span(with_b: bool) -> float:
+        best = float("inf")
+        for _ in range(reps):
+            torch.cuda.synchronize(dev)
+            e0, ea, eb = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record(a)
+            if with_b:
+                b.wait_event(e0)                             # both spins start behind the same point of stream a
+            with torch.cuda.stream(a):
                 torch.cuda._sleep(cycles)
-        torch.cuda.synchronize(dev)
-        return time.perf_counter() - t
-    wall([a])                                               # (warm-up: first use of a stream binds it to a hardware queue)
-    wall([b])
-    one = min(wall([a]), wall([a]))
-    both = min(wall([a, b]), wall([a, b]))
-    return both < 1.5 * one
+            ea.record(a)
+            if with_b:
+                with torch.cuda.stream(b):
+                    torch.cuda._sleep(cycles)
+                eb.record(b)
+            torch.cuda.synchronize(dev)
+            t = e0.elapsed_time(ea)
+            if with_b:
+                t = max(t, e0.elapsed_time(eb))
+            best = min(best, t)
+        return best
+    span(False)                                             # (warm-up: first use of a stream binds it to a hardware queue)
+    with torch.cuda.stream(b):
+        torch.cuda._sleep(1000)
+    return span(True) < 1.5 * span(False)
 
 
 def concurrent_streams(device, k: int):
@@ -305,8 +334,10 @@ def concurrent_streams(device, k: int):
 
 def _concurrent_streams_locked(key, k):
     import torch
+    import time
     have = _stream_sets.setdefault(key, [])
-    if len(have) < k and not getattr(concurrent_streams, "_exhausted_" + str(key), False):
+    # (a search that came up short is repeated after a minute, not never: what else the process runs changes)
+    if len(have) < k and time.monotonic() >= _stream_retry_at.get(key, 0.0):
         cur = torch.cuda.current_stream(key)
         tries = 0
         while len(have) < k and tries < 16:
@@ -315,10 +346,22 @@ def _concurrent_streams_locked(key, k):
             if _run_side_by_side(cur, cand, key) and all(_run_side_by_side(h, cand, key) for h in have):
                 have.append(cand)
         if len(have) < k:
-            setattr(concurrent_streams, "_exhausted_" + str(key), True)
+            _stream_retry_at[key] = time.monotonic() + 60.0
             if not have:
                 have.append(torch.cuda.Stream(device=key))
     return [have[min(i, len(have) - 1)] for i in range(k)]
+
+
+def remeasure_side_streams(device=None) -> None:
+    """Forget the side streams picked so far (of one device, or of all): the next forward measures again."""
+    import torch
+    with _stream_lock:
+        keys = list(_stream_sets) if device is None else [torch.device(device).index if torch.device(device).index is not None
+                                                          else torch.cuda.current_device()]
+        for key in keys:
+            _stream_sets.pop(key, None)
+            _side_streams.pop(key, None)
+            _stream_retry_at.pop(key, None)
 
 
 def side_stream(device) -> C.c_void_p:

@@ -23,6 +23,10 @@
 #include "tgnn_common.h"
 
 namespace tgnn {
+int spin_error_collect_stale(hipStream_t s);   // forward_small.hip (forward_persist.h)
+}
+
+namespace tgnn {
 
 static thread_local char g_err[512] = "";
 
@@ -249,6 +253,8 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
                                      : (sh->allreduce_f64 && sh->alltoall_rows), "shard communicator / callbacks");
         TGNN_CHECK_ARG(sh->n_send == 0 || sh->send_idx, "send_idx");
     }
+    // a persistent kernel of an earlier call that gave up and whose failure nobody collected (forward_persist.h): loud, here
+    TGNN_TRY(spin_error_collect_stale(static_cast<hipStream_t>(stream)));
     Workspace w = carve(*dims, n, nr, graph->n_types, ws, ws_bytes);
     if (!ws || w.bytes > ws_bytes) {
         set_error("tgnn_forward: workspace too small (%zu < %zu)", ws_bytes, w.bytes);

@@ -75,7 +75,7 @@ struct MidArgs {
     double *runstat;             // [depth][128] parked batch statistics for the running buffers
     unsigned *ctr;               // barrier counter (zero before the launch)
     unsigned *bounds;            // [0, depth]: max |slot k| as float bits (this kernel fills 1 ..); [depth + 1 ..]: max |root_i|
-    unsigned *err;
+    unsigned *err, *err_host;    // the device's spin-error word and its host-mapped mirror (forward_persist.h)
     unsigned long long spin_budget;
     int64_t n;
     int n_types, depth, update_running, tiles_per_block, deg_log2, fault, nn_split;
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(kMidThreads) void forward_layers_mid_kernel(MidArgs
     const int kb = (int)(n_tiles - tile0 < K ? (n_tiles - tile0 > 0 ? n_tiles - tile0 : 0) : K);   // tiles of this block
     const unsigned nblk = gridDim.x, blk = blockIdx.x;
     const size_t slot = (size_t)n * 32;
-    SpinCtx spin{A.err, A.spin_budget, false};
+    SpinCtx spin{A.err, A.spin_budget, false, A.err_host};
     unsigned b_target = 0;
     const bool ent_resident = K <= kMidWaves;                    // one tile per wave: its batches stay in LDS for all layers
     double bn1 = 0.0, bn2 = 0.0;                                  // this wave's BatchNorm sums of the layer: lane = (channel, sum | sumsq)
@@ -632,6 +632,7 @@ int mid_layout_tiles_per_block(const tgnn_model_dims *d, const tgnn_graph *g, in
     if (d->network_width != 32 || d->network_depth < 1 || d->network_depth > kMaxDepth) return 0;
     if (g->nn_max_in_degree < 1 || g->n_types + 1 > kMidTileBatches) return 0;
     if (mid_lds_bytes(g->n_types) > kMidMaxLds) return 0;
+    if (!persist_allowed()) return 0;                             // (a starved persistent kernel a few forwards ago: general schedule for now)
     static std::atomic<int> capacity[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
@@ -646,7 +647,7 @@ int mid_layout_tiles_per_block(const tgnn_model_dims *d, const tgnn_graph *g, in
         capacity[dev].store(cap, std::memory_order_release);
     }
     if (cap <= 0) return 0;
-    int max_blocks = cap;
+    int max_blocks = cap < 256 ? cap : 256;                       // (mid_part / gpart are sized for 256 blocks: launch_forward_mid)
     if (const int dbg = g_mid_blocks_cap.load(std::memory_order_relaxed); dbg > 0 && dbg < max_blocks) max_blocks = dbg;
     const int64_t n_tiles = (n_nodes + 15) / 16;
     int64_t k = (n_tiles + max_blocks - 1) / max_blocks;
@@ -686,6 +687,7 @@ int launch_forward_mid(const tgnn_model_dims *d, const Params &P, float *mid, fl
     A.ctr = ctr;
     A.bounds = bounds;
     A.err = spin_error_word();
+    A.err_host = spin_error_mirror();
     A.spin_budget = spin_budget_ticks();
     A.fault = spin_take_fault();
     if (!A.err) {

@@ -260,6 +260,8 @@ struct SpinCtx {
     unsigned *err;                       // device error word (never NULL)
     unsigned long long budget;           // ticks
     bool gave_up;                        // this thread has given up (it then stops waiting for good)
+    unsigned *mirror = nullptr;          // the same word in host-mapped memory (may be NULL): written by whoever GIVES UP, so
+                                         // that the host sees a failure at its next forward call without a copy or a wait
 };
 // true: go on waiting; false: stop (budget used up, or somebody reported an error)
 __device__ __forceinline__ bool spin_continue(SpinCtx &sp, unsigned long long t0, unsigned iter, unsigned code) {
@@ -271,6 +273,7 @@ __device__ __forceinline__ bool spin_continue(SpinCtx &sp, unsigned long long t0
     }
     if (wall_clock64() - t0 > sp.budget) {
         __hip_atomic_fetch_or(sp.err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sp.mirror) __hip_atomic_fetch_or(sp.mirror, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         sp.gave_up = true;
         return false;
     }
@@ -287,6 +290,16 @@ __device__ __forceinline__ void spin_until_ge(const unsigned *ctr, unsigned targ
 
 // the per-device error word + budget of the spin kernels (forward_small.hip); NULL when the allocation failed
 unsigned *spin_error_word();
+// its host-mapped mirror as the device sees it (NULL: none); spin_error_pending: what the host sees there right now
+unsigned *spin_error_mirror();
+unsigned spin_error_pending();
+// A failure nobody has collected (tgnn_spin_error_poll was not called behind the forward that failed: plain forward(), the crop
+// loop, a C caller): cleared here, the persistent schedules go off for a while (persist_fallback) and the caller is told.  Called
+// at the entry of every forward of the library; returns TGNN_OK or TGNN_ERR_STALE_RESULT with the message set.
+int spin_error_collect_stale(hipStream_t s);
+// the persistent schedules are off for the next n forwards of this process, then come back (0: back now)
+void persist_fallback(int64_t n_forwards);
+bool persist_allowed();                  // (counts a forward of the window down)
 unsigned long long spin_budget_ticks();
 // test hook (tgnn_debug_spin_fault): 1 = the launch being queued runs with its last block absent (it returns at once), which
 // is what a block that never becomes resident looks like to the others

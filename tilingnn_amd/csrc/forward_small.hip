@@ -131,6 +131,7 @@ struct SmallArgs {
     const unsigned *weights_done;   // NULL, or: blocks of the edge-weight kernel that have finished (the kernel may start before them)
     unsigned weights_target;
     unsigned *err;               // the device's spin-error word (forward_persist.h: no wait of this kernel spins without bound)
+    unsigned *err_host;          // ... and its host-mapped mirror (may be NULL)
     unsigned long long spin_budget;
     int64_t n;
     int n_types, depth, update_running, fault;
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
     const bool row_ok = my_row < n;
     const unsigned nblk = gridDim.x;
     unsigned target = 0;
-    SpinCtx spin{A.err, A.spin_budget, false};
+    SpinCtx spin{A.err, A.spin_budget, false, A.err_host};
     const size_t slot = (size_t)n * 32;
     const __amdgpu_buffer_rsrc_t part_rs = rsrc_of(A.part);
 #ifdef TGNN_SMALL_TIMING
@@ -1030,6 +1031,65 @@ unsigned *spin_error_word() {
     return word[dev];
 }
 
+// The mirror: 64 bytes of host memory mapped into the device, one per device.  Only a thread that gives up writes it (a
+// system-scope OR over the host link: rare by construction); the waiters poll the DEVICE word.
+struct SpinMirror {
+    unsigned *host = nullptr, *dev = nullptr;
+};
+static SpinMirror *spin_mirror_of_current_device() {
+    static std::mutex mu;
+    static SpinMirror m[64];
+    static bool tried[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!tried[dev]) {
+        tried[dev] = true;
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess) {
+            for (int i = 0; i < 16; ++i) static_cast<volatile unsigned *>(h)[i] = 0u;
+            if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+                m[dev].host = static_cast<unsigned *>(h);
+                m[dev].dev = static_cast<unsigned *>(d);
+            } else {
+                (void)hipHostFree(h);
+            }
+        }
+    }
+    return m[dev].host ? &m[dev] : nullptr;
+}
+unsigned *spin_error_mirror() {
+    SpinMirror *m = spin_mirror_of_current_device();
+    return m ? m->dev : nullptr;
+}
+unsigned spin_error_pending() {
+    SpinMirror *m = spin_mirror_of_current_device();
+    return m ? __atomic_load_n(m->host, __ATOMIC_RELAXED) : 0u;
+}
+static void spin_error_clear(hipStream_t s) {                // (stream-ordered for the device word; the mirror at once)
+    if (unsigned *w = spin_error_word()) (void)hipMemsetAsync(w, 0, 4, s);
+    if (SpinMirror *m = spin_mirror_of_current_device()) __atomic_store_n(m->host, 0u, __ATOMIC_RELAXED);
+}
+static std::atomic<int64_t> g_persist_off{0};                // forwards left in the fallback window
+void persist_fallback(int64_t n_forwards) { g_persist_off.store(n_forwards > 0 ? n_forwards : 0, std::memory_order_relaxed); }
+bool persist_allowed() {
+    int64_t v = g_persist_off.load(std::memory_order_relaxed);
+    while (v > 0 && !g_persist_off.compare_exchange_weak(v, v - 1)) {}
+    return v <= 0;
+}
+constexpr int64_t kPersistFallbackForwards = 256;            // how long a starved persistent kernel keeps its kind off
+int spin_error_collect_stale(hipStream_t s) {
+    const unsigned code = spin_error_pending();
+    if (!code) return TGNN_OK;
+    spin_error_clear(s);
+    persist_fallback(kPersistFallbackForwards);
+    set_error("a persistent forward kernel of an EARLIER call gave up waiting for its other blocks (reason bits %u: 1 grid barrier, 2 "
+              "partial rows, 4 edge weights) and nobody collected the failure: the results of that forward -- and of any persistent "
+              "forward queued behind it -- are invalid.  The word is cleared, the persistent schedules are off for the next %lld "
+              "forwards; repeat the call (TilinGNN.forward_checked does all this by itself)", code, (long long)kPersistFallbackForwards);
+    return TGNN_ERR_STALE_RESULT;
+}
+
 static size_t small_lds_bytes(int n_types, int depth) {
     return ((size_t)small_s_offset(depth) + (size_t)(n_types + 1) * 512) * sizeof(float);
 }
@@ -1042,6 +1102,7 @@ static std::atomic<int64_t> g_small_limit{4096};
 int small_layout_teams(const tgnn_model_dims *d, int64_t n_nodes, int n_types, int max_in_degree) {
     const int64_t limit = g_small_limit.load(std::memory_order_relaxed);
     if (n_nodes < 2 || n_nodes > limit || n_nodes > 4096) return 0;
+    if (!persist_allowed()) return 0;                        // (a starved kernel of this kind a few forwards ago: general schedule for now)
     if (max_in_degree < 1 || max_in_degree + 1 > kNnEntries) return 0;   // a row's gather list (edges + the root row) in registers
     if (d->network_width != 32 || d->network_depth < 1 || d->network_depth > kSmallMaxDepth || d->output_dim > 256 ||
         d->node_features_dim > 256)
@@ -1188,6 +1249,7 @@ int launch_forward_small(const tgnn_model_dims *d, const Params &P, const float 
     A.eps = eps;
     A.momentum = momentum;
     A.err = spin_error_word();
+    A.err_host = spin_error_mirror();
     A.spin_budget = spin_budget_ticks();
     A.fault = spin_take_fault();
     if (!A.err) {
@@ -1250,15 +1312,23 @@ extern "C" int tgnn_spin_error_poll(tgnn_stream_t stream, uint32_t *code_out) {
     unsigned host = 0;
     TGNN_CHECK_HIP(hipMemcpyAsync(&host, w, 4, hipMemcpyDeviceToHost, s));
     TGNN_CHECK_HIP(hipStreamSynchronize(s));
-    if (host) TGNN_CHECK_HIP(hipMemsetAsync(w, 0, 4, s));
+    host |= tgnn::spin_error_pending();
+    if (host) {
+        tgnn::spin_error_clear(s);
+        tgnn::persist_fallback(tgnn::kPersistFallbackForwards);   // both persistent schedules off for a while, then re-armed
+    }
     *code_out = host;
     if (host)
         tgnn::set_error("a persistent forward kernel gave up waiting for its other blocks (reason bits %u: 1 grid barrier, 2 partial "
                         "rows, 4 edge weights): another process or tenant holds compute units; the results of that forward are "
-                        "invalid -- run the general schedule (tgnn_set_small_layout_limit(0), tgnn_set_mid_layout_limit(0))", host);
+                        "invalid -- repeat it: the persistent schedules are off for the next %lld forwards", host,
+                        (long long)tgnn::kPersistFallbackForwards);
     return TGNN_OK;
 }
+extern "C" void tgnn_persist_fallback(int64_t n_forwards) { tgnn::persist_fallback(n_forwards); }
+#ifdef TGNN_DEBUG
 extern "C" void tgnn_debug_spin_fault(int32_t n_launches) { tgnn::g_spin_fault.store(n_launches > 0 ? n_launches : 0); }
+#endif
 extern "C" uint64_t tgnn_set_spin_budget_us(uint64_t us) {
     const unsigned long long ticks = us * 100ull;             // wall_clock64: 100 MHz
     return tgnn::g_spin_budget.exchange(ticks ? ticks : tgnn::kSpinBudgetTicksDefault) / 100ull;

@@ -765,10 +765,12 @@ using namespace tgnn;
 namespace tgnn { std::atomic<int> g_debug_block_cap[2]; static std::atomic<int> g_gin_fused{1}; std::atomic<int> g_gin_mlp16{0}; }
 extern "C" int32_t tgnn_set_gin_mlp_f16(int32_t on) { return tgnn::g_gin_mlp16.exchange(on ? 1 : 0); }
 extern "C" int32_t tgnn_set_gin_fused(int32_t mode) { return tgnn::g_gin_fused.exchange(mode < 0 ? 0 : (mode > 2 ? 2 : mode)); }
+#ifdef TGNN_DEBUG
 extern "C" void tgnn_debug_set_block_caps(int32_t nnconv_blocks, int32_t gin_mlp_blocks) {
     g_debug_block_cap[0].store(nnconv_blocks);
     g_debug_block_cap[1].store(gin_mlp_blocks);
 }
+#endif
 
 namespace tgnn {
 int gin32_fwd_folded(const float *a, int64_t lda, const float *in_stat, const int32_t *rowptr, const int32_t *col_src, const float *eps,

@@ -1279,11 +1279,13 @@ static int csr_build_pair_bucketed(const int64_t *adj_ei, int64_t ea, const int6
 
 using namespace tgnn;
 
+#ifdef TGNN_DEBUG
 extern "C" int32_t tgnn_debug_set_csr_bucket_cap(int32_t cap) {
     const int prev = g_bk_cap.load();
     if (cap >= 0) g_bk_cap.store(cap > kBkCap ? kBkCap : cap);
     return prev;
 }
+#endif
 
 extern "C" size_t tgnn_csr_workspace_bytes(int64_t n_nodes, int64_t n_edges) {
     return align_up((size_t)(n_nodes + 1) * 4, 256) + align_up((size_t)(n_edges > 0 ? n_edges : 1) * 4, 256) +

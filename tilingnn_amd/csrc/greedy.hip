@@ -51,7 +51,10 @@ __global__ void greedy_beaten_kernel(const int64_t *__restrict__ col, int64_t ec
         if (u < 0 || u >= n_sub || v < 0 || v >= n_sub) { *err = 1; continue; }
         if (u == v) continue;                                     // (GINConv drops self loops; so does the collision test)
         const double pu = p[u], pv = p[v];
+        // the later of the two in the visiting order is beaten -- marked from EITHER direction of the pair, so that a collision
+        // stored one way only (the reference stores both, tile_graph.py:206-207) still keeps the two apart
         if (pv > pu || (pv == pu && v < u)) flags[u] = 1;         // (every writer stores the same word)
+        else flags[v] = 1;
     }
 }
 __global__ void greedy_accept_kernel(const int64_t *__restrict__ inverse, int64_t n_sub, const double *__restrict__ p, int round,

@@ -198,7 +198,7 @@ def compact_shard_device(shard: Shard, inputs: Dict[str, Tensor], alive) -> "tup
     n_halo = n_rows - n_own
     x, adj, attr, col = inputs["x"], inputs["adj"], inputs["attr"], inputs["col"]
     fx = int(x.shape[1])
-    ea, ec, fe = int(adj.shape[1]), int(col.shape[1]), int(attr.shape[1]) if attr.numel() else 1
+    ea, ec, fe = int(adj.shape[1]), int(col.shape[1]), int(attr.shape[1])   # (the width also of an EMPTY attribute array: every rank keeps [*, Fe])
     stream = _lib.current_stream(dev)
     alive_d = (alive if torch.is_tensor(alive) and alive.is_cuda else torch.from_numpy(alive_h.astype(np.int32)).to(dev)).to(torch.int32)
     gid = torch.cat([torch.arange(lo, hi, dtype=torch.int64, device=dev),
@@ -811,6 +811,9 @@ def solve_sharded(net, shard: Shard, device, collectives, setup, collide_edge_in
     sharding: it returns with `sweep.unlabelled` non-empty and the caller finishes the few remaining rounds on one device
     (finish_on_one_device).  Returns (sweep, rounds): sweep.selection / .order / .unlabelled over the original numbering."""
     from .util.algorithms import HostSweep
+    if int(getattr(net, "output_dim", 1)) != 1:
+        raise ValueError("solve_sharded scores with probability map 0: the network must have output_dim == 1 (ML_Solver picks the "
+                         "map by its loss; the sharded loop has no loss pass)")
     world = shard.world
     n = shard.n_total
     sweep = HostSweep(n, collide_edge_index, uniform)
@@ -828,6 +831,7 @@ def solve_sharded(net, shard: Shard, device, collectives, setup, collide_edge_in
         else:
             fwd = FusedShardForward(net, shard, device, collectives, inputs=inputs, rccl=rccl)
             fwd.two_streams = rccl is not None
+            # (ML_Solver picks the probability map by its loss; with the reference's single map that is map 0)
             own = fwd.step()[:, 0].contiguous()
             prob = torch.cat([p.reshape(-1) for p in collectives.allgather(own)]).cpu().numpy()
         if on_round is not None:
