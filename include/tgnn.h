@@ -440,6 +440,8 @@ uint64_t tgnn_set_spin_budget_us(uint64_t us);
  * any forward entry point that finds one nobody collected -- it then returns TGNN_ERR_STALE_RESULT (the word cleared, the message
  * set): the results of the EARLIER forward that failed, and of persistent forwards queued behind it, are invalid. */
 void tgnn_persist_fallback(int64_t n_forwards);
+/* what the host sees of the current device's spin-error word right now (its host-mapped mirror: no copy, no wait, not cleared) */
+uint32_t tgnn_spin_error_peek(void);
 int64_t tgnn_get_small_layout_limit(void);
 
 /* Split precision of the general schedule's matrix-core kernels (NNConv, the final MLP's first Linear).  Both hold the fp32

@@ -105,6 +105,7 @@ def _load() -> C.CDLL:
         "tgnn_spin_error_poll": (C.c_int, [p, C.POINTER(C.c_uint32)]),
         "tgnn_set_spin_budget_us": (C.c_uint64, [C.c_uint64]),
         "tgnn_persist_fallback": (None, [i64]),
+        "tgnn_spin_error_peek": (C.c_uint32, []),
         "tgnn_gin_fwd": (C.c_int, [p, i64, p, p, p, p, p, p, p, p, p, p, i64, i32, i32, p, p, p, pi32, p]),
         "tgnn_dense_act_fwd": (C.c_int, [p, i64, i64, p, p, p, i64, i32, i32, i32, p, i64, p, pi32, p]),
         "tgnn_dense_act_slots_fwd": (C.c_int, [p, i32, i64, p, p, p, i64, i32, i32, i32, p, i64, p, pi32, p]),
@@ -218,7 +219,7 @@ EXPORTED_SYMBOLS = (
     "tgnn_nnconv_mean_fwd", "tgnn_nnconv_cols_max_columns", "tgnn_nnconv_cols_workspace_bytes",
     "tgnn_nnconv_cols_build", "tgnn_nnconv_cols_max_types", "tgnn_nnconv_weight_image_floats", "tgnn_nnconv_mean_cols_fwd", "tgnn_nnconv_mean_cols_f16_fwd",
     "tgnn_ubench_row_gather", "tgnn_mid_entries_words", "tgnn_mid_entries_build", "tgnn_forward_path_counts", "tgnn_set_mid_layout_limit", "tgnn_get_mid_layout_limit", "tgnn_mid_layout_max_nodes",
-    "tgnn_spin_error_poll", "tgnn_set_spin_budget_us", "tgnn_persist_fallback", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_dense_act_slots_fwd", "tgnn_dense_act_slots_f16_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
+    "tgnn_spin_error_poll", "tgnn_set_spin_budget_us", "tgnn_persist_fallback", "tgnn_spin_error_peek", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_dense_act_slots_fwd", "tgnn_dense_act_slots_f16_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
     "tgnn_merge_fwd", "tgnn_param_count", "tgnn_param_name", "tgnn_forward_workspace_bytes", "tgnn_forward",
     "tgnn_forward_profiled", "tgnn_forward_profiled_two_stream", "tgnn_forward_stamped", "tgnn_forward_many", "tgnn_graph_prep_small_max_nodes", "tgnn_graph_prep_small_max_edges", "tgnn_graph_prep_small_tmp_ints",
     "tgnn_graph_prep_small", "tgnn_graph_prep_workspace_bytes", "tgnn_graph_prep", "tgnn_set_small_layout_limit", "tgnn_get_small_layout_limit", "tgnn_set_split_precision", "tgnn_set_gin_fused", "tgnn_set_gin_mlp_f16", "tgnn_rccl_available", "tgnn_rccl_unique_id_bytes", "tgnn_rccl_unique_id", "tgnn_rccl_comm_create", "tgnn_rccl_comm_destroy", "tgnn_rccl_counters", "tgnn_forward_train", "tgnn_backward_workspace_bytes", "tgnn_backward", "tgnn_forward_sharded_workspace_bytes", "tgnn_forward_sharded",

@@ -273,7 +273,8 @@ __device__ __forceinline__ bool spin_continue(SpinCtx &sp, unsigned long long t0
     }
     if (wall_clock64() - t0 > sp.budget) {
         __hip_atomic_fetch_or(sp.err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (sp.mirror) __hip_atomic_fetch_or(sp.mirror, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (a STORE: of the read-modify-writes only add / swap / compare-and-swap exist on the host link; any non-zero value says it)
+        if (sp.mirror) __hip_atomic_store(sp.mirror, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         sp.gave_up = true;
         return false;
     }

@@ -1046,7 +1046,7 @@ static SpinMirror *spin_mirror_of_current_device() {
     if (!tried[dev]) {
         tried[dev] = true;
         void *h = nullptr, *d = nullptr;
-        if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess) {
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
             for (int i = 0; i < 16; ++i) static_cast<volatile unsigned *>(h)[i] = 0u;
             if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
                 m[dev].host = static_cast<unsigned *>(h);
@@ -1326,6 +1326,7 @@ extern "C" int tgnn_spin_error_poll(tgnn_stream_t stream, uint32_t *code_out) {
     return TGNN_OK;
 }
 extern "C" void tgnn_persist_fallback(int64_t n_forwards) { tgnn::persist_fallback(n_forwards); }
+extern "C" uint32_t tgnn_spin_error_peek(void) { return tgnn::spin_error_pending(); }
 #ifdef TGNN_DEBUG
 extern "C" void tgnn_debug_spin_fault(int32_t n_launches) { tgnn::g_spin_fault.store(n_launches > 0 ? n_launches : 0); }
 #endif

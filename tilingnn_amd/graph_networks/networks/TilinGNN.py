@@ -193,8 +193,8 @@ class TilinGNN(Tracked, nn.Module):
         """forward() + the health check of the persistent kernels (layouts of up to 65 536 nodes run their layers as ONE kernel
         whose blocks wait for each other: csrc/forward_small.hip, forward_mid.hip).  Every such wait is bounded; a kernel
         that was starved of compute units by another process gives up and leaves a word behind.  This call SYNCHRONISES the
-        current stream, reads that word and, if it is set, switches the persistent schedules off for the process and runs the
-        forward again on the general launch schedule.  ML_Solver.predict goes through here (it copies the probabilities to the
+        current stream, reads that word and, if it is set, runs the forward again on the general launch schedule (which the next
+        256 forwards of the process take too: tgnn_persist_fallback).  ML_Solver.predict goes through here (it copies the probabilities to the
         host right away, so the synchronisation costs it nothing); forward() itself stays asynchronous."""
         out = self._forward_one(x, adj_e_index, adj_e_features, col_e_idx, col_e_features)
         dev = x.device
@@ -202,11 +202,11 @@ class TilinGNN(Tracked, nn.Module):
         check(lib.tgnn_spin_error_poll(_lib.current_stream(dev), C.byref(code)))
         if code.value:
             import warnings
+            # (the poll has opened the fallback window: the next 256 forwards of the process take the general schedule, then the
+            #  persistent ones are tried again -- a transient neighbour does not cost every later predict 30-50 %)
             warnings.warn("tilingnn_amd: a persistent forward kernel gave up waiting for its blocks (another process holds compute "
-                          f"units; reason bits {code.value}); the persistent schedules are switched off for this process and the "
-                          "forward is repeated on the general launch schedule", RuntimeWarning)
-            lib.tgnn_set_small_layout_limit(0)
-            lib.tgnn_set_mid_layout_limit(0)
+                          f"units; reason bits {code.value}); the forward is repeated on the general launch schedule, which the "
+                          "next forwards of this process take as well", RuntimeWarning)
             out = self._forward_one(x, adj_e_index, adj_e_features, col_e_idx, col_e_features)
         return out
 
