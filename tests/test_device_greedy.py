@@ -118,3 +118,41 @@ def test_ml_solver_switches_to_the_device_loop_above_its_threshold(dev):
     assert alg.solve_by_device_greedy.last_rounds > 0
     _check_selection(out.predict, col, 6000)
     assert out.predict_probs.shape == (6000,)
+
+
+def test_device_greedy_tilings_score_like_the_host_sweeps_on_the_real_layout(dev):
+    """The substitute must not buy its O(log N) rounds with worse tilings.  The real labyrinth layout (1 254 placements), the
+    reference's own score formula (oracle.greedy_oracle.solution_score = losses.py:120-148; the fixture carries no polygons, so
+    with unit perimeters and the layout's total tile area as the contour: a quantity both loops are measured with alike), five
+    seeds each: the device loop's mean score within 3 % of the host sweep's (util/algorithms.py:18-62, the reference's random
+    stream), its tile counts within 5 %, every selection collision free and maximal."""
+    from oracle import greedy_oracle as go
+    from tests.golden_util import load_labyrinth_graph
+    from tilingnn_amd.solver.ml_solver.ml_solver import LayoutArrays, ML_Solver
+    from tilingnn_amd.util import algorithms as alg
+    g = load_labyrinth_graph()
+    n = int(g["x"].shape[0])
+    col = np.asarray(g["col"])
+    contour = float(np.asarray(g["x"], dtype=np.float64)[:, -1].sum())
+
+    def score(sel):
+        return go.solution_score((np.asarray(sel) > 0).astype(np.float32), g["x"], g["adj"], g["adj_attr"], np.ones(n), 1.0, 1.0, contour)
+
+    host, device, tiles_h, tiles_d = [], [], [], []
+    for seed in range(5):
+        net, _ = make_net(dev)                                  # fresh running statistics for every solve
+        solver = ML_Solver(None, dev, None, net, num_prob_maps=1)
+        layout = LayoutArrays(g["x"], g["adj"], g["adj_attr"], g["col"], g["col_attr"])
+        np.random.seed(seed)
+        out, _ = solver.solve(layout)
+        tiles_h.append(_check_selection(out.predict, col, n))
+        host.append(score(out.predict))
+        net, _ = make_net(dev)
+        solver = ML_Solver(None, dev, None, net, num_prob_maps=1)
+        sel, _, _ = alg.solve_by_device_greedy(solver, LayoutArrays(g["x"], g["adj"], g["adj_attr"], g["col"], g["col_attr"]), seed=seed)
+        tiles_d.append(_check_selection(sel, col, n))
+        device.append(score(sel))
+    mh, md = float(np.mean(host)), float(np.mean(device))
+    print(f"labyrinth, 5 seeds: host sweep score {mh:.5f} ({np.mean(tiles_h):.1f} tiles), device loop {md:.5f} ({np.mean(tiles_d):.1f} tiles)")
+    assert md >= 0.97 * mh, (host, device)
+    assert abs(np.mean(tiles_d) - np.mean(tiles_h)) <= 0.05 * np.mean(tiles_h), (tiles_h, tiles_d)

@@ -378,10 +378,6 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     const bool tiled = graph->nn_tile_col_ptr && c == 32 && (int64_t)nr * c * 4 < (int64_t(1) << 31);   // buffer-addressed gathers
     // Small layouts: the layer loop below is replaced by one persistent kernel (forward_small.hip)
     const int small_teams = (tiled && !sh && !keep && !use_running_stats && !prof.on && nr == n) ? small_layout_teams(dims, n, T, graph->nn_max_in_degree) : 0;
-    // ... which, with CUs to spare, does not wait for the edge weights on the host's event but on a counter of that kernel's
-    // finished blocks: its init MLP runs beside them
-    unsigned *weights_done = (small_teams == 2 && s2 && weights_on_side) ? w.small_ctr + 16 : nullptr;
-    if (weights_done) TGNN_CHECK_HIP(hipMemsetAsync(weights_done, 0, 4, s));
     const int64_t cat_w_floats = (int64_t)c * (D + 1) * kFinalDims[0];
     const int fin_dims[5] = {c * (D + 1), kFinalDims[0], kFinalDims[1], kFinalDims[2], c};   // in / out widths of the final MLP's layers
     // fp16-pair operands (3 matrix terms instead of the 6 of bf16 x 3) wherever a bound of the operand is at hand: the kernels
@@ -395,15 +391,41 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
                      graph->nn_max_in_degree >= 1 && D <= kMaxDepth && (cat_w_floats % 4) == 0;
     unsigned *slot_max = f16 ? w.bounds : nullptr, *root_max = f16 ? w.bounds + D + 1 : nullptr,
              *dense_max = f16 ? w.bounds + 2 * D + 1 : nullptr;
+    // Mid-size layouts (above the small-layout limit, up to 65 536 nodes): the D layers between the init and the final MLP are
+    // ONE persistent kernel carrying both chains (forward_mid.hip) instead of ~5 dependent launches per layer on two streams
+    int mid_blocks = 0;
+    const int mid_k = (f16 && !sh && !keep && !prof.on && nr == n) ? mid_layout_tiles_per_block(dims, graph, n, &mid_blocks) : 0;
+    // The persistent kernels, with CUs to spare for the edge-weight kernel's blocks, do not wait for the edge weights on the host's
+    // event (~12 us of cross-queue latency on a launch-bound forward) but on a counter of that kernel's finished blocks: the small
+    // kernel's init MLP, the mid kernel's first collision layer run beside them
+    // (the mid path's counter is a word of w.bounds that launch_forward_scales below zeroes anyway: no launch of its own)
+    const bool mid_counter = mid_k && mid_blocks + 16 <= device_cus() && s2 && weights_on_side;
+    unsigned *weights_done = mid_counter ? w.bounds + 2 * D + 6 : (small_teams == 2 && s2 && weights_on_side) ? w.small_ctr + 16 : nullptr;
+    if (weights_done && !mid_counter) TGNN_CHECK_HIP(hipMemsetAsync(weights_done, 0, 4, s));
     if (f16) {
         const float *roots[kMaxDepth];
         for (int i = 0; i < D; ++i) roots[i] = P.f(P.layer(i) + 6);
-        launch_forward_scales(w.bounds, 2 * D + 6, roots, D, root_max, P.f(P.fin(0)), cat_w_floats, dense_max, s);   // (before the fork: both chains see the zeroed words)
+        launch_forward_scales(w.bounds, 2 * D + 7, roots, D, root_max, P.f(P.fin(0)), cat_w_floats, dense_max, s);   // (before the fork: both chains see the zeroed words)
     }
     if (s2 && weights_on_side) {
         TGNN_CHECK_HIP(hipEventRecord(ev[kEvFork], s));     // everything the caller queued on `stream` so far
         TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[kEvFork], 0));
         sw = s2;
+    }
+    // (first on the side stream: the layer loop waits for these, the final MLP's bounds and images have the whole loop's time)
+    if (T > 0 || tiled) {
+        // edge MLP of every (layer, type) and, for the matrix-core NNConv, its operand images (root = pseudo-type T): one launch
+        EdgeMlpLayers layers{};
+        const float *roots[kMaxDepth];
+        for (int i = 0; i < D; ++i) {
+            const int b = P.layer(i);
+            layers.l[i] = EdgeMlpLayer{P.f(b), P.f(b + 1), P.f(b + 2), P.f(b + 3), P.f(b + 4), P.f(b + 5)};
+            roots[i] = P.f(b + 6);
+        }
+        prof.begin(0);
+        launch_edge_weight_table_batched(adj_edge_attr, graph->type_rep_edge, T, fe, layers, D, c, w.wtab, tiled ? roots : nullptr,
+                                         tiled ? w.wimg : nullptr, sw, weights_done, root_max);
+        prof.end();
     }
     bool dimg_ok[3] = {false, false, false};
     if (f16) {
@@ -427,25 +449,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
             dimg_ok[l] = c == 32 && n >= kDenseRowsKernelMin && dense_f16_image_build(P.f(P.fin(l)), fin_dims[l], fin_dims[l + 1], wm, w.dimg[l], sw) == TGNN_OK;
         }
     }
-    if (T > 0 || tiled) {
-        // edge MLP of every (layer, type) and, for the matrix-core NNConv, its operand images (root = pseudo-type T): one launch
-        EdgeMlpLayers layers{};
-        const float *roots[kMaxDepth];
-        for (int i = 0; i < D; ++i) {
-            const int b = P.layer(i);
-            layers.l[i] = EdgeMlpLayer{P.f(b), P.f(b + 1), P.f(b + 2), P.f(b + 3), P.f(b + 4), P.f(b + 5)};
-            roots[i] = P.f(b + 6);
-        }
-        prof.begin(0);
-        launch_edge_weight_table_batched(adj_edge_attr, graph->type_rep_edge, T, fe, layers, D, c, w.wtab, tiled ? roots : nullptr,
-                                         tiled ? w.wimg : nullptr, sw, weights_done, root_max);
-        prof.end();
-    }
     if (small_teams) launch_small_pack(P, D, w.small_pack, w.small_ctr, s);   // on the main stream: it has nothing else to do yet
-    // Mid-size layouts (above the small-layout limit, up to 65 536 nodes): the D layers between the init and the final MLP are
-    // ONE persistent kernel carrying both chains (forward_mid.hip) instead of ~5 dependent launches per layer on two streams
-    int mid_blocks = 0;
-    const int mid_k = (f16 && !sh && !keep && !prof.on && nr == n) ? mid_layout_tiles_per_block(dims, graph, n, &mid_blocks) : 0;
     // (parameter vectors + GIN images of the layers; the same launch clears the barrier counter and the tagged partial rows)
     if (mid_k) launch_small_pack(P, D, w.small_pack, w.small_ctr, s, false, w.mid_part, mid_part_doubles() * sizeof(double));
     if (sw != s) TGNN_CHECK_HIP(hipEventRecord(ev[kEvWeights], s2));
@@ -523,9 +527,12 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         return TGNN_OK;
     };
     if (mid_k) {
-        if (sw != s) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[kEvWeights], 0));   // (the images and the bounds of the side stream)
+        if (sw != s && !weights_done) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[kEvWeights], 0));   // (the images of the side stream)
         TGNN_TRY(launch_forward_mid(dims, P, w.mid, w.a1, w.a2[0], w.a2[1], w.wimg, w.small_pack, graph, w.mid_part, w.small_runstat,
-                                    w.small_ctr, w.bounds, n, mid_k, mid_blocks, update_running, eps, momentum, s));
+                                    w.small_ctr, w.bounds, n, mid_k, mid_blocks, update_running, eps, momentum, s, weights_done,
+                                    (unsigned)((T + 1) * D)));
+        // (the final MLP reads the side stream's bounds and operand images: behind the layer loop, where the wait costs nothing)
+        if (sw != s && weights_done) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[kEvWeights], 0));
     } else if (s2) {
         TGNN_CHECK_HIP(hipEventRecord(ev[0], s));            // middle[0] is complete
         TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[0], 0));

@@ -66,6 +66,8 @@ struct MidArgs {
     float *a1;                   // [n][32] GraphConv pre-BatchNorm rows of the layer
     float *a2[2];                // CollConv pre-BatchNorm rows, two-deep
     const float *wimg;           // NNConv fp16-pair weight images [depth][(T + 1)][kWtTypeF16]
+    const unsigned *weights_done;   // NULL, or: blocks of the edge-weight kernel that have finished (this kernel may start before them)
+    unsigned weights_target;
     const float *pack;           // [depth][kSpStride] parameter vectors + GIN MFMA images (small_pack_kernel)
     const int *adj_rowptr;       // in-degrees of the adjacency set
     const int *col_rowptr, *col_nbr;
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(kMidThreads) void forward_layers_mid_kernel(MidArgs
     };
 
     // ---- prologue: images of layer 0, the batches of one-tile waves, the zeroed tiles; then GIN_0 (reads slot 0, no statistics)
-    mid_dma(A.wimg, wl, (T + 1) * kWtTypeF16 * 4, wave, lane);
+    if (!A.weights_done) mid_dma(A.wimg, wl, (T + 1) * kWtTypeF16 * 4, wave, lane);
     mid_dma(A.pack + kSpGinW, gw, kSpGinFrags * 16, wave, lane);
     for (int i = lane; i < kMidTileFloats / 4; i += 64) reinterpret_cast<f32x4 *>(tbuf)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     int nb_res = 0;
@@ -364,6 +366,15 @@ __global__ __launch_bounds__(kMidThreads) void forward_layers_mid_kernel(MidArgs
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();                                              // GIN_0 is through with the GIN image
     if (D > 1) mid_dma(A.pack + (size_t)kSpStride + kSpGinW, gw, kSpGinFrags * 16, wave, lane);
+    if (A.weights_done) {
+        // the NNConv operand images come from a kernel on another stream that may still be running (GIN_0 above did not need
+        // them): wait for its last block, drop what this CU caches of other XCDs' lines, then bring layer 0's image in
+        if (tid == 0) spin_until_ge(A.weights_done, A.weights_target, spin, kSpinErrWeights);
+        __syncthreads();
+        if (wave == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+        mid_dma(A.wimg, wl, (T + 1) * kWtTypeF16 * 4, wave, lane);
+    }
 
     for (int layer = 0; layer < D; ++layer) {
         const float *sp = A.pack + (size_t)layer * kSpStride;
@@ -667,9 +678,12 @@ size_t mid_part_doubles() { return (size_t)2 * 2 * 256 * 128; }   // part + gpar
 
 int launch_forward_mid(const tgnn_model_dims *d, const Params &P, float *mid, float *a1, float *a2_0, float *a2_1, const float *wimg,
                        const float *pack, const tgnn_graph *graph, double *part, double *runstat, unsigned *ctr, unsigned *bounds,
-                       int64_t n, int tiles_per_block, int blocks, int update_running, float eps, float momentum, hipStream_t s) {
+                       int64_t n, int tiles_per_block, int blocks, int update_running, float eps, float momentum, hipStream_t s,
+                       const unsigned *weights_done, unsigned weights_target) {
     const int depth = d->network_depth;
     MidArgs A{};
+    A.weights_done = weights_done;
+    A.weights_target = weights_target;
     A.mid = mid;
     A.a1 = a1;
     A.a2[0] = a2_0;

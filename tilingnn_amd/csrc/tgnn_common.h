@@ -470,7 +470,8 @@ int mid_layout_tiles_per_block(const tgnn_model_dims *d, const tgnn_graph *g, in
 size_t mid_part_doubles();
 int launch_forward_mid(const tgnn_model_dims *d, const Params &P, float *mid, float *a1, float *a2_0, float *a2_1, const float *wimg,
                        const float *pack, const tgnn_graph *graph, double *part, double *runstat, unsigned *ctr, unsigned *bounds,
-                       int64_t n, int tiles_per_block, int blocks, int update_running, float eps, float momentum, hipStream_t s);
+                       int64_t n, int tiles_per_block, int blocks, int update_running, float eps, float momentum, hipStream_t s,
+                       const unsigned *weights_done = nullptr, unsigned weights_target = 0);
 // MFMA weight image of the column NNConv, per type: [plane 3 (hi, mid, lo)][M block 2][g 4][i 16] x 8 bf16 --
 // the A fragment of lane 16 g + i for one (plane, M block) is one 16-byte read, a wavefront reads 1 KB in lane order
 // (conflict-free: SQ_LDS_BANK_CONFLICT 2.3e6 -> 2.3e5 per launch against the [i][g] order of round 1); 6144 B per type
