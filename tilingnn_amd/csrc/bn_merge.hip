@@ -305,26 +305,35 @@ __global__ __launch_bounds__(1024) void merge_bn1_wide_kernel(const float *__res
         }
     }
     if (tid >= 1024 - 4 * c) st2s[tid - (1024 - 4 * c)] = st2[tid - (1024 - 4 * c)];
+    // [r5] ONE round trip for the partial rows -- every thread asks for its <= 32 rows (g, g + 16, ..) at once through a buffer
+    // descriptor that ends with the rows (a row past the end returns 0.0 without touching memory and adds nothing: the same
+    // sum, term by term, as bn_finalize_kernel's batches) -- and the first kPf items' operands go out BEHIND them: the wait
+    // for the rows leaves those HBM loads in flight, so the reduction (~4 us in front of every block's stream before) now
+    // runs under them.  (At 100 000 nodes a thread has 3.05 items in all.)
+    constexpr int kPf = 3;
+    const int64_t i_first = (int64_t)blockIdx.x * blockDim.x + tid, i_step = (int64_t)gridDim.x * blockDim.x;
+    float4 px1[kPf], px2[kPf], pr[kPf];
     {
+        using u32x2_ = __attribute__((ext_vector_type(2))) unsigned int;
         const int j = tid % two_f, g = tid / two_f;
-        const double *src = j1.partials + j;
+        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<double *>(j1.partials), 0, (int)((uint32_t)j1.n_partials * (uint32_t)two_f * 8u), 0x00020000);
+        static_assert(TGNN_BN_MAX_PARTIALS <= 32 * groups, "32 rows per thread cover every partial row");
+        u32x2_ v[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q)
+            v[q] = __builtin_amdgcn_raw_buffer_load_b64(prs, ((uint32_t)(g + q * groups) * (uint32_t)two_f + (uint32_t)j) * 8u, 0, 0);
+#pragma unroll
+        for (int k = 0; k < kPf; ++k) {
+            const int64_t i = i_first + k * i_step;
+            const int64_t ii = i < n4 ? i : n4 - 1;          // (clamped: nothing is loaded inside a branch)
+            px1[k] = reinterpret_cast<const float4 *>(a1)[ii];
+            px2[k] = reinterpret_cast<const float4 *>(a2)[ii];
+            pr[k] = resid ? reinterpret_cast<const float4 *>(resid)[ii] : float4{0.f, 0.f, 0.f, 0.f};
+        }
         double acc = 0.0;
-        int p = g;
-        for (; p + 31 * groups < j1.n_partials; p += 32 * groups) {
-            double v[32];
 #pragma unroll
-            for (int q = 0; q < 32; ++q) v[q] = src[(int64_t)(p + q * groups) * two_f];
-#pragma unroll
-            for (int q = 0; q < 32; ++q) acc += v[q];
-        }
-        for (; p + 7 * groups < j1.n_partials; p += 8 * groups) {
-            double v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = src[(int64_t)(p + q * groups) * two_f];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) acc += v[q];
-        }
-        for (; p < j1.n_partials; p += groups) acc += src[(int64_t)p * two_f];
+        for (int q = 0; q < 32; ++q) acc += __builtin_bit_cast(double, v[q]);
         red[tid] = acc;
     }
     __syncthreads();
@@ -364,20 +373,26 @@ __global__ __launch_bounds__(1024) void merge_bn1_wide_kernel(const float *__res
     const float4 m2h = *reinterpret_cast<const float4 *>(st2s + col), m2l = *reinterpret_cast<const float4 *>(st2s + c + col);
     const float4 g2 = *reinterpret_cast<const float4 *>(st2s + 2 * c + col), b2 = *reinterpret_cast<const float4 *>(st2s + 3 * c + col);
     float am = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + tid; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        const float4 x1 = reinterpret_cast<const float4 *>(a1)[i];
-        const float4 x2 = reinterpret_cast<const float4 *>(a2)[i];
+    auto item = [&](const float4 &x1, const float4 &x2, const float4 &r, int64_t i) {
         float4 o;
         o.x = bn_apply1(x1.x, m1h.x, m1l.x, g1.x, b1.x) * bn_apply1(x2.x, m2h.x, m2l.x, g2.x, b2.x);
         o.y = bn_apply1(x1.y, m1h.y, m1l.y, g1.y, b1.y) * bn_apply1(x2.y, m2h.y, m2l.y, g2.y, b2.y);
         o.z = bn_apply1(x1.z, m1h.z, m1l.z, g1.z, b1.z) * bn_apply1(x2.z, m2h.z, m2l.z, g2.z, b2.z);
         o.w = bn_apply1(x1.w, m1h.w, m1l.w, g1.w, b1.w) * bn_apply1(x2.w, m2h.w, m2l.w, g2.w, b2.w);
-        if (resid) {
-            const float4 r = reinterpret_cast<const float4 *>(resid)[i];
-            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-        }
+        if (resid) { o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
         reinterpret_cast<float4 *>(out)[i] = o;
         am = absmax4(am, o);
+    };
+#pragma unroll
+    for (int k = 0; k < kPf; ++k) {
+        const int64_t i = i_first + k * i_step;
+        if (i < n4) item(px1[k], px2[k], pr[k], i);
+    }
+    for (int64_t i = i_first + kPf * i_step; i < n4; i += i_step) {
+        const float4 x1 = reinterpret_cast<const float4 *>(a1)[i];
+        const float4 x2 = reinterpret_cast<const float4 *>(a2)[i];
+        const float4 r = resid ? reinterpret_cast<const float4 *>(resid)[i] : float4{0.f, 0.f, 0.f, 0.f};
+        item(x1, x2, r, i);
     }
     absmax_flush(am, absmax_out);
 }
