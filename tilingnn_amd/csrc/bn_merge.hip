@@ -374,6 +374,9 @@ __global__ __launch_bounds__(1024) void merge_bn1_wide_kernel(const float *__res
     const float4 g2 = *reinterpret_cast<const float4 *>(st2s + 2 * c + col), b2 = *reinterpret_cast<const float4 *>(st2s + 3 * c + col);
     float am = 0.f;
     auto item = [&](const float4 &x1, const float4 &x2, const float4 &r, int64_t i) {
+        // (no contraction of the product with the residual add: with r in a register the compiler would fuse them into one
+        //  fma -- one rounding less than merge_kernel / the sharded step's merge, whose add sits behind a branch.  Same bits.)
+#pragma clang fp contract(off)
         float4 o;
         o.x = bn_apply1(x1.x, m1h.x, m1l.x, g1.x, b1.x) * bn_apply1(x2.x, m2h.x, m2l.x, g2.x, b2.x);
         o.y = bn_apply1(x1.y, m1h.y, m1l.y, g1.y, b1.y) * bn_apply1(x2.y, m2h.y, m2l.y, g2.y, b2.y);
