@@ -219,6 +219,90 @@ def test_mid_kernel_running_statistics_match_the_general_schedule(dev):
             assert int(sds[0][k]) == int(sds[1][k]) == 1, k
 
 
+@contextlib.contextmanager
+def mid_tail(on):
+    from tilingnn_amd import _lib
+    before = _lib.lib.tgnn_set_mid_tail(int(on))
+    try:
+        yield
+    finally:
+        _lib.lib.tgnn_set_mid_tail(before)
+
+
+def _forward_slots_maps(net, inputs, n, dev, out_dim, update_running=0):
+    """_forward_with_slots for any number of probability maps"""
+    from tilingnn_amd import _lib, ops
+    x, adj, adj_attr, col = inputs
+    graph = ops.prepare_graph(n, adj, adj_attr, col)
+    dims = net._dims()
+    table, _ = net._param_table()
+    ws_bytes = _lib.lib.tgnn_forward_workspace_bytes(C.byref(dims), n, graph.n_types)
+    ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
+    probs = torch.empty(n, out_dim, device=dev)
+    g = graph.c_struct()
+    _lib.check(_lib.lib.tgnn_forward(C.byref(dims), table, ops.ptr(x), ops.ptr(adj_attr), C.byref(g), update_running, 0,
+                                    ops.ptr(probs), ops.ptr(ws), ws_bytes, _lib.current_stream(dev), _lib.side_stream(dev)))
+    torch.cuda.synchronize()
+    d = net.network_depth
+    return probs.cpu(), ws[: (d + 1) * n * 32 * 4].view(torch.float32).view(d + 1, n, 32).clone().cpu()
+
+
+@pytest.mark.parametrize("n,depth,out_dim", [(4100, 20, 1), (10000, 20, 1), (16384, 20, 1), (7000, 6, 3), (9000, 8, 1), (12000, 23, 2)])
+def test_final_mlp_as_one_persistent_kernel_against_the_launch_per_layer_one_and_the_oracle(dev, n, depth, out_dim):
+    """csrc/forward_tail.hip (TilinGNN.py:74-76 behind the persistent layer loop): same skip buffer in, probabilities and the four
+    BatchNorms' running statistics against the general final MLP (fp16 pairs / bf16 x 3 there too: rounding only) and against the
+    float64 oracle's final MLP on the kernel's own skip buffer; K = 32 (depth + 1) below, at and above a multiple of the 8-step
+    chunk; 2 / 3 / 4 tiles per block; several probability maps; twelve runs bit-identical."""
+    from tilingnn_amd import TilinGNN, _lib
+    from tilingnn_amd.synth import make_super_graph
+    from tilingnn_amd.weights import make_state_dict
+    sg = make_super_graph(n, 10 * n, 12 * n, tile_count=2, n_edge_types=13, seed=depth)
+    inputs = sg.to_torch(dev)[:4]
+    sd = make_state_dict(15, depth, 32, out_dim, 3, seed=2)
+    res = {}
+    for tail in (0, 1):
+        net = TilinGNN(adj_edge_features_dim=15, network_depth=depth, network_width=32, output_dim=out_dim, node_features_dim=3)
+        net.load_state_dict(sd, strict=True)
+        net = net.to(dev).train()
+        with mid_limit(65536), mid_tail(tail):
+            c0 = _lib.forward_path_counts()
+            probs, slots = _forward_slots_maps(net, inputs, n, dev, out_dim, update_running=1)
+            assert _lib.forward_path_counts()[2] == c0[2] + 1
+            stats = {k: v.detach().cpu().double() for k, v in net.state_dict().items() if k.startswith("final_mlp")}
+            if tail:
+                for _ in range(11):
+                    again, _ = _forward_slots_maps(net, inputs, n, dev, out_dim)
+                    assert torch.equal(again, probs)
+        assert _spin_ok(dev) == 0
+        res[tail] = (probs.double(), slots, stats)
+    assert torch.equal(res[0][1], res[1][1])                     # the same skip buffer went into both
+    gap = float((res[0][0] - res[1][0]).abs().max())
+    with torch.no_grad():                                        # the oracle's final MLP on the kernel's own skip buffer (float64)
+        cat = torch.cat([res[1][1][k].double() for k in range(depth + 1)], dim=1)
+        want = orc.final_mlp(cat, orc.cast_sd(sd, torch.float64))
+    ogap = float((res[1][0] - want).abs().max())
+    print(f"n {n} depth {depth} maps {out_dim}: max |p_tail - p_general| {gap:.1e}, max |p_tail - p64(final MLP)| {ogap:.1e}")
+    assert ogap < 5e-6 and gap < 1e-5, (ogap, gap)
+    for k, v in res[0][2].items():
+        if "running" in k:
+            assert orc.rel_max_err(res[1][2][k], v) < 1e-5, k
+        elif k.endswith("num_batches_tracked"):
+            assert int(v) == int(res[1][2][k]) == 1, k
+
+
+def test_final_mlp_kernel_is_left_out_above_four_tiles_per_block(dev):
+    """From 16 385 nodes on (5 tiles per CU) the launch-per-layer final MLP runs behind the layer loop: bit-identical with the switch off."""
+    n = 20000
+    inputs, _ = _layout(n, dev, seed=2)
+    net, _ = make_net(dev, depth=3)
+    with mid_limit(65536):
+        with mid_tail(1):
+            p1, _ = _forward_with_slots(net, inputs, n, dev)
+        with mid_tail(0):
+            p0, _ = _forward_with_slots(net, inputs, n, dev)
+    assert torch.equal(p0, p1)
+
+
 @pytest.mark.parametrize("n", [2000, 8000])
 def test_a_starved_persistent_kernel_gives_up_and_the_module_falls_back(dev, n, debug_hooks):
     """Bounded spins (csrc/forward_persist.h).  A persistent kernel one of whose blocks never shows up -- what a kernel looks like

@@ -399,6 +399,9 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     // event (~12 us of cross-queue latency on a launch-bound forward) but on a counter of that kernel's finished blocks: the small
     // kernel's init MLP, the mid kernel's first collision layer run beside them
     // (the mid path's counter is a word of w.bounds that launch_forward_scales below zeroes anyway: no launch of its own)
+    // ... and the final MLP behind it as one more persistent kernel (forward_tail.hip) instead of 5 + 4 launches
+    int tail_blocks = 0;
+    const int tail_k = mid_k ? mid_tail_tiles_per_block(dims, n, &tail_blocks) : 0;
     const bool mid_counter = mid_k && mid_blocks + 16 <= device_cus() && s2 && weights_on_side;
     unsigned *weights_done = mid_counter ? w.bounds + 2 * D + 6 : (small_teams == 2 && s2 && weights_on_side) ? w.small_ctr + 16 : nullptr;
     if (weights_done && !mid_counter) TGNN_CHECK_HIP(hipMemsetAsync(weights_done, 0, 4, s));
@@ -428,7 +431,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         prof.end();
     }
     bool dimg_ok[3] = {false, false, false};
-    if (f16) {
+    if (f16 && !tail_k) {
         // the final MLP's layers 1 and 2 (256 -> 128 -> 64): weights' bounds and, from the BatchNorm parameters alone, their inputs'
         const float *bw[2], *bg[2], *bb[2];
         int64_t bwn[2];
@@ -451,7 +454,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     }
     if (small_teams) launch_small_pack(P, D, w.small_pack, w.small_ctr, s);   // on the main stream: it has nothing else to do yet
     // (parameter vectors + GIN images of the layers; the same launch clears the barrier counter and the tagged partial rows)
-    if (mid_k) launch_small_pack(P, D, w.small_pack, w.small_ctr, s, false, w.mid_part, mid_part_doubles() * sizeof(double));
+    if (mid_k) launch_small_pack(P, D, w.small_pack, w.small_ctr, s, tail_k > 0, w.mid_part, mid_part_doubles() * sizeof(double), tail_k > 0 ? dense_max : nullptr);
     if (sw != s) TGNN_CHECK_HIP(hipEventRecord(ev[kEvWeights], s2));
     g_path_count[small_teams ? 1 : mid_k ? 2 : 0].fetch_add(1, std::memory_order_relaxed);
     if (small_teams) {
@@ -527,12 +530,18 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         return TGNN_OK;
     };
     if (mid_k) {
+        double *const tail_zero[2] = {w.partf, w.small_part_wide};   // the tail kernel's tagged rows: cleared by the layer loop's blocks
         if (sw != s && !weights_done) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[kEvWeights], 0));   // (the images of the side stream)
         TGNN_TRY(launch_forward_mid(dims, P, w.mid, w.a1, w.a2[0], w.a2[1], w.wimg, w.small_pack, graph, w.mid_part, w.small_runstat,
                                     w.small_ctr, w.bounds, n, mid_k, mid_blocks, update_running, eps, momentum, s, weights_done,
-                                    (unsigned)((T + 1) * D)));
+                                    (unsigned)((T + 1) * D), tail_k ? tail_zero : nullptr, mid_tail_part_doubles()));
         // (the final MLP reads the side stream's bounds and operand images: behind the layer loop, where the wait costs nothing)
         if (sw != s && weights_done) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[kEvWeights], 0));
+        if (tail_k) {
+            TGNN_TRY(launch_forward_tail(dims, P, w.mid, w.small_pack, probs, w.partf, w.small_part_wide, slot_max, dense_max, n, tail_k,
+                                         tail_blocks, update_running, eps, momentum, s));
+            return TGNN_OK;
+        }
     } else if (s2) {
         TGNN_CHECK_HIP(hipEventRecord(ev[0], s));            // middle[0] is complete
         TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[0], 0));

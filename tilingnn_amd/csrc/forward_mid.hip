@@ -76,6 +76,8 @@ struct MidArgs {
     double *part, *gpart;        // [2][blocks][128] tagged partial rows / group sums (zeroed before the launch)
     double *runstat;             // [depth][128] parked batch statistics for the running buffers
     unsigned *ctr;               // barrier counter (zero before the launch)
+    double *tail_zero[2];        // NULL, or: the tagged rows of the final MLP's kernel behind this one (forward_tail.hip), cleared here
+    unsigned tail_zero_vec;      // ... 16-byte pieces of each
     unsigned *bounds;            // [0, depth]: max |slot k| as float bits (this kernel fills 1 ..); [depth + 1 ..]: max |root_i|
     unsigned *err, *err_host;    // the device's spin-error word and its host-mapped mirror (forward_persist.h)
     unsigned long long spin_budget;
@@ -355,6 +357,9 @@ __global__ __launch_bounds__(kMidThreads) void forward_layers_mid_kernel(MidArgs
     };
 
     // ---- prologue: images of layer 0, the batches of one-tile waves, the zeroed tiles; then GIN_0 (reads slot 0, no statistics)
+    if (A.tail_zero[0])
+        for (unsigned i = blockIdx.x * kMidThreads + tid; i < 2u * A.tail_zero_vec; i += gridDim.x * kMidThreads)
+            reinterpret_cast<u32x4 *>(A.tail_zero[i >= A.tail_zero_vec])[i >= A.tail_zero_vec ? i - A.tail_zero_vec : i] = u32x4{0u, 0u, 0u, 0u};
     if (!A.weights_done) mid_dma(A.wimg, wl, (T + 1) * kWtTypeF16 * 4, wave, lane);
     mid_dma(A.pack + kSpGinW, gw, kSpGinFrags * 16, wave, lane);
     for (int i = lane; i < kMidTileFloats / 4; i += 64) reinterpret_cast<f32x4 *>(tbuf)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -679,11 +684,14 @@ size_t mid_part_doubles() { return (size_t)2 * 2 * 256 * 128; }   // part + gpar
 int launch_forward_mid(const tgnn_model_dims *d, const Params &P, float *mid, float *a1, float *a2_0, float *a2_1, const float *wimg,
                        const float *pack, const tgnn_graph *graph, double *part, double *runstat, unsigned *ctr, unsigned *bounds,
                        int64_t n, int tiles_per_block, int blocks, int update_running, float eps, float momentum, hipStream_t s,
-                       const unsigned *weights_done, unsigned weights_target) {
+                       const unsigned *weights_done, unsigned weights_target, double *const *tail_zero, size_t tail_zero_doubles) {
     const int depth = d->network_depth;
     MidArgs A{};
     A.weights_done = weights_done;
     A.weights_target = weights_target;
+    A.tail_zero[0] = tail_zero ? tail_zero[0] : nullptr;
+    A.tail_zero[1] = tail_zero ? tail_zero[1] : nullptr;
+    A.tail_zero_vec = (unsigned)(tail_zero_doubles / 2);
     A.mid = mid;
     A.a1 = a1;
     A.a2[0] = a2_0;

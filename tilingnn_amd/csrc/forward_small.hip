@@ -49,6 +49,7 @@ struct SmallImageJob {
     const float *w;              // [m][k] row-major (torch Linear.weight)
     float *img;
     int m, k;                    // multiples of 16 / 32
+    const unsigned *f16_max;     // NULL: bf16 x 3 planes; else fp16 pairs of w * pow2_scale_for(*f16_max) (forward_tail.hip, layer 0)
 };
 struct SmallImageJobs {
     SmallImageJob j[5];
@@ -71,6 +72,11 @@ __global__ __launch_bounds__(256) void small_pack_kernel(SmallPackLayers layers,
             const float4 *src = reinterpret_cast<const float4 *>(J.w + (size_t)(16 * mb + i) * J.k + 32 * ks + 8 * q);
             const float4 a = src[0], b = src[1];
             const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            if (J.f16_max) {
+                tgnn_f16x8 *dst = reinterpret_cast<tgnn_f16x8 *>(J.img) + (size_t)blk * 2 * 64 + lane;
+                split2_f16(x, pow2_scale_for(*J.f16_max, 0), dst[0], dst[64]);
+                continue;
+            }
             bf16x8 *dst = reinterpret_cast<bf16x8 *>(J.img) + (size_t)blk * 3 * 64 + lane;
             split3_trunc(x, dst[0], dst[64], dst[128]);
         }
@@ -1141,6 +1147,12 @@ static size_t small_image_floats(int depth, size_t (&off)[5]) {
     }
     return at;
 }
+// image k (0: init Linear 1; 1 .. 4: the final MLP's Linears) inside a pack built with dense_images
+const float *small_dense_image(const float *pack, int depth, int k) {
+    size_t off[5];
+    small_image_floats(depth, off);
+    return pack + (size_t)depth * kSpStride + off[k];
+}
 size_t small_pack_floats(int depth) {
     size_t off[5];
     return (size_t)depth * kSpStride + small_image_floats(depth, off);
@@ -1149,16 +1161,16 @@ size_t small_pack_floats(int depth) {
 // Per-forward pre-pass (side stream): parameter packs + GIN images of the layers, MFMA images of the dense layers; re-arms
 // the barrier counter
 void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrier_ctr, hipStream_t s, bool dense_images, void *zero,
-                       size_t zero_bytes) {
+                       size_t zero_bytes, const unsigned *fin0_f16_max) {
     size_t off[5];
     small_image_floats(depth, off);
     float *img = pack + (size_t)depth * kSpStride;
     SmallImageJobs J{};
-    J.j[0] = SmallImageJob{P.f(P.init(1)), img + off[0], 32, 32};
-    J.j[1] = SmallImageJob{P.f(P.fin(0)), img + off[1], 256, 32 * (depth + 1)};
-    J.j[2] = SmallImageJob{P.f(P.fin(1)), img + off[2], 128, 256};
-    J.j[3] = SmallImageJob{P.f(P.fin(2)), img + off[3], 64, 128};
-    J.j[4] = SmallImageJob{P.f(P.fin(3)), img + off[4], 32, 64};
+    J.j[0] = SmallImageJob{P.f(P.init(1)), img + off[0], 32, 32, nullptr};
+    J.j[1] = SmallImageJob{P.f(P.fin(0)), img + off[1], 256, 32 * (depth + 1), fin0_f16_max};
+    J.j[2] = SmallImageJob{P.f(P.fin(1)), img + off[2], 128, 256, nullptr};
+    J.j[3] = SmallImageJob{P.f(P.fin(2)), img + off[3], 64, 128, nullptr};
+    J.j[4] = SmallImageJob{P.f(P.fin(3)), img + off[4], 32, 64, nullptr};
     for (int lo = 0; lo < depth; lo += kSmallPackChunk) {
         const int nl = depth - lo < kSmallPackChunk ? depth - lo : kSmallPackChunk;
         SmallPackLayers L{};

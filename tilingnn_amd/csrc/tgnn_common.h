@@ -457,8 +457,9 @@ int spin_kernel_chain(hipStream_t s, void (*launch)(void *ctx, hipStream_t s), v
 int small_layout_teams(const tgnn_model_dims *d, int64_t n_nodes, int n_types, int max_in_degree);
 size_t small_pack_floats(int depth);
 // zero / zero_bytes (a multiple of 16): memory the same launch clears (the mid-size kernel's tagged partial rows)
+// fin0_f16_max: the final MLP's first Linear as an fp16-pair image scaled by pow2_scale_for(*fin0_f16_max) (forward_tail.hip)
 void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrier_ctr, hipStream_t s, bool dense_images = true,
-                       void *zero = nullptr, size_t zero_bytes = 0);
+                       void *zero = nullptr, size_t zero_bytes = 0, const unsigned *fin0_f16_max = nullptr);
 int launch_forward_small(const tgnn_model_dims *d, const Params &P, const float *x, float *probs, float *mid, float *a2_0,
                          float *a2_1, const float *wimg, float *pack, const tgnn_graph *graph, double *part, double *part_wide,
                          double *runstat, unsigned *ctr, const unsigned *weights_done, unsigned weights_target, int64_t n,
@@ -471,7 +472,17 @@ size_t mid_part_doubles();
 int launch_forward_mid(const tgnn_model_dims *d, const Params &P, float *mid, float *a1, float *a2_0, float *a2_1, const float *wimg,
                        const float *pack, const tgnn_graph *graph, double *part, double *runstat, unsigned *ctr, unsigned *bounds,
                        int64_t n, int tiles_per_block, int blocks, int update_running, float eps, float momentum, hipStream_t s,
-                       const unsigned *weights_done = nullptr, unsigned weights_target = 0);
+                       const unsigned *weights_done = nullptr, unsigned weights_target = 0, double *const *tail_zero = nullptr,
+                       size_t tail_zero_doubles = 0);
+// ... and the final MLP behind it as one persistent kernel too (forward_tail.hip): 0 = not eligible / switched off
+// (tgnn_set_mid_tail); needs a pack built with dense_images; part / gpart: mid_tail_part_doubles() doubles each, ZEROED by
+// the layer loop's kernel in front of it (launch_forward_mid: tail_zero)
+int mid_tail_tiles_per_block(const tgnn_model_dims *d, int64_t n_nodes, int *blocks_out);
+size_t mid_tail_part_doubles();
+const float *small_dense_image(const float *pack, int depth, int k);
+int launch_forward_tail(const tgnn_model_dims *d, const Params &P, const float *mid, const float *pack, float *probs, double *part,
+                        double *gpart, const unsigned *slot_max, const unsigned *w0_max, int64_t n, int tiles_per_block, int blocks,
+                        int update_running, float eps, float momentum, hipStream_t s);
 // MFMA weight image of the column NNConv, per type: [plane 3 (hi, mid, lo)][M block 2][g 4][i 16] x 8 bf16 --
 // the A fragment of lane 16 g + i for one (plane, M block) is one 16-byte read, a wavefront reads 1 KB in lane order
 // (conflict-free: SQ_LDS_BANK_CONFLICT 2.3e6 -> 2.3e5 per launch against the [i][g] order of round 1); 6144 B per type
