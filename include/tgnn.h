@@ -463,10 +463,12 @@ int32_t tgnn_set_gin_fused(int32_t mode);
  * (three matrix terms; their inputs are sigmoids), 16 waves per block (csrc/gin.hip: gin32_mlp16_kernel); 0 (default: the
  * forward measured no faster with it, csrc/gin.hip) = the bf16 x 3 kernel the training forward and tgnn_gin_fwd run.  Returns the previous setting. */
 int32_t tgnn_set_gin_mlp_f16(int32_t on);
-/* Mid-size layouts (4 097 .. tgnn_get_mid_layout_limit() nodes; reference: graph_networks/networks/TilinGNN.py:74-76): the final
- * MLP behind the persistent layer loop as one persistent kernel of its own (csrc/forward_tail.hip: bf16 x 3 operands, BatchNorm
- * statistics all-reduced over the grid) instead of 5 Linear + 4 bn_finalize launches: 1 (default) on, 0 off.  Returns the
- * previous setting (any other argument: only queries). */
+/* Mid-size layouts (4 097 .. tgnn_get_mid_layout_limit() nodes): the two ends of the network inside the persistent kernels
+ * instead of launch-per-layer (reference: graph_networks/networks/TilinGNN.py:54 and :74-76).  Bit 0: the final MLP behind the
+ * persistent layer loop as one persistent kernel of its own (csrc/forward_tail.hip; layouts of up to 16 384 nodes) instead of 5
+ * Linear + 4 bn_finalize launches; bit 1: the init MLP in the layer loop's prologue (csrc/forward_mid.hip; node_features_dim <= 8)
+ * instead of 5 launches in front of it.  BatchNorm statistics are all-reduced over the grid in a fixed order (bit-reproducible).
+ * Default 3; returns the previous setting (an argument outside 0 .. 3 only queries). */
 int32_t tgnn_set_mid_tail(int32_t on);
 
 /* Small layouts (<= tgnn_graph_prep_small_max_nodes() nodes, <= ..._max_edges() edges per set): everything above --

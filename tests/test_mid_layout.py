@@ -135,7 +135,9 @@ def test_mid_kernel_against_the_general_schedule_layer_by_layer(dev, n):
     c2 = _lib.forward_path_counts()
     assert (c1[0] - c0[0], c1[2] - c0[2]) == (1, 0) and (c2[0] - c1[0], c2[2] - c1[2]) == (0, 1)   # it IS another path
     assert _spin_ok(dev) == 0
-    assert torch.equal(s_mid[0], s_gen[0])                      # the init MLP is the general schedule's
+    e0 = orc.rel_max_err(s_mid[0], s_gen[0].double())
+    print(f"n {n} slot 0: {e0:.2e}")
+    assert e0 < slot_tol(0)                                    # (the init MLP may run in the kernel's prologue: rounding only)
     for k in range(1, 4):
         err = orc.rel_max_err(s_mid[k], s_gen[k].double())
         print(f"n {n} slot {k}: {err:.2e}")
@@ -288,6 +290,45 @@ def test_final_mlp_as_one_persistent_kernel_against_the_launch_per_layer_one_and
             assert orc.rel_max_err(res[1][2][k], v) < 1e-5, k
         elif k.endswith("num_batches_tracked"):
             assert int(v) == int(res[1][2][k]) == 1, k
+
+
+@pytest.mark.parametrize("n,tile_count", [(4100, 1), (10000, 2), (20000, 4), (50000, 2)])
+def test_init_mlp_in_the_layer_loops_prologue_against_the_launches_and_the_oracle(dev, n, tile_count):
+    """TilinGNN.py:54 inside forward_layers_mid_kernel (2, 4, 8 and 16 tiles per block: every way the waves share them; node features
+    of 2, 3 and 5 columns): slot 0 against the five launches it replaces and against the float64 oracle, the two BatchNorms' running
+    statistics, and what the rest of the network makes of it."""
+    from tilingnn_amd import TilinGNN, _lib
+    from tilingnn_amd.synth import make_super_graph
+    from tilingnn_amd.weights import make_state_dict
+    depth = 3
+    sg = make_super_graph(n, 10 * n, 12 * n, tile_count=tile_count, n_edge_types=13, seed=4)
+    inputs = sg.to_torch(dev)[:4]
+    fx = int(inputs[0].shape[1])
+    sd = make_state_dict(15, depth, 32, 1, fx, seed=6)
+    res = {}
+    for mode in (1, 3):
+        net = TilinGNN(adj_edge_features_dim=15, network_depth=depth, network_width=32, output_dim=1, node_features_dim=fx)
+        net.load_state_dict(sd, strict=True)
+        net = net.to(dev).train()
+        with mid_limit(65536), mid_tail(mode):
+            c0 = _lib.forward_path_counts()
+            probs, slots = _forward_slots_maps(net, inputs, n, dev, 1, update_running=1)
+            assert _lib.forward_path_counts()[2] == c0[2] + 1
+        assert _spin_ok(dev) == 0
+        res[mode] = (probs.double(), slots, {k: v.detach().cpu().double() for k, v in net.state_dict().items() if k.startswith("init_node")})
+    with torch.no_grad():
+        want0 = orc.init_node_feature_trans(inputs[0].detach().cpu().double(), orc.cast_sd(sd, torch.float64))
+    e_launch = orc.rel_max_err(res[3][1][0], res[1][1][0].double())
+    e_oracle = orc.rel_max_err(res[3][1][0], want0)
+    print(f"n {n} fx {fx}: slot 0 against the launches {e_launch:.1e}, against the oracle {e_oracle:.1e}; "
+          f"max |p - p_launches| {float((res[3][0] - res[1][0]).abs().max()):.1e}")
+    assert e_launch < slot_tol(0) and e_oracle < slot_tol(0), (e_launch, e_oracle)
+    assert float((res[3][0] - res[1][0]).abs().max()) < 1e-4
+    for k, v in res[1][2].items():
+        if "running" in k:
+            assert orc.rel_max_err(res[3][2][k], v) < 1e-5, k
+        elif k.endswith("num_batches_tracked"):
+            assert int(v) == int(res[3][2][k]) == 1, k
 
 
 def test_final_mlp_kernel_is_left_out_above_four_tiles_per_block(dev):

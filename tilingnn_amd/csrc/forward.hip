@@ -403,8 +403,13 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     int tail_blocks = 0;
     const int tail_k = mid_k ? mid_tail_tiles_per_block(dims, n, &tail_blocks) : 0;
     const bool mid_counter = mid_k && mid_blocks + 16 <= device_cus() && s2 && weights_on_side;
+    // the init MLP in that kernel's prologue instead of 5 launches -- where the kernel starts beside the edge-weight kernel (with
+    // a block on every CU it starts BEHIND it, a cross-queue event later, and the launches, which run beside it, win: measured at
+    // 16 384 and 32 768 nodes, profiles/r05_mid_tail.txt)
+    const bool mid_init = mid_counter && mid_init_in_kernel() && fx <= 8;
     unsigned *weights_done = mid_counter ? w.bounds + 2 * D + 6 : (small_teams == 2 && s2 && weights_on_side) ? w.small_ctr + 16 : nullptr;
     if (weights_done && !mid_counter) TGNN_CHECK_HIP(hipMemsetAsync(weights_done, 0, 4, s));
+    const unsigned weights_target = edge_weight_table_blocks(T, fe, D, c, tiled);
     if (f16) {
         const float *roots[kMaxDepth];
         for (int i = 0; i < D; ++i) roots[i] = P.f(P.layer(i) + 6);
@@ -454,33 +459,36 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     }
     if (small_teams) launch_small_pack(P, D, w.small_pack, w.small_ctr, s);   // on the main stream: it has nothing else to do yet
     // (parameter vectors + GIN images of the layers; the same launch clears the barrier counter and the tagged partial rows)
-    if (mid_k) launch_small_pack(P, D, w.small_pack, w.small_ctr, s, tail_k > 0, w.mid_part, mid_part_doubles() * sizeof(double), tail_k > 0 ? dense_max : nullptr);
+    if (mid_k) launch_small_pack(P, D, w.small_pack, w.small_ctr, s, tail_k > 0 || mid_init, w.mid_part, mid_part_doubles() * sizeof(double), tail_k > 0 ? dense_max : nullptr,
+                                 sw != s ? sw : nullptr);   // (the final MLP's images: side stream, joined behind the layer loop)
     if (sw != s) TGNN_CHECK_HIP(hipEventRecord(ev[kEvWeights], s2));
     g_path_count[small_teams ? 1 : mid_k ? 2 : 0].fetch_add(1, std::memory_order_relaxed);
     if (small_teams) {
         // init MLP, the layers and the final MLP: one persistent kernel behind the pre-pass
         if (sw != s && !weights_done) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[kEvWeights], 0));
         TGNN_TRY(launch_forward_small(dims, P, x, probs, w.mid, w.a2[0], w.a2[1], w.wimg, w.small_pack, graph, w.small_part,
-                                      w.small_part_wide, w.small_runstat, w.small_ctr, weights_done, (unsigned)((T + 1) * D), n,
+                                      w.small_part_wide, w.small_runstat, w.small_ctr, weights_done, weights_target, n,
                                       update_running, eps, momentum, s));
         TGNN_CHECK_LAUNCH();
         return TGNN_OK;
     }
 
     // ---- K10: init MLP  (TilinGNN.py:54)
-    prof.begin(1);
-    TGNN_TRY(tgnn_dense_act_fwd(x, fx, 32, nullptr, P.f(P.init(0)), P.f(P.init(0) + 1), n, fx, c, TGNN_ACT_LEAKY_RELU,
-                                w.t0, c, w.partf, &np1, s));
-    prof.end();
-    TGNN_TRY(finalize1(w.partf, np1, c, P.bn(P.init(0) + 2), w.stat_i[0]));
-    prof.begin(1);
-    TGNN_TRY(tgnn_dense_act_fwd(w.t0, c, 32, w.stat_i[0], P.f(P.init(1)), P.f(P.init(1) + 1), n, c, c,
-                                TGNN_ACT_LEAKY_RELU, w.a1, c, w.partf, &np1, s));
-    prof.end();
-    TGNN_TRY(finalize1(w.partf, np1, c, P.bn(P.init(1) + 2), w.stat_i[1]));
-    prof.begin(1);
-    launch_bn_apply(w.a1, c, w.stat_i[1], n, c, w.mid, c, slot_max, s);   // middle[0] = brch_1 = brch_2 (:55,58)
-    prof.end();
+    if (!mid_init) {
+        prof.begin(1);
+        TGNN_TRY(tgnn_dense_act_fwd(x, fx, 32, nullptr, P.f(P.init(0)), P.f(P.init(0) + 1), n, fx, c, TGNN_ACT_LEAKY_RELU,
+                                    w.t0, c, w.partf, &np1, s));
+        prof.end();
+        TGNN_TRY(finalize1(w.partf, np1, c, P.bn(P.init(0) + 2), w.stat_i[0]));
+        prof.begin(1);
+        TGNN_TRY(tgnn_dense_act_fwd(w.t0, c, 32, w.stat_i[0], P.f(P.init(1)), P.f(P.init(1) + 1), n, c, c,
+                                    TGNN_ACT_LEAKY_RELU, w.a1, c, w.partf, &np1, s));
+        prof.end();
+        TGNN_TRY(finalize1(w.partf, np1, c, P.bn(P.init(1) + 2), w.stat_i[1]));
+        prof.begin(1);
+        launch_bn_apply(w.a1, c, w.stat_i[1], n, c, w.mid, c, slot_max, s);   // middle[0] = brch_1 = brch_2 (:55,58)
+        prof.end();
+    }
     TGNN_TRY(exchange(0, nullptr, nullptr));
     if (f16 && n_halo > 0) launch_absmax(w.mid + (size_t)n * c, n_halo * c, slot_max, s);   // (the halo rows of middle[0])
 
@@ -534,7 +542,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         if (sw != s && !weights_done) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[kEvWeights], 0));   // (the images of the side stream)
         TGNN_TRY(launch_forward_mid(dims, P, w.mid, w.a1, w.a2[0], w.a2[1], w.wimg, w.small_pack, graph, w.mid_part, w.small_runstat,
                                     w.small_ctr, w.bounds, n, mid_k, mid_blocks, update_running, eps, momentum, s, weights_done,
-                                    (unsigned)((T + 1) * D), tail_k ? tail_zero : nullptr, mid_tail_part_doubles()));
+                                    weights_target, tail_k ? tail_zero : nullptr, mid_tail_part_doubles(), mid_init ? x : nullptr));
         // (the final MLP reads the side stream's bounds and operand images: behind the layer loop, where the wait costs nothing)
         if (sw != s && weights_done) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[kEvWeights], 0));
         if (tail_k) {

@@ -57,8 +57,10 @@ constexpr int kMidColFirst = 1 << 8;
 // [16 + w] wave w's time inside its NNConv items, [32 + w] inside its GIN items
 __device__ unsigned long long g_mid_timing[256 * 64];
 #define TGNN_MT(slot) { const unsigned long long now_ = wall_clock64(); if (tid == 0) tacc[slot] += now_ - tlast; tlast = now_; }
+#define TGNN_MI(slot) if (tid == 0 && blockIdx.x < 256) g_mid_timing[blockIdx.x * 64 + 48 + (slot)] = wall_clock64();
 #else
 #define TGNN_MT(slot)
+#define TGNN_MI(slot)
 #endif
 
 struct MidArgs {
@@ -76,6 +78,13 @@ struct MidArgs {
     double *part, *gpart;        // [2][blocks][128] tagged partial rows / group sums (zeroed before the launch)
     double *runstat;             // [depth][128] parked batch statistics for the running buffers
     unsigned *ctr;               // barrier counter (zero before the launch)
+    // the init MLP (TilinGNN.py:54) in this kernel's prologue (x != NULL), else slot 0 arrives filled by the launches in front
+    const float *x;              // node features [n][fx], fx <= 8
+    const float *iw0, *ib0, *ig0, *ibt0;        // Linear 0 [32][fx], bias; BatchNorm 0 weight, bias
+    const float *i1img, *ib1, *ig1, *ibt1;      // Linear 1 as a bf16 x 3 MFMA image [2][1][3][64] x 16 B (small_pack_kernel), bias; BatchNorm 1
+    float *irm0, *irv0, *irm1, *irv1;           // running buffers (update_running)
+    int64_t *inbt0, *inbt1;
+    int fx;
     double *tail_zero[2];        // NULL, or: the tagged rows of the final MLP's kernel behind this one (forward_tail.hip), cleared here
     unsigned tail_zero_vec;      // ... 16-byte pieces of each
     unsigned *bounds;            // [0, depth]: max |slot k| as float bits (this kernel fills 1 ..); [depth + 1 ..]: max |root_i|
@@ -269,6 +278,66 @@ __device__ __forceinline__ void mid_nnconv_finish(const MidNn &N, const MidArgs 
 
 // global -> LDS by DMA: `bytes` (a multiple of 1 KB) starting at src, shared out round the block's waves; 1 KB per wave-level
 // instruction, no register in between
+// Grid all-reduce of ONE BatchNorm's 64 column sums outside the layer loop (the init MLP in the prologue): the layer loop's scheme --
+// tagged rows, two levels of 16, fixed order -- on the rows of parity `par` with a tag the layers never use.  bn: lane = (channel
+// lane & 31, sum | sum of squares) of this wave; the totals land in tot [0, 64).  (red aliases the waves' tiles.)
+constexpr unsigned kMidTagInit = 3u;
+__device__ __forceinline__ void mid_allreduce_init(double *part, double *gpart, double bn, int par, double *bnred, double *red, double *tot,
+                                                   SpinCtx &spin, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const unsigned nblk = gridDim.x, blk = blockIdx.x;
+    bnred[wave * 128 + lane] = bn;
+    bnred[wave * 128 + 64 + lane] = 0.0;
+    __syncthreads();
+    const size_t po = (size_t)par * nblk * 128;
+    const __amdgpu_buffer_rsrc_t p_rs = rsrc_of(part + po), g_rs = rsrc_of(gpart + po);
+    if (tid < 128) {
+        double blocksum = 0.0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) blocksum += bnred[w * 128 + tid];
+        __builtin_amdgcn_raw_buffer_store_b64(mid_tag(blocksum, kMidTagInit), p_rs, (blk * 128u + (uint32_t)tid) * 8u, 0, kCpSc1);
+    }
+    __syncthreads();
+    const int jp = tid & 63, r = tid >> 6;
+    const unsigned gbase = blk & ~15u;
+    double x0, x1, y0, y1;
+    mid_poll_pair(p_rs, gbase + r < nblk ? (int64_t)(gbase + r) : -1, jp, kMidTagInit, x0, x1, spin);
+    mid_poll_pair(p_rs, gbase + r + 8 < nblk ? (int64_t)(gbase + r + 8) : -1, jp, kMidTagInit, y0, y1, spin);
+    red[r * 128 + 2 * jp] = x0;
+    red[r * 128 + 2 * jp + 1] = x1;
+    red[(r + 8) * 128 + 2 * jp] = y0;
+    red[(r + 8) * 128 + 2 * jp + 1] = y1;
+    __syncthreads();
+    if (tid < 128) {
+        double s = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) s += red[rr * 128 + tid];
+        __builtin_amdgcn_raw_buffer_store_b64(mid_tag(s, kMidTagInit), g_rs, (blk * 128u + (uint32_t)tid) * 8u, 0, kCpSc1);
+    }
+    const unsigned n_groups = (nblk + 15u) >> 4;
+    auto group_row = [&](unsigned g) -> int64_t {
+        if (g >= n_groups) return -1;
+        const unsigned gsize = nblk - 16u * g < 16u ? nblk - 16u * g : 16u;
+        const unsigned member = (blk & 15u) < gsize ? (blk & 15u) : gsize - 1u;
+        return (int64_t)(16u * g + member);
+    };
+    mid_poll_pair(g_rs, group_row((unsigned)r), jp, kMidTagInit, x0, x1, spin);
+    mid_poll_pair(g_rs, group_row((unsigned)r + 8u), jp, kMidTagInit, y0, y1, spin);
+    __syncthreads();                                              // (level 1's sums have been read)
+    red[r * 128 + 2 * jp] = x0;
+    red[r * 128 + 2 * jp + 1] = x1;
+    red[(r + 8) * 128 + 2 * jp] = y0;
+    red[(r + 8) * 128 + 2 * jp + 1] = y1;
+    __syncthreads();
+    if (tid < 128) {
+        double s = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) s += red[rr * 128 + tid];
+        tot[tid] = s;
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ void mid_dma(const float *src, float *dst_lds, int bytes, int wave, int lane) {
     const int chunks = bytes >> 10;
     for (int c = wave; c < chunks; c += kMidWaves)
@@ -360,6 +429,173 @@ __global__ __launch_bounds__(kMidThreads) void forward_layers_mid_kernel(MidArgs
     if (A.tail_zero[0])
         for (unsigned i = blockIdx.x * kMidThreads + tid; i < 2u * A.tail_zero_vec; i += gridDim.x * kMidThreads)
             reinterpret_cast<u32x4 *>(A.tail_zero[i >= A.tail_zero_vec])[i >= A.tail_zero_vec ? i - A.tail_zero_vec : i] = u32x4{0u, 0u, 0u, 0u};
+    if (A.x) {
+        // =========================================== init MLP (TilinGNN.py:54) ===========================================
+        // Linear(fx, 32) + LeakyReLU + BatchNorm, Linear(32, 32) + LeakyReLU + BatchNorm -> slot 0, own rows: 5 launches of the
+        // general schedule (47 us in front of this kernel at 10 000 nodes: profiles/r05_mid_trace_10000.txt) as two grid all-reduces
+        // and a barrier.  A wave's tiles are those it owns in the layer loop (W > 1: the first wave of a tile's shares); lane
+        // (fj, fq) computes channels 8 fq .. + 7 of row fj of Linear 0 -- which IS its piece of Linear 1's matrix operand.
+        constexpr int kInitTiles = kMidMaxTilesPerBlock / kMidWaves;
+        const int fj = lane & 15, fq = lane >> 4, ch = lane & 31;
+        const bool sq = lane >= 32;
+        int64_t itile[kInitTiles];
+        bool iok[kInitTiles];
+#pragma unroll
+        for (int u = 0; u < kInitTiles; ++u) {
+            const int k = W == 1 ? wave + kMidWaves * u : (u == 0 && my_part == 0 ? my_k : K);
+            iok[u] = k < kb;
+            itile[u] = tile0 + k;
+        }
+        TGNN_MI(0)
+        float a0[kInitTiles][8];
+        double bn = 0.0;
+#pragma unroll
+        for (int u = 0; u < kInitTiles; ++u) {
+            if (!iok[u]) continue;                                // (uniform per wave)
+            const int64_t row = itile[u] * 16 + fj;
+            float xin[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xin[k] = (k < A.fx && row < n) ? A.x[row * A.fx + k] : 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float acc = A.ib0[8 * fq + c];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k < A.fx) acc = fmaf(xin[k], A.iw0[(8 * fq + c) * A.fx + k], acc);
+                a0[u][c] = leakyf_(acc);
+            }
+            // column sums over the tile's valid rows, through the wave's tile: lane = (channel, sum | sum of squares)
+            *reinterpret_cast<f32x4 *>(tbuf + mid_chunk(fj, 2 * fq)) = f32x4{a0[u][0], a0[u][1], a0[u][2], a0[u][3]};
+            *reinterpret_cast<f32x4 *>(tbuf + mid_chunk(fj, 2 * fq + 1)) = f32x4{a0[u][4], a0[u][5], a0[u][6], a0[u][7]};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int r = 0; r < 16; ++r)
+                if (itile[u] * 16 + r < n) {
+                    const double v = (double)tbuf[r * kMidRowFloats + ch];
+                    bn += sq ? v * v : v;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        auto init_record = [&](const float *gamma, const float *beta, float *rm, float *rv, int64_t *nbt) {
+            if (tid < 32) {
+                const double inv_n = 1.0 / (double)n;
+                const double mean = tot[tid] * inv_n;
+                double var = tot[32 + tid] * inv_n - mean * mean;
+                if (var < 0.0) var = 0.0;
+                const float mh = (float)mean;
+                st[tid] = mh;
+                st[32 + tid] = (float)(mean - (double)mh);
+                st[64 + tid] = (float)((double)gamma[tid] / sqrt(var + (double)A.eps));
+                st[96 + tid] = beta[tid];
+                if (blk == 0 && A.update_running && __hip_atomic_load(A.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    const double unbiased = n > 1 ? var * ((double)n / (double)(n - 1)) : var;
+                    rm[tid] = (float)((1.0 - (double)A.momentum) * (double)rm[tid] + (double)A.momentum * mean);
+                    rv[tid] = (float)((1.0 - (double)A.momentum) * (double)rv[tid] + (double)A.momentum * unbiased);
+                    if (tid == 0) *nbt += 1;
+                }
+            }
+            __syncthreads();
+        };
+        TGNN_MI(1)
+        mid_allreduce_init(A.part, A.gpart, bn, 0, bnred, red, tot, spin, tid);
+        TGNN_MI(2)
+        init_record(A.ig0, A.ibt0, A.irm0, A.irv0, A.inbt0);
+        TGNN_MI(3)
+        // Linear 1 on the matrix pipe, bf16 x 3 (small_tile_dense's order): D^T = W . X^T, X = BatchNorm 0 of the lane's own piece
+        f32x4 a1v[kInitTiles][2];
+        {
+            const bf16x8 *wi = reinterpret_cast<const bf16x8 *>(A.i1img) + lane;
+            bf16x8 wf[2][3];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wf[mb][pl] = wi[(mb * 3 + pl) * 64];
+            bn = 0.0;
+#pragma unroll
+            for (int u = 0; u < kInitTiles; ++u) {
+                if (!iok[u]) continue;
+                const bool row_ok = itile[u] * 16 + fj < n;
+                float xs[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    xs[e] = row_ok ? bn_apply1(a0[u][e], st[8 * fq + e], st[32 + 8 * fq + e], st[64 + 8 * fq + e], st[96 + 8 * fq + e]) : 0.f;
+                bf16x8 x3[3];
+                split3_trunc(xs, x3[0], x3[1], x3[2]);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const float4 b = *reinterpret_cast<const float4 *>(A.ib1 + 16 * mb + 4 * fq);
+                    f32x4 acc = f32x4{b.x, b.y, b.z, b.w};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mb][2], x3[0], acc, 0, 0, 0);   // lo . hi
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mb][0], x3[2], acc, 0, 0, 0);   // hi . lo
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mb][1], x3[1], acc, 0, 0, 0);   // mid . mid
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mb][1], x3[0], acc, 0, 0, 0);   // mid . hi
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mb][0], x3[1], acc, 0, 0, 0);   // hi . mid
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mb][0], x3[0], acc, 0, 0, 0);   // hi . hi
+                    a1v[u][mb] = f32x4{leakyf_(acc[0]), leakyf_(acc[1]), leakyf_(acc[2]), leakyf_(acc[3])};
+                    *reinterpret_cast<f32x4 *>(tbuf + mid_chunk(fj, 4 * mb + fq)) = a1v[u][mb];     // (row fj, channels 16 mb + 4 fq .. + 3)
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int r = 0; r < 16; ++r)
+                    if (itile[u] * 16 + r < n) {
+                        const double v = (double)tbuf[r * kMidRowFloats + ch];
+                        bn += sq ? v * v : v;
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+        TGNN_MI(4)
+        mid_allreduce_init(A.part, A.gpart, bn, 1, bnred, red, tot, spin, tid);
+        TGNN_MI(5)
+        init_record(A.ig1, A.ibt1, A.irm1, A.irv1, A.inbt1);
+        TGNN_MI(6)
+        // slot 0 = BatchNorm 1 of the own rows; its largest magnitude for the first NNConv's scale; everybody's rows before anybody gathers
+        {
+            const __amdgpu_buffer_rsrc_t o_rs = rsrc_of(A.mid);
+            float mx = 0.f;
+#pragma unroll
+            for (int u = 0; u < kInitTiles; ++u) {
+                if (!iok[u]) continue;
+                const int64_t row = itile[u] * 16 + fj;
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const int c0 = 16 * mb + 4 * fq;
+                    float4 o;
+                    o.x = bn_apply1(a1v[u][mb][0], st[c0 + 0], st[32 + c0 + 0], st[64 + c0 + 0], st[96 + c0 + 0]);
+                    o.y = bn_apply1(a1v[u][mb][1], st[c0 + 1], st[32 + c0 + 1], st[64 + c0 + 1], st[96 + c0 + 1]);
+                    o.z = bn_apply1(a1v[u][mb][2], st[c0 + 2], st[32 + c0 + 2], st[64 + c0 + 2], st[96 + c0 + 2]);
+                    o.w = bn_apply1(a1v[u][mb][3], st[c0 + 3], st[32 + c0 + 3], st[64 + c0 + 3], st[96 + c0 + 3]);
+                    if (row < n) {
+                        mx = absmax4(mx, o);
+                        st_sc1_f4(o_rs, (uint32_t)row * 128u + (uint32_t)c0 * 4u, o);
+                    }
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+            if (lane == 0) scr[wave] = mx;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            b_target += nblk;
+            if (tid == kMidThreads - 64) {
+                float m = scr[0];
+#pragma unroll
+                for (int w = 1; w < kMidWaves; ++w) m = fmaxf(m, scr[w]);
+                if (m > 0.f) atomicMax(A.bounds, __float_as_uint(m));
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(A.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                spin_until_ge(A.ctr, b_target, spin, kSpinErrBarrier);
+            }
+            __syncthreads();
+            TGNN_MI(7)
+        }
+    }
     if (!A.weights_done) mid_dma(A.wimg, wl, (T + 1) * kWtTypeF16 * 4, wave, lane);
     mid_dma(A.pack + kSpGinW, gw, kSpGinFrags * 16, wave, lane);
     for (int i = lane; i < kMidTileFloats / 4; i += 64) reinterpret_cast<f32x4 *>(tbuf)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -684,7 +920,8 @@ size_t mid_part_doubles() { return (size_t)2 * 2 * 256 * 128; }   // part + gpar
 int launch_forward_mid(const tgnn_model_dims *d, const Params &P, float *mid, float *a1, float *a2_0, float *a2_1, const float *wimg,
                        const float *pack, const tgnn_graph *graph, double *part, double *runstat, unsigned *ctr, unsigned *bounds,
                        int64_t n, int tiles_per_block, int blocks, int update_running, float eps, float momentum, hipStream_t s,
-                       const unsigned *weights_done, unsigned weights_target, double *const *tail_zero, size_t tail_zero_doubles) {
+                       const unsigned *weights_done, unsigned weights_target, double *const *tail_zero, size_t tail_zero_doubles,
+                       const float *x_init) {
     const int depth = d->network_depth;
     MidArgs A{};
     A.weights_done = weights_done;
@@ -692,6 +929,17 @@ int launch_forward_mid(const tgnn_model_dims *d, const Params &P, float *mid, fl
     A.tail_zero[0] = tail_zero ? tail_zero[0] : nullptr;
     A.tail_zero[1] = tail_zero ? tail_zero[1] : nullptr;
     A.tail_zero_vec = (unsigned)(tail_zero_doubles / 2);
+    if (x_init) {                                                 // the init MLP in the prologue (the pack carries Linear 1's image)
+        const BnPtrs b0 = P.bn(P.init(0) + 2), b1 = P.bn(P.init(1) + 2);
+        A.x = x_init;
+        A.fx = d->node_features_dim;
+        A.iw0 = P.f(P.init(0));
+        A.ib0 = P.f(P.init(0) + 1);
+        A.ig0 = b0.gamma; A.ibt0 = b0.beta; A.irm0 = b0.rm; A.irv0 = b0.rv; A.inbt0 = b0.nbt;
+        A.i1img = small_dense_image(pack, depth, 0);
+        A.ib1 = P.f(P.init(1) + 1);
+        A.ig1 = b1.gamma; A.ibt1 = b1.beta; A.irm1 = b1.rm; A.irv1 = b1.rv; A.inbt1 = b1.nbt;
+    }
     A.mid = mid;
     A.a1 = a1;
     A.a2[0] = a2_0;

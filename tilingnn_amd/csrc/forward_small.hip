@@ -1161,7 +1161,7 @@ size_t small_pack_floats(int depth) {
 // Per-forward pre-pass (side stream): parameter packs + GIN images of the layers, MFMA images of the dense layers; re-arms
 // the barrier counter
 void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrier_ctr, hipStream_t s, bool dense_images, void *zero,
-                       size_t zero_bytes, const unsigned *fin0_f16_max) {
+                       size_t zero_bytes, const unsigned *fin0_f16_max, hipStream_t final_images_stream) {
     size_t off[5];
     small_image_floats(depth, off);
     float *img = pack + (size_t)depth * kSpStride;
@@ -1180,9 +1180,17 @@ void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrie
                                     P.f(b + 14), P.f(b + 15), P.f(b + 16), P.f(b + 17), P.f(b + 18), P.f(b + 19)};
         }
         const bool first = lo == 0 && dense_images;             // the dense images ride along with the first chunk
-        small_pack_kernel<<<dim3(first ? 64 : 1, nl + (first ? 5 : 0)), 256, 0, s>>>(L, nl, pack + (size_t)lo * kSpStride,
-                                                                                     lo == 0 ? barrier_ctr : nullptr, J,
-                                                                                     lo == 0 ? static_cast<u32x4 *>(zero) : nullptr, (int64_t)(zero_bytes / 16));
+        // (final_images_stream: only the init Linear's there -- the final MLP's four, needed a whole layer loop later, go to a
+        //  launch of their own on that stream: 64 x 4 blocks less in front of the persistent kernel)
+        const int n_img = first ? (final_images_stream ? 1 : 5) : 0;
+        small_pack_kernel<<<dim3(n_img > 1 ? 64 : 1, nl + n_img), 256, 0, s>>>(L, nl, pack + (size_t)lo * kSpStride,
+                                                                               lo == 0 ? barrier_ctr : nullptr, J,
+                                                                               lo == 0 ? static_cast<u32x4 *>(zero) : nullptr, (int64_t)(zero_bytes / 16));
+    }
+    if (dense_images && final_images_stream) {
+        SmallImageJobs J4{};
+        for (int k = 0; k < 4; ++k) J4.j[k] = J.j[1 + k];
+        small_pack_kernel<<<dim3(64, 4), 256, 0, final_images_stream>>>(SmallPackLayers{}, 0, pack, nullptr, J4, nullptr, 0);
     }
 }
 

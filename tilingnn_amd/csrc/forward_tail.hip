@@ -448,11 +448,12 @@ __global__ __launch_bounds__(kTailThreads) void forward_tail_mid_kernel(TailArgs
     TGNN_TT(25)
 }
 
-static std::atomic<int> g_mid_tail{1};
+static std::atomic<int> g_mid_tail{3};                           // bit 0: this kernel; bit 1: the init MLP in the layer loop's prologue
+bool mid_init_in_kernel() { return (g_mid_tail.load(std::memory_order_relaxed) & 2) != 0; }
 
 // > 0: tiles per block (2 .. 4) of the tail kernel for this layout (behind the persistent layer loop only); 0: the general final MLP
 int mid_tail_tiles_per_block(const tgnn_model_dims *d, int64_t n_nodes, int *blocks_out) {
-    if (!g_mid_tail.load(std::memory_order_relaxed)) return 0;
+    if (!(g_mid_tail.load(std::memory_order_relaxed) & 1)) return 0;
     if (d->network_width != 32 || d->network_depth + 1 > 64 || n_nodes < 1 || n_nodes > 65536) return 0;
     static std::atomic<int> capacity[64];
     int dev = 0;
@@ -536,6 +537,6 @@ extern "C" int tgnn_debug_tail_timing(unsigned long long *out, int n_blocks) {
 }
 #endif
 extern "C" int32_t tgnn_set_mid_tail(int32_t on) {
-    if (on != 0 && on != 1) return tgnn::g_mid_tail.load();
+    if (on < 0 || on > 3) return tgnn::g_mid_tail.load();
     return tgnn::g_mid_tail.exchange(on);
 }

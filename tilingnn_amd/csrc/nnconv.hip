@@ -415,7 +415,97 @@ __global__ __launch_bounds__(256) void nnconv_generic_kernel(
     }
 }
 
+// [r5] The same table with the blocks laid over (layer, 256 OUTPUTS) instead of (layer, type): a thread owns one of the cc outputs of
+// the last Linear -- its row of W3 (64 floats) sits in registers ONCE for all types -- and the two small hidden layers of every type
+// are recomputed by each of the layer's cc / 256 blocks (T x 2 528 multiply-adds: nothing).  With a block per (layer, type) every
+// block streamed the whole 256 KB W3 out of L2 for one type: 280 blocks x 256 KB and ~29 us on the side stream at 13 types x 20
+// layers -- during which the persistent layer loops (forward_small.hip, forward_mid.hip), started beside it, found no free CUs for
+// half of their blocks.  Same multiply-add order per output as edge_weight_table_kernel: the same bits.
+constexpr int kEwTypes = 16, kEwMaxFe = 64;   // types per pass; attribute columns (beyond: the kernel above)
+__global__ __launch_bounds__(256) void edge_weight_table_chunks_kernel(
+    const float *__restrict__ edge_attr, const int *__restrict__ type_rep_edge, int fe, EdgeMlpLayers layers, int cc,
+    float *__restrict__ wtab_all, int n_types, RootPtrs roots, float *__restrict__ wimg_all, unsigned *__restrict__ done_ctr,
+    const unsigned *__restrict__ root_max) {
+    const bool f16 = root_max != nullptr;
+    const float wscale = f16 ? nnconv_weight_scale(root_max[blockIdx.y]) : 1.0f;
+    const int chunks = cc / 256, tid = threadIdx.x;
+    auto image_of = [&](int t) { return wimg_all + ((int64_t)blockIdx.y * (n_types + 1) + t) * (f16 ? kWtTypeF16 : kWtType); };
+    if ((int)blockIdx.x == chunks) {                             // the root matrix's image (width 32 only)
+        const float *src = roots.p[blockIdx.y];
+        __bf16 *img = reinterpret_cast<__bf16 *>(image_of(n_types));
+        if (f16) for (int r = tid; r < 1024; r += 256) weight_image_put_f16(reinterpret_cast<_Float16 *>(img), r, src[r] * wscale);
+        else for (int r = tid; r < 1024; r += 256) weight_image_put(img, r, src[r]);
+    } else {
+        const EdgeMlpLayer L = layers.l[blockIdx.y];
+        const float *__restrict__ w1 = L.w1, *__restrict__ b1 = L.b1, *__restrict__ w2 = L.w2, *__restrict__ b2 = L.b2,
+                    *__restrict__ w3 = L.w3, *__restrict__ b3 = L.b3;
+        float *__restrict__ wtab = wtab_all + (int64_t)blockIdx.y * n_types * cc;
+        __shared__ float e_s[kEwTypes * kEwMaxFe];
+        __shared__ float h1_s[kEwTypes * kEH1];
+        __shared__ __attribute__((aligned(16))) float h2_s[kEwTypes * kEH2];
+        const int j = blockIdx.x * 256 + tid;                     // this thread's output
+        float4 wr[kEH2 / 4];
+#pragma unroll
+        for (int q = 0; q < kEH2 / 4; ++q) wr[q] = reinterpret_cast<const float4 *>(w3 + (int64_t)j * kEH2)[q];
+        const float bj = b3[j];
+        for (int t0 = 0; t0 < n_types; t0 += kEwTypes) {
+            const int nt = n_types - t0 < kEwTypes ? n_types - t0 : kEwTypes;
+            __syncthreads();                                      // (the previous pass's h2 has been read)
+            for (int i = tid; i < nt * fe; i += 256) {
+                const int t = i / fe, k = i - t * fe;
+                e_s[t * kEwMaxFe + k] = edge_attr[(int64_t)type_rep_edge[t0 + t] * fe + k];
+            }
+            __syncthreads();
+            for (int i = tid; i < nt * kEH1; i += 256) {
+                const int t = i / kEH1, u = i % kEH1;
+                float acc = b1[u];
+                for (int k = 0; k < fe; ++k) acc = fmaf(e_s[t * kEwMaxFe + k], w1[u * fe + k], acc);
+                h1_s[t * kEH1 + u] = sigmoidf_(acc);
+            }
+            __syncthreads();
+            for (int i = tid; i < nt * kEH2; i += 256) {
+                const int t = i / kEH2, v = i % kEH2;
+                float acc = b2[v];
+#pragma unroll
+                for (int k = 0; k < kEH1; ++k) acc = fmaf(h1_s[t * kEH1 + k], w2[v * kEH1 + k], acc);
+                h2_s[t * kEH2 + v] = sigmoidf_(acc);
+            }
+            __syncthreads();
+            for (int t = 0; t < nt; ++t) {
+                float acc = bj;
+#pragma unroll
+                for (int q = 0; q < kEH2 / 4; ++q) {
+                    const float4 h = *reinterpret_cast<const float4 *>(h2_s + t * kEH2 + 4 * q);   // (one address per wave: a broadcast)
+                    acc = fmaf(h.x, wr[q].x, acc);
+                    acc = fmaf(h.y, wr[q].y, acc);
+                    acc = fmaf(h.z, wr[q].z, acc);
+                    acc = fmaf(h.w, wr[q].w, acc);
+                }
+                const float v = sigmoidf_(acc);
+                wtab[(int64_t)(t0 + t) * cc + j] = v;
+                if (wimg_all) {
+                    __bf16 *img = reinterpret_cast<__bf16 *>(image_of(t0 + t));
+                    if (f16) weight_image_put_f16(reinterpret_cast<_Float16 *>(img), j, v * wscale);
+                    else weight_image_put(img, j, v);
+                }
+            }
+        }
+    }
+    if (done_ctr) {                                               // (a consumer on another stream counts the finished blocks)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every wave's stores are in L2 before thread 0 writes L2 back
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(done_ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 constexpr size_t kMaxDynLds = 160 * 1024 - 256;
+
+static bool edge_table_by_chunks(int fe, int c) { return fe <= kEwMaxFe && (c * c) % 256 == 0; }
+// blocks of the launch below = what its done counter reaches
+unsigned edge_weight_table_blocks(int n_types, int fe, int depth, int c, bool image) {
+    image = image && c == 32;
+    return (unsigned)depth * (unsigned)((edge_table_by_chunks(fe, c) ? c * c / 256 : n_types) + (image ? 1 : 0));
+}
 
 void launch_edge_weight_table_batched(const float *edge_attr, const int *type_rep_edge, int n_types, int fe,
                                       const EdgeMlpLayers &layers, int depth, int c, float *wtab, const float *const *roots,
@@ -424,6 +514,11 @@ void launch_edge_weight_table_batched(const float *edge_attr, const int *type_re
     const bool image = wimg_all && roots && c == 32;
     if (image)
         for (int i = 0; i < depth; ++i) rp.p[i] = roots[i];
+    if (edge_table_by_chunks(fe, c)) {
+        edge_weight_table_chunks_kernel<<<dim3(c * c / 256 + (image ? 1 : 0), depth), 256, 0, s>>>(
+            edge_attr, type_rep_edge, fe, layers, c * c, wtab, n_types, rp, image ? wimg_all : nullptr, done_ctr, image ? root_max : nullptr);
+        return;
+    }
     edge_weight_table_kernel<<<dim3(n_types + (image ? 1 : 0), depth), 256, 0, s>>>(edge_attr, type_rep_edge, fe, layers, c * c, wtab,
                                                                                   n_types, rp, image ? wimg_all : nullptr, done_ctr,
                                                                                   image ? root_max : nullptr);

@@ -387,6 +387,7 @@ struct EdgeMlpLayers {
 };
 // wtab [depth][T][C*C]
 // roots + wimg_all given (width 32): the same launch also writes the NNConv operand images [(T+1)][kWtType] of all layers
+unsigned edge_weight_table_blocks(int n_types, int fe, int depth, int c, bool image);   // what done_ctr of the launch below reaches
 void launch_edge_weight_table_batched(const float *edge_attr, const int *type_rep_edge, int n_types, int fe,
                                       const EdgeMlpLayers &layers, int depth, int c, float *wtab, const float *const *roots,
                                       float *wimg_all, hipStream_t s, unsigned *done_ctr = nullptr,
@@ -459,7 +460,8 @@ size_t small_pack_floats(int depth);
 // zero / zero_bytes (a multiple of 16): memory the same launch clears (the mid-size kernel's tagged partial rows)
 // fin0_f16_max: the final MLP's first Linear as an fp16-pair image scaled by pow2_scale_for(*fin0_f16_max) (forward_tail.hip)
 void launch_small_pack(const Params &P, int depth, float *pack, unsigned *barrier_ctr, hipStream_t s, bool dense_images = true,
-                       void *zero = nullptr, size_t zero_bytes = 0, const unsigned *fin0_f16_max = nullptr);
+                       void *zero = nullptr, size_t zero_bytes = 0, const unsigned *fin0_f16_max = nullptr,
+                       hipStream_t final_images_stream = nullptr);
 int launch_forward_small(const tgnn_model_dims *d, const Params &P, const float *x, float *probs, float *mid, float *a2_0,
                          float *a2_1, const float *wimg, float *pack, const tgnn_graph *graph, double *part, double *part_wide,
                          double *runstat, unsigned *ctr, const unsigned *weights_done, unsigned weights_target, int64_t n,
@@ -473,11 +475,14 @@ int launch_forward_mid(const tgnn_model_dims *d, const Params &P, float *mid, fl
                        const float *pack, const tgnn_graph *graph, double *part, double *runstat, unsigned *ctr, unsigned *bounds,
                        int64_t n, int tiles_per_block, int blocks, int update_running, float eps, float momentum, hipStream_t s,
                        const unsigned *weights_done = nullptr, unsigned weights_target = 0, double *const *tail_zero = nullptr,
-                       size_t tail_zero_doubles = 0);
+                       size_t tail_zero_doubles = 0, const float *x_init = nullptr);
+// x_init: the node features -- the init MLP then runs in the kernel's prologue (node_features_dim <= 8; the pack must carry the
+// dense images) instead of as launches in front of it
 // ... and the final MLP behind it as one persistent kernel too (forward_tail.hip): 0 = not eligible / switched off
 // (tgnn_set_mid_tail); needs a pack built with dense_images; part / gpart: mid_tail_part_doubles() doubles each, ZEROED by
 // the layer loop's kernel in front of it (launch_forward_mid: tail_zero)
 int mid_tail_tiles_per_block(const tgnn_model_dims *d, int64_t n_nodes, int *blocks_out);
+bool mid_init_in_kernel();     // tgnn_set_mid_tail bit 1
 size_t mid_tail_part_doubles();
 const float *small_dense_image(const float *pack, int depth, int k);
 int launch_forward_tail(const tgnn_model_dims *d, const Params &P, const float *mid, const float *pack, float *probs, double *part,
