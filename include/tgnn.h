@@ -163,6 +163,28 @@ int tgnn_nnconv_mean_cols_f16_fwd(const float *h, int64_t ldh, int64_t n_src_row
                                   float *out, float *wimg_scratch, uint32_t *bounds_scratch, double *bn_partial,
                                   int32_t *n_partials_host, tgnn_stream_t stream);
 
+/* The same NNConv (edge_conv.py:24-27) over EDGE GROUPS instead of type columns (csrc/nnconv_eg.hip): the in-edges of a 16-row
+ * tile sorted by (type, destination row, original order) and cut into groups of up to 16 edges of one type, so that a gather
+ * instruction of the kernel fetches 16 source rows whatever rows of the tile they belong to (a type column is ~30 % full on
+ * real layouts, a group ~70 %); the rows of a group are multiplied by the type's matrix and folded into their destination
+ * rows by a second matrix product with the group's 0 / 1 selection matrix.  The last group of a tile is the root group.
+ *   tile_grp_ptr int32 [ceil(N/16)+1]   group range of every tile
+ *   grp_src      int32 [16*n_groups]    source row of slot k, -1 = none; root group: float bits of max(in-degree, 1) of row k,
+ *                                       -1 for rows >= N
+ *   grp_sm       int32 [16*n_groups]    word j of a group: mask of the slots that end in row j | (type | root << 8) << 16
+ * n_groups <= tgnn_nnconv_eg_max_groups(N, E, T) (allocate for that many: the kernel reads index words past the end); workspace
+ * of the build: tgnn_nnconv_cols_workspace_bytes(N).  tgnn_nnconv_mean_eg_fwd is the op for tests (bounds and the fp16-pair
+ * weight image computed inside, as tgnn_nnconv_mean_cols_f16_fwd does); width 32, packed rows (ldh == 32). */
+int64_t tgnn_nnconv_eg_max_groups(int64_t n_nodes, int64_t n_edges, int32_t n_types);
+int tgnn_nnconv_eg_build(const int32_t *rowptr, const int32_t *col_src, const int32_t *col_type, int64_t n_nodes,
+                         int32_t n_types, int32_t *tile_grp_ptr, int32_t *grp_src, int32_t *grp_sm, void *ws, size_t ws_bytes,
+                         tgnn_stream_t stream);
+int tgnn_nnconv_mean_eg_fwd(const float *h, int64_t ldh, int64_t n_src_rows, const int32_t *tile_grp_ptr,
+                            const int32_t *grp_src, const int32_t *grp_sm, const float *wtab, int32_t n_types,
+                            const float *root, const float *bias, int64_t n_nodes, int32_t act, float *out,
+                            float *wimg_scratch, uint32_t *bounds_scratch, double *bn_partial, int32_t *n_partials_host,
+                            tgnn_stream_t stream);
+
 /* Measurement helper of bench.py (roofline.gather_bound; csrc/ubench.hip): rows of 128 bytes gathered per second by one launch
  * over every CU from an L2 / Infinity-Cache resident table of n_rows x 128 bytes (>= 8192 rows), band-local random rows, best of
  * `reps` launches of `iters` x 8 gather steps per wave.  shape 0 = the column NNConv's lane map (16 rows x 64 bytes per

@@ -95,6 +95,9 @@ def _load() -> C.CDLL:
         "tgnn_nnconv_weight_image_floats": (sz, [i32]),
         "tgnn_nnconv_mean_cols_fwd": (C.c_int, [p, i64, p, p, p, p, i32, p, p, i64, i32, i32, p, p, p, pi32, p]),
         "tgnn_nnconv_mean_cols_f16_fwd": (C.c_int, [p, i64, i64, p, p, p, p, i32, p, p, i64, i32, i32, p, p, p, p, pi32, p]),
+        "tgnn_nnconv_eg_max_groups": (i64, [i64, i64, i32]),
+        "tgnn_nnconv_eg_build": (C.c_int, [p, p, p, i64, i32, p, p, p, p, sz, p]),
+        "tgnn_nnconv_mean_eg_fwd": (C.c_int, [p, i64, i64, p, p, p, p, i32, p, p, i64, i32, p, p, p, p, pi32, p]),
         "tgnn_ubench_row_gather": (C.c_int, [i32, p, i64, p, i32, i32, C.POINTER(C.c_double), p]),
         "tgnn_mid_entries_words": (i64, [i64]),
         "tgnn_mid_entries_build": (C.c_int, [p, p, p, i64, p, p, p, p, p]),
@@ -218,7 +221,7 @@ EXPORTED_SYMBOLS = (
     "tgnn_version", "tgnn_last_error", "tgnn_csr_workspace_bytes", "tgnn_csr_build",
     "tgnn_edge_dedup_workspace_bytes", "tgnn_edge_type_dedup", "tgnn_gather_i32", "tgnn_edge_weight_table",
     "tgnn_nnconv_mean_fwd", "tgnn_nnconv_cols_max_columns", "tgnn_nnconv_cols_workspace_bytes",
-    "tgnn_nnconv_cols_build", "tgnn_nnconv_cols_max_types", "tgnn_nnconv_weight_image_floats", "tgnn_nnconv_mean_cols_fwd", "tgnn_nnconv_mean_cols_f16_fwd",
+    "tgnn_nnconv_cols_build", "tgnn_nnconv_cols_max_types", "tgnn_nnconv_weight_image_floats", "tgnn_nnconv_mean_cols_fwd", "tgnn_nnconv_mean_cols_f16_fwd", "tgnn_nnconv_eg_max_groups", "tgnn_nnconv_eg_build", "tgnn_nnconv_mean_eg_fwd",
     "tgnn_ubench_row_gather", "tgnn_mid_entries_words", "tgnn_mid_entries_build", "tgnn_forward_path_counts", "tgnn_set_mid_layout_limit", "tgnn_get_mid_layout_limit", "tgnn_mid_layout_max_nodes",
     "tgnn_spin_error_poll", "tgnn_set_spin_budget_us", "tgnn_persist_fallback", "tgnn_spin_error_peek", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_dense_act_slots_fwd", "tgnn_dense_act_slots_f16_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
     "tgnn_merge_fwd", "tgnn_param_count", "tgnn_param_name", "tgnn_forward_workspace_bytes", "tgnn_forward",

@@ -523,6 +523,93 @@ __global__ __launch_bounds__(64) void nnconv_col_kernel(const int *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// NNConv edge groups (nnconv_eg.hip): per 16 destination rows its in-edges sorted by (type, row, CSR order) and cut into
+// GROUPS of up to 16 edges of ONE type -- a gather instruction of the kernel fetches 16 source rows whatever rows of the
+// tile they go to (the type columns above fill 29 % of their slots at 10 edges over 13 types; groups 70 %).
+//   grp_src [16 * n_groups]: source row of slot k, -1 = none; in the root group (the last of a tile) the float bits of
+//                            max(in-degree, 1) of row k, -1 for rows >= N
+//   grp_sm  [16 * n_groups]: word j of a group = (mask of the slots that go to row j) | (type | root << 8) << 16
+// One block = 64 rows = 4 tiles, one thread per row.
+// ------------------------------------------------------------------------------------------
+constexpr int kEgRoot = 1 << 8;
+
+template <bool FILL>
+__global__ __launch_bounds__(64) void nnconv_eg_kernel(const int *__restrict__ rowptr, const int *__restrict__ col_src,
+                                                       const int *__restrict__ col_type, int64_t n, int n_types_host,
+                                                       int *__restrict__ tile_grps,            // !FILL: out, groups per tile
+                                                       const int *__restrict__ tile_grp_ptr,   // FILL
+                                                       int *__restrict__ grp_src, int *__restrict__ grp_sm,
+                                                       const int *__restrict__ n_types_dev = nullptr, int max_types = kMaxColTypes,
+                                                       int *__restrict__ built_flag = nullptr) {
+    const int n_types = n_types_dev ? *n_types_dev : n_types_host;
+    const int64_t n_tiles = (n + kColTileRows - 1) / kColTileRows;
+    if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) tile_grps[n_tiles] = 0;   // (the scan's last entry)
+    const int tid = threadIdx.x, k = tid >> 4, i = tid & 15;
+    const int64_t row = (int64_t)blockIdx.x * 64 + tid;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + k;
+    if (n_types > max_types || n_types > kMaxColTypes) {
+        if (!FILL && i == 0 && tile < n_tiles) tile_grps[tile] = 0;
+        return;
+    }
+    if (built_flag && blockIdx.x == 0 && threadIdx.x == 0) *built_flag = 1;
+    __shared__ int cnt[64][kMaxColTypes + 1];    // edges of (row, type); +1: odd stride
+    __shared__ int pre[64][kMaxColTypes + 1];    // edges of the type in the tile's rows above this one
+    __shared__ int base[4][kMaxColTypes + 1];    // first group of (tile, type)
+    for (int t = 0; t < n_types; ++t) cnt[tid][t] = 0;
+    int e0 = 0, e1 = 0;
+    if (row < n) { e0 = rowptr[row]; e1 = rowptr[row + 1]; }
+    for (int e = e0; e < e1; ++e) cnt[tid][col_type[e]]++;
+    __syncthreads();
+    for (int t = i; t < n_types; t += 16) {
+        int acc = 0;
+        for (int r = 0; r < 16; ++r) {
+            pre[k * 16 + r][t] = acc;
+            acc += cnt[k * 16 + r][t];
+        }
+        base[k][t] = (acc + 15) >> 4;            // (groups of the type: turned into offsets below)
+    }
+    __syncthreads();
+    if (i == 0) {
+        int acc = 0;
+        for (int t = 0; t < n_types; ++t) { const int g = base[k][t]; base[k][t] = acc; acc += g; }
+        base[k][n_types] = acc;
+        if (!FILL && tile < n_tiles) tile_grps[tile] = acc + 1;
+    }
+    if (!FILL) return;
+    __syncthreads();
+    if (tile >= n_tiles) return;                 // whole 16-thread group: no barrier below
+    const int64_t g0 = tile_grp_ptr[tile];
+    const int n_edge_grps = base[k][n_types];
+    // thread i: slot i of every group's sources, and row i's word of every group
+    for (int t = 0; t < n_types; ++t)
+        for (int g = base[k][t]; g < base[k][t + 1]; ++g) {
+            grp_src[(g0 + g) * 16 + i] = -1;
+            grp_sm[(g0 + g) * 16 + i] = t << 16;
+        }
+    const int deg = e1 - e0;
+    grp_src[(g0 + n_edge_grps) * 16 + i] = row < n ? __float_as_int((float)(deg > 0 ? deg : 1)) : -1;
+    grp_sm[(g0 + n_edge_grps) * 16 + i] = (n_types | kEgRoot) << 16 | 1 << i;
+    // the 16 threads of a tile are lanes of one wavefront: their -1 stores above are ordered before the sources below
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int t = 0; t < n_types; ++t) {
+        const int c = cnt[tid][t];
+        if (c == 0) continue;
+        const int p0 = pre[tid][t], p1 = p0 + c;                  // this row's slots of the type's sorted list
+        for (int g = p0 >> 4; g <= (p1 - 1) >> 4; ++g) {
+            const int lo = max(p0 - 16 * g, 0), hi = min(p1 - 16 * g, 16);
+            grp_sm[(g0 + base[k][t] + g) * 16 + i] = t << 16 | (((1 << hi) - 1) & ~((1 << lo) - 1));
+        }
+        cnt[tid][t] = 0;
+    }
+    for (int e = e0; e < e1; ++e) {
+        const int t = col_type[e];
+        const int p = pre[tid][t] + cnt[tid][t]++;
+        grp_src[(g0 + base[k][t] + (p >> 4)) * 16 + (p & 15)] = col_src[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Small layouts (what the greedy loop scores every round: ~1 000 nodes, ~20 000 edges): the whole preparation -- both CSRs,
 // the exact edge-type de-duplication, types in CSR order, the NNConv column structure -- in ONE launch instead of ~30 tiny
 // ones (0.19 ms per layout of which the kernels themselves were a fifth): up to 16 resident blocks that pass through the
@@ -1436,6 +1523,50 @@ extern "C" int tgnn_nnconv_cols_build(const int32_t *rowptr, const int32_t *col_
     exclusive_scan_i32(tile_cols, tile_col_ptr, nt16 + 1, scan_ws, s);
     nnconv_col_kernel<true><<<blocks, 64, 0, s>>>(rowptr, col_src, col_type, n_nodes, n_types, nullptr, tile_col_ptr,
                                                   col_meta, col_slot_src);
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}
+
+extern "C" int64_t tgnn_nnconv_eg_max_groups(int64_t n_nodes, int64_t n_edges, int32_t n_types) {
+    // per (tile, type) at most one group that is not full; one root group per tile; slack: the kernel fetches index words
+    // in fours and up to 3 fours ahead
+    const int64_t ntiles = (n_nodes + kColTileRows - 1) / kColTileRows;
+    const int64_t a = n_edges / 16 + ntiles * (int64_t)n_types, b = n_edges;
+    return (a < b ? a : b) + ntiles + 32;
+}
+
+static void launch_nnconv_eg_build(const int32_t *rowptr, const int32_t *col_src, const int32_t *col_type, int64_t n_nodes,
+                                   int32_t n_types, const int *n_types_dev, int max_types, int32_t *tile_grps,
+                                   int32_t *tile_grp_ptr, int32_t *grp_src, int32_t *grp_sm, int *scan_ws, int *built_flag,
+                                   hipStream_t s) {
+    const int64_t nt16 = (n_nodes + kColTileRows - 1) / kColTileRows;
+    const unsigned blocks = (unsigned)((n_nodes + 63) / 64);
+    nnconv_eg_kernel<false><<<blocks, 64, 0, s>>>(rowptr, col_src, col_type, n_nodes, n_types, tile_grps, nullptr, nullptr,
+                                                  nullptr, n_types_dev, max_types, built_flag);
+    exclusive_scan_i32(tile_grps, tile_grp_ptr, nt16 + 1, scan_ws, s);
+    nnconv_eg_kernel<true><<<blocks, 64, 0, s>>>(rowptr, col_src, col_type, n_nodes, n_types, nullptr, tile_grp_ptr, grp_src,
+                                                 grp_sm, n_types_dev, max_types, nullptr);
+}
+
+extern "C" int tgnn_nnconv_eg_build(const int32_t *rowptr, const int32_t *col_src, const int32_t *col_type,
+                                    int64_t n_nodes, int32_t n_types, int32_t *tile_grp_ptr, int32_t *grp_src,
+                                    int32_t *grp_sm, void *ws, size_t ws_bytes, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
+    TGNN_CHECK_ARG(n_nodes >= 1, "n_nodes");
+    TGNN_CHECK_ARG(n_types >= 0 && n_types <= kMaxColTypes, "the NNConv edge-group structure supports at most 40 edge types");
+    TGNN_CHECK_ARG(rowptr && tile_grp_ptr && grp_src && grp_sm, "null pointer");
+    TGNN_CHECK_ARG(n_types == 0 || (col_src && col_type), "null CSR pointer");
+    if (!ws || ws_bytes < tgnn_nnconv_cols_workspace_bytes(n_nodes)) {
+        set_error("tgnn_nnconv_eg_build: workspace too small");
+        return TGNN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t nt16 = (n_nodes + kColTileRows - 1) / kColTileRows;
+    Carver cv(ws, ws_bytes);
+    int *tile_grps = cv.take<int>(nt16 + 1);
+    int *scan_ws = cv.take<int>(scan_ws_ints(nt16 + 1));
+    launch_nnconv_eg_build(rowptr, col_src, col_type, n_nodes, n_types, nullptr, kMaxColTypes, tile_grps, tile_grp_ptr, grp_src,
+                           grp_sm, scan_ws, nullptr, s);
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
 }

@@ -61,12 +61,12 @@ __device__ __forceinline__ void weight_image_put_f16(_Float16 *dst, int r, float
 __global__ __launch_bounds__(256) void edge_weight_table_kernel(
     const float *__restrict__ edge_attr, const int *__restrict__ type_rep_edge, int fe, EdgeMlpLayers layers, int cc,
     float *__restrict__ wtab_all, int n_types, RootPtrs roots, float *__restrict__ wimg_all, unsigned *__restrict__ done_ctr,
-    const unsigned *__restrict__ root_max) {
+    const unsigned *__restrict__ root_max, float img_scale) {
     // wimg_all != NULL (width 32): the block also writes its type's slice of the matrix-core operand image, and one more
     // block per layer (blockIdx.x == n_types) the root matrix's -- no second launch on the way to the first NNConv
     // root_max != NULL: fp16-pair images (two planes, scaled), else bf16 x 3
     const bool f16 = root_max != nullptr;
-    const float wscale = f16 ? nnconv_weight_scale(root_max[blockIdx.y]) : 1.0f;
+    const float wscale = f16 ? nnconv_weight_scale(root_max[blockIdx.y]) * img_scale : 1.0f;   // (img_scale: a power of two)
     const int64_t img_at = ((int64_t)blockIdx.y * (n_types + 1) + blockIdx.x) * (f16 ? kWtTypeF16 : kWtType);
     __bf16 *img = wimg_all ? reinterpret_cast<__bf16 *>(wimg_all + img_at) : nullptr;
     _Float16 *img16 = reinterpret_cast<_Float16 *>(img);
@@ -345,11 +345,11 @@ __global__ __launch_bounds__(kNNThreads) void nnconv32_lds_kernel(
 // straight coalesced 16-byte copy.
 __global__ __launch_bounds__(256) void nnconv_weight_image_kernel(const float *__restrict__ wtab_all, RootPtrs roots,
                                                                   int n_types, float *__restrict__ wimg_all,
-                                                                  const unsigned *__restrict__ root_max) {
+                                                                  const unsigned *__restrict__ root_max, float img_scale) {
     const int t = blockIdx.x, layer = blockIdx.y;
     const float *src = t < n_types ? wtab_all + ((int64_t)layer * n_types + t) * 1024 : roots.p[layer];
     if (root_max) {                                           // fp16-pair image
-        const float wscale = nnconv_weight_scale(root_max[layer]);
+        const float wscale = nnconv_weight_scale(root_max[layer]) * img_scale;
         _Float16 *dst = reinterpret_cast<_Float16 *>(wimg_all + ((int64_t)layer * (n_types + 1) + t) * kWtTypeF16);
         for (int r = threadIdx.x; r < 1024; r += 256) weight_image_put_f16(dst, r, src[r] * wscale);
         return;
@@ -425,9 +425,9 @@ constexpr int kEwTypes = 16, kEwMaxFe = 64;   // types per pass; attribute colum
 __global__ __launch_bounds__(256) void edge_weight_table_chunks_kernel(
     const float *__restrict__ edge_attr, const int *__restrict__ type_rep_edge, int fe, EdgeMlpLayers layers, int cc,
     float *__restrict__ wtab_all, int n_types, RootPtrs roots, float *__restrict__ wimg_all, unsigned *__restrict__ done_ctr,
-    const unsigned *__restrict__ root_max) {
+    const unsigned *__restrict__ root_max, float img_scale) {
     const bool f16 = root_max != nullptr;
-    const float wscale = f16 ? nnconv_weight_scale(root_max[blockIdx.y]) : 1.0f;
+    const float wscale = f16 ? nnconv_weight_scale(root_max[blockIdx.y]) * img_scale : 1.0f;
     const int chunks = cc / 256, tid = threadIdx.x;
     auto image_of = [&](int t) { return wimg_all + ((int64_t)blockIdx.y * (n_types + 1) + t) * (f16 ? kWtTypeF16 : kWtType); };
     if ((int)blockIdx.x == chunks) {                             // the root matrix's image (width 32 only)
@@ -509,19 +509,20 @@ unsigned edge_weight_table_blocks(int n_types, int fe, int depth, int c, bool im
 
 void launch_edge_weight_table_batched(const float *edge_attr, const int *type_rep_edge, int n_types, int fe,
                                       const EdgeMlpLayers &layers, int depth, int c, float *wtab, const float *const *roots,
-                                      float *wimg_all, hipStream_t s, unsigned *done_ctr, const unsigned *root_max) {
+                                      float *wimg_all, hipStream_t s, unsigned *done_ctr, const unsigned *root_max, float img_scale) {
     RootPtrs rp{};
     const bool image = wimg_all && roots && c == 32;
     if (image)
         for (int i = 0; i < depth; ++i) rp.p[i] = roots[i];
     if (edge_table_by_chunks(fe, c)) {
         edge_weight_table_chunks_kernel<<<dim3(c * c / 256 + (image ? 1 : 0), depth), 256, 0, s>>>(
-            edge_attr, type_rep_edge, fe, layers, c * c, wtab, n_types, rp, image ? wimg_all : nullptr, done_ctr, image ? root_max : nullptr);
+            edge_attr, type_rep_edge, fe, layers, c * c, wtab, n_types, rp, image ? wimg_all : nullptr, done_ctr, image ? root_max : nullptr,
+            img_scale);
         return;
     }
     edge_weight_table_kernel<<<dim3(n_types + (image ? 1 : 0), depth), 256, 0, s>>>(edge_attr, type_rep_edge, fe, layers, c * c, wtab,
                                                                                   n_types, rp, image ? wimg_all : nullptr, done_ctr,
-                                                                                  image ? root_max : nullptr);
+                                                                                  image ? root_max : nullptr, img_scale);
 }
 
 // words [0, n_zero) = 0; then block b < depth: max |roots[b]| -> root_max[b]; the other blocks: their share of dense_w -> *dense_max
@@ -647,10 +648,10 @@ extern "C" int tgnn_nnconv_mean_fwd(const float *h, int64_t ldh, const int32_t *
 
 namespace tgnn {
 void launch_nnconv_weight_image(const float *wtab_all, const float *const *roots, int n_types, int depth,
-                                float *wimg_all, hipStream_t s, const unsigned *root_max) {
+                                float *wimg_all, hipStream_t s, const unsigned *root_max, float img_scale) {
     RootPtrs rp{};
     for (int i = 0; i < depth; ++i) rp.p[i] = roots[i];
-    nnconv_weight_image_kernel<<<dim3(n_types + 1, depth), 256, 0, s>>>(wtab_all, rp, n_types, wimg_all, root_max);
+    nnconv_weight_image_kernel<<<dim3(n_types + 1, depth), 256, 0, s>>>(wtab_all, rp, n_types, wimg_all, root_max, img_scale);
 }
 }  // namespace tgnn
 

@@ -1,0 +1,331 @@
+// NNConv(aggr="mean"), network_width 32, "edge group" formulation for gfx950: full gathers instead of type columns.
+//
+// Reference semantics: GraphConv.forward (/root/reference/graph_networks/layers/edge_conv.py:24-27) over
+// PyG 1.3.2 NNConv:   out[v] = mean_{e: dst_e = v} h[src_e] . W_{type_e}  +  h[v] . root + bias  (+ LeakyReLU)
+//
+// Why another formulation: the type-column kernel (nnconv_cols.hip) is bound by the CU's gather path
+// and its columns -- one gather instruction per (type, k-th edge of a row) of a 16-row tile -- are 29 % full at 10 edges
+// over 13 types: 70 gather instructions per tile.  Here a gather instruction fetches the sources of 16 EDGES of one type,
+// whatever rows of the tile they end in (graph_prep.hip: nnconv_eg_kernel): ~15 groups + the root group per tile, 70-77 %
+// full, 31 instructions.  Two chained matrix products per group, both on the matrix pipe, no LDS between them:
+//     M [16 edges x 32]  = G [16 edges x 32] . W_t        (fp16-pair split, 3 terms: v_mfma_f32_16x16x32_f16 x 6)
+//     out[16 rows x 32] += S [16 rows x 16 edges] . M     (S: 0 / 1 selection of the group, exact; M split into an fp16 pair:
+//                                                          v_mfma_f32_16x16x16_f16 x 4)
+// The accumulator layout of the first product (lane (j, q): edges 4 q + r, channel j) IS the B-operand layout of the second.
+// The root group (the rows themselves, W = root) takes the same path with S = diag(max(deg, 1)): one 1 / deg at the end of the
+// tile turns the edge sum into the mean and leaves the root term as it is (in-degrees up to 2048: exact in fp16).  The
+// BatchNorm partial sums need no transpose any more (a lane holds ONE channel of 4 rows).
+#include <atomic>
+#include <type_traits>
+
+#include "tgnn_common.h"
+
+namespace tgnn {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f16x8 = tgnn_f16x8;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+
+constexpr int kEgRootBit = 1 << 8, kEgSkip = 1 << 9;      // meta = type | root << 8 (graph_prep.hip: kEgRoot)
+constexpr int kEgExtraLog2 = 5;                             // h . sx < 2^10: 32 products with weights below 1 stay below 2^15
+
+// a = x . s (s a power of two: exact) -> fp16 pair hi = RN16(a), lo = RN16(a - hi); 5 instructions per two values
+// (v_pk_mul_f32, v_cvt_pk_f16_f32, 2 x v_fma_mix_f32 reading hi as fp16, v_cvt_pk_f16_f32)
+__device__ __forceinline__ void split_pair_f16(float x0, float x1, float s, unsigned &hi, unsigned &lo) {
+    const float a0 = x0 * s, a1 = x1 * s;
+    using h2 = __attribute__((ext_vector_type(2))) _Float16;
+    h2 hv;
+    hv[0] = (_Float16)a0;
+    hv[1] = (_Float16)a1;
+    hi = __builtin_bit_cast(unsigned, hv);
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi), "v"(a0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi), "v"(a1));
+    h2 lv;
+    lv[0] = (_Float16)l0;
+    lv[1] = (_Float16)l1;
+    lo = __builtin_bit_cast(unsigned, lv);
+}
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+
+template <int WAVES, int OCC>
+__global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_eg_kernel(
+    const float *__restrict__ h, const int *__restrict__ tile_grp_ptr, const int *__restrict__ grp_src,
+    const int *__restrict__ grp_sm, const float *__restrict__ wimg, int n_types, const float *__restrict__ bias, int64_t n,
+    int act, float *__restrict__ out, double *__restrict__ bn_partial, const unsigned *__restrict__ h_max,
+    const unsigned *__restrict__ root_max, unsigned long long *__restrict__ stamp) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (stamp && threadIdx.x == 0) atomicMin(stamp, wall_clock64());
+    constexpr int kTy = kWtTypeF16;                         // floats of one type's image
+    float *wl = lds;                                        // [(T+1)][2 planes][2 N blocks][4][16] x 8 fp16
+    f16x4 *lut = reinterpret_cast<f16x4 *>(lds + (n_types + 1) * kTy);   // [16]: 4 selection bits -> 4 fp16 of 0 / 1
+    const float sx = pow2_scale_for(*h_max, kEgExtraLog2);
+    const float unscale = 1.0f / (sx * nnconv_weight_scale(*root_max) * kEgImageScale);   // (powers of two: exact)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fj = lane & 15, fq = lane >> 4;
+    constexpr int kThreads = WAVES * 64;
+    {   // weight image: straight copy, all loads of a thread issued before the first LDS store
+        const int n4 = (n_types + 1) * kTy / 4;
+        for (int i = tid; i < n4; i += 4 * kThreads) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ii = i + u * kThreads < n4 ? i + u * kThreads : n4 - 1;
+                v[u] = reinterpret_cast<const float4 *>(wimg)[ii];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i + u * kThreads < n4) reinterpret_cast<float4 *>(wl)[i + u * kThreads] = v[u];
+        }
+        if (tid < 16) {
+            f16x4 e;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) e[b] = (tid >> b & 1) ? (_Float16)1.0f : (_Float16)0.0f;
+            lut[tid] = e;
+        }
+    }
+
+    // ---- this wave's run of 16-row tiles (as nnconv_cols.hip: shares follow the XCD, the block, the SIMD)
+    static_assert(WAVES % 4 == 0, "whole SIMD quads");
+    const int64_t n_tiles = (n + 15) / 16;
+    const int nblk = gridDim.x;
+    int64_t blk = blockIdx.x;
+    if (nblk >= 8 && (nblk & 7) == 0) blk = (int64_t)(blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    const int64_t slot = blk * 4 + (wave & 3), n_slots = (int64_t)nblk * 4;
+    const int64_t q0 = n_tiles * slot / n_slots, q1 = n_tiles * (slot + 1) / n_slots;
+    constexpr int kSubs = WAVES / 4;
+    const int sub = wave >> 2;
+    const int64_t t0 = q0 + (q1 - q0) * sub / kSubs, t1 = q0 + (q1 - q0) * (sub + 1) / kSubs;
+    const int cbeg = __builtin_amdgcn_readfirstlane(tile_grp_ptr[t0]);
+    const int cend = __builtin_amdgcn_readfirstlane(tile_grp_ptr[t1]);
+
+    const float bias0 = bias[fj], bias1 = bias[16 + fj];
+    // BN partial sums of this lane: channel 16 m + fj over the rows 4 fq .. 4 fq + 3 of every tile
+    double bs[2] = {0, 0}, bq[2] = {0, 0};
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t h_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(h), 0, (int)0x80000000u, 0x00020000);   // 2 GB window
+    const uint32_t fq_bytes = (uint32_t)fq * 32u;
+    auto load_four = [&](int p, int &s4, int &m4) {         // groups p .. p+3: lane (fj, fq) <- group p + fq, word fj
+        const int pc = p < cend ? p : cbeg;                  // (reads past cend stay inside the slack)
+        s4 = grp_src[(int64_t)pc * 16 + lane];
+        m4 = grp_sm[(int64_t)pc * 16 + lane];
+    };
+    // group u of a four: s = source of slot fj, m = row fj's mask, meta (wave-uniform) = type | root << 8
+    auto unpack = [&](auto steady, int p, int u, int s4, int m4, int &s, int &m, int &meta) {
+        s = __shfl(s4, u * 16 + fj, 64);
+        m = __shfl(m4, u * 16 + fj, 64);
+        meta = __builtin_amdgcn_readlane(m4, u * 16) >> 16;
+        if constexpr (!decltype(steady)::value)
+            if (p + u >= cend) {                             // wave-uniform
+                s = -1;
+                meta = kEgSkip;
+            }
+    };
+    int64_t gtile = t0;                                     // tile of the group the gather stage is at
+    auto own_off_of = [&](int64_t tile) -> uint32_t {
+        const int64_t r = tile * 16 + fj;
+        return r < n ? (uint32_t)r * 128u + fq_bytes : 0x80000000u;
+    };
+    uint32_t own_off = own_off_of(gtile);
+    auto issue_gather = [&](int s, int meta, float4 (&x)[2]) {
+        const bool root = (meta & kEgRootBit) != 0;          // wave-uniform
+        const uint32_t off = root ? own_off : ((uint32_t)s << 7) + fq_bytes;   // s = -1: beyond the window, loads zeros
+        x[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, off, 0, 0));
+        x[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, off + 16u, 0, 0));
+        if (root) {
+            ++gtile;
+            own_off = own_off_of(gtile);
+        }
+    };
+
+    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;               // out tile: rows 4 fq + r, channel fj (d0) and 16 + fj (d1)
+    int64_t ctile = t0;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto consume = [&](auto steady, int s, int m, int meta, const float4 (&x)[2]) {
+        if constexpr (!decltype(steady)::value)
+            if (meta & kEgSkip) return;                      // wave-uniform
+        const int t = meta & 0xff;
+        unsigned xh0, xh1, xh2, xh3, xl0, xl1, xl2, xl3;
+        split_pair_f16(x[0].x, x[0].y, sx, xh0, xl0);
+        split_pair_f16(x[0].z, x[0].w, sx, xh1, xl1);
+        split_pair_f16(x[1].x, x[1].y, sx, xh2, xl2);
+        split_pair_f16(x[1].z, x[1].w, sx, xh3, xl3);
+        const f16x8 gh = __builtin_bit_cast(f16x8, u32x4{xh0, xh1, xh2, xh3}), gl = __builtin_bit_cast(f16x8, u32x4{xl0, xl1, xl2, xl3});
+        constexpr int kPl = kWtPlane / 4;                    // 16-byte fragments per plane
+        const f16x8 *wp = reinterpret_cast<const f16x8 *>(wl + t * kTy) + lane;      // lane order: conflict-free
+        const f16x8 h0 = wp[0], h1 = wp[64], l0 = wp[kPl], l1 = wp[kPl + 64];
+        f32x4 m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, l0, zero4, 0, 0, 0);   // hi . lo
+        f32x4 m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, l1, zero4, 0, 0, 0);
+        m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl, h0, m0, 0, 0, 0);           // lo . hi
+        m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl, h1, m1, 0, 0, 0);
+        m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, h0, m0, 0, 0, 0);           // hi . hi
+        m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, h1, m1, 0, 0, 0);
+        unsigned a00, a01, b00, b01, a10, a11, b10, b11;     // the messages as fp16 pairs (below 2^15 by the scales)
+        split_pair_f16(m0[0], m0[1], 1.0f, a00, b00);
+        split_pair_f16(m0[2], m0[3], 1.0f, a01, b01);
+        split_pair_f16(m1[0], m1[1], 1.0f, a10, b10);
+        split_pair_f16(m1[2], m1[3], 1.0f, a11, b11);
+        const u32x2 a0 = {a00, a01}, b0 = {b00, b01}, a1 = {a10, a11}, b1 = {b10, b11};
+        f16x4 sel = lut[(m >> (4 * fq)) & 15];               // S[row fj][edges 4 fq .. 4 fq + 3]
+        const bool root = (meta & kEgRootBit) != 0;          // wave-uniform
+        if (root) {                                          // S = diag(max(deg, 1)): s = its float bits for row fj
+            const _Float16 dg = (_Float16)__int_as_float(s);
+            sel = sel * dg;
+        }
+        d0 = __builtin_amdgcn_mfma_f32_16x16x16f16(sel, __builtin_bit_cast(f16x4, b0), d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x16f16(sel, __builtin_bit_cast(f16x4, b1), d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x16f16(sel, __builtin_bit_cast(f16x4, a0), d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x16f16(sel, __builtin_bit_cast(f16x4, a1), d1, 0, 0, 0);
+        if (root) {
+            // end of the tile
+            double s0 = 0, s1 = 0, z0 = 0, z1 = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int dg = __shfl(s, 4 * fq + r, 64);    // row 4 fq + r's word (-1: row >= n)
+                const bool valid = dg >= 0;
+                const float inv = unscale * __builtin_amdgcn_rcpf(__int_as_float(dg));
+                float o0 = fmaf(d0[r], inv, bias0);
+                float o1 = fmaf(d1[r], inv, bias1);
+                if (act == TGNN_ACT_LEAKY_RELU) {
+                    o0 = leakyf_(o0);
+                    o1 = leakyf_(o1);
+                }
+                const int64_t v = ctile * 16 + 4 * fq + r;
+                if (valid) {
+                    out[v * 32 + fj] = o0;
+                    out[v * 32 + 16 + fj] = o1;
+                    s0 += (double)o0; z0 += (double)o0 * (double)o0;
+                    s1 += (double)o1; z1 += (double)o1 * (double)o1;
+                }
+            }
+            bs[0] += s0; bq[0] += z0;
+            bs[1] += s1; bq[1] += z1;
+            d0 = zero4;
+            d1 = zero4;
+            ++ctile;
+        }
+    };
+
+    // ---- the group stream, four groups at a time: a four's index words are fetched two rounds ahead, its gathers one
+    int s4n, m4n;
+    int xs[4], xm[4], xt[4];
+    float4 x[4][2];
+    {
+        int s4, m4;
+        load_four(cbeg, s4, m4);
+        load_four(cbeg + 4, s4n, m4n);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            unpack(std::false_type{}, cbeg, u, s4, m4, xs[u], xm[u], xt[u]);
+            issue_gather(xs[u], xt[u], x[u]);
+        }
+    }
+    int base = cbeg;
+    for (; base + 8 <= cend; base += 4) {                    // steady state: the four gathered in this round lies before cend
+        int s4c, m4c;
+        load_four(base + 8, s4c, m4c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            consume(std::true_type{}, xs[u], xm[u], xt[u], x[u]);
+            unpack(std::true_type{}, base + 4, u, s4n, m4n, xs[u], xm[u], xt[u]);
+            issue_gather(xs[u], xt[u], x[u]);
+        }
+        s4n = s4c;
+        m4n = m4c;
+    }
+    for (; base < cend; base += 4) {
+        int s4c, m4c;
+        load_four(base + 8, s4c, m4c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            consume(std::false_type{}, xs[u], xm[u], xt[u], x[u]);
+            unpack(std::false_type{}, base + 4, u, s4n, m4n, xs[u], xm[u], xt[u]);
+            issue_gather(xs[u], xt[u], x[u]);
+        }
+        s4n = s4c;
+        m4n = m4c;
+    }
+
+    // ---- BN partials of the block: lanes (fj, fq) -> channel 16 m + fj; fold fq, then the waves, in fixed order
+    if (bn_partial) {
+        __syncthreads();                                     // everybody is done with the weight image
+        double *red = reinterpret_cast<double *>(lds);       // [WAVES][64 lanes][4]
+        double *mine = red + ((int64_t)wave * 64 + lane) * 4;
+        mine[0] = bs[0]; mine[1] = bs[1]; mine[2] = bq[0]; mine[3] = bq[1];
+        __syncthreads();
+        if (tid < 64) {                                      // tid = which * 32 + channel
+            const int which = tid >> 5, ch = tid & 31, m2 = ch >> 4, j = ch & 15;
+            double acc = 0;
+            for (int w = 0; w < WAVES; ++w)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc += red[((int64_t)w * 64 + q * 16 + j) * 4 + which * 2 + m2];
+            bn_partial[(int64_t)blockIdx.x * 64 + tid] = acc;
+        }
+    }
+    if (stamp && tid == 0) atomicMax(stamp + 1, wall_clock64());
+}
+
+static size_t eg_lds_bytes(int n_types, int waves) {
+    const size_t a = (size_t)(n_types + 1) * kWtTypeF16 * sizeof(float) + 16 * 8;
+    const size_t b = (size_t)waves * 64 * 4 * sizeof(double);
+    return a > b ? a : b;
+}
+
+constexpr size_t kEgMaxLds = 160 * 1024 - 256;
+
+int launch_nnconv_eg(const float *h, const int32_t *tile_grp_ptr, const int32_t *grp_src, const int32_t *grp_sm,
+                     const float *wimg, int32_t n_types, const float *bias, int64_t n_nodes, int32_t act, float *out,
+                     double *bn_partial, int32_t *n_partials_host, hipStream_t s, const unsigned *h_max, const unsigned *root_max,
+                     unsigned long long *stamp) {
+    constexpr int WAVES = 16;
+    auto kern = nnconv32_eg_kernel<WAVES, 4>;
+    static LdsOptIn site;
+    TGNN_CHECK_HIP(opt_in_dynamic_lds(kern, (int)kEgMaxLds, site));
+    const int64_t n_tiles = (n_nodes + 15) / 16;
+    constexpr int tiles_per_block = 4;
+    int64_t blocks = (n_tiles + tiles_per_block - 1) / tiles_per_block;
+    constexpr int reserve = 32;                              // (CUs left to the collision chain: nnconv_cols.hip)
+    int64_t cap = cus_minus(reserve);
+    if (const int dbg = g_debug_block_cap[0].load(); dbg > 0) cap = dbg < device_cus() ? dbg : device_cus();
+    if (blocks > cap) blocks = cap;
+    if (blocks >= 8) blocks &= ~7;
+    if (blocks < 1) blocks = 1;
+    kern<<<(unsigned)blocks, WAVES * 64, eg_lds_bytes(n_types, WAVES), s>>>(h, tile_grp_ptr, grp_src, grp_sm, wimg, n_types, bias,
+                                                                            n_nodes, act, out, bn_partial, h_max, root_max, stamp);
+    if (n_partials_host) *n_partials_host = (int32_t)blocks;
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}
+
+}  // namespace tgnn
+
+using namespace tgnn;
+
+extern "C" int tgnn_nnconv_mean_eg_fwd(const float *h, int64_t ldh, int64_t n_src_rows, const int32_t *tile_grp_ptr,
+                                       const int32_t *grp_src, const int32_t *grp_sm, const float *wtab, int32_t n_types,
+                                       const float *root, const float *bias, int64_t n_nodes, int32_t act, float *out,
+                                       float *wimg_scratch, uint32_t *bounds_scratch, double *bn_partial,
+                                       int32_t *n_partials_host, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
+    TGNN_CHECK_ARG(n_nodes >= 1 && n_src_rows >= n_nodes, "shape");
+    TGNN_CHECK_ARG(act == TGNN_ACT_NONE || act == TGNN_ACT_LEAKY_RELU, "activation");
+    TGNN_CHECK_ARG(h && tile_grp_ptr && grp_src && grp_sm && root && bias && out && wimg_scratch && bounds_scratch, "null pointer");
+    TGNN_CHECK_ARG(n_types == 0 || wtab, "null weight table");
+    TGNN_CHECK_ARG(ldh == 32 && ((uintptr_t)h % 16) == 0 && ((uintptr_t)wimg_scratch % 16) == 0 && ((uintptr_t)root % 16) == 0,
+                   "alignment / packed rows");
+    TGNN_CHECK_ARG(n_src_rows * 128 < ((int64_t)1 << 31), "source rows must lie within 2 GB of h");
+    if ((size_t)(n_types + 1) * kWtTypeF16 * sizeof(float) + 16 * 8 > kEgMaxLds) {
+        set_error("tgnn_nnconv_mean_eg_fwd: %d edge types do not fit the LDS weight image", n_types);
+        return TGNN_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // bounds: [0] = max |h| over every row that can be gathered, [1] = max |root|
+    launch_forward_scales(bounds_scratch, 2, &root, 1, bounds_scratch + 1, nullptr, 0, nullptr, s);
+    launch_absmax(h, n_src_rows * 32, bounds_scratch, s);
+    launch_nnconv_weight_image(wtab, &root, n_types, 1, wimg_scratch, s, bounds_scratch + 1, kEgImageScale);
+    return launch_nnconv_eg(h, tile_grp_ptr, grp_src, grp_sm, wimg_scratch, n_types, bias, n_nodes, act, out, bn_partial,
+                            n_partials_host, s, bounds_scratch, bounds_scratch + 1, nullptr);
+}

@@ -391,7 +391,8 @@ unsigned edge_weight_table_blocks(int n_types, int fe, int depth, int c, bool im
 void launch_edge_weight_table_batched(const float *edge_attr, const int *type_rep_edge, int n_types, int fe,
                                       const EdgeMlpLayers &layers, int depth, int c, float *wtab, const float *const *roots,
                                       float *wimg_all, hipStream_t s, unsigned *done_ctr = nullptr,
-                                      const unsigned *root_max = nullptr);
+                                      const unsigned *root_max = nullptr, float img_scale = 1.0f);
+// img_scale (a power of two): on top of nnconv_weight_scale in the fp16-pair images -- kEgImageScale for the edge-group kernel
 // root_max (device, [depth] words = max |root_i| as float bits, forward_scales below): the images are fp16-pair images
 // [(T+1)][kWtTypeF16] instead.
 // Bounds of a forward's fp16-pair operands in one launch behind a memset: words [0, n_zero) = 0 (the slots' maxima, filled by the
@@ -401,7 +402,8 @@ void launch_forward_scales(unsigned *words, int n_zero, const float *const *root
 // NNConv B-operand weight images [(T+1)][1152] for `depth` layers (roots[i] = layer i's root matrix); nnconv.hip
 // (root_max given -- [depth] words, max |root_i| as float bits: fp16-pair images [(T+1)][kWtTypeF16] instead)
 void launch_nnconv_weight_image(const float *wtab_all, const float *const *roots, int n_types, int depth,
-                                float *wimg_all, hipStream_t s, const unsigned *root_max = nullptr);
+                                float *wimg_all, hipStream_t s, const unsigned *root_max = nullptr, float img_scale = 1.0f);
+constexpr float kEgImageScale = 1.0f / 32768.0f;   // nnconv_eg.hip: every weight below 1, so that 32 products of < 2^10 stay below 2^15
 // h_max + root_max given (device words, float bits: max |h|, max |root|) with max_in_degree >= 1: wimg is an fp16-pair image and
 // the kernel runs the 3-term fp16 split (operands scaled by powers of two from the bounds); else the bf16 x 3 image / split
 int launch_nnconv_cols(const float *h, int64_t ldh, const int32_t *tile_col_ptr, const int32_t *col_meta,
@@ -409,6 +411,12 @@ int launch_nnconv_cols(const float *h, int64_t ldh, const int32_t *tile_col_ptr,
                        int64_t n_nodes, int32_t act, float *out, double *bn_partial, int32_t *n_partials_host,
                        hipStream_t s, const unsigned *h_max = nullptr, const unsigned *root_max = nullptr,
                        int max_in_degree = 0, unsigned long long *stamp = nullptr);
+// the same NNConv over the edge-group structure (graph_prep.hip: nnconv_eg_kernel; nnconv_eg.hip): fp16-pair images and bounds as
+// above, no in-degree needed (nothing is summed before the split)
+int launch_nnconv_eg(const float *h, const int32_t *tile_grp_ptr, const int32_t *grp_src, const int32_t *grp_sm,
+                     const float *wimg, int32_t n_types, const float *bias, int64_t n_nodes, int32_t act, float *out,
+                     double *bn_partial, int32_t *n_partials_host, hipStream_t s, const unsigned *h_max, const unsigned *root_max,
+                     unsigned long long *stamp = nullptr);
 // largest |h[0 .. n_floats)| (n_floats % 4 == 0) as float bits, atomicMax into *max_bits; bn_merge.hip
 void launch_absmax(const float *h, int64_t n_floats, unsigned *max_bits, hipStream_t s);
 // max |W_k| and a bound of |BN(v)| from the BatchNorm's parameters alone (nnconv.hip: dense_bounds_kernel), atomicMax into

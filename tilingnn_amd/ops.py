@@ -143,6 +143,32 @@ def build_nnconv_columns(n_nodes: int, n_edges: int, n_types: int, rowptr: Tenso
     return cols
 
 
+@dataclass
+class NNConvGroups:
+    """Per-16-row tiles of edge groups: up to 16 in-edges of one type per group (tgnn_nnconv_eg_build, include/tgnn.h)."""
+    tile_grp_ptr: Tensor      # int32 [ceil(N/16) + 1]
+    grp_src: Tensor           # int32 [16 * cap]: source row of slot k, -1 = none; root groups: float bits of max(deg,1)
+    grp_sm: Tensor            # int32 [16 * cap]: word j = mask of the slots that end in row j | (type | root << 8) << 16
+
+
+def build_nnconv_groups(n_nodes: int, n_edges: int, n_types: int, rowptr: Tensor, col_src: Tensor,
+                        col_type: Tensor) -> Optional[NNConvGroups]:
+    """None when the layout has more edge types than the structure takes."""
+    if n_types > lib.tgnn_nnconv_cols_max_types() or n_types > 40:
+        return None
+    dev = rowptr.device
+    cap = int(lib.tgnn_nnconv_eg_max_groups(n_nodes, n_edges, n_types))
+    ntiles = (n_nodes + 15) // 16
+    grp = NNConvGroups(torch.empty(ntiles + 1, dtype=torch.int32, device=dev),
+                       torch.empty(cap * 16, dtype=torch.int32, device=dev),
+                       torch.empty(cap * 16, dtype=torch.int32, device=dev))
+    ws_bytes = lib.tgnn_nnconv_cols_workspace_bytes(n_nodes)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    check(lib.tgnn_nnconv_eg_build(ptr(rowptr), ptr(col_src), ptr(col_type), n_nodes, n_types,
+                                   ptr(grp.tile_grp_ptr), ptr(grp.grp_src), ptr(grp.grp_sm), ptr(ws), ws_bytes, _stream(rowptr)))
+    return grp
+
+
 def _check_edge_index(ei: Tensor, name: str) -> Tensor:
     _need_gpu(ei, name)
     if ei.dtype != torch.int64:
@@ -365,6 +391,19 @@ def nnconv_mean(h: Tensor, graph: PreparedGraph, wtab: Tensor, root: Tensor, bia
     out = torch.empty(n, c, dtype=torch.float32, device=h.device)
     npart = C.c_int32(0)
     wt = _f32c(wtab, "wtab")
+    if kernel == "eg":
+        grp = graph.__dict__.get("_eg")
+        if grp is None:
+            grp = graph.__dict__["_eg"] = build_nnconv_groups(n, graph.n_adj_edges, graph.n_types, graph.adj_rowptr,
+                                                               graph.adj_src, graph.adj_type)
+        if grp is None or c != 32:
+            raise ValueError("the edge-group kernel needs <= 40 edge types and width 32")
+        wimg = torch.empty(lib.tgnn_nnconv_weight_image_floats(graph.n_types), dtype=torch.float32, device=h.device)
+        bounds = torch.empty(2, dtype=torch.int32, device=h.device)
+        check(lib.tgnn_nnconv_mean_eg_fwd(ptr(h), c, int(h.shape[0]), ptr(grp.tile_grp_ptr), ptr(grp.grp_src), ptr(grp.grp_sm),
+                                          ptr(wt), graph.n_types, ptr(_f32c(root, "root")), ptr(_f32c(bias, "bias")), n, act,
+                                          ptr(out), ptr(wimg), ptr(bounds), ptr(partials), C.byref(npart), _stream(h)))
+        return out, npart.value
     tl = graph.cols
     if kernel == "cols_f16":
         if tl is None or c != 32:
