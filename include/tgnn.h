@@ -169,18 +169,17 @@ int tgnn_nnconv_mean_cols_f16_fwd(const float *h, int64_t ldh, int64_t n_src_row
  * real layouts, a group ~70 %); the rows of a group are multiplied by the type's matrix and folded into their destination
  * rows by a second matrix product with the group's 0 / 1 selection matrix.  The last group of a tile is the root group.
  *   tile_grp_ptr int32 [ceil(N/16)+1]   group range of every tile
- *   grp_src      int32 [16*n_groups]    source row of slot k, -1 = none; root group: float bits of max(in-degree, 1) of row k,
- *                                       -1 for rows >= N
- *   grp_sm       int32 [16*n_groups]    word j of a group: mask of the slots that end in row j | (type | root << 8) << 16
+ *   grp          int32 [2*16*n_groups]  (src, sm) pairs, 8-byte aligned.  src of slot k: source row, -1 = none; root group:
+ *                                       float bits of max(in-degree, 1) of row k, -1 for rows >= N.  sm of word j of a
+ *                                       group: mask of the slots that end in row j | (type | root << 8) << 16
  * n_groups <= tgnn_nnconv_eg_max_groups(N, E, T) (allocate for that many: the kernel reads index words past the end); workspace
  * of the build: tgnn_nnconv_cols_workspace_bytes(N).  tgnn_nnconv_mean_eg_fwd is the op for tests (bounds and the fp16-pair
  * weight image computed inside, as tgnn_nnconv_mean_cols_f16_fwd does); width 32, packed rows (ldh == 32). */
 int64_t tgnn_nnconv_eg_max_groups(int64_t n_nodes, int64_t n_edges, int32_t n_types);
 int tgnn_nnconv_eg_build(const int32_t *rowptr, const int32_t *col_src, const int32_t *col_type, int64_t n_nodes,
-                         int32_t n_types, int32_t *tile_grp_ptr, int32_t *grp_src, int32_t *grp_sm, void *ws, size_t ws_bytes,
-                         tgnn_stream_t stream);
+                         int32_t n_types, int32_t *tile_grp_ptr, int32_t *grp, void *ws, size_t ws_bytes, tgnn_stream_t stream);
 int tgnn_nnconv_mean_eg_fwd(const float *h, int64_t ldh, int64_t n_src_rows, const int32_t *tile_grp_ptr,
-                            const int32_t *grp_src, const int32_t *grp_sm, const float *wtab, int32_t n_types,
+                            const int32_t *grp, const float *wtab, int32_t n_types,
                             const float *root, const float *bias, int64_t n_nodes, int32_t act, float *out,
                             float *wimg_scratch, uint32_t *bounds_scratch, double *bn_partial, int32_t *n_partials_host,
                             tgnn_stream_t stream);
@@ -319,6 +318,10 @@ typedef struct tgnn_graph {
     /* NNConv batches of the mid-size persistent layer loop (tgnn_mid_entries_build; both NULL => the general schedule). */
     const int32_t *nn_mid_tile_nb;
     const uint32_t *nn_mid_ent;
+    /* NNConv edge-group structure (tgnn_nnconv_eg_build; both NULL => the type columns, or the CSR kernel, are used).  The
+     * general schedule of the fp32 width-32 forward prefers it (tgnn_set_nnconv_eg; in-degrees up to 2048). */
+    const int32_t *nn_tile_grp_ptr;
+    const int32_t *nn_grp;
 } tgnn_graph;
 
 size_t tgnn_forward_workspace_bytes(const tgnn_model_dims *dims, int64_t n_nodes, int32_t n_types);
@@ -492,6 +495,10 @@ int32_t tgnn_set_gin_mlp_f16(int32_t on);
  * instead of 5 launches in front of it.  BatchNorm statistics are all-reduced over the grid in a fixed order (bit-reproducible).
  * Default 3; returns the previous setting (an argument outside 0 .. 3 only queries). */
 int32_t tgnn_set_mid_tail(int32_t on);
+/* General schedule, width 32, fp16-pair operands: the NNConv over the layout's edge groups (csrc/nnconv_eg.hip) when the graph
+ * carries them, instead of over its type columns.  Default 1; returns the previous setting (an argument outside 0 .. 1 only
+ * queries). */
+int32_t tgnn_set_nnconv_eg(int32_t on);
 
 /* Small layouts (<= tgnn_graph_prep_small_max_nodes() nodes, <= ..._max_edges() edges per set): everything above --
  * tgnn_csr_build of both edge sets (self loops dropped from the collision set), tgnn_edge_type_dedup, the types in CSR
@@ -516,13 +523,16 @@ int tgnn_graph_prep_small(const int64_t *adj_edge_index, int64_t n_adj_edges, co
  * structure hold nothing usable, the caller goes through the separate calls (tgnn_edge_type_dedup has no such limit).  With
  * mid_tile_nb / mid_ent (both or none; sized as for tgnn_mid_entries_build) the batches of the mid-size layer loop are built
  * too: result[8..9] = that call's result words.  n_src_nodes >= n_nodes: sources may index rows behind the n_nodes destinations
- * (the halo rows of a shard, as in tgnn_csr_build); n_nodes on a single device. */
+ * (the halo rows of a shard, as in tgnn_csr_build); n_nodes on a single device.
+ * The NNConv structures: the type columns (tile_col_ptr, col_meta, col_slot_src: all three or none) and / or the edge groups
+ * (tile_grp_ptr + grp, sized by tgnn_nnconv_eg_max_groups with T = tgnn_nnconv_cols_max_types(): both or none; result[10] = 1:
+ * built); at least one of the two. */
 size_t tgnn_graph_prep_workspace_bytes(int64_t n_nodes, int64_t n_adj_edges, int64_t n_col_edges, int32_t fe);
 int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edges, const float *adj_edge_attr, int32_t fe,
                     const int64_t *col_edge_index, int64_t n_col_edges, int64_t n_nodes, int64_t n_src_nodes, int32_t *adj_rowptr,
                     int32_t *adj_src, int32_t *adj_eid, int32_t *adj_type, int32_t *edge_type, int32_t *type_rep_edge, int32_t *col_rowptr,
                     int32_t *col_src, int32_t *col_eid, int32_t *tile_col_ptr, int32_t *col_meta, int32_t *col_slot_src,
-                    int32_t *mid_tile_nb, uint32_t *mid_ent,
+                    int32_t *mid_tile_nb, uint32_t *mid_ent, int32_t *tile_grp_ptr, int32_t *grp,
                     void *ws, size_t ws_bytes, int32_t *result, tgnn_stream_t stream);
 #ifdef TGNN_DEBUG
 /* ---- test / experiment hooks: only in libtgnn_debug.so (make -C tilingnn_amd/csrc debug: the same sources with -DTGNN_DEBUG); the

@@ -40,9 +40,9 @@ scale = float(ref.abs().max())
 print(f"n={n} ea={ea} T={g.n_types} |ref|max {scale:.3f}")
 print(f"cols_f16 vs fp64: max abs {float((out_c.double() - ref).abs().max()):.3e}")
 print(f"eg       vs fp64: max abs {float((out_e.double() - ref).abs().max()):.3e}")
-grp = g.__dict__["_eg"]
+grp = ops.graph_groups(g)
 ng = int(grp.tile_grp_ptr[-1])
-nc = int(g.cols.tile_col_ptr[-1])
+nc = int(ops.graph_columns(g).tile_col_ptr[-1])
 ntile = (n + 15) // 16
 print(f"groups {ng} ({ng / ntile:.2f} per tile, fill {dst.numel() / max(ng - ntile, 1) / 16:.3f}); columns {nc} ({nc / ntile:.2f} per tile)")
 pc = part[:np_c].double().sum(0)

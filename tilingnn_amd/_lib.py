@@ -34,7 +34,8 @@ class Graph(C.Structure):
                 ("type_rep_edge", C.c_void_p), ("col_rowptr", C.c_void_p), ("col_src", C.c_void_p),
                 ("nn_tile_col_ptr", C.c_void_p), ("nn_col_meta", C.c_void_p), ("nn_col_src", C.c_void_p),
                 ("nn_max_in_degree", C.c_int32),
-                ("nn_mid_tile_nb", C.c_void_p), ("nn_mid_ent", C.c_void_p)]
+                ("nn_mid_tile_nb", C.c_void_p), ("nn_mid_ent", C.c_void_p),
+                ("nn_tile_grp_ptr", C.c_void_p), ("nn_grp", C.c_void_p)]
 
 
 class TrainSave(C.Structure):
@@ -96,8 +97,8 @@ def _load() -> C.CDLL:
         "tgnn_nnconv_mean_cols_fwd": (C.c_int, [p, i64, p, p, p, p, i32, p, p, i64, i32, i32, p, p, p, pi32, p]),
         "tgnn_nnconv_mean_cols_f16_fwd": (C.c_int, [p, i64, i64, p, p, p, p, i32, p, p, i64, i32, i32, p, p, p, p, pi32, p]),
         "tgnn_nnconv_eg_max_groups": (i64, [i64, i64, i32]),
-        "tgnn_nnconv_eg_build": (C.c_int, [p, p, p, i64, i32, p, p, p, p, sz, p]),
-        "tgnn_nnconv_mean_eg_fwd": (C.c_int, [p, i64, i64, p, p, p, p, i32, p, p, i64, i32, p, p, p, p, pi32, p]),
+        "tgnn_nnconv_eg_build": (C.c_int, [p, p, p, i64, i32, p, p, p, sz, p]),
+        "tgnn_nnconv_mean_eg_fwd": (C.c_int, [p, i64, i64, p, p, p, i32, p, p, i64, i32, p, p, p, p, pi32, p]),
         "tgnn_ubench_row_gather": (C.c_int, [i32, p, i64, p, i32, i32, C.POINTER(C.c_double), p]),
         "tgnn_mid_entries_words": (i64, [i64]),
         "tgnn_mid_entries_build": (C.c_int, [p, p, p, i64, p, p, p, p, p]),
@@ -137,7 +138,8 @@ def _load() -> C.CDLL:
         "tgnn_graph_prep_small_tmp_ints": (sz, [i64, i64, i64]),
         "tgnn_graph_prep_small": (C.c_int, [p, i64, p, i32, p, i64, i64] + [p] * 15 + [p]),
         "tgnn_graph_prep_workspace_bytes": (sz, [i64, i64, i64, i32]),
-        "tgnn_graph_prep": (C.c_int, [p, i64, p, i32, p, i64, i64, i64] + [p] * 15 + [sz, p, p]),
+        "tgnn_graph_prep": (C.c_int, [p, i64, p, i32, p, i64, i64, i64] + [p] * 17 + [sz, p, p]),
+        "tgnn_set_nnconv_eg": (i32, [i32]),
         "tgnn_set_small_layout_limit": (None, [i64]),
         "tgnn_get_small_layout_limit": (i64, []),
         "tgnn_set_split_precision": (i32, [i32]),
@@ -226,7 +228,7 @@ EXPORTED_SYMBOLS = (
     "tgnn_spin_error_poll", "tgnn_set_spin_budget_us", "tgnn_persist_fallback", "tgnn_spin_error_peek", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_dense_act_slots_fwd", "tgnn_dense_act_slots_f16_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
     "tgnn_merge_fwd", "tgnn_param_count", "tgnn_param_name", "tgnn_forward_workspace_bytes", "tgnn_forward",
     "tgnn_forward_profiled", "tgnn_forward_profiled_two_stream", "tgnn_forward_stamped", "tgnn_forward_many", "tgnn_graph_prep_small_max_nodes", "tgnn_graph_prep_small_max_edges", "tgnn_graph_prep_small_tmp_ints",
-    "tgnn_graph_prep_small", "tgnn_graph_prep_workspace_bytes", "tgnn_graph_prep", "tgnn_set_small_layout_limit", "tgnn_get_small_layout_limit", "tgnn_set_split_precision", "tgnn_set_gin_fused", "tgnn_set_gin_mlp_f16", "tgnn_set_mid_tail", "tgnn_rccl_available", "tgnn_rccl_unique_id_bytes", "tgnn_rccl_unique_id", "tgnn_rccl_comm_create", "tgnn_rccl_comm_destroy", "tgnn_rccl_counters", "tgnn_forward_train", "tgnn_backward_workspace_bytes", "tgnn_backward", "tgnn_forward_sharded_workspace_bytes", "tgnn_forward_sharded",
+    "tgnn_graph_prep_small", "tgnn_graph_prep_workspace_bytes", "tgnn_graph_prep", "tgnn_set_small_layout_limit", "tgnn_get_small_layout_limit", "tgnn_set_split_precision", "tgnn_set_gin_fused", "tgnn_set_gin_mlp_f16", "tgnn_set_mid_tail", "tgnn_set_nnconv_eg", "tgnn_rccl_available", "tgnn_rccl_unique_id_bytes", "tgnn_rccl_unique_id", "tgnn_rccl_comm_create", "tgnn_rccl_comm_destroy", "tgnn_rccl_counters", "tgnn_forward_train", "tgnn_backward_workspace_bytes", "tgnn_backward", "tgnn_forward_sharded_workspace_bytes", "tgnn_forward_sharded",
     "tgnn_rows_gather", "tgnn_rows_scatter", "tgnn_unsupervised_loss_workspace_bytes", "tgnn_unsupervised_loss", "tgnn_solution_score_sums",
     "tgnn_sublayout_workspace_bytes", "tgnn_sublayout_compact", "tgnn_greedy_round_workspace_bytes", "tgnn_greedy_round", "tgnn_shard_alive_rows",
     "tgnn_transpose", "tgnn_swap_leading", "tgnn_gin_aggregate", "tgnn_sigmoid_bwd", "tgnn_add_into", "tgnn_reduce_workspace_bytes", "tgnn_colsum",

@@ -132,6 +132,7 @@ struct Prof {
 
 static const int kFinalDims[4] = {256, 128, 64, 0};  // TilinGNN.py:46 hidden_layer_dims; [3] = C
 static std::atomic<int> g_split_f16{1};              // tgnn_set_split_precision
+static std::atomic<int> g_nnconv_eg{1};              // tgnn_set_nnconv_eg
 static std::atomic<int64_t> g_path_count[3];          // forwards queued on the general schedule / small-layout kernel / mid-size kernel
 
 // n = rows this device computes; nr >= n = rows of the buffers that are GATHERED from (owned rows, then halo rows
@@ -183,6 +184,11 @@ extern "C" int tgnn_version(void) { return TGNN_VERSION; }
 extern "C" int32_t tgnn_set_split_precision(int32_t mode) {
     if (mode != 0 && mode != 1) return g_split_f16.load();
     return g_split_f16.exchange(mode);
+}
+
+extern "C" int32_t tgnn_set_nnconv_eg(int32_t on) {
+    if (on != 0 && on != 1) return g_nnconv_eg.load();
+    return g_nnconv_eg.exchange(on);
 }
 extern "C" const char *tgnn_last_error(void) { return g_err; }
 extern "C" void tgnn_forward_path_counts(int64_t *out3) {
@@ -375,9 +381,11 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     //      critical chain; the first NNConv waits for them.
     hipStream_t sw = s;
     constexpr bool weights_on_side = true;
-    const bool tiled = graph->nn_tile_col_ptr && c == 32 && (int64_t)nr * c * 4 < (int64_t(1) << 31);   // buffer-addressed gathers
+    const bool addr_ok = c == 32 && (int64_t)nr * c * 4 < (int64_t(1) << 31);   // buffer-addressed gathers
+    const bool cols_ok = graph->nn_tile_col_ptr && addr_ok;
+    const bool groups_ok = graph->nn_tile_grp_ptr && graph->nn_grp && addr_ok && graph->nn_max_in_degree <= 2048 && g_nnconv_eg;
     // Small layouts: the layer loop below is replaced by one persistent kernel (forward_small.hip)
-    const int small_teams = (tiled && !sh && !keep && !use_running_stats && !prof.on && nr == n) ? small_layout_teams(dims, n, T, graph->nn_max_in_degree) : 0;
+    const int small_teams = (cols_ok && !sh && !keep && !use_running_stats && !prof.on && nr == n) ? small_layout_teams(dims, n, T, graph->nn_max_in_degree) : 0;
     const int64_t cat_w_floats = (int64_t)c * (D + 1) * kFinalDims[0];
     const int fin_dims[5] = {c * (D + 1), kFinalDims[0], kFinalDims[1], kFinalDims[2], c};   // in / out widths of the final MLP's layers
     // fp16-pair operands (3 matrix terms instead of the 6 of bf16 x 3) wherever a bound of the operand is at hand: the kernels
@@ -387,7 +395,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     // leaves covers every row its NNConv gathers (the shards' scales may differ -- powers of two, taken off again: each
     // shard's results are as accurate as a single device's); the all-reduce + all-to-all scheme stays on bf16 x 3.
     const bool fused_shard = sh && sh->send_idx_fused && sh->recv_idx_fused && sh->world >= 1 && c == 32;
-    const bool f16 = g_split_f16 && tiled && (!sh || fused_shard) && !small_teams && !use_running_stats &&
+    const bool f16 = g_split_f16 && (cols_ok || groups_ok) && (!sh || fused_shard) && !small_teams && !use_running_stats &&
                      graph->nn_max_in_degree >= 1 && D <= kMaxDepth && (cat_w_floats % 4) == 0;
     unsigned *slot_max = f16 ? w.bounds : nullptr, *root_max = f16 ? w.bounds + D + 1 : nullptr,
              *dense_max = f16 ? w.bounds + 2 * D + 1 : nullptr;
@@ -402,6 +410,10 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     // ... and the final MLP behind it as one more persistent kernel (forward_tail.hip) instead of 5 + 4 launches
     int tail_blocks = 0;
     const int tail_k = mid_k ? mid_tail_tiles_per_block(dims, n, &tail_blocks) : 0;
+    // the NNConv of the general schedule over the layout's edge groups (nnconv_eg.hip) where the graph carries them; its
+    // operand images are the fp16-pair ones with one more power of two on the weights
+    const bool eg = f16 && groups_ok && !mid_k;
+    const bool tiled = cols_ok || eg;
     const bool mid_counter = mid_k && mid_blocks + 16 <= device_cus() && s2 && weights_on_side;
     // the init MLP in that kernel's prologue instead of 5 launches -- where the kernel starts beside the edge-weight kernel (with
     // a block on every CU it starts BEHIND it, a cross-queue event later, and the launches, which run beside it, win: measured at
@@ -432,7 +444,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         }
         prof.begin(0);
         launch_edge_weight_table_batched(adj_edge_attr, graph->type_rep_edge, T, fe, layers, D, c, w.wtab, tiled ? roots : nullptr,
-                                         tiled ? w.wimg : nullptr, sw, weights_done, root_max);
+                                         tiled ? w.wimg : nullptr, sw, weights_done, root_max, eg ? kEgImageScale : 1.0f);
         prof.end();
     }
     bool dimg_ok[3] = {false, false, false};
@@ -605,7 +617,11 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         }
         // GraphConv (:62): NNConv mean + LeakyReLU; BN statistics emitted as partials
         prof.begin(2);
-        if (tiled) {
+        if (eg) {
+            TGNN_TRY(launch_nnconv_eg(h1, graph->nn_tile_grp_ptr, graph->nn_grp, w.wimg + (size_t)i * (T + 1) * kWtTypeF16, T,
+                                      P.f(b + 7), n, TGNN_ACT_LEAKY_RELU, w.a1, w.part1, &np1, s, slot_max + i, root_max + i,
+                                      prof.stamps ? prof.stamps + 2 * i : nullptr));
+        } else if (tiled) {
             TGNN_TRY(launch_nnconv_cols(h1, c, graph->nn_tile_col_ptr, graph->nn_col_meta, graph->nn_col_src,
                                         w.wimg + (size_t)i * (T + 1) * (f16 ? kWtTypeF16 : kWtType), T, P.f(b + 7), n,
                                         TGNN_ACT_LEAKY_RELU, w.a1, w.part1, &np1, s, f16 ? slot_max + i : nullptr,

@@ -526,9 +526,10 @@ __global__ __launch_bounds__(64) void nnconv_col_kernel(const int *__restrict__ 
 // NNConv edge groups (nnconv_eg.hip): per 16 destination rows its in-edges sorted by (type, row, CSR order) and cut into
 // GROUPS of up to 16 edges of ONE type -- a gather instruction of the kernel fetches 16 source rows whatever rows of the
 // tile they go to (the type columns above fill 29 % of their slots at 10 edges over 13 types; groups 70 %).
-//   grp_src [16 * n_groups]: source row of slot k, -1 = none; in the root group (the last of a tile) the float bits of
-//                            max(in-degree, 1) of row k, -1 for rows >= N
-//   grp_sm  [16 * n_groups]: word j of a group = (mask of the slots that go to row j) | (type | root << 8) << 16
+//   grp [16 * n_groups] of (src, sm) pairs:
+//     src of slot k: source row, -1 = none; in the root group (the last of a tile) the float bits of max(in-degree, 1) of
+//                    row k, -1 for rows >= N
+//     sm of word j:  (mask of the slots that go to row j) | (type | root << 8) << 16
 // One block = 64 rows = 4 tiles, one thread per row.
 // ------------------------------------------------------------------------------------------
 constexpr int kEgRoot = 1 << 8;
@@ -538,11 +539,19 @@ __global__ __launch_bounds__(64) void nnconv_eg_kernel(const int *__restrict__ r
                                                        const int *__restrict__ col_type, int64_t n, int n_types_host,
                                                        int *__restrict__ tile_grps,            // !FILL: out, groups per tile
                                                        const int *__restrict__ tile_grp_ptr,   // FILL
-                                                       int *__restrict__ grp_src, int *__restrict__ grp_sm,
+                                                       int2 *__restrict__ grp,
                                                        const int *__restrict__ n_types_dev = nullptr, int max_types = kMaxColTypes,
-                                                       int *__restrict__ built_flag = nullptr) {
+                                                       int *__restrict__ built_flag = nullptr,
+                                                       const int *__restrict__ edge_type = nullptr,
+                                                       const int *__restrict__ col_eid = nullptr,
+                                                       int *__restrict__ col_type_out = nullptr) {
     const int n_types = n_types_dev ? *n_types_dev : n_types_host;
     const int64_t n_tiles = (n + kColTileRows - 1) / kColTileRows;
+    if (!FILL && col_type_out) {   // tgnn_graph_prep without the column structure: the types in CSR order are gathered here
+        const int64_t row0 = (int64_t)blockIdx.x * 64 + threadIdx.x;
+        if (row0 < n)
+            for (int e = rowptr[row0]; e < rowptr[row0 + 1]; ++e) col_type_out[e] = edge_type[col_eid[e]];
+    }
     if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) tile_grps[n_tiles] = 0;   // (the scan's last entry)
     const int tid = threadIdx.x, k = tid >> 4, i = tid & 15;
     const int64_t row = (int64_t)blockIdx.x * 64 + tid;
@@ -558,7 +567,11 @@ __global__ __launch_bounds__(64) void nnconv_eg_kernel(const int *__restrict__ r
     for (int t = 0; t < n_types; ++t) cnt[tid][t] = 0;
     int e0 = 0, e1 = 0;
     if (row < n) { e0 = rowptr[row]; e1 = rowptr[row + 1]; }
-    for (int e = e0; e < e1; ++e) cnt[tid][col_type[e]]++;
+    if (!FILL && col_type_out) {
+        for (int e = e0; e < e1; ++e) cnt[tid][col_type_out[e]]++;          // (this thread's own stores above)
+    } else {
+        for (int e = e0; e < e1; ++e) cnt[tid][col_type[e]]++;
+    }
     __syncthreads();
     for (int t = i; t < n_types; t += 16) {
         int acc = 0;
@@ -582,13 +595,10 @@ __global__ __launch_bounds__(64) void nnconv_eg_kernel(const int *__restrict__ r
     const int n_edge_grps = base[k][n_types];
     // thread i: slot i of every group's sources, and row i's word of every group
     for (int t = 0; t < n_types; ++t)
-        for (int g = base[k][t]; g < base[k][t + 1]; ++g) {
-            grp_src[(g0 + g) * 16 + i] = -1;
-            grp_sm[(g0 + g) * 16 + i] = t << 16;
-        }
+        for (int g = base[k][t]; g < base[k][t + 1]; ++g) grp[(g0 + g) * 16 + i] = make_int2(-1, t << 16);
     const int deg = e1 - e0;
-    grp_src[(g0 + n_edge_grps) * 16 + i] = row < n ? __float_as_int((float)(deg > 0 ? deg : 1)) : -1;
-    grp_sm[(g0 + n_edge_grps) * 16 + i] = (n_types | kEgRoot) << 16 | 1 << i;
+    grp[(g0 + n_edge_grps) * 16 + i] =
+        make_int2(row < n ? __float_as_int((float)(deg > 0 ? deg : 1)) : -1, (n_types | kEgRoot) << 16 | 1 << i);
     // the 16 threads of a tile are lanes of one wavefront: their -1 stores above are ordered before the sources below
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -598,14 +608,14 @@ __global__ __launch_bounds__(64) void nnconv_eg_kernel(const int *__restrict__ r
         const int p0 = pre[tid][t], p1 = p0 + c;                  // this row's slots of the type's sorted list
         for (int g = p0 >> 4; g <= (p1 - 1) >> 4; ++g) {
             const int lo = max(p0 - 16 * g, 0), hi = min(p1 - 16 * g, 16);
-            grp_sm[(g0 + base[k][t] + g) * 16 + i] = t << 16 | (((1 << hi) - 1) & ~((1 << lo) - 1));
+            grp[(g0 + base[k][t] + g) * 16 + i].y = t << 16 | (((1 << hi) - 1) & ~((1 << lo) - 1));
         }
         cnt[tid][t] = 0;
     }
     for (int e = e0; e < e1; ++e) {
         const int t = col_type[e];
         const int p = pre[tid][t] + cnt[tid][t]++;
-        grp_src[(g0 + base[k][t] + (p >> 4)) * 16 + (p & 15)] = col_src[e];
+        grp[(g0 + base[k][t] + (p >> 4)) * 16 + (p & 15)].x = col_src[e];
     }
 }
 
@@ -1535,26 +1545,28 @@ extern "C" int64_t tgnn_nnconv_eg_max_groups(int64_t n_nodes, int64_t n_edges, i
     return (a < b ? a : b) + ntiles + 32;
 }
 
-static void launch_nnconv_eg_build(const int32_t *rowptr, const int32_t *col_src, const int32_t *col_type, int64_t n_nodes,
+// edge_type + col_eid given: the count pass also gathers the types into CSR order (col_type is then its OUTPUT)
+static void launch_nnconv_eg_build(const int32_t *rowptr, const int32_t *col_src, int32_t *col_type, int64_t n_nodes,
                                    int32_t n_types, const int *n_types_dev, int max_types, int32_t *tile_grps,
-                                   int32_t *tile_grp_ptr, int32_t *grp_src, int32_t *grp_sm, int *scan_ws, int *built_flag,
-                                   hipStream_t s) {
+                                   int32_t *tile_grp_ptr, int32_t *grp, int *scan_ws, int *built_flag, hipStream_t s,
+                                   const int32_t *edge_type = nullptr, const int32_t *col_eid = nullptr) {
     const int64_t nt16 = (n_nodes + kColTileRows - 1) / kColTileRows;
     const unsigned blocks = (unsigned)((n_nodes + 63) / 64);
     nnconv_eg_kernel<false><<<blocks, 64, 0, s>>>(rowptr, col_src, col_type, n_nodes, n_types, tile_grps, nullptr, nullptr,
-                                                  nullptr, n_types_dev, max_types, built_flag);
+                                                  n_types_dev, max_types, built_flag, edge_type, col_eid,
+                                                  edge_type ? col_type : nullptr);
     exclusive_scan_i32(tile_grps, tile_grp_ptr, nt16 + 1, scan_ws, s);
-    nnconv_eg_kernel<true><<<blocks, 64, 0, s>>>(rowptr, col_src, col_type, n_nodes, n_types, nullptr, tile_grp_ptr, grp_src,
-                                                 grp_sm, n_types_dev, max_types, nullptr);
+    nnconv_eg_kernel<true><<<blocks, 64, 0, s>>>(rowptr, col_src, col_type, n_nodes, n_types, nullptr, tile_grp_ptr,
+                                                 reinterpret_cast<int2 *>(grp), n_types_dev, max_types, nullptr);
 }
 
 extern "C" int tgnn_nnconv_eg_build(const int32_t *rowptr, const int32_t *col_src, const int32_t *col_type,
-                                    int64_t n_nodes, int32_t n_types, int32_t *tile_grp_ptr, int32_t *grp_src,
-                                    int32_t *grp_sm, void *ws, size_t ws_bytes, tgnn_stream_t stream) {
+                                    int64_t n_nodes, int32_t n_types, int32_t *tile_grp_ptr, int32_t *grp, void *ws,
+                                    size_t ws_bytes, tgnn_stream_t stream) {
     DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_nodes >= 1, "n_nodes");
     TGNN_CHECK_ARG(n_types >= 0 && n_types <= kMaxColTypes, "the NNConv edge-group structure supports at most 40 edge types");
-    TGNN_CHECK_ARG(rowptr && tile_grp_ptr && grp_src && grp_sm, "null pointer");
+    TGNN_CHECK_ARG(rowptr && tile_grp_ptr && grp && ((uintptr_t)grp % 8) == 0, "null / misaligned pointer");
     TGNN_CHECK_ARG(n_types == 0 || (col_src && col_type), "null CSR pointer");
     if (!ws || ws_bytes < tgnn_nnconv_cols_workspace_bytes(n_nodes)) {
         set_error("tgnn_nnconv_eg_build: workspace too small");
@@ -1565,8 +1577,8 @@ extern "C" int tgnn_nnconv_eg_build(const int32_t *rowptr, const int32_t *col_sr
     Carver cv(ws, ws_bytes);
     int *tile_grps = cv.take<int>(nt16 + 1);
     int *scan_ws = cv.take<int>(scan_ws_ints(nt16 + 1));
-    launch_nnconv_eg_build(rowptr, col_src, col_type, n_nodes, n_types, nullptr, kMaxColTypes, tile_grps, tile_grp_ptr, grp_src,
-                           grp_sm, scan_ws, nullptr, s);
+    launch_nnconv_eg_build(rowptr, col_src, const_cast<int32_t *>(col_type), n_nodes, n_types, nullptr, kMaxColTypes, tile_grps,
+                           tile_grp_ptr, grp, scan_ws, nullptr, s);
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
 }
@@ -1801,12 +1813,17 @@ extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edge
                                int32_t *adj_rowptr, int32_t *adj_src, int32_t *adj_eid, int32_t *adj_type, int32_t *edge_type,
                                int32_t *type_rep_edge,
                                int32_t *col_rowptr, int32_t *col_src, int32_t *col_eid, int32_t *tile_col_ptr, int32_t *col_meta,
-                               int32_t *col_slot_src, int32_t *mid_tile_nb, uint32_t *mid_ent, void *ws, size_t ws_bytes,
-                               int32_t *result, tgnn_stream_t stream) {
+                               int32_t *col_slot_src, int32_t *mid_tile_nb, uint32_t *mid_ent, int32_t *tile_grp_ptr, int32_t *grp,
+                               void *ws, size_t ws_bytes, int32_t *result, tgnn_stream_t stream) {
     DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_nodes >= 1 && fe >= 1 && n_adj_edges >= 0 && n_col_edges >= 0, "shape");
     TGNN_CHECK_ARG(n_src_nodes >= n_nodes && n_src_nodes < (1ll << 31) - 1, "n_src_nodes must be >= n_nodes and fit int32");
-    TGNN_CHECK_ARG(adj_rowptr && col_rowptr && tile_col_ptr && col_meta && col_slot_src && result, "null pointer");
+    const bool want_cols = tile_col_ptr != nullptr, want_eg = tile_grp_ptr != nullptr;
+    TGNN_CHECK_ARG(adj_rowptr && col_rowptr && result, "null pointer");
+    TGNN_CHECK_ARG(want_cols || want_eg, "no NNConv structure asked for (type columns and / or edge groups)");
+    TGNN_CHECK_ARG(!want_cols || (col_meta && col_slot_src), "type columns: tile_col_ptr, col_meta, col_slot_src go together");
+    TGNN_CHECK_ARG(!want_eg || (grp && ((uintptr_t)grp % 8) == 0), "edge groups: tile_grp_ptr and an 8-byte aligned grp go together");
+    TGNN_CHECK_ARG(want_cols || !(mid_tile_nb && mid_ent), "the mid-size batches are built from the type columns");
     if (!ws || ws_bytes < tgnn_graph_prep_workspace_bytes(n_nodes, n_adj_edges, n_col_edges, fe)) {
         set_error("tgnn_graph_prep: workspace too small");
         return TGNN_ERR_WORKSPACE;
@@ -1878,12 +1895,19 @@ extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edge
     const unsigned blocks = (unsigned)((n_nodes + 63) / 64);
     const int max_types = tgnn_nnconv_cols_max_types();
     // (the first pass also gathers the types into CSR order -- adj_type -- and writes every entry the scan reads)
-    nnconv_col_kernel<false><<<blocks, 64, 0, s>>>(adj_rowptr, adj_src, adj_type, n_nodes, 0, tile_cols, nullptr, nullptr, nullptr,
-                                                   result + 0, max_types, nullptr, n_adj_edges > 0 ? edge_type : nullptr, adj_eid,
-                                                   n_adj_edges > 0 ? adj_type : nullptr);
-    exclusive_scan_i32(tile_cols, tile_col_ptr, nt16 + 1, scan_ws, s);
-    nnconv_col_kernel<true><<<blocks, 64, 0, s>>>(adj_rowptr, adj_src, adj_type, n_nodes, 0, nullptr, tile_col_ptr, col_meta,
-                                                  col_slot_src, result + 0, max_types, result + 5);
+    if (want_cols) {
+        nnconv_col_kernel<false><<<blocks, 64, 0, s>>>(adj_rowptr, adj_src, adj_type, n_nodes, 0, tile_cols, nullptr, nullptr, nullptr,
+                                                       result + 0, max_types, nullptr, n_adj_edges > 0 ? edge_type : nullptr, adj_eid,
+                                                       n_adj_edges > 0 ? adj_type : nullptr);
+        exclusive_scan_i32(tile_cols, tile_col_ptr, nt16 + 1, scan_ws, s);
+        nnconv_col_kernel<true><<<blocks, 64, 0, s>>>(adj_rowptr, adj_src, adj_type, n_nodes, 0, nullptr, tile_col_ptr, col_meta,
+                                                      col_slot_src, result + 0, max_types, result + 5);
+    }
+    if (want_eg) {   // (behind the columns on the same stream: the same scratch; without them its first pass gathers the types)
+        const bool gather_types = !want_cols && n_adj_edges > 0;
+        launch_nnconv_eg_build(adj_rowptr, adj_src, adj_type, n_nodes, 0, result + 0, max_types, tile_cols, tile_grp_ptr, grp, scan_ws,
+                               result + 10, s, gather_types ? edge_type : nullptr, gather_types ? adj_eid : nullptr);
+    }
     TGNN_CHECK_LAUNCH();
     if (mid_tile_nb && mid_ent) {
         // the batches of the mid-size persistent layer loop (forward_mid.hip), straight from the columns; result[8..9]

@@ -51,8 +51,8 @@ using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 
 template <int WAVES, int OCC>
 __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_eg_kernel(
-    const float *__restrict__ h, const int *__restrict__ tile_grp_ptr, const int *__restrict__ grp_src,
-    const int *__restrict__ grp_sm, const float *__restrict__ wimg, int n_types, const float *__restrict__ bias, int64_t n,
+    const float *__restrict__ h, const int *__restrict__ tile_grp_ptr, const int2 *__restrict__ grp,
+    const float *__restrict__ wimg, int n_types, const float *__restrict__ bias, int64_t n,
     int act, float *__restrict__ out, double *__restrict__ bn_partial, const unsigned *__restrict__ h_max,
     const unsigned *__restrict__ root_max, unsigned long long *__restrict__ stamp) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -110,8 +110,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_eg_kernel(
     const uint32_t fq_bytes = (uint32_t)fq * 32u;
     auto load_four = [&](int p, int &s4, int &m4) {         // groups p .. p+3: lane (fj, fq) <- group p + fq, word fj
         const int pc = p < cend ? p : cbeg;                  // (reads past cend stay inside the slack)
-        s4 = grp_src[(int64_t)pc * 16 + lane];
-        m4 = grp_sm[(int64_t)pc * 16 + lane];
+        const int2 v = grp[(int64_t)pc * 16 + lane];        // one 8-byte load: (source, mask | meta << 16)
+        s4 = v.x;
+        m4 = v.y;
     };
     // group u of a four: s = source of slot fj, m = row fj's mask, meta (wave-uniform) = type | root << 8
     auto unpack = [&](auto steady, int p, int u, int s4, int m4, int &s, int &m, int &meta) {
@@ -132,7 +133,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_eg_kernel(
     uint32_t own_off = own_off_of(gtile);
     auto issue_gather = [&](int s, int meta, float4 (&x)[2]) {
         const bool root = (meta & kEgRootBit) != 0;          // wave-uniform
+#ifdef TGNN_ABL_EGNOGATHER
+        const uint32_t off = 0x80000000u + (((uint32_t)s + own_off) & 0);   // (timing ablation: no row is fetched)
+#else
         const uint32_t off = root ? own_off : ((uint32_t)s << 7) + fq_bytes;   // s = -1: beyond the window, loads zeros
+#endif
         x[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, off, 0, 0));
         x[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, off + 16u, 0, 0));
         if (root) {
@@ -172,6 +177,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_eg_kernel(
         f16x4 sel = lut[(m >> (4 * fq)) & 15];               // S[row fj][edges 4 fq .. 4 fq + 3]
         const bool root = (meta & kEgRootBit) != 0;          // wave-uniform
         if (root) {                                          // S = diag(max(deg, 1)): s = its float bits for row fj
+            asm volatile("" ::: "memory");                   // (a real branch: one group in ~16 takes it)
             const _Float16 dg = (_Float16)__int_as_float(s);
             sel = sel * dg;
         }
@@ -224,6 +230,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_eg_kernel(
         }
     }
     int base = cbeg;
+#ifdef TGNN_ABL_EGNOLOOP
+    base = cend;                                             // (timing ablation: what a launch costs without its groups)
+#endif
     for (; base + 8 <= cend; base += 4) {                    // steady state: the four gathered in this round lies before cend
         int s4c, m4c;
         load_four(base + 8, s4c, m4c);
@@ -276,8 +285,7 @@ static size_t eg_lds_bytes(int n_types, int waves) {
 
 constexpr size_t kEgMaxLds = 160 * 1024 - 256;
 
-int launch_nnconv_eg(const float *h, const int32_t *tile_grp_ptr, const int32_t *grp_src, const int32_t *grp_sm,
-                     const float *wimg, int32_t n_types, const float *bias, int64_t n_nodes, int32_t act, float *out,
+int launch_nnconv_eg(const float *h, const int32_t *tile_grp_ptr, const int32_t *grp, const float *wimg, int32_t n_types, const float *bias, int64_t n_nodes, int32_t act, float *out,
                      double *bn_partial, int32_t *n_partials_host, hipStream_t s, const unsigned *h_max, const unsigned *root_max,
                      unsigned long long *stamp) {
     constexpr int WAVES = 16;
@@ -293,8 +301,9 @@ int launch_nnconv_eg(const float *h, const int32_t *tile_grp_ptr, const int32_t 
     if (blocks > cap) blocks = cap;
     if (blocks >= 8) blocks &= ~7;
     if (blocks < 1) blocks = 1;
-    kern<<<(unsigned)blocks, WAVES * 64, eg_lds_bytes(n_types, WAVES), s>>>(h, tile_grp_ptr, grp_src, grp_sm, wimg, n_types, bias,
-                                                                            n_nodes, act, out, bn_partial, h_max, root_max, stamp);
+    kern<<<(unsigned)blocks, WAVES * 64, eg_lds_bytes(n_types, WAVES), s>>>(h, tile_grp_ptr, reinterpret_cast<const int2 *>(grp), wimg,
+                                                                            n_types, bias, n_nodes, act, out, bn_partial, h_max, root_max,
+                                                                            stamp);
     if (n_partials_host) *n_partials_host = (int32_t)blocks;
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
@@ -305,14 +314,14 @@ int launch_nnconv_eg(const float *h, const int32_t *tile_grp_ptr, const int32_t 
 using namespace tgnn;
 
 extern "C" int tgnn_nnconv_mean_eg_fwd(const float *h, int64_t ldh, int64_t n_src_rows, const int32_t *tile_grp_ptr,
-                                       const int32_t *grp_src, const int32_t *grp_sm, const float *wtab, int32_t n_types,
+                                       const int32_t *grp, const float *wtab, int32_t n_types,
                                        const float *root, const float *bias, int64_t n_nodes, int32_t act, float *out,
                                        float *wimg_scratch, uint32_t *bounds_scratch, double *bn_partial,
                                        int32_t *n_partials_host, tgnn_stream_t stream) {
     DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_nodes >= 1 && n_src_rows >= n_nodes, "shape");
     TGNN_CHECK_ARG(act == TGNN_ACT_NONE || act == TGNN_ACT_LEAKY_RELU, "activation");
-    TGNN_CHECK_ARG(h && tile_grp_ptr && grp_src && grp_sm && root && bias && out && wimg_scratch && bounds_scratch, "null pointer");
+    TGNN_CHECK_ARG(h && tile_grp_ptr && grp && root && bias && out && wimg_scratch && bounds_scratch, "null pointer");
     TGNN_CHECK_ARG(n_types == 0 || wtab, "null weight table");
     TGNN_CHECK_ARG(ldh == 32 && ((uintptr_t)h % 16) == 0 && ((uintptr_t)wimg_scratch % 16) == 0 && ((uintptr_t)root % 16) == 0,
                    "alignment / packed rows");
@@ -326,6 +335,6 @@ extern "C" int tgnn_nnconv_mean_eg_fwd(const float *h, int64_t ldh, int64_t n_sr
     launch_forward_scales(bounds_scratch, 2, &root, 1, bounds_scratch + 1, nullptr, 0, nullptr, s);
     launch_absmax(h, n_src_rows * 32, bounds_scratch, s);
     launch_nnconv_weight_image(wtab, &root, n_types, 1, wimg_scratch, s, bounds_scratch + 1, kEgImageScale);
-    return launch_nnconv_eg(h, tile_grp_ptr, grp_src, grp_sm, wimg_scratch, n_types, bias, n_nodes, act, out, bn_partial,
+    return launch_nnconv_eg(h, tile_grp_ptr, grp, wimg_scratch, n_types, bias, n_nodes, act, out, bn_partial,
                             n_partials_host, s, bounds_scratch, bounds_scratch + 1, nullptr);
 }

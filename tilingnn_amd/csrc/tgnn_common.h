@@ -413,8 +413,7 @@ int launch_nnconv_cols(const float *h, int64_t ldh, const int32_t *tile_col_ptr,
                        int max_in_degree = 0, unsigned long long *stamp = nullptr);
 // the same NNConv over the edge-group structure (graph_prep.hip: nnconv_eg_kernel; nnconv_eg.hip): fp16-pair images and bounds as
 // above, no in-degree needed (nothing is summed before the split)
-int launch_nnconv_eg(const float *h, const int32_t *tile_grp_ptr, const int32_t *grp_src, const int32_t *grp_sm,
-                     const float *wimg, int32_t n_types, const float *bias, int64_t n_nodes, int32_t act, float *out,
+int launch_nnconv_eg(const float *h, const int32_t *tile_grp_ptr, const int32_t *grp, const float *wimg, int32_t n_types, const float *bias, int64_t n_nodes, int32_t act, float *out,
                      double *bn_partial, int32_t *n_partials_host, hipStream_t s, const unsigned *h_max, const unsigned *root_max,
                      unsigned long long *stamp = nullptr);
 // largest |h[0 .. n_floats)| (n_floats % 4 == 0) as float bits, atomicMax into *max_bits; bn_merge.hip

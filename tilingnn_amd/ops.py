@@ -73,6 +73,7 @@ class PreparedGraph:
     cols: Optional["NNConvColumns"] = None     # matrix-core NNConv column structure (None: CSR kernel is used)
     max_in_degree: int = 0                     # largest adjacency in-degree (0 = not known: no small-layout kernel)
     mid: Optional["NNConvBatches"] = None      # NNConv batches of the mid-size persistent layer loop (None: general schedule)
+    groups: Optional["NNConvGroups"] = None    # NNConv edge groups (layouts of the general schedule; None: the type columns are used)
 
     def c_struct(self) -> _lib.Graph:
         hit = self.__dict__.get("_c_struct")          # (the tensors of a prepared graph are never replaced)
@@ -81,13 +82,14 @@ class PreparedGraph:
         return hit
 
     def _build_c_struct(self) -> _lib.Graph:
-        t, st = self.cols, self.mid
+        t, st, gr = self.cols, self.mid, self.groups
         return _lib.Graph(self.n_nodes, self.n_adj_edges, self.n_col_edges, self.n_types,
                           self.adj_rowptr.data_ptr(), self.adj_src.data_ptr(), self.adj_type.data_ptr(),
                           self.type_rep_edge.data_ptr(), self.col_rowptr.data_ptr(), self.col_src.data_ptr(),
                           *((t.tile_col_ptr.data_ptr(), t.col_meta.data_ptr(), t.col_src.data_ptr())
                             if t is not None else (None,) * 3), self.max_in_degree,
-                          *((st.tile_nb.data_ptr(), st.ent.data_ptr()) if st is not None else (None,) * 2))
+                          *((st.tile_nb.data_ptr(), st.ent.data_ptr()) if st is not None else (None,) * 2),
+                          *((gr.tile_grp_ptr.data_ptr(), gr.grp.data_ptr()) if gr is not None else (None,) * 2))
 
 
 @dataclass
@@ -147,8 +149,8 @@ def build_nnconv_columns(n_nodes: int, n_edges: int, n_types: int, rowptr: Tenso
 class NNConvGroups:
     """Per-16-row tiles of edge groups: up to 16 in-edges of one type per group (tgnn_nnconv_eg_build, include/tgnn.h)."""
     tile_grp_ptr: Tensor      # int32 [ceil(N/16) + 1]
-    grp_src: Tensor           # int32 [16 * cap]: source row of slot k, -1 = none; root groups: float bits of max(deg,1)
-    grp_sm: Tensor            # int32 [16 * cap]: word j = mask of the slots that end in row j | (type | root << 8) << 16
+    grp: Tensor               # int32 [16 * cap, 2]: (source row of slot k, -1 = none; root groups: float bits of max(deg,1) |
+                              #                      word j: mask of the slots that end in row j | (type | root << 8) << 16)
 
 
 def build_nnconv_groups(n_nodes: int, n_edges: int, n_types: int, rowptr: Tensor, col_src: Tensor,
@@ -160,12 +162,11 @@ def build_nnconv_groups(n_nodes: int, n_edges: int, n_types: int, rowptr: Tensor
     cap = int(lib.tgnn_nnconv_eg_max_groups(n_nodes, n_edges, n_types))
     ntiles = (n_nodes + 15) // 16
     grp = NNConvGroups(torch.empty(ntiles + 1, dtype=torch.int32, device=dev),
-                       torch.empty(cap * 16, dtype=torch.int32, device=dev),
-                       torch.empty(cap * 16, dtype=torch.int32, device=dev))
+                       torch.empty(cap * 16, 2, dtype=torch.int32, device=dev))
     ws_bytes = lib.tgnn_nnconv_cols_workspace_bytes(n_nodes)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     check(lib.tgnn_nnconv_eg_build(ptr(rowptr), ptr(col_src), ptr(col_type), n_nodes, n_types,
-                                   ptr(grp.tile_grp_ptr), ptr(grp.grp_src), ptr(grp.grp_sm), ptr(ws), ws_bytes, _stream(rowptr)))
+                                   ptr(grp.tile_grp_ptr), ptr(grp.grp), ptr(ws), ws_bytes, _stream(rowptr)))
     return grp
 
 
@@ -222,6 +223,7 @@ def dedup_edge_types(edge_attr: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
 # 0.80 / 0.76, 2 500: 0.94 / 0.90, 5 000: 0.90 / 0.93, 10 000: 0.91 / 1.04, 20 000: 1.03 / 1.31, 100 000: 2.26 / 3.77
 # (scratch/cols_ab.py).  The knob stays for experiments and for the tests that pin the CSR kernel end to end.
 COLS_MIN_NODES = int(os.environ.get("TGNN_COLS_MIN_NODES", "0"))
+GROUPS = os.environ.get("TGNN_GROUPS", "1") != "0"     # layouts of the general schedule are prepared with NNConv edge groups
 
 
 def _small_prep_limits(_cache=[]):
@@ -259,7 +261,7 @@ def _read_back(res: Tensor):
 
 
 def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, small: bool,
-                         n_src_nodes: Optional[int] = None) -> Optional[PreparedGraph]:
+                         n_src_nodes: Optional[int] = None, groups: Optional[bool] = None) -> Optional[PreparedGraph]:
     """prepare_graph as ONE library call + the one sync: `small`: tgnn_graph_prep_small (one launch); else tgnn_graph_prep
     (the launches of the separate calls, queued by the library without a host round trip).  None = fall back."""
     ea, ec = int(adj.shape[1]), int(col.shape[1])
@@ -268,7 +270,6 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
     attr = _f32c(attr, "adj_e_features")
     dev = adj.device
     ntiles = (n_nodes + 15) // 16
-    cap = int(lib.tgnn_nnconv_cols_max_columns(n_nodes, ea))
     e1, c1 = max(ea, 1), max(ec, 1)
     fe = int(attr.shape[1])
     ws_ints = int(lib.tgnn_graph_prep_small_tmp_ints(n_nodes, ea, ec)) if small else \
@@ -276,10 +277,15 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
     lo_mid, hi_mid = mid_layout_range()
     want_mid = not small and n_src_nodes is None and lo_mid < n_nodes <= hi_mid
     mid_words = int(lib.tgnn_mid_entries_words(n_nodes)) if want_mid else 0
+    # layouts of the general schedule carry the NNConv edge groups INSTEAD of the type columns (whoever needs the other
+    # structure later builds it: graph_columns / graph_groups)
+    want_eg = not small and groups if groups is not None else (not small and GROUPS and n_nodes > hi_mid)
+    cap = 0 if want_eg else int(lib.tgnn_nnconv_cols_max_columns(n_nodes, ea))
+    gcap = int(lib.tgnn_nnconv_eg_max_groups(n_nodes, ea, lib.tgnn_nnconv_cols_max_types())) if want_eg else 0
     # the persistent outputs share ONE long-lived allocation; the scratch (CSR / de-dup tables, scan workspaces) and the result
     # words are tensors of their own, freed after the read-back -- a cached graph does not pin hundreds of MB of scratch
     sizes = [n_nodes + 1, e1, e1, e1, e1, e1, n_nodes + 1, c1, c1, ntiles + 1, cap, cap * 16,
-             ntiles if want_mid else 0, mid_words]
+             ntiles if want_mid else 0, mid_words, ntiles + 1 if want_eg else 0, gcap * 32]
     offs, at = [], 0
     for sz in sizes:
         offs.append(at)
@@ -287,31 +293,37 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
     buf = torch.empty(at, dtype=torch.int32, device=dev)
     v = [buf[o:o + sz] for o, sz in zip(offs, sizes)]
     (a_rowptr, a_src, a_eid, adj_type, edge_type, rep, c_rowptr, c_src, c_eid, tile_col_ptr, col_meta, col_slot_src,
-     mid_nb, mid_ent) = v
+     mid_nb, mid_ent, tile_grp_ptr, grp) = v
     res = torch.empty(32, dtype=torch.int32, device=dev)
     tmp = torch.empty(ws_ints, dtype=torch.int32, device=dev)
     head = (ptr(adj), ea, ptr(attr), fe, ptr(col), ec, n_nodes) + (() if small else (n_src_nodes or n_nodes,)) + (ptr(a_rowptr), ptr(a_src), ptr(a_eid), ptr(adj_type), ptr(edge_type),
-            ptr(rep), ptr(c_rowptr), ptr(c_src), ptr(c_eid), ptr(tile_col_ptr), ptr(col_meta), ptr(col_slot_src))
+            ptr(rep), ptr(c_rowptr), ptr(c_src), ptr(c_eid),
+            *((None,) * 3 if want_eg else (ptr(tile_col_ptr), ptr(col_meta), ptr(col_slot_src))))
     if small:
         check(lib.tgnn_graph_prep_small(*head, ptr(tmp), ptr(res), ptr(_small_prep_counters(dev)), _stream(adj)))
     else:
         mid_args = (ptr(mid_nb), ptr(mid_ent)) if want_mid else (None,) * 2
-        check(lib.tgnn_graph_prep(*head, *mid_args, ptr(tmp), ws_ints * 4, ptr(res), _stream(adj)))
+        eg_args = (ptr(tile_grp_ptr), ptr(grp)) if want_eg else (None,) * 2
+        check(lib.tgnn_graph_prep(*head, *mid_args, *eg_args, ptr(tmp), ws_ints * 4, ptr(res), _stream(adj)))
     host = _read_back(res)                                                       # the one sync
     if host[1] or host[2]:
         raise IndexError(f"edge index out of range [0, {n_nodes}) in {'adj_e_index' if host[1] else 'col_e_idx'}")
     if host[6]:
         return None
-    cols = NNConvColumns(tile_col_ptr, col_meta, col_slot_src) if host[5] else None
+    cols = NNConvColumns(tile_col_ptr, col_meta, col_slot_src) if host[5] and not want_eg else None
     mid = NNConvBatches(mid_nb, mid_ent) if want_mid and cols is not None and host[9] == 0 else None
+    groups_ = NNConvGroups(tile_grp_ptr, grp.view(-1, 2)) if want_eg and host[10] else None
     return PreparedGraph(n_nodes, ea, int(host[3]), int(host[0]), a_rowptr, a_src, a_eid, adj_type, edge_type, rep,
-                         c_rowptr, c_src, c_eid, cols, int(host[4]), mid)
+                         c_rowptr, c_src, c_eid, cols, int(host[4]), mid, groups_)
 
 
 def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col_e_idx: Tensor,
-                  tile_width: int = 32, n_src_nodes: Optional[int] = None, columns: Optional[bool] = None) -> PreparedGraph:
+                  tile_width: int = 32, n_src_nodes: Optional[int] = None, columns: Optional[bool] = None,
+                  groups: Optional[bool] = None) -> PreparedGraph:
     """Everything the 20 layers share: CSR of both edge sets, edge-type ids in CSR order, and (columns: None = for
-    layouts above COLS_MIN_NODES) the NNConv column structure.
+    layouts above COLS_MIN_NODES) the NNConv column structure -- or (groups: None = for layouts of the general schedule,
+    i.e. above the mid-size limit, when GROUPS is on) the NNConv edge groups in its place; `graph_columns` / `graph_groups`
+    build the other structure for whoever needs it.
     Synchronises once (the type count and the self-loop-free collision edge count are read back)."""
     adj = _check_edge_index(adj_e_index, "adj_e_index")
     col = _check_edge_index(col_e_idx, "col_e_idx")
@@ -321,7 +333,7 @@ def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col
     if SMALL_PREP and tile_width == 32 and columns in (None, True) and COLS_MIN_NODES == 0 and n_nodes >= 1:
         # (a shard's layout -- sources behind the destination rows -- goes through the any-size call)
         small = n_src_nodes is None and n_nodes <= _small_prep_limits()[0] and max(ea, ec) <= _small_prep_limits()[1]
-        g = _prepare_graph_fused(n_nodes, adj, adj_e_features, col, small, n_src_nodes)
+        g = _prepare_graph_fused(n_nodes, adj, adj_e_features, col, small, n_src_nodes, groups)
         if g is not None:
             return g
     a_rowptr, a_src, a_eid, a_err = build_csr(adj, n_nodes, False, n_src_nodes)
@@ -344,13 +356,37 @@ def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col
     n_types = int(host[0])
     if columns is None:
         columns = n_nodes > COLS_MIN_NODES
-    cols = build_nnconv_columns(n_nodes, ea, n_types, a_rowptr, a_src, adj_type) if tile_width == 32 and columns else None
-    mid = None
     lo_mid, hi_mid = mid_layout_range()
+    want_eg = tile_width == 32 and (groups if groups is not None else (columns and GROUPS and n_nodes > hi_mid))
+    grp = build_nnconv_groups(n_nodes, ea, n_types, a_rowptr, a_src, adj_type) if want_eg else None
+    cols = build_nnconv_columns(n_nodes, ea, n_types, a_rowptr, a_src, adj_type) if tile_width == 32 and columns and grp is None else None
+    mid = None
     if cols is not None and n_src_nodes is None and lo_mid < n_nodes <= hi_mid:
         mid = build_nnconv_batches(n_nodes, cols)
     return PreparedGraph(n_nodes, ea, int(host[3]), n_types, a_rowptr, a_src, a_eid, adj_type, edge_type, rep,
-                         c_rowptr, c_src, c_eid, cols, int(host[4]), mid)
+                         c_rowptr, c_src, c_eid, cols, int(host[4]), mid, grp)
+
+
+def graph_columns(graph: PreparedGraph) -> Optional[NNConvColumns]:
+    """The graph's type columns, built on first use when the preparation left them out (layouts that carry edge groups)."""
+    if graph.cols is not None:
+        return graph.cols
+    hit = graph.__dict__.get("_lazy_cols", False)
+    if hit is False:
+        hit = graph.__dict__["_lazy_cols"] = build_nnconv_columns(graph.n_nodes, graph.n_adj_edges, graph.n_types, graph.adj_rowptr,
+                                                                  graph.adj_src, graph.adj_type)
+    return hit
+
+
+def graph_groups(graph: PreparedGraph) -> Optional[NNConvGroups]:
+    """The graph's edge groups, built on first use when the preparation left them out."""
+    if graph.groups is not None:
+        return graph.groups
+    hit = graph.__dict__.get("_lazy_groups", False)
+    if hit is False:
+        hit = graph.__dict__["_lazy_groups"] = build_nnconv_groups(graph.n_nodes, graph.n_adj_edges, graph.n_types, graph.adj_rowptr,
+                                                                   graph.adj_src, graph.adj_type)
+    return hit
 
 
 # ----------------------------------------------------------------------------------------------
@@ -392,19 +428,15 @@ def nnconv_mean(h: Tensor, graph: PreparedGraph, wtab: Tensor, root: Tensor, bia
     npart = C.c_int32(0)
     wt = _f32c(wtab, "wtab")
     if kernel == "eg":
-        grp = graph.__dict__.get("_eg")
-        if grp is None:
-            grp = graph.__dict__["_eg"] = build_nnconv_groups(n, graph.n_adj_edges, graph.n_types, graph.adj_rowptr,
-                                                               graph.adj_src, graph.adj_type)
+        grp = graph_groups(graph)
         if grp is None or c != 32:
             raise ValueError("the edge-group kernel needs <= 40 edge types and width 32")
         wimg = torch.empty(lib.tgnn_nnconv_weight_image_floats(graph.n_types), dtype=torch.float32, device=h.device)
         bounds = torch.empty(2, dtype=torch.int32, device=h.device)
-        check(lib.tgnn_nnconv_mean_eg_fwd(ptr(h), c, int(h.shape[0]), ptr(grp.tile_grp_ptr), ptr(grp.grp_src), ptr(grp.grp_sm),
-                                          ptr(wt), graph.n_types, ptr(_f32c(root, "root")), ptr(_f32c(bias, "bias")), n, act,
+        check(lib.tgnn_nnconv_mean_eg_fwd(ptr(h), c, int(h.shape[0]), ptr(grp.tile_grp_ptr), ptr(grp.grp), ptr(wt), graph.n_types, ptr(_f32c(root, "root")), ptr(_f32c(bias, "bias")), n, act,
                                           ptr(out), ptr(wimg), ptr(bounds), ptr(partials), C.byref(npart), _stream(h)))
         return out, npart.value
-    tl = graph.cols
+    tl = graph_columns(graph) if (kernel == "cols_f16" or (graph.groups is not None and not force_csr_kernel)) else graph.cols
     if kernel == "cols_f16":
         if tl is None or c != 32:
             raise ValueError("the fp16-pair column kernel needs the column structure and width 32")

@@ -43,14 +43,14 @@ def nnconv64(h: Tensor, graph: ops.PreparedGraph, wtab: Tensor, root: Tensor, bi
              partials: Optional[Tensor] = None) -> Tuple[Tensor, int]:
     h = _bf16c(h, "x")
     n = graph.n_nodes
-    if graph.cols is None:
+    if ops.graph_columns(graph) is None:
         raise ValueError("the bf16 NNConv runs on the type-column structure (prepare_graph(columns=True))")
     if tuple(root.shape) != (WIDTH, WIDTH) or tuple(bias.shape) != (WIDTH,):
         raise ValueError("NNConv root/bias shape mismatch")
     out = torch.empty(n, WIDTH, dtype=torch.bfloat16, device=h.device)
     wimg = torch.empty(lib.tgnn_nnconv64_image_elems(graph.n_types), dtype=torch.bfloat16, device=h.device)
     npart = C.c_int32(0)
-    tl = graph.cols
+    tl = ops.graph_columns(graph)
     check(lib.tgnn_nnconv64_bf16_fwd(ptr(h), int(h.shape[0]), ptr(tl.tile_col_ptr), ptr(tl.col_meta), ptr(tl.col_src),
                                      ptr(ops._f32c(wtab, "wtab")), graph.n_types, ptr(ops._f32c(root, "root")),
                                      ptr(ops._f32c(bias, "bias")), n, act, ptr(out), ptr(wimg), ptr(partials),
@@ -131,7 +131,13 @@ def forward(net, x: Tensor, adj_e_index: Tensor, adj_e_features: Tensor, col_e_i
     table, dev = net._param_table()
     n = int(x.shape[0])
     if graph is None:
-        graph = ops.prepare_graph(n, adj_e_index, adj_e_features, col_e_idx)
+        graph = ops.prepare_graph(n, adj_e_index, adj_e_features, col_e_idx, groups=False)
+    if graph.cols is None and graph.groups is not None:      # (a layout prepared for the fp32 network: its columns on first use)
+        import dataclasses
+        hit = graph.__dict__.get("_with_cols")
+        if hit is None:
+            hit = graph.__dict__["_with_cols"] = dataclasses.replace(graph, cols=ops.graph_columns(graph), groups=None)
+        graph = hit
     if graph.cols is None or graph.n_types > max_types():
         raise ValueError(f"the bf16 path needs the type-column structure and at most {max_types()} edge types")
     dims = net._dims()
