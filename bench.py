@@ -255,7 +255,8 @@ def kernel_roofline(class_ms, n, ea, ec, n_types):
         return class_ms[k]["ms_per_forward"] / max(1, class_ms[k]["launches_per_forward"]) * 1e-3
     t_nn = per_launch_s("nnconv")
     b_alg = nnconv_bytes(n, ea, n_types)
-    out = {"kernel": "nnconv32_cols_kernel (NNConv mean as a type-column MFMA product, per layer)", "bound": "hbm",
+    out = {"kernel": "nnconv32_eg_kernel (NNConv mean over edge groups: 16 source rows per gather, two chained MFMA products, per layer)",
+           "bound": "hbm",
            "achieved": b_alg / t_nn / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_alg / t_nn / 1e9 / HBM_PEAK_GBS,
            "traffic": None, "algorithmic_bytes_per_launch": b_alg, "avg_launch_us": t_nn * 1e6,
            "timing": "HIP events on the launch stream, instrumented single-stream pass of this run",
@@ -489,9 +490,9 @@ def main():
                 "floor_us": nn_rows_bytes / (ceil["nnconv_lane_map_16rows_x_64B"] * 1e9) * 1e6,
                 "frac_single_stream": nn_rows_bytes / t_ss / 1e9 / ceil["nnconv_lane_map_16rows_x_64B"],
                 "whole_row_peak_GBs": ceil["whole_rows_8lanes_x_16B"],
-                "note": "the floor assumes every gather instruction full; at the benchmark's column fill (29 % outside the root column) the "
-                        "instruction floor of the 70 gathers of a tile puts the path at ~27 us per launch (profiles/r05_nnconv_study.txt): "
-                        "the kernel runs at ~0.8 of THAT"}
+                "note": "the floor assumes every gather instruction full; the edge groups of the benchmark layout are 68 % full (15.6 groups "
+                        "of 16 slots per 16-row tile; the type columns of rounds 1-4 were 29 % full: profiles/r05_nnconv_study.txt, "
+                        "r05_nnconv_eg.txt)"}
             gk = roofline["gin_kernel"]
             gin_rows_bytes = (ec_total + n_total) * 128
             gk["gather_bound"] = {"bytes": gin_rows_bytes, "peak_GBs": ceil["whole_rows_8lanes_x_16B"],

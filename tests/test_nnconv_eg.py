@@ -1,0 +1,181 @@
+"""NNConv over edge groups (csrc/nnconv_eg.hip, graph_prep.hip: nnconv_eg_kernel) -- the kernel the general schedule runs at
+the benchmark's size.  Reference semantics: GraphConv.forward, /root/reference/graph_networks/layers/edge_conv.py:24-27 (PyG
+NNConv, aggr="mean", root weight, bias) -- restated in fp64 below exactly as oracle/tilingnn_oracle.py: nnconv_mean does
+(index_add of per-edge messages, mean by the in-degree clamped at 1, root term, bias).
+
+* the structure against a numpy restatement of its definition (every in-edge exactly once, sorted by (type, row, original
+  order), groups of 16, the root group last, selection masks, in-degrees), ragged sizes and rows without in-edges included;
+* the op against fp64 at 37 ... 100 000 nodes, 1 ... 22 edge types, rows with more than 16 in-edges of ONE type, magnitudes
+  from 1e-3 to 1e3, with and without LeakyReLU, BatchNorm partial sums included;
+* tgnn_forward on groups against tgnn_forward on type columns, and the fall-back when the kernel is switched off.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def random_layout(n, ea, n_types, seed, max_type_run=0):
+    """adjacency [2, ea] (int64), attribute rows with n_types distinct values; max_type_run > 0: node 3 receives that many
+    in-edges of ONE type (more than a group holds), node 5 none at all."""
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randint(0, n, (ea,), generator=g)
+    dst = torch.randint(0, n, (ea,), generator=g)
+    typ = torch.randint(0, n_types, (ea,), generator=g)
+    if n > 8:
+        dst[dst == 5] = 6                                           # a row without in-edges
+        if max_type_run:
+            dst[:max_type_run] = 3
+            typ[:max_type_run] = typ[0]
+    table = torch.rand(n_types, 4, generator=g)
+    return torch.stack([src, dst]), table[typ].contiguous()
+
+
+def fp64_nnconv(h, adj, edge_type, wtab, root, bias, n, leaky):
+    """oracle/tilingnn_oracle.py: nnconv_mean in fp64 on the device (edge_conv.py:25; LeakyReLU of :26-27 behind it)."""
+    src, dst = adj[0], adj[1]
+    msg = torch.einsum("ek,eko->eo", h.double()[src], wtab.double()[edge_type])
+    agg = torch.zeros(n, 32, dtype=torch.float64, device=h.device).index_add_(0, dst, msg)
+    deg = torch.zeros(n, dtype=torch.float64, device=h.device).index_add_(0, dst, torch.ones_like(dst, dtype=torch.float64))
+    out = agg / deg.clamp(min=1).unsqueeze(1) + h.double()[:n] @ root.double() + bias.double()
+    return torch.where(out >= 0, out, out * 0.01) if leaky else out
+
+
+@pytest.mark.parametrize("n,ea,n_types,run", [(37, 200, 3, 0), (1254, 9000, 13, 0), (1000, 12000, 2, 40), (4097, 30000, 22, 0)])
+def test_group_structure_is_its_definition(dev, n, ea, n_types, run):
+    from tilingnn_amd import ops
+    adj, attr = random_layout(n, ea, n_types, seed=n, max_type_run=run)
+    col = torch.zeros(2, 0, dtype=torch.int64)
+    g = ops.prepare_graph(n, adj.to(dev), attr.to(dev), col.to(dev), groups=True)
+    assert g.groups is not None and g.cols is None
+    rowptr = g.adj_rowptr.cpu().numpy()
+    csr_src = g.adj_src.cpu().numpy()
+    csr_type = g.adj_type.cpu().numpy()
+    tptr = g.groups.tile_grp_ptr.cpu().numpy()
+    grp = g.groups.grp.cpu().numpy()
+    ntiles = (n + 15) // 16
+    assert tptr[0] == 0 and len(tptr) == ntiles + 1
+    for tile in range(ntiles):
+        rows = range(tile * 16, min(tile * 16 + 16, n))
+        want = []                                                  # (type, row in tile, CSR position, source)
+        for r in rows:
+            for e in range(rowptr[r], rowptr[r + 1]):
+                want.append((int(csr_type[e]), r - tile * 16, e, int(csr_src[e])))
+        want.sort()
+        groups = []
+        for t in sorted({w[0] for w in want}):
+            es = [w for w in want if w[0] == t]
+            groups += [(t, es[i:i + 16]) for i in range(0, len(es), 16)]
+        g0, g1 = int(tptr[tile]), int(tptr[tile + 1])
+        assert g1 - g0 == len(groups) + 1, (tile, g1 - g0, len(groups))
+        for k, (t, es) in enumerate(groups):
+            rec = grp[(g0 + k) * 16:(g0 + k + 1) * 16]
+            assert [int(v) for v in rec[:len(es), 0]] == [e[3] for e in es] and (rec[len(es):, 0] == -1).all()
+            assert ((rec[:, 1] >> 16) == t).all()
+            for j in range(16):
+                mask = sum(1 << i for i, e in enumerate(es) if e[1] == j)
+                assert int(rec[j, 1]) & 0xffff == mask
+        root = grp[(g1 - 1) * 16:g1 * 16]
+        assert ((root[:, 1] >> 16) == (g.n_types | 1 << 8)).all()
+        for j in range(16):
+            r = tile * 16 + j
+            if r < n:
+                deg = max(int(rowptr[r + 1] - rowptr[r]), 1)
+                assert root[j, 0] == np.float32(deg).view(np.int32) and int(root[j, 1]) & 0xffff == 1 << j
+            else:
+                assert root[j, 0] == -1
+
+
+@pytest.mark.parametrize("n,ea,n_types,run,scale", [(37, 200, 3, 0, 1.0), (1254, 9000, 13, 0, 1.0), (1000, 12000, 1, 40, 1.0),
+                                                     (5000, 60000, 22, 0, 1.0), (10_000, 80_000, 13, 0, 1e3),
+                                                     (10_000, 80_000, 13, 0, 1e-3), (10_000, 80_000, 13, 0, 8.0),
+                                                     (100_000, 1_000_000, 13, 20, 1.0)])
+@pytest.mark.parametrize("leaky", [False, True])
+def test_op_against_fp64(dev, n, ea, n_types, run, scale, leaky):
+    """Tolerance: 2e-6 of the largest output (measured 1.5e-7 .. 3e-7: three fp16-pair splits of 2^-22 each and fp32 sums), the
+    bound the column kernel's fp16-pair form is held to (tests/test_hip_parity.py: nnconv_f16_pair); magnitudes 1e-3, 1 and 1e3
+    take the scaled branch of the row split, 8 the unscaled one."""
+    from tilingnn_amd import ops
+    import oracle.tilingnn_oracle as orc
+    adj, attr = random_layout(n, ea, n_types, seed=n + n_types, max_type_run=run)
+    adj, attr = adj.to(dev), attr.to(dev)
+    g = ops.prepare_graph(n, adj, attr, torch.zeros(2, 0, dtype=torch.int64, device=dev), groups=True)
+    assert g.n_types == n_types
+    gen = torch.Generator().manual_seed(1)
+    h = (torch.randn(n, 32, generator=gen) * torch.randn(n, 32, generator=gen) * scale).to(dev)
+    wtab = torch.rand(g.n_types, 32, 32, generator=gen).to(dev)                # edge-MLP outputs are sigmoids
+    root = (torch.randn(32, 32, generator=gen) * 0.3).to(dev)
+    bias = (torch.randn(32, generator=gen) * scale).to(dev)
+    want = fp64_nnconv(h, adj, g.edge_type[:ea].long(), wtab, root, bias, n, leaky)
+    part = ops.new_partials(32, dev)
+    out, npart = ops.nnconv_mean(h, g, wtab, root, bias, ops.ACT_LEAKY_RELU if leaky else ops.ACT_NONE, part, kernel="eg")
+    assert out.shape == (n, 32) and bool(torch.isfinite(out).all())
+    assert orc.rel_max_err(out.cpu(), want.cpu()) < 2e-6
+    # BatchNorm partial rows: [blocks][sum 32 | sum of squares 32] in fp64
+    p = part[:npart * 64].view(npart, 64).sum(0)
+    assert torch.allclose(p[:32].cpu(), want.sum(0).cpu(), rtol=1e-6, atol=1e-6 * float(want.abs().max()) * n)
+    assert torch.allclose(p[32:].cpu(), (want * want).sum(0).cpu(), rtol=1e-5, atol=1e-6 * float(want.abs().max()) ** 2 * n)
+    # ... and the default per-op entry point takes the same kernel on a layout that carries groups: the same bits
+    out2, _ = ops.nnconv_mean(h, g, wtab, root, bias, ops.ACT_LEAKY_RELU if leaky else ops.ACT_NONE, ops.new_partials(32, dev))
+    assert torch.equal(out, out2)
+
+
+def test_halo_rows_behind_the_destinations(dev):
+    """A shard's layout: sources index rows behind the n destination rows (n_src_nodes > n_nodes)."""
+    from tilingnn_amd import ops
+    import oracle.tilingnn_oracle as orc
+    n, n_src, ea = 3000, 3700, 30000
+    gen = torch.Generator().manual_seed(4)
+    adj = torch.stack([torch.randint(0, n_src, (ea,), generator=gen), torch.randint(0, n, (ea,), generator=gen)]).to(dev)
+    table = torch.rand(7, 3, generator=gen)
+    attr = table[torch.randint(0, 7, (ea,), generator=gen)].contiguous().to(dev)
+    g = ops.prepare_graph(n, adj, attr, torch.zeros(2, 0, dtype=torch.int64, device=dev), n_src_nodes=n_src)
+    assert g.groups is not None                                    # (a shard always runs the general schedule)
+    h = torch.randn(n_src, 32, generator=gen).to(dev)
+    wtab = torch.rand(g.n_types, 32, 32, generator=gen).to(dev)
+    root = (torch.randn(32, 32, generator=gen) * 0.3).to(dev)
+    bias = torch.randn(32, generator=gen).to(dev)
+    want = fp64_nnconv(h, adj, g.edge_type[:ea].long(), wtab, root, bias, n, False)
+    out, _ = ops.nnconv_mean(h, g, wtab, root, bias, ops.ACT_NONE, ops.new_partials(32, dev), kernel="eg")
+    assert orc.rel_max_err(out.cpu(), want.cpu()) < 2e-6
+
+
+def test_forward_on_groups_against_columns_and_fallback(dev):
+    """A layout of the general schedule (above the mid-size limit): the forward over edge groups, over type columns
+    (tgnn_set_nnconv_eg(0), prepare_graph(groups=False)) and -- groups only, kernel switched off -- over the CSR kernel.
+    20 chaotic layers: the three agree as closely as two roundings of the same network do (measured 7e-6 at 100 000 nodes)."""
+    from tilingnn_amd import TilinGNN, ops
+    from tilingnn_amd._lib import lib
+    from tilingnn_amd.synth import make_super_graph
+    from tilingnn_amd.weights import make_state_dict
+    n = 40_000
+    sg = make_super_graph(n, 10 * n, 12 * n, tile_count=2, n_edge_types=13, seed=3)
+    x, adj, attr, col, _ = sg.to_torch(dev)
+    net = TilinGNN(15, 20, 32, node_features_dim=3)
+    net.load_state_dict(make_state_dict(15, 20, 32, 1, 3))
+    net = net.to(dev).train()
+    net.cache_graph = False
+    assert ops.prepare_graph(n, adj, attr, col).groups is not None
+    p_groups = net(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)[0].clone()
+    prev = lib.tgnn_set_nnconv_eg(0)
+    try:
+        p_csr = net(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)[0].clone()      # groups only, kernel off
+        ops.GROUPS, keep = False, ops.GROUPS
+        try:
+            assert ops.prepare_graph(n, adj, attr, col).cols is not None
+            p_cols = net(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)[0].clone()
+        finally:
+            ops.GROUPS = keep
+    finally:
+        lib.tgnn_set_nnconv_eg(prev)
+    assert bool(torch.isfinite(p_groups).all())
+    assert float((p_groups - p_cols).abs().max()) < 2e-4
+    assert float((p_groups - p_csr).abs().max()) < 2e-4

@@ -75,8 +75,10 @@ def test_small_kernel_matches_the_general_schedule_layer_by_layer(dev, n):
     for k in range(1, 4):
         err = orc.rel_max_err(s_small[k], s_gen[k].double())
         print(f"n {n} slot {k}: {err:.2e}")
-        # BatchNorm of near-constant collision columns amplifies the last-bit differences of the sums
-        assert err < 2e-5 * (4 ** (k - 1)), (k, err)
+        # BatchNorm of near-constant collision columns amplifies the last-bit differences of the sums; 17 rows: statistics over
+        # 17 values -- against the fp64 oracle the persistent kernel sits at 1.8e-4 in slot 2, the general schedule at 9.0e-5
+        # (on edge groups; 1.1e-4 on type columns: scratch/slot_err_17.py), two realisations up to 2x further apart than larger layouts'
+        assert err < 2e-5 * (4 ** (k - 1)) * (2 if n < 64 else 1), (k, err)
     assert not torch.equal(s_gen[1], s_small[1])                # (it IS a different path)
     assert float((p_small - p_gen).abs().max()) < 1e-3
 

@@ -561,8 +561,10 @@ __global__ __launch_bounds__(64) void nnconv_eg_kernel(const int *__restrict__ r
         return;
     }
     if (built_flag && blockIdx.x == 0 && threadIdx.x == 0) *built_flag = 1;
-    __shared__ int cnt[64][kMaxColTypes + 1];    // edges of (row, type); +1: odd stride
-    __shared__ int pre[64][kMaxColTypes + 1];    // edges of the type in the tile's rows above this one
+    // 16-bit counters: 2 x 5 KB of LDS per 64-row block (in-degrees beyond 2048 are not served by the kernel that reads this
+    // structure -- tgnn_forward checks nn_max_in_degree --; both passes wrap alike, every store stays inside the tile's range)
+    __shared__ unsigned short cnt[64][kMaxColTypes + 1];    // edges of (row, type); +1: odd stride
+    __shared__ unsigned short pre[FILL ? 64 : 1][kMaxColTypes + 1];    // edges of the type in the tile's rows above this one
     __shared__ int base[4][kMaxColTypes + 1];    // first group of (tile, type)
     for (int t = 0; t < n_types; ++t) cnt[tid][t] = 0;
     int e0 = 0, e1 = 0;
@@ -576,7 +578,7 @@ __global__ __launch_bounds__(64) void nnconv_eg_kernel(const int *__restrict__ r
     for (int t = i; t < n_types; t += 16) {
         int acc = 0;
         for (int r = 0; r < 16; ++r) {
-            pre[k * 16 + r][t] = acc;
+            if constexpr (FILL) pre[k * 16 + r][t] = (unsigned short)acc;
             acc += cnt[k * 16 + r][t];
         }
         base[k][t] = (acc + 15) >> 4;            // (groups of the type: turned into offsets below)
@@ -614,7 +616,7 @@ __global__ __launch_bounds__(64) void nnconv_eg_kernel(const int *__restrict__ r
     }
     for (int e = e0; e < e1; ++e) {
         const int t = col_type[e];
-        const int p = pre[tid][t] + cnt[tid][t]++;
+        const int p = (unsigned short)(pre[tid][t] + cnt[tid][t]++);
         grp[(g0 + base[k][t] + (p >> 4)) * 16 + (p & 15)].x = col_src[e];
     }
 }

@@ -26,13 +26,28 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f16x8 = tgnn_f16x8;
 using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 
-constexpr int kEgRootBit = 1 << 8, kEgSkip = 1 << 9;      // meta = type | root << 8 (graph_prep.hip: kEgRoot)
+constexpr int kEgRootBit = 1 << 8;                        // meta = type | root << 8 (graph_prep.hip: kEgRoot)
 constexpr int kEgExtraLog2 = 5;                             // h . sx < 2^10: 32 products with weights below 1 stay below 2^15
 
-// a = x . s (s a power of two: exact) -> fp16 pair hi = RN16(a), lo = RN16(a - hi); 5 instructions per two values
-// (v_pk_mul_f32, v_cvt_pk_f16_f32, 2 x v_fma_mix_f32 reading hi as fp16, v_cvt_pk_f16_f32)
+// a = x . s (s a power of two: exact) -> fp16 pair hi = RN16(a), lo = RN16(a - hi); 5 instructions per two values, none of them
+// a multiply of its own: v_fma_mixlo_f16 / v_fma_mixhi_f16 (hi = RN16(x s)), 2 x v_fma_mix_f32 (x s - hi, hi read as fp16),
+// v_cvt_pk_f16_f32
 __device__ __forceinline__ void split_pair_f16(float x0, float x1, float s, unsigned &hi, unsigned &lo) {
-    const float a0 = x0 * s, a1 = x1 * s;
+    unsigned h;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(s));
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(x0), "v"(s), "v"(h));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(x1), "v"(s), "v"(h));
+    using h2 = __attribute__((ext_vector_type(2))) _Float16;
+    h2 lv;
+    lv[0] = (_Float16)l0;
+    lv[1] = (_Float16)l1;
+    hi = h;
+    lo = __builtin_bit_cast(unsigned, lv);
+}
+// the same without a scale (the messages: in range by construction); 4 instructions per two values
+__device__ __forceinline__ void split_pair_f16(float a0, float a1, unsigned &hi, unsigned &lo) {
     using h2 = __attribute__((ext_vector_type(2))) _Float16;
     h2 hv;
     hv[0] = (_Float16)a0;
@@ -49,7 +64,7 @@ __device__ __forceinline__ void split_pair_f16(float x0, float x1, float s, unsi
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 
-template <int WAVES, int OCC>
+template <int WAVES, int OCC, int ACT>
 __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_eg_kernel(
     const float *__restrict__ h, const int *__restrict__ tile_grp_ptr, const int2 *__restrict__ grp,
     const float *__restrict__ wimg, int n_types, const float *__restrict__ bias, int64_t n,
@@ -60,42 +75,31 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_eg_kernel(
     constexpr int kTy = kWtTypeF16;                         // floats of one type's image
     float *wl = lds;                                        // [(T+1)][2 planes][2 N blocks][4][16] x 8 fp16
     f16x4 *lut = reinterpret_cast<f16x4 *>(lds + (n_types + 1) * kTy);   // [16]: 4 selection bits -> 4 fp16 of 0 / 1
-    const float sx = pow2_scale_for(*h_max, kEgExtraLog2);
+    const unsigned hm_bits = *h_max, hm_exp = (hm_bits >> 23) & 0xffu;           // max |h| < 2^(hm_exp - 126)
+#ifdef TGNN_ABL_EGNOUNIT
+    const bool unit = hm_exp > 300;                         // (timing ablation: always scaled)
+#else
+    // no scale where the rows are in range as they are: 2^3 <= max |h| < 2^10 (elements down to 2^-3 keep a NORMAL fp16 low
+    // half -- 22 bits --, smaller ones are off by at most 2^-25, 2^-28 of the largest; below 2^3 the scaled split is the exact one)
+    const bool unit = hm_exp >= 130 && hm_exp <= 136;
+#endif
+    const float sx = unit ? 1.0f : pow2_scale_for(hm_bits, kEgExtraLog2);
     const float unscale = 1.0f / (sx * nnconv_weight_scale(*root_max) * kEgImageScale);   // (powers of two: exact)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fj = lane & 15, fq = lane >> 4;
     constexpr int kThreads = WAVES * 64;
-    {   // weight image: straight copy, all loads of a thread issued before the first LDS store
-        const int n4 = (n_types + 1) * kTy / 4;
-        for (int i = tid; i < n4; i += 4 * kThreads) {
-            float4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int ii = i + u * kThreads < n4 ? i + u * kThreads : n4 - 1;
-                v[u] = reinterpret_cast<const float4 *>(wimg)[ii];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (i + u * kThreads < n4) reinterpret_cast<float4 *>(wl)[i + u * kThreads] = v[u];
-        }
-        if (tid < 16) {
-            f16x4 e;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) e[b] = (tid >> b & 1) ? (_Float16)1.0f : (_Float16)0.0f;
-            lut[tid] = e;
-        }
-    }
-
     // ---- this wave's run of 16-row tiles (as nnconv_cols.hip: shares follow the XCD, the block, the SIMD)
     static_assert(WAVES % 4 == 0, "whole SIMD quads");
-    const int64_t n_tiles = (n + 15) / 16;
-    const int nblk = gridDim.x;
-    int64_t blk = blockIdx.x;
-    if (nblk >= 8 && (nblk & 7) == 0) blk = (int64_t)(blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
-    const int64_t slot = blk * 4 + (wave & 3), n_slots = (int64_t)nblk * 4;
-    const int64_t q0 = n_tiles * slot / n_slots, q1 = n_tiles * (slot + 1) / n_slots;
-    constexpr int kSubs = WAVES / 4;
-    const int sub = wave >> 2;
+    // (32-bit arithmetic: a 64-bit division is ~150 instructions and this prologue is a fifth of a wave's vector work)
+    const uint32_t n_tiles = (uint32_t)((n + 15) / 16);
+    const uint32_t nblk = gridDim.x;
+    uint32_t blk = blockIdx.x;
+    if (nblk >= 8 && (nblk & 7) == 0) blk = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    const uint32_t slot = blk * 4 + (wave & 3), n_slots = nblk * 4;
+    const uint32_t tq = n_tiles / n_slots, tr = n_tiles % n_slots;          // n_tiles * slot / n_slots without the wide product
+    const uint32_t q0 = tq * slot + tr * slot / n_slots, q1 = tq * (slot + 1) + tr * (slot + 1) / n_slots;
+    constexpr uint32_t kSubs = WAVES / 4;
+    const uint32_t sub = wave >> 2;
     const int64_t t0 = q0 + (q1 - q0) * sub / kSubs, t1 = q0 + (q1 - q0) * (sub + 1) / kSubs;
     const int cbeg = __builtin_amdgcn_readfirstlane(tile_grp_ptr[t0]);
     const int cend = __builtin_amdgcn_readfirstlane(tile_grp_ptr[t1]);
@@ -103,7 +107,6 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_eg_kernel(
     const float bias0 = bias[fj], bias1 = bias[16 + fj];
     // BN partial sums of this lane: channel 16 m + fj over the rows 4 fq .. 4 fq + 3 of every tile
     double bs[2] = {0, 0}, bq[2] = {0, 0};
-    __syncthreads();
 
     const __amdgpu_buffer_rsrc_t h_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(h), 0, (int)0x80000000u, 0x00020000);   // 2 GB window
@@ -120,9 +123,10 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_eg_kernel(
         m = __shfl(m4, u * 16 + fj, 64);
         meta = __builtin_amdgcn_readlane(m4, u * 16) >> 16;
         if constexpr (!decltype(steady)::value)
-            if (p + u >= cend) {                             // wave-uniform
+            if (p + u >= cend) {                             // wave-uniform: past the share = an empty group of type 0
                 s = -1;
-                meta = kEgSkip;
+                m = 0;
+                meta = 0;
             }
     };
     int64_t gtile = t0;                                     // tile of the group the gather stage is at
@@ -149,19 +153,34 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_eg_kernel(
     f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;               // out tile: rows 4 fq + r, channel fj (d0) and 16 + fj (d1)
     int64_t ctile = t0;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    auto consume = [&](auto steady, int s, int m, int meta, const float4 (&x)[2]) {
-        if constexpr (!decltype(steady)::value)
-            if (meta & kEgSkip) return;                      // wave-uniform
+    // unit: the rows go into the fp16 pair as they are (no scale: 4 instructions less per row pair)
+    struct Msg {                                            // a group's messages M = G . W_t as fp16 pairs + its selection operand
+        u32x2 a0, b0, a1, b1;                               // hi / lo of channel fj (a0, b0) and 16 + fj (a1, b1), edges 4 fq + r
+        f16x4 sel;                                          // S[row fj][edges 4 fq .. 4 fq + 3]
+    };
+    auto stage1 = [&](int s, int m, int meta, const float4 (&x)[2]) -> Msg {
         const int t = meta & 0xff;
-        unsigned xh0, xh1, xh2, xh3, xl0, xl1, xl2, xl3;
-        split_pair_f16(x[0].x, x[0].y, sx, xh0, xl0);
-        split_pair_f16(x[0].z, x[0].w, sx, xh1, xl1);
-        split_pair_f16(x[1].x, x[1].y, sx, xh2, xl2);
-        split_pair_f16(x[1].z, x[1].w, sx, xh3, xl3);
-        const f16x8 gh = __builtin_bit_cast(f16x8, u32x4{xh0, xh1, xh2, xh3}), gl = __builtin_bit_cast(f16x8, u32x4{xl0, xl1, xl2, xl3});
+        // the type's operand fragments and the selection operand first: their LDS round trip runs under the split's instructions
         constexpr int kPl = kWtPlane / 4;                    // 16-byte fragments per plane
         const f16x8 *wp = reinterpret_cast<const f16x8 *>(wl + t * kTy) + lane;      // lane order: conflict-free
         const f16x8 h0 = wp[0], h1 = wp[64], l0 = wp[kPl], l1 = wp[kPl + 64];
+        f16x4 sel0 = lut[(m >> (4 * fq)) & 15];
+#ifndef TGNN_ABL_EGLATE
+        asm volatile("" : "+v"(sel0) :: "memory");            // (keeps the reads above the split)
+#endif
+        unsigned xh0, xh1, xh2, xh3, xl0, xl1, xl2, xl3;
+        if (unit) {                                          // wave-uniform
+            split_pair_f16(x[0].x, x[0].y, xh0, xl0);
+            split_pair_f16(x[0].z, x[0].w, xh1, xl1);
+            split_pair_f16(x[1].x, x[1].y, xh2, xl2);
+            split_pair_f16(x[1].z, x[1].w, xh3, xl3);
+        } else {
+            split_pair_f16(x[0].x, x[0].y, sx, xh0, xl0);
+            split_pair_f16(x[0].z, x[0].w, sx, xh1, xl1);
+            split_pair_f16(x[1].x, x[1].y, sx, xh2, xl2);
+            split_pair_f16(x[1].z, x[1].w, sx, xh3, xl3);
+        }
+        const f16x8 gh = __builtin_bit_cast(f16x8, u32x4{xh0, xh1, xh2, xh3}), gl = __builtin_bit_cast(f16x8, u32x4{xl0, xl1, xl2, xl3});
         f32x4 m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, l0, zero4, 0, 0, 0);   // hi . lo
         f32x4 m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, l1, zero4, 0, 0, 0);
         m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl, h0, m0, 0, 0, 0);           // lo . hi
@@ -169,50 +188,79 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_eg_kernel(
         m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, h0, m0, 0, 0, 0);           // hi . hi
         m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, h1, m1, 0, 0, 0);
         unsigned a00, a01, b00, b01, a10, a11, b10, b11;     // the messages as fp16 pairs (below 2^15 by the scales)
-        split_pair_f16(m0[0], m0[1], 1.0f, a00, b00);
-        split_pair_f16(m0[2], m0[3], 1.0f, a01, b01);
-        split_pair_f16(m1[0], m1[1], 1.0f, a10, b10);
-        split_pair_f16(m1[2], m1[3], 1.0f, a11, b11);
-        const u32x2 a0 = {a00, a01}, b0 = {b00, b01}, a1 = {a10, a11}, b1 = {b10, b11};
-        f16x4 sel = lut[(m >> (4 * fq)) & 15];               // S[row fj][edges 4 fq .. 4 fq + 3]
-        const bool root = (meta & kEgRootBit) != 0;          // wave-uniform
-        if (root) {                                          // S = diag(max(deg, 1)): s = its float bits for row fj
+        split_pair_f16(m0[0], m0[1], a00, b00);
+        split_pair_f16(m0[2], m0[3], a01, b01);
+        split_pair_f16(m1[0], m1[1], a10, b10);
+        split_pair_f16(m1[2], m1[3], a11, b11);
+        Msg r;
+        r.a0 = u32x2{a00, a01}; r.b0 = u32x2{b00, b01}; r.a1 = u32x2{a10, a11}; r.b1 = u32x2{b10, b11};
+        r.sel = sel0;
+        if (meta & kEgRootBit) {                             // S = diag(max(deg, 1)): s = its float bits for row fj
             asm volatile("" ::: "memory");                   // (a real branch: one group in ~16 takes it)
             const _Float16 dg = (_Float16)__int_as_float(s);
-            sel = sel * dg;
+            r.sel = r.sel * dg;
         }
-        d0 = __builtin_amdgcn_mfma_f32_16x16x16f16(sel, __builtin_bit_cast(f16x4, b0), d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_16x16x16f16(sel, __builtin_bit_cast(f16x4, b1), d1, 0, 0, 0);
-        d0 = __builtin_amdgcn_mfma_f32_16x16x16f16(sel, __builtin_bit_cast(f16x4, a0), d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_16x16x16f16(sel, __builtin_bit_cast(f16x4, a1), d1, 0, 0, 0);
-        if (root) {
-            // end of the tile
-            double s0 = 0, s1 = 0, z0 = 0, z1 = 0;
+        return r;
+    };
+    auto fold16 = [&](const Msg &g) {                        // out += S . M, one group: K = 16
+        d0 = __builtin_amdgcn_mfma_f32_16x16x16f16(g.sel, __builtin_bit_cast(f16x4, g.b0), d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x16f16(g.sel, __builtin_bit_cast(f16x4, g.b1), d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x16f16(g.sel, __builtin_bit_cast(f16x4, g.a0), d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x16f16(g.sel, __builtin_bit_cast(f16x4, g.a1), d1, 0, 0, 0);
+    };
+    auto fold32 = [&](const Msg &g, const Msg &k) {          // two groups of one tile: K = 32 (the K = 16 form costs the same 16 cycles)
+        using f16x8v = f16x8;
+        const f16x4 sg = g.sel, sk = k.sel;
+        const f16x8v sel = {sg[0], sg[1], sg[2], sg[3], sk[0], sk[1], sk[2], sk[3]};
+        auto cat = [](u32x2 p, u32x2 q) { return __builtin_bit_cast(f16x8v, u32x4{p[0], p[1], q[0], q[1]}); };
+        d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(sel, cat(g.b0, k.b0), d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(sel, cat(g.b1, k.b1), d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(sel, cat(g.a0, k.a0), d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(sel, cat(g.a1, k.a1), d1, 0, 0, 0);
+    };
+    auto finish_tile = [&](int s) {                          // s: float bits of max(deg, 1) of row fj (-1: row >= n)
+        double s0 = 0, s1 = 0, z0 = 0, z1 = 0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int dg = __shfl(s, 4 * fq + r, 64);    // row 4 fq + r's word (-1: row >= n)
-                const bool valid = dg >= 0;
-                const float inv = unscale * __builtin_amdgcn_rcpf(__int_as_float(dg));
-                float o0 = fmaf(d0[r], inv, bias0);
-                float o1 = fmaf(d1[r], inv, bias1);
-                if (act == TGNN_ACT_LEAKY_RELU) {
-                    o0 = leakyf_(o0);
-                    o1 = leakyf_(o1);
-                }
-                const int64_t v = ctile * 16 + 4 * fq + r;
-                if (valid) {
-                    out[v * 32 + fj] = o0;
-                    out[v * 32 + 16 + fj] = o1;
-                    s0 += (double)o0; z0 += (double)o0 * (double)o0;
-                    s1 += (double)o1; z1 += (double)o1 * (double)o1;
-                }
+        for (int r = 0; r < 4; ++r) {
+            const int dg = __shfl(s, 4 * fq + r, 64);        // row 4 fq + r's word
+            const bool valid = dg >= 0;
+            const float inv = unscale * __builtin_amdgcn_rcpf(__int_as_float(dg));
+            float o0 = fmaf(d0[r], inv, bias0);
+            float o1 = fmaf(d1[r], inv, bias1);
+            if constexpr (ACT == TGNN_ACT_LEAKY_RELU) {
+                o0 = leakyf_(o0);
+                o1 = leakyf_(o1);
             }
-            bs[0] += s0; bq[0] += z0;
-            bs[1] += s1; bq[1] += z1;
-            d0 = zero4;
-            d1 = zero4;
-            ++ctile;
+            const int64_t v = ctile * 16 + 4 * fq + r;
+            if (valid) {
+                out[v * 32 + fj] = o0;
+                out[v * 32 + 16 + fj] = o1;
+                s0 += (double)o0; z0 += (double)o0 * (double)o0;
+                s1 += (double)o1; z1 += (double)o1 * (double)o1;
+            }
         }
+        bs[0] += s0; bq[0] += z0;
+        bs[1] += s1; bq[1] += z1;
+        d0 = zero4;
+        d1 = zero4;
+        ++ctile;
+    };
+    // two consecutive groups of the stream: one K = 32 fold unless the first one ends its tile
+    auto consume_pair = [&](int sa, int ma, int ta, const float4 (&xa)[2], int sb, int mb, int tb, const float4 (&xb)[2]) {
+        const Msg ga = stage1(sa, ma, ta, xa);
+        const Msg gb = stage1(sb, mb, tb, xb);
+#ifdef TGNN_ABL_EGSINGLE
+        if (true) {                                          // (timing ablation: every group folded on its own)
+#else
+        if (ta & kEgRootBit) {                               // wave-uniform
+#endif
+            fold16(ga);
+            finish_tile(sa);
+            fold16(gb);
+        } else {
+            fold32(ga, gb);
+        }
+        if (tb & kEgRootBit) finish_tile(sb);
     };
 
     // ---- the group stream, four groups at a time: a four's index words are fetched two rounds ahead, its gathers one
@@ -229,6 +277,29 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_eg_kernel(
             issue_gather(xs[u], xt[u], x[u]);
         }
     }
+    // (the first gathers are in flight: the block's weight image lands behind them)
+    {   // weight image: straight copy, all loads of a thread issued before the first LDS store
+        const int n4 = (n_types + 1) * kTy / 4;
+        for (int i = tid; i < n4; i += 4 * kThreads) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ii = i + u * kThreads < n4 ? i + u * kThreads : n4 - 1;
+                v[u] = reinterpret_cast<const float4 *>(wimg)[ii];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i + u * kThreads < n4) reinterpret_cast<float4 *>(wl)[i + u * kThreads] = v[u];
+        }
+        if (tid < 16) {
+            f16x4 e;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) e[b] = (tid >> b & 1) ? (_Float16)1.0f : (_Float16)0.0f;
+            lut[tid] = e;
+        }
+    }
+
+    __syncthreads();
     int base = cbeg;
 #ifdef TGNN_ABL_EGNOLOOP
     base = cend;                                             // (timing ablation: what a launch costs without its groups)
@@ -237,10 +308,13 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_eg_kernel(
         int s4c, m4c;
         load_four(base + 8, s4c, m4c);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            consume(std::true_type{}, xs[u], xm[u], xt[u], x[u]);
-            unpack(std::true_type{}, base + 4, u, s4n, m4n, xs[u], xm[u], xt[u]);
-            issue_gather(xs[u], xt[u], x[u]);
+        for (int u = 0; u < 4; u += 2) {
+            consume_pair(xs[u], xm[u], xt[u], x[u], xs[u + 1], xm[u + 1], xt[u + 1], x[u + 1]);
+#pragma unroll
+            for (int v = u; v < u + 2; ++v) {
+                unpack(std::true_type{}, base + 4, v, s4n, m4n, xs[v], xm[v], xt[v]);
+                issue_gather(xs[v], xt[v], x[v]);
+            }
         }
         s4n = s4c;
         m4n = m4c;
@@ -249,10 +323,13 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_eg_kernel(
         int s4c, m4c;
         load_four(base + 8, s4c, m4c);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            consume(std::false_type{}, xs[u], xm[u], xt[u], x[u]);
-            unpack(std::false_type{}, base + 4, u, s4n, m4n, xs[u], xm[u], xt[u]);
-            issue_gather(xs[u], xt[u], x[u]);
+        for (int u = 0; u < 4; u += 2) {
+            consume_pair(xs[u], xm[u], xt[u], x[u], xs[u + 1], xm[u + 1], xt[u + 1], x[u + 1]);
+#pragma unroll
+            for (int v = u; v < u + 2; ++v) {
+                unpack(std::false_type{}, base + 4, v, s4n, m4n, xs[v], xm[v], xt[v]);
+                issue_gather(xs[v], xt[v], x[v]);
+            }
         }
         s4n = s4c;
         m4n = m4c;
@@ -289,9 +366,10 @@ int launch_nnconv_eg(const float *h, const int32_t *tile_grp_ptr, const int32_t 
                      double *bn_partial, int32_t *n_partials_host, hipStream_t s, const unsigned *h_max, const unsigned *root_max,
                      unsigned long long *stamp) {
     constexpr int WAVES = 16;
-    auto kern = nnconv32_eg_kernel<WAVES, 4>;
-    static LdsOptIn site;
-    TGNN_CHECK_HIP(opt_in_dynamic_lds(kern, (int)kEgMaxLds, site));
+    const bool leaky = act == TGNN_ACT_LEAKY_RELU;
+    auto kern = leaky ? nnconv32_eg_kernel<WAVES, 4, TGNN_ACT_LEAKY_RELU> : nnconv32_eg_kernel<WAVES, 4, TGNN_ACT_NONE>;
+    static LdsOptIn site[2];
+    TGNN_CHECK_HIP(opt_in_dynamic_lds(kern, (int)kEgMaxLds, site[leaky]));
     const int64_t n_tiles = (n_nodes + 15) / 16;
     constexpr int tiles_per_block = 4;
     int64_t blocks = (n_tiles + tiles_per_block - 1) / tiles_per_block;

@@ -45,8 +45,9 @@ def clear():
 
 def get_full(n_nodes, adj_e_index, adj_e_features, col_e_idx):
     ts = (adj_e_index, adj_e_features, col_e_idx)
-    # (what a prepared graph carries depends on the size range of the mid-size persistent kernel: part of the key)
-    return _lookup(("full", n_nodes, ops.mid_layout_range()) + _key(*ts), ts,
+    # (what a prepared graph carries depends on the size range of the mid-size persistent kernel and on the schedule its
+    #  size is run by -- type columns and mid-size batches, or edge groups: part of the key)
+    return _lookup(("full", n_nodes, ops.mid_layout_range(), ops.GROUPS and ops.runs_general_schedule(n_nodes)) + _key(*ts), ts,
                    lambda: ops.prepare_graph(n_nodes, adj_e_index, adj_e_features, col_e_idx))
 
 
@@ -55,7 +56,7 @@ def get_adj(n_nodes, adj_e_index, adj_e_features):
     import torch
     ts = (adj_e_index, adj_e_features)
     empty = torch.empty(2, 0, dtype=torch.int64, device=adj_e_index.device)
-    return _lookup(("adj", n_nodes) + _key(*ts), ts,
+    return _lookup(("adj", n_nodes, ops.GROUPS and ops.runs_general_schedule(n_nodes)) + _key(*ts), ts,
                    lambda: ops.prepare_graph(n_nodes, adj_e_index, adj_e_features, empty))
 
 

@@ -108,6 +108,14 @@ class NNConvBatches:
     ent: Tensor               # int32 (uint32 bits) [ceil(N/16) * 24 * 36]
 
 
+def runs_general_schedule(n_nodes: int) -> bool:
+    """True when tgnn_forward takes a layout of this size through the launch-per-op schedule (neither persistent kernel)."""
+    lo_mid, hi_mid = 4096, int(lib.tgnn_get_mid_layout_limit())
+    if n_nodes <= lo_mid:
+        return n_nodes > int(lib.tgnn_get_small_layout_limit())
+    return n_nodes > hi_mid
+
+
 def mid_layout_range() -> Tuple[int, int]:
     """(lo, hi]: node counts whose layer loop runs as the mid-size persistent kernel (layouts of up to 4 096 nodes belong to the
     small-layout kernel, or to the general schedule when that one is switched off)."""
@@ -275,11 +283,13 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
     ws_ints = int(lib.tgnn_graph_prep_small_tmp_ints(n_nodes, ea, ec)) if small else \
         (int(lib.tgnn_graph_prep_workspace_bytes(n_nodes, ea, ec, fe)) + 3) // 4 + 64
     lo_mid, hi_mid = mid_layout_range()
-    want_mid = not small and n_src_nodes is None and lo_mid < n_nodes <= hi_mid
-    mid_words = int(lib.tgnn_mid_entries_words(n_nodes)) if want_mid else 0
     # layouts of the general schedule carry the NNConv edge groups INSTEAD of the type columns (whoever needs the other
     # structure later builds it: graph_columns / graph_groups)
-    want_eg = not small and groups if groups is not None else (not small and GROUPS and n_nodes > hi_mid)
+    # (a shard's layout always runs the general schedule)
+    want_eg = (not small and groups) if groups is not None else \
+        (not small and GROUPS and (n_src_nodes is not None or runs_general_schedule(n_nodes)))
+    want_mid = not small and not want_eg and n_src_nodes is None and lo_mid < n_nodes <= hi_mid   # (built from the columns)
+    mid_words = int(lib.tgnn_mid_entries_words(n_nodes)) if want_mid else 0
     cap = 0 if want_eg else int(lib.tgnn_nnconv_cols_max_columns(n_nodes, ea))
     gcap = int(lib.tgnn_nnconv_eg_max_groups(n_nodes, ea, lib.tgnn_nnconv_cols_max_types())) if want_eg else 0
     # the persistent outputs share ONE long-lived allocation; the scratch (CSR / de-dup tables, scan workspaces) and the result
@@ -332,7 +342,8 @@ def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col
         raise ValueError(f"adj_e_features has {adj_e_features.shape[0]} rows for {ea} edges")
     if SMALL_PREP and tile_width == 32 and columns in (None, True) and COLS_MIN_NODES == 0 and n_nodes >= 1:
         # (a shard's layout -- sources behind the destination rows -- goes through the any-size call)
-        small = n_src_nodes is None and n_nodes <= _small_prep_limits()[0] and max(ea, ec) <= _small_prep_limits()[1]
+        small = n_src_nodes is None and n_nodes <= _small_prep_limits()[0] and max(ea, ec) <= _small_prep_limits()[1] and \
+            not (groups or (groups is None and GROUPS and runs_general_schedule(n_nodes)))   # (the one-launch preparation builds columns)
         g = _prepare_graph_fused(n_nodes, adj, adj_e_features, col, small, n_src_nodes, groups)
         if g is not None:
             return g
@@ -357,7 +368,8 @@ def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col
     if columns is None:
         columns = n_nodes > COLS_MIN_NODES
     lo_mid, hi_mid = mid_layout_range()
-    want_eg = tile_width == 32 and (groups if groups is not None else (columns and GROUPS and n_nodes > hi_mid))
+    want_eg = tile_width == 32 and (groups if groups is not None else
+                                    (columns and GROUPS and (n_src_nodes is not None or runs_general_schedule(n_nodes))))
     grp = build_nnconv_groups(n_nodes, ea, n_types, a_rowptr, a_src, adj_type) if want_eg else None
     cols = build_nnconv_columns(n_nodes, ea, n_types, a_rowptr, a_src, adj_type) if tile_width == 32 and columns and grp is None else None
     mid = None
@@ -427,6 +439,9 @@ def nnconv_mean(h: Tensor, graph: PreparedGraph, wtab: Tensor, root: Tensor, bia
     out = torch.empty(n, c, dtype=torch.float32, device=h.device)
     npart = C.c_int32(0)
     wt = _f32c(wtab, "wtab")
+    if kernel is None and graph.groups is not None and c == 32 and not force_csr_kernel and 1 <= graph.max_in_degree <= 2048 \
+            and int(h.shape[0]) * c * 4 < 2 ** 31:
+        kernel = "eg"                          # a layout that carries edge groups: the kernel tgnn_forward runs on it
     if kernel == "eg":
         grp = graph_groups(graph)
         if grp is None or c != 32:
