@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 evidence for profiles/: the bench line, rocprofv3 kernel stats of the bench command and of the production forward alone, HBM /
-# SQ counters of the column NNConv and the GIN pair (separate --pmc passes, kernel-trace only, every profiler command under its own
+# SQ counters of the edge-group NNConv and the GIN pair (separate --pmc passes, kernel-trace only, every profiler command under its own
 # timeout), HBM bytes of the whole forward per kernel, timelines (100 000 and 10 000 nodes), mid sizes, config 3, the sharded step at
 # world 1.  Output: gpurun_out/r05/ (copied to profiles/r05_*).  The studies of the round have their own scripts (profiles/README.md).
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
@@ -19,7 +19,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" \
   i=$((i+1)); rm -rf /tmp/pmc_r05_$i
   timeout 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc_r05_$i -- python scratch/run_nnconv_only.py nnconv > /tmp/pmc_r05_$i.log 2>&1
   f=$(find /tmp/pmc_r05_$i -name "*counter_collection.csv" | head -1)
-  [ -n "$f" ] && python scratch/pmc.py cols_kernel $f >> $O/pmc_nnconv.txt
+  [ -n "$f" ] && python scratch/pmc.py nnconv32_eg $f >> $O/pmc_nnconv.txt
 done
 for grp in "FETCH_SIZE" "WRITE_SIZE"; do
   rm -rf /tmp/pmc_r05_g

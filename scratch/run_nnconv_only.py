@@ -1,5 +1,5 @@
-"""Runs only NNConv / GIN launches (for PMC passes): N=100k/Ea=1M synthetic graph.  argv[1]: nnconv = the column kernel as
-tgnn_forward runs it (fp16 x 2 split), nnconv_bf16x3 = its bf16 x 3 variant (the per-op entry point), gin = the collision branch."""
+"""Runs only NNConv / GIN launches (for PMC passes): N=100k/Ea=1M synthetic graph.  argv[1]: nnconv = the edge-group kernel as
+tgnn_forward runs it at this size, nnconv_cols = the type-column kernel (fp16 x 2 split), nnconv_bf16x3 = its bf16 x 3 variant (the per-op entry point), gin = the collision branch."""
 import sys, torch
 sys.path.insert(0, '.')
 from tilingnn_amd import TilinGNN, ops
@@ -16,6 +16,8 @@ conv = net.brch_1_graph_conv_layers[0]
 wtab = ops.edge_weight_table(adj_attr, g, *conv.nnConv._edge_mlp_params(), 32)
 for _ in range(5):
     if which == 'nnconv':
+        ops.nnconv_mean(h, g, wtab, conv.nnConv.root, conv.nnConv.bias, ops.ACT_LEAKY_RELU, ops.new_partials(32, dev), kernel="eg")
+    elif which == 'nnconv_cols':
         ops.nnconv_mean(h, g, wtab, conv.nnConv.root, conv.nnConv.bias, ops.ACT_LEAKY_RELU, ops.new_partials(32, dev), kernel="cols_f16")
     elif which == 'nnconv_bf16x3':
         ops.nnconv_mean(h, g, wtab, conv.nnConv.root, conv.nnConv.bias, ops.ACT_LEAKY_RELU, ops.new_partials(32, dev), kernel="cols")
