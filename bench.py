@@ -248,14 +248,15 @@ def gather_ceiling(dev, n_rows=100_000):
     return out
 
 
-def kernel_roofline(class_ms, n, ea, ec, n_types):
+def kernel_roofline(class_ms, n, ea, ec, n_types, edge_groups=True):
     """`roofline` of the NNConv column kernel (the path's scatter-add) + the GIN pair and merge, all against the HBM
     bound with SURVEY 8d's algorithmic bytes; `achieved` = bytes / the average launch duration of the events above."""
     def per_launch_s(k):
         return class_ms[k]["ms_per_forward"] / max(1, class_ms[k]["launches_per_forward"]) * 1e-3
     t_nn = per_launch_s("nnconv")
     b_alg = nnconv_bytes(n, ea, n_types)
-    out = {"kernel": "nnconv32_eg_kernel (NNConv mean over edge groups: 16 source rows per gather, two chained MFMA products, per layer)",
+    out = {"kernel": "nnconv32_eg_kernel (NNConv mean over edge groups: 16 source rows per gather, two chained MFMA products, per layer)"
+                     if edge_groups else "nnconv32_cols_kernel (NNConv mean as a type-column MFMA product, per layer)",
            "bound": "hbm",
            "achieved": b_alg / t_nn / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_alg / t_nn / 1e9 / HBM_PEAK_GBS,
            "traffic": None, "algorithmic_bytes_per_launch": b_alg, "avg_launch_us": t_nn * 1e6,
@@ -469,7 +470,9 @@ def main():
     if not sharded:
         class_ms, n_types_seen = profiled_classes(net, x, adj, adj_attr, col, args.steps)
         dom = max(("nnconv", "gin", "dense_final"), key=lambda k: class_ms[k]["ms_per_forward"])
-        roofline = kernel_roofline(class_ms, n_total, ea_total, ec_total, n_types_seen)
+        from tilingnn_amd import ops as _ops
+        roofline = kernel_roofline(class_ms, n_total, ea_total, ec_total, n_types_seen,
+                                   edge_groups=bool(_ops.GROUPS and _ops.runs_general_schedule(n_total)))
         roofline["slowest_class"] = dom
         # THE headline fraction is the kernel's average launch duration inside the production two-stream forward (the
         # collision chain competes for the CUs), first block in -> last block out on the device clock -- the quantity a
@@ -578,7 +581,8 @@ def main():
                 ts.append((time.perf_counter() - tb) * 1e3)
             med = sorted(ts)[2]
             cls, nt = profiled_classes(net, xb, adjb, attrb, colb, 3)
-            rf = kernel_roofline(cls, n_big, int(adjb.shape[1]), int(colb.shape[1]), nt)
+            rf = kernel_roofline(cls, n_big, int(adjb.shape[1]), int(colb.shape[1]), nt,
+                                 edge_groups=bool(_ops.GROUPS and _ops.runs_general_schedule(n_big)))
             extras.append({"n_nodes": n_big, "n_adj_edges": int(adjb.shape[1]), "n_col_edges": int(colb.shape[1]),
                            "ms_per_step": med, "value": n_big / (med * 1e-3), "data": "synthetic, drawn on the device",
                            "nnconv": {k: rf[k] for k in ("avg_launch_us", "achieved", "frac")},
