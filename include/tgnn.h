@@ -760,6 +760,14 @@ int tgnn_nnconv64_bf16_fwd(const void *h_bf16, int64_t n_src_rows, const int32_t
                            const int32_t *col_src, const float *wtab, int32_t n_types, const float *root,
                            const float *bias, int64_t n_nodes, int32_t act, void *out_bf16, void *wimg_scratch,
                            double *bn_partial, int32_t *n_partials_host, tgnn_stream_t stream);
+/* The same op over the layout's edge groups (tgnn_nnconv_eg_build) instead of its type columns: csrc/bf16_path.hip,
+ * nnconv64_bf16_eg_kernel -- what tgnn_forward_bf16 runs on a graph that carries groups (tgnn_set_nnconv_eg).  The messages
+ * are rounded to bf16 once before they are folded into their rows (one more rounding of 2^-9 beside those of the operands and
+ * of the result: inside the path's stated 2^-7). */
+int tgnn_nnconv64_bf16_eg_fwd(const void *h_bf16, int64_t n_src_rows, const int32_t *tile_grp_ptr, const int32_t *grp,
+                              const float *wtab, int32_t n_types, const float *root, const float *bias, int64_t n_nodes,
+                              int32_t act, void *out_bf16, void *wimg_scratch, double *bn_partial, int32_t *n_partials_host,
+                              tgnn_stream_t stream);
 /* GINConv (MLP 64 -> 32 -> 64 -> 64, sigmoids) + optional LeakyReLU; in_stat as in tgnn_gin_fwd; z_scratch_bf16 [N][64] */
 int tgnn_gin64_bf16_fwd(const void *a_bf16, const float *in_stat, const int32_t *rowptr, const int32_t *col_src,
                         const float *eps, const float *w1, const float *b1, const float *w2, const float *b2,

@@ -179,3 +179,44 @@ def test_forward_on_groups_against_columns_and_fallback(dev):
     assert bool(torch.isfinite(p_groups).all())
     assert float((p_groups - p_cols).abs().max()) < 2e-4
     assert float((p_groups - p_csr).abs().max()) < 2e-4
+
+
+@pytest.mark.parametrize("n,ea,n_types,run", [(37, 200, 3, 0), (1254, 9000, 13, 0), (1000, 12000, 1, 40), (100_000, 1_000_000, 13, 20)])
+@pytest.mark.parametrize("leaky", [False, True])
+def test_bf16_width64_op_on_groups(dev, n, ea, n_types, run, leaky):
+    """BASELINE config 3's NNConv (width 64, bf16 storage; csrc/bf16_path.hip: nnconv64_bf16_eg_kernel) over edge groups: against
+    fp64 on the bf16-rounded operands within the path's stated 2^-7 of the output's max-norm (tests/test_bf16_path.py), and
+    against the type-column kernel of the same path (both outputs are bf16: up to an ulp, 2^-7 of the max-norm, apart); the
+    BatchNorm sums are those of the stored (rounded) values."""
+    from tilingnn_amd import ops, ops_bf16
+    import oracle.tilingnn_oracle as orc
+    adj, attr = random_layout(n, ea, n_types, seed=n + 7, max_type_run=run)
+    adj, attr = adj.to(dev), attr.to(dev)
+    g = ops.prepare_graph(n, adj, attr, torch.zeros(2, 0, dtype=torch.int64, device=dev), groups=True)
+    gen = torch.Generator().manual_seed(2)
+    h = torch.randn(n, 64, generator=gen).to(dev).to(torch.bfloat16)
+    wtab = torch.rand(g.n_types, 64, 64, generator=gen).to(dev)
+    root = (torch.randn(64, 64, generator=gen) * 0.3).to(dev)
+    bias = torch.randn(64, generator=gen).to(dev)
+    act = ops.ACT_LEAKY_RELU if leaky else ops.ACT_NONE
+    src, dst = adj[0], adj[1]
+    et = g.edge_type[:ea].long()
+    wb, rb = wtab.to(torch.bfloat16).double(), root.to(torch.bfloat16).double()       # the path rounds its weights once
+    msg = torch.einsum("ek,eko->eo", h.double()[src], wb[et])
+    agg = torch.zeros(n, 64, dtype=torch.float64, device=dev).index_add_(0, dst, msg)
+    deg = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, dst, torch.ones_like(dst, dtype=torch.float64))
+    want = agg / deg.clamp(min=1).unsqueeze(1) + h.double() @ rb + bias.double()
+    if leaky:
+        want = torch.where(want >= 0, want, want * 0.01)
+    part = ops.new_partials(64, dev)
+    out, npart = ops_bf16.nnconv64(h, g, wtab, root, bias, act, part, kernel="eg")
+    assert out.dtype == torch.bfloat16 and out.shape == (n, 64) and bool(torch.isfinite(out.float()).all())
+    assert orc.rel_max_err(out.float().cpu(), want.cpu()) < 2.0 ** -7
+    out_c, _ = ops_bf16.nnconv64(h, g, wtab, root, bias, act, ops.new_partials(64, dev), kernel="cols")
+    assert orc.rel_max_err(out.float().cpu(), out_c.double().cpu()) < 2.0 ** -7      # (two roundings to bf16: up to an ulp apart)
+    p = part[:npart * 128].view(npart, 128).sum(0)
+    stored = out.double()
+    assert float((p[:64] - stored.sum(0)).abs().max()) < 1e-9 * float(stored.abs().sum(0).max())
+    assert float((p[64:] - (stored * stored).sum(0)).abs().max()) < 1e-9 * float((stored * stored).sum(0).max())
+    out_d, _ = ops_bf16.nnconv64(h, g, wtab, root, bias, act, ops.new_partials(64, dev))    # a layout with groups: the default
+    assert torch.equal(out, out_d)

@@ -187,6 +187,7 @@ def _load() -> C.CDLL:
         "tgnn_f32_to_bf16": (C.c_int, [p, i64, p, p]),
         "tgnn_nnconv64_image_elems": (sz, [i32]),
         "tgnn_nnconv64_bf16_fwd": (C.c_int, [p, i64, p, p, p, p, i32, p, p, i64, i32, p, p, p, pi32, p]),
+        "tgnn_nnconv64_bf16_eg_fwd": (C.c_int, [p, i64, p, p, p, i32, p, p, i64, i32, p, p, p, pi32, p]),
         "tgnn_gin64_bf16_fwd": (C.c_int, [p, p, p, p, p, p, p, p, p, p, p, i64, i32, p, p, p, pi32, p]),
         "tgnn_collconv64_bf16_fwd": (C.c_int, [p, p, p, p, p, p, p, p, p, p, p, p, p, p, p, i64, p, p, p, p, p, p]),
         "tgnn_merge_bf16_fwd": (C.c_int, [p, p, p, p, p, i64, i32, p, p]),
@@ -235,7 +236,7 @@ EXPORTED_SYMBOLS = (
     "tgnn_bn_bwd_reduce", "tgnn_bn_bwd_apply", "tgnn_merge_bwd_reduce", "tgnn_wgrad_workspace_bytes", "tgnn_wgrad",
     "tgnn_sigmoid_mlp_bwd_workspace_bytes", "tgnn_sigmoid_mlp_bwd",
     "tgnn_nnconv_type_sum", "tgnn_csr_degree", "tgnn_unsupervised_loss_bwd",
-    "tgnn_f32_to_bf16", "tgnn_nnconv64_image_elems", "tgnn_nnconv64_bf16_fwd", "tgnn_gin64_bf16_fwd", "tgnn_collconv64_bf16_fwd", "tgnn_merge_bf16_fwd",
+    "tgnn_f32_to_bf16", "tgnn_nnconv64_image_elems", "tgnn_nnconv64_bf16_fwd", "tgnn_nnconv64_bf16_eg_fwd", "tgnn_gin64_bf16_fwd", "tgnn_collconv64_bf16_fwd", "tgnn_merge_bf16_fwd",
     "tgnn_dense_bf16_slots_fwd", "tgnn_forward_bf16_workspace_bytes", "tgnn_forward_bf16")
 
 

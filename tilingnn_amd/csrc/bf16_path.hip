@@ -15,6 +15,7 @@
 // Parity (tests/test_bf16_path.py): per op, teacher forced on bf16-rounded inputs against the fp64 oracle; the stated
 // tolerance is 2^-7 = 7.8e-3 of the output's max-norm (one bf16 rounding of the weights, one of the output).
 #include <atomic>
+#include <type_traits>
 
 #include "tgnn_common.h"
 
@@ -24,6 +25,8 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
+using bf16x4s = __attribute__((ext_vector_type(4))) short;   // (operand type of the K = 16 bf16 matrix builtin)
 
 constexpr int kC = 64;                      // network_width of this path
 constexpr int kW64Frag = 8 * 64;            // 16-byte fragments per type image: [M block 4][K chunk 2][lane 64]
@@ -924,6 +927,314 @@ extern "C" int tgnn_nnconv64_bf16_fwd(const void *h_bf16, int64_t n_src_rows, co
                            static_cast<__bf16 *>(out_bf16), bn_partial, n_partials_host, s);
 }
 
+// ------------------------------------------------------------------------------------------ NNConv, width 64, on EDGE GROUPS
+// The same op over the edge-group structure of nnconv_eg.hip (graph_prep.hip: nnconv_eg_kernel) instead of the type columns:
+// a gather instruction fetches the sources of 16 in-edges of ONE type of a 16-row tile (15.6 groups per tile 68 % full at the
+// benchmark layout against 34.8 columns 29 % full), the gathered rows ARE the A operand (bf16 storage: no split) of
+//     M [16 edges x 64] = G [16 x 64] . W_t            8 x v_mfma_f32_16x16x32_bf16 (4 output blocks x 2 K chunks)
+// and the messages, rounded to bf16 once (the operands and the result of this path are bf16: one more rounding of 2^-9, inside
+// the stated 2^-7), are folded into their destination rows by
+//     out [16 rows x 64] += S [16 rows x 16 edges] . M   S = the group's 0 / 1 selection matrix (4 x v_mfma_f32_16x16x16_bf16)
+// The accumulator layout of the first product is the B-operand layout of the second.  The root group (last of a tile): the edge
+// sum is first turned into the mean (rows' 1 / max(deg, 1)), then the root product joins with S = I.
+struct Msg64 {
+    u32x2 m[4];                                             // M[edges 4 fq + r][channel 16 mb + fj] as 4 bf16, mb = 0 .. 3
+    bf16x4 sel;                                             // S[row fj][edges 4 fq .. 4 fq + 3]
+};
+constexpr int kEg64Root = 1 << 8;
+
+template <int WAVES, int ACT>
+__global__ __launch_bounds__(WAVES * 64, 4) void nnconv64_bf16_eg_kernel(
+    const __bf16 *__restrict__ h, uint32_t h_bytes, const int *__restrict__ tile_grp_ptr, const int2 *__restrict__ grp,
+    const __bf16 *__restrict__ wimg, int n_types, const float *__restrict__ bias, int64_t n, __bf16 *__restrict__ out,
+    double *__restrict__ bn_partial, GinFin fin) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *wl = lds;                                        // [(T+1)][8 fragments][64 lanes] x 16 B
+    float *bias_s = lds + (n_types + 1) * kW64Floats;       // [64]
+    bf16x4 *lut = reinterpret_cast<bf16x4 *>(bias_s + kC);  // [16]: 4 selection bits -> 4 bf16 of 0 / 1
+    float *stage = bias_s + kC + 32;                        // [WAVES][16][20]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fj = lane & 15, fq = lane >> 4;
+    constexpr int kThreads = WAVES * 64;
+    float *stg = stage + wave * kStage64;
+
+    static_assert(WAVES % 4 == 0, "whole SIMD quads");
+    const uint32_t n_tiles = (uint32_t)((n + 15) / 16);
+    const uint32_t nblk = gridDim.x;
+    uint32_t blk = blockIdx.x;
+    if (nblk >= 8 && (nblk & 7) == 0) blk = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    const uint32_t slot = blk * 4 + (wave & 3), n_slots = nblk * 4;
+    const uint32_t tq = n_tiles / n_slots, tr = n_tiles % n_slots;
+    const uint32_t q0 = tq * slot + tr * slot / n_slots, q1 = tq * (slot + 1) + tr * (slot + 1) / n_slots;
+    constexpr uint32_t kSubs = WAVES / 4;
+    const uint32_t sub = wave >> 2;
+    const int64_t t0 = q0 + (q1 - q0) * sub / kSubs, t1 = q0 + (q1 - q0) * (sub + 1) / kSubs;
+    const int cbeg = __builtin_amdgcn_readfirstlane(tile_grp_ptr[t0]);
+    const int cend = __builtin_amdgcn_readfirstlane(tile_grp_ptr[t1]);
+
+    double bs[4] = {0, 0, 0, 0}, bq[4] = {0, 0, 0, 0};       // BN sums of channel 16 mb + fj over rows 4 fq .. 4 fq + 3
+
+    const __amdgpu_buffer_rsrc_t h_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(h), 0, (int)h_bytes, 0x00020000);
+    const uint32_t fq_bytes = (uint32_t)fq * 16u;
+    auto load_four = [&](int p, int &s4, int &m4) {         // groups p .. p+3: lane (fj, fq) <- group p + fq, word fj
+        const int pc = p < cend ? p : cbeg;
+        const int2 v = grp[(int64_t)pc * 16 + lane];
+        s4 = v.x;
+        m4 = v.y;
+    };
+    auto unpack = [&](auto steady, int p, int u, int s4, int m4, int &s, int &m, int &meta) {
+        s = __shfl(s4, u * 16 + fj, 64);
+        m = __shfl(m4, u * 16 + fj, 64);
+        meta = __builtin_amdgcn_readlane(m4, u * 16) >> 16;
+        if constexpr (!decltype(steady)::value)
+            if (p + u >= cend) {                             // wave-uniform: past the share = an empty group of type 0
+                s = -1;
+                m = 0;
+                meta = 0;
+            }
+    };
+    int64_t gtile = t0;
+    auto own_off_of = [&](int64_t tile) -> uint32_t {
+        const int64_t r = tile * 16 + fj;
+        return r < n ? (uint32_t)r * 128u + fq_bytes : 0x80000000u;
+    };
+    uint32_t own_off = own_off_of(gtile);
+    auto issue_gather = [&](int s, int meta, u32x4 (&x)[2]) {
+        const bool root = (meta & kEg64Root) != 0;           // wave-uniform
+        const uint32_t off = root ? own_off : ((uint32_t)s << 7) + fq_bytes;   // s = -1: beyond the rows, loads zeros
+        x[0] = __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, off, 0, 0);       // K chunk 0: channels 8 fq ..
+        x[1] = __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, off + 64u, 0, 0); // K chunk 1: channels 32 + 8 fq ..
+        if (root) {
+            ++gtile;
+            own_off = own_off_of(gtile);
+        }
+    };
+
+    f32x4 d[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) d[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    int64_t ctile = t0;
+    auto stage1 = [&](int m, int meta, const u32x4 (&x)[2]) -> Msg64 {
+        const int t = meta & 0xff;
+        const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(wl + t * kW64Floats) + lane;
+        Msg64 r;
+        r.sel = lut[(m >> (4 * fq)) & 15];
+        const bf16x8 x0 = __builtin_bit_cast(bf16x8, x[0]), x1 = __builtin_bit_cast(bf16x8, x[1]);
+        // two output blocks at a time: all eight fragments in flight at once are 32 registers the gather pipeline needs
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            bf16x8 w[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) w[f] = wp[(4 * hb + f) * 64];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int mb = 2 * hb + k;
+                f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, w[2 * k], zero4, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, w[2 * k + 1], acc, 0, 0, 0);
+                const bf16x4 mv = {(__bf16)acc[0], (__bf16)acc[1], (__bf16)acc[2], (__bf16)acc[3]};
+                r.m[mb] = __builtin_bit_cast(u32x2, mv);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return r;
+    };
+    auto fold16 = [&](const Msg64 &g) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+            d[mb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf16x4s, g.sel), __builtin_bit_cast(bf16x4s, g.m[mb]), d[mb], 0, 0, 0);
+    };
+    // the edge sum of rows 4 fq + r -> their mean (s: float bits of max(deg, 1) of row fj, -1 = row >= n)
+    auto to_mean = [&](int s) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int dg = __shfl(s, 4 * fq + r, 64);
+            const float inv = dg >= 0 ? 1.0f / __int_as_float(dg) : 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) d[mb][r] *= inv;
+        }
+    };
+    auto finish_tile = [&](int s) {
+        // lane (fj, fq): channel 16 mb + fj of rows 4 fq + r -> through the wave's LDS tile -> row fj, channels 16 mb + 4 fq .. + 3
+        bool rv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rv[r] = __shfl(s, 4 * fq + r, 64) >= 0;
+        const bool valid = s >= 0;
+        const int64_t v = ctile * 16 + fj;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const float b = bias_s[16 * mb + fj];
+            double sum = 0, sq = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float o = d[mb][r] + b;
+                if constexpr (ACT == TGNN_ACT_LEAKY_RELU) o = leakyf_(o);
+                o = bf16_round(o);                             // statistics of what is stored
+                stg[(4 * fq + r) * 20 + fj] = o;
+                if (rv[r]) {
+                    sum += (double)o;
+                    sq += (double)o * (double)o;
+                }
+            }
+            bs[mb] += sum;
+            bq[mb] += sq;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const float4 o4 = *reinterpret_cast<const float4 *>(stg + fj * 20 + 4 * fq);
+            const bf16x4 ob = {(__bf16)o4.x, (__bf16)o4.y, (__bf16)o4.z, (__bf16)o4.w};   // (exact: rounded above)
+            if (valid) *reinterpret_cast<bf16x4 *>(out + v * kC + 16 * mb + 4 * fq) = ob;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            d[mb] = zero4;
+        }
+        ++ctile;
+    };
+    // one group at a time (two groups per K = 32 fold, as the fp32 kernel does, keep two groups' messages and 16 operand
+    // fragments alive: 128 registers do not hold them beside the gather pipeline)
+    auto consume = [&](int s, int m, int meta, const u32x4 (&x)[2]) {
+        const Msg64 g = stage1(m, meta, x);
+        const bool root = (meta & kEg64Root) != 0;           // wave-uniform
+        if (root) to_mean(s);
+        fold16(g);
+        if (root) finish_tile(s);
+    };
+
+    int s4n, m4n;
+    int xs[4], xm[4], xt[4];
+    u32x4 x[4][2];
+    {
+        int s4, m4;
+        load_four(cbeg, s4, m4);
+        load_four(cbeg + 4, s4n, m4n);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            unpack(std::false_type{}, cbeg, u, s4, m4, xs[u], xm[u], xt[u]);
+            issue_gather(xs[u], xt[u], x[u]);
+        }
+    }
+    {   // (the first gathers are in flight: the block's weight image lands behind them)
+        const int n4 = (n_types + 1) * kW64Floats / 4;
+        const float4 *src = reinterpret_cast<const float4 *>(wimg);
+        for (int i = tid; i < n4; i += 4 * kThreads) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = src[i + u * kThreads < n4 ? i + u * kThreads : n4 - 1];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i + u * kThreads < n4) reinterpret_cast<float4 *>(wl)[i + u * kThreads] = v[u];
+        }
+        if (tid < kC) bias_s[tid] = bias[tid];
+        if (tid < 16) {
+            bf16x4 e;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) e[b] = (tid >> b & 1) ? (__bf16)1.0f : (__bf16)0.0f;
+            lut[tid] = e;
+        }
+    }
+    __syncthreads();
+    int base = cbeg;
+    for (; base + 8 <= cend; base += 4) {                    // steady state: the four gathered in this round lies before cend
+        int s4c, m4c;
+        load_four(base + 8, s4c, m4c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            consume(xs[u], xm[u], xt[u], x[u]);
+            unpack(std::true_type{}, base + 4, u, s4n, m4n, xs[u], xm[u], xt[u]);
+            issue_gather(xs[u], xt[u], x[u]);
+        }
+        s4n = s4c;
+        m4n = m4c;
+    }
+    for (; base < cend; base += 4) {
+        int s4c, m4c;
+        load_four(base + 8, s4c, m4c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            consume(xs[u], xm[u], xt[u], x[u]);
+            unpack(std::false_type{}, base + 4, u, s4n, m4n, xs[u], xm[u], xt[u]);
+            issue_gather(xs[u], xt[u], x[u]);
+        }
+        s4n = s4c;
+        m4n = m4c;
+    }
+
+    if (bn_partial) {
+        __syncthreads();
+        double *red = reinterpret_cast<double *>(lds);       // [WAVES][64 lanes][8]
+        double *mine = red + ((int64_t)wave * 64 + lane) * 8;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) { mine[mb] = bs[mb]; mine[4 + mb] = bq[mb]; }
+        __syncthreads();
+        if (tid < 128) {                                     // tid = which * 64 + channel
+            const int which = tid >> 6, ch = tid & 63, mb = ch >> 4, j = ch & 15;
+            double acc = 0;
+            for (int w = 0; w < WAVES; ++w)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc += red[((int64_t)w * 64 + q * 16 + j) * 8 + which * 4 + mb];
+            if (fin.counter) st_partial_sc1(bn_partial, (int64_t)blockIdx.x * 128 + tid, acc);
+            else bn_partial[(int64_t)blockIdx.x * 128 + tid] = acc;
+        }
+        if (fin.counter) bn_fold_finish<kC>(fin, bn_partial, red + (size_t)WAVES * 64 * 8);
+    }
+}
+
+static size_t nnconv64_eg_lds_bytes(int n_types, int waves) {
+    const size_t a = ((size_t)(n_types + 1) * kW64Floats + kC + 32 + (size_t)waves * kStage64) * sizeof(float);
+    const size_t b = (size_t)waves * 64 * 8 * sizeof(double) + bn_fold_scratch_bytes(kC);
+    return a > b ? a : b;
+}
+
+static int launch_nnconv64_eg(const __bf16 *h, int64_t n_src_rows, const int32_t *tile_grp_ptr, const int32_t *grp, const __bf16 *wimg,
+                              int32_t n_types, const float *bias, int64_t n_nodes, int32_t act, __bf16 *out, double *bn_partial,
+                              int32_t *n_partials_host, hipStream_t s, const GinFin *fin = nullptr) {
+    constexpr int WAVES = 16;
+    const bool leaky = act == TGNN_ACT_LEAKY_RELU;
+    auto kern = leaky ? nnconv64_bf16_eg_kernel<WAVES, TGNN_ACT_LEAKY_RELU> : nnconv64_bf16_eg_kernel<WAVES, TGNN_ACT_NONE>;
+    static LdsOptIn site[2];
+    TGNN_CHECK_HIP(opt_in_dynamic_lds(kern, (int)kMaxLds64, site[leaky]));
+    const int64_t n_tiles = (n_nodes + 15) / 16;
+    int64_t blocks = (n_tiles + 3) / 4;
+    const int64_t cap = cus_minus(32);                       // (CUs left to the collision chain, as in the fp32 path)
+    if (blocks > cap) blocks = cap;
+    if (blocks >= 8) blocks &= ~(int64_t)7;
+    if (blocks < 1) blocks = 1;
+    GinFin f{};
+    if (fin && bn_partial) {
+        f = *fin;
+        f.job.partials = bn_partial;
+        f.job.n_partials = (int)blocks;
+    }
+    kern<<<(unsigned)blocks, WAVES * 64, nnconv64_eg_lds_bytes(n_types, WAVES), s>>>(
+        h, (uint32_t)(n_src_rows * 128), tile_grp_ptr, reinterpret_cast<const int2 *>(grp), wimg, n_types, bias, n_nodes, out, bn_partial, f);
+    if (n_partials_host) *n_partials_host = (int32_t)blocks;
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}
+
+extern "C" int tgnn_nnconv64_bf16_eg_fwd(const void *h_bf16, int64_t n_src_rows, const int32_t *tile_grp_ptr, const int32_t *grp,
+                                         const float *wtab, int32_t n_types, const float *root, const float *bias, int64_t n_nodes,
+                                         int32_t act, void *out_bf16, void *wimg_scratch, double *bn_partial,
+                                         int32_t *n_partials_host, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
+    TGNN_CHECK_ARG(n_nodes >= 1 && n_src_rows >= n_nodes && n_src_rows * 128 < (int64_t(1) << 31), "rows");
+    TGNN_CHECK_ARG(act == TGNN_ACT_NONE || act == TGNN_ACT_LEAKY_RELU, "activation");
+    TGNN_CHECK_ARG(h_bf16 && tile_grp_ptr && grp && root && bias && out_bf16 && wimg_scratch, "null pointer");
+    TGNN_CHECK_ARG(n_types == 0 || wtab, "null weight table");
+    if (nnconv64_eg_lds_bytes(n_types, 16) > kMaxLds64) {
+        set_error("tgnn_nnconv64_bf16_eg_fwd: %d edge types do not fit the LDS weight image", n_types);
+        return TGNN_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    RootPtrs64 rp{};
+    rp.p[0] = root;
+    nnconv64_image_kernel<<<dim3(n_types + 1, 1), 256, 0, s>>>(wtab, rp, n_types, static_cast<__bf16 *>(wimg_scratch));
+    return launch_nnconv64_eg(static_cast<const __bf16 *>(h_bf16), n_src_rows, tile_grp_ptr, grp, static_cast<const __bf16 *>(wimg_scratch),
+                              n_types, bias, n_nodes, act, static_cast<__bf16 *>(out_bf16), bn_partial, n_partials_host, s);
+}
+
 static unsigned gin64_agg_blocks(int64_t n) {
     const int64_t rows_per_xcd = (n + 7) / 8;
     return (unsigned)(8 * ((rows_per_xcd + 31) / 32));
@@ -1088,12 +1399,14 @@ extern "C" int tgnn_forward_bf16(const tgnn_model_dims *dims, const void *const 
     TGNN_CHECK_ARG(params_host && graph && probs && x, "null pointer");
     const int64_t n = graph->n_nodes;
     TGNN_CHECK_ARG(n >= 2, "train-mode BatchNorm needs more than one row");
-    TGNN_CHECK_ARG(graph->adj_rowptr && graph->col_rowptr && graph->nn_tile_col_ptr && graph->nn_col_meta && graph->nn_col_src,
-                   "graph pointers (the column structure is required)");
+    const bool have_cols = graph->nn_tile_col_ptr && graph->nn_col_meta && graph->nn_col_src;
+    const bool eg = graph->nn_tile_grp_ptr && graph->nn_grp && tgnn_set_nnconv_eg(-1) != 0;   // (edge groups: nnconv64_bf16_eg_kernel)
+    TGNN_CHECK_ARG(graph->adj_rowptr && graph->col_rowptr && (have_cols || eg),
+                   "graph pointers (the NNConv column structure or the edge groups are required)");
     TGNN_CHECK_ARG(n * 128 < (int64_t(1) << 31), "rows must lie within 2 GB");
     const int T = graph->n_types, D = dims->network_depth, fx = dims->node_features_dim, fe = dims->adj_edge_features_dim;
     TGNN_CHECK_ARG(T == 0 || (adj_edge_attr && graph->type_rep_edge), "adjacency pointers");
-    if (nnconv64_lds_bytes(T, 16) > kMaxLds64) {
+    if ((eg ? nnconv64_eg_lds_bytes(T, 16) : nnconv64_lds_bytes(T, 16)) > kMaxLds64) {
         set_error("tgnn_forward_bf16: %d edge types do not fit the LDS weight image", T);
         return TGNN_ERR_UNSUPPORTED;
     }
@@ -1174,9 +1487,13 @@ extern "C" int tgnn_forward_bf16(const tgnn_model_dims *dims, const void *const 
         fin1.n_total = n;
         fin1.eps = eps;
         fin1.momentum = momentum;
-        TGNN_TRY64(launch_nnconv64(h1, n, graph->nn_tile_col_ptr, graph->nn_col_meta, graph->nn_col_src,
-                                   w.wimg + (size_t)i * (T + 1) * kC * kC, T, P.f(b + 7), n, TGNN_ACT_LEAKY_RELU, w.a1, w.part1,
-                                   &np1, s, &fin1));
+        if (eg)
+            TGNN_TRY64(launch_nnconv64_eg(h1, n, graph->nn_tile_grp_ptr, graph->nn_grp, w.wimg + (size_t)i * (T + 1) * kC * kC, T,
+                                          P.f(b + 7), n, TGNN_ACT_LEAKY_RELU, w.a1, w.part1, &np1, s, &fin1));
+        else
+            TGNN_TRY64(launch_nnconv64(h1, n, graph->nn_tile_col_ptr, graph->nn_col_meta, graph->nn_col_src,
+                                       w.wimg + (size_t)i * (T + 1) * kC * kC, T, P.f(b + 7), n, TGNN_ACT_LEAKY_RELU, w.a1, w.part1,
+                                       &np1, s, &fin1));
         if (s2) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[1 + i], 0));
         const __bf16 *resid = i >= 2 ? w.mid + (size_t)(i - 2) * n * kC : nullptr;
         merge_bf16_kernel<<<ew_grid64(n * kC / 8), 256, 8 * kC * sizeof(float), s>>>(w.a1, w.stat1, w.a2[i & 1], nullptr, resid, n * kC / 8, kC,

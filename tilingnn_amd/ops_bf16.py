@@ -40,16 +40,26 @@ def max_types() -> int:
 
 
 def nnconv64(h: Tensor, graph: ops.PreparedGraph, wtab: Tensor, root: Tensor, bias: Tensor, act: int = ops.ACT_NONE,
-             partials: Optional[Tensor] = None) -> Tuple[Tensor, int]:
+             partials: Optional[Tensor] = None, kernel: Optional[str] = None) -> Tuple[Tensor, int]:
+    """kernel: None = over the structure the layout carries (edge groups where it has them, as tgnn_forward_bf16 does), "eg" /
+    "cols" = over its edge groups / type columns (built on first use)."""
     h = _bf16c(h, "x")
     n = graph.n_nodes
-    if ops.graph_columns(graph) is None:
-        raise ValueError("the bf16 NNConv runs on the type-column structure (prepare_graph(columns=True))")
     if tuple(root.shape) != (WIDTH, WIDTH) or tuple(bias.shape) != (WIDTH,):
         raise ValueError("NNConv root/bias shape mismatch")
     out = torch.empty(n, WIDTH, dtype=torch.bfloat16, device=h.device)
     wimg = torch.empty(lib.tgnn_nnconv64_image_elems(graph.n_types), dtype=torch.bfloat16, device=h.device)
     npart = C.c_int32(0)
+    if kernel == "eg" or (kernel is None and graph.groups is not None):
+        grp = ops.graph_groups(graph)
+        if grp is None:
+            raise ValueError("the layout has more edge types than the edge-group structure takes")
+        check(lib.tgnn_nnconv64_bf16_eg_fwd(ptr(h), int(h.shape[0]), ptr(grp.tile_grp_ptr), ptr(grp.grp), ptr(ops._f32c(wtab, "wtab")),
+                                            graph.n_types, ptr(ops._f32c(root, "root")), ptr(ops._f32c(bias, "bias")), n, act,
+                                            ptr(out), ptr(wimg), ptr(partials), C.byref(npart), _lib.current_stream(h.device)))
+        return out, npart.value
+    if ops.graph_columns(graph) is None:
+        raise ValueError("the bf16 NNConv runs on the type-column structure (prepare_graph(columns=True))")
     tl = ops.graph_columns(graph)
     check(lib.tgnn_nnconv64_bf16_fwd(ptr(h), int(h.shape[0]), ptr(tl.tile_col_ptr), ptr(tl.col_meta), ptr(tl.col_src),
                                      ptr(ops._f32c(wtab, "wtab")), graph.n_types, ptr(ops._f32c(root, "root")),
@@ -131,15 +141,9 @@ def forward(net, x: Tensor, adj_e_index: Tensor, adj_e_features: Tensor, col_e_i
     table, dev = net._param_table()
     n = int(x.shape[0])
     if graph is None:
-        graph = ops.prepare_graph(n, adj_e_index, adj_e_features, col_e_idx, groups=False)
-    if graph.cols is None and graph.groups is not None:      # (a layout prepared for the fp32 network: its columns on first use)
-        import dataclasses
-        hit = graph.__dict__.get("_with_cols")
-        if hit is None:
-            hit = graph.__dict__["_with_cols"] = dataclasses.replace(graph, cols=ops.graph_columns(graph), groups=None)
-        graph = hit
-    if graph.cols is None or graph.n_types > max_types():
-        raise ValueError(f"the bf16 path needs the type-column structure and at most {max_types()} edge types")
+        graph = ops.prepare_graph(n, adj_e_index, adj_e_features, col_e_idx)
+    if (graph.cols is None and graph.groups is None) or graph.n_types > max_types():
+        raise ValueError(f"the bf16 path needs the NNConv type columns or edge groups and at most {max_types()} edge types")
     dims = net._dims()
     ws_bytes = lib.tgnn_forward_bf16_workspace_bytes(C.byref(dims), n, graph.n_types)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
