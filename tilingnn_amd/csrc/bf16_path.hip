@@ -53,19 +53,38 @@ __global__ void bn_apply_bf16_kernel(const float *__restrict__ v, const float *_
 // registers: BatchNorm of the collision branch applied to the fp32 rows its MLP left (gin64_bf16_mlp_kernel<3>)
 __global__ __launch_bounds__(256) void bn_apply64_bf16_kernel(const float *__restrict__ v, const float *__restrict__ stat, int64_t n8,
                                                               __bf16 *__restrict__ out) {
-    const int c0 = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % 8) * 8;
+    // [r5] the record as 8 16-byte loads per thread instead of 32 4-byte ones, and enough rows per thread to pay for them
+    // (launch_bn_apply64: ~6 items per thread, two in flight): 20 -> ~10 us per layer at 100 000 nodes, on config 3's long chain
+    const int c0 = (int)(threadIdx.x & 7) * 8;               // ((block * 256 + thread) % 8: 256 is a multiple of 8)
     float mh[8], ml[8], g[8], b[8];
+    {
+        const float4 *s4 = reinterpret_cast<const float4 *>(stat + c0);
+        const float4 a0 = s4[0], a1 = s4[1], b0 = s4[kC / 4], b1 = s4[kC / 4 + 1], c0v = s4[2 * kC / 4], c1v = s4[2 * kC / 4 + 1],
+                     d0 = s4[3 * kC / 4], d1 = s4[3 * kC / 4 + 1];
+        const float t0[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, t1[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w},
+                    t2[8] = {c0v.x, c0v.y, c0v.z, c0v.w, c1v.x, c1v.y, c1v.z, c1v.w}, t3[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        mh[k] = stat[c0 + k]; ml[k] = stat[kC + c0 + k]; g[k] = stat[2 * kC + c0 + k]; b[k] = stat[3 * kC + c0 + k];
+        for (int k = 0; k < 8; ++k) { mh[k] = t0[k]; ml[k] = t1[k]; g[k] = t2[k]; b[k] = t3[k]; }
     }
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
-        const float4 x0 = reinterpret_cast<const float4 *>(v)[2 * i], x1 = reinterpret_cast<const float4 *>(v)[2 * i + 1];
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    auto item = [&](const float4 &x0, const float4 &x1, int64_t i) {
         const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
         bf16x8 o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = (__bf16)bn_apply1(x[k], mh[k], ml[k], g[k], b[k]);
         reinterpret_cast<bf16x8 *>(out)[i] = o;
+    };
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + stride < n8; i += 2 * stride) {               // two items' loads in flight
+        const float4 *p = reinterpret_cast<const float4 *>(v) + 2 * i, *q = reinterpret_cast<const float4 *>(v) + 2 * (i + stride);
+        const float4 x0 = p[0], x1 = p[1], y0 = q[0], y1 = q[1];
+        item(x0, x1, i);
+        item(y0, y1, i + stride);
+    }
+    if (i < n8) {
+        const float4 *p = reinterpret_cast<const float4 *>(v) + 2 * i;
+        const float4 x0 = p[0], x1 = p[1];
+        item(x0, x1, i);
     }
 }
 
@@ -1281,7 +1300,7 @@ static int collconv64_launch(const __bf16 *h2_in, const int32_t *rowptr, const i
         jobs.job[0] = fin.job;
         launch_bn_finalize(jobs, 1, 0, kC, n_total, bn_eps, momentum, s);
     }
-    bn_apply64_bf16_kernel<<<ew_grid64(n * kC / 8), 256, 0, s>>>(pre32, bn.stat, n * kC / 8, out);
+    bn_apply64_bf16_kernel<<<ew_grid64(n * kC / 8, 512), 256, 0, s>>>(pre32, bn.stat, n * kC / 8, out);
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
 }
