@@ -1315,6 +1315,28 @@ static int prep_side_stream(hipStream_t *st, hipEvent_t *fork, hipEvent_t *join)
     return TGNN_OK;
 }
 
+// the event behind tgnn_graph_prep's early copy of the result words: one per host thread and device
+static thread_local hipEvent_t g_prep_words_ev[64] = {};
+static hipError_t prep_words_event(hipEvent_t *ev) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!g_prep_words_ev[dev]) {
+        e = hipEventCreateWithFlags(&g_prep_words_ev[dev], hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
+    *ev = g_prep_words_ev[dev];
+    return hipSuccess;
+}
+
+extern "C" int tgnn_graph_prep_wait(void) {
+    hipEvent_t ev = nullptr;
+    TGNN_CHECK_HIP(prep_words_event(&ev));
+    TGNN_CHECK_HIP(hipEventSynchronize(ev));
+    return TGNN_OK;
+}
+
 static int bk_blocks(int64_t e_max) {
     int64_t nblk = (e_max + 8191) / 8192;
     return (int)(nblk < 1 ? 1 : (nblk > 256 ? 256 : nblk));
@@ -1816,7 +1838,7 @@ extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edge
                                int32_t *type_rep_edge,
                                int32_t *col_rowptr, int32_t *col_src, int32_t *col_eid, int32_t *tile_col_ptr, int32_t *col_meta,
                                int32_t *col_slot_src, int32_t *mid_tile_nb, uint32_t *mid_ent, int32_t *tile_grp_ptr, int32_t *grp,
-                               void *ws, size_t ws_bytes, int32_t *result, tgnn_stream_t stream) {
+                               void *ws, size_t ws_bytes, int32_t *result, int32_t *result_host, tgnn_stream_t stream) {
     DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_nodes >= 1 && fe >= 1 && n_adj_edges >= 0 && n_col_edges >= 0, "shape");
     TGNN_CHECK_ARG(n_src_nodes >= n_nodes && n_src_nodes < (1ll << 31) - 1, "n_src_nodes must be >= n_nodes and fit int32");
@@ -1888,6 +1910,15 @@ extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edge
     if (!bucketed) {                                          // (the bucketed builder leaves result[3], result[4] itself)
         int64_t rb = (n_nodes + 1023) / 1024;
         prep_result_kernel<<<(unsigned)(rb > 256 ? 256 : rb), 256, 0, s>>>(col_rowptr, adj_rowptr, n_nodes, result);
+    }
+    // [r5] result_host (pinned): the words the caller reads -- type count, index errors, collision slots, largest in-degree, the
+    // fall-back flag: all of them final here -- travel to the host BEFORE the NNConv structure is built; the caller waits for
+    // the copy alone (tgnn_graph_prep_wait) and queues its forward while the structure's three launches still run
+    if (result_host) {
+        hipEvent_t ev_words = nullptr;
+        TGNN_CHECK_HIP(prep_words_event(&ev_words));
+        TGNN_CHECK_HIP(hipMemcpyAsync(result_host, result, 32 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        TGNN_CHECK_HIP(hipEventRecord(ev_words, s));
     }
     // column structure with the type count read on the device
     const int64_t nt16 = (n_nodes + kColTileRows - 1) / kColTileRows;

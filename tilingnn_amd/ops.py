@@ -255,6 +255,15 @@ SMALL_PREP = True      # one library call per layout (up to 4 096 nodes: one lau
 _pinned_words = {}
 
 
+def _pinned_result_words(dev):
+    import threading
+    key = (threading.get_ident(), dev.index, "early")
+    host = _pinned_words.get(key)
+    if host is None:
+        host = _pinned_words[key] = torch.empty(32, dtype=torch.int32, pin_memory=True)
+    return host
+
+
 def _read_back(res: Tensor):
     """The preparation's 32 result words on the host: an asynchronous copy into a pinned buffer of this thread + one stream
     synchronise (`.cpu()` allocates a pageable tensor and stages the copy: ~10 us more per call)."""
@@ -314,8 +323,17 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
     else:
         mid_args = (ptr(mid_nb), ptr(mid_ent)) if want_mid else (None,) * 2
         eg_args = (ptr(tile_grp_ptr), ptr(grp)) if want_eg else (None,) * 2
-        check(lib.tgnn_graph_prep(*head, *mid_args, *eg_args, ptr(tmp), ws_ints * 4, ptr(res), _stream(adj)))
-    host = _read_back(res)                                                       # the one sync
+        # the words read below are final before the NNConv structure is built: without the mid-size batches (whose result words
+        # come last) the library copies them out early and the forward is queued while the structure's launches still run
+        early = _pinned_result_words(dev) if not want_mid else None
+        check(lib.tgnn_graph_prep(*head, *mid_args, *eg_args, ptr(tmp), ws_ints * 4, ptr(res),
+                                  C.c_void_p(early.data_ptr()) if early is not None else None, _stream(adj)))
+    if not small and early is not None:
+        check(lib.tgnn_graph_prep_wait())                                        # the one sync: the copy of the words alone
+        host = early.tolist()
+        host[5] = host[10] = int(host[0] <= lib.tgnn_nnconv_cols_max_types() and not host[6])
+    else:
+        host = _read_back(res)                                                   # the one sync
     if host[1] or host[2]:
         raise IndexError(f"edge index out of range [0, {n_nodes}) in {'adj_e_index' if host[1] else 'col_e_idx'}")
     if host[6]:
