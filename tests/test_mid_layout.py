@@ -416,3 +416,34 @@ def test_a_starved_persistent_kernel_gives_up_and_the_module_falls_back(dev, n, 
         _lib.lib.tgnn_persist_fallback(0)
     assert _spin_ok(dev) == 0
     assert torch.equal(net.forward_checked(*inputs)[0].cpu(), net(*inputs)[0].cpu())   # healthy: the persistent schedule's own result
+
+
+def test_batches_that_do_not_fit_are_seen_behind_the_launches(dev):
+    """[r5] prepare_graph returns before the NNConv structure of a mid-size layout is built (tgnn_graph_prep copies the words the
+    host reads out early); the batches' verdict -- result[9]: a tile with more batches than the persistent layer loop takes --
+    comes with the LAST launch and is looked at behind the forward's launches (PreparedGraph.late_words_failed): a layout with
+    such a tile (one node with 600 in-edges) must still come back with the general schedule's probabilities."""
+    from tilingnn_amd import _lib, ops
+    from tilingnn_amd.synth import make_super_graph
+    n = 6000
+    sg = make_super_graph(n, 8 * n, 10 * n, tile_count=2, n_edge_types=13, seed=11)
+    x, adj, attr, col, _ = sg.to_torch(dev)
+    adj = adj.clone()
+    adj[1, :600] = 77                                             # a hub: its tile needs more than 24 batches
+    net, _ = make_net(dev, depth=3)
+    net.cache_graph = False
+    g = ops.prepare_graph(n, adj, attr, col)
+    assert "_late_words" in g.__dict__ and g.mid is not None      # (optimistic until the words are looked at)
+    assert g.late_words_failed() and g.mid is None and not g.late_words_failed()
+    before = _lib.forward_path_counts()
+    probs = net(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)[0].clone()
+    after = _lib.forward_path_counts()
+    with_limits = (_lib.lib.tgnn_get_small_layout_limit(), _lib.lib.tgnn_get_mid_layout_limit())
+    _lib.lib.tgnn_set_mid_layout_limit(0)
+    try:
+        want = net(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)[0]
+    finally:
+        _lib.lib.tgnn_set_mid_layout_limit(with_limits[1])
+    # the optimistic launch took the mid-size kernel once, the repeat the general schedule; what comes back is the repeat's result
+    assert after[2] - before[2] == 1 and after[0] - before[0] == 1
+    assert float((probs - want).abs().max()) < 1e-4

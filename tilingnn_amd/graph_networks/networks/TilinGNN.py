@@ -247,9 +247,13 @@ class TilinGNN(Tracked, nn.Module):
         ws_bytes = lib.tgnn_forward_workspace_bytes(C.byref(dims), n, graph.n_types)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         probs = torch.empty(n, self.output_dim, dtype=torch.float32, device=dev)
-        g = graph.c_struct()
+        g = graph.c_struct(defer_late_check=True)
         check(lib.tgnn_forward(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), int(bn_train and update_running), int(not bn_train),
                                ptr(probs), ptr(ws), ws_bytes, _lib.current_stream(dev), _lib.side_stream(dev)))
+        if graph.late_words_failed():                                         # (a just-prepared mid-size layout whose batches did not fit)
+            g = graph.c_struct()
+            check(lib.tgnn_forward(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), int(bn_train and update_running),
+                                   int(not bn_train), ptr(probs), ptr(ws), ws_bytes, _lib.current_stream(dev), _lib.side_stream(dev)))
         if self._param_table_stale():                                         # (see the top: checked behind the launches)
             table, dev = self._param_table()
             check(lib.tgnn_forward(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), int(bn_train and update_running),

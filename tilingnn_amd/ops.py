@@ -75,11 +75,29 @@ class PreparedGraph:
     mid: Optional["NNConvBatches"] = None      # NNConv batches of the mid-size persistent layer loop (None: general schedule)
     groups: Optional["NNConvGroups"] = None    # NNConv edge groups (layouts of the general schedule; None: the type columns are used)
 
-    def c_struct(self) -> _lib.Graph:
+    def c_struct(self, defer_late_check: bool = False) -> _lib.Graph:
+        """defer_late_check: the caller queues its launches first and asks `late_words_failed()` behind them (the mid-size
+        batches' verdict is the preparation's LAST result word: waiting for it here would wait for the whole preparation)."""
+        if not defer_late_check and "_late_words" in self.__dict__:
+            self.late_words_failed()
         hit = self.__dict__.get("_c_struct")          # (the tensors of a prepared graph are never replaced)
         if hit is None:
             hit = self.__dict__["_c_struct"] = self._build_c_struct()
         return hit
+
+    def late_words_failed(self) -> bool:
+        """True ONCE if the preparation's last result words say that the mid-size batches do not fit (a tile with more batches
+        than the persistent layer loop takes): `mid` is dropped, the C struct rebuilt -- a forward that was queued on the
+        optimistic struct ran the persistent kernel on truncated batches (memory-safe, wrong) and has to be repeated."""
+        late = self.__dict__.pop("_late_words", None)
+        if late is None:
+            return False
+        late[1].synchronize()
+        if int(late[0][9]) == 0:
+            return False
+        self.mid = None
+        self.__dict__.pop("_c_struct", None)
+        return True
 
     def _build_c_struct(self) -> _lib.Graph:
         t, st, gr = self.cols, self.mid, self.groups
@@ -325,13 +343,23 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
         eg_args = (ptr(tile_grp_ptr), ptr(grp)) if want_eg else (None,) * 2
         # the words read below are final before the NNConv structure is built: without the mid-size batches (whose result words
         # come last) the library copies them out early and the forward is queued while the structure's launches still run
-        early = _pinned_result_words(dev) if not want_mid else None
+        early = _pinned_result_words(dev)
         check(lib.tgnn_graph_prep(*head, *mid_args, *eg_args, ptr(tmp), ws_ints * 4, ptr(res),
                                   C.c_void_p(early.data_ptr()) if early is not None else None, _stream(adj)))
+    late = None
     if not small and early is not None:
+        if want_mid:
+            # the mid-size batches' verdict (result[9]: a tile that does not fit sends the layout to the general schedule) comes
+            # with the LAST launch: copied behind it, looked at when the graph's C struct is first built (c_struct)
+            words = torch.empty(32, dtype=torch.int32, pin_memory=True)
+            words.copy_(res, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            late = (words, ev, res)
         check(lib.tgnn_graph_prep_wait())                                        # the one sync: the copy of the words alone
         host = early.tolist()
         host[5] = host[10] = int(host[0] <= lib.tgnn_nnconv_cols_max_types() and not host[6])
+        host[9] = 0                                                              # (optimistic: see `late`)
     else:
         host = _read_back(res)                                                   # the one sync
     if host[1] or host[2]:
@@ -341,8 +369,11 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
     cols = NNConvColumns(tile_col_ptr, col_meta, col_slot_src) if host[5] and not want_eg else None
     mid = NNConvBatches(mid_nb, mid_ent) if want_mid and cols is not None and host[9] == 0 else None
     groups_ = NNConvGroups(tile_grp_ptr, grp.view(-1, 2)) if want_eg and host[10] else None
-    return PreparedGraph(n_nodes, ea, int(host[3]), int(host[0]), a_rowptr, a_src, a_eid, adj_type, edge_type, rep,
-                         c_rowptr, c_src, c_eid, cols, int(host[4]), mid, groups_)
+    g = PreparedGraph(n_nodes, ea, int(host[3]), int(host[0]), a_rowptr, a_src, a_eid, adj_type, edge_type, rep,
+                      c_rowptr, c_src, c_eid, cols, int(host[4]), mid, groups_)
+    if late is not None and mid is not None:
+        g.__dict__["_late_words"] = late
+    return g
 
 
 def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col_e_idx: Tensor,
