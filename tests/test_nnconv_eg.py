@@ -220,3 +220,41 @@ def test_bf16_width64_op_on_groups(dev, n, ea, n_types, run, leaky):
     assert float((p[64:] - (stored * stored).sum(0)).abs().max()) < 1e-9 * float((stored * stored).sum(0).max())
     out_d, _ = ops_bf16.nnconv64(h, g, wtab, root, bias, act, ops.new_partials(64, dev))    # a layout with groups: the default
     assert torch.equal(out, out_d)
+
+
+def test_in_degree_beyond_the_kernels_limit_takes_another_kernel(dev):
+    """The edge-group kernel folds the root term with S = diag(max(deg, 1)) in fp16: exact up to 2 048.  A layout of the general
+    schedule with a hub of 3 000 in-edges is prepared with groups like any other, tgnn_forward sees nn_max_in_degree and keeps
+    off the kernel (CSR kernel: the layout carries no columns); the per-op entry point builds the columns and takes those.
+    Both against the forward / the op on type columns."""
+    from tilingnn_amd import TilinGNN, ops
+    from tilingnn_amd._lib import lib
+    from tilingnn_amd.synth import make_super_graph
+    from tilingnn_amd.weights import make_state_dict
+    import oracle.tilingnn_oracle as orc
+    n = 40_000
+    sg = make_super_graph(n, 10 * n, 12 * n, tile_count=2, n_edge_types=13, seed=4)
+    x, adj, attr, col, _ = sg.to_torch(dev)
+    adj = adj.clone()
+    adj[1, :3000] = 123
+    g = ops.prepare_graph(n, adj, attr, col)
+    assert g.groups is not None and g.max_in_degree >= 3000
+    gen = torch.Generator().manual_seed(5)
+    h = torch.randn(n, 32, generator=gen).to(dev)
+    wtab = torch.rand(g.n_types, 32, 32, generator=gen).to(dev)
+    root = (torch.randn(32, 32, generator=gen) * 0.3).to(dev)
+    bias = torch.randn(32, generator=gen).to(dev)
+    want = fp64_nnconv(h, adj, g.edge_type[:adj.shape[1]].long(), wtab, root, bias, n, True)
+    out, _ = ops.nnconv_mean(h, g, wtab, root, bias, ops.ACT_LEAKY_RELU, ops.new_partials(32, dev))     # (columns, built on first use)
+    assert orc.rel_max_err(out.cpu(), want.cpu()) < 2e-6
+    net = TilinGNN(15, 6, 32, node_features_dim=3)
+    net.load_state_dict(make_state_dict(15, 6, 32, 1, 3))
+    net = net.to(dev).train()
+    net.cache_graph = False
+    p_groups_graph = net(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)[0].clone()
+    keep, ops.GROUPS = ops.GROUPS, False
+    try:
+        p_cols = net(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)[0].clone()
+    finally:
+        ops.GROUPS = keep
+    assert bool(torch.isfinite(p_groups_graph).all()) and float((p_groups_graph - p_cols).abs().max()) < 2e-4
