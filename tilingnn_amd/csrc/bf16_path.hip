@@ -532,11 +532,15 @@ __global__ __launch_bounds__(kMlp64Threads, 2) void gin64_bf16_mlp_kernel(
         const bf16x8 za = zin[0], zb = zin[1];
         load_z(tile + 1 < t1 ? tile + 1 : tile, zin);
         // ---- layer 1: 2 M blocks x 2 K chunks, z exact
+        // [r5] (its 8 weight fragments are re-read from LDS every tile: hoisted out of the loop with those of layers 2 and 3 they
+        //  made 290 live registers, 34 of them in scratch memory and reloaded -- 13 scratch loads -- in every tile)
+        const bf16x8 *w1h = W1s[0], *w1l = W1s[1];
+        asm volatile("" : "+v"(w1h), "+v"(w1l));
         f32x4 h1[2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
-            h1[mb] = mma(W1s[0], W1s[1], (mb * 2 + 0) * 64 + lane, za, nullptr, bias4(0, mb));
-            h1[mb] = mma(W1s[0], W1s[1], (mb * 2 + 1) * 64 + lane, zb, nullptr, h1[mb]);
+            h1[mb] = mma(w1h, w1l, (mb * 2 + 0) * 64 + lane, za, nullptr, bias4(0, mb));
+            h1[mb] = mma(w1h, w1l, (mb * 2 + 1) * 64 + lane, zb, nullptr, h1[mb]);
         }
         bf16x8 x1h, x1l;
         sig8(h1[0], h1[1], x1h, x1l);
