@@ -258,3 +258,28 @@ def test_in_degree_beyond_the_kernels_limit_takes_another_kernel(dev):
     finally:
         ops.GROUPS = keep
     assert bool(torch.isfinite(p_groups_graph).all()) and float((p_groups_graph - p_cols).abs().max()) < 2e-4
+
+
+def test_one_preparation_call_builds_both_structures(dev):
+    """tgnn_graph_prep handed the buffers of BOTH NNConv structures (type columns + mid-size batches, edge groups) builds both on
+    the same scratch, one behind the other: bit for bit what the calls that build only one of them leave."""
+    from tilingnn_amd import ops
+    from tilingnn_amd.synth import make_super_graph
+    n = 9000
+    sg = make_super_graph(n, 9 * n, 11 * n, tile_count=2, n_edge_types=13, seed=6)
+    x, adj, attr, col, _ = sg.to_torch(dev)
+    both = ops.prepare_graph(n, adj, attr, col, groups="both")
+    only_c = ops.prepare_graph(n, adj, attr, col, groups=False)
+    only_g = ops.prepare_graph(n, adj, attr, col, groups=True)
+    assert both.cols is not None and both.groups is not None and both.mid is not None
+    assert only_c.groups is None and only_g.cols is None
+    ntiles = (n + 15) // 16
+    ncol = int(only_c.cols.tile_col_ptr[ntiles])
+    assert torch.equal(both.cols.tile_col_ptr[:ntiles + 1], only_c.cols.tile_col_ptr[:ntiles + 1])
+    assert torch.equal(both.cols.col_meta[:ncol], only_c.cols.col_meta[:ncol])
+    assert torch.equal(both.cols.col_src[:ncol * 16], only_c.cols.col_src[:ncol * 16])
+    ng = int(only_g.groups.tile_grp_ptr[ntiles])
+    assert torch.equal(both.groups.tile_grp_ptr[:ntiles + 1], only_g.groups.tile_grp_ptr[:ntiles + 1])
+    assert torch.equal(both.groups.grp[:ng * 16], only_g.groups.grp[:ng * 16])
+    assert torch.equal(both.adj_type[:both.n_adj_edges], only_g.adj_type[:only_g.n_adj_edges])
+    assert torch.equal(both.mid.tile_nb, only_c.mid.tile_nb) and torch.equal(both.mid.ent, only_c.mid.ent)

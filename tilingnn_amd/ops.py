@@ -315,9 +315,11 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
     # (a shard's layout always runs the general schedule)
     want_eg = (not small and groups) if groups is not None else \
         (not small and GROUPS and (n_src_nodes is not None or runs_general_schedule(n_nodes)))
-    want_mid = not small and not want_eg and n_src_nodes is None and lo_mid < n_nodes <= hi_mid   # (built from the columns)
+    both = groups == "both" and not small                      # (tests: tgnn_graph_prep building the two structures in one call)
+    want_cols = both or not want_eg
+    want_mid = not small and want_cols and n_src_nodes is None and lo_mid < n_nodes <= hi_mid   # (built from the columns)
     mid_words = int(lib.tgnn_mid_entries_words(n_nodes)) if want_mid else 0
-    cap = 0 if want_eg else int(lib.tgnn_nnconv_cols_max_columns(n_nodes, ea))
+    cap = int(lib.tgnn_nnconv_cols_max_columns(n_nodes, ea)) if want_cols else 0
     gcap = int(lib.tgnn_nnconv_eg_max_groups(n_nodes, ea, lib.tgnn_nnconv_cols_max_types())) if want_eg else 0
     # the persistent outputs share ONE long-lived allocation; the scratch (CSR / de-dup tables, scan workspaces) and the result
     # words are tensors of their own, freed after the read-back -- a cached graph does not pin hundreds of MB of scratch
@@ -335,7 +337,7 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
     tmp = torch.empty(ws_ints, dtype=torch.int32, device=dev)
     head = (ptr(adj), ea, ptr(attr), fe, ptr(col), ec, n_nodes) + (() if small else (n_src_nodes or n_nodes,)) + (ptr(a_rowptr), ptr(a_src), ptr(a_eid), ptr(adj_type), ptr(edge_type),
             ptr(rep), ptr(c_rowptr), ptr(c_src), ptr(c_eid),
-            *((None,) * 3 if want_eg else (ptr(tile_col_ptr), ptr(col_meta), ptr(col_slot_src))))
+            *((ptr(tile_col_ptr), ptr(col_meta), ptr(col_slot_src)) if want_cols else (None,) * 3))
     if small:
         check(lib.tgnn_graph_prep_small(*head, ptr(tmp), ptr(res), ptr(_small_prep_counters(dev)), _stream(adj)))
     else:
@@ -366,7 +368,7 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
         raise IndexError(f"edge index out of range [0, {n_nodes}) in {'adj_e_index' if host[1] else 'col_e_idx'}")
     if host[6]:
         return None
-    cols = NNConvColumns(tile_col_ptr, col_meta, col_slot_src) if host[5] and not want_eg else None
+    cols = NNConvColumns(tile_col_ptr, col_meta, col_slot_src) if host[5] and want_cols else None
     mid = NNConvBatches(mid_nb, mid_ent) if want_mid and cols is not None and host[9] == 0 else None
     groups_ = NNConvGroups(tile_grp_ptr, grp.view(-1, 2)) if want_eg and host[10] else None
     g = PreparedGraph(n_nodes, ea, int(host[3]), int(host[0]), a_rowptr, a_src, a_eid, adj_type, edge_type, rep,
