@@ -199,12 +199,12 @@ __device__ __forceinline__ void gin_tile_mlp(const GinGraph &A, int64_t tile, fl
         o0 = small_mma6(w3p + (0 * 2 + ks) * 64, 256, xb, o0);
         o1 = small_mma6(w3p + (1 * 2 + ks) * 64, 256, xb, o1);
     }
-    auto sig_out = [](float v) { return 1.0f / (1.0f + expf(-v)); };     // full precision, as gin32_mlp_kernel
+    auto sig_out = [](float v) { return sigmoid_out_f32(v); };           // full accuracy, as gin32_mlp_kernel (LeakyReLU behind a sigmoid: the identity)
     const int64_t my_row = tile * 16 + fj;
     const bool row_ok = my_row < n;
     f32x4 r0, r1;
-    r0[0] = leakyf_(sig_out(o0[0])); r0[1] = leakyf_(sig_out(o0[1])); r0[2] = leakyf_(sig_out(o0[2])); r0[3] = leakyf_(sig_out(o0[3]));
-    r1[0] = leakyf_(sig_out(o1[0])); r1[1] = leakyf_(sig_out(o1[1])); r1[2] = leakyf_(sig_out(o1[2])); r1[3] = leakyf_(sig_out(o1[3]));
+    r0[0] = sig_out(o0[0]); r0[1] = sig_out(o0[1]); r0[2] = sig_out(o0[2]); r0[3] = sig_out(o0[3]);
+    r1[0] = sig_out(o1[0]); r1[1] = sig_out(o1[1]); r1[2] = sig_out(o1[2]); r1[3] = sig_out(o1[3]);
     if (!row_ok) r0 = r1 = f32x4{0.f, 0.f, 0.f, 0.f};
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();                              // (everybody has read z)

@@ -770,10 +770,10 @@ __global__ __launch_bounds__(kSmallThreads) void forward_layers_small_kernel(Sma
                 o1 = small_mma6(w3p + (1 * 2 + ks) * 64, 256, xb, o1);
             }
             TGNN_ST2(2)
-            auto sig_out = [](float v) { return 1.0f / (1.0f + expf(-v)); };     // full precision, as gin32_mlp_kernel
+            auto sig_out = [](float v) { return sigmoid_out_f32(v); };           // full accuracy, as gin32_mlp_kernel (LeakyReLU behind a sigmoid: the identity)
             float4 r0, r1;
-            r0.x = leakyf_(sig_out(o0[0])); r0.y = leakyf_(sig_out(o0[1])); r0.z = leakyf_(sig_out(o0[2])); r0.w = leakyf_(sig_out(o0[3]));
-            r1.x = leakyf_(sig_out(o1[0])); r1.y = leakyf_(sig_out(o1[1])); r1.z = leakyf_(sig_out(o1[2])); r1.w = leakyf_(sig_out(o1[3]));
+            r0.x = sig_out(o0[0]); r0.y = sig_out(o0[1]); r0.z = sig_out(o0[2]); r0.w = sig_out(o0[3]);
+            r1.x = sig_out(o1[0]); r1.y = sig_out(o1[1]); r1.z = sig_out(o1[2]); r1.w = sig_out(o1[3]);
             if (!row_ok) r0 = r1 = zero4;
             // row fj, channels 4 fq + r and 16 + 4 fq + r: to the LDS tile (merge, BatchNorm sums) and to HBM (next layer's gathers)
             if (mine) {

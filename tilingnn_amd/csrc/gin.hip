@@ -234,10 +234,10 @@ __global__ __launch_bounds__(kMlpThreads, 2) void gin32_mlp_kernel(
         }
         // ---- epilogue: row fn, features 4 q + r and 16 + 4 q + r
         float4 r0, r1;
-        // the OUTPUT sigmoid in full precision (libm expf + IEEE division, ~1.5 ulp instead of the hardware
-        // transcendentals' ~3): the BatchNorm behind this kernel divides columns that vary by ~1 % of their value, so
-        // every ulp here is ~100 ulp there (CollConv incl. BatchNorm vs fp64: 1.4e-5 with the fast form)
-        auto sig_out = [](float v) { return 1.0f / (1.0f + expf(-v)); };
+        // the OUTPUT sigmoid at full fp32 accuracy (tgnn_common.h: sigmoid_out_f32, ~1.5 ulp where the hardware transcendentals
+        // alone give ~3): the BatchNorm behind this kernel divides columns that vary by ~1 % of their value, so every ulp here is
+        // ~100 ulp there (CollConv incl. BatchNorm vs fp64: 1.4e-5 with sigmoidf_)
+        auto sig_out = [](float v) { return sigmoid_out_f32(v); };
         r0.x = sig_out(o0[0]); r0.y = sig_out(o0[1]); r0.z = sig_out(o0[2]); r0.w = sig_out(o0[3]);
         r1.x = sig_out(o1[0]); r1.y = sig_out(o1[1]); r1.z = sig_out(o1[2]); r1.w = sig_out(o1[3]);
         if (act == TGNN_ACT_LEAKY_RELU) {
@@ -353,20 +353,6 @@ extern std::atomic<int> g_gin_mlp16;     // tgnn_set_gin_mlp_f16 (default off: s
 #endif
 constexpr int kMlp16Waves = TGNN_GIN16_WAVES, kMlp16Threads = kMlp16Waves * 64;
 using f16x8g = tgnn_f16x8;
-
-// 1 / (1 + exp(-v)), ~1.5 ulp: t = -v log2 e as th + tl, e = 2^th (1 + tl ln 2), r = 1 / (1 + e) refined once
-__device__ __forceinline__ float gin_sigmoid_out(float v) {
-    constexpr float kL2eH = 1.44269502162933349609375f, kL2eL = 1.925963033500011e-8f, kLn2 = 0.693147182464599609375f;
-    const float nv = -fmaxf(v, -87.0f);                       // (e stays finite: the result there is < 2e-38 either way)
-    const float th = nv * kL2eH;
-    const float tl = fmaf(nv, kL2eH, -th) + nv * kL2eL;
-    const float eh = __builtin_amdgcn_exp2f(th);
-    const float e = fmaf(eh, tl * kLn2, eh);
-    const float d = 1.0f + e;
-    float r = __builtin_amdgcn_rcpf(d);
-    r = fmaf(fmaf(-d, r, 1.0f), r, r);
-    return r;
-}
 
 __global__ __launch_bounds__(kMlp16Threads) void gin32_mlp16_kernel(
     const float *__restrict__ z, const float *__restrict__ w1, const float *__restrict__ b1,
@@ -506,8 +492,8 @@ __global__ __launch_bounds__(kMlp16Threads) void gin32_mlp16_kernel(
         // ---- epilogue: row fn, features 4 q + r and 16 + 4 q + r.  (The BatchNorm behind this kernel divides columns that vary
         //      by ~1 % of their value: every ulp here is ~100 ulp there -- hence the careful sigmoid.  LeakyReLU of a sigmoid: identity.)
         float4 r0, r1;
-        r0.x = gin_sigmoid_out(o0[0] * inv3); r0.y = gin_sigmoid_out(o0[1] * inv3); r0.z = gin_sigmoid_out(o0[2] * inv3); r0.w = gin_sigmoid_out(o0[3] * inv3);
-        r1.x = gin_sigmoid_out(o1[0] * inv3); r1.y = gin_sigmoid_out(o1[1] * inv3); r1.z = gin_sigmoid_out(o1[2] * inv3); r1.w = gin_sigmoid_out(o1[3] * inv3);
+        r0.x = sigmoid_out_f32(o0[0] * inv3); r0.y = sigmoid_out_f32(o0[1] * inv3); r0.z = sigmoid_out_f32(o0[2] * inv3); r0.w = sigmoid_out_f32(o0[3] * inv3);
+        r1.x = sigmoid_out_f32(o1[0] * inv3); r1.y = sigmoid_out_f32(o1[1] * inv3); r1.z = sigmoid_out_f32(o1[2] * inv3); r1.w = sigmoid_out_f32(o1[3] * inv3);
         const int64_t row = tile * 16 + fn;
         if (row < n) {
             *reinterpret_cast<float4 *>(out + row * 32 + 4 * fq) = r0;

@@ -119,6 +119,23 @@ struct Carver {
 // 1e-5 parity bar.  The IEEE expf + division sequence cost as many VALU cycles as the GIN MLP's
 // MFMAs (64 sigmoids per lane per 32-row tile).
 __device__ __forceinline__ float sigmoidf_(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+// 1 / (1 + exp(-v)) at the accuracy of libm's expf + an IEEE division (~1.5 ulp) in a third of their instructions -- the output
+// sigmoid of the collision branch's MLP, 40 % of that kernel's vector stream with libm (profiles/r05_pmc_gin_mlp.txt):
+// t = -v log2 e as th + tl (the rounding of v log2 e is what costs accuracy at |v| ~ 10), e = 2^th (1 + tl ln 2), r = 1 / (1 + e)
+// from the hardware reciprocal refined by one Newton step.  EVERY schedule's collision MLP ends in this function (gin.hip,
+// forward_persist.h, forward_small.hip): the schedules are compared bit for bit.
+__device__ __forceinline__ float sigmoid_out_f32(float v) {
+    constexpr float kL2eH = 1.44269502162933349609375f, kL2eL = 1.925963033500011e-8f, kLn2 = 0.693147182464599609375f;
+    const float nv = -fmaxf(v, -87.0f);                       // (e stays finite: the result there is < 2e-38 either way)
+    const float th = nv * kL2eH;
+    const float tl = fmaf(nv, kL2eH, -th) + nv * kL2eL;
+    const float eh = __builtin_amdgcn_exp2f(th);
+    const float e = fmaf(eh, tl * kLn2, eh);
+    const float d = 1.0f + e;
+    float r = __builtin_amdgcn_rcpf(d);
+    r = fmaf(fmaf(-d, r, 1.0f), r, r);
+    return r;
+}
 __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == TGNN_ACT_LEAKY_RELU) return v >= 0.f ? v : v * kLeakySlope;
     if (act == TGNN_ACT_SIGMOID) return sigmoidf_(v);
