@@ -234,8 +234,8 @@ __global__ __launch_bounds__(kMlpThreads, 2) void gin32_mlp_kernel(
         }
         // ---- epilogue: row fn, features 4 q + r and 16 + 4 q + r
         float4 r0, r1;
-        // the OUTPUT sigmoid at full fp32 accuracy (tgnn_common.h: sigmoid_out_f32, ~1.5 ulp where the hardware transcendentals
-        // alone give ~3): the BatchNorm behind this kernel divides columns that vary by ~1 % of their value, so every ulp here is
+        // the OUTPUT sigmoid at the accuracy of expf + a division (tgnn_common.h: sigmoid_out_f32; the hardware transcendentals
+        // alone lose an order of magnitude at |v| ~ 20): the BatchNorm behind this kernel divides columns that vary by ~1 % of their value, so every ulp here is
         // ~100 ulp there (CollConv incl. BatchNorm vs fp64: 1.4e-5 with sigmoidf_)
         auto sig_out = [](float v) { return sigmoid_out_f32(v); };
         r0.x = sig_out(o0[0]); r0.y = sig_out(o0[1]); r0.z = sig_out(o0[2]); r0.w = sig_out(o0[3]);

@@ -119,7 +119,8 @@ struct Carver {
 // 1e-5 parity bar.  The IEEE expf + division sequence cost as many VALU cycles as the GIN MLP's
 // MFMAs (64 sigmoids per lane per 32-row tile).
 __device__ __forceinline__ float sigmoidf_(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
-// 1 / (1 + exp(-v)) at the accuracy of libm's expf + an IEEE division (~1.5 ulp) in a third of their instructions -- the output
+// 1 / (1 + exp(-v)) at the accuracy of libm's expf + an IEEE division (both ~3 ulp at worst, 0.4 on average: the form restated on
+// the host in tests/test_sigmoid_form.py; the hardware transcendentals alone, sigmoidf_, lose ~30 ulp at |v| ~ 20) in a third of their instructions -- the output
 // sigmoid of the collision branch's MLP, 40 % of that kernel's vector stream with libm (profiles/r05_pmc_gin_mlp.txt):
 // t = -v log2 e as th + tl (the rounding of v log2 e is what costs accuracy at |v| ~ 10), e = 2^th (1 + tl ln 2), r = 1 / (1 + e)
 // from the hardware reciprocal refined by one Newton step.  EVERY schedule's collision MLP ends in this function (gin.hip,
