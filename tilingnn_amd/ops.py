@@ -380,11 +380,12 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
 
 def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col_e_idx: Tensor,
                   tile_width: int = 32, n_src_nodes: Optional[int] = None, columns: Optional[bool] = None,
-                  groups: Optional[bool] = None) -> PreparedGraph:
+                  groups=None) -> PreparedGraph:
     """Everything the 20 layers share: CSR of both edge sets, edge-type ids in CSR order, and (columns: None = for
     layouts above COLS_MIN_NODES) the NNConv column structure -- or (groups: None = for layouts of the general schedule,
-    i.e. above the mid-size limit, when GROUPS is on) the NNConv edge groups in its place; `graph_columns` / `graph_groups`
-    build the other structure for whoever needs it.
+    i.e. above the mid-size limit, when GROUPS is on; "both": columns, mid-size batches AND groups from the one
+    tgnn_graph_prep call) the NNConv edge groups in its place; `graph_columns` / `graph_groups` build the other structure
+    for whoever needs it.
     Synchronises once (the type count and the self-loop-free collision edge count are read back)."""
     adj = _check_edge_index(adj_e_index, "adj_e_index")
     col = _check_edge_index(col_e_idx, "col_e_idx")
