@@ -344,14 +344,14 @@ __global__ __launch_bounds__(kMlpThreads, 2) void gin32_mlp_kernel(
 //   * the output sigmoid keeps its accuracy at a third of the instructions: exp2 on a two-part product (the rounding of
 //     v log2 e is what costs accuracy at |v| ~ 10), one Newton step on the hardware reciprocal; LeakyReLU behind a sigmoid is the
 //     identity and is not executed.
-//   * weight fragments come out of the LDS image per tile instead of living in 120 registers: 16 waves per block (4 per SIMD)
-//     cover each other's waits.
+//   * the output sigmoid (tgnn_common.h: sigmoid_out_f32) is the one the kernel above has taken over since.
+//   * 22 weight fragments in 88 registers (the kernel above: 30 in 120).  A first form re-read them from the LDS image every tile
+//     to run 16 waves per block: 1 - 1.5 % slower in the forward.  As it stands the tile loop is 313 vector + 36 matrix
+//     instructions (above: 377 + 60) and the forward takes exactly as long with either kernel (same-box pairs: 1.864 / 1.862 and
+//     1.893 / 1.891 ms) -- which is why this one stays opt-in.
 // ------------------------------------------------------------------------------------------
 extern std::atomic<int> g_gin_mlp16;     // tgnn_set_gin_mlp_f16 (default off: see the note below)
-#ifndef TGNN_GIN16_WAVES
-#define TGNN_GIN16_WAVES 8
-#endif
-constexpr int kMlp16Waves = TGNN_GIN16_WAVES, kMlp16Threads = kMlp16Waves * 64;
+constexpr int kMlp16Waves = 8, kMlp16Threads = kMlp16Waves * 64;      // (two waves per SIMD: the fragments' 206 VGPRs)
 using f16x8g = tgnn_f16x8;
 
 __global__ __launch_bounds__(kMlp16Threads) void gin32_mlp16_kernel(
@@ -448,18 +448,46 @@ __global__ __launch_bounds__(kMlp16Threads) void gin32_mlp16_kernel(
     // sigma(acc / s) = 1 / (1 + 2^(acc * c)),  c = -log2 e / s  (s a power of two: exact)
     const float c2 = -1.44269504088896340736f / s2, inv3 = 1.0f / s3;
     auto sig2 = [&](float a) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a * c2)); };
-    // acc += W . X over one K step of 32, fp16 pairs: three cross terms, smallest first
-    auto mma3 = [&](const f16x8g *wpl, int plane_stride, const f16x8g &xh, const f16x8g &xl, f32x4 acc) {
-        const f16x8g wh = wpl[0], wl = wpl[plane_stride];
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc, 0, 0, 0);   // lo . hi
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc, 0, 0, 0);   // hi . lo
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc, 0, 0, 0);   // hi . hi
+    double cs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cq[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // BN sums of this lane's 8 output features
+    // the 22 weight fragments and the biases live in registers (206 VGPRs, two waves per SIMD), as gin32_mlp_kernel keeps its 30:
+    // re-read from the LDS image every tile (106 VGPRs, up to 16 waves per block) the forward was 1 - 1.5 % slower, same bits
+    bf16x8 rw1[2][3];
+    f16x8g rw2[4][2], rw3[4][2];
+    f32x4 rb1[2], rb2[4], rb3[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) rw1[mb][pl] = w1p[mb * 64 + pl * 2 * 64];
+        rb1[mb] = bias4(0, mb);
+        rb3[mb] = bias4(96, mb);
+    }
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            rw2[mb][pl] = w2p[mb * 64 + pl * 4 * 64];
+            rw3[mb][pl] = w3p[mb * 64 + pl * 256];           // mb = M block * 2 + K step
+        }
+        rb2[mb] = bias4(32, mb);
+    }
+    auto mma6r = [&](const bf16x8 (&w)[3], const bf16x8 (&x)[3], f32x4 acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2], x[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], x[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], x[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], x[0], acc, 0, 0, 0);
         return acc;
     };
-    double cs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cq[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // BN sums of this lane's 8 output features
+    // acc += W . X over one K step of 32, fp16 pairs: three cross terms, smallest first
+    auto mma3r = [&](const f16x8g (&w)[2], const f16x8g &xh, const f16x8g &xl, f32x4 acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[1], xh, acc, 0, 0, 0);   // lo . hi
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[0], xl, acc, 0, 0, 0);   // hi . lo
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[0], xh, acc, 0, 0, 0);   // hi . hi
+        return acc;
+    };
 
     for (int64_t tile = t0; tile < t1; ++tile) {
-        asm volatile("" ::: "memory");                       // (the fragments are re-read from the image every tile: no 88 registers of them)
         bf16x8 xb[3];
         {
             const float x[8] = {zin[0].x, zin[0].y, zin[0].z, zin[0].w, zin[1].x, zin[1].y, zin[1].z, zin[1].w};
@@ -467,8 +495,8 @@ __global__ __launch_bounds__(kMlp16Threads) void gin32_mlp16_kernel(
         }
         load_z(tile + 1 < t1 ? tile + 1 : tile, zin);
         // ---- layer 1 (bf16 x 3): 2 M blocks
-        const f32x4 h1a = gin_mma6(w1p + 0 * 64, 2 * 64, xb, bias4(0, 0));
-        const f32x4 h1b = gin_mma6(w1p + 1 * 64, 2 * 64, xb, bias4(0, 1));
+        const f32x4 h1a = mma6r(rw1[0], xb, rb1[0]);
+        const f32x4 h1b = mma6r(rw1[1], xb, rb1[1]);
         f16x8g xh, xl;
         {
             const float x[8] = {sigmoidf_(h1a[0]), sigmoidf_(h1a[1]), sigmoidf_(h1a[2]), sigmoidf_(h1a[3]),
@@ -478,16 +506,15 @@ __global__ __launch_bounds__(kMlp16Threads) void gin32_mlp16_kernel(
         // ---- layer 2 (fp16 pairs): 4 M blocks
         f32x4 h2[4];
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) h2[mb] = mma3(w2p + mb * 64, 4 * 64, xh, xl, bias4(32, mb));
-        // ---- layer 3 (fp16 pairs): 2 M blocks x 2 K steps
-        f32x4 o0 = bias4(96, 0), o1 = bias4(96, 1);
+        for (int mb = 0; mb < 4; ++mb) h2[mb] = mma3r(rw2[mb], xh, xl, rb2[mb]);
+        f32x4 o0 = rb3[0], o1 = rb3[1];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const float x[8] = {sig2(h2[2 * ks][0]), sig2(h2[2 * ks][1]), sig2(h2[2 * ks][2]), sig2(h2[2 * ks][3]),
                                 sig2(h2[2 * ks + 1][0]), sig2(h2[2 * ks + 1][1]), sig2(h2[2 * ks + 1][2]), sig2(h2[2 * ks + 1][3])};
             split2_f16(x, 1.0f, xh, xl);
-            o0 = mma3(w3p + (0 * 2 + ks) * 64, 256, xh, xl, o0);
-            o1 = mma3(w3p + (1 * 2 + ks) * 64, 256, xh, xl, o1);
+            o0 = mma3r(rw3[0 * 2 + ks], xh, xl, o0);
+            o1 = mma3r(rw3[1 * 2 + ks], xh, xl, o1);
         }
         // ---- epilogue: row fn, features 4 q + r and 16 + 4 q + r.  (The BatchNorm behind this kernel divides columns that vary
         //      by ~1 % of their value: every ulp here is ~100 ulp there -- hence the careful sigmoid.  LeakyReLU of a sigmoid: identity.)
