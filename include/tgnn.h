@@ -499,6 +499,16 @@ int32_t tgnn_set_mid_tail(int32_t on);
  * carries them, instead of over its type columns.  Default 1; returns the previous setting (an argument outside 0 .. 1 only
  * queries). */
 int32_t tgnn_set_nnconv_eg(int32_t on);
+/* The final MLP's fp16-pair Linears for many rows (csrc/dense.hip; reference: graph_networks/networks/TilinGNN.py:74-76): 1 (default)
+ * = dense_f16_rows2_kernel, one wave per SIMD with every operand two k-tiles in flight; 0 = dense_f16_rows_kernel (two waves per
+ * SIMD, LDS-DMA one k-tile ahead).  The same bits.  Returns the previous setting (an argument outside 0 .. 1 only queries). */
+int32_t tgnn_set_dense_rows_mode(int32_t mode);
+/* The front of the general schedule (reference: graph_networks/networks/TilinGNN.py:54 and the operand preparation in front of the
+ * first layer).  Bit 0: no memset in front of the first launch, the layer loop waits for the edge weights only (the final MLP's
+ * bounds and operand images are one launch each behind them); bit 1: the init MLP as three launches that recompute from x
+ * (csrc/init_mlp.hip; the same bits as the five launches it replaces).  Default 3; returns the previous setting (an argument
+ * outside 0 .. 3 only queries). */
+int32_t tgnn_set_lean_head(int32_t bits);
 
 /* Small layouts (<= tgnn_graph_prep_small_max_nodes() nodes, <= ..._max_edges() edges per set): everything above --
  * tgnn_csr_build of both edge sets (self loops dropped from the collision set), tgnn_edge_type_dedup, the types in CSR

@@ -80,6 +80,35 @@ def batch_norm_train(v: Tensor, sd: SD, prefix: str, update_running: bool = Fals
     return y
 
 
+class reference_ops:
+    """Context: the three element-wise pieces above as the modules the REFERENCE calls -- torch.nn.Sigmoid (edge_conv.py:12,17;
+    coll_conv.py:17), nn.LeakyReLU (TilinGNN.py:31), nn.BatchNorm1d in train mode (layers/util.py:28,35) -- one fused pass each
+    instead of the decomposed forms (1/(1+exp(-v)) is four passes over the [Ea, 1024] tensor of the edge MLP).  Same values to
+    fp32 rounding (tests/test_oracle_vs_reference_golden.py); the CHECKER keeps the decomposed forms (they are dtype-generic and
+    were pinned in fp64), `bench.py`'s cpu_baseline TIMES this one: it is the reference's op sequence."""
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        g = globals()
+        self._saved = {k: g[k] for k in ("leaky_relu", "sigmoid", "batch_norm_train")}
+
+        def bn(v: Tensor, sd: SD, prefix: str, update_running: bool = False) -> Tensor:
+            rm = sd[prefix + ".running_mean"] if update_running else None
+            rv = sd[prefix + ".running_var"] if update_running else None
+            if update_running:
+                sd[prefix + ".num_batches_tracked"] = sd[prefix + ".num_batches_tracked"] + 1
+            return F.batch_norm(v, rm, rv, sd[prefix + ".weight"], sd[prefix + ".bias"], True, BN_MOMENTUM, BN_EPS)
+
+        g["leaky_relu"] = lambda v: F.leaky_relu(v, LEAKY_SLOPE)
+        g["sigmoid"] = torch.sigmoid
+        g["batch_norm_train"] = bn
+        return self
+
+    def __exit__(self, *exc):
+        globals().update(self._saved)
+        return False
+
+
 def linear(v: Tensor, sd: SD, prefix: str) -> Tensor:
     return v @ sd[prefix + ".weight"].t() + sd[prefix + ".bias"]
 

@@ -677,12 +677,231 @@ __global__ __launch_bounds__(kRowsThreads, 2) void dense_f16_rows_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// [r6] The same Linear, ONE wave per SIMD with the whole register file (one 4-wave block per CU, up to 512 registers per lane):
+// dense_f16_rows_kernel above runs 2 waves per SIMD on 253 registers and hipcc has no room to move a load: per accumulator it
+// emits "2 ds_read_b128, s_waitcnt lgkmcnt(0), 3 dependent matrix instructions", and per k-tile one "s_waitcnt vmcnt(0)" on
+// loads issued a single k-tile (~0.7 us) earlier -- 166 us at 100 000 rows against 41 us of matrix work.  Here
+//  * everything that comes from memory is in flight for TWO k-tiles: the A rows and the W image tile travel to registers (plain,
+//    compiler-counted loads; the image tile is stored to LDS one k-tile before it is read) -- no LDS-DMA, hence no vmcnt(0) in
+//    front of a barrier;
+//  * the matrix instructions of a k-half go term-major (lo.hi over all TN accumulators, then hi.lo, then hi.hi): eight
+//    independent instructions between two on the same accumulator, all operand fragments of the half in registers before
+//    the first one (the next half's reads are issued behind them);
+//  * per accumulator the order of the terms is the one of the kernels above: the same bits.
+// ------------------------------------------------------------------------------------------
+template <int TN, bool STAT>
+__global__ __launch_bounds__(kRowsThreads, 1) void dense_f16_rows2_kernel(
+    const float *__restrict__ a, int64_t lda, int64_t a_kb_stride, int kps, const float *__restrict__ in_stat,
+    const u32x4_ *__restrict__ wimg, const float *__restrict__ bias, int64_t n, int in_dim, int act, float *__restrict__ out,
+    int64_t ldo, double *__restrict__ bn_partial, const unsigned *__restrict__ a_max, int n_a_max,
+    const unsigned *__restrict__ w_max) {
+    constexpr int N = 32 * TN, TNH = TN / 2;
+    constexpr int kTileVec = 2 * TN * 2 * 64;                 // 16-byte pieces of one k-tile of the image
+    constexpr int RB = kTileVec / kRowsThreads;               // ... per thread
+    // dynamic LDS (more than the 64 KB a kernel may declare statically): two image tiles, the column sums of the four waves, the
+    // BatchNorm record of the input (STAT)
+    extern __shared__ __attribute__((aligned(1024))) unsigned char rows2_lds[];
+    u32x4_ (*Bs)[kTileVec] = reinterpret_cast<u32x4_ (*)[kTileVec]>(rows2_lds);
+    double *red = reinterpret_cast<double *>(rows2_lds + sizeof(u32x4_) * 2 * kTileVec);                       // [wave][2][N]
+    float *st = reinterpret_cast<float *>(rows2_lds + sizeof(u32x4_) * 2 * kTileVec + sizeof(double) * 8 * N);   // [4][in_dim]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 31, fg = lane >> 5;
+    const int ktiles = in_dim / kBK;
+    float sa, unscale;
+    {
+        unsigned mb = 0;
+        for (int i = lane; i < n_a_max; i += 64) mb = max(mb, a_max[i]);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, d, 64));
+        sa = pow2_scale_for(mb, 0);
+        unscale = 1.0f / (sa * pow2_scale_for(*w_max, 0));
+    }
+    if (STAT) {
+        for (int i = tid; i < 4 * in_dim; i += kRowsThreads) st[i] = in_stat[i];
+    }
+    const int64_t row_tiles = (n + 127) / 128;
+    double bsum[2] = {0.0, 0.0};
+    const bool leaky = act == TGNN_ACT_LEAKY_RELU;
+
+    for (int64_t rt = blockIdx.x; rt < row_tiles; rt += gridDim.x) {
+        const int64_t m0 = rt * 128 + wave * 32;
+        int64_t row = m0 + fi;
+        row = row < n ? row : n - 1;
+        const float *arow = a + row * lda + 8 * fg;
+        auto load_a = [&](int kt, float4 (&r)[4]) {
+            const float4 *p = reinterpret_cast<const float4 *>(arow + (int64_t)kt * a_kb_stride);   // (kps == 1: the launcher's condition)
+            r[0] = p[0]; r[1] = p[1]; r[2] = p[4]; r[3] = p[5];        // k = 8 g .. + 7 and 16 + 8 g .. + 7
+        };
+        auto load_b = [&](int kt, u32x4_ (&r)[RB]) {
+            const u32x4_ *p = wimg + (int64_t)kt * kTileVec + tid;
+#pragma unroll
+            for (int j = 0; j < RB; ++j) r[j] = p[kRowsThreads * j];
+        };
+        auto store_b = [&](const u32x4_ (&r)[RB], u32x4_ *dst) {
+#pragma unroll
+            for (int j = 0; j < RB; ++j) dst[tid + kRowsThreads * j] = r[j];
+        };
+        auto split_a = [&](int kt, const float4 (&r)[4], f16x8 (&hi)[2], f16x8 (&lo)[2]) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                float x[8] = {r[2 * kb].x, r[2 * kb].y, r[2 * kb].z, r[2 * kb].w,
+                              r[2 * kb + 1].x, r[2 * kb + 1].y, r[2 * kb + 1].z, r[2 * kb + 1].w};
+                if (STAT) {
+                    const int k = kt * kBK + kb * 16 + 8 * fg;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        x[e] = bn_apply1(x[e], st[k + e], st[in_dim + k + e], st[2 * in_dim + k + e], st[3 * in_dim + k + e]);
+                }
+                split2_f16(x, sa, hi[kb], lo[kb]);
+            }
+        };
+        f32x16 acc[TN];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tn][r] = 0.f;
+        // registers of the pipeline, by the parity of the k-tile they hold
+        float4 araw0[4], araw1[4];
+        u32x4_ breg0[RB], breg1[RB];
+        f16x8 ah0[2], al0[2], ah1[2], al1[2];
+        const int last = ktiles - 1;
+        auto clampk = [&](int kt) { return kt < last ? kt : last; };
+        load_a(0, araw0);
+        load_b(0, breg0);
+        load_a(clampk(1), araw1);
+        load_b(clampk(1), breg1);
+        __syncthreads();                                      // the previous row tile's reads of Bs (and st's fill) are over
+        store_b(breg0, Bs[0]);
+        split_a(0, araw0, ah0, al0);
+        load_a(clampk(2), araw0);
+        load_b(clampk(2), breg0);
+        // Branch-free inside the k loop (an accumulator modified on two paths of a loop costs hipcc a register copy per element and
+        // iteration): loads past the last tile re-read the last tile, the store / split of a tile nobody multiplies are harmless.
+        auto mma = [&](const u32x4_ *bcur, const f16x8 (&ahc)[2], const f16x8 (&alc)[2]) {
+            const u32x4_ *bt = bcur + lane;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                f16x8 bh[TN], bl[TN];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    bh[tn] = __builtin_bit_cast(f16x8, bt[(kb * TN + tn) * 128]);
+                    bl[tn] = __builtin_bit_cast(f16x8, bt[(kb * TN + tn) * 128 + 64]);
+                }
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alc[kb], bh[tn], acc[tn], 0, 0, 0);   // lo . hi
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahc[kb], bl[tn], acc[tn], 0, 0, 0);   // hi . lo
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahc[kb], bh[tn], acc[tn], 0, 0, 0);   // hi . hi
+            }
+        };
+        const int pairs = ktiles >> 1;
+        for (int kp = 0; kp < pairs; ++kp) {
+            const int kt = 2 * kp;
+            // step kt: tile kt is in Bs[0] behind the barrier, A(kt) split in (ah0, al0); tile kt + 1 goes registers -> Bs[1] and is
+            // split, its registers take tile kt + 3; then the 6 TN matrix instructions of tile kt
+            __syncthreads();
+            store_b(breg1, Bs[1]);
+            split_a(clampk(kt + 1), araw1, ah1, al1);
+            load_a(clampk(kt + 3), araw1);
+            load_b(clampk(kt + 3), breg1);
+            mma(Bs[0], ah0, al0);
+            // step kt + 1 the other way round
+            __syncthreads();
+            store_b(breg0, Bs[0]);
+            split_a(clampk(kt + 2), araw0, ah0, al0);
+            load_a(clampk(kt + 4), araw0);
+            load_b(clampk(kt + 4), breg0);
+            mma(Bs[1], ah1, al1);
+        }
+        if (ktiles & 1) {                                     // (uniform) the last tile of an odd count: in Bs[0], split in (ah0, al0)
+            __syncthreads();
+            mma(Bs[0], ah0, al0);
+        }
+        // ---- epilogue (C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5))
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = tn * 32 + fi;
+            const float b = bias[col];
+            double s_ = 0.0, q_ = 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t orow = m0 + (r & 3) + 8 * (r >> 2) + 4 * fg;
+                if (orow < n) {
+                    const float u = fmaf(acc[tn][r], unscale, b);
+                    const float v = leaky ? (u >= 0.f ? u : u * kLeakySlope) : act_apply(u, act);
+                    out[orow * ldo + col] = v;
+                    s_ += (double)v;
+                    q_ += (double)v * (double)v;
+                }
+            }
+            s_ += __shfl_xor(s_, 32, 64);
+            q_ += __shfl_xor(q_, 32, 64);
+            if (bn_partial && (tn / TNH) == fg) {             // (lanes < 32 write the columns of tn < TN / 2, the others the rest)
+                red[(wave * 2 + 0) * N + col] = s_;
+                red[(wave * 2 + 1) * N + col] = q_;
+            }
+        }
+        if (bn_partial) {
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = tid + kRowsThreads * h;
+                if (i < 2 * N) {
+                    const int which = i / N, cl = i % N;
+                    double tot = 0.0;
+#pragma unroll
+                    for (int wv = 0; wv < 4; ++wv) tot += red[(wv * 2 + which) * N + cl];
+                    bsum[h] += tot;
+                }
+            }
+        }
+    }
+
+    if (bn_partial) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = tid + kRowsThreads * h;
+            if (i < 2 * N) bn_partial[(int64_t)blockIdx.x * 2 * N + i] = bsum[h];
+        }
+    }
+}
+
 static size_t dense_f16_image_bytes(int in_dim, int out_dim) { return (size_t)in_dim * out_dim * 4; }
+static std::atomic<int> g_dense_rows_mode{0};                // tgnn_set_dense_rows_mode: 0 = dense_f16_rows_kernel, 1 = dense_f16_rows2_kernel
+
+template <int TN>
+static int launch_dense_f16_rows2(hipStream_t s, const float *a, int64_t lda, int64_t akb, int kps, const float *in_stat,
+                                  const void *wimg, const float *b, int64_t n, int in_dim, int act, float *out, int64_t ldo,
+                                  double *bn_partial, const unsigned *a_max, int n_a_max, const unsigned *w_max) {
+    constexpr size_t fixed = sizeof(u32x4_) * 2 * (2 * TN * 2 * 64) + sizeof(double) * 8 * (32 * TN);
+    const size_t lds = fixed + (in_stat ? (size_t)4 * in_dim * sizeof(float) : 0);
+    int blocks = producer_blocks(n, 128);
+    const int cap = device_cus();                             // one block per CU: each wave has a SIMD's registers to itself
+    if (blocks > cap) blocks = cap;
+    const u32x4_ *img = static_cast<const u32x4_ *>(wimg);
+    if (in_stat) {
+        static LdsOptIn site;
+        (void)opt_in_dynamic_lds(dense_f16_rows2_kernel<TN, true>, 160 * 1024 - 256, site);
+        dense_f16_rows2_kernel<TN, true><<<blocks, kRowsThreads, lds, s>>>(a, lda, akb, kps, in_stat, img, b, n, in_dim, act, out, ldo,
+                                                                          bn_partial, a_max, n_a_max, w_max);
+    } else {
+        static LdsOptIn site;
+        (void)opt_in_dynamic_lds(dense_f16_rows2_kernel<TN, false>, 160 * 1024 - 256, site);
+        dense_f16_rows2_kernel<TN, false><<<blocks, kRowsThreads, lds, s>>>(a, lda, akb, kps, nullptr, img, b, n, in_dim, act, out, ldo,
+                                                                           bn_partial, a_max, n_a_max, w_max);
+    }
+    return blocks;
+}
 
 template <int TN>
 static int launch_dense_f16_rows(hipStream_t s, const float *a, int64_t lda, int64_t akb, int kps, const float *in_stat,
                                  const void *wimg, const float *b, int64_t n, int in_dim, int act, float *out, int64_t ldo,
                                  double *bn_partial, const unsigned *a_max, int n_a_max, const unsigned *w_max) {
+    if (g_dense_rows_mode.load(std::memory_order_relaxed) == 1 && kps == 1)
+        return launch_dense_f16_rows2<TN>(s, a, lda, akb, kps, in_stat, wimg, b, n, in_dim, act, out, ldo, bn_partial, a_max, n_a_max,
+                                          w_max);
     const size_t lds = in_stat ? (size_t)4 * in_dim * sizeof(float) : 0;     // (dynamic part: the BatchNorm record)
     int blocks = producer_blocks(n, 128);
     const int cap = 2 * device_cus();
@@ -949,6 +1168,11 @@ static int dense_act_impl(const float *a, int64_t lda, int64_t a_kblock_stride, 
     return TGNN_OK;
 }
 
+extern "C" int32_t tgnn_set_dense_rows_mode(int32_t mode) {
+    if (mode != 0 && mode != 1) return g_dense_rows_mode.load();
+    return g_dense_rows_mode.exchange(mode);
+}
+
 extern "C" int tgnn_dense_act_fwd(const float *a, int64_t lda, int64_t a_kblock_stride, const float *in_stat,
                                   const float *w, const float *b, int64_t n_rows, int32_t in_dim, int32_t out_dim,
                                   int32_t act, float *out, int64_t ldo, double *bn_partial,
@@ -983,6 +1207,51 @@ int dense_f16_image_build(const float *w, int in_dim, int out_dim, const unsigne
     if (in_dim % kBK || out_dim % 32 || ((uintptr_t)w % 16) || ((uintptr_t)wimg % 16)) return TGNN_ERR_UNSUPPORTED;
     const int items = (in_dim / kBK) * 2 * (out_dim / 32) * 64;
     dense_f16_image_kernel<<<(items + 255) / 256, 256, 0, s>>>(w, in_dim, out_dim / 32, w_max, static_cast<u32x4_ *>(wimg));
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}
+// [r6] several images in one launch: block ranges per job
+struct DenseImageJobs {
+    const float *w[4];
+    u32x4_ *img[4];
+    const unsigned *w_max[4];
+    int in_dim[4], tn_count[4], block0[5];
+};
+__global__ __launch_bounds__(256) void dense_f16_images_kernel(DenseImageJobs J, int n_jobs) {
+    int k = 0;
+    while (k + 1 < n_jobs && (int)blockIdx.x >= J.block0[k + 1]) ++k;
+    const int in_dim = J.in_dim[k], tn_count = J.tn_count[k], ktiles = in_dim / kBK;
+    const int item = ((int)blockIdx.x - J.block0[k]) * 256 + threadIdx.x;
+    if (item >= ktiles * 2 * tn_count * 64) return;
+    const int lane = item & 63, t = item >> 6, tn = t % tn_count, kb = (t / tn_count) & 1, kt = t / (2 * tn_count);
+    const int col = tn * 32 + (lane & 31), k0 = kt * kBK + kb * 16 + 8 * (lane >> 5);
+    const float sw = pow2_scale_for(*J.w_max[k], 0);
+    const float4 *p = reinterpret_cast<const float4 *>(J.w[k] + (int64_t)col * in_dim + k0);
+    const float4 x0 = p[0], x1 = p[1];
+    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    f16x8 hi, lo;
+    split2_f16(x, sw, hi, lo);
+    const int64_t o = ((int64_t)(kt * 2 + kb) * tn_count + tn) * 128 + lane;
+    J.img[k][o] = __builtin_bit_cast(u32x4_, hi);
+    J.img[k][o + 64] = __builtin_bit_cast(u32x4_, lo);
+}
+int dense_f16_images_build(int n_jobs, const float *const *w, const int *in_dim, const int *out_dim, const unsigned *const *w_max,
+                           void *const *wimg, hipStream_t s) {
+    if (n_jobs < 1 || n_jobs > 4) return TGNN_ERR_UNSUPPORTED;
+    DenseImageJobs J{};
+    int blocks = 0;
+    for (int k = 0; k < n_jobs; ++k) {
+        if (in_dim[k] % kBK || out_dim[k] % 32 || ((uintptr_t)w[k] % 16) || ((uintptr_t)wimg[k] % 16)) return TGNN_ERR_UNSUPPORTED;
+        J.w[k] = w[k];
+        J.img[k] = static_cast<u32x4_ *>(wimg[k]);
+        J.w_max[k] = w_max[k];
+        J.in_dim[k] = in_dim[k];
+        J.tn_count[k] = out_dim[k] / 32;
+        J.block0[k] = blocks;
+        blocks += ((in_dim[k] / kBK) * 2 * (out_dim[k] / 32) * 64 + 255) / 256;
+    }
+    J.block0[n_jobs] = blocks;
+    dense_f16_images_kernel<<<blocks, 256, 0, s>>>(J, n_jobs);
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
 }

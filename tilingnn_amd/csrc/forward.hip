@@ -133,6 +133,7 @@ struct Prof {
 static const int kFinalDims[4] = {256, 128, 64, 0};  // TilinGNN.py:46 hidden_layer_dims; [3] = C
 static std::atomic<int> g_split_f16{1};              // tgnn_set_split_precision
 static std::atomic<int> g_nnconv_eg{1};              // tgnn_set_nnconv_eg
+static std::atomic<int> g_lean_head{3};              // tgnn_set_lean_head: bit 0 the head without memsets / early edge-weight event, bit 1 the fused init MLP
 static std::atomic<int64_t> g_path_count[3];          // forwards queued on the general schedule / small-layout kernel / mid-size kernel
 
 // n = rows this device computes; nr >= n = rows of the buffers that are GATHERED from (owned rows, then halo rows
@@ -189,6 +190,10 @@ extern "C" int32_t tgnn_set_split_precision(int32_t mode) {
 extern "C" int32_t tgnn_set_nnconv_eg(int32_t on) {
     if (on != 0 && on != 1) return g_nnconv_eg.load();
     return g_nnconv_eg.exchange(on);
+}
+extern "C" int32_t tgnn_set_lean_head(int32_t bits) {
+    if (bits < 0 || bits > 3) return g_lean_head.load();
+    return g_lean_head.exchange(bits);
 }
 extern "C" const char *tgnn_last_error(void) { return g_err; }
 extern "C" void tgnn_forward_path_counts(int64_t *out3) {
@@ -422,10 +427,18 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     unsigned *weights_done = mid_counter ? w.bounds + 2 * D + 6 : (small_teams == 2 && s2 && weights_on_side) ? w.small_ctr + 16 : nullptr;
     if (weights_done && !mid_counter) TGNN_CHECK_HIP(hipMemsetAsync(weights_done, 0, 4, s));
     const unsigned weights_target = edge_weight_table_blocks(T, fe, D, c, tiled);
+    // [r6] the general schedule's head: no memset anywhere (a hipMemsetAsync is two fill kernels and ~10 us in front of the first
+    // launch) -- the scales kernel clears the words, among them the collision branch's fold counter; the first Linear's bound is
+    // taken on the side stream with the other two (nobody needs it before the final MLP)
+    const bool lean_head = f16 && !mid_k && !small_teams && (g_lean_head.load(std::memory_order_relaxed) & 1);
+    unsigned *fold_ctr = lean_head ? w.bounds + 2 * D + 7 : w.small_ctr + 32;
     if (f16) {
         const float *roots[kMaxDepth];
         for (int i = 0; i < D; ++i) roots[i] = P.f(P.layer(i) + 6);
-        launch_forward_scales(w.bounds, 2 * D + 7, roots, D, root_max, P.f(P.fin(0)), cat_w_floats, dense_max, s);   // (before the fork: both chains see the zeroed words)
+        if (lean_head)
+            launch_forward_scales(w.bounds, 2 * D + 8, roots, D, root_max, nullptr, 0, nullptr, s);
+        else
+            launch_forward_scales(w.bounds, 2 * D + 7, roots, D, root_max, P.f(P.fin(0)), cat_w_floats, dense_max, s);   // (before the fork: both chains see the zeroed words)
     }
     if (s2 && weights_on_side) {
         TGNN_CHECK_HIP(hipEventRecord(ev[kEvFork], s));     // everything the caller queued on `stream` so far
@@ -447,8 +460,44 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
                                          tiled ? w.wimg : nullptr, sw, weights_done, root_max, eg ? kEgImageScale : 1.0f);
         prof.end();
     }
+    // [r6] the layer loop waits for the edge weights alone: the event sits in front of the final MLP's bounds and images (they
+    // are joined with the collision chain, which the last merge waits for) -- 12 us of idle main stream in front of the first NNConv
+    bool weights_recorded = false;
+    if (lean_head && sw != s) {
+        TGNN_CHECK_HIP(hipEventRecord(ev[kEvWeights], s2));
+        weights_recorded = true;
+    }
     bool dimg_ok[3] = {false, false, false};
-    if (f16 && !tail_k) {
+    if (lean_head) {
+        // bounds of the three Linears' weights (+ of layers 1, 2's inputs from their BatchNorm parameters), then the three operand
+        // images in ONE launch
+        const float *bw[3], *bg[3], *bb[3];
+        int64_t bwn[3];
+        int bf[3];
+        unsigned *bwm[3], *bam[3];
+        bw[0] = P.f(P.fin(0)); bwn[0] = cat_w_floats; bg[0] = nullptr; bb[0] = nullptr; bf[0] = 0; bwm[0] = dense_max; bam[0] = nullptr;
+        for (int l = 1; l <= 2; ++l) {
+            const BnPtrs bp = P.bn(P.fin(l - 1) + 2);
+            bw[l] = P.f(P.fin(l));
+            bwn[l] = (int64_t)fin_dims[l] * fin_dims[l + 1];
+            bg[l] = bp.gamma; bb[l] = bp.beta; bf[l] = fin_dims[l];
+            bwm[l] = w.bounds + 2 * D + 2 + 2 * (l - 1);
+            bam[l] = w.bounds + 2 * D + 3 + 2 * (l - 1);
+        }
+        launch_dense_bounds(3, bw, bwn, bg, bb, bf, bwm, bam, n_total, sw);
+        if (c == 32 && n >= kDenseRowsKernelMin) {
+            const float *iw[3];
+            int iin[3], iout[3];
+            const unsigned *iwm[3];
+            void *iimg[3];
+            for (int l = 0; l < 3; ++l) {
+                iw[l] = P.f(P.fin(l)); iin[l] = fin_dims[l]; iout[l] = fin_dims[l + 1];
+                iwm[l] = l == 0 ? dense_max : w.bounds + 2 * D + 2 + 2 * (l - 1);
+                iimg[l] = w.dimg[l];
+            }
+            if (dense_f16_images_build(3, iw, iin, iout, iwm, iimg, sw) == TGNN_OK) dimg_ok[0] = dimg_ok[1] = dimg_ok[2] = true;
+        }
+    } else if (f16 && !tail_k) {
         // the final MLP's layers 1 and 2 (256 -> 128 -> 64): weights' bounds and, from the BatchNorm parameters alone, their inputs'
         const float *bw[2], *bg[2], *bb[2];
         int64_t bwn[2];
@@ -473,7 +522,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     // (parameter vectors + GIN images of the layers; the same launch clears the barrier counter and the tagged partial rows)
     if (mid_k) launch_small_pack(P, D, w.small_pack, w.small_ctr, s, tail_k > 0 || mid_init, w.mid_part, mid_part_doubles() * sizeof(double), tail_k > 0 ? dense_max : nullptr,
                                  sw != s ? sw : nullptr);   // (the final MLP's images: side stream, joined behind the layer loop)
-    if (sw != s) TGNN_CHECK_HIP(hipEventRecord(ev[kEvWeights], s2));
+    if (sw != s && !weights_recorded) TGNN_CHECK_HIP(hipEventRecord(ev[kEvWeights], s2));
     g_path_count[small_teams ? 1 : mid_k ? 2 : 0].fetch_add(1, std::memory_order_relaxed);
     if (small_teams) {
         // init MLP, the layers and the final MLP: one persistent kernel behind the pre-pass
@@ -486,7 +535,24 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     }
 
     // ---- K10: init MLP  (TilinGNN.py:54)
-    if (!mid_init) {
+    // [r6] three launches that recompute from x instead of five that store (init_mlp.hip); the launch-per-op form stays for what
+    // keeps the activations (training), all-reduces the statistics (shards) or normalises with running statistics
+    const bool init_fused = !mid_init && c == 32 && fx <= 8 && !sh && !keep && !use_running_stats && (g_lean_head.load(std::memory_order_relaxed) & 2);
+    if (init_fused) {
+        const int ib = init_mlp_fused_blocks(n);
+        BnJob j0 = BnJob{w.partf, ib, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, w.stat_i[0]};
+        BnJob j1 = BnJob{w.partf + (size_t)TGNN_BN_MAX_PARTIALS * 64, ib, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, w.stat_i[1]};
+        const BnPtrs b0 = P.bn(P.init(0) + 2), b1 = P.bn(P.init(1) + 2);
+        j0.gamma = b0.gamma; j0.beta = b0.beta; j1.gamma = b1.gamma; j1.beta = b1.beta;
+        if (update_running) {
+            j0.running_mean = b0.rm; j0.running_var = b0.rv; j0.num_batches_tracked = b0.nbt;
+            j1.running_mean = b1.rm; j1.running_var = b1.rv; j1.num_batches_tracked = b1.nbt;
+        }
+        prof.begin(1);
+        TGNN_TRY(launch_init_mlp_fused(x, fx, fx, P.f(P.init(0)), P.f(P.init(0) + 1), P.f(P.init(1)), P.f(P.init(1) + 1), j0, j1, n, eps,
+                                       momentum, w.mid, slot_max, s));
+        prof.end();
+    } else if (!mid_init) {
         prof.begin(1);
         TGNN_TRY(tgnn_dense_act_fwd(x, fx, 32, nullptr, P.f(P.init(0)), P.f(P.init(0) + 1), n, fx, c, TGNN_ACT_LEAKY_RELU,
                                     w.t0, c, w.partf, &np1, s));
@@ -522,14 +588,14 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
 #else
     const bool fold_fin2 = c == 32 && !sh && !use_running_stats;
 #endif
-    if (fold_fin2 && !mid_k) TGNN_CHECK_HIP(hipMemsetAsync(w.small_ctr + 32, 0, sizeof(unsigned), s));   // (before ev[0]: the side chain sees it)
+    if (fold_fin2 && !mid_k && !lean_head) TGNN_CHECK_HIP(hipMemsetAsync(fold_ctr, 0, sizeof(unsigned), s));   // (before ev[0]: the side chain sees it)
     auto gin_layer = [&](int i, hipStream_t gs) -> int {
         const int b = P.layer(i);
         const float *gin_in = i == 0 ? w.mid : w.a2[(i - 1) & 1];
         const float *gin_stat = i == 0 ? nullptr : w.stat2[(i - 1) & 1];
         if (fold_fin2) {
             GinFin fin{};
-            fin.counter = w.small_ctr + 32;
+            fin.counter = fold_ctr;
             fin.job = bn_job(nullptr, 0, P.bn(b + 20), w.stat2[i & 1]);
             fin.n_total = n;
             fin.eps = eps;

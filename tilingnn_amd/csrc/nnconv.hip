@@ -557,11 +557,15 @@ struct DenseBoundJob {
 struct DenseBoundJobs {
     DenseBoundJob job[4];
 };
+// [r6] grid (jobs, slices): a job's weights are walked by `slices` blocks (one block per job took 17-20 us for 32 dependent rounds
+// of loads); the words are zeroed by the caller, the blocks fold into them with atomicMax
 __global__ __launch_bounds__(256) void dense_bounds_kernel(DenseBoundJobs jobs, float sqrt_n) {
     const DenseBoundJob j = jobs.job[blockIdx.x];
     float m = 0.f;
-    for (int64_t i = threadIdx.x; i < j.w_n4; i += 256) m = absmax4(m, reinterpret_cast<const float4 *>(j.w)[i]);
+    for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < j.w_n4; i += (int64_t)gridDim.y * 256)
+        m = absmax4(m, reinterpret_cast<const float4 *>(j.w)[i]);
     absmax_flush(m, j.w_max);
+    if (blockIdx.y != 0 || !j.gamma) return;                  // (uniform)
     float a = 0.f;
     for (int c = threadIdx.x; c < j.f; c += 256) a = fmaxf(a, fmaf(fabsf(j.gamma[c]), sqrt_n, fabsf(j.beta[c])));
     absmax_flush(a, j.a_max);
@@ -570,14 +574,35 @@ void launch_dense_bounds(int n_jobs, const float *const *w, const int64_t *w_n, 
                          const int *f, unsigned *const *w_max, unsigned *const *a_max, int64_t n_total, hipStream_t s) {
     DenseBoundJobs jobs{};
     for (int k = 0; k < n_jobs && k < 4; ++k) jobs.job[k] = DenseBoundJob{w[k], w_n[k] / 4, gamma[k], beta[k], f[k], w_max[k], a_max[k]};
-    dense_bounds_kernel<<<n_jobs, 256, 0, s>>>(jobs, sqrtf((float)n_total) * 1.0001f);
+    dense_bounds_kernel<<<dim3(n_jobs, 16), 256, 0, s>>>(jobs, sqrtf((float)n_total) * 1.0001f);
+}
+
+// [r6] launch_forward_scales without a memset and without atomics: block b = max |roots[b]| as a plain store; block 0 also clears
+// every word of [0, n_zero) outside [root_off, root_off + depth)
+__global__ __launch_bounds__(256) void forward_scales_store_kernel(RootPtrs roots, int depth, unsigned *__restrict__ words, int n_zero,
+                                                                   int root_off) {
+    __shared__ float wave_max[4];
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < n_zero; i += 256)
+            if (i < root_off || i >= root_off + depth) words[i] = 0u;
+    float m = 0.f;
+    m = absmax4(m, reinterpret_cast<const float4 *>(roots.p[blockIdx.x])[threadIdx.x]);   // 1024 floats
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) words[root_off + blockIdx.x] = __float_as_uint(fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3])));
 }
 
 void launch_forward_scales(unsigned *words, int n_words, const float *const *roots, int depth, unsigned *root_max,
                            const float *dense_w, int64_t dense_n, unsigned *dense_max, hipStream_t s) {
-    (void)hipMemsetAsync(words, 0, (size_t)n_words * sizeof(unsigned), s);
     RootPtrs rp{};
     for (int i = 0; i < depth; ++i) rp.p[i] = roots[i];
+    if (!dense_w && depth > 0 && root_max >= words && root_max + depth <= words + n_words) {
+        forward_scales_store_kernel<<<depth, 256, 0, s>>>(rp, depth, words, n_words, (int)(root_max - words));
+        return;
+    }
+    (void)hipMemsetAsync(words, 0, (size_t)n_words * sizeof(unsigned), s);
     const int dense_blocks = dense_w ? 32 : 0;
     if (depth + dense_blocks > 0)
         forward_scales_kernel<<<depth + dense_blocks, 256, 0, s>>>(rp, depth, root_max, dense_w, dense_n / 4, dense_max);

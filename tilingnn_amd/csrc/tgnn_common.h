@@ -413,8 +413,16 @@ void launch_edge_weight_table_batched(const float *edge_attr, const int *type_re
 // img_scale (a power of two): on top of nnconv_weight_scale in the fp16-pair images -- kEgImageScale for the edge-group kernel
 // root_max (device, [depth] words = max |root_i| as float bits, forward_scales below): the images are fp16-pair images
 // [(T+1)][kWtTypeF16] instead.
+// [r6] the init MLP (fx <= 8 -> 32 -> 32, LeakyReLU, train-mode BatchNorm) as three launches that recompute from x: init_mlp.hip.
+// job0 / job1: the two BatchNorms, partials = distinct scratch areas of init_mlp_fused_blocks(n) x 64 doubles; out [n][32].
+int init_mlp_fused_blocks(int64_t n);
+int launch_init_mlp_fused(const float *x, int64_t ldx, int fx, const float *w0, const float *b0, const float *w1, const float *b1,
+                          BnJob job0, BnJob job1, int64_t n, float eps, float momentum, float *out, unsigned *absmax_out,
+                          hipStream_t s);
 // Bounds of a forward's fp16-pair operands in one launch behind a memset: words [0, n_zero) = 0 (the slots' maxima, filled by the
 // producers), root_max[i] = max |roots[i]|, *dense_max = max |dense_w[0 .. dense_n)|
+// (dense_w == NULL [r6]: ONE kernel and no memset -- every root maximum is one block's plain store, block 0 clears the other
+//  words; root_max must lie inside words[0, n_zero))
 void launch_forward_scales(unsigned *words, int n_zero, const float *const *roots, int depth, unsigned *root_max,
                            const float *dense_w, int64_t dense_n, unsigned *dense_max, hipStream_t s);
 // NNConv B-operand weight images [(T+1)][1152] for `depth` layers (roots[i] = layer i's root matrix); nnconv.hip
@@ -438,6 +446,7 @@ int launch_nnconv_eg(const float *h, const int32_t *tile_grp_ptr, const int32_t 
 void launch_absmax(const float *h, int64_t n_floats, unsigned *max_bits, hipStream_t s);
 // max |W_k| and a bound of |BN(v)| from the BatchNorm's parameters alone (nnconv.hip: dense_bounds_kernel), atomicMax into
 // zeroed words: what the final MLP's inner layers need to run the fp16-pair kernel on a BatchNorm-on-load input
+// (gamma[k] == NULL: the weights' bound only; the words are zeroed by the caller: several blocks per job fold into them)
 void launch_dense_bounds(int n_jobs, const float *const *w, const int64_t *w_n, const float *const *gamma, const float *const *beta,
                          const int *f, unsigned *const *w_max, unsigned *const *a_max, int64_t n_total, hipStream_t s);
 // tgnn_dense_act_fwd with bounds of both operands (a_max: of the input AFTER in_stat's BatchNorm, if any): dense.hip
@@ -450,6 +459,9 @@ int dense_act_bounded(const float *a, int64_t lda, int64_t a_kblock_stride, cons
 constexpr int64_t kDenseRowsKernelMin = 49152;       // rows from which that kernel is taken (below: the block-tile kernels win)
 size_t dense_f16_image_size(int in_dim, int out_dim);
 int dense_f16_image_build(const float *w, int in_dim, int out_dim, const unsigned *w_max, void *wimg, hipStream_t s);
+// [r6] up to four images in ONE launch (the final MLP's Linears; same bits as dense_f16_image_build each)
+int dense_f16_images_build(int n_jobs, const float *const *w, const int *in_dim, const int *out_dim, const unsigned *const *w_max,
+                           void *const *wimg, hipStream_t s);
 // tgnn_dense_act_slots_fwd (no input BatchNorm) with bounds of both operands: a_max[0 .. n_a_max) / w_max = max |a| per slot /
 // max |w| as float bits (device) -> the fp16-pair kernel (dense.hip: dense_split_kernel<.., F16>); dense.hip
 int dense_act_slots_bounded(const float *a, int32_t slot_width, int64_t slot_stride, const float *w, const float *b,
