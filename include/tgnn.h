@@ -338,6 +338,22 @@ int tgnn_forward(const tgnn_model_dims *dims, const void *const *params_host, co
                  int32_t use_running_stats, float *probs, void *ws, size_t ws_bytes,
                  tgnn_stream_t stream, tgnn_stream_t stream2);
 
+/* [r6] The forward in two calls around the layout's preparation (ML_Solver.predict on a NEW layout: util/data_util.py:110-117 then
+ * networks/TilinGNN.py:51-78).  tgnn_forward_begin queues, on stream2 and ordered behind what `stream` holds so far, everything the
+ * general schedule does in front of its first layer that needs nothing of the graph -- the operands' bounds, the init MLP
+ * (middle[0]), the final MLP's bounds and operand images -- so that it runs BESIDE the preparation's launches (tgnn_graph_prep on
+ * `stream`) instead of behind them; tgnn_forward_resume is tgnn_forward (train-mode BatchNorm) picking that work up.  Same
+ * workspace (sized by tgnn_forward_workspace_bytes with any type count up to 16: the pieces begin fills do not move with it),
+ * same thread, same node count; the result is bit-identical to tgnn_forward's.
+ * tgnn_forward_begin returns TGNN_ERR_UNSUPPORTED (and queues nothing) where it does not apply -- layouts of the persistent
+ * schedules, widths other than 32, more than 8 node features, no side stream -- : call tgnn_forward then.  A layout that
+ * turns out not to take the fp16-pair path (more than 16 edge types, in-degree above 2 048) is handled by resume itself. */
+int tgnn_forward_begin(const tgnn_model_dims *dims, const void *const *params_host, const float *x, int64_t n_nodes,
+                       int32_t update_running, void *ws, size_t ws_bytes, tgnn_stream_t stream, tgnn_stream_t stream2);
+int tgnn_forward_resume(const tgnn_model_dims *dims, const void *const *params_host, const float *x, const float *adj_edge_attr,
+                        const tgnn_graph *graph, int32_t update_running, float *probs, void *ws, size_t ws_bytes,
+                        tgnn_stream_t stream, tgnn_stream_t stream2);
+
 /* ---- the same forward for the TRAINING step (Trainer.train, solver/ml_solver/trainer.py:68-75: the network in train mode
  * with autograd recording): identical kernels and schedule, but what the backward reads is kept in the caller's buffers
  * instead of the rotating workspace ones.  C = network_width, D = network_depth, T = graph->n_types. */
@@ -499,9 +515,11 @@ int32_t tgnn_set_mid_tail(int32_t on);
  * carries them, instead of over its type columns.  Default 1; returns the previous setting (an argument outside 0 .. 1 only
  * queries). */
 int32_t tgnn_set_nnconv_eg(int32_t on);
-/* The final MLP's fp16-pair Linears for many rows (csrc/dense.hip; reference: graph_networks/networks/TilinGNN.py:74-76): 1 (default)
- * = dense_f16_rows2_kernel, one wave per SIMD with every operand two k-tiles in flight; 0 = dense_f16_rows_kernel (two waves per
- * SIMD, LDS-DMA one k-tile ahead).  The same bits.  Returns the previous setting (an argument outside 0 .. 1 only queries). */
+/* The final MLP's fp16-pair Linears for many rows (csrc/dense.hip; reference: graph_networks/networks/TilinGNN.py:74-76).  Bit 1
+ * (default on): the BatchNorm-on-load layers 256 -> 128 -> 64 on dense_f16_resident_kernel (W's operand image resident in LDS, no
+ * barrier in the k loop, 16 KB requests per wave).  Bit 0 (default off; an experiment that measured slower): dense_f16_rows2_kernel
+ * (one wave per SIMD, every operand two k-tiles in flight) instead of dense_f16_rows_kernel for what is left.  The same bits
+ * in every setting.  Default 2; returns the previous setting (an argument outside 0 .. 3 only queries). */
 int32_t tgnn_set_dense_rows_mode(int32_t mode);
 /* The front of the general schedule (reference: graph_networks/networks/TilinGNN.py:54 and the operand preparation in front of the
  * first layer).  Bit 0: no memset in front of the first launch, the layer loop waits for the edge weights only (the final MLP's

@@ -122,6 +122,8 @@ def _load() -> C.CDLL:
         "tgnn_forward_workspace_bytes": (sz, [C.POINTER(ModelDims), i64, i32]),
         "tgnn_forward": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), p, p, C.POINTER(Graph), i32, i32,
                                    p, p, sz, p, p]),
+        "tgnn_forward_begin": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), p, i64, i32, p, sz, p, p]),
+        "tgnn_forward_resume": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), p, p, C.POINTER(Graph), i32, p, p, sz, p, p]),
         "tgnn_forward_sharded_workspace_bytes": (sz, [C.POINTER(ModelDims), i64, i64, i32]),
         "tgnn_forward_sharded": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), p, p, C.POINTER(Graph),
                                            C.POINTER(ShardDesc), i32, p, p, sz, p]),
@@ -230,7 +232,7 @@ EXPORTED_SYMBOLS = (
     "tgnn_nnconv_cols_build", "tgnn_nnconv_cols_max_types", "tgnn_nnconv_weight_image_floats", "tgnn_nnconv_mean_cols_fwd", "tgnn_nnconv_mean_cols_f16_fwd", "tgnn_nnconv_eg_max_groups", "tgnn_nnconv_eg_build", "tgnn_nnconv_mean_eg_fwd",
     "tgnn_ubench_row_gather", "tgnn_mid_entries_words", "tgnn_mid_entries_build", "tgnn_forward_path_counts", "tgnn_set_mid_layout_limit", "tgnn_get_mid_layout_limit", "tgnn_mid_layout_max_nodes",
     "tgnn_spin_error_poll", "tgnn_set_spin_budget_us", "tgnn_persist_fallback", "tgnn_spin_error_peek", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_dense_act_slots_fwd", "tgnn_dense_act_slots_f16_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
-    "tgnn_merge_fwd", "tgnn_param_count", "tgnn_param_name", "tgnn_forward_workspace_bytes", "tgnn_forward",
+    "tgnn_merge_fwd", "tgnn_param_count", "tgnn_param_name", "tgnn_forward_workspace_bytes", "tgnn_forward", "tgnn_forward_begin", "tgnn_forward_resume",
     "tgnn_forward_profiled", "tgnn_forward_profiled_two_stream", "tgnn_forward_stamped", "tgnn_forward_many", "tgnn_graph_prep_small_max_nodes", "tgnn_graph_prep_small_max_edges", "tgnn_graph_prep_small_tmp_ints",
     "tgnn_graph_prep_small", "tgnn_graph_prep_workspace_bytes", "tgnn_graph_prep", "tgnn_graph_prep_wait", "tgnn_set_small_layout_limit", "tgnn_get_small_layout_limit", "tgnn_set_split_precision", "tgnn_set_gin_fused", "tgnn_set_gin_mlp_f16", "tgnn_set_mid_tail", "tgnn_set_nnconv_eg", "tgnn_set_dense_rows_mode", "tgnn_set_lean_head", "tgnn_rccl_available", "tgnn_rccl_unique_id_bytes", "tgnn_rccl_unique_id", "tgnn_rccl_comm_create", "tgnn_rccl_comm_destroy", "tgnn_rccl_counters", "tgnn_forward_train", "tgnn_backward_workspace_bytes", "tgnn_backward", "tgnn_forward_sharded_workspace_bytes", "tgnn_forward_sharded",
     "tgnn_rows_gather", "tgnn_rows_scatter", "tgnn_unsupervised_loss_workspace_bytes", "tgnn_unsupervised_loss", "tgnn_solution_score_sums",
@@ -389,6 +391,18 @@ def side_stream(device) -> C.c_void_p:
     if st is None:
         st = _side_streams[key] = concurrent_streams(key, 1)[0]
     return C.c_void_p(st.cuda_stream)
+
+
+ERR_UNSUPPORTED = -4          # TGNN_ERR_UNSUPPORTED (include/tgnn.h)
+
+
+def side_stream_torch(device):
+    """The torch.cuda.Stream behind side_stream(device) (None when the two-chain schedule is off)."""
+    import torch
+    if not side_stream(device).value:
+        return None
+    key = torch.device(device).index
+    return _side_streams.get(torch.cuda.current_device() if key is None else key)
 
 
 def param_names(dims: ModelDims):

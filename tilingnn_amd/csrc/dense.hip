@@ -868,7 +868,154 @@ __global__ __launch_bounds__(kRowsThreads, 1) void dense_f16_rows2_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// [r6] The final MLP's inner Linears (256 -> 128 -> 64, BatchNorm on load) with the WHOLE operand image of W resident in LDS
+// (128 KB / 32 KB: one 8-wave block per CU, the image copied once per block) -- nothing is shared between the waves after
+// that, so the k loop has NO barrier: every wave streams its own 32-row tiles, two k-tiles (8 KB) per request, two requests in
+// flight (128 KB per CU).  These layers are HBM-bound (154 + 77 MB at 100 000 rows); dense_f16_rows_kernel waits for every k-tile's rows one
+// tile after asking for them -- 8 / 4 round trips per row tile with 4 KB per wave in flight: 55.6 + 27.1 us, 2.8 TB/s.
+// Per accumulator the matrix terms come in the rows kernels' order (k ascending; lo.hi, hi.lo, hi.hi): the same bits.
+// One BatchNorm partial row per block (column sums kept per lane in fp64 over all of a wave's tiles).
+// ------------------------------------------------------------------------------------------
+constexpr int kResThreads = 512, kResChunk = 2;               // k-tiles per request (8 KB per wave; two requests in flight)
+template <int TN, int CPT>                                    // CPT = requests per row tile (even): in_dim = 64 CPT
+__global__ __launch_bounds__(kResThreads, 1) void dense_f16_resident_kernel(
+    const float *__restrict__ a, int64_t lda, const float *__restrict__ in_stat, const u32x4_ *__restrict__ wimg,
+    const float *__restrict__ bias, int64_t n, int act, float *__restrict__ out, int64_t ldo, double *__restrict__ bn_partial,
+    const unsigned *__restrict__ a_max, const unsigned *__restrict__ w_max) {
+    constexpr int N = 32 * TN, K = 64 * CPT, KT = K / kBK;
+    constexpr int kTileVec = 2 * TN * 2 * 64;                 // 16-byte pieces of one k-tile of the image
+    extern __shared__ __attribute__((aligned(1024))) unsigned char res_lds[];
+    u32x4_ *Bs = reinterpret_cast<u32x4_ *>(res_lds);                                   // [KT][kTileVec]
+    float *st = reinterpret_cast<float *>(res_lds + sizeof(u32x4_) * KT * kTileVec);    // [4][K]
+    double *red = reinterpret_cast<double *>(res_lds + sizeof(u32x4_) * KT * kTileVec + sizeof(float) * 4 * K);   // [8 waves][2][N]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 31, fg = lane >> 5;
+    const int64_t tiles = (n + 31) / 32, stride = (int64_t)gridDim.x * 8;
+    int64_t tile = (int64_t)blockIdx.x * 8 + wave;
+    auto arow_of = [&](int64_t t) {
+        int64_t row = (t < tiles ? t : tiles - 1) * 32 + fi;
+        row = row < n ? row : n - 1;
+        return a + row * lda + 8 * fg;
+    };
+    // one request: two k-tiles of the wave's 32 rows, 8 x 16 bytes per lane
+    auto load_chunk = [&](const float *arow, int c, float4 (&r)[4 * kResChunk]) {
+#pragma unroll
+        for (int t = 0; t < kResChunk; ++t) {
+            const float4 *p = reinterpret_cast<const float4 *>(arow + (c * kResChunk + t) * kBK);
+            r[4 * t] = p[0]; r[4 * t + 1] = p[1]; r[4 * t + 2] = p[4]; r[4 * t + 3] = p[5];   // k = 8 g .. + 7 and 16 + 8 g .. + 7
+        }
+    };
+    float4 ra0[4 * kResChunk], ra1[4 * kResChunk];
+    // the first two requests go out before anything else: they land while the image is copied
+    load_chunk(arow_of(tile), 0, ra0);
+    load_chunk(arow_of(tile), 1, ra1);
+    for (int i = tid; i < KT * kTileVec; i += kResThreads) Bs[i] = wimg[i];
+    for (int i = tid; i < 4 * K; i += kResThreads) st[i] = in_stat[i];
+    const float sa = pow2_scale_for(*a_max, 0);
+    const float unscale = 1.0f / (sa * pow2_scale_for(*w_max, 0));
+    const bool leaky = act == TGNN_ACT_LEAKY_RELU;
+    float bcol[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) bcol[tn] = bias[tn * 32 + fi];
+    double cs[TN], cq[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) cs[tn] = cq[tn] = 0.0;
+    __syncthreads();
+
+    // the k-tiles c * 4 .. + 3 of a row tile out of one request's registers
+    auto mma_chunk = [&](int c, const float4 (&r)[4 * kResChunk], f32x16 (&acc)[TN]) {
+#pragma unroll
+        for (int t = 0; t < kResChunk; ++t) {
+            const int kt = c * kResChunk + t;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                float x[8] = {r[4 * t + 2 * kb].x, r[4 * t + 2 * kb].y, r[4 * t + 2 * kb].z, r[4 * t + 2 * kb].w,
+                              r[4 * t + 2 * kb + 1].x, r[4 * t + 2 * kb + 1].y, r[4 * t + 2 * kb + 1].z, r[4 * t + 2 * kb + 1].w};
+                const int k = kt * kBK + kb * 16 + 8 * fg;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = bn_apply1(x[e], st[k + e], st[K + k + e], st[2 * K + k + e], st[3 * K + k + e]);
+                f16x8 ah, al;
+                split2_f16(x, sa, ah, al);
+                // term-major: TN independent matrix instructions between two on the same accumulator, every fragment of the k-half
+                // requested before the first one (per accumulator the order stays lo.hi, hi.lo, hi.hi)
+                const u32x4_ *bt = Bs + (int64_t)kt * kTileVec + lane;
+                f16x8 bh[TN], bl[TN];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    bh[tn] = __builtin_bit_cast(f16x8, bt[(kb * TN + tn) * 128]);
+                    bl[tn] = __builtin_bit_cast(f16x8, bt[(kb * TN + tn) * 128 + 64]);
+                }
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[tn], acc[tn], 0, 0, 0);   // lo . hi
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[tn], acc[tn], 0, 0, 0);   // hi . lo
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[tn], acc[tn], 0, 0, 0);   // hi . hi
+            }
+        }
+    };
+    auto epilogue = [&](int64_t t, const f32x16 (&acc)[TN]) {
+        const int64_t m0 = t * 32;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = tn * 32 + fi;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t orow = m0 + (r & 3) + 8 * (r >> 2) + 4 * fg;
+                if (orow < n) {
+                    const float u = fmaf(acc[tn][r], unscale, bcol[tn]);
+                    const float v = leaky ? (u >= 0.f ? u : u * kLeakySlope) : act_apply(u, act);
+                    out[orow * ldo + col] = v;
+                    cs[tn] += (double)v;
+                    cq[tn] += (double)v * (double)v;
+                }
+            }
+        }
+    };
+    static_assert(CPT % 2 == 0, "requests alternate between the two register sets");
+    for (; tile < tiles; tile += stride) {
+        f32x16 acc[TN];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tn][r] = 0.f;
+        const float *acur = arow_of(tile), *anext = arow_of(tile + stride);
+#pragma unroll
+        for (int c = 0; c < CPT; c += 2) {
+            // request c + 2 (of this row tile or, behind its last two, of the wave's next one) into the registers request c leaves
+            mma_chunk(c, ra0, acc);
+            if (c + 2 < CPT) load_chunk(acur, c + 2, ra0);
+            else load_chunk(anext, c + 2 - CPT, ra0);
+            mma_chunk(c + 1, ra1, acc);
+            if (c + 3 < CPT) load_chunk(acur, c + 3, ra1);
+            else load_chunk(anext, c + 3 - CPT, ra1);
+        }
+        epilogue(tile, acc);
+    }
+    if (bn_partial) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const double s_ = cs[tn] + __shfl_xor(cs[tn], 32, 64);
+            const double q_ = cq[tn] + __shfl_xor(cq[tn], 32, 64);
+            if (fg == 0) {
+                red[(wave * 2 + 0) * N + tn * 32 + fi] = s_;
+                red[(wave * 2 + 1) * N + tn * 32 + fi] = q_;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * N; i += kResThreads) {
+            const int which = i / N, cl = i % N;
+            double tot = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < 8; ++wv) tot += red[(wv * 2 + which) * N + cl];
+            bn_partial[(int64_t)blockIdx.x * 2 * N + i] = tot;
+        }
+    }
+}
+
 static size_t dense_f16_image_bytes(int in_dim, int out_dim) { return (size_t)in_dim * out_dim * 4; }
+static std::atomic<int> g_dense_resident{1};                 // tgnn_set_dense_rows_mode bit 1 (0 = off): dense_f16_resident_kernel for the inner layers
 static std::atomic<int> g_dense_rows_mode{0};                // tgnn_set_dense_rows_mode: 0 = dense_f16_rows_kernel, 1 = dense_f16_rows2_kernel
 
 template <int TN>
@@ -899,6 +1046,28 @@ template <int TN>
 static int launch_dense_f16_rows(hipStream_t s, const float *a, int64_t lda, int64_t akb, int kps, const float *in_stat,
                                  const void *wimg, const float *b, int64_t n, int in_dim, int act, float *out, int64_t ldo,
                                  double *bn_partial, const unsigned *a_max, int n_a_max, const unsigned *w_max) {
+    // [r6] BatchNorm-on-load layers whose whole image fits LDS: the barrier-free resident kernel
+    if constexpr (TN == 4 || TN == 2)
+    if (g_dense_resident.load(std::memory_order_relaxed) && in_stat && n_a_max == 1 && kps == 1 && akb == kBK && (in_dim == 128 || in_dim == 256) &&
+        lda % 4 == 0) {
+        constexpr int N = 32 * TN;
+        const size_t lds = (size_t)in_dim * N * 4 + (size_t)4 * in_dim * sizeof(float) + (size_t)8 * 2 * N * sizeof(double);
+        int blocks = (int)((n + 255) / 256);
+        const int cap = device_cus();
+        if (blocks > cap) blocks = cap;
+        if (blocks < 1) blocks = 1;
+        const u32x4_ *img = static_cast<const u32x4_ *>(wimg);
+        if (in_dim == 256) {
+            static LdsOptIn site;
+            (void)opt_in_dynamic_lds(dense_f16_resident_kernel<TN, 4>, 160 * 1024 - 256, site);
+            dense_f16_resident_kernel<TN, 4><<<blocks, kResThreads, lds, s>>>(a, lda, in_stat, img, b, n, act, out, ldo, bn_partial, a_max, w_max);
+        } else {
+            static LdsOptIn site;
+            (void)opt_in_dynamic_lds(dense_f16_resident_kernel<TN, 2>, 160 * 1024 - 256, site);
+            dense_f16_resident_kernel<TN, 2><<<blocks, kResThreads, lds, s>>>(a, lda, in_stat, img, b, n, act, out, ldo, bn_partial, a_max, w_max);
+        }
+        return blocks;
+    }
     if (g_dense_rows_mode.load(std::memory_order_relaxed) == 1 && kps == 1)
         return launch_dense_f16_rows2<TN>(s, a, lda, akb, kps, in_stat, wimg, b, n, in_dim, act, out, ldo, bn_partial, a_max, n_a_max,
                                           w_max);
@@ -1169,8 +1338,11 @@ static int dense_act_impl(const float *a, int64_t lda, int64_t a_kblock_stride, 
 }
 
 extern "C" int32_t tgnn_set_dense_rows_mode(int32_t mode) {
-    if (mode != 0 && mode != 1) return g_dense_rows_mode.load();
-    return g_dense_rows_mode.exchange(mode);
+    const int prev = g_dense_rows_mode.load() | (g_dense_resident.load() ? 2 : 0);
+    if (mode < 0 || mode > 3) return prev;
+    g_dense_rows_mode.store(mode & 1);
+    g_dense_resident.store((mode >> 1) & 1);
+    return prev;
 }
 
 extern "C" int tgnn_dense_act_fwd(const float *a, int64_t lda, int64_t a_kblock_stride, const float *in_stat,

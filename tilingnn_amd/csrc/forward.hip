@@ -131,6 +131,7 @@ struct Prof {
 };
 
 static const int kFinalDims[4] = {256, 128, 64, 0};  // TilinGNN.py:46 hidden_layer_dims; [3] = C
+constexpr int kCarveTypes = 16;                      // (= tgnn_nnconv_cols_max_types(): what the matrix-core NNConv kernels take)
 static std::atomic<int> g_split_f16{1};              // tgnn_set_split_precision
 static std::atomic<int> g_nnconv_eg{1};              // tgnn_set_nnconv_eg
 static std::atomic<int> g_lean_head{3};              // tgnn_set_lean_head: bit 0 the head without memsets / early edge-weight event, bit 1 the fused init MLP
@@ -151,8 +152,11 @@ static Workspace carve(const tgnn_model_dims &d, int64_t n, int64_t nr, int32_t 
     w.f2 = cv.take<float>((size_t)n * 128);
     w.f3 = cv.take<float>((size_t)n * 64);
     w.f4 = cv.take<float>((size_t)n * c);
-    w.wtab = cv.take<float>((size_t)D * (n_types > 0 ? n_types : 1) * c * c);
-    w.wimg = cv.take<float>((size_t)D * (n_types + 1) * kWtType);  // MFMA operand images of the column NNConv
+    // [r6] the two type-dependent pieces are sized for at least kCarveTypes types: every other piece then sits at the same offset
+    // whatever the layout's type count turns out to be -- tgnn_forward_begin fills its pieces before the preparation has counted
+    const int tc = n_types < kCarveTypes ? kCarveTypes : n_types;
+    w.wtab = cv.take<float>((size_t)D * tc * c * c);
+    w.wimg = cv.take<float>((size_t)D * (tc + 1) * kWtType);  // MFMA operand images of the column NNConv
     w.part1 = cv.take<double>((size_t)TGNN_BN_MAX_PARTIALS * 2 * c);
     w.part2 = cv.take<double>((size_t)TGNN_BN_MAX_PARTIALS * 2 * c);
     w.partf = cv.take<double>((size_t)TGNN_BN_MAX_PARTIALS * 2 * 256);
@@ -233,11 +237,70 @@ extern "C" size_t tgnn_forward_sharded_workspace_bytes(const tgnn_model_dims *di
         if (rc__ != TGNN_OK) return rc__; \
     } while (0)
 
+// [r6] What the general schedule does in front of its first layer that needs NOTHING of the graph: the operands' bounds, the init
+// MLP (middle[0] and its bound), the final MLP's bounds and operand images.  Either inside forward_impl or -- tgnn_forward_begin --
+// before the layout is prepared, on the side stream, beside the preparation's launches.
+struct HeadEvent {
+    hipEvent_t ev = nullptr;
+    const void *ws = nullptr;        // what the last tgnn_forward_begin of this thread and device filled
+    int64_t n = 0;
+};
+static thread_local HeadEvent g_head[64];
+static int forward_head_bounds_images(const tgnn_model_dims *dims, const Params &P, const Workspace &w, int64_t n, int64_t n_total,
+                                      hipStream_t st, bool *images_ok) {
+    const int c = dims->network_width, D = dims->network_depth;
+    const int fin_dims[5] = {c * (D + 1), kFinalDims[0], kFinalDims[1], kFinalDims[2], c};
+    unsigned *dense_max = w.bounds + 2 * D + 1;
+    const float *bw[3], *bg[3], *bb[3];
+    int64_t bwn[3];
+    int bf[3];
+    unsigned *bwm[3], *bam[3];
+    bw[0] = P.f(P.fin(0)); bwn[0] = (int64_t)fin_dims[0] * fin_dims[1]; bg[0] = nullptr; bb[0] = nullptr; bf[0] = 0; bwm[0] = dense_max; bam[0] = nullptr;
+    for (int l = 1; l <= 2; ++l) {
+        const BnPtrs bp = P.bn(P.fin(l - 1) + 2);
+        bw[l] = P.f(P.fin(l));
+        bwn[l] = (int64_t)fin_dims[l] * fin_dims[l + 1];
+        bg[l] = bp.gamma; bb[l] = bp.beta; bf[l] = fin_dims[l];
+        bwm[l] = w.bounds + 2 * D + 2 + 2 * (l - 1);
+        bam[l] = w.bounds + 2 * D + 3 + 2 * (l - 1);
+    }
+    launch_dense_bounds(3, bw, bwn, bg, bb, bf, bwm, bam, n_total, st);
+    *images_ok = false;
+    if (c == 32 && n >= kDenseRowsKernelMin) {
+        const float *iw[3];
+        int iin[3], iout[3];
+        const unsigned *iwm[3];
+        void *iimg[3];
+        for (int l = 0; l < 3; ++l) {
+            iw[l] = P.f(P.fin(l)); iin[l] = fin_dims[l]; iout[l] = fin_dims[l + 1];
+            iwm[l] = l == 0 ? dense_max : w.bounds + 2 * D + 2 + 2 * (l - 1);
+            iimg[l] = w.dimg[l];
+        }
+        *images_ok = dense_f16_images_build(3, iw, iin, iout, iwm, iimg, st) == TGNN_OK;
+    }
+    return TGNN_OK;
+}
+static int forward_head_init(const tgnn_model_dims *dims, const Params &P, const float *x, const Workspace &w, int64_t n,
+                             int32_t update_running, unsigned *slot_max, hipStream_t st) {
+    const int fx = dims->node_features_dim;
+    const int ib = init_mlp_fused_blocks(n);
+    BnJob j0 = BnJob{w.partf, ib, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, w.stat_i[0]};
+    BnJob j1 = BnJob{w.partf + (size_t)TGNN_BN_MAX_PARTIALS * 64, ib, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, w.stat_i[1]};
+    const BnPtrs b0 = P.bn(P.init(0) + 2), b1 = P.bn(P.init(1) + 2);
+    j0.gamma = b0.gamma; j0.beta = b0.beta; j1.gamma = b1.gamma; j1.beta = b1.beta;
+    if (update_running) {
+        j0.running_mean = b0.rm; j0.running_var = b0.rv; j0.num_batches_tracked = b0.nbt;
+        j1.running_mean = b1.rm; j1.running_var = b1.rv; j1.num_batches_tracked = b1.nbt;
+    }
+    return launch_init_mlp_fused(x, fx, fx, P.f(P.init(0)), P.f(P.init(0) + 1), P.f(P.init(1)), P.f(P.init(1) + 1), j0, j1, n, 1e-5f, 0.1f,
+                                 w.mid, slot_max, st);
+}
+
 static int forward_impl(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
                         const float *adj_edge_attr, const tgnn_graph *graph, int32_t update_running,
                         int32_t use_running_stats, float *probs, void *ws, size_t ws_bytes, tgnn_stream_t stream,
                         tgnn_stream_t stream2, Prof &prof, const tgnn_shard *sh = nullptr,
-                        const tgnn_train_save *keep = nullptr) {
+                        const tgnn_train_save *keep = nullptr, bool head_done = false) {
     TGNN_CHECK_ARG(dims_ok(dims), "model dims");
     TGNN_CHECK_ARG(params_host && graph && probs && x, "null pointer");
     const int64_t n = graph->n_nodes;
@@ -288,6 +351,14 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         for (int l = 0; l < 4; ++l) w.stat_f[l] = keep->fin_stat[l];
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (head_done) {
+        int dev = 0;
+        TGNN_CHECK_HIP(hipGetDevice(&dev));
+        TGNN_CHECK_ARG(dev >= 0 && dev < 64 && g_head[dev].ev && g_head[dev].ws == ws && g_head[dev].n == n,
+                       "tgnn_forward_resume without a matching tgnn_forward_begin (same thread, device, workspace, node count)");
+        g_head[dev].ws = nullptr;
+        TGNN_CHECK_HIP(hipStreamWaitEvent(s, g_head[dev].ev, 0));   // middle[0], the bounds, the final MLP's images: done long ago (the preparation ran meanwhile)
+    }
     // Two-chain schedule: the collision branch is a chain of its own -- CollConv_i reads only CollConv_{i-1}
     // (TilinGNN.py:63); the branches meet in the product of :64 only.  With a side stream the whole GIN chain runs
     // free beside the NNConv chain and fills the GPU wherever the latter leaves it idle (1-block BN finalizes, the
@@ -431,11 +502,16 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     // launch) -- the scales kernel clears the words, among them the collision branch's fold counter; the first Linear's bound is
     // taken on the side stream with the other two (nobody needs it before the final MLP)
     const bool lean_head = f16 && !mid_k && !small_teams && (g_lean_head.load(std::memory_order_relaxed) & 1);
+    // (what the init MLP's fused form needs is known here already: tgnn_forward_begin's work is used if and only if both hold)
+    const bool init_fused_early = c == 32 && fx <= 8 && !sh && !keep && !use_running_stats && (g_lean_head.load(std::memory_order_relaxed) & 2);
+    const bool head_used = head_done && lean_head && init_fused_early;
     unsigned *fold_ctr = lean_head ? w.bounds + 2 * D + 7 : w.small_ctr + 32;
     if (f16) {
         const float *roots[kMaxDepth];
         for (int i = 0; i < D; ++i) roots[i] = P.f(P.layer(i) + 6);
-        if (lean_head)
+        if (lean_head && head_done && init_fused_early)
+            ;                                                 // (tgnn_forward_begin's, on the side stream)
+        else if (lean_head)
             launch_forward_scales(w.bounds, 2 * D + 8, roots, D, root_max, nullptr, 0, nullptr, s);
         else
             launch_forward_scales(w.bounds, 2 * D + 7, roots, D, root_max, P.f(P.fin(0)), cat_w_floats, dense_max, s);   // (before the fork: both chains see the zeroed words)
@@ -468,35 +544,14 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         weights_recorded = true;
     }
     bool dimg_ok[3] = {false, false, false};
-    if (lean_head) {
+    if (lean_head && head_done && init_fused_early) {
+        dimg_ok[0] = dimg_ok[1] = dimg_ok[2] = c == 32 && n >= kDenseRowsKernelMin;   // (built by tgnn_forward_begin)
+    } else if (lean_head) {
         // bounds of the three Linears' weights (+ of layers 1, 2's inputs from their BatchNorm parameters), then the three operand
         // images in ONE launch
-        const float *bw[3], *bg[3], *bb[3];
-        int64_t bwn[3];
-        int bf[3];
-        unsigned *bwm[3], *bam[3];
-        bw[0] = P.f(P.fin(0)); bwn[0] = cat_w_floats; bg[0] = nullptr; bb[0] = nullptr; bf[0] = 0; bwm[0] = dense_max; bam[0] = nullptr;
-        for (int l = 1; l <= 2; ++l) {
-            const BnPtrs bp = P.bn(P.fin(l - 1) + 2);
-            bw[l] = P.f(P.fin(l));
-            bwn[l] = (int64_t)fin_dims[l] * fin_dims[l + 1];
-            bg[l] = bp.gamma; bb[l] = bp.beta; bf[l] = fin_dims[l];
-            bwm[l] = w.bounds + 2 * D + 2 + 2 * (l - 1);
-            bam[l] = w.bounds + 2 * D + 3 + 2 * (l - 1);
-        }
-        launch_dense_bounds(3, bw, bwn, bg, bb, bf, bwm, bam, n_total, sw);
-        if (c == 32 && n >= kDenseRowsKernelMin) {
-            const float *iw[3];
-            int iin[3], iout[3];
-            const unsigned *iwm[3];
-            void *iimg[3];
-            for (int l = 0; l < 3; ++l) {
-                iw[l] = P.f(P.fin(l)); iin[l] = fin_dims[l]; iout[l] = fin_dims[l + 1];
-                iwm[l] = l == 0 ? dense_max : w.bounds + 2 * D + 2 + 2 * (l - 1);
-                iimg[l] = w.dimg[l];
-            }
-            if (dense_f16_images_build(3, iw, iin, iout, iwm, iimg, sw) == TGNN_OK) dimg_ok[0] = dimg_ok[1] = dimg_ok[2] = true;
-        }
+        bool ok = false;
+        TGNN_TRY(forward_head_bounds_images(dims, P, w, n, n_total, sw, &ok));
+        dimg_ok[0] = dimg_ok[1] = dimg_ok[2] = ok;
     } else if (f16 && !tail_k) {
         // the final MLP's layers 1 and 2 (256 -> 128 -> 64): weights' bounds and, from the BatchNorm parameters alone, their inputs'
         const float *bw[2], *bg[2], *bb[2];
@@ -538,31 +593,29 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     // [r6] three launches that recompute from x instead of five that store (init_mlp.hip); the launch-per-op form stays for what
     // keeps the activations (training), all-reduces the statistics (shards) or normalises with running statistics
     const bool init_fused = !mid_init && c == 32 && fx <= 8 && !sh && !keep && !use_running_stats && (g_lean_head.load(std::memory_order_relaxed) & 2);
-    if (init_fused) {
-        const int ib = init_mlp_fused_blocks(n);
-        BnJob j0 = BnJob{w.partf, ib, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, w.stat_i[0]};
-        BnJob j1 = BnJob{w.partf + (size_t)TGNN_BN_MAX_PARTIALS * 64, ib, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, w.stat_i[1]};
-        const BnPtrs b0 = P.bn(P.init(0) + 2), b1 = P.bn(P.init(1) + 2);
-        j0.gamma = b0.gamma; j0.beta = b0.beta; j1.gamma = b1.gamma; j1.beta = b1.beta;
-        if (update_running) {
-            j0.running_mean = b0.rm; j0.running_var = b0.rv; j0.num_batches_tracked = b0.nbt;
-            j1.running_mean = b1.rm; j1.running_var = b1.rv; j1.num_batches_tracked = b1.nbt;
-        }
+    // (a layout that turns out not to take the fp16-pair path -- more than 16 edge types, an in-degree above 2 048 -- runs its head
+    //  again, the launch-per-op way; the init MLP's running statistics were updated by tgnn_forward_begin already)
+    BnPtrs ibn0 = P.bn(P.init(0) + 2), ibn1 = P.bn(P.init(1) + 2);
+    if (head_done && !head_used) {
+        ibn0.rm = ibn0.rv = ibn1.rm = ibn1.rv = nullptr;
+        ibn0.nbt = ibn1.nbt = nullptr;
+    }
+    if (head_used) {
+    } else if (init_fused) {
         prof.begin(1);
-        TGNN_TRY(launch_init_mlp_fused(x, fx, fx, P.f(P.init(0)), P.f(P.init(0) + 1), P.f(P.init(1)), P.f(P.init(1) + 1), j0, j1, n, eps,
-                                       momentum, w.mid, slot_max, s));
+        TGNN_TRY(forward_head_init(dims, P, x, w, n, update_running, slot_max, s));
         prof.end();
     } else if (!mid_init) {
         prof.begin(1);
         TGNN_TRY(tgnn_dense_act_fwd(x, fx, 32, nullptr, P.f(P.init(0)), P.f(P.init(0) + 1), n, fx, c, TGNN_ACT_LEAKY_RELU,
                                     w.t0, c, w.partf, &np1, s));
         prof.end();
-        TGNN_TRY(finalize1(w.partf, np1, c, P.bn(P.init(0) + 2), w.stat_i[0]));
+        TGNN_TRY(finalize1(w.partf, np1, c, ibn0, w.stat_i[0]));
         prof.begin(1);
         TGNN_TRY(tgnn_dense_act_fwd(w.t0, c, 32, w.stat_i[0], P.f(P.init(1)), P.f(P.init(1) + 1), n, c, c,
                                     TGNN_ACT_LEAKY_RELU, w.a1, c, w.partf, &np1, s));
         prof.end();
-        TGNN_TRY(finalize1(w.partf, np1, c, P.bn(P.init(1) + 2), w.stat_i[1]));
+        TGNN_TRY(finalize1(w.partf, np1, c, ibn1, w.stat_i[1]));
         prof.begin(1);
         launch_bn_apply(w.a1, c, w.stat_i[1], n, c, w.mid, c, slot_max, s);   // middle[0] = brch_1 = brch_2 (:55,58)
         prof.end();
@@ -848,6 +901,60 @@ extern "C" int tgnn_forward(const tgnn_model_dims *dims, const void *const *para
     Prof prof;
     return forward_impl(dims, params_host, x, adj_edge_attr, graph, update_running, use_running_stats, probs, ws,
                         ws_bytes, stream, stream2, prof);
+}
+
+extern "C" int tgnn_forward_begin(const tgnn_model_dims *dims, const void *const *params_host, const float *x, int64_t n_nodes,
+                                  int32_t update_running, void *ws, size_t ws_bytes, tgnn_stream_t stream, tgnn_stream_t stream2) {
+    DeviceGuard guard__(stream);
+    TGNN_CHECK_ARG(dims_ok(dims) && params_host && x && n_nodes >= 2, "arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream), s2 = static_cast<hipStream_t>(stream2);
+    const int c = dims->network_width, D = dims->network_depth, fx = dims->node_features_dim;
+    // what forward_impl's lean head + fused init MLP need, as far as it can be known without the graph; the rest (fp16-pair
+    // operands: edge groups / columns, largest in-degree) is checked by tgnn_forward_resume
+    if (!s2 || s2 == s || c != 32 || fx > 8 || D > kMaxDepth || ((int64_t)c * (D + 1) * kFinalDims[0]) % 4 != 0 || !g_split_f16 ||
+        (g_lean_head.load(std::memory_order_relaxed) & 3) != 3 || n_nodes <= tgnn_get_mid_layout_limit() || n_nodes <= tgnn_get_small_layout_limit())
+        return TGNN_ERR_UNSUPPORTED;
+    const int np = tgnn_param_count(dims);
+    for (int i = 0; i < np; ++i)
+        if (!params_host[i]) {
+            set_error("tgnn_forward_begin: params_host[%d] is null", i);
+            return TGNN_ERR_INVALID_ARG;
+        }
+    Workspace w = carve(*dims, n_nodes, n_nodes, 0, ws, ws_bytes);
+    if (!ws || w.bytes > ws_bytes) {
+        set_error("tgnn_forward_begin: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
+        return TGNN_ERR_WORKSPACE;
+    }
+    int dev = 0;
+    TGNN_CHECK_HIP(hipGetDevice(&dev));
+    TGNN_CHECK_ARG(dev >= 0 && dev < 64, "device index");
+    HeadEvent &he = g_head[dev];
+    static thread_local hipEvent_t fork_ev[64] = {};
+    if (!he.ev) TGNN_CHECK_HIP(hipEventCreateWithFlags(&he.ev, hipEventDisableTiming));
+    if (!fork_ev[dev]) TGNN_CHECK_HIP(hipEventCreateWithFlags(&fork_ev[dev], hipEventDisableTiming));
+    TGNN_CHECK_HIP(hipEventRecord(fork_ev[dev], s));           // x and the parameters are the caller's, ordered on `stream`
+    TGNN_CHECK_HIP(hipStreamWaitEvent(s2, fork_ev[dev], 0));
+    const Params P{params_host, D};
+    const float *roots[kMaxDepth];
+    for (int i = 0; i < D; ++i) roots[i] = P.f(P.layer(i) + 6);
+    launch_forward_scales(w.bounds, 2 * D + 8, roots, D, w.bounds + D + 1, nullptr, 0, nullptr, s2);
+    TGNN_TRY(forward_head_init(dims, P, x, w, n_nodes, update_running, w.bounds, s2));
+    bool ok = false;
+    TGNN_TRY(forward_head_bounds_images(dims, P, w, n_nodes, n_nodes, s2, &ok));
+    TGNN_CHECK_HIP(hipEventRecord(he.ev, s2));
+    he.ws = ws;
+    he.n = n_nodes;
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}
+
+extern "C" int tgnn_forward_resume(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
+                                   const float *adj_edge_attr, const tgnn_graph *graph, int32_t update_running, float *probs, void *ws,
+                                   size_t ws_bytes, tgnn_stream_t stream, tgnn_stream_t stream2) {
+    DeviceGuard guard__(stream);
+    Prof prof;
+    return forward_impl(dims, params_host, x, adj_edge_attr, graph, update_running, 0, probs, ws, ws_bytes, stream, stream2, prof,
+                        nullptr, nullptr, true);
 }
 
 extern "C" int tgnn_forward_many(const tgnn_model_dims *dims, const void *const *params_host, int32_t n_layouts,

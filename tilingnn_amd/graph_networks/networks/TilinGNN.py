@@ -239,15 +239,49 @@ class TilinGNN(Tracked, nn.Module):
             raise ValueError("activation_dtype must be torch.float32 or torch.bfloat16")
         xf = ops._f32c(x, "x")
         ea = ops._f32c(adj_e_features, "adj_e_features")
+        dims = self._dims()
+        begun = False
         if self.cache_graph:
             graph = _graph_cache.get_full(n, adj_e_index, adj_e_features, col_e_idx)
         else:
-            graph = ops.prepare_graph(n, adj_e_index, adj_e_features, col_e_idx)
-        dims = self._dims()
-        ws_bytes = lib.tgnn_forward_workspace_bytes(C.byref(dims), n, graph.n_types)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            # a NEW layout of the general schedule: what the forward does in front of its first layer without the graph (bounds, init
+            # MLP, the final MLP's operand images) is queued on the side stream BEFORE the preparation and runs beside it
+            # (tgnn_forward_begin / tgnn_forward_resume; the workspace's layout does not depend on the type count up to 16)
+            if bn_train and ops.runs_general_schedule(n) and n > 4096:
+                ws_bytes = lib.tgnn_forward_workspace_bytes(C.byref(dims), n, 0)
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                rc = lib.tgnn_forward_begin(C.byref(dims), table, ptr(xf), n, int(update_running), ptr(ws), ws_bytes,
+                                            _lib.current_stream(dev), _lib.side_stream(dev))
+                begun = rc == 0
+                if rc not in (0, _lib.ERR_UNSUPPORTED):
+                    check(rc)
+            try:
+                graph = ops.prepare_graph(n, adj_e_index, adj_e_features, col_e_idx)
+            except Exception:
+                side = _lib.side_stream_torch(dev) if begun else None
+                if side is not None:                                          # (begin's launches write the workspace freed below)
+                    torch.cuda.current_stream(dev).wait_stream(side)
+                raise
+        if begun and graph.n_types > 16:
+            ws_need = lib.tgnn_forward_workspace_bytes(C.byref(dims), n, graph.n_types)       # (a larger edge-weight table: rare)
+            if ws_need > ws_bytes:
+                side = _lib.side_stream_torch(dev)
+                if side is not None:
+                    torch.cuda.current_stream(dev).wait_stream(side)          # (begin's launches still write the smaller workspace)
+                begun = False
+        if not begun:
+            ws_bytes = lib.tgnn_forward_workspace_bytes(C.byref(dims), n, graph.n_types)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         probs = torch.empty(n, self.output_dim, dtype=torch.float32, device=dev)
         g = graph.c_struct(defer_late_check=True)
+        if begun:
+            check(lib.tgnn_forward_resume(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), int(update_running), ptr(probs), ptr(ws),
+                                          ws_bytes, _lib.current_stream(dev), _lib.side_stream(dev)))
+            if self._param_table_stale():                                     # (the begin / resume pair read a stale table: repeat, plain)
+                table, dev = self._param_table()
+                check(lib.tgnn_forward(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), 0, 0, ptr(probs), ptr(ws), ws_bytes,
+                                       _lib.current_stream(dev), _lib.side_stream(dev)))
+            return probs, adj_e_features
         check(lib.tgnn_forward(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), int(bn_train and update_running), int(not bn_train),
                                ptr(probs), ptr(ws), ws_bytes, _lib.current_stream(dev), _lib.side_stream(dev)))
         if graph.late_words_failed():                                         # (a just-prepared mid-size layout whose batches did not fit)
