@@ -564,11 +564,12 @@ int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edges, const fl
                     void *ws, size_t ws_bytes, int32_t *result, int32_t *result_host, tgnn_stream_t stream);
 /* result_host (pinned host memory, 32 words, or NULL): the library copies `result` there as soon as the words a caller reads --
  * [0] type count, [1] [2] index errors, [3] collision CSR slots, [4] largest in-degree, [6] fall-back -- are final, i.e. BEFORE the
- * launches that build the NNConv structure; tgnn_graph_prep_wait() (same host thread, same device) waits for that copy alone, so
+ * launches that build the NNConv structure; tgnn_graph_prep_wait(stream) (same host thread, the stream tgnn_graph_prep was given:
+ * the event belongs to that stream's device, whatever the thread's current device is) waits for that copy alone, so
  * the caller can queue its forward while the structure is still being built.  Words [5], [8], [9], [10] are not final in that
  * copy: [5] = [10] = ([0] <= tgnn_nnconv_cols_max_types() && ![6]) for the structures asked for; a caller that needs [8] / [9]
  * (the mid-size batches) reads `result` after the stream instead. */
-int tgnn_graph_prep_wait(void);
+int tgnn_graph_prep_wait(tgnn_stream_t stream);
 #ifdef TGNN_DEBUG
 /* ---- test / experiment hooks: only in libtgnn_debug.so (make -C tilingnn_amd/csrc debug: the same sources with -DTGNN_DEBUG); the
  *      production library does not export them ---- */

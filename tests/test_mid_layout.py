@@ -437,9 +437,20 @@ def test_batches_that_do_not_fit_are_seen_behind_the_launches(dev):
     g = ops.prepare_graph(n, adj, attr, col)
     assert "_late_words" in g.__dict__ and g.mid is not None      # (optimistic until the words are looked at)
     assert g.late_words_failed() and g.mid is None and not g.late_words_failed()
+    # [r6] with the running-statistics update on (forward()'s default: the buffers are state) the verdict is waited for BEFORE the
+    # launches -- an optimistic launch that has to be repeated would have applied a momentum update from garbage: ONE launch, on
+    # the general schedule, one update
     before = _lib.forward_path_counts()
-    probs = net(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)[0].clone()
+    probs_upd = net(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)[0].clone()
     after = _lib.forward_path_counts()
+    assert after[2] - before[2] == 0 and after[0] - before[0] == 1
+    assert int(net.init_node_feature_trans.mlp[0].batch_norm.num_batches_tracked) == 1
+    assert int(net.brch_2_coll_conv_layers[1].batch_norm.num_batches_tracked) == 1
+    # without the update (forward_many's mode) the launch is optimistic and looked at behind
+    before = _lib.forward_path_counts()
+    probs = net._forward_one(x, adj, attr, col, update_running=False)[0].clone()
+    after = _lib.forward_path_counts()
+    assert float((probs - probs_upd).abs().max()) < 1e-6
     with_limits = (_lib.lib.tgnn_get_small_layout_limit(), _lib.lib.tgnn_get_mid_layout_limit())
     _lib.lib.tgnn_set_mid_layout_limit(0)
     try:

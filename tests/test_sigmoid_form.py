@@ -32,14 +32,15 @@ def fma32(a, b, c):
 
 def sigmoid_form(v, k, clamp):
     one = np.float32(1.0)
-    nv = -np.maximum(v, clamp)
+    nv = -np.minimum(np.maximum(v, clamp), -clamp)          # (both sides: e stays finite and non-zero)
     th = nv * k["kL2eH"]
     tl = fma32(nv, np.full_like(nv, k["kL2eH"]), -th) + nv * k["kL2eL"]
     eh = np.exp2(th.astype(np.float64)).astype(np.float32)
     e = fma32(eh, tl * k["kLn2"], eh)
     d = one + e
     r = (1.0 / d.astype(np.float64)).astype(np.float32)
-    return fma32(fma32(-d, r, np.full_like(d, one)), r, r)
+    r = fma32(fma32(-d, r, np.full_like(d, one)), r, r)
+    return np.where(np.isnan(v), v, r)                      # (the clamps drop a NaN: put back, as torch.sigmoid propagates it)
 
 
 def test_constants_are_log2e_in_two_parts():
@@ -85,3 +86,19 @@ def test_monotone_and_symmetric_to_rounding():
     s = sigmoid_form(v, k, clamp)
     assert (np.diff(s.astype(np.float64)) >= -np.spacing(s[1:])).all()
     assert np.abs((s + s[::-1]).astype(np.float64) - 1.0).max() < 2e-7
+
+
+def test_infinities_and_nan_behave_like_torch_sigmoid():
+    """ADVICE r5: sigmoid(+inf) = 1, sigmoid(-inf) = 0, sigmoid(NaN) = NaN (the one-sided clamp gave NaN at +inf and 1.6e-38 for NaN);
+    the header's form carries the two-sided clamp and the NaN pass-through this restatement mirrors."""
+    k, clamp = header_constants()
+    src = open(HEADER).read()
+    body = src[src.index("float sigmoid_out_f32(float v)"):]
+    body = body[:body.index("\n}\n")]
+    assert re.search(r"fminf\(fmaxf\(v, -[0-9.]+f\), [0-9.]+f\)", body), "two-sided clamp"
+    assert "v != v ? v : r" in body, "NaN pass-through"
+    with np.errstate(invalid="ignore", over="ignore"):
+        got = sigmoid_form(np.array([np.inf, -np.inf, np.nan, 3.0e38, -3.0e38], dtype=np.float32), k, clamp)
+    assert got[0] == 1.0 and got[3] == 1.0
+    assert 0.0 <= got[1] < 1e-37 and 0.0 <= got[4] < 1e-37
+    assert np.isnan(got[2])

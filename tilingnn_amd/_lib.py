@@ -141,7 +141,7 @@ def _load() -> C.CDLL:
         "tgnn_graph_prep_small": (C.c_int, [p, i64, p, i32, p, i64, i64] + [p] * 15 + [p]),
         "tgnn_graph_prep_workspace_bytes": (sz, [i64, i64, i64, i32]),
         "tgnn_graph_prep": (C.c_int, [p, i64, p, i32, p, i64, i64, i64] + [p] * 17 + [sz, p, p, p]),
-        "tgnn_graph_prep_wait": (C.c_int, []),
+        "tgnn_graph_prep_wait": (C.c_int, [p]),
         "tgnn_set_nnconv_eg": (i32, [i32]),
         "tgnn_set_dense_rows_mode": (i32, [i32]),
         "tgnn_set_lean_head": (i32, [i32]),

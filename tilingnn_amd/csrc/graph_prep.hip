@@ -1330,7 +1330,8 @@ static hipError_t prep_words_event(hipEvent_t *ev) {
     return hipSuccess;
 }
 
-extern "C" int tgnn_graph_prep_wait(void) {
+extern "C" int tgnn_graph_prep_wait(tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);                             // (the event slot of the device tgnn_graph_prep recorded on: the stream's)
     hipEvent_t ev = nullptr;
     TGNN_CHECK_HIP(prep_words_event(&ev));
     TGNN_CHECK_HIP(hipEventSynchronize(ev));

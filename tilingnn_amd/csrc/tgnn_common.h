@@ -127,7 +127,7 @@ __device__ __forceinline__ float sigmoidf_(float v) { return __builtin_amdgcn_rc
 // forward_persist.h, forward_small.hip): the schedules are compared bit for bit.
 __device__ __forceinline__ float sigmoid_out_f32(float v) {
     constexpr float kL2eH = 1.44269502162933349609375f, kL2eL = 1.925963033500011e-8f, kLn2 = 0.693147182464599609375f;
-    const float nv = -fmaxf(v, -87.0f);                       // (e stays finite: the result there is < 2e-38 either way)
+    const float nv = -fminf(fmaxf(v, -87.0f), 87.0f);         // (e stays finite and non-zero: beyond +-87 the result is 0 / 1 to fp32 either way)
     const float th = nv * kL2eH;
     const float tl = fmaf(nv, kL2eH, -th) + nv * kL2eL;
     const float eh = __builtin_amdgcn_exp2f(th);
@@ -135,7 +135,7 @@ __device__ __forceinline__ float sigmoid_out_f32(float v) {
     const float d = 1.0f + e;
     float r = __builtin_amdgcn_rcpf(d);
     r = fmaf(fmaf(-d, r, 1.0f), r, r);
-    return r;
+    return v != v ? v : r;                                    // (fmaxf / fminf drop a NaN: a diverged branch must stay visible, as in torch)
 }
 __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == TGNN_ACT_LEAKY_RELU) return v >= 0.f ? v : v * kLeakySlope;

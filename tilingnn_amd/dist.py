@@ -577,6 +577,8 @@ class FusedShardForward:
         C, _lib, ops, sh, net = self._C, self._lib, self._ops, self.shard, self.net
         inp = self.inputs
         graph = ops.prepare_graph(sh.n_own, inp["adj"], inp["attr"], inp["col"], n_src_nodes=sh.n_rows)
+        if not self.fused or _lib.lib.tgnn_set_split_precision(-1) == 0:
+            graph.ensure_columns()         # (the all-reduce + all-to-all scheme stays on bf16 x 3: the column kernel, not the CSR one)
         dims = net._dims()
         table, _ = net._param_table()
         ws_bytes = _lib.lib.tgnn_forward_sharded_workspace_bytes(C.byref(dims), sh.n_own, sh.n_rows, graph.n_types)

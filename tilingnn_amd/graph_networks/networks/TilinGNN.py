@@ -272,13 +272,20 @@ class TilinGNN(Tracked, nn.Module):
         if not begun:
             ws_bytes = lib.tgnn_forward_workspace_bytes(C.byref(dims), n, graph.n_types)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        if graph.cols is None and graph.groups is not None and (not bn_train or lib.tgnn_set_split_precision(-1) == 0 or
+                                                                 self.network_depth > 64):
+            graph.ensure_columns()                                            # (no fp16-pair path: the column kernel, not the CSR one)
         probs = torch.empty(n, self.output_dim, dtype=torch.float32, device=dev)
-        g = graph.c_struct(defer_late_check=True)
+        # One running-statistics update per forward() (the buffers are state: ml_solver.py:129-131 keeps the network in train mode):
+        # an optimistic launch on a just-prepared mid-size layout's unverified batches would, when it has to be repeated, have
+        # applied a momentum update from garbage already -- with the update on, the preparation's last words are waited for first
+        writes_stats = bool(bn_train and update_running)
+        g = graph.c_struct(defer_late_check=not writes_stats)
         if begun:
             check(lib.tgnn_forward_resume(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), int(update_running), ptr(probs), ptr(ws),
                                           ws_bytes, _lib.current_stream(dev), _lib.side_stream(dev)))
-            if self._param_table_stale():                                     # (the begin / resume pair read a stale table: repeat, plain)
-                table, dev = self._param_table()
+            if self._param_table_stale():                                     # (the begin / resume pair read a stale table: repeat, plain;
+                table, dev = self._param_table()                              #  the running statistics were updated by the first pass)
                 check(lib.tgnn_forward(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), 0, 0, ptr(probs), ptr(ws), ws_bytes,
                                        _lib.current_stream(dev), _lib.side_stream(dev)))
             return probs, adj_e_features
@@ -289,7 +296,9 @@ class TilinGNN(Tracked, nn.Module):
             check(lib.tgnn_forward(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), int(bn_train and update_running),
                                    int(not bn_train), ptr(probs), ptr(ws), ws_bytes, _lib.current_stream(dev), _lib.side_stream(dev)))
         if self._param_table_stale():                                         # (see the top: checked behind the launches)
+            # the repeat leaves the running statistics alone: the first pass -- on the swapped-out storages, which the cache kept
+            # alive -- has applied this forward's ONE momentum update to the (verified) running buffers already
             table, dev = self._param_table()
-            check(lib.tgnn_forward(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), int(bn_train and update_running),
+            check(lib.tgnn_forward(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), 0,
                                    int(not bn_train), ptr(probs), ptr(ws), ws_bytes, _lib.current_stream(dev), _lib.side_stream(dev)))
         return probs, adj_e_features                                          # TilinGNN.py:78
