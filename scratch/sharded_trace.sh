@@ -35,7 +35,7 @@ for i in range(1, len(rows)):
 sel = rows[cut:]
 t0 = int(sel[0]['Start_Timestamp'])
 print("== two_streams", sys.argv[2], "kernels", len(sel), "total us", (max(int(r['End_Timestamp']) for r in sel) - t0) / 1e3)
-idx = [i for i, r in enumerate(sel) if 'nnconv32_cols' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(sel) if 'nnconv32_' in r['Kernel_Name']]
 a, b = idx[8], idx[10]
 prev_end = int(sel[a]['Start_Timestamp'])
 for r in sel[a:b]:

@@ -631,6 +631,107 @@ __global__ __launch_bounds__(1024) void shard_unpack1_kernel(const float *__rest
     }
 }
 
+// [r6] unpack1 + merge of the adjacency branch in ONE launch (the sharded step's chain NNConv -> pack -> all-to-all -> unpack ->
+// merge is serial on the main stream; every launch on it costs its duration plus a 4 - 12 us gap: profiles/r06_sharded_trace.txt).
+// Every block derives the first BatchNorm's record from the shards' sums itself (own sums + the peers' sums rows of the message,
+// added in rank order exactly as shard_unpack1_kernel's block 0 does: the same bits; block 0 writes the record and the running
+// statistics) and reads the HALO rows of a1 straight out of the message instead of from a scattered copy: halo row h of peer p is
+// message row h + 4 p (a peer's rows are followed by its 4 sums rows), p found from the sums rows' positions.
+__global__ __launch_bounds__(256) void shard_unpack1_merge_kernel(const float *__restrict__ in, const int *__restrict__ idx,
+                                                                  int64_t n_in, int64_t n_own, const float *__restrict__ a1, BnJob job,
+                                                                  int world, int rank, int64_t n_total, float eps, float momentum,
+                                                                  const float *__restrict__ a2, const float *__restrict__ st2,
+                                                                  const float *__restrict__ resid, int64_t n_rows,
+                                                                  float *__restrict__ out, unsigned *__restrict__ absmax_out) {
+    constexpr int c = 32;
+    __shared__ int pos[4 * 64];
+    __shared__ int hend[64];                                  // halo rows of peers 0 .. p end here
+    __shared__ double tot[64];
+    __shared__ __attribute__((aligned(16))) float st1[4 * c];
+    const int tid = threadIdx.x;
+    for (int64_t r = tid; r < n_in; r += 256) {
+        const int id = idx[r];
+        if (id < 0 && -1 - id < 4 * 64) pos[-1 - id] = (int)r;
+    }
+    float pre_gamma = 1.f, pre_beta = 0.f, pre_rm = 0.f, pre_rv = 1.f;
+    if (tid < c) {
+        pre_gamma = job.gamma[tid];
+        pre_beta = job.beta[tid];
+        if (blockIdx.x == 0 && job.running_mean) {
+            pre_rm = job.running_mean[tid];
+            pre_rv = job.running_var[tid];
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int k = tid >> 4, jj = tid & 15;                // sums row k of a peer holds doubles 16 k .. 16 k + 15
+        double t = 0.0;
+        for (int p = 0; p < world; ++p)
+            t += p == rank ? job.sums[tid] : reinterpret_cast<const double *>(in + (int64_t)pos[4 * p + k] * 32)[jj];
+        tot[tid] = t;
+        if (tid < world) hend[tid] = pos[4 * tid] - 4 * tid;  // (the first sums row of peer p sits behind its halo rows and 4 p sums rows)
+    }
+    __syncthreads();
+    if (tid < c) {                                            // bn_record_from_sums' arithmetic
+        const double inv_n = 1.0 / (double)n_total;
+        const double mean = tot[tid] * inv_n;
+        double var = tot[c + tid] * inv_n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float mh = (float)mean;
+        st1[tid] = mh;
+        st1[c + tid] = (float)(mean - (double)mh);
+        st1[2 * c + tid] = (float)((double)pre_gamma / sqrt(var + (double)eps));
+        st1[3 * c + tid] = pre_beta;
+        if (blockIdx.x == 0) {
+            job.stat[tid] = st1[tid]; job.stat[c + tid] = st1[c + tid];
+            job.stat[2 * c + tid] = st1[2 * c + tid]; job.stat[3 * c + tid] = st1[3 * c + tid];
+            if (job.running_mean) {
+                const double unbiased = n_total > 1 ? var * ((double)n_total / (double)(n_total - 1)) : var;
+                job.running_mean[tid] = (float)((1.0 - (double)momentum) * (double)pre_rm + (double)momentum * mean);
+                job.running_var[tid] = (float)((1.0 - (double)momentum) * (double)pre_rv + (double)momentum * unbiased);
+            }
+            if (tid == 0 && job.num_batches_tracked) *job.num_batches_tracked += 1;
+        }
+    }
+    __syncthreads();
+    float am = 0.f;
+    const int64_t n4 = n_rows * c / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + tid; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)((i * 4) % c);
+        const int64_t row = i >> 3;
+        float4 x1;
+        if (row < n_own) {
+            x1 = reinterpret_cast<const float4 *>(a1)[i];
+        } else {
+            const int h = (int)(row - n_own);
+            int p = 0;
+            while (p + 1 < world && h >= hend[p]) ++p;
+            x1 = reinterpret_cast<const float4 *>(in)[((int64_t)h + 4 * p) * 8 + (i & 7)];
+        }
+        const float4 x2 = reinterpret_cast<const float4 *>(a2)[i];
+        const float4 m1h = *reinterpret_cast<const float4 *>(st1 + col), m1l = *reinterpret_cast<const float4 *>(st1 + c + col);
+        const float4 g1 = *reinterpret_cast<const float4 *>(st1 + 2 * c + col), b1 = *reinterpret_cast<const float4 *>(st1 + 3 * c + col);
+        const float4 m2h = *reinterpret_cast<const float4 *>(st2 + col), m2l = *reinterpret_cast<const float4 *>(st2 + c + col);
+        const float4 g2 = *reinterpret_cast<const float4 *>(st2 + 2 * c + col), b2 = *reinterpret_cast<const float4 *>(st2 + 3 * c + col);
+        float4 y2, o;
+        y2.x = bn_apply1(x2.x, m2h.x, m2l.x, g2.x, b2.x);
+        y2.y = bn_apply1(x2.y, m2h.y, m2l.y, g2.y, b2.y);
+        y2.z = bn_apply1(x2.z, m2h.z, m2l.z, g2.z, b2.z);
+        y2.w = bn_apply1(x2.w, m2h.w, m2l.w, g2.w, b2.w);
+        o.x = bn_apply1(x1.x, m1h.x, m1l.x, g1.x, b1.x) * y2.x;
+        o.y = bn_apply1(x1.y, m1h.y, m1l.y, g1.y, b1.y) * y2.y;
+        o.z = bn_apply1(x1.z, m1h.z, m1l.z, g1.z, b1.z) * y2.z;
+        o.w = bn_apply1(x1.w, m1h.w, m1l.w, g1.w, b1.w) * y2.w;
+        if (resid) {
+            const float4 r = reinterpret_cast<const float4 *>(resid)[i];
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        reinterpret_cast<float4 *>(out)[i] = o;
+        am = absmax4(am, o);
+    }
+    absmax_flush(am, absmax_out);
+}
+
 static inline unsigned shard_copy_blocks(int64_t n_rows) {
     int64_t b = (n_rows * 64 + 1023) / 1024;
     if (b < 1) b = 1;
@@ -655,6 +756,14 @@ void launch_shard_unpack1(const float *in, const int *idx, int64_t n_rows, int64
                           int rank, int64_t n_total, float eps, float momentum, hipStream_t s) {
     shard_unpack1_kernel<<<1 + shard_copy_blocks((n_rows + 1) / 2), 1024, 0, s>>>(in, idx, n_rows, n_own, a, job, world, rank,
                                                                                  n_total, eps, momentum);
+}
+
+void launch_shard_unpack1_merge(const float *in, const int *idx, int64_t n_in, int64_t n_own, const float *a1, const BnJob &job,
+                                int world, int rank, int64_t n_total, float eps, float momentum, const float *a2, const float *stat2,
+                                const float *resid, int64_t n_rows, float *out, unsigned *absmax_out, hipStream_t s) {
+    const int64_t n4 = n_rows * 32 / 4;
+    shard_unpack1_merge_kernel<<<ew_grid(n4, 512), 256, 0, s>>>(in, idx, n_in, n_own, a1, job, world, rank, n_total, eps, momentum, a2,
+                                                               stat2, resid, n_rows, out, absmax_out);
 }
 
 void launch_shard_pack(const float *a1, const float *a2, const int *idx, int64_t n_rows, const double *sums, float *out,

@@ -760,15 +760,12 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
             const int64_t n_out = sh->n_send + 4 * (int64_t)sh->world, n_in = n_halo + 4 * (int64_t)sh->world;
             launch_shard_pack1(w.a1, sh->send_idx_fused, n_out, j1, sh->send_buf, s);
             TGNN_TRY(alltoall(sh->send_buf, sh->recv_buf, c, 4, s));
-            launch_shard_unpack1(sh->recv_buf, sh->recv_idx_fused, n_in, n, w.a1, j1, sh->world, sh->rank, n_total, eps, momentum, s);
-            TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[1 + i], 0));
             const float *resid_f = i >= 2 ? w.mid + (size_t)(i - 2) * nr * c : nullptr;
-            if (f16)
-                launch_merge(w.a1, w.stat1, w.a2[i & 1], w.stat2[i & 1], resid_f, nr, c, w.mid + (size_t)(i + 1) * nr * c, nullptr,
-                             slot_max + i + 1, s);
-            else
-                TGNN_TRY(tgnn_merge_fwd(w.a1, w.stat1, w.a2[i & 1], w.stat2[i & 1], resid_f, nr, c,
-                                        w.mid + (size_t)(i + 1) * nr * c, nullptr, s));
+            TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[1 + i], 0));
+            // [r6] unpack + merge as one launch: the record from the shards' sums in every block, the halo rows of a1 out of the message
+            launch_shard_unpack1_merge(sh->recv_buf, sh->recv_idx_fused, n_in, n, w.a1, j1, sh->world, sh->rank, n_total, eps, momentum,
+                                       w.a2[i & 1], w.stat2[i & 1], resid_f, nr, w.mid + (size_t)(i + 1) * nr * c,
+                                       f16 ? slot_max + i + 1 : nullptr, s);
             TGNN_CHECK_HIP(hipEventRecord(ev[1 + kMaxDepth + i], s));       // (a2[i & 1] / stat2[i & 1] are free for GIN_{i+2})
             continue;
         }

@@ -169,7 +169,15 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_eg_kernel(
         asm volatile("" : "+v"(sel0) :: "memory");            // (keeps the reads above the split)
 #endif
         unsigned xh0, xh1, xh2, xh3, xl0, xl1, xl2, xl3;
+#ifdef TGNN_ABL_EGNOSPLIT
+        // (timing ablation, VERDICT r5 item 7: the gathered words used as if their producer had split them -- garbage values, the
+        //  same instruction stream minus the row split's ~20 instructions per group)
+        xh0 = __float_as_uint(x[0].x); xl0 = __float_as_uint(x[0].y); xh1 = __float_as_uint(x[0].z); xl1 = __float_as_uint(x[0].w);
+        xh2 = __float_as_uint(x[1].x); xl2 = __float_as_uint(x[1].y); xh3 = __float_as_uint(x[1].z); xl3 = __float_as_uint(x[1].w);
+        if (false) {
+#else
         if (unit) {                                          // wave-uniform
+#endif
             split_pair_f16(x[0].x, x[0].y, xh0, xl0);
             split_pair_f16(x[0].z, x[0].w, xh1, xl1);
             split_pair_f16(x[1].x, x[1].y, xh2, xl2);
@@ -188,10 +196,16 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_eg_kernel(
         m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, h0, m0, 0, 0, 0);           // hi . hi
         m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, h1, m1, 0, 0, 0);
         unsigned a00, a01, b00, b01, a10, a11, b10, b11;     // the messages as fp16 pairs (below 2^15 by the scales)
+#ifdef TGNN_ABL_EGNOMSGSPLIT
+        // (timing ablation: the message words taken as the pair halves -- garbage, minus the message split's 16 instructions per group)
+        a00 = __float_as_uint(m0[0]); b00 = __float_as_uint(m0[1]); a01 = __float_as_uint(m0[2]); b01 = __float_as_uint(m0[3]);
+        a10 = __float_as_uint(m1[0]); b10 = __float_as_uint(m1[1]); a11 = __float_as_uint(m1[2]); b11 = __float_as_uint(m1[3]);
+#else
         split_pair_f16(m0[0], m0[1], a00, b00);
         split_pair_f16(m0[2], m0[3], a01, b01);
         split_pair_f16(m1[0], m1[1], a10, b10);
         split_pair_f16(m1[2], m1[3], a11, b11);
+#endif
         Msg r;
         r.a0 = u32x2{a00, a01}; r.b0 = u32x2{b00, b01}; r.a1 = u32x2{a10, a11}; r.b1 = u32x2{b10, b11};
         r.sel = sel0;

@@ -391,6 +391,10 @@ int rccl_allreduce_f64(void *comm, double *buf, int64_t count, hipStream_t s);
 void launch_shard_pack1(const float *a, const int *idx, int64_t n_rows, const BnJob &job, float *out, hipStream_t s);
 void launch_shard_unpack1(const float *in, const int *idx, int64_t n_rows, int64_t n_own, float *a, const BnJob &job, int world,
                           int rank, int64_t n_total, float eps, float momentum, hipStream_t s);
+// [r6] unpack1 of the adjacency branch + merge over own AND halo rows in one launch (halo rows of a1 read from the message)
+void launch_shard_unpack1_merge(const float *in, const int *idx, int64_t n_in, int64_t n_own, const float *a1, const BnJob &job,
+                                int world, int rank, int64_t n_total, float eps, float momentum, const float *a2, const float *stat2,
+                                const float *resid, int64_t n_rows, float *out, unsigned *absmax_out, hipStream_t s);
 void launch_shard_unpack_finalize(const float *in, const int *idx, int64_t n_rows, int64_t n_own, float *a1, float *a2,
                                   const BnJobs &jobs, int world, int rank, int64_t n_total, float eps, float momentum,
                                   hipStream_t s);
