@@ -345,6 +345,8 @@ int tgnn_forward(const tgnn_model_dims *dims, const void *const *params_host, co
  * `stream`) instead of behind them; tgnn_forward_resume is tgnn_forward (train-mode BatchNorm) picking that work up.  Same
  * workspace (sized by tgnn_forward_workspace_bytes with any type count up to 16: the pieces begin fills do not move with it),
  * same thread, same node count; the result is bit-identical to tgnn_forward's.
+ * stream == NULL in tgnn_forward_begin: stream2 is NOT ordered behind `stream` by the call -- the caller has done that at the point
+ * where x and the parameters were ready (the host mirror queues the preparation's launches on `stream` first, then begin's).
  * tgnn_forward_begin returns TGNN_ERR_UNSUPPORTED (and queues nothing) where it does not apply -- layouts of the persistent
  * schedules, widths other than 32, more than 8 node features, no side stream -- : call tgnn_forward then.  A layout that
  * turns out not to take the fp16-pair path (more than 16 edge types, in-degree above 2 048) is handled by resume itself. */

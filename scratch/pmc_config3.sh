@@ -9,7 +9,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" \
   rm -rf /tmp/pmc_c3_$i
   timeout 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc_c3_$i -- python scratch/run_config3_only.py > /tmp/pmc_c3_$i.log 2>&1
   f=$(find /tmp/pmc_c3_$i -name "*counter_collection.csv" | head -1)
-  for k in nnconv64_bf16_cols gin64_bf16_aggregate gin64_bf16_mlp_kernelILi3 bn_apply64_bf16 merge_bf16 dense_bf16_slots; do
+  for k in nnconv64_bf16_eg nnconv64_bf16_cols gin64_bf16_aggregate gin64_bf16_mlp_kernelILi3 bn_apply64_bf16 merge_bf16 dense_bf16_slots; do
     [ -n "$f" ] && python scratch/pmc.py $k $f | sed "s/^/$k  /"
   done
 done

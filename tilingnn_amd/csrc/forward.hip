@@ -902,7 +902,7 @@ extern "C" int tgnn_forward(const tgnn_model_dims *dims, const void *const *para
 
 extern "C" int tgnn_forward_begin(const tgnn_model_dims *dims, const void *const *params_host, const float *x, int64_t n_nodes,
                                   int32_t update_running, void *ws, size_t ws_bytes, tgnn_stream_t stream, tgnn_stream_t stream2) {
-    DeviceGuard guard__(stream);
+    DeviceGuard guard__(stream ? stream : stream2);
     TGNN_CHECK_ARG(dims_ok(dims) && params_host && x && n_nodes >= 2, "arguments");
     hipStream_t s = static_cast<hipStream_t>(stream), s2 = static_cast<hipStream_t>(stream2);
     const int c = dims->network_width, D = dims->network_depth, fx = dims->node_features_dim;
@@ -929,8 +929,10 @@ extern "C" int tgnn_forward_begin(const tgnn_model_dims *dims, const void *const
     static thread_local hipEvent_t fork_ev[64] = {};
     if (!he.ev) TGNN_CHECK_HIP(hipEventCreateWithFlags(&he.ev, hipEventDisableTiming));
     if (!fork_ev[dev]) TGNN_CHECK_HIP(hipEventCreateWithFlags(&fork_ev[dev], hipEventDisableTiming));
-    TGNN_CHECK_HIP(hipEventRecord(fork_ev[dev], s));           // x and the parameters are the caller's, ordered on `stream`
-    TGNN_CHECK_HIP(hipStreamWaitEvent(s2, fork_ev[dev], 0));
+    if (s) {                                                 // (stream == NULL: the caller has ordered stream2 behind x and the parameters itself)
+        TGNN_CHECK_HIP(hipEventRecord(fork_ev[dev], s));       // x and the parameters are the caller's, ordered on `stream`
+        TGNN_CHECK_HIP(hipStreamWaitEvent(s2, fork_ev[dev], 0));
+    }
     const Params P{params_host, D};
     const float *roots[kMaxDepth];
     for (int i = 0; i < D; ++i) roots[i] = P.f(P.layer(i) + 6);

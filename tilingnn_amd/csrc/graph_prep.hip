@@ -67,6 +67,66 @@ __global__ __launch_bounds__(kScanThreads) void scan_add_offsets_kernel(int *__r
         if (base + k < n) out[base + k] += off;
 }
 
+// [r6] scan_tiles_kernel whose LAST block to finish (a ticket) also scans the tile totals: the three launches of a long scan
+// become one when the readers add their tile's offset themselves (bk_scanned below) -- out[i] stays the prefix inside its tile,
+// tile_off[i / kScanTile] the prefix of the tiles before.  At most kScanFusedTiles tiles (2 M entries); *ticket == 0 on entry
+// and on exit.
+constexpr int kScanFusedTiles = 1024;
+__global__ __launch_bounds__(kScanThreads) void scan_tiles_fused_kernel(const int *in, int *out, int *__restrict__ block_sums,
+                                                                        int *__restrict__ tile_off, int64_t n, unsigned *ticket) {
+    __shared__ int wave_tot[kScanThreads / 64];
+    __shared__ unsigned my_ticket;
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    int v[kScanItems];
+    int tsum = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        tsum += v[k];
+    }
+    const int incl = wave_inclusive_scan(tsum);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wave_tot[w];
+    int run = woff + incl - tsum;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == kScanThreads - 1) {
+        __hip_atomic_store(block_sums + blockIdx.x, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read by another block: past L1 / the XCD's L2)
+        __threadfence();
+        my_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (my_ticket != gridDim.x - 1) return;                  // (uniform)
+    __threadfence();
+    const int nb = (int)gridDim.x, per = (nb + kScanThreads - 1) / kScanThreads;     // <= 4 consecutive totals per thread
+    int t[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = threadIdx.x * per + k;
+        t[k] = (k < per && i < nb) ? __hip_atomic_load(block_sums + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        sum += t[k];
+    }
+    __syncthreads();                                         // (wave_tot is reused)
+    const int incl2 = wave_inclusive_scan(sum);
+    if (lane == 63) wave_tot[wave] = incl2;
+    __syncthreads();
+    int run2 = incl2 - sum;
+    for (int w = 0; w < wave; ++w) run2 += wave_tot[w];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = threadIdx.x * per + k;
+        if (k < per && i < nb) tile_off[i] = run2;
+        run2 += t[k];
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 static size_t scan_ws_ints(int64_t n) {
     size_t total = 0;
     while (n > kScanTile) {
@@ -74,7 +134,7 @@ static size_t scan_ws_ints(int64_t n) {
         total += align_up((size_t)nb, 64) * 2;  // sums + their scan
         n = nb;
     }
-    return total + 128;
+    return total + 128 + 64;                                 // (+ the fused scan's ticket word)
 }
 
 // short arrays (<= 32 768 entries): one block, one launch instead of three (each ~5 us of mostly launch latency)
@@ -1092,7 +1152,13 @@ struct BkArgs {
     int cap;                                         // <= cap_lds (tests lower it to reach the slow path)
     int cap_lds;                                     // records the LDS arrays of bk_rows hold: kBkCap / kBkCapHalf
     int *hist;                                       // [2][nb][nblk] + 1
+    const int *tile_off;                             // [r6] NULL: hist is the finished scan; else + tile_off[i / kScanTile] (scan_tiles_fused_kernel)
+    unsigned *scan_ticket;                           // ... and its ticket word, cleared by bk_hist_kernel
 };
+__device__ __forceinline__ int bk_scanned(const BkArgs &A, int64_t i) {
+    const int v = A.hist[i];
+    return A.tile_off ? v + A.tile_off[i / kScanTile] : v;
+}
 
 __global__ __launch_bounds__(kBkThreads) void bk_hist_kernel(BkArgs A) {
     extern __shared__ int bk_h[];
@@ -1111,7 +1177,10 @@ __global__ __launch_bounds__(kBkThreads) void bk_hist_kernel(BkArgs A) {
     }
     __syncthreads();
     for (int b = tid; b < A.nb; b += kBkThreads) A.hist[((int64_t)blockIdx.y * A.nb + b) * A.nblk + blk] = bk_h[b];
-    if (blk == 0 && blockIdx.y == 1 && tid == 0) A.hist[(int64_t)2 * A.nb * A.nblk] = 0;
+    if (blk == 0 && blockIdx.y == 1 && tid == 0) {
+        A.hist[(int64_t)2 * A.nb * A.nblk] = 0;
+        if (A.scan_ticket) *A.scan_ticket = 0u;
+    }
 }
 
 // The records of a (bucket, block) cell leave the block as ONE contiguous run: the block first sorts its edges by bucket in LDS
@@ -1125,8 +1194,8 @@ __global__ __launch_bounds__(kBkThreads) void bk_scatter_kernel(BkArgs A) {
     unsigned short *l_row = reinterpret_cast<unsigned short *>(l_src + kBkChunk), *l_bkt = l_row + kBkChunk;
     const BkSet S = A.set[blockIdx.y];
     const int tid = threadIdx.x, blk = blockIdx.x;
-    const int base = A.hist[(int64_t)blockIdx.y * A.nb * A.nblk];             // where this set's records start in the scan
-    for (int b = tid; b < A.nb; b += kBkThreads) cur[b] = A.hist[((int64_t)blockIdx.y * A.nb + b) * A.nblk + blk] - base;
+    const int base = bk_scanned(A, (int64_t)blockIdx.y * A.nb * A.nblk);      // where this set's records start in the scan
+    for (int b = tid; b < A.nb; b += kBkThreads) cur[b] = bk_scanned(A, ((int64_t)blockIdx.y * A.nb + b) * A.nblk + blk) - base;
     const int64_t i0 = S.e * blk / A.nblk, i1 = S.e * (blk + 1) / A.nblk;
     const int per = (A.nb + kBkThreads - 1) / kBkThreads;                     // buckets per thread in the scan (<= 4)
     for (int64_t c0 = i0; c0 < i1; c0 += kBkChunk) {
@@ -1200,9 +1269,9 @@ __global__ __launch_bounds__(kBkThreads) void bk_rows_kernel(BkArgs A) {
     unsigned short *row_s = reinterpret_cast<unsigned short *>(val_s + A.cap_lds);
     const BkSet S = A.set[blockIdx.y];
     const int tid = threadIdx.x, b = blockIdx.x;
-    const int base = A.hist[(int64_t)blockIdx.y * A.nb * A.nblk];
-    const int lo = A.hist[((int64_t)blockIdx.y * A.nb + b) * A.nblk] - base;
-    const int hi = A.hist[((int64_t)blockIdx.y * A.nb + b + 1) * A.nblk] - base;   // (the next set's start / the total behind the last)
+    const int base = bk_scanned(A, (int64_t)blockIdx.y * A.nb * A.nblk);
+    const int lo = bk_scanned(A, ((int64_t)blockIdx.y * A.nb + b) * A.nblk) - base;
+    const int hi = bk_scanned(A, ((int64_t)blockIdx.y * A.nb + b + 1) * A.nblk) - base;   // (the next set's start / the total behind the last)
     const int m = hi - lo;
     const bool in_lds = m <= A.cap;                                           // uniform
     if (tid < rows) cnt[tid] = 0;
@@ -1304,7 +1373,16 @@ static int prep_side_stream(hipStream_t *st, hipEvent_t *fork, hipEvent_t *join)
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return TGNN_ERR_INVALID_ARG;
     {
         std::lock_guard<std::mutex> lock(mu);
-        if (!streams[dev] && hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess) return TGNN_ERR_INVALID_ARG;
+        if (!streams[dev]) {
+            // [r6] the LOWEST priority: the de-duplication chain (57 us) has 60 us of slack against the CSR chain on the caller's
+            // stream, but its 1 M-thread insert kernel fills the chip and the CSR chain's small scans queued behind it (18 + 24 us
+            // for kernels that take 5 + 5 alone: profiles/r06_step_trace_100000.txt)
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+            if (hipStreamCreateWithPriority(&streams[dev], hipStreamNonBlocking, least) != hipSuccess &&
+                hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess)
+                return TGNN_ERR_INVALID_ARG;
+        }
     }
     if (!events[dev][0])
         for (int k = 0; k < 2; ++k)
@@ -1383,8 +1461,19 @@ static int csr_build_pair_bucketed(const int64_t *adj_ei, int64_t ea, const int6
     A.set[0].max_deg_out = a_max_deg;
     A.set[1].total_out = c_total;
     const size_t lds_h = (size_t)A.nb * sizeof(int);
+    // [r6] one launch for the scan of the cells where it is long enough to need three (the readers add the tile offsets themselves)
+    const int64_t scan_tiles = (cells + kScanTile - 1) / kScanTile;
+    const bool fused_scan = cells > kScanOneMax && scan_tiles <= kScanFusedTiles;
+    if (fused_scan) {
+        A.tile_off = scan_ws + align_up((size_t)scan_tiles, 64);
+        A.scan_ticket = reinterpret_cast<unsigned *>(scan_ws + scan_ws_ints(cells) - 32);
+    }
     bk_hist_kernel<<<dim3(A.nblk, 2), kBkThreads, lds_h, s>>>(A);
-    exclusive_scan_i32(A.hist, A.hist, cells, scan_ws, s);
+    if (fused_scan)
+        scan_tiles_fused_kernel<<<(unsigned)scan_tiles, kScanThreads, 0, s>>>(A.hist, A.hist, scan_ws, const_cast<int *>(A.tile_off), cells,
+                                                                             A.scan_ticket);
+    else
+        exclusive_scan_i32(A.hist, A.hist, cells, scan_ws, s);
     const size_t lds_s = (size_t)(3 * A.nb + 16 + 2 * kBkChunk) * sizeof(int) + (size_t)2 * kBkChunk * sizeof(unsigned short);
     static LdsOptIn site_s;
     TGNN_CHECK_HIP(opt_in_dynamic_lds(bk_scatter_kernel, (int)(160 * 1024 - 256), site_s));
@@ -1879,15 +1968,7 @@ extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edge
         if (s_side && hipEventRecord(ev_join, s_side) == hipSuccess) (void)hipStreamWaitEvent(s, ev_join, 0);
         return code;
     };
-    if (s_side) {
-        rc = edge_type_dedup_listed(adj_edge_attr, n_adj_edges, fe, edge_type, type_rep_edge, result + 0, result + 6, ws_dd, dd_b, s_side);
-        if (rc != TGNN_OK) return bail(rc);
-        if (hipEventRecord(ev_join, s_side) != hipSuccess) {
-            (void)hipStreamSynchronize(s_side);
-            set_error("tgnn_graph_prep: hipEventRecord failed");
-            return TGNN_ERR_LAUNCH;
-        }
-    }
+    // [r6] the CSR chain is the longer one (90 against 57 us) and the host needs ~4 us per launch: its launches are queued FIRST
     if (bk_fits(n_nodes) && n_adj_edges < (int64_t(1) << 31) - 1 && n_col_edges < (int64_t(1) << 31) - 1) {
         // both CSRs through 512-row buckets: four kernels + one scan, no device-scope returning atomic
         const size_t bk_b = bk_workspace_bytes(n_nodes, n_adj_edges, n_col_edges);
@@ -1901,6 +1982,15 @@ extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edge
         if (rc != TGNN_OK) return bail(rc);
         rc = tgnn_csr_build(col_edge_index, n_col_edges, n_nodes, n_src_nodes, 1, col_rowptr, col_src, col_eid, result + 2, ws_csr, csr_b, stream);
         if (rc != TGNN_OK) return bail(rc);
+    }
+    if (s_side) {
+        rc = edge_type_dedup_listed(adj_edge_attr, n_adj_edges, fe, edge_type, type_rep_edge, result + 0, result + 6, ws_dd, dd_b, s_side);
+        if (rc != TGNN_OK) return bail(rc);
+        if (hipEventRecord(ev_join, s_side) != hipSuccess) {
+            (void)hipStreamSynchronize(s_side);
+            set_error("tgnn_graph_prep: hipEventRecord failed");
+            return TGNN_ERR_LAUNCH;
+        }
     }
     if (s_side) {
         TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev_join, 0));
@@ -1918,8 +2008,16 @@ extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edge
     if (result_host) {
         hipEvent_t ev_words = nullptr;
         TGNN_CHECK_HIP(prep_words_event(&ev_words));
-        TGNN_CHECK_HIP(hipMemcpyAsync(result_host, result, 32 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        TGNN_CHECK_HIP(hipEventRecord(ev_words, s));
+        if (s_side) {
+            // [r6] on the side stream (idle by now): the copy's ~10 us of launch and gap leave the chain the NNConv structure hangs on
+            TGNN_CHECK_HIP(hipEventRecord(ev_fork, s));
+            TGNN_CHECK_HIP(hipStreamWaitEvent(s_side, ev_fork, 0));
+            TGNN_CHECK_HIP(hipMemcpyAsync(result_host, result, 32 * sizeof(int32_t), hipMemcpyDeviceToHost, s_side));
+            TGNN_CHECK_HIP(hipEventRecord(ev_words, s_side));
+        } else {
+            TGNN_CHECK_HIP(hipMemcpyAsync(result_host, result, 32 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            TGNN_CHECK_HIP(hipEventRecord(ev_words, s));
+        }
     }
     // column structure with the type count read on the device
     const int64_t nt16 = (n_nodes + kColTileRows - 1) / kColTileRows;

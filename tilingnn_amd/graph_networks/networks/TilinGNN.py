@@ -27,6 +27,12 @@ from ..layers.edge_conv import GraphConv
 from ..layers.util import MLP, Linear_trans
 
 
+import os as _os
+# tgnn_forward_begin's launches in front of the preparation's (default; same-box A/B at 100 000 nodes: 1.921 against 1.937 ms per step
+# with them behind the preparation's launches -- ops.prepare_graph's after_enqueue hook --, profiles/r06_begin_order.txt)
+_BEGIN_FIRST = _os.environ.get("TGNN_BEGIN_FIRST", "1") == "1"
+
+
 def _default_node_features_dim():
     """The reference evaluates `environment.tile_count + 1` at import (TilinGNN.py:19).  When this
     module is dropped into the reference tree the same global is honoured."""
@@ -247,17 +253,35 @@ class TilinGNN(Tracked, nn.Module):
             # a NEW layout of the general schedule: what the forward does in front of its first layer without the graph (bounds, init
             # MLP, the final MLP's operand images) is queued on the side stream BEFORE the preparation and runs beside it
             # (tgnn_forward_begin / tgnn_forward_resume; the workspace's layout does not depend on the type count up to 16)
-            if bn_train and ops.runs_general_schedule(n) and n > 4096:
-                ws_bytes = lib.tgnn_forward_workspace_bytes(C.byref(dims), n, 0)
-                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-                rc = lib.tgnn_forward_begin(C.byref(dims), table, ptr(xf), n, int(update_running), ptr(ws), ws_bytes,
-                                            _lib.current_stream(dev), _lib.side_stream(dev))
-                begun = rc == 0
-                if rc not in (0, _lib.ERR_UNSUPPORTED):
-                    check(rc)
+            # (the preparation's launches first -- its CSR chain is the critical one --, begin's behind them and in front of the
+            #  preparation's one synchronisation: ops.prepare_graph's after_enqueue)
+            state = {}
+
+            def begin():
+                state["bytes"] = lib.tgnn_forward_workspace_bytes(C.byref(dims), n, 0)
+                state["ws"] = torch.empty(state["bytes"], dtype=torch.uint8, device=dev)
+                state["rc"] = lib.tgnn_forward_begin(C.byref(dims), table, ptr(xf), n, int(update_running), ptr(state["ws"]), state["bytes"],
+                                                     None, _lib.side_stream(dev))
+
+            use_begin = bn_train and ops.runs_general_schedule(n) and n > 4096
+            if use_begin:
+                side = _lib.side_stream_torch(dev)
+                if side is None:
+                    use_begin = False
+                else:
+                    side.wait_stream(torch.cuda.current_stream(dev))          # x and the parameters are ready HERE: in front of the preparation
+            if use_begin and _BEGIN_FIRST:
+                begin()
             try:
-                graph = ops.prepare_graph(n, adj_e_index, adj_e_features, col_e_idx)
+                graph = ops.prepare_graph(n, adj_e_index, adj_e_features, col_e_idx,
+                                          after_enqueue=begin if use_begin and not _BEGIN_FIRST else None)
+                begun = state.get("rc") == 0
+                if begun:
+                    ws, ws_bytes = state["ws"], state["bytes"]
+                elif state.get("rc") not in (None, _lib.ERR_UNSUPPORTED):
+                    check(state["rc"])
             except Exception:
+                begun = state.get("rc") == 0
                 side = _lib.side_stream_torch(dev) if begun else None
                 if side is not None:                                          # (begin's launches write the workspace freed below)
                     torch.cuda.current_stream(dev).wait_stream(side)

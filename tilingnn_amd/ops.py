@@ -306,7 +306,7 @@ def _read_back(res: Tensor):
 
 
 def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, small: bool,
-                         n_src_nodes: Optional[int] = None, groups: Optional[bool] = None) -> Optional[PreparedGraph]:
+                         n_src_nodes: Optional[int] = None, groups: Optional[bool] = None, after_enqueue=None) -> Optional[PreparedGraph]:
     """prepare_graph as ONE library call + the one sync: `small`: tgnn_graph_prep_small (one launch); else tgnn_graph_prep
     (the launches of the separate calls, queued by the library without a host round trip).  None = fall back."""
     ea, ec = int(adj.shape[1]), int(col.shape[1])
@@ -368,11 +368,16 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
             late = (words, ev, res)
+        if after_enqueue is not None:
+            after_enqueue()                                                      # (the caller's launches that need nothing of the graph)
+            after_enqueue = None
         check(lib.tgnn_graph_prep_wait(_stream(adj)))                                        # the one sync: the copy of the words alone
         host = early.tolist()
         host[5] = host[10] = int(host[0] <= lib.tgnn_nnconv_cols_max_types() and not host[6])
         host[9] = 0                                                              # (optimistic: see `late`)
     else:
+        if after_enqueue is not None:
+            after_enqueue()
         host = _read_back(res)                                                   # the one sync
     if host[1] or host[2]:
         raise IndexError(f"edge index out of range [0, {n_nodes}) in {'adj_e_index' if host[1] else 'col_e_idx'}")
@@ -390,13 +395,23 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
 
 def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col_e_idx: Tensor,
                   tile_width: int = 32, n_src_nodes: Optional[int] = None, columns: Optional[bool] = None,
-                  groups=None) -> PreparedGraph:
+                  groups=None, after_enqueue=None) -> PreparedGraph:
     """Everything the 20 layers share: CSR of both edge sets, edge-type ids in CSR order, and (columns: None = for
     layouts above COLS_MIN_NODES) the NNConv column structure -- or (groups: None = for layouts of the general schedule,
     i.e. above the mid-size limit, when GROUPS is on; "both": columns, mid-size batches AND groups from the one
     tgnn_graph_prep call) the NNConv edge groups in its place; `graph_columns` / `graph_groups` build the other structure
     for whoever needs it.
-    Synchronises once (the type count and the self-loop-free collision edge count are read back)."""
+    Synchronises once (the type count and the self-loop-free collision edge count are read back).
+    after_enqueue: called once, with no arguments, behind the preparation's launches and in front of that synchronisation (or first
+    thing on the paths that synchronise more than once): launches of the caller's that need nothing of the graph go there."""
+    done = [False]
+    if after_enqueue is not None:
+        user_cb = after_enqueue
+
+        def after_enqueue():
+            if not done[0]:
+                done[0] = True
+                user_cb()
     adj = _check_edge_index(adj_e_index, "adj_e_index")
     col = _check_edge_index(col_e_idx, "col_e_idx")
     ea, ec = int(adj.shape[1]), int(col.shape[1])
@@ -406,9 +421,11 @@ def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col
         # (a shard's layout -- sources behind the destination rows -- goes through the any-size call)
         small = n_src_nodes is None and n_nodes <= _small_prep_limits()[0] and max(ea, ec) <= _small_prep_limits()[1] and \
             not (groups or (groups is None and GROUPS and runs_general_schedule(n_nodes)))   # (the one-launch preparation builds columns)
-        g = _prepare_graph_fused(n_nodes, adj, adj_e_features, col, small, n_src_nodes, groups)
+        g = _prepare_graph_fused(n_nodes, adj, adj_e_features, col, small, n_src_nodes, groups, after_enqueue)
         if g is not None:
             return g
+    if after_enqueue is not None:
+        after_enqueue()
     a_rowptr, a_src, a_eid, a_err = build_csr(adj, n_nodes, False, n_src_nodes)
     c_rowptr, c_src, c_eid, c_err = build_csr(col, n_nodes, True, n_src_nodes)        # GINConv strips self loops
     edge_type, rep, n_types = dedup_edge_types(adj_e_features)
