@@ -551,9 +551,9 @@ def main():
                               "wait for CUs the NNConv holds)"}
         # quoted, not measured here: rocprofv3 of the same command (cannot run inside this process) and the PMC passes;
         # only for the workload they were taken on, with the file they come from
-        prof_file = os.path.join(REPO, "profiles", "r05_nnconv.json")
+        prof_file = os.path.join(REPO, "profiles", "r06_nnconv.json")
         if not os.path.exists(prof_file):
-            prof_file = os.path.join(REPO, "profiles", "r04_nnconv.json")
+            prof_file = os.path.join(REPO, "profiles", "r05_nnconv.json")
         if os.path.exists(prof_file) and (n_total, ea_total, n_types_seen) == (100_000, 1_000_000, 13):
             with open(prof_file) as fh:
                 q = json.load(fh)
@@ -647,8 +647,9 @@ def main():
                    "value": n3 / (res3["ms_per_step"] * 1e-3), "cached_layout_ms": res3["cached_layout_ms"],
                    "whole_forward": {"algorithmic_bytes": b3, "frac_of_hbm_peak": b3 / (res3["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
                    "nnconv_algorithmic_bytes_per_launch": nnconv_bytes(n3, ea3, N_TYPES, c=64, s=2),
-                   "profile": "profiles/r05_config3_kernel_stats.txt (rocprofv3 --kernel-trace --stats of scratch/run_config3_only.py), "
-                              "profiles/r04_config3_pmc.txt (HBM / MFMA counters of nnconv64_bf16_cols_kernel and the other kernels of a layer)"}
+                   "profile": "profiles/r06_config3_kernel_stats.txt (rocprofv3 --kernel-trace --stats of scratch/run_config3_only.py), "
+                              "profiles/r06_config3_pmc.txt (FETCH / WRITE, SQ_INSTS_VALU / MFMA, MFMA-busy, wait cycles of nnconv64_bf16_eg_kernel -- the "
+                              "kernel that runs -- and the other kernels of a layer; scratch/pmc_config3.sh)"}
         del net3, x3, adj3, attr3, col3
         torch.cuda.empty_cache()
 

@@ -111,10 +111,24 @@ def test_op_against_fp64(dev, n, ea, n_types, run, scale, leaky):
     assert g.n_types == n_types
     gen = torch.Generator().manual_seed(1)
     h = (torch.randn(n, 32, generator=gen) * torch.randn(n, 32, generator=gen) * scale).to(dev)
-    wtab = torch.rand(g.n_types, 32, 32, generator=gen).to(dev)                # edge-MLP outputs are sigmoids
-    root = (torch.randn(32, 32, generator=gen) * 0.3).to(dev)
-    bias = (torch.randn(32, generator=gen) * scale).to(dev)
-    want = fp64_nnconv(h, adj, g.edge_type[:ea].long(), wtab, root, bias, n, leaky)
+    # [r6] the expectation comes from the PINNED oracle (oracle.nnconv_mean_dedup: edge_conv.py:17-18, 25 -- the edge MLP on the distinct
+    # attribute rows, messages, mean, root term), not from a formula of this file: the per-type matrices are GraphConv's edge MLP
+    # 4 -> 32 -> 64 -> 1024 with random weights, evaluated in fp64 by the oracle and by tgnn_edge_weight_table on the device
+    prefix = "g"
+    sd = {f"{prefix}.mlp.mlp.0.linear.weight": torch.randn(32, 4, generator=gen) * 0.5, f"{prefix}.mlp.mlp.0.linear.bias": torch.randn(32, generator=gen) * 0.1,
+          f"{prefix}.mlp.mlp.1.linear.weight": torch.randn(64, 32, generator=gen) * 0.2, f"{prefix}.mlp.mlp.1.linear.bias": torch.randn(64, generator=gen) * 0.1,
+          f"{prefix}.mlp.mlp.2.linear.weight": torch.randn(1024, 64, generator=gen) * 0.2, f"{prefix}.mlp.mlp.2.linear.bias": torch.randn(1024, generator=gen) * 0.1,
+          f"{prefix}.nnConv.root": torch.randn(32, 32, generator=gen) * 0.3, f"{prefix}.nnConv.bias": torch.randn(32, generator=gen) * scale}
+    mlp = [sd[f"{prefix}.mlp.mlp.{i}.linear.{k}"].to(dev) for i in range(3) for k in ("weight", "bias")]
+    wtab = ops.edge_weight_table(attr, g, *mlp, 32)
+    root, bias = sd[f"{prefix}.nnConv.root"].to(dev), sd[f"{prefix}.nnConv.bias"].to(dev)
+    with torch.no_grad():
+        want = orc.nnconv_mean_dedup(h.double().cpu(), adj.cpu(), attr.double().cpu(), orc.cast_sd(sd, torch.float64), prefix)
+    if leaky:
+        want = orc.leaky_relu(want)
+    want = want.to(dev)
+    # (this file's own restatement, on the device's table: the two expectations agree to the table's fp32 rounding)
+    assert orc.rel_max_err(fp64_nnconv(h, adj, g.edge_type[:ea].long(), wtab, root, bias, n, leaky).cpu(), want.cpu()) < 1e-6
     part = ops.new_partials(32, dev)
     out, npart = ops.nnconv_mean(h, g, wtab, root, bias, ops.ACT_LEAKY_RELU if leaky else ops.ACT_NONE, part, kernel="eg")
     assert out.shape == (n, 32) and bool(torch.isfinite(out).all())

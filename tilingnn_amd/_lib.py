@@ -17,7 +17,7 @@ BN_STAT_ROWS = 4
 
 
 class TgnnError(RuntimeError):
-    pass
+    code = 0          # the library's status (include/tgnn.h: TGNN_ERR_*)
 
 
 class ModelDims(C.Structure):
@@ -255,7 +255,9 @@ def forward_path_counts():
 def check(rc: int) -> None:
     if rc != 0:
         msg = lib.tgnn_last_error()
-        raise TgnnError(f"libtgnn error {rc}: {msg.decode() if msg else '?'}")
+        err = TgnnError(f"libtgnn error {rc}: {msg.decode() if msg else '?'}")
+        err.code = int(rc)
+        raise err
 
 
 def ptr(t) -> C.c_void_p:
@@ -394,6 +396,7 @@ def side_stream(device) -> C.c_void_p:
 
 
 ERR_UNSUPPORTED = -4          # TGNN_ERR_UNSUPPORTED (include/tgnn.h)
+ERR_STALE_RESULT = -6         # TGNN_ERR_STALE_RESULT
 
 
 def side_stream_torch(device):

@@ -869,6 +869,198 @@ __global__ __launch_bounds__(kRowsThreads, 1) void dense_f16_rows2_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// [r6] dense_f16_rows2_kernel's pipeline on HALF the output columns per work item (item = (128-row tile, column half): a wave's
+// accumulators are 64 registers, the block's image tile 16 KB), two or three blocks per CU: the one-block-per-CU form loses to
+// the bubbles at every row tile's start and end (nothing else runs on the CU meanwhile).  The A rows of a tile are read and
+// split by both of its items (the second read comes out of L2: the two run on neighbouring blocks at the same time).
+// ------------------------------------------------------------------------------------------
+template <int TNI, int TN>                                    // TNI 32-column blocks in the image, TN of them per work item
+__global__ __launch_bounds__(kRowsThreads, 2) void dense_f16_halves_kernel(
+    const float *__restrict__ a, int64_t lda, int64_t a_kb_stride, int kps, const float *__restrict__ in_stat,
+    const u32x4_ *__restrict__ wimg, const float *__restrict__ bias, int64_t n, int in_dim, int act, float *__restrict__ out,
+    int64_t ldo, double *__restrict__ bn_partial, const unsigned *__restrict__ a_max, int n_a_max,
+    const unsigned *__restrict__ w_max) {
+    constexpr bool STAT = false;
+    constexpr int N = 32 * TN, TNH = TN / 2, NI = 32 * TNI, PARTS = TNI / TN;
+    constexpr int kTileVec = 2 * TN * 2 * 64;                 // 16-byte pieces of one k-tile of the image, this item's columns
+    constexpr int kImgTileVec = 2 * TNI * 2 * 64;             // ... all columns
+    constexpr int RB = kTileVec / kRowsThreads;               // ... per thread
+    // dynamic LDS (more than the 64 KB a kernel may declare statically): two image tiles, the column sums of the four waves, the
+    // BatchNorm record of the input (STAT)
+    extern __shared__ __attribute__((aligned(1024))) unsigned char halves_lds[];
+    u32x4_ (*Bs)[kTileVec] = reinterpret_cast<u32x4_ (*)[kTileVec]>(halves_lds);
+    double *red = reinterpret_cast<double *>(halves_lds + sizeof(u32x4_) * 2 * kTileVec);                       // [wave][2][N]
+    float *st = reinterpret_cast<float *>(halves_lds + sizeof(u32x4_) * 2 * kTileVec + sizeof(double) * 8 * N);   // [4][in_dim]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 31, fg = lane >> 5;
+    const int ktiles = in_dim / kBK;
+    float sa, unscale;
+    {
+        unsigned mb = 0;
+        for (int i = lane; i < n_a_max; i += 64) mb = max(mb, a_max[i]);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, d, 64));
+        sa = pow2_scale_for(mb, 0);
+        unscale = 1.0f / (sa * pow2_scale_for(*w_max, 0));
+    }
+    if (STAT) {
+        for (int i = tid; i < 4 * in_dim; i += kRowsThreads) st[i] = in_stat[i];
+    }
+    const int64_t row_tiles = (n + 127) / 128, items = row_tiles * PARTS;
+    // BatchNorm sums of the block: thread t keeps entries t, t + 256, .. of the row [sum NI | sum of squares NI]
+    constexpr int BS = 2 * NI / kRowsThreads;
+    double bsum[BS];
+#pragma unroll
+    for (int e = 0; e < BS; ++e) bsum[e] = 0.0;
+    const bool leaky = act == TGNN_ACT_LEAKY_RELU;
+
+    for (int64_t it = blockIdx.x; it < items; it += gridDim.x) {
+        const int64_t rt = it / PARTS;
+        const int part = (int)(it % PARTS);                   // columns 32 TN part .. + 32 TN
+        const int64_t m0 = rt * 128 + wave * 32;
+        int64_t row = m0 + fi;
+        row = row < n ? row : n - 1;
+        const float *arow = a + row * lda + 8 * fg;
+        auto load_a = [&](int kt, float4 (&r)[4]) {
+            const float4 *p = reinterpret_cast<const float4 *>(arow + (int64_t)kt * a_kb_stride);   // (kps == 1: the launcher's condition)
+            r[0] = p[0]; r[1] = p[1]; r[2] = p[4]; r[3] = p[5];        // k = 8 g .. + 7 and 16 + 8 g .. + 7
+        };
+        auto load_b = [&](int kt, u32x4_ (&r)[RB]) {
+            // the item's columns of image tile kt: per k-half a run of TN * 128 pieces at (kb TNI + part TN) * 128
+            const u32x4_ *p = wimg + (int64_t)kt * kImgTileVec;
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const int i = tid + kRowsThreads * j, kb = i / (TN * 128), rem = i % (TN * 128);
+                r[j] = p[(kb * TNI + part * TN) * 128 + rem];
+            }
+        };
+        auto store_b = [&](const u32x4_ (&r)[RB], u32x4_ *dst) {
+#pragma unroll
+            for (int j = 0; j < RB; ++j) dst[tid + kRowsThreads * j] = r[j];
+        };
+        auto split_a = [&](int kt, const float4 (&r)[4], f16x8 (&hi)[2], f16x8 (&lo)[2]) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                float x[8] = {r[2 * kb].x, r[2 * kb].y, r[2 * kb].z, r[2 * kb].w,
+                              r[2 * kb + 1].x, r[2 * kb + 1].y, r[2 * kb + 1].z, r[2 * kb + 1].w};
+                if (STAT) {
+                    const int k = kt * kBK + kb * 16 + 8 * fg;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        x[e] = bn_apply1(x[e], st[k + e], st[in_dim + k + e], st[2 * in_dim + k + e], st[3 * in_dim + k + e]);
+                }
+                split2_f16(x, sa, hi[kb], lo[kb]);
+            }
+        };
+        f32x16 acc[TN];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tn][r] = 0.f;
+        // registers of the pipeline, by the parity of the k-tile they hold
+        float4 araw0[4], araw1[4];
+        u32x4_ breg0[RB], breg1[RB];
+        f16x8 ah0[2], al0[2], ah1[2], al1[2];
+        const int last = ktiles - 1;
+        auto clampk = [&](int kt) { return kt < last ? kt : last; };
+        load_a(0, araw0);
+        load_b(0, breg0);
+        load_a(clampk(1), araw1);
+        load_b(clampk(1), breg1);
+        __syncthreads();                                      // the previous row tile's reads of Bs (and st's fill) are over
+        store_b(breg0, Bs[0]);
+        split_a(0, araw0, ah0, al0);
+        load_a(clampk(2), araw0);
+        load_b(clampk(2), breg0);
+        // Branch-free inside the k loop (an accumulator modified on two paths of a loop costs hipcc a register copy per element and
+        // iteration): loads past the last tile re-read the last tile, the store / split of a tile nobody multiplies are harmless.
+        auto mma = [&](const u32x4_ *bcur, const f16x8 (&ahc)[2], const f16x8 (&alc)[2]) {
+            const u32x4_ *bt = bcur + lane;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                f16x8 bh[TN], bl[TN];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    bh[tn] = __builtin_bit_cast(f16x8, bt[(kb * TN + tn) * 128]);
+                    bl[tn] = __builtin_bit_cast(f16x8, bt[(kb * TN + tn) * 128 + 64]);
+                }
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alc[kb], bh[tn], acc[tn], 0, 0, 0);   // lo . hi
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahc[kb], bl[tn], acc[tn], 0, 0, 0);   // hi . lo
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahc[kb], bh[tn], acc[tn], 0, 0, 0);   // hi . hi
+            }
+        };
+        const int pairs = ktiles >> 1;
+        for (int kp = 0; kp < pairs; ++kp) {
+            const int kt = 2 * kp;
+            // step kt: tile kt is in Bs[0] behind the barrier, A(kt) split in (ah0, al0); tile kt + 1 goes registers -> Bs[1] and is
+            // split, its registers take tile kt + 3; then the 6 TN matrix instructions of tile kt
+            __syncthreads();
+            store_b(breg1, Bs[1]);
+            split_a(clampk(kt + 1), araw1, ah1, al1);
+            load_a(clampk(kt + 3), araw1);
+            load_b(clampk(kt + 3), breg1);
+            mma(Bs[0], ah0, al0);
+            // step kt + 1 the other way round
+            __syncthreads();
+            store_b(breg0, Bs[0]);
+            split_a(clampk(kt + 2), araw0, ah0, al0);
+            load_a(clampk(kt + 4), araw0);
+            load_b(clampk(kt + 4), breg0);
+            mma(Bs[1], ah1, al1);
+        }
+        if (ktiles & 1) {                                     // (uniform) the last tile of an odd count: in Bs[0], split in (ah0, al0)
+            __syncthreads();
+            mma(Bs[0], ah0, al0);
+        }
+        // ---- epilogue (C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5))
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = (part * TN + tn) * 32 + fi;
+            const float b = bias[col];
+            double s_ = 0.0, q_ = 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t orow = m0 + (r & 3) + 8 * (r >> 2) + 4 * fg;
+                if (orow < n) {
+                    const float u = fmaf(acc[tn][r], unscale, b);
+                    const float v = leaky ? (u >= 0.f ? u : u * kLeakySlope) : act_apply(u, act);
+                    out[orow * ldo + col] = v;
+                    s_ += (double)v;
+                    q_ += (double)v * (double)v;
+                }
+            }
+            s_ += __shfl_xor(s_, 32, 64);
+            q_ += __shfl_xor(q_, 32, 64);
+            if (bn_partial && (tn / TNH) == fg) {             // (lanes < 32 write the columns of tn < TN / 2, the others the rest)
+                red[(wave * 2 + 0) * N + tn * 32 + fi] = s_;
+                red[(wave * 2 + 1) * N + tn * 32 + fi] = q_;
+            }
+        }
+        if (bn_partial) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < BS; ++e) {
+                const int i = tid + kRowsThreads * e, which = i / NI, cl = i % NI;
+                if (cl / N == part) {
+                    double tot = 0.0;
+#pragma unroll
+                    for (int wv = 0; wv < 4; ++wv) tot += red[(wv * 2 + which) * N + cl % N];
+                    bsum[e] += tot;
+                }
+            }
+        }
+    }
+
+    if (bn_partial) {
+#pragma unroll
+        for (int e = 0; e < BS; ++e) bn_partial[(int64_t)blockIdx.x * 2 * NI + tid + kRowsThreads * e] = bsum[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // [r6] The final MLP's inner Linears (256 -> 128 -> 64, BatchNorm on load) with the WHOLE operand image of W resident in LDS
 // (128 KB / 32 KB: one 8-wave block per CU, the image copied once per block) -- nothing is shared between the waves after
 // that, so the k loop has NO barrier: every wave streams its own 32-row tiles, two k-tiles (8 KB) per request, two requests in
@@ -877,13 +1069,14 @@ __global__ __launch_bounds__(kRowsThreads, 1) void dense_f16_rows2_kernel(
 // Per accumulator the matrix terms come in the rows kernels' order (k ascending; lo.hi, hi.lo, hi.hi): the same bits.
 // One BatchNorm partial row per block (column sums kept per lane in fp64 over all of a wave's tiles).
 // ------------------------------------------------------------------------------------------
-constexpr int kResThreads = 512, kResChunk = 2;               // k-tiles per request (8 KB per wave; two requests in flight)
-template <int TN, int CPT>                                    // CPT = requests per row tile (even): in_dim = 64 CPT
+constexpr int kResThreads = 512;
+template <int TN, int CPT, int kResChunk = 2>                 // kResChunk k-tiles per request (2: 8 KB per wave; two requests in flight), CPT
+                                                              // requests per row tile (even): in_dim = 32 kResChunk CPT
 __global__ __launch_bounds__(kResThreads, 1) void dense_f16_resident_kernel(
     const float *__restrict__ a, int64_t lda, const float *__restrict__ in_stat, const u32x4_ *__restrict__ wimg,
     const float *__restrict__ bias, int64_t n, int act, float *__restrict__ out, int64_t ldo, double *__restrict__ bn_partial,
     const unsigned *__restrict__ a_max, const unsigned *__restrict__ w_max) {
-    constexpr int N = 32 * TN, K = 64 * CPT, KT = K / kBK;
+    constexpr int N = 32 * TN, K = 32 * kResChunk * CPT, KT = K / kBK;
     constexpr int kTileVec = 2 * TN * 2 * 64;                 // 16-byte pieces of one k-tile of the image
     extern __shared__ __attribute__((aligned(1024))) unsigned char res_lds[];
     u32x4_ *Bs = reinterpret_cast<u32x4_ *>(res_lds);                                   // [KT][kTileVec]
@@ -1016,6 +1209,7 @@ __global__ __launch_bounds__(kResThreads, 1) void dense_f16_resident_kernel(
 
 static size_t dense_f16_image_bytes(int in_dim, int out_dim) { return (size_t)in_dim * out_dim * 4; }
 static std::atomic<int> g_dense_resident{1};                 // tgnn_set_dense_rows_mode bit 1 (0 = off): dense_f16_resident_kernel for the inner layers
+static std::atomic<int> g_dense_halves{0};                   // tgnn_set_dense_rows_mode bits 2-3: blocks per CU of dense_f16_halves_kernel (0 = off)
 static std::atomic<int> g_dense_rows_mode{0};                // tgnn_set_dense_rows_mode: 0 = dense_f16_rows_kernel, 1 = dense_f16_rows2_kernel
 
 template <int TN>
@@ -1042,6 +1236,21 @@ static int launch_dense_f16_rows2(hipStream_t s, const float *a, int64_t lda, in
     return blocks;
 }
 
+// 64 -> 32 (the final MLP's fourth Linear) on the resident kernel, one k-tile per request; -1 = not applicable
+static int launch_dense_f16_resident1(hipStream_t s, const float *a, int64_t lda, int64_t akb, int kps, const float *in_stat,
+                                      const void *wimg, const float *b, int64_t n, int in_dim, int act, float *out, int64_t ldo,
+                                      double *bn_partial, const unsigned *a_max, int n_a_max, const unsigned *w_max) {
+    if (!(g_dense_resident.load(std::memory_order_relaxed) && in_stat && n_a_max == 1 && kps == 1 && akb == kBK && in_dim == 64 && lda % 4 == 0))
+        return -1;
+    const size_t lds1 = (size_t)in_dim * 32 * 4 + (size_t)4 * in_dim * sizeof(float) + (size_t)8 * 2 * 32 * sizeof(double);
+    int blocks1 = (int)((n + 255) / 256);
+    if (blocks1 > device_cus()) blocks1 = device_cus();
+    if (blocks1 < 1) blocks1 = 1;
+    dense_f16_resident_kernel<1, 2, 1><<<blocks1, kResThreads, lds1, s>>>(a, lda, in_stat, static_cast<const u32x4_ *>(wimg), b, n, act, out,
+                                                                        ldo, bn_partial, a_max, w_max);
+    return blocks1;
+}
+
 template <int TN>
 static int launch_dense_f16_rows(hipStream_t s, const float *a, int64_t lda, int64_t akb, int kps, const float *in_stat,
                                  const void *wimg, const float *b, int64_t n, int in_dim, int act, float *out, int64_t ldo,
@@ -1066,6 +1275,18 @@ static int launch_dense_f16_rows(hipStream_t s, const float *a, int64_t lda, int
             (void)opt_in_dynamic_lds(dense_f16_resident_kernel<TN, 2>, 160 * 1024 - 256, site);
             dense_f16_resident_kernel<TN, 2><<<blocks, kResThreads, lds, s>>>(a, lda, in_stat, img, b, n, act, out, ldo, bn_partial, a_max, w_max);
         }
+        return blocks;
+    }
+    if constexpr (TN == 8)
+    if (g_dense_halves.load(std::memory_order_relaxed) && !in_stat && kps == 1) {
+        constexpr size_t lds = sizeof(u32x4_) * 2 * (2 * 4 * 2 * 64) + sizeof(double) * 8 * 128;
+        const int64_t items = ((n + 127) / 128) * 2;
+        int blocks = (int)(items < TGNN_BN_MAX_PARTIALS ? items : TGNN_BN_MAX_PARTIALS);
+        const int cap = g_dense_halves.load(std::memory_order_relaxed) * device_cus();
+        if (blocks > cap) blocks = cap;
+        if (blocks > 1) blocks &= ~1;                         // (even: a block keeps its column half over its items)
+        dense_f16_halves_kernel<8, 4><<<blocks, kRowsThreads, lds, s>>>(a, lda, akb, kps, nullptr, static_cast<const u32x4_ *>(wimg), b, n,
+                                                                       in_dim, act, out, ldo, bn_partial, a_max, n_a_max, w_max);
         return blocks;
     }
     if (g_dense_rows_mode.load(std::memory_order_relaxed) == 1 && kps == 1)
@@ -1254,6 +1475,18 @@ static int dense_act_impl(const float *a, int64_t lda, int64_t a_kblock_stride, 
     const int blocks_x = row_blocks(kBM);
     const bool fast = vec_a && vec_w && in_dim % kBK == 0;
     constexpr int exact_only = 0;     // 1: exact-fp32 MFMA kernels everywhere (the split-precision ones measured equal to 4e-7)
+    // [r6] 64 -> 32 with bounds and an operand image at hand (the final MLP's fourth Linear at benchmark sizes): the resident kernel's
+    // smallest form on fp16 pairs instead of the exact-fp32 block-tile kernel (17.6 us for 38 MB at 100 000 rows)
+    if (fast && !exact_only && out_dim == 32 && in_dim == 64 && a_max && w_max && n_a_max == 1 && wimg && in_stat &&
+        n_rows >= kDenseRowsKernelMin && ((uintptr_t)wimg % 16) == 0) {
+        const int nb = launch_dense_f16_resident1(s, a, lda, a_kblock_stride, kps, in_stat, wimg, b, n_rows, in_dim, act, out, ldo, bn_partial,
+                                                  a_max, n_a_max, w_max);
+        if (nb > 0) {
+            if (n_partials_host) *n_partials_host = nb;
+            TGNN_CHECK_LAUNCH();
+            return TGNN_OK;
+        }
+    }
     if (fast && out_dim >= 64 && !exact_only && lda % 8 == 0 && a_kblock_stride % 8 == 0 && in_dim % 8 == 0) {
         // bf16 x 3 split-precision path (see dense_split_kernel)
         // few row tiles (small layouts): the 128 x 64 block tile puts twice as many blocks on the chip and halves the
@@ -1338,10 +1571,11 @@ static int dense_act_impl(const float *a, int64_t lda, int64_t a_kblock_stride, 
 }
 
 extern "C" int32_t tgnn_set_dense_rows_mode(int32_t mode) {
-    const int prev = g_dense_rows_mode.load() | (g_dense_resident.load() ? 2 : 0);
-    if (mode < 0 || mode > 3) return prev;
+    const int prev = g_dense_rows_mode.load() | (g_dense_resident.load() ? 2 : 0) | (g_dense_halves.load() << 2);
+    if (mode < 0 || mode > 15) return prev;
     g_dense_rows_mode.store(mode & 1);
     g_dense_resident.store((mode >> 1) & 1);
+    g_dense_halves.store((mode >> 2) & 3);
     return prev;
 }
 

@@ -85,7 +85,7 @@ struct Workspace {
     double *small_part, *small_part_wide, *small_runstat;
     double *mid_part;             // mid-size persistent layer loop: tagged partial rows + group sums (forward_mid.hip)
     unsigned *small_ctr;
-    void *dimg[3];                 // fp16-pair operand images of the final MLP's first three Linears (dense_f16_image_build)
+    void *dimg[4];                 // fp16-pair operand images of the final MLP's four Linears (dense_f16_image_build; [r6] the fourth, 64 -> 32)
     unsigned *bounds;            // [0, D]: max |middle[k]| as float bits; [D + 1, 2 D]: max |root_i|; [2 D + 1]: max |final W_0|
     float *stat1, *stat2[2], *stat_i[2], *stat_f[4];
     size_t bytes;
@@ -166,10 +166,11 @@ static Workspace carve(const tgnn_model_dims &d, int64_t n, int64_t nr, int32_t 
     w.small_runstat = cv.take<double>((size_t)D * 128);
     w.mid_part = cv.take<double>(mid_part_doubles());
     w.small_ctr = cv.take<unsigned>(64);
-    w.bounds = cv.take<unsigned>(2 * kMaxDepth + 8);
+    w.bounds = cv.take<unsigned>(2 * kMaxDepth + 12);
     {
         const int fd[4] = {c * (D + 1), kFinalDims[0], kFinalDims[1], kFinalDims[2]};
         for (int l = 0; l < 3; ++l) w.dimg[l] = cv.take<unsigned char>(dense_f16_image_size(fd[l], fd[l + 1]));
+        w.dimg[3] = cv.take<unsigned char>(dense_f16_image_size(fd[3], c));
     }
     w.stat1 = cv.take<float>(4 * c);
     w.stat2[0] = cv.take<float>(4 * c);
@@ -246,37 +247,42 @@ struct HeadEvent {
     int64_t n = 0;
 };
 static thread_local HeadEvent g_head[64];
+// words of w.bounds holding (max |W_l|, bound of |BN(input of l)|) of the final MLP's layer l = 1 .. 3 (3: lean head only)
+static inline unsigned *final_bound_word(const Workspace &w, int D, int l) { return w.bounds + (l <= 2 ? 2 * D + 2 + 2 * (l - 1) : 2 * D + 8); }
 static int forward_head_bounds_images(const tgnn_model_dims *dims, const Params &P, const Workspace &w, int64_t n, int64_t n_total,
                                       hipStream_t st, bool *images_ok) {
     const int c = dims->network_width, D = dims->network_depth;
     const int fin_dims[5] = {c * (D + 1), kFinalDims[0], kFinalDims[1], kFinalDims[2], c};
     unsigned *dense_max = w.bounds + 2 * D + 1;
-    const float *bw[3], *bg[3], *bb[3];
-    int64_t bwn[3];
-    int bf[3];
-    unsigned *bwm[3], *bam[3];
+    // layers 1 .. 3 (256 -> 128 -> 64 -> 32): the weights' bound and, from the producer's BatchNorm parameters, the input's; layer 3
+    // ([r6]: it ran the exact-fp32 kernel, 17.6 us for 38 MB) only where the row count takes the resident kernel
+    const int nl = (c == 32 && n >= kDenseRowsKernelMin) ? 4 : 3;
+    const float *bw[4], *bg[4], *bb[4];
+    int64_t bwn[4];
+    int bf[4];
+    unsigned *bwm[4], *bam[4];
     bw[0] = P.f(P.fin(0)); bwn[0] = (int64_t)fin_dims[0] * fin_dims[1]; bg[0] = nullptr; bb[0] = nullptr; bf[0] = 0; bwm[0] = dense_max; bam[0] = nullptr;
-    for (int l = 1; l <= 2; ++l) {
+    for (int l = 1; l < nl; ++l) {
         const BnPtrs bp = P.bn(P.fin(l - 1) + 2);
         bw[l] = P.f(P.fin(l));
         bwn[l] = (int64_t)fin_dims[l] * fin_dims[l + 1];
         bg[l] = bp.gamma; bb[l] = bp.beta; bf[l] = fin_dims[l];
-        bwm[l] = w.bounds + 2 * D + 2 + 2 * (l - 1);
-        bam[l] = w.bounds + 2 * D + 3 + 2 * (l - 1);
+        bwm[l] = final_bound_word(w, D, l);
+        bam[l] = final_bound_word(w, D, l) + 1;
     }
-    launch_dense_bounds(3, bw, bwn, bg, bb, bf, bwm, bam, n_total, st);
+    launch_dense_bounds(nl, bw, bwn, bg, bb, bf, bwm, bam, n_total, st);
     *images_ok = false;
-    if (c == 32 && n >= kDenseRowsKernelMin) {
-        const float *iw[3];
-        int iin[3], iout[3];
-        const unsigned *iwm[3];
-        void *iimg[3];
-        for (int l = 0; l < 3; ++l) {
+    if (nl == 4) {
+        const float *iw[4];
+        int iin[4], iout[4];
+        const unsigned *iwm[4];
+        void *iimg[4];
+        for (int l = 0; l < 4; ++l) {
             iw[l] = P.f(P.fin(l)); iin[l] = fin_dims[l]; iout[l] = fin_dims[l + 1];
-            iwm[l] = l == 0 ? dense_max : w.bounds + 2 * D + 2 + 2 * (l - 1);
+            iwm[l] = l == 0 ? dense_max : final_bound_word(w, D, l);
             iimg[l] = w.dimg[l];
         }
-        *images_ok = dense_f16_images_build(3, iw, iin, iout, iwm, iimg, st) == TGNN_OK;
+        *images_ok = dense_f16_images_build(4, iw, iin, iout, iwm, iimg, st) == TGNN_OK;
     }
     return TGNN_OK;
 }
@@ -512,7 +518,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         if (lean_head && head_done && init_fused_early)
             ;                                                 // (tgnn_forward_begin's, on the side stream)
         else if (lean_head)
-            launch_forward_scales(w.bounds, 2 * D + 8, roots, D, root_max, nullptr, 0, nullptr, s);
+            launch_forward_scales(w.bounds, 2 * D + 10, roots, D, root_max, nullptr, 0, nullptr, s);
         else
             launch_forward_scales(w.bounds, 2 * D + 7, roots, D, root_max, P.f(P.fin(0)), cat_w_floats, dense_max, s);   // (before the fork: both chains see the zeroed words)
     }
@@ -543,15 +549,15 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         TGNN_CHECK_HIP(hipEventRecord(ev[kEvWeights], s2));
         weights_recorded = true;
     }
-    bool dimg_ok[3] = {false, false, false};
+    bool dimg_ok[4] = {false, false, false, false};
     if (lean_head && head_done && init_fused_early) {
-        dimg_ok[0] = dimg_ok[1] = dimg_ok[2] = c == 32 && n >= kDenseRowsKernelMin;   // (built by tgnn_forward_begin)
+        dimg_ok[0] = dimg_ok[1] = dimg_ok[2] = dimg_ok[3] = c == 32 && n >= kDenseRowsKernelMin;   // (built by tgnn_forward_begin)
     } else if (lean_head) {
         // bounds of the three Linears' weights (+ of layers 1, 2's inputs from their BatchNorm parameters), then the three operand
         // images in ONE launch
         bool ok = false;
         TGNN_TRY(forward_head_bounds_images(dims, P, w, n, n_total, sw, &ok));
-        dimg_ok[0] = dimg_ok[1] = dimg_ok[2] = ok;
+        dimg_ok[0] = dimg_ok[1] = dimg_ok[2] = dimg_ok[3] = ok;
     } else if (f16 && !tail_k) {
         // the final MLP's layers 1 and 2 (256 -> 128 -> 64): weights' bounds and, from the BatchNorm parameters alone, their inputs'
         const float *bw[2], *bg[2], *bb[2];
@@ -871,10 +877,10 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
             prof.end();
         } else {
             prof.begin(6);
-            if (f16 && l <= 2)       // fp16 pairs: the input's bound follows from the producer's BatchNorm parameters (dense_bounds_kernel)
+            if (f16 && (l <= 2 || dimg_ok[l]))   // fp16 pairs: the input's bound follows from the producer's BatchNorm parameters (dense_bounds_kernel)
                 TGNN_TRY(dense_act_bounded(fbuf[l - 1], fdim[l], 32, w.stat_f[l - 1], P.f(pi), P.f(pi + 1), n, fdim[l], fdim[l + 1],
-                                           TGNN_ACT_LEAKY_RELU, fbuf[l], fdim[l + 1], w.partf, &np1, w.bounds + 2 * D + 3 + 2 * (l - 1), 1,
-                                           w.bounds + 2 * D + 2 + 2 * (l - 1), s, dimg_ok[l] ? w.dimg[l] : nullptr));
+                                           TGNN_ACT_LEAKY_RELU, fbuf[l], fdim[l + 1], w.partf, &np1, final_bound_word(w, D, l) + 1, 1,
+                                           final_bound_word(w, D, l), s, dimg_ok[l] ? w.dimg[l] : nullptr));
             else
                 TGNN_TRY(tgnn_dense_act_fwd(fbuf[l - 1], fdim[l], 32, w.stat_f[l - 1], P.f(pi), P.f(pi + 1), n, fdim[l],
                                             fdim[l + 1], TGNN_ACT_LEAKY_RELU, fbuf[l], fdim[l + 1], w.partf, &np1, s));
@@ -936,7 +942,7 @@ extern "C" int tgnn_forward_begin(const tgnn_model_dims *dims, const void *const
     const Params P{params_host, D};
     const float *roots[kMaxDepth];
     for (int i = 0; i < D; ++i) roots[i] = P.f(P.layer(i) + 6);
-    launch_forward_scales(w.bounds, 2 * D + 8, roots, D, w.bounds + D + 1, nullptr, 0, nullptr, s2);
+    launch_forward_scales(w.bounds, 2 * D + 10, roots, D, w.bounds + D + 1, nullptr, 0, nullptr, s2);
     TGNN_TRY(forward_head_init(dims, P, x, w, n_nodes, update_running, w.bounds, s2));
     bool ok = false;
     TGNN_TRY(forward_head_bounds_images(dims, P, w, n_nodes, n_nodes, s2, &ok));

@@ -297,7 +297,12 @@ __global__ __launch_bounds__(kMlpThreads, 2) void gin32_mlp_kernel(
             __syncthreads();
             if (tid == 0) ticket = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
+#ifdef TGNN_ABL_NOFOLDWORK
+            if (ticket == gridDim.x - 1 && tid == 0) __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (false) {                                      // (timing ablation: see bn_fold_finish)
+#else
             if (ticket == gridDim.x - 1) {                    // (uniform)
+#endif
                 const int j = tid & 63, h = tid >> 6;
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {

@@ -1373,16 +1373,11 @@ static int prep_side_stream(hipStream_t *st, hipEvent_t *fork, hipEvent_t *join)
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return TGNN_ERR_INVALID_ARG;
     {
         std::lock_guard<std::mutex> lock(mu);
-        if (!streams[dev]) {
-            // [r6] the LOWEST priority: the de-duplication chain (57 us) has 60 us of slack against the CSR chain on the caller's
-            // stream, but its 1 M-thread insert kernel fills the chip and the CSR chain's small scans queued behind it (18 + 24 us
-            // for kernels that take 5 + 5 alone: profiles/r06_step_trace_100000.txt)
-            int least = 0, greatest = 0;
-            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
-            if (hipStreamCreateWithPriority(&streams[dev], hipStreamNonBlocking, least) != hipSuccess &&
-                hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess)
-                return TGNN_ERR_INVALID_ARG;
-        }
+        // ([r6] a LOWEST-priority stream was tried here -- the de-duplication's 1 M-thread insert kernel has the CSR chain's small scans
+        //  queue behind it -- and withdrawn: with it the full GPU suite lost the mid-size persistent kernel's edge-weight wait (reason
+        //  bits 4) once per run, in isolation never; another priority level is another pool of hardware queues, and which streams
+        //  then share a queue with the persistent kernel's is no longer what _lib.concurrent_streams measured)
+        if (!streams[dev] && hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess) return TGNN_ERR_INVALID_ARG;
     }
     if (!events[dev][0])
         for (int k = 0; k < 2; ++k)

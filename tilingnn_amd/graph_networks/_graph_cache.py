@@ -43,12 +43,14 @@ def clear():
     _entries.clear()
 
 
-def get_full(n_nodes, adj_e_index, adj_e_features, col_e_idx):
+def get_full(n_nodes, adj_e_index, adj_e_features, col_e_idx, build=None):
+    """build: what prepares the graph on a miss (default: ops.prepare_graph) -- TilinGNN.forward passes a builder that queues the
+    forward's graph-independent head beside the preparation."""
     ts = (adj_e_index, adj_e_features, col_e_idx)
     # (what a prepared graph carries depends on the size range of the mid-size persistent kernel and on the schedule its
     #  size is run by -- type columns and mid-size batches, or edge groups: part of the key)
     return _lookup(("full", n_nodes, ops.mid_layout_range(), ops.GROUPS and ops.runs_general_schedule(n_nodes)) + _key(*ts), ts,
-                   lambda: ops.prepare_graph(n_nodes, adj_e_index, adj_e_features, col_e_idx))
+                   build or (lambda: ops.prepare_graph(n_nodes, adj_e_index, adj_e_features, col_e_idx)))
 
 
 def get_adj(n_nodes, adj_e_index, adj_e_features):

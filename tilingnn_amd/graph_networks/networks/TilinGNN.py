@@ -202,7 +202,14 @@ class TilinGNN(Tracked, nn.Module):
         current stream, reads that word and, if it is set, runs the forward again on the general launch schedule (which the next
         256 forwards of the process take too: tgnn_persist_fallback).  ML_Solver.predict goes through here (it copies the probabilities to the
         host right away, so the synchronisation costs it nothing); forward() itself stays asynchronous."""
-        out = self._forward_one(x, adj_e_index, adj_e_features, col_e_idx, col_e_features)
+        try:
+            out = self._forward_one(x, adj_e_index, adj_e_features, col_e_idx, col_e_features)
+        except _lib.TgnnError as exc:
+            # an EARLIER, unchecked forward's persistent kernel gave up and this entry was the first to see it: the library has cleared
+            # the word and opened the fall-back window -- this call's own forward was not queued; queue it now, once
+            if exc.code != _lib.ERR_STALE_RESULT:
+                raise
+            out = self._forward_one(x, adj_e_index, adj_e_features, col_e_idx, col_e_features)
         dev = x.device
         code = C.c_uint32(0)
         check(lib.tgnn_spin_error_poll(_lib.current_stream(dev), C.byref(code)))
@@ -247,16 +254,13 @@ class TilinGNN(Tracked, nn.Module):
         ea = ops._f32c(adj_e_features, "adj_e_features")
         dims = self._dims()
         begun = False
-        if self.cache_graph:
-            graph = _graph_cache.get_full(n, adj_e_index, adj_e_features, col_e_idx)
-        else:
-            # a NEW layout of the general schedule: what the forward does in front of its first layer without the graph (bounds, init
-            # MLP, the final MLP's operand images) is queued on the side stream BEFORE the preparation and runs beside it
-            # (tgnn_forward_begin / tgnn_forward_resume; the workspace's layout does not depend on the type count up to 16)
-            # (the preparation's launches first -- its CSR chain is the critical one --, begin's behind them and in front of the
-            #  preparation's one synchronisation: ops.prepare_graph's after_enqueue)
-            state = {}
+        state = {}
 
+        def prepare_new():
+            # a NEW layout of the general schedule (cache off, or not in the cache): what the forward does in front of its first layer
+            # without the graph (bounds, init MLP, the final MLP's operand images) is queued on the side stream BEFORE the preparation
+            # and runs beside it (tgnn_forward_begin / tgnn_forward_resume; the workspace's layout does not depend on the type count
+            # up to 16).  _BEGIN_FIRST = 0: behind the preparation's launches, in front of its one synchronisation (after_enqueue).
             def begin():
                 state["bytes"] = lib.tgnn_forward_workspace_bytes(C.byref(dims), n, 0)
                 state["ws"] = torch.empty(state["bytes"], dtype=torch.uint8, device=dev)
@@ -273,19 +277,20 @@ class TilinGNN(Tracked, nn.Module):
             if use_begin and _BEGIN_FIRST:
                 begin()
             try:
-                graph = ops.prepare_graph(n, adj_e_index, adj_e_features, col_e_idx,
-                                          after_enqueue=begin if use_begin and not _BEGIN_FIRST else None)
-                begun = state.get("rc") == 0
-                if begun:
-                    ws, ws_bytes = state["ws"], state["bytes"]
-                elif state.get("rc") not in (None, _lib.ERR_UNSUPPORTED):
-                    check(state["rc"])
+                return ops.prepare_graph(n, adj_e_index, adj_e_features, col_e_idx,
+                                         after_enqueue=begin if use_begin and not _BEGIN_FIRST else None)
             except Exception:
-                begun = state.get("rc") == 0
-                side = _lib.side_stream_torch(dev) if begun else None
+                side = _lib.side_stream_torch(dev) if state.get("rc") == 0 else None
                 if side is not None:                                          # (begin's launches write the workspace freed below)
                     torch.cuda.current_stream(dev).wait_stream(side)
                 raise
+
+        graph = _graph_cache.get_full(n, adj_e_index, adj_e_features, col_e_idx, build=prepare_new) if self.cache_graph else prepare_new()
+        begun = state.get("rc") == 0
+        if begun:
+            ws, ws_bytes = state["ws"], state["bytes"]
+        elif state.get("rc") not in (None, _lib.ERR_UNSUPPORTED):
+            check(state["rc"])
         if begun and graph.n_types > 16:
             ws_need = lib.tgnn_forward_workspace_bytes(C.byref(dims), n, graph.n_types)       # (a larger edge-weight table: rare)
             if ws_need > ws_bytes:
