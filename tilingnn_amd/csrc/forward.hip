@@ -166,7 +166,7 @@ static Workspace carve(const tgnn_model_dims &d, int64_t n, int64_t nr, int32_t 
     w.small_runstat = cv.take<double>((size_t)D * 128);
     w.mid_part = cv.take<double>(mid_part_doubles());
     w.small_ctr = cv.take<unsigned>(64);
-    w.bounds = cv.take<unsigned>(2 * kMaxDepth + 12);
+    w.bounds = cv.take<unsigned>(2 * kMaxDepth + 32);
     {
         const int fd[4] = {c * (D + 1), kFinalDims[0], kFinalDims[1], kFinalDims[2]};
         for (int l = 0; l < 3; ++l) w.dimg[l] = cv.take<unsigned char>(dense_f16_image_size(fd[l], fd[l + 1]));
@@ -511,14 +511,15 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     // (what the init MLP's fused form needs is known here already: tgnn_forward_begin's work is used if and only if both hold)
     const bool init_fused_early = c == 32 && fx <= 8 && !sh && !keep && !use_running_stats && (g_lean_head.load(std::memory_order_relaxed) & 2);
     const bool head_used = head_done && lean_head && init_fused_early;
-    unsigned *fold_ctr = lean_head ? w.bounds + 2 * D + 7 : w.small_ctr + 32;
+    // (17 words: gin32_mlp_kernel folds the collision branch's BatchNorm in two levels -- a ticket per row group and one over the groups)
+    unsigned *fold_ctr = lean_head ? w.bounds + 2 * D + 10 : w.small_ctr + 32;
     if (f16) {
         const float *roots[kMaxDepth];
         for (int i = 0; i < D; ++i) roots[i] = P.f(P.layer(i) + 6);
         if (lean_head && head_done && init_fused_early)
             ;                                                 // (tgnn_forward_begin's, on the side stream)
         else if (lean_head)
-            launch_forward_scales(w.bounds, 2 * D + 10, roots, D, root_max, nullptr, 0, nullptr, s);
+            launch_forward_scales(w.bounds, 2 * D + 27, roots, D, root_max, nullptr, 0, nullptr, s);
         else
             launch_forward_scales(w.bounds, 2 * D + 7, roots, D, root_max, P.f(P.fin(0)), cat_w_floats, dense_max, s);   // (before the fork: both chains see the zeroed words)
     }
@@ -647,7 +648,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
 #else
     const bool fold_fin2 = c == 32 && !sh && !use_running_stats;
 #endif
-    if (fold_fin2 && !mid_k && !lean_head) TGNN_CHECK_HIP(hipMemsetAsync(fold_ctr, 0, sizeof(unsigned), s));   // (before ev[0]: the side chain sees it)
+    if (fold_fin2 && !mid_k && !lean_head) TGNN_CHECK_HIP(hipMemsetAsync(fold_ctr, 0, 17 * sizeof(unsigned), s));   // (before ev[0]: the side chain sees it)
     auto gin_layer = [&](int i, hipStream_t gs) -> int {
         const int b = P.layer(i);
         const float *gin_in = i == 0 ? w.mid : w.a2[(i - 1) & 1];
@@ -942,7 +943,7 @@ extern "C" int tgnn_forward_begin(const tgnn_model_dims *dims, const void *const
     const Params P{params_host, D};
     const float *roots[kMaxDepth];
     for (int i = 0; i < D; ++i) roots[i] = P.f(P.layer(i) + 6);
-    launch_forward_scales(w.bounds, 2 * D + 10, roots, D, w.bounds + D + 1, nullptr, 0, nullptr, s2);
+    launch_forward_scales(w.bounds, 2 * D + 27, roots, D, w.bounds + D + 1, nullptr, 0, nullptr, s2);
     TGNN_TRY(forward_head_init(dims, P, x, w, n_nodes, update_running, w.bounds, s2));
     bool ok = false;
     TGNN_TRY(forward_head_bounds_images(dims, P, w, n_nodes, n_nodes, s2, &ok));

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void gin32_aggregate_kernel(
 // tiles-per-SIMD quantisation of 32-row tiles were the cost); this one: see profiles/.
 // ------------------------------------------------------------------------------------------
 constexpr int kMlpWaves = 8, kMlpThreads = kMlpWaves * 64;
+constexpr int kGinGroupRow0 = TGNN_BN_MAX_PARTIALS - 16;      // [r6] the 16 group rows of gin32_mlp_kernel's two-level BatchNorm fold
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
@@ -288,50 +289,67 @@ __global__ __launch_bounds__(kMlpThreads, 2) void gin32_mlp_kernel(
                 bn_partial[(int64_t)blockIdx.x * 64 + tid] = tot;
         }
         if (fin.counter) {
-            // the last block to get here writes the BatchNorm's record: bn_finalize_kernel's reduction (16 row groups of the
-            // partial rows in order, then the fixed 16-way fold) with two groups per thread -- the same bits, no launch behind
+            // [r6] The BatchNorm's record in TWO levels (bn_finalize_kernel's tree -- 16 row groups p = g, g + 16, .. summed in
+            // ascending p, then the groups in ascending g: the same bits -- no launch behind).  One last block folding all ~224 rows
+            // was 7 us of serial tail per launch (ticket -> rows -> sums -> record with 255 CUs idle; without it the forward is 60 us
+            // shorter: profiles/r06_gin_fold_ablation.txt).  Now the last block OF A GROUP (ticket fin.counter[1 + g]) folds its
+            // group's ~14 rows into a group row as soon as they are there -- the groups finish at different times, most of this runs
+            // under the other blocks' tiles -- and only the last group-finisher (ticket fin.counter[0]) adds 16 group rows and
+            // writes the record.  Group rows: rows kGinGroupRow0 .. + 15 of bn_partial.  fin.counter: 17 zeroed words, left zeroed.
             __shared__ unsigned ticket;
-            __shared__ double fred[16 * 64];
             __shared__ double ftot[64];
+            const int g = (int)(blockIdx.x & 15u), np = (int)gridDim.x;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this block's row has been written through before its ticket
             __syncthreads();
-            if (tid == 0) ticket = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) ticket = __hip_atomic_fetch_add(fin.counter + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
+            const unsigned group_size = (unsigned)((np - g + 15) / 16);
 #ifdef TGNN_ABL_NOFOLDWORK
-            if (ticket == gridDim.x - 1 && tid == 0) __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ticket == group_size - 1 && tid == 0) __hip_atomic_store(fin.counter + 1 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (false) {                                      // (timing ablation: see bn_fold_finish)
 #else
-            if (ticket == gridDim.x - 1) {                    // (uniform)
+            if (ticket == group_size - 1) {                   // (uniform) the group's rows are all written
 #endif
-                const int j = tid & 63, h = tid >> 6;
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int g = h + 8 * half;
+                if (tid < 64) {
+                    // rows g, g + 16, ..: sixteen at a time (one batch up to 256 partial rows), added in ascending order
                     double acc = 0.0;
-                    const int np = (int)gridDim.x;
-                    int p = g;
-                    for (; p < np; p += 8 * 16) {             // eight coherent loads in flight (rows past the end read as 0)
-                        u32x2 v[8];
+                    for (int u0 = 0; g + u0 * 16 < np; u0 += 16) {
+                        u32x2 v[16];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int pp = p + u * 16;
-                            v[u] = __builtin_amdgcn_raw_buffer_load_b64(prs, pp < np ? ((uint32_t)pp * 64u + (uint32_t)j) * 8u : 0x80000000u, 0, kSc1);
+                        for (int u = 0; u < 16; ++u) {
+                            const int pp = g + (u0 + u) * 16;
+                            v[u] = __builtin_amdgcn_raw_buffer_load_b64(prs, pp < np ? ((uint32_t)pp * 64u + (uint32_t)tid) * 8u : 0x80000000u, 0, kSc1);
                         }
 #pragma unroll
-                        for (int u = 0; u < 8; ++u)
-                            if (p + u * 16 < np) acc += __builtin_bit_cast(double, v[u]);
+                        for (int u = 0; u < 16; ++u)
+                            if (g + (u0 + u) * 16 < np) acc += __builtin_bit_cast(double, v[u]);
                     }
-                    fred[g * 64 + j] = acc;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, acc), prs, ((uint32_t)(kGinGroupRow0 + g) * 64u + (uint32_t)tid) * 8u, 0, kSc1);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    __hip_atomic_store(fin.counter + 1 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ticket = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 __syncthreads();
-                if (tid < 64) {
-                    double t = 0.0;
-                    for (int gg = 0; gg < 16; ++gg) t += fred[gg * 64 + tid];
-                    ftot[tid] = t;
+                const unsigned n_groups = (unsigned)(np < 16 ? np : 16);
+                if (ticket == n_groups - 1) {                 // (uniform) all group rows are written
+                    if (tid < 64) {
+                        u32x2 v[16];
+#pragma unroll
+                        for (int gg = 0; gg < 16; ++gg)
+                            v[gg] = __builtin_amdgcn_raw_buffer_load_b64(prs, gg < (int)n_groups ? ((uint32_t)(kGinGroupRow0 + gg) * 64u + (uint32_t)tid) * 8u : 0x80000000u, 0, kSc1);
+                        double t = 0.0;
+#pragma unroll
+                        for (int gg = 0; gg < 16; ++gg)
+                            if (gg < (int)n_groups) t += __builtin_bit_cast(double, v[gg]);
+                        ftot[tid] = t;
+                    }
+                    __syncthreads();
+                    bn_record_from_sums(fin.job, ftot, 32, fin.n_total, fin.eps, fin.momentum);
+                    if (tid == 0) __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                __syncthreads();
-                bn_record_from_sums(fin.job, ftot, 32, fin.n_total, fin.eps, fin.momentum);
-                if (tid == 0) __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
