@@ -526,8 +526,9 @@ int32_t tgnn_set_dense_rows_mode(int32_t mode);
 /* The front of the general schedule (reference: graph_networks/networks/TilinGNN.py:54 and the operand preparation in front of the
  * first layer).  Bit 0: no memset in front of the first launch, the layer loop waits for the edge weights only (the final MLP's
  * bounds and operand images are one launch each behind them); bit 1: the init MLP as three launches that recompute from x
- * (csrc/init_mlp.hip; the same bits as the five launches it replaces).  Default 3; returns the previous setting (an argument
- * outside 0 .. 3 only queries). */
+ * (csrc/init_mlp.hip; the same bits as the five launches it replaces); bit 2 (off by default: measured no faster): the final MLP's
+ * BatchNorm records written by their producers (bn_fold_two_level) instead of a bn_finalize launch behind each -- the same bits.
+ * Default 3; returns the previous setting (an argument outside 0 .. 7 only queries). */
 int32_t tgnn_set_lean_head(int32_t bits);
 
 /* Small layouts (<= tgnn_graph_prep_small_max_nodes() nodes, <= ..._max_edges() edges per set): everything above --

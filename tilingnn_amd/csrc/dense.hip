@@ -532,7 +532,7 @@ __global__ __launch_bounds__(kRowsThreads, 2) void dense_f16_rows_kernel(
     const float *__restrict__ a, int64_t lda, int64_t a_kb_stride, int kps, const float *__restrict__ in_stat,
     const u32x4_ *__restrict__ wimg, const float *__restrict__ bias, int64_t n, int in_dim, int act, float *__restrict__ out,
     int64_t ldo, double *__restrict__ bn_partial, const unsigned *__restrict__ a_max, int n_a_max,
-    const unsigned *__restrict__ w_max) {
+    const unsigned *__restrict__ w_max, GinFin fin, double *__restrict__ fold_rows) {
     constexpr int N = 32 * TN, TNH = TN / 2;
     constexpr int kTileVec = 2 * TN * 2 * 64;                 // 16-byte pieces of one k-tile of the image
     constexpr int RB = kTileVec / kRowsThreads;               // ... per thread
@@ -672,8 +672,14 @@ __global__ __launch_bounds__(kRowsThreads, 2) void dense_f16_rows_kernel(
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int i = tid + kRowsThreads * h;
-            if (i < 2 * N) bn_partial[(int64_t)blockIdx.x * 2 * N + i] = bsum[h];
+            if (i < 2 * N) {
+                if (fin.counter) st_partial_sc1(bn_partial, (int64_t)blockIdx.x * 2 * N + i, bsum[h]);   // (another block of this launch reads it)
+                else bn_partial[(int64_t)blockIdx.x * 2 * N + i] = bsum[h];
+            }
         }
+        // [r6] the BatchNorm's record by the producer itself, in two levels (no bn_finalize launch behind the kernel); the dead image
+        // tiles are the fold's LDS
+        if (fin.counter) bn_fold_two_level<N>(fin, bn_partial, fold_rows, reinterpret_cast<double *>(Bs0), reinterpret_cast<unsigned *>(Bs1));
     }
 }
 
@@ -1075,7 +1081,7 @@ template <int TN, int CPT, int kResChunk = 2>                 // kResChunk k-til
 __global__ __launch_bounds__(kResThreads, 1) void dense_f16_resident_kernel(
     const float *__restrict__ a, int64_t lda, const float *__restrict__ in_stat, const u32x4_ *__restrict__ wimg,
     const float *__restrict__ bias, int64_t n, int act, float *__restrict__ out, int64_t ldo, double *__restrict__ bn_partial,
-    const unsigned *__restrict__ a_max, const unsigned *__restrict__ w_max) {
+    const unsigned *__restrict__ a_max, const unsigned *__restrict__ w_max, GinFin fin, double *__restrict__ fold_rows) {
     constexpr int N = 32 * TN, K = 32 * kResChunk * CPT, KT = K / kBK;
     constexpr int kTileVec = 2 * TN * 2 * 64;                 // 16-byte pieces of one k-tile of the image
     extern __shared__ __attribute__((aligned(1024))) unsigned char res_lds[];
@@ -1202,8 +1208,11 @@ __global__ __launch_bounds__(kResThreads, 1) void dense_f16_resident_kernel(
             double tot = 0.0;
 #pragma unroll
             for (int wv = 0; wv < 8; ++wv) tot += red[(wv * 2 + which) * N + cl];
-            bn_partial[(int64_t)blockIdx.x * 2 * N + i] = tot;
+            if (fin.counter) st_partial_sc1(bn_partial, (int64_t)blockIdx.x * 2 * N + i, tot);
+            else bn_partial[(int64_t)blockIdx.x * 2 * N + i] = tot;
         }
+        // [r6] the record by the producer itself (see dense_f16_rows_kernel); `red` is dead behind the helper's first barrier
+        if (fin.counter) bn_fold_two_level<N>(fin, bn_partial, fold_rows, red, reinterpret_cast<unsigned *>(red + 2 * N));
     }
 }
 
@@ -1239,7 +1248,8 @@ static int launch_dense_f16_rows2(hipStream_t s, const float *a, int64_t lda, in
 // 64 -> 32 (the final MLP's fourth Linear) on the resident kernel, one k-tile per request; -1 = not applicable
 static int launch_dense_f16_resident1(hipStream_t s, const float *a, int64_t lda, int64_t akb, int kps, const float *in_stat,
                                       const void *wimg, const float *b, int64_t n, int in_dim, int act, float *out, int64_t ldo,
-                                      double *bn_partial, const unsigned *a_max, int n_a_max, const unsigned *w_max) {
+                                      double *bn_partial, const unsigned *a_max, int n_a_max, const unsigned *w_max,
+                                      const GinFin &fin = GinFin{}, double *fold_rows = nullptr) {
     if (!(g_dense_resident.load(std::memory_order_relaxed) && in_stat && n_a_max == 1 && kps == 1 && akb == kBK && in_dim == 64 && lda % 4 == 0))
         return -1;
     const size_t lds1 = (size_t)in_dim * 32 * 4 + (size_t)4 * in_dim * sizeof(float) + (size_t)8 * 2 * 32 * sizeof(double);
@@ -1247,14 +1257,18 @@ static int launch_dense_f16_resident1(hipStream_t s, const float *a, int64_t lda
     if (blocks1 > device_cus()) blocks1 = device_cus();
     if (blocks1 < 1) blocks1 = 1;
     dense_f16_resident_kernel<1, 2, 1><<<blocks1, kResThreads, lds1, s>>>(a, lda, in_stat, static_cast<const u32x4_ *>(wimg), b, n, act, out,
-                                                                        ldo, bn_partial, a_max, w_max);
+                                                                        ldo, bn_partial, a_max, w_max, fin, fold_rows);
     return blocks1;
 }
 
+// fin.counter != NULL: the kernel writes the BatchNorm's record itself (bn_fold_two_level) and *folded is set -- the rows and the
+// resident kernels; the experimental ones leave *folded alone (the caller's finalize launch follows)
 template <int TN>
 static int launch_dense_f16_rows(hipStream_t s, const float *a, int64_t lda, int64_t akb, int kps, const float *in_stat,
                                  const void *wimg, const float *b, int64_t n, int in_dim, int act, float *out, int64_t ldo,
-                                 double *bn_partial, const unsigned *a_max, int n_a_max, const unsigned *w_max) {
+                                 double *bn_partial, const unsigned *a_max, int n_a_max, const unsigned *w_max,
+                                 const GinFin &fin_in = GinFin{}, double *fold_rows = nullptr, bool *folded = nullptr) {
+    GinFin fin = (bn_partial && fold_rows && folded) ? fin_in : GinFin{};
     // [r6] BatchNorm-on-load layers whose whole image fits LDS: the barrier-free resident kernel
     if constexpr (TN == 4 || TN == 2)
     if (g_dense_resident.load(std::memory_order_relaxed) && in_stat && n_a_max == 1 && kps == 1 && akb == kBK && (in_dim == 128 || in_dim == 256) &&
@@ -1269,12 +1283,15 @@ static int launch_dense_f16_rows(hipStream_t s, const float *a, int64_t lda, int
         if (in_dim == 256) {
             static LdsOptIn site;
             (void)opt_in_dynamic_lds(dense_f16_resident_kernel<TN, 4>, 160 * 1024 - 256, site);
-            dense_f16_resident_kernel<TN, 4><<<blocks, kResThreads, lds, s>>>(a, lda, in_stat, img, b, n, act, out, ldo, bn_partial, a_max, w_max);
+            dense_f16_resident_kernel<TN, 4><<<blocks, kResThreads, lds, s>>>(a, lda, in_stat, img, b, n, act, out, ldo, bn_partial, a_max, w_max, fin,
+                                                                              fold_rows);
         } else {
             static LdsOptIn site;
             (void)opt_in_dynamic_lds(dense_f16_resident_kernel<TN, 2>, 160 * 1024 - 256, site);
-            dense_f16_resident_kernel<TN, 2><<<blocks, kResThreads, lds, s>>>(a, lda, in_stat, img, b, n, act, out, ldo, bn_partial, a_max, w_max);
+            dense_f16_resident_kernel<TN, 2><<<blocks, kResThreads, lds, s>>>(a, lda, in_stat, img, b, n, act, out, ldo, bn_partial, a_max, w_max, fin,
+                                                                              fold_rows);
         }
+        if (fin.counter) *folded = true;
         return blocks;
     }
     if constexpr (TN == 8)
@@ -1301,11 +1318,12 @@ static int launch_dense_f16_rows(hipStream_t s, const float *a, int64_t lda, int
         static LdsOptIn site;
         if (TN == 8) (void)opt_in_dynamic_lds(dense_f16_rows_kernel<TN, true>, (int)lds, site);
         dense_f16_rows_kernel<TN, true><<<blocks, kRowsThreads, lds, s>>>(a, lda, akb, kps, in_stat, img, b, n, in_dim, act, out, ldo,
-                                                                         bn_partial, a_max, n_a_max, w_max);
+                                                                         bn_partial, a_max, n_a_max, w_max, fin, fold_rows);
     } else {
         dense_f16_rows_kernel<TN, false><<<blocks, kRowsThreads, lds, s>>>(a, lda, akb, kps, nullptr, img, b, n, in_dim, act, out, ldo,
-                                                                          bn_partial, a_max, n_a_max, w_max);
+                                                                          bn_partial, a_max, n_a_max, w_max, fin, fold_rows);
     }
+    if (fin.counter) *folded = true;
     return blocks;
 }
 
@@ -1423,7 +1441,9 @@ static int dense_act_impl(const float *a, int64_t lda, int64_t a_kblock_stride, 
                           const float *w, const float *b, int64_t n_rows, int32_t in_dim, int32_t out_dim, int32_t act,
                           float *out, int64_t ldo, double *bn_partial, int32_t *n_partials_host, tgnn_stream_t stream,
                           const unsigned *a_max = nullptr, int n_a_max = 0, const unsigned *w_max = nullptr,
-                          const void *wimg = nullptr) {
+                          const void *wimg = nullptr, const GinFin *fold = nullptr, double *fold_rows = nullptr, bool *folded = nullptr) {
+    const GinFin fin = (fold && fold_rows && folded && fold->counter) ? *fold : GinFin{};
+    if (folded) *folded = false;
     TGNN_CHECK_ARG(n_rows >= 0 && in_dim >= 1 && out_dim >= 1, "shape");
     TGNN_CHECK_ARG(act >= TGNN_ACT_NONE && act <= TGNN_ACT_SIGMOID, "activation");
     if (n_rows == 0) {
@@ -1480,8 +1500,9 @@ static int dense_act_impl(const float *a, int64_t lda, int64_t a_kblock_stride, 
     if (fast && !exact_only && out_dim == 32 && in_dim == 64 && a_max && w_max && n_a_max == 1 && wimg && in_stat &&
         n_rows >= kDenseRowsKernelMin && ((uintptr_t)wimg % 16) == 0) {
         const int nb = launch_dense_f16_resident1(s, a, lda, a_kblock_stride, kps, in_stat, wimg, b, n_rows, in_dim, act, out, ldo, bn_partial,
-                                                  a_max, n_a_max, w_max);
+                                                  a_max, n_a_max, w_max, bn_partial ? fin : GinFin{}, fold_rows);
         if (nb > 0) {
+            if (fin.counter && bn_partial) *folded = true;
             if (n_partials_host) *n_partials_host = nb;
             TGNN_CHECK_LAUNCH();
             return TGNN_OK;
@@ -1506,13 +1527,13 @@ static int dense_act_impl(const float *a, int64_t lda, int64_t a_kblock_stride, 
             int nb;
             if (out_dim == 256)
                 nb = launch_dense_f16_rows<8>(s, a, lda, a_kblock_stride, kps, in_stat, wimg, b, n_rows, in_dim, act, out, ldo, bn_partial,
-                                              a_max, n_a_max, w_max);
+                                              a_max, n_a_max, w_max, fin, fold_rows, folded);
             else if (out_dim == 128)
                 nb = launch_dense_f16_rows<4>(s, a, lda, a_kblock_stride, kps, in_stat, wimg, b, n_rows, in_dim, act, out, ldo, bn_partial,
-                                              a_max, n_a_max, w_max);
+                                              a_max, n_a_max, w_max, fin, fold_rows, folded);
             else
                 nb = launch_dense_f16_rows<2>(s, a, lda, a_kblock_stride, kps, in_stat, wimg, b, n_rows, in_dim, act, out, ldo, bn_partial,
-                                              a_max, n_a_max, w_max);
+                                              a_max, n_a_max, w_max, fin, fold_rows, folded);
             if (n_partials_host) *n_partials_host = nb;
             TGNN_CHECK_LAUNCH();
             return TGNN_OK;
@@ -1603,9 +1624,9 @@ namespace tgnn {
 int dense_act_bounded(const float *a, int64_t lda, int64_t a_kblock_stride, const float *in_stat, const float *w, const float *b,
                       int64_t n_rows, int32_t in_dim, int32_t out_dim, int32_t act, float *out, int64_t ldo, double *bn_partial,
                       int32_t *n_partials_host, const unsigned *a_max, int n_a_max, const unsigned *w_max, hipStream_t s,
-                      const void *wimg) {
+                      const void *wimg, const GinFin *fold, double *fold_group_rows, bool *folded) {
     return dense_act_impl(a, lda, a_kblock_stride, 1, in_stat, w, b, n_rows, in_dim, out_dim, act, out, ldo, bn_partial,
-                          n_partials_host, s, a_max, n_a_max, w_max, wimg);
+                          n_partials_host, s, a_max, n_a_max, w_max, wimg, fold, fold_group_rows, folded);
 }
 size_t dense_f16_image_size(int in_dim, int out_dim) { return align_up(dense_f16_image_bytes(in_dim, out_dim), 256); }
 // W [out_dim][in_dim] -> the fp16-pair operand image dense_f16_rows_kernel reads (scaled by w_max's power of two)
@@ -1665,9 +1686,10 @@ int dense_f16_images_build(int n_jobs, const float *const *w, const int *in_dim,
 int dense_act_slots_bounded(const float *a, int32_t slot_width, int64_t slot_stride, const float *w, const float *b,
                             int64_t n_rows, int32_t in_dim, int32_t out_dim, int32_t act, float *out, int64_t ldo,
                             double *bn_partial, int32_t *n_partials_host, const unsigned *a_max, int n_a_max,
-                            const unsigned *w_max, hipStream_t s, const void *wimg) {
+                            const unsigned *w_max, hipStream_t s, const void *wimg, const GinFin *fold, double *fold_group_rows,
+                            bool *folded) {
     return dense_act_impl(a, slot_width, slot_stride, slot_width / 32, nullptr, w, b, n_rows, in_dim, out_dim, act, out, ldo,
-                          bn_partial, n_partials_host, s, a_max, n_a_max, w_max, wimg);
+                          bn_partial, n_partials_host, s, a_max, n_a_max, w_max, wimg, fold, fold_group_rows, folded);
 }
 }  // namespace tgnn
 

@@ -166,7 +166,7 @@ static Workspace carve(const tgnn_model_dims &d, int64_t n, int64_t nr, int32_t 
     w.small_runstat = cv.take<double>((size_t)D * 128);
     w.mid_part = cv.take<double>(mid_part_doubles());
     w.small_ctr = cv.take<unsigned>(64);
-    w.bounds = cv.take<unsigned>(2 * kMaxDepth + 32);
+    w.bounds = cv.take<unsigned>(2 * kMaxDepth + 100);
     {
         const int fd[4] = {c * (D + 1), kFinalDims[0], kFinalDims[1], kFinalDims[2]};
         for (int l = 0; l < 3; ++l) w.dimg[l] = cv.take<unsigned char>(dense_f16_image_size(fd[l], fd[l + 1]));
@@ -197,7 +197,7 @@ extern "C" int32_t tgnn_set_nnconv_eg(int32_t on) {
     return g_nnconv_eg.exchange(on);
 }
 extern "C" int32_t tgnn_set_lean_head(int32_t bits) {
-    if (bits < 0 || bits > 3) return g_lean_head.load();
+    if (bits < 0 || bits > 7) return g_lean_head.load();
     return g_lean_head.exchange(bits);
 }
 extern "C" const char *tgnn_last_error(void) { return g_err; }
@@ -519,7 +519,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         if (lean_head && head_done && init_fused_early)
             ;                                                 // (tgnn_forward_begin's, on the side stream)
         else if (lean_head)
-            launch_forward_scales(w.bounds, 2 * D + 27, roots, D, root_max, nullptr, 0, nullptr, s);
+            launch_forward_scales(w.bounds, 2 * D + 95, roots, D, root_max, nullptr, 0, nullptr, s);
         else
             launch_forward_scales(w.bounds, 2 * D + 7, roots, D, root_max, P.f(P.fin(0)), cat_w_floats, dense_max, s);   // (before the fork: both chains see the zeroed words)
     }
@@ -863,15 +863,31 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     const int cat_dim = c * (D + 1);
     float *fbuf[4] = {w.f1, w.f2, w.f3, w.f4};
     int fdim[5] = {cat_dim, kFinalDims[0], kFinalDims[1], kFinalDims[2], c};
+    // [r6] the final MLP's BatchNorm records by their producers (bn_fold_two_level in the rows / resident kernels: the same bits) instead
+    // of a 7 us bn_finalize launch behind each; 17 counter words per layer behind the collision branch's, cleared by the scales kernel
+    // (bit 2 of tgnn_set_lean_head, OFF by default: measured, every producer grew by the 6 - 8 us its finalize launch took -- all of
+    //  a dense kernel's blocks finish together, so both levels of the fold are serial latency behind the last one, unlike in the
+    //  collision MLP, whose row groups finish at different times: profiles/r06_tail_fold.txt)
+    const bool fold_final = lean_head && !sh && !use_running_stats && c == 32 && (g_lean_head.load(std::memory_order_relaxed) & 4);
     for (int l = 0; l < 4; ++l) {
         const int pi = P.fin(l);
+        GinFin ff{};
+        bool folded = false;
+        if (fold_final) {
+            ff.counter = w.bounds + 2 * D + 27 + 17 * l;
+            ff.job = bn_job(nullptr, 0, P.bn(pi + 2), w.stat_f[l]);
+            ff.n_total = n;
+            ff.eps = eps;
+            ff.momentum = momentum;
+        }
+        double *fold_rows = w.small_part_wide + (size_t)l * 16 * 512;
         if (l == 0) {
             TGNN_CHECK_ARG(c % 32 == 0, "final MLP over the slot-major buffer needs a network_width that is a multiple of 32");
             prof.begin(6);
             if (f16)
                 TGNN_TRY(dense_act_slots_bounded(w.mid, c, (int64_t)nr * c, P.f(pi), P.f(pi + 1), n, cat_dim, fdim[1],
                                                  TGNN_ACT_LEAKY_RELU, fbuf[0], fdim[1], w.partf, &np1, slot_max, D + 1, dense_max, s,
-                                                 dimg_ok[0] ? w.dimg[0] : nullptr));
+                                                 dimg_ok[0] ? w.dimg[0] : nullptr, fold_final ? &ff : nullptr, fold_rows, &folded));
             else
                 TGNN_TRY(tgnn_dense_act_slots_fwd(w.mid, c, (int64_t)nr * c, nullptr, P.f(pi), P.f(pi + 1), n, cat_dim, fdim[1],
                                                   TGNN_ACT_LEAKY_RELU, fbuf[0], fdim[1], w.partf, &np1, s));
@@ -881,13 +897,14 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
             if (f16 && (l <= 2 || dimg_ok[l]))   // fp16 pairs: the input's bound follows from the producer's BatchNorm parameters (dense_bounds_kernel)
                 TGNN_TRY(dense_act_bounded(fbuf[l - 1], fdim[l], 32, w.stat_f[l - 1], P.f(pi), P.f(pi + 1), n, fdim[l], fdim[l + 1],
                                            TGNN_ACT_LEAKY_RELU, fbuf[l], fdim[l + 1], w.partf, &np1, final_bound_word(w, D, l) + 1, 1,
-                                           final_bound_word(w, D, l), s, dimg_ok[l] ? w.dimg[l] : nullptr));
+                                           final_bound_word(w, D, l), s, dimg_ok[l] ? w.dimg[l] : nullptr, fold_final ? &ff : nullptr, fold_rows,
+                                           &folded));
             else
                 TGNN_TRY(tgnn_dense_act_fwd(fbuf[l - 1], fdim[l], 32, w.stat_f[l - 1], P.f(pi), P.f(pi + 1), n, fdim[l],
                                             fdim[l + 1], TGNN_ACT_LEAKY_RELU, fbuf[l], fdim[l + 1], w.partf, &np1, s));
             prof.end();
         }
-        TGNN_TRY(finalize1(w.partf, np1, fdim[l + 1], P.bn(pi + 2), w.stat_f[l]));
+        if (!folded) TGNN_TRY(finalize1(w.partf, np1, fdim[l + 1], P.bn(pi + 2), w.stat_f[l]));
     }
     prof.begin(6);
     TGNN_TRY(tgnn_dense_act_fwd(fbuf[3], c, 32, w.stat_f[3], P.f(P.last()), P.f(P.last() + 1), n, c, dims->output_dim,
@@ -943,7 +960,7 @@ extern "C" int tgnn_forward_begin(const tgnn_model_dims *dims, const void *const
     const Params P{params_host, D};
     const float *roots[kMaxDepth];
     for (int i = 0; i < D; ++i) roots[i] = P.f(P.layer(i) + 6);
-    launch_forward_scales(w.bounds, 2 * D + 27, roots, D, w.bounds + D + 1, nullptr, 0, nullptr, s2);
+    launch_forward_scales(w.bounds, 2 * D + 95, roots, D, w.bounds + D + 1, nullptr, 0, nullptr, s2);
     TGNN_TRY(forward_head_init(dims, P, x, w, n_nodes, update_running, w.bounds, s2));
     bool ok = false;
     TGNN_TRY(forward_head_bounds_images(dims, P, w, n_nodes, n_nodes, s2, &ok));

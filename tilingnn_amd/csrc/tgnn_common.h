@@ -364,6 +364,65 @@ __device__ __forceinline__ void bn_fold_finish(const GinFin &fin, double *bn_par
     bn_record_from_sums(fin.job, ftot, F, fin.n_total, fin.eps, fin.momentum);
     if (tid == 0) __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// [r6] The same in TWO levels, for any width F <= blockDim.x: called by ALL threads of every block after the block's partial row
+// (2 F doubles at bn_partial + blockIdx.x * 2 F) has been stored with st_partial_sc1.  The last block of each of the 16 row
+// GROUPS g = blockIdx.x & 15 (ticket fin.counter[1 + g]) folds its group's rows in ascending order into group_rows[g]; the last
+// group-finisher (ticket fin.counter[0]) adds the group rows in ascending g and writes the record -- bn_finalize_kernel's tree,
+// the same bits -- so that only 16 rows are folded behind the kernel's last block instead of all of them.  fin.counter: 17
+// zeroed words, left zeroed; group_rows: 16 x 2 F doubles; ftot: 2 F doubles of LDS, ticket: one LDS word (both free to reuse
+// dead tiles).  fin.job.n_partials is not read (gridDim.x rows).
+template <int F>
+__device__ __forceinline__ void bn_fold_two_level(const GinFin &fin, double *bn_partial, double *group_rows, double *ftot,
+                                                  unsigned *ticket) {
+    using u32x2_ = __attribute__((ext_vector_type(2))) unsigned int;
+    constexpr int kRow = 2 * F, kSc1 = 16;
+    const int tid = threadIdx.x, nthr = blockDim.x, np = (int)gridDim.x, g = (int)(blockIdx.x & 15u);
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(bn_partial, 0, (int)0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(group_rows, 0, (int)0x80000000u, 0x00020000);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this block's row has been written through before its ticket
+    __syncthreads();
+    if (tid == 0) *ticket = __hip_atomic_fetch_add(fin.counter + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*ticket != (unsigned)((np - g + 15) / 16) - 1u) return;   // (uniform) not the last of its group
+    for (int j = tid; j < kRow; j += nthr) {
+        double acc = 0.0;
+        for (int u0 = 0; g + u0 * 16 < np; u0 += 16) {        // sixteen rows at a time: one batch up to 256 partial rows
+            u32x2_ v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int pp = g + (u0 + u) * 16;
+                v[u] = __builtin_amdgcn_raw_buffer_load_b64(prs, pp < np ? ((uint32_t)pp * (uint32_t)kRow + (uint32_t)j) * 8u : 0x80000000u, 0, kSc1);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (g + (u0 + u) * 16 < np) acc += __builtin_bit_cast(double, v[u]);
+        }
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, acc), grs, ((uint32_t)g * (uint32_t)kRow + (uint32_t)j) * 8u, 0, kSc1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store(fin.counter + 1 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *ticket = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const int n_groups = np < 16 ? np : 16;
+    if (*ticket != (unsigned)n_groups - 1u) return;          // (uniform) not the last group-finisher
+    for (int j = tid; j < kRow; j += nthr) {
+        u32x2_ v[16];
+#pragma unroll
+        for (int gg = 0; gg < 16; ++gg)
+            v[gg] = __builtin_amdgcn_raw_buffer_load_b64(grs, gg < n_groups ? ((uint32_t)gg * (uint32_t)kRow + (uint32_t)j) * 8u : 0x80000000u, 0, kSc1);
+        double t = 0.0;
+#pragma unroll
+        for (int gg = 0; gg < 16; ++gg)
+            if (gg < n_groups) t += __builtin_bit_cast(double, v[gg]);
+        ftot[j] = t;
+    }
+    __syncthreads();
+    bn_record_from_sums(fin.job, ftot, F, fin.n_total, fin.eps, fin.momentum);
+    if (tid == 0) __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // one block per job (1 or 2 BatchNorms of the same width finalised by one launch); bn_merge.hip
 void launch_bn_finalize(const BnJobs &jobs, int n_jobs, int mode, int f, int64_t n_total, float eps, float momentum,
                         hipStream_t s);
@@ -460,10 +519,12 @@ void launch_absmax(const float *h, int64_t n_floats, unsigned *max_bits, hipStre
 void launch_dense_bounds(int n_jobs, const float *const *w, const int64_t *w_n, const float *const *gamma, const float *const *beta,
                          const int *f, unsigned *const *w_max, unsigned *const *a_max, int64_t n_total, hipStream_t s);
 // tgnn_dense_act_fwd with bounds of both operands (a_max: of the input AFTER in_stat's BatchNorm, if any): dense.hip
+// [r6] fold (counter != NULL) + fold_group_rows (16 x 2 out_dim doubles): the kernels that can -- the rows and the resident kernels --
+// write the BatchNorm's record themselves (bn_fold_two_level) and set *folded; otherwise the caller launches its finalize
 int dense_act_bounded(const float *a, int64_t lda, int64_t a_kblock_stride, const float *in_stat, const float *w, const float *b,
                       int64_t n_rows, int32_t in_dim, int32_t out_dim, int32_t act, float *out, int64_t ldo, double *bn_partial,
                       int32_t *n_partials_host, const unsigned *a_max, int n_a_max, const unsigned *w_max, hipStream_t s,
-                      const void *wimg = nullptr);
+                      const void *wimg = nullptr, const GinFin *fold = nullptr, double *fold_group_rows = nullptr, bool *folded = nullptr);
 // the fp16-pair operand image of a Linear's W [out_dim][in_dim] (out_dim 64 / 128 / 256, in_dim % 32 == 0) that routes
 // dense_act_bounded / dense_act_slots_bounded to the rows-per-wave kernel (dense.hip: dense_f16_rows_kernel)
 constexpr int64_t kDenseRowsKernelMin = 49152;       // rows from which that kernel is taken (below: the block-tile kernels win)
@@ -477,7 +538,8 @@ int dense_f16_images_build(int n_jobs, const float *const *w, const int *in_dim,
 int dense_act_slots_bounded(const float *a, int32_t slot_width, int64_t slot_stride, const float *w, const float *b,
                             int64_t n_rows, int32_t in_dim, int32_t out_dim, int32_t act, float *out, int64_t ldo,
                             double *bn_partial, int32_t *n_partials_host, const unsigned *a_max, int n_a_max,
-                            const unsigned *w_max, hipStream_t s, const void *wimg = nullptr);
+                            const unsigned *w_max, hipStream_t s, const void *wimg = nullptr, const GinFin *fold = nullptr,
+                            double *fold_group_rows = nullptr, bool *folded = nullptr);
 // the MLP half of tgnn_gin_fwd (width 32) behind tgnn_gin_aggregate; gin.hip
 // experiment knob (tgnn_debug_set_block_caps): upper bounds of the whole-CU kernels' grids, 0 = the built-in policy
 extern std::atomic<int> g_debug_block_cap[2];   // [0] column NNConv, [1] GIN MLP
