@@ -1963,7 +1963,26 @@ extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edge
         if (s_side && hipEventRecord(ev_join, s_side) == hipSuccess) (void)hipStreamWaitEvent(s, ev_join, 0);
         return code;
     };
-    // [r6] the CSR chain is the longer one (90 against 57 us) and the host needs ~4 us per launch: its launches are queued FIRST
+    // [r6] the host needs ~4 us per launch, so the order of the two chains' launches matters: at benchmark sizes the CSR chain is the longer
+    // one (90 against 57 us at 100 000 nodes) and goes FIRST; on smaller layouts the chains are level (29 against 23 us at 10 000 nodes) and
+    // the de-duplication, which has one launch more in front of its first kernel, goes first as it always did (measured the other way round:
+    // +20 us at 10 000 nodes, profiles/r06_prep_trace_10000.txt)
+    const bool csr_first = n_adj_edges + n_col_edges >= 1000000;
+    auto queue_dedup = [&]() -> int {
+        if (!s_side) return TGNN_OK;
+        rc = edge_type_dedup_listed(adj_edge_attr, n_adj_edges, fe, edge_type, type_rep_edge, result + 0, result + 6, ws_dd, dd_b, s_side);
+        if (rc != TGNN_OK) return bail(rc);
+        if (hipEventRecord(ev_join, s_side) != hipSuccess) {
+            (void)hipStreamSynchronize(s_side);
+            set_error("tgnn_graph_prep: hipEventRecord failed");
+            return TGNN_ERR_LAUNCH;
+        }
+        return TGNN_OK;
+    };
+    if (!csr_first) {
+        const int rcd = queue_dedup();
+        if (rcd != TGNN_OK) return rcd;
+    }
     if (bk_fits(n_nodes) && n_adj_edges < (int64_t(1) << 31) - 1 && n_col_edges < (int64_t(1) << 31) - 1) {
         // both CSRs through 512-row buckets: four kernels + one scan, no device-scope returning atomic
         const size_t bk_b = bk_workspace_bytes(n_nodes, n_adj_edges, n_col_edges);
@@ -1978,14 +1997,9 @@ extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edge
         rc = tgnn_csr_build(col_edge_index, n_col_edges, n_nodes, n_src_nodes, 1, col_rowptr, col_src, col_eid, result + 2, ws_csr, csr_b, stream);
         if (rc != TGNN_OK) return bail(rc);
     }
-    if (s_side) {
-        rc = edge_type_dedup_listed(adj_edge_attr, n_adj_edges, fe, edge_type, type_rep_edge, result + 0, result + 6, ws_dd, dd_b, s_side);
-        if (rc != TGNN_OK) return bail(rc);
-        if (hipEventRecord(ev_join, s_side) != hipSuccess) {
-            (void)hipStreamSynchronize(s_side);
-            set_error("tgnn_graph_prep: hipEventRecord failed");
-            return TGNN_ERR_LAUNCH;
-        }
+    if (csr_first) {
+        const int rcd = queue_dedup();
+        if (rcd != TGNN_OK) return rcd;
     }
     if (s_side) {
         TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev_join, 0));
