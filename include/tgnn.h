@@ -437,6 +437,11 @@ typedef struct tgnn_shard {
      * (host, [world]): rows sent to / received from every peer in one exchange, without the extra rows. */
     void *rccl_comm, *rccl_comm_side;
     const int64_t *send_counts, *recv_counts;
+    /* [r6] optional (NULL: a pack launch behind every NNConv), split exchange: the INVERSE of send_idx_fused -- for own row v the
+     * message rows that carry it are send_row_slot[send_row_ptr[v] .. send_row_ptr[v + 1]) (device, int32, [n_own + 1] and
+     * [n_send]).  With them the NNConv's epilogue writes the adjacency branch's halo message itself and its last block the
+     * BatchNorm sums: one launch less on the step's critical chain per layer. */
+    const int32_t *send_row_ptr, *send_row_slot;
 } tgnn_shard;
 
 /* RCCL communicators for tgnn_shard.rccl_comm.  RCCL is looked up at run time (librccl.so.1, the copy already in the process

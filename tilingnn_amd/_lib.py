@@ -63,7 +63,8 @@ class ShardDesc(C.Structure):
                 ("allreduce_f64", ALLREDUCE_CB), ("alltoall_rows", ALLTOALL_CB), ("ctx", C.c_void_p),
                 ("world", C.c_int32), ("rank", C.c_int32), ("send_idx_fused", C.c_void_p), ("recv_idx_fused", C.c_void_p),
                 ("side_stream", C.c_void_p), ("rccl_comm", C.c_void_p), ("rccl_comm_side", C.c_void_p),
-                ("send_counts", C.c_void_p), ("recv_counts", C.c_void_p)]
+                ("send_counts", C.c_void_p), ("recv_counts", C.c_void_p),
+                ("send_row_ptr", C.c_void_p), ("send_row_slot", C.c_void_p)]
 
 
 def _load() -> C.CDLL:

@@ -743,10 +743,16 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         }
         // GraphConv (:62): NNConv mean + LeakyReLU; BN statistics emitted as partials
         prof.begin(2);
+        // [r6] sharded, split exchange: the pack of the adjacency branch's message inside the NNConv (nnconv_eg.hip: SHARD)
+        const bool pack_in_nnconv = eg && split && i + 1 < D && sh->send_row_ptr && sh->send_row_slot && lean_head;
         if (eg) {
+            EgShardPack pk{};
+            if (pack_in_nnconv)
+                pk = EgShardPack{sh->send_row_ptr, sh->send_row_slot, sh->send_buf, sh->send_idx_fused, sh->n_send + 4 * (int64_t)sh->world,
+                                 sh->sum_buf, w.bounds + 2 * D + 27, w.small_part_wide + (size_t)4 * 16 * 512};
             TGNN_TRY(launch_nnconv_eg(h1, graph->nn_tile_grp_ptr, graph->nn_grp, w.wimg + (size_t)i * (T + 1) * kWtTypeF16, T,
                                       P.f(b + 7), n, TGNN_ACT_LEAKY_RELU, w.a1, w.part1, &np1, s, slot_max + i, root_max + i,
-                                      prof.stamps ? prof.stamps + 2 * i : nullptr));
+                                      prof.stamps ? prof.stamps + 2 * i : nullptr, pack_in_nnconv ? &pk : nullptr));
         } else if (tiled) {
             TGNN_TRY(launch_nnconv_cols(h1, c, graph->nn_tile_col_ptr, graph->nn_col_meta, graph->nn_col_src,
                                         w.wimg + (size_t)i * (T + 1) * (f16 ? kWtTypeF16 : kWtType), T, P.f(b + 7), n,
@@ -765,7 +771,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
             BnJob j1 = bn_job(w.part1, np1, P.bn(b + 8), w.stat1);
             j1.sums = sh->sum_buf;
             const int64_t n_out = sh->n_send + 4 * (int64_t)sh->world, n_in = n_halo + 4 * (int64_t)sh->world;
-            launch_shard_pack1(w.a1, sh->send_idx_fused, n_out, j1, sh->send_buf, s);
+            if (!pack_in_nnconv) launch_shard_pack1(w.a1, sh->send_idx_fused, n_out, j1, sh->send_buf, s);
             TGNN_TRY(alltoall(sh->send_buf, sh->recv_buf, c, 4, s));
             const float *resid_f = i >= 2 ? w.mid + (size_t)(i - 2) * nr * c : nullptr;
             TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[1 + i], 0));

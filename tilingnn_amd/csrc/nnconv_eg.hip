@@ -64,12 +64,27 @@ __device__ __forceinline__ void split_pair_f16(float a0, float a1, unsigned &hi,
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 
-template <int WAVES, int OCC, int ACT>
+// [r6] SHARD: the sharded step's pack launch inside this kernel (forward.hip, split exchange: NNConv -> pack -> all-to-all -> ... is a
+// serial chain of launches with a 4 - 12 us gap each).  The epilogue also stores a row into every message slot that carries it
+// (send_row_ptr / send_row_slot: the inverse of the message's row list), and the LAST block to finish (two-level ticket fold of the
+// partial rows, bn_finalize_kernel's tree: the same bits as shard_pack1_kernel's block 0) writes the shard's BatchNorm sums into
+// `sums` and into the message's sums rows (msg_idx[r] = -1 - k: sums row k).
+struct EgShard {
+    const int *send_row_ptr, *send_row_slot;   // [n + 1], [n_send]: message rows that carry row v
+    float *msg;                                // the message, 32 floats per row
+    const int *msg_idx;                        // [n_msg]: >= 0 a row of this shard, -1 - k the sums row k
+    int64_t n_msg;
+    double *sums;                              // [64] this shard's sums (read by the unpack side for the own rank)
+    unsigned *counter;                         // 17 zeroed words, left zeroed
+    double *group_rows;                        // 16 x 64 doubles
+};
+
+template <int WAVES, int OCC, int ACT, bool SHARD = false>
 __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_eg_kernel(
     const float *__restrict__ h, const int *__restrict__ tile_grp_ptr, const int2 *__restrict__ grp,
     const float *__restrict__ wimg, int n_types, const float *__restrict__ bias, int64_t n,
     int act, float *__restrict__ out, double *__restrict__ bn_partial, const unsigned *__restrict__ h_max,
-    const unsigned *__restrict__ root_max, unsigned long long *__restrict__ stamp) {
+    const unsigned *__restrict__ root_max, unsigned long long *__restrict__ stamp, EgShard sh = EgShard{}) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (stamp && threadIdx.x == 0) atomicMin(stamp, wall_clock64());
     constexpr int kTy = kWtTypeF16;                         // floats of one type's image
@@ -249,6 +264,14 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_eg_kernel(
             if (valid) {
                 out[v * 32 + fj] = o0;
                 out[v * 32 + 16 + fj] = o1;
+                if constexpr (SHARD) {                       // the row's copies in the halo message (most rows: none)
+                    const int p0 = sh.send_row_ptr[v], p1 = sh.send_row_ptr[v + 1];
+                    for (int pp = p0; pp < p1; ++pp) {
+                        float *dst = sh.msg + (int64_t)sh.send_row_slot[pp] * 32;
+                        dst[fj] = o0;
+                        dst[16 + fj] = o1;
+                    }
+                }
                 s0 += (double)o0; z0 += (double)o0 * (double)o0;
                 s1 += (double)o1; z1 += (double)o1 * (double)o1;
             }
@@ -362,7 +385,68 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_eg_kernel(
             for (int w = 0; w < WAVES; ++w)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc += red[((int64_t)w * 64 + q * 16 + j) * 4 + which * 2 + m2];
-            bn_partial[(int64_t)blockIdx.x * 64 + tid] = acc;
+            if constexpr (SHARD) st_partial_sc1(bn_partial, (int64_t)blockIdx.x * 64 + tid, acc);   // (another block reads the row)
+            else bn_partial[(int64_t)blockIdx.x * 64 + tid] = acc;
+        }
+        if constexpr (SHARD) {
+            // two-level fold of the partial rows to the shard's sums (the tree of bn_fold_two_level, which writes a record instead)
+            using u32x2_ = __attribute__((ext_vector_type(2))) unsigned int;
+            constexpr int kSc1 = 16;
+            double *ftot = red + WAVES * 64 * 4;             // (behind the block's own reduction array: eg_lds_bytes)
+            unsigned *ticket = reinterpret_cast<unsigned *>(ftot + 64);
+            const int np = (int)gridDim.x, g = (int)(blockIdx.x & 15u);
+            const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(bn_partial, 0, (int)0x80000000u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(sh.group_rows, 0, (int)0x80000000u, 0x00020000);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the partial row AND the message rows of this block are out
+            __syncthreads();
+            if (tid == 0) *ticket = __hip_atomic_fetch_add(sh.counter + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (*ticket == (unsigned)((np - g + 15) / 16) - 1u) {        // (uniform) last of its row group
+                if (tid < 64) {
+                    double acc = 0.0;
+                    for (int u0 = 0; g + u0 * 16 < np; u0 += 16) {
+                        u32x2_ v[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) {
+                            const int pp = g + (u0 + u) * 16;
+                            v[u] = __builtin_amdgcn_raw_buffer_load_b64(prs, pp < np ? ((uint32_t)pp * 64u + (uint32_t)tid) * 8u : 0x80000000u, 0, kSc1);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 16; ++u)
+                            if (g + (u0 + u) * 16 < np) acc += __builtin_bit_cast(double, v[u]);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, acc), grs, ((uint32_t)g * 64u + (uint32_t)tid) * 8u, 0, kSc1);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    __hip_atomic_store(sh.counter + 1 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *ticket = __hip_atomic_fetch_add(sh.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                const int n_groups = np < 16 ? np : 16;
+                if (*ticket == (unsigned)n_groups - 1u) {    // (uniform) the last group-finisher: every block's rows are out
+                    if (tid < 64) {
+                        u32x2_ v[16];
+#pragma unroll
+                        for (int gg = 0; gg < 16; ++gg)
+                            v[gg] = __builtin_amdgcn_raw_buffer_load_b64(grs, gg < n_groups ? ((uint32_t)gg * 64u + (uint32_t)tid) * 8u : 0x80000000u, 0, kSc1);
+                        double t = 0.0;
+#pragma unroll
+                        for (int gg = 0; gg < 16; ++gg)
+                            if (gg < n_groups) t += __builtin_bit_cast(double, v[gg]);
+                        ftot[tid] = t;
+                        sh.sums[tid] = t;
+                    }
+                    __syncthreads();
+                    const float *tf = reinterpret_cast<const float *>(ftot);      // 64 doubles = 4 message rows of 32 floats
+                    for (int64_t r = tid >> 5; r < sh.n_msg; r += kThreads / 32) {
+                        const int id = sh.msg_idx[r];
+                        if (id < 0) sh.msg[r * 32 + (tid & 31)] = tf[(-1 - id) * 32 + (tid & 31)];
+                    }
+                    if (tid == 0) __hip_atomic_store(sh.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
     }
     if (stamp && tid == 0) atomicMax(stamp + 1, wall_clock64());
@@ -370,7 +454,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void nnconv32_eg_kernel(
 
 static size_t eg_lds_bytes(int n_types, int waves) {
     const size_t a = (size_t)(n_types + 1) * kWtTypeF16 * sizeof(float) + 16 * 8;
-    const size_t b = (size_t)waves * 64 * 4 * sizeof(double);
+    const size_t b = (size_t)waves * 64 * 4 * sizeof(double) + 64 * sizeof(double) + 16;   // (+ the SHARD tail's sums and ticket)
     return a > b ? a : b;
 }
 
@@ -378,12 +462,16 @@ constexpr size_t kEgMaxLds = 160 * 1024 - 256;
 
 int launch_nnconv_eg(const float *h, const int32_t *tile_grp_ptr, const int32_t *grp, const float *wimg, int32_t n_types, const float *bias, int64_t n_nodes, int32_t act, float *out,
                      double *bn_partial, int32_t *n_partials_host, hipStream_t s, const unsigned *h_max, const unsigned *root_max,
-                     unsigned long long *stamp) {
+                     unsigned long long *stamp, const EgShardPack *pack) {
     constexpr int WAVES = 16;
     const bool leaky = act == TGNN_ACT_LEAKY_RELU;
-    auto kern = leaky ? nnconv32_eg_kernel<WAVES, 4, TGNN_ACT_LEAKY_RELU> : nnconv32_eg_kernel<WAVES, 4, TGNN_ACT_NONE>;
-    static LdsOptIn site[2];
-    TGNN_CHECK_HIP(opt_in_dynamic_lds(kern, (int)kEgMaxLds, site[leaky]));
+    const bool shard = pack && pack->counter && bn_partial && leaky;
+    auto kern = shard ? nnconv32_eg_kernel<WAVES, 4, TGNN_ACT_LEAKY_RELU, true>
+                      : leaky ? nnconv32_eg_kernel<WAVES, 4, TGNN_ACT_LEAKY_RELU> : nnconv32_eg_kernel<WAVES, 4, TGNN_ACT_NONE>;
+    static LdsOptIn site[3];
+    TGNN_CHECK_HIP(opt_in_dynamic_lds(kern, (int)kEgMaxLds, site[shard ? 2 : leaky]));
+    EgShard sh{};
+    if (shard) sh = EgShard{pack->send_row_ptr, pack->send_row_slot, pack->msg, pack->msg_idx, pack->n_msg, pack->sums, pack->counter, pack->group_rows};
     const int64_t n_tiles = (n_nodes + 15) / 16;
     constexpr int tiles_per_block = 4;
     int64_t blocks = (n_tiles + tiles_per_block - 1) / tiles_per_block;
@@ -395,7 +483,7 @@ int launch_nnconv_eg(const float *h, const int32_t *tile_grp_ptr, const int32_t 
     if (blocks < 1) blocks = 1;
     kern<<<(unsigned)blocks, WAVES * 64, eg_lds_bytes(n_types, WAVES), s>>>(h, tile_grp_ptr, reinterpret_cast<const int2 *>(grp), wimg,
                                                                             n_types, bias, n_nodes, act, out, bn_partial, h_max, root_max,
-                                                                            stamp);
+                                                                            stamp, sh);
     if (n_partials_host) *n_partials_host = (int32_t)blocks;
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
@@ -428,5 +516,5 @@ extern "C" int tgnn_nnconv_mean_eg_fwd(const float *h, int64_t ldh, int64_t n_sr
     launch_absmax(h, n_src_rows * 32, bounds_scratch, s);
     launch_nnconv_weight_image(wtab, &root, n_types, 1, wimg_scratch, s, bounds_scratch + 1, kEgImageScale);
     return launch_nnconv_eg(h, tile_grp_ptr, grp, wimg_scratch, n_types, bias, n_nodes, act, out, bn_partial,
-                            n_partials_host, s, bounds_scratch, bounds_scratch + 1, nullptr);
+                            n_partials_host, s, bounds_scratch, bounds_scratch + 1, nullptr, nullptr);
 }

@@ -508,9 +508,20 @@ int launch_nnconv_cols(const float *h, int64_t ldh, const int32_t *tile_col_ptr,
                        int max_in_degree = 0, unsigned long long *stamp = nullptr);
 // the same NNConv over the edge-group structure (graph_prep.hip: nnconv_eg_kernel; nnconv_eg.hip): fp16-pair images and bounds as
 // above, no in-degree needed (nothing is summed before the split)
+// pack (counter != NULL; LeakyReLU, bn_partial given) [r6]: the sharded step's pack inside the kernel -- the epilogue also stores a row
+// into the message slots that carry it, the last block writes the shard's BatchNorm sums (sums + the message's sums rows)
+struct EgShardPack {
+    const int *send_row_ptr, *send_row_slot;   // device, [n + 1], [n_send]
+    float *msg;                                // device: the message, 32 floats per row
+    const int *msg_idx;                        // device, [n_msg]: >= 0 a row, -1 - k the sums row k
+    int64_t n_msg;
+    double *sums;                              // device, [64]
+    unsigned *counter;                         // device, 17 zeroed words (left zeroed)
+    double *group_rows;                        // device, 16 x 64 doubles
+};
 int launch_nnconv_eg(const float *h, const int32_t *tile_grp_ptr, const int32_t *grp, const float *wimg, int32_t n_types, const float *bias, int64_t n_nodes, int32_t act, float *out,
                      double *bn_partial, int32_t *n_partials_host, hipStream_t s, const unsigned *h_max, const unsigned *root_max,
-                     unsigned long long *stamp = nullptr);
+                     unsigned long long *stamp = nullptr, const EgShardPack *pack = nullptr);
 // largest |h[0 .. n_floats)| (n_floats % 4 == 0) as float bits, atomicMax into *max_bits; bn_merge.hip
 void launch_absmax(const float *h, int64_t n_floats, unsigned *max_bits, hipStream_t s);
 // max |W_k| and a bound of |BN(v)| from the BatchNorm's parameters alone (nnconv.hip: dense_bounds_kernel), atomicMax into

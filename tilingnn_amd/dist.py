@@ -529,8 +529,19 @@ class FusedShardForward:
         # needs the exchange of layer i-1, the chain cannot run ahead as it does unsharded, and every cross-queue dependency on
         # the critical path costs ~10-15 us (scratch/time_sharded.py, scratch/sharded_trace.sh)
         self.two_streams = False
-        self.send_idx_fused = torch.from_numpy(np.concatenate(send_ext)).to(self.dev)
+        msg_rows = np.concatenate(send_ext)
+        self.send_idx_fused = torch.from_numpy(msg_rows).to(self.dev)
         self.recv_idx_fused = torch.from_numpy(np.concatenate(recv_ext)).to(self.dev)
+        # [r6] the inverse of the message's row list (tgnn_shard.send_row_ptr / send_row_slot): with it the NNConv writes the adjacency
+        # branch's halo message itself -- no pack launch on the step's critical chain
+        slots = np.nonzero(msg_rows >= 0)[0].astype(np.int32)
+        order = np.argsort(msg_rows[slots], kind="stable")
+        counts = np.bincount(msg_rows[slots], minlength=shard.n_own).astype(np.int64)
+        ptr_ = np.zeros(shard.n_own + 1, dtype=np.int32)
+        np.cumsum(counts, out=ptr_[1:])
+        self.send_row_ptr = torch.from_numpy(ptr_).to(self.dev)
+        self.send_row_slot = torch.from_numpy(slots[order] if slots.size else np.zeros(1, dtype=np.int32)).to(self.dev)
+        self.pack_in_nnconv = True
 
         self._ext_streams = {}
 
@@ -591,7 +602,9 @@ class FusedShardForward:
                               self.recv_idx_fused.data_ptr() if self.fused else None,
                               _lib.side_stream(self.dev) if self.two_streams else None,
                               self.rccl.comm if self.rccl else None, self.rccl.comm_side if self.rccl else None,
-                              C.cast(self._counts[0], C.c_void_p), C.cast(self._counts[1], C.c_void_p))
+                              C.cast(self._counts[0], C.c_void_p), C.cast(self._counts[1], C.c_void_p),
+                              self.send_row_ptr.data_ptr() if self.fused and self.pack_in_nnconv else None,
+                              self.send_row_slot.data_ptr() if self.fused and self.pack_in_nnconv else None)
         g = graph.c_struct()
         self._error = None
         rc = _lib.lib.tgnn_forward_sharded(C.byref(dims), table, ops.ptr(inp["x"]), ops.ptr(inp["attr"]), C.byref(g),
