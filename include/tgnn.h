@@ -329,6 +329,9 @@ size_t tgnn_forward_workspace_bytes(const tgnn_model_dims *dims, int64_t n_nodes
 /* probs [N, output_dim].  BatchNorm runs with batch statistics and updates the running buffers
  * in `params` when update_running != 0 (train mode); with use_running_stats != 0 it normalises
  * with the running buffers instead (eval mode; never used by the reference's solver).
+ * update_running is a bit field: bit 0 the update; bit 1 (general schedule, batch statistics) "the init MLP's two BatchNorms have
+ * this forward's update already" -- for the caller whose tgnn_forward_begin could not be resumed (a layout with more than 16 edge
+ * types needs a larger workspace than begin carved) and who runs the whole forward again: ONE update per forward.
  * With stream2 != NULL (and != stream) the collision branch -- a chain of its own, CollConv_i reads only
  * CollConv_{i-1} (TilinGNN.py:63) -- is enqueued on stream2 and runs free beside the adjacency branch; the two
  * meet at the product of :64 through events the library records itself, so on return all work is ordered on

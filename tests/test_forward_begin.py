@@ -43,23 +43,28 @@ def test_lean_head_and_fused_init_are_the_launch_per_op_head_bit_for_bit(dev, n)
         assert float((outs[0] - outs[3]).abs().max()) < 2e-6
 
 
-@pytest.mark.parametrize("n,n_types", [(40_000, 13), (70_000, 13), (40_000, 20)])
-def test_begin_resume_is_the_plain_forward(dev, n, n_types):
+@pytest.mark.parametrize("n,n_types,hub", [(40_000, 13, 0), (70_000, 13, 0), (40_000, 20, 0), (40_000, 13, 3000)])
+def test_begin_resume_is_the_plain_forward(dev, n, n_types, hub):
     """A new layout (cache off / a cache miss) takes tgnn_forward_begin + tgnn_forward_resume, a cached one the plain tgnn_forward: the
-    same bits.  20 edge types: no fp16-pair path (CSR NNConv) -- resume runs the launch-per-op head again, without a second update of
-    the init MLP's running statistics."""
+    same bits.  20 edge types (a larger workspace than begin carved: the whole forward again, bit 1 of update_running) and an
+    in-degree above 2 048 (resume without the edge groups): begin's work is not picked up, and the init MLP's running statistics still
+    get ONE update."""
     x, adj, attr, col = _layout(dev, n, n_types=n_types)
-    ref, _ = make_net(dev)
+    if hub:                                          # (one node with an in-degree above 2 048: no edge groups either)
+        adj = adj.clone()
+        adj[1, :hub] = 5
+    fe = attr.shape[1]
+    ref, _ = make_net(dev, fe=fe)
     ref(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)       # cache miss: begin / resume
     want = ref(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)[0].clone()   # cache hit: plain
-    net, _ = make_net(dev)
+    net, _ = make_net(dev, fe=fe)
     net.cache_graph = False
     got = net(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)[0]
     torch.cuda.synchronize()
     assert torch.equal(got, want)
     assert int(net.init_node_feature_trans.mlp[1].batch_norm.num_batches_tracked) == 1
     assert int(net.final_mlp[0].mlp[3].batch_norm.num_batches_tracked) == 1
-    fresh, _ = make_net(dev)
+    fresh, _ = make_net(dev, fe=fe)
     fresh(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)
     assert torch.allclose(net.init_node_feature_trans.mlp[0].batch_norm.running_mean, fresh.init_node_feature_trans.mlp[0].batch_norm.running_mean,
                           rtol=1e-6, atol=1e-8)

@@ -309,6 +309,10 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
                         const tgnn_train_save *keep = nullptr, bool head_done = false) {
     TGNN_CHECK_ARG(dims_ok(dims), "model dims");
     TGNN_CHECK_ARG(params_host && graph && probs && x, "null pointer");
+    // (bit 1 of update_running: the init MLP's running statistics have this forward's update already -- a tgnn_forward_begin whose
+    //  work could not be picked up, tgnn.h)
+    const bool init_running_done = (update_running & 2) != 0;
+    update_running &= 1;
     const int64_t n = graph->n_nodes;
     TGNN_CHECK_ARG(n >= 1, "empty graph");
     TGNN_CHECK_ARG(use_running_stats || sh || n >= 2, "train-mode BatchNorm needs more than one row");
@@ -603,14 +607,15 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     // (a layout that turns out not to take the fp16-pair path -- more than 16 edge types, an in-degree above 2 048 -- runs its head
     //  again, the launch-per-op way; the init MLP's running statistics were updated by tgnn_forward_begin already)
     BnPtrs ibn0 = P.bn(P.init(0) + 2), ibn1 = P.bn(P.init(1) + 2);
-    if (head_done && !head_used) {
+    const bool init_stats_written = (head_done && !head_used) || (init_running_done && !use_running_stats);
+    if (init_stats_written) {
         ibn0.rm = ibn0.rv = ibn1.rm = ibn1.rv = nullptr;
         ibn0.nbt = ibn1.nbt = nullptr;
     }
     if (head_used) {
     } else if (init_fused) {
         prof.begin(1);
-        TGNN_TRY(forward_head_init(dims, P, x, w, n, update_running, slot_max, s));
+        TGNN_TRY(forward_head_init(dims, P, x, w, n, init_stats_written ? 0 : update_running, slot_max, s));
         prof.end();
     } else if (!mid_init) {
         prof.begin(1);

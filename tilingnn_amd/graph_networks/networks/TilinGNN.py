@@ -254,6 +254,7 @@ class TilinGNN(Tracked, nn.Module):
         ea = ops._f32c(adj_e_features, "adj_e_features")
         dims = self._dims()
         begun = False
+        init_done = 0                     # bit 1 of tgnn_forward's update_running: the init MLP's running statistics have their update
         state = {}
 
         def prepare_new():
@@ -298,6 +299,7 @@ class TilinGNN(Tracked, nn.Module):
                 if side is not None:
                     torch.cuda.current_stream(dev).wait_stream(side)          # (begin's launches still write the smaller workspace)
                 begun = False
+                init_done = 2 if update_running else 0                        # (... and have updated the init MLP's running statistics)
         if not begun:
             ws_bytes = lib.tgnn_forward_workspace_bytes(C.byref(dims), n, graph.n_types)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -318,8 +320,8 @@ class TilinGNN(Tracked, nn.Module):
                 check(lib.tgnn_forward(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), 0, 0, ptr(probs), ptr(ws), ws_bytes,
                                        _lib.current_stream(dev), _lib.side_stream(dev)))
             return probs, adj_e_features
-        check(lib.tgnn_forward(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), int(bn_train and update_running), int(not bn_train),
-                               ptr(probs), ptr(ws), ws_bytes, _lib.current_stream(dev), _lib.side_stream(dev)))
+        check(lib.tgnn_forward(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), int(bn_train and update_running) | init_done,
+                               int(not bn_train), ptr(probs), ptr(ws), ws_bytes, _lib.current_stream(dev), _lib.side_stream(dev)))
         if graph.late_words_failed():                                         # (a just-prepared mid-size layout whose batches did not fit)
             g = graph.c_struct()
             check(lib.tgnn_forward(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), int(bn_train and update_running),
