@@ -864,6 +864,7 @@ struct Ws64 {
     unsigned *ctr;                                            // [0], [16]: the folded finalizes' tickets (bn_fold_finish)
     double *part1, *part2, *partf;
     float *stat1, *stat2[2], *stat_i[2], *stat_f[4];
+    unsigned char *dimg[3];                                   // [r6] fp16-pair operand images of the final MLP's Linears 1 .. 3 (dense.hip)
     size_t bytes;
 };
 static Ws64 carve64(const tgnn_model_dims &d, int64_t n, int32_t n_types, void *ws, size_t ws_bytes) {
@@ -878,7 +879,11 @@ static Ws64 carve64(const tgnn_model_dims &d, int64_t n, int32_t n_types, void *
     w.wimg = cv.take<__bf16>((size_t)D * (n_types + 1) * kC * kC);
     w.wfin = cv.take<__bf16>((size_t)256 * kC * (D + 1));
     w.pre32 = cv.take<float>((size_t)n * kC);
-    w.ctr = cv.take<unsigned>(64);
+    w.ctr = cv.take<unsigned>(64);                           // ([32 .. 37]: the final MLP's bounds, dense_bounds_kernel)
+    {
+        const int fd[4] = {256, 128, 64, kC};
+        for (int l = 0; l < 3; ++l) w.dimg[l] = cv.take<unsigned char>(dense_f16_image_size(fd[l], fd[l + 1]));
+    }
     w.t0 = cv.take<float>((size_t)n * kC);
     w.ainit = cv.take<float>((size_t)n * kC);
     w.f1 = cv.take<float>((size_t)n * 256);
@@ -1443,7 +1448,8 @@ extern "C" int tgnn_forward_bf16(const tgnn_model_dims *dims, const void *const 
     // TilinGNN.py:63) and runs on stream2 beside the adjacency branch; the chains meet in merge only
     hipStream_t s2 = static_cast<hipStream_t>(stream2);
     if (s2 == s) s2 = nullptr;
-    constexpr int kEv = 1 + 2 * kMaxDepth;        // [0] middle[0] done, [1 + i] CollConv_i done, [1 + kMaxDepth + i] merge_i done
+    constexpr int kEv = 3 + 2 * kMaxDepth;        // [0] middle[0] done, [1 + i] CollConv_i done, [1 + kMaxDepth + i] merge_i done, then fork / edge weights
+    constexpr int kEvFork64 = 1 + 2 * kMaxDepth, kEvWeights64 = 2 + 2 * kMaxDepth;
     static thread_local hipEvent_t ev_cache[64][kEv] = {};
     hipEvent_t *ev = nullptr;
     if (s2) {
@@ -1467,19 +1473,32 @@ extern "C" int tgnn_forward_bf16(const tgnn_model_dims *dims, const void *const 
         launch_bn_finalize(jobs, 1, 0, f, n, eps, momentum, s);
     };
     // ---- per-type NNConv matrices of all layers (fp32 table, then the bf16 operand images)
+    // [r6] on the side stream, beside the init MLP (the first NNConv waits for them; ~40 us of the head were serial)
+    hipStream_t sw = s;
+#ifndef TGNN_ABL_C3SERIALHEAD
+    if (s2)
+#else
+    if (false)
+#endif
+    {
+        TGNN_CHECK_HIP(hipEventRecord(ev[kEvFork64], s));    // what the caller queued on `stream` so far (x, the parameters, the layout)
+        TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[kEvFork64], 0));
+        sw = s2;
+    }
     if (T > 0) {
         EdgeMlpLayers layers{};
         for (int i = 0; i < D; ++i) {
             const int b = P.layer(i);
             layers.l[i] = EdgeMlpLayer{P.f(b), P.f(b + 1), P.f(b + 2), P.f(b + 3), P.f(b + 4), P.f(b + 5)};
         }
-        launch_edge_weight_table_batched(adj_edge_attr, graph->type_rep_edge, T, fe, layers, D, kC, w.wtab, nullptr, nullptr, s);
+        launch_edge_weight_table_batched(adj_edge_attr, graph->type_rep_edge, T, fe, layers, D, kC, w.wtab, nullptr, nullptr, sw);
     }
     {
         RootPtrs64 rp{};
         for (int i = 0; i < D; ++i) rp.p[i] = P.f(P.layer(i) + 6);
-        nnconv64_image_kernel<<<dim3(T + 1, D), 256, 0, s>>>(w.wtab, rp, T, w.wimg);
+        nnconv64_image_kernel<<<dim3(T + 1, D), 256, 0, sw>>>(w.wtab, rp, T, w.wimg);
     }
+    if (sw != s) TGNN_CHECK_HIP(hipEventRecord(ev[kEvWeights64], s2));
     // ---- init MLP (fp32 products on the existing dense kernels), middle[0] stored as bf16
     TGNN_TRY64(tgnn_dense_act_fwd(x, fx, 32, nullptr, P.f(P.init(0)), P.f(P.init(0) + 1), n, fx, kC, TGNN_ACT_LEAKY_RELU, w.t0, kC,
                                   w.partf, &np1, stream));
@@ -1495,6 +1514,32 @@ extern "C" int tgnn_forward_bf16(const tgnn_model_dims *dims, const void *const 
         TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[0], 0));
     }
     hipStream_t sc = s2 ? s2 : s;
+    // [r6] the final MLP's Linears 1 .. 3 (256 -> 128 -> 64 -> 64, BatchNorm on load) on the fp32 path's fp16-pair kernels with W
+    // resident in LDS (dense.hip: dense_f16_resident_kernel; bf16 x 3 block-tile kernels before: 84 + 31 + 31 us at 100 000 rows):
+    // the weights' bounds, the inputs' bounds from the producers' BatchNorm parameters and the operand images, in front of the
+    // collision chain (every merge joins it, so the final MLP finds them done)
+    const int fdim[5] = {0, 256, 128, 64, kC};
+    bool tail_f16 = n >= kDenseRowsKernelMin && tgnn_set_split_precision(-1) != 0;
+    if (tail_f16) {
+        const float *bw[3], *bg[3], *bb[3];
+        int64_t bwn[3];
+        int bf[3], iin[3], iout[3];
+        unsigned *bwm[3], *bam[3];
+        const unsigned *iwm[3];
+        void *iimg[3];
+        for (int l = 1; l <= 3; ++l) {
+            const BnPtrs bp = P.bn(P.fin(l - 1) + 2);
+            bw[l - 1] = P.f(P.fin(l));
+            bwn[l - 1] = (int64_t)fdim[l] * fdim[l + 1];
+            bg[l - 1] = bp.gamma; bb[l - 1] = bp.beta; bf[l - 1] = fdim[l];
+            bwm[l - 1] = w.ctr + 32 + 2 * (l - 1);
+            bam[l - 1] = w.ctr + 33 + 2 * (l - 1);
+            iin[l - 1] = fdim[l]; iout[l - 1] = fdim[l + 1]; iwm[l - 1] = bwm[l - 1]; iimg[l - 1] = w.dimg[l - 1];
+        }
+        launch_dense_bounds(3, bw, bwn, bg, bb, bf, bwm, bam, n, sc);
+        tail_f16 = dense_f16_images_build(3, bw, iin, iout, iwm, iimg, sc) == TGNN_OK;
+    }
+    if (sw != s) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[kEvWeights64], 0));
     for (int i = 0; i < D; ++i) {
         const int b = P.layer(i);
         const __bf16 *h1 = w.mid + (size_t)i * n * kC;
@@ -1531,11 +1576,15 @@ extern "C" int tgnn_forward_bf16(const tgnn_model_dims *dims, const void *const 
         finalize1(w.partf, np1, 256, P.bn(pi + 2), w.stat_f[0]);
     }
     float *fbuf[4] = {w.f1, w.f2, w.f3, w.f4};
-    const int fdim[5] = {0, 256, 128, 64, kC};
     for (int l = 1; l < 4; ++l) {
         const int pi = P.fin(l);
-        TGNN_TRY64(tgnn_dense_act_fwd(fbuf[l - 1], fdim[l], 32, w.stat_f[l - 1], P.f(pi), P.f(pi + 1), n, fdim[l], fdim[l + 1],
-                                      TGNN_ACT_LEAKY_RELU, fbuf[l], fdim[l + 1], w.partf, &np1, stream));
+        if (tail_f16)
+            TGNN_TRY64(dense_act_bounded(fbuf[l - 1], fdim[l], 32, w.stat_f[l - 1], P.f(pi), P.f(pi + 1), n, fdim[l], fdim[l + 1],
+                                         TGNN_ACT_LEAKY_RELU, fbuf[l], fdim[l + 1], w.partf, &np1, w.ctr + 33 + 2 * (l - 1), 1,
+                                         w.ctr + 32 + 2 * (l - 1), s, w.dimg[l - 1], nullptr, nullptr, nullptr));
+        else
+            TGNN_TRY64(tgnn_dense_act_fwd(fbuf[l - 1], fdim[l], 32, w.stat_f[l - 1], P.f(pi), P.f(pi + 1), n, fdim[l], fdim[l + 1],
+                                          TGNN_ACT_LEAKY_RELU, fbuf[l], fdim[l + 1], w.partf, &np1, stream));
         finalize1(w.partf, np1, fdim[l + 1], P.bn(pi + 2), w.stat_f[l]);
     }
     TGNN_TRY64(tgnn_dense_act_fwd(fbuf[3], kC, 32, w.stat_f[3], P.f(P.last()), P.f(P.last() + 1), n, kC, dims->output_dim,

@@ -1271,8 +1271,8 @@ static int launch_dense_f16_rows(hipStream_t s, const float *a, int64_t lda, int
     GinFin fin = (bn_partial && fold_rows && folded) ? fin_in : GinFin{};
     // [r6] BatchNorm-on-load layers whose whole image fits LDS: the barrier-free resident kernel
     if constexpr (TN == 4 || TN == 2)
-    if (g_dense_resident.load(std::memory_order_relaxed) && in_stat && n_a_max == 1 && kps == 1 && akb == kBK && (in_dim == 128 || in_dim == 256) &&
-        lda % 4 == 0) {
+    if (g_dense_resident.load(std::memory_order_relaxed) && in_stat && n_a_max == 1 && kps == 1 && akb == kBK &&
+        (in_dim == 128 || in_dim == 256 || (in_dim == 64 && TN == 2)) && lda % 4 == 0) {
         constexpr int N = 32 * TN;
         const size_t lds = (size_t)in_dim * N * 4 + (size_t)4 * in_dim * sizeof(float) + (size_t)8 * 2 * N * sizeof(double);
         int blocks = (int)((n + 255) / 256);
@@ -1280,6 +1280,13 @@ static int launch_dense_f16_rows(hipStream_t s, const float *a, int64_t lda, int
         if (blocks > cap) blocks = cap;
         if (blocks < 1) blocks = 1;
         const u32x4_ *img = static_cast<const u32x4_ *>(wimg);
+        if constexpr (TN == 2)
+        if (in_dim == 64) {                                   // (config 3's fourth Linear, 64 -> 64: one k-tile per request)
+            dense_f16_resident_kernel<2, 2, 1><<<blocks, kResThreads, lds, s>>>(a, lda, in_stat, img, b, n, act, out, ldo, bn_partial, a_max, w_max, fin,
+                                                                                fold_rows);
+            if (fin.counter) *folded = true;
+            return blocks;
+        }
         if (in_dim == 256) {
             static LdsOptIn site;
             (void)opt_in_dynamic_lds(dense_f16_resident_kernel<TN, 4>, 160 * 1024 - 256, site);
