@@ -164,9 +164,10 @@ def nnconv_mean(x: Tensor, edge_index: Tensor, edge_attr: Tensor, sd: SD, prefix
 
 
 def graph_conv(x: Tensor, edge_index: Tensor, edge_attr: Tensor, sd: SD, prefix: str,
-               update_running: bool = False) -> Tensor:
-    """GraphConv.forward (edge_conv.py:24-30): NNConv -> LeakyReLU -> BatchNorm1d."""
-    v = leaky_relu(nnconv_mean(x, edge_index, edge_attr, sd, prefix))
+               update_running: bool = False, pre: Optional[Tensor] = None) -> Tensor:
+    """GraphConv.forward (edge_conv.py:24-30): NNConv -> LeakyReLU -> BatchNorm1d.
+    `pre`: the NNConv's output when the caller has it already (tilingnn_forward's capture) -- the same tensor, not recomputed."""
+    v = leaky_relu(nnconv_mean(x, edge_index, edge_attr, sd, prefix) if pre is None else pre)
     return batch_norm_train(v, sd, prefix + ".batch_norm", update_running)
 
 
@@ -183,9 +184,10 @@ def gin_conv(x: Tensor, edge_index: Tensor, sd: SD, prefix: str) -> Tensor:
     return mlp(z, sd, prefix + ".ginConv.nn", 3, sigmoid, bn=False)
 
 
-def coll_conv(x: Tensor, edge_index: Tensor, sd: SD, prefix: str, update_running: bool = False) -> Tensor:
-    """CollConv.forward (coll_conv.py:24-30): GINConv -> LeakyReLU -> BatchNorm1d."""
-    v = leaky_relu(gin_conv(x, edge_index, sd, prefix))
+def coll_conv(x: Tensor, edge_index: Tensor, sd: SD, prefix: str, update_running: bool = False,
+              pre: Optional[Tensor] = None) -> Tensor:
+    """CollConv.forward (coll_conv.py:24-30): GINConv -> LeakyReLU -> BatchNorm1d.  `pre`: see graph_conv."""
+    v = leaky_relu(gin_conv(x, edge_index, sd, prefix) if pre is None else pre)
     return batch_norm_train(v, sd, prefix + ".batch_norm", update_running)
 
 
@@ -230,12 +232,13 @@ def tilingnn_forward(sd: SD, x: Tensor, adj_e_index: Tensor, adj_e_features: Ten
     for i in range(depth):                                  # :59-71
         p1 = f"brch_1_graph_conv_layers.{i}"
         p2 = f"brch_2_coll_conv_layers.{i}"
-        if capture is not None:
+        pre1 = pre2 = None
+        if capture is not None:                             # (the two convolutions once: their outputs are captured AND passed on)
             capture[f"h1_in.{i}"], capture[f"h2_in.{i}"] = h1, h2
-            capture[f"nnconv.{i}"] = nnconv_mean(h1, adj_e_index, adj_e_features, sd, p1)
-            capture[f"gin.{i}"] = gin_conv(h2, col_e_idx, sd, p2)
-        g1 = graph_conv(h1, adj_e_index, adj_e_features, sd, p1, update_running)    # :62
-        h2 = coll_conv(h2, col_e_idx, sd, p2, update_running)                       # :63
+            pre1 = capture[f"nnconv.{i}"] = nnconv_mean(h1, adj_e_index, adj_e_features, sd, p1)
+            pre2 = capture[f"gin.{i}"] = gin_conv(h2, col_e_idx, sd, p2)
+        g1 = graph_conv(h1, adj_e_index, adj_e_features, sd, p1, update_running, pre1)    # :62
+        h2 = coll_conv(h2, col_e_idx, sd, p2, update_running, pre2)                       # :63
         h1 = g1 * h2                                                                # :64
         if i - residual_skip_num >= 0:                                              # :67-69
             h1 = h1 + middle[i - residual_skip_num]
