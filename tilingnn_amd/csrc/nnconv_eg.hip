@@ -463,7 +463,11 @@ constexpr size_t kEgMaxLds = 160 * 1024 - 256;
 int launch_nnconv_eg(const float *h, const int32_t *tile_grp_ptr, const int32_t *grp, const float *wimg, int32_t n_types, const float *bias, int64_t n_nodes, int32_t act, float *out,
                      double *bn_partial, int32_t *n_partials_host, hipStream_t s, const unsigned *h_max, const unsigned *root_max,
                      unsigned long long *stamp, const EgShardPack *pack) {
-    constexpr int WAVES = 16;
+#ifdef TGNN_ABL_EGW8                                        // (ablation: two 8-wave blocks per CU instead of one 16-wave block)
+    constexpr int WAVES = 8, kBlocksPerCu = 2;
+#else
+    constexpr int WAVES = 16, kBlocksPerCu = 1;
+#endif
     const bool leaky = act == TGNN_ACT_LEAKY_RELU;
     const bool shard = pack && pack->counter && bn_partial && leaky;
     auto kern = shard ? nnconv32_eg_kernel<WAVES, 4, TGNN_ACT_LEAKY_RELU, true>
@@ -476,7 +480,7 @@ int launch_nnconv_eg(const float *h, const int32_t *tile_grp_ptr, const int32_t 
     constexpr int tiles_per_block = 4;
     int64_t blocks = (n_tiles + tiles_per_block - 1) / tiles_per_block;
     constexpr int reserve = 32;                              // (CUs left to the collision chain: nnconv_cols.hip)
-    int64_t cap = cus_minus(reserve);
+    int64_t cap = (int64_t)cus_minus(reserve) * kBlocksPerCu;
     if (const int dbg = g_debug_block_cap[0].load(); dbg > 0) cap = dbg < device_cus() ? dbg : device_cus();
     if (blocks > cap) blocks = cap;
     if (blocks >= 8) blocks &= ~7;
