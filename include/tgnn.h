@@ -535,8 +535,10 @@ int32_t tgnn_set_dense_rows_mode(int32_t mode);
  * first layer).  Bit 0: no memset in front of the first launch, the layer loop waits for the edge weights only (the final MLP's
  * bounds and operand images are one launch each behind them); bit 1: the init MLP as three launches that recompute from x
  * (csrc/init_mlp.hip; the same bits as the five launches it replaces); bit 2 (off by default: measured no faster): the final MLP's
- * BatchNorm records written by their producers (bn_fold_two_level) instead of a bn_finalize launch behind each -- the same bits.
- * Default 3; returns the previous setting (an argument outside 0 .. 7 only queries). */
+ * BatchNorm records written by their producers (bn_fold_two_level) instead of a bn_finalize launch behind each -- the same bits;
+ * bit 3 (off by default; A/B switch): tgnn_forward_resume keeps the edge weights on the side stream instead of queueing them on
+ * `stream` straight behind the preparation's last launch (40 us slower per step, profiles/r06_resume_weights.txt).
+ * Default 3; returns the previous setting (an argument outside 0 .. 15 only queries). */
 int32_t tgnn_set_lean_head(int32_t bits);
 
 /* Small layouts (<= tgnn_graph_prep_small_max_nodes() nodes, <= ..._max_edges() edges per set): everything above --

@@ -197,7 +197,7 @@ extern "C" int32_t tgnn_set_nnconv_eg(int32_t on) {
     return g_nnconv_eg.exchange(on);
 }
 extern "C" int32_t tgnn_set_lean_head(int32_t bits) {
-    if (bits < 0 || bits > 7) return g_lean_head.load();
+    if (bits < 0 || bits > 15) return g_lean_head.load();
     return g_lean_head.exchange(bits);
 }
 extern "C" const char *tgnn_last_error(void) { return g_err; }
@@ -527,7 +527,15 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         else
             launch_forward_scales(w.bounds, 2 * D + 7, roots, D, root_max, P.f(P.fin(0)), cat_w_floats, dense_max, s);   // (before the fork: both chains see the zeroed words)
     }
-    if (s2 && weights_on_side) {
+    // [r6] tgnn_forward_resume picking up tgnn_forward_begin's work: `stream` has nothing to do in front of the first NNConv but wait
+    // for the preparation's last launches, so the edge weights go on IT, straight behind them (no cross-queue hand-over in front of
+    // them and none in front of the first NNConv: ~12 us each), and the collision chain is released first -- its first aggregate
+    // runs beside them instead of behind them
+    const bool weights_on_main = head_used && s2 && !sh && !keep && !mid_k && !small_teams && (g_lean_head.load(std::memory_order_relaxed) & 8) == 0;
+    if (weights_on_main) {
+        TGNN_CHECK_HIP(hipEventRecord(ev[0], s));            // middle[0] (the head's event, waited for above) and the layout are complete
+        TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[0], 0));
+    } else if (s2 && weights_on_side) {
         TGNN_CHECK_HIP(hipEventRecord(ev[kEvFork], s));     // everything the caller queued on `stream` so far
         TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[kEvFork], 0));
         sw = s2;
@@ -693,7 +701,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
                                          tail_blocks, update_running, eps, momentum, s));
             return TGNN_OK;
         }
-    } else if (s2) {
+    } else if (s2 && !weights_on_main) {
         TGNN_CHECK_HIP(hipEventRecord(ev[0], s));            // middle[0] is complete
         TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[0], 0));
         if (sw != s) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[kEvWeights], 0));
