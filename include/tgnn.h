@@ -583,6 +583,13 @@ int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edges, const fl
  * copy: [5] = [10] = ([0] <= tgnn_nnconv_cols_max_types() && ![6]) for the structures asked for; a caller that needs [8] / [9]
  * (the mid-size batches) reads `result` after the stream instead. */
 int tgnn_graph_prep_wait(tgnn_stream_t stream);
+/* [r6] With edge groups alone asked for (the general schedule's layouts) and result_host addressable by the device
+ * (hipHostGetDevicePointer), the words are not copied: the first wave of the first launch behind the join of the preparation's two
+ * chains stores them into result_host and sets word 31 to 0x600D0001 last (system scope), and tgnn_graph_prep_wait polls that word
+ * (two seconds, then it synchronises the stream) -- no copy launch and no hand-over to a second queue between the CSR chain and
+ * the host.  result_host[31] is the library's from tgnn_graph_prep to tgnn_graph_prep_wait.  on = 0: always the copy; returns the
+ * previous setting (negative: query). */
+int32_t tgnn_set_prep_words_poll(int32_t on);
 #ifdef TGNN_DEBUG
 /* ---- test / experiment hooks: only in libtgnn_debug.so (make -C tilingnn_amd/csrc debug: the same sources with -DTGNN_DEBUG); the
  *      production library does not export them ---- */

@@ -7,6 +7,7 @@
 // edge_index[1].  Here the scatter becomes a gather: rows of a destination-sorted CSR, built once
 // per layout and reused by all 20 layers of both branches.
 #include <atomic>
+#include <chrono>
 #include <mutex>
 
 #include "tgnn_common.h"
@@ -593,6 +594,7 @@ __global__ __launch_bounds__(64) void nnconv_col_kernel(const int *__restrict__ 
 // One block = 64 rows = 4 tiles, one thread per row.
 // ------------------------------------------------------------------------------------------
 constexpr int kEgRoot = 1 << 8;
+constexpr int kPrepWordsMagic = 0x600D0001;                 // word 31 of the pinned result words: "the other 31 have landed"
 
 template <bool FILL>
 __global__ __launch_bounds__(64) void nnconv_eg_kernel(const int *__restrict__ rowptr, const int *__restrict__ col_src,
@@ -604,7 +606,17 @@ __global__ __launch_bounds__(64) void nnconv_eg_kernel(const int *__restrict__ r
                                                        int *__restrict__ built_flag = nullptr,
                                                        const int *__restrict__ edge_type = nullptr,
                                                        const int *__restrict__ col_eid = nullptr,
-                                                       int *__restrict__ col_type_out = nullptr) {
+                                                       int *__restrict__ col_type_out = nullptr,
+                                                       const int *__restrict__ result_words = nullptr,
+                                                       int *__restrict__ host_words = nullptr) {
+    // [r6] tgnn_graph_prep's result words straight into the caller's pinned host buffer by the first wave of the first launch behind
+    // the join of its two chains -- no copy launch, no hand-over to another queue, the host polls word 31 (tgnn_graph_prep_wait)
+    if (!FILL && host_words && blockIdx.x == 0 && threadIdx.x < 32) {
+        const int v = result_words[threadIdx.x];
+        if (threadIdx.x < 31) __hip_atomic_store(host_words + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();                              // (one wave: its 31 stores are acknowledged before word 31 goes out)
+        if (threadIdx.x == 31) __hip_atomic_store(host_words + 31, kPrepWordsMagic, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     const int n_types = n_types_dev ? *n_types_dev : n_types_host;
     const int64_t n_tiles = (n + kColTileRows - 1) / kColTileRows;
     if (!FILL && col_type_out) {   // tgnn_graph_prep without the column structure: the types in CSR order are gathered here
@@ -1403,8 +1415,35 @@ static hipError_t prep_words_event(hipEvent_t *ev) {
     return hipSuccess;
 }
 
+// [r6] ... or, when the words are written by a kernel of the preparation itself (nnconv_eg_kernel<false>), the pinned buffer whose
+// word 31 the host polls: one per host thread and device, NULL = the event above
+static thread_local volatile int32_t *g_prep_poll[64] = {};
+static std::atomic<int> g_prep_poll_on{1};                   // tgnn_set_prep_words_poll
+
+extern "C" int32_t tgnn_set_prep_words_poll(int32_t on) {
+    if (on < 0) return g_prep_poll_on.load();
+    return g_prep_poll_on.exchange(on ? 1 : 0);
+}
+
 extern "C" int tgnn_graph_prep_wait(tgnn_stream_t stream) {
     DeviceGuard guard__(stream);                             // (the event slot of the device tgnn_graph_prep recorded on: the stream's)
+    int dev = 0;
+    TGNN_CHECK_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && g_prep_poll[dev]) {
+        volatile int32_t *h = g_prep_poll[dev];
+        g_prep_poll[dev] = nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            if (__atomic_load_n(const_cast<const int32_t *>(h) + 31, __ATOMIC_ACQUIRE) == kPrepWordsMagic) return TGNN_OK;
+            __builtin_ia32_pause();
+            if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+        }
+        // (not seen for two seconds: wait for the stream itself -- the kernel that writes the words is on it -- and look again)
+        TGNN_CHECK_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+        if (__atomic_load_n(const_cast<const int32_t *>(h) + 31, __ATOMIC_ACQUIRE) == kPrepWordsMagic) return TGNN_OK;
+        set_error("tgnn_graph_prep_wait: the result words never reached the host buffer");
+        return TGNN_ERR_INVALID_ARG;
+    }
     hipEvent_t ev = nullptr;
     TGNN_CHECK_HIP(prep_words_event(&ev));
     TGNN_CHECK_HIP(hipEventSynchronize(ev));
@@ -1658,12 +1697,13 @@ extern "C" int64_t tgnn_nnconv_eg_max_groups(int64_t n_nodes, int64_t n_edges, i
 static void launch_nnconv_eg_build(const int32_t *rowptr, const int32_t *col_src, int32_t *col_type, int64_t n_nodes,
                                    int32_t n_types, const int *n_types_dev, int max_types, int32_t *tile_grps,
                                    int32_t *tile_grp_ptr, int32_t *grp, int *scan_ws, int *built_flag, hipStream_t s,
-                                   const int32_t *edge_type = nullptr, const int32_t *col_eid = nullptr) {
+                                   const int32_t *edge_type = nullptr, const int32_t *col_eid = nullptr,
+                                   const int32_t *result_words = nullptr, int32_t *host_words = nullptr) {
     const int64_t nt16 = (n_nodes + kColTileRows - 1) / kColTileRows;
     const unsigned blocks = (unsigned)((n_nodes + 63) / 64);
     nnconv_eg_kernel<false><<<blocks, 64, 0, s>>>(rowptr, col_src, col_type, n_nodes, n_types, tile_grps, nullptr, nullptr,
                                                   n_types_dev, max_types, built_flag, edge_type, col_eid,
-                                                  edge_type ? col_type : nullptr);
+                                                  edge_type ? col_type : nullptr, result_words, host_words);
     exclusive_scan_i32(tile_grps, tile_grp_ptr, nt16 + 1, scan_ws, s);
     nnconv_eg_kernel<true><<<blocks, 64, 0, s>>>(rowptr, col_src, col_type, n_nodes, n_types, nullptr, tile_grp_ptr,
                                                  reinterpret_cast<int2 *>(grp), n_types_dev, max_types, nullptr);
@@ -2014,7 +2054,19 @@ extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edge
     // [r5] result_host (pinned): the words the caller reads -- type count, index errors, collision slots, largest in-degree, the
     // fall-back flag: all of them final here -- travel to the host BEFORE the NNConv structure is built; the caller waits for
     // the copy alone (tgnn_graph_prep_wait) and queues its forward while the structure's three launches still run
-    if (result_host) {
+    int32_t *host_words_dev = nullptr;                       // (the device's address of result_host when a kernel writes the words)
+    if (result_host && want_eg && !want_cols && !(mid_tile_nb && mid_ent) && g_prep_poll_on.load(std::memory_order_relaxed)) {
+        int dev = 0;
+        void *dptr = nullptr;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && hipHostGetDevicePointer(&dptr, result_host, 0) == hipSuccess && dptr) {
+            host_words_dev = static_cast<int32_t *>(dptr);
+            __atomic_store_n(result_host + 31, 0, __ATOMIC_RELEASE);   // (the last preparation's words were waited for: nothing in flight)
+            g_prep_poll[dev] = result_host;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    if (result_host && !host_words_dev) {
         hipEvent_t ev_words = nullptr;
         TGNN_CHECK_HIP(prep_words_event(&ev_words));
         if (s_side) {
@@ -2047,7 +2099,8 @@ extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edge
     if (want_eg) {   // (behind the columns on the same stream: the same scratch; without them its first pass gathers the types)
         const bool gather_types = !want_cols && n_adj_edges > 0;
         launch_nnconv_eg_build(adj_rowptr, adj_src, adj_type, n_nodes, 0, result + 0, max_types, tile_cols, tile_grp_ptr, grp, scan_ws,
-                               result + 10, s, gather_types ? edge_type : nullptr, gather_types ? adj_eid : nullptr);
+                               result + 10, s, gather_types ? edge_type : nullptr, gather_types ? adj_eid : nullptr,
+                               host_words_dev ? result : nullptr, host_words_dev);
     }
     TGNN_CHECK_LAUNCH();
     if (mid_tile_nb && mid_ent) {
