@@ -358,6 +358,14 @@ int tgnn_forward_begin(const tgnn_model_dims *dims, const void *const *params_ho
 int tgnn_forward_resume(const tgnn_model_dims *dims, const void *const *params_host, const float *x, const float *adj_edge_attr,
                         const tgnn_graph *graph, int32_t update_running, float *probs, void *ws, size_t ws_bytes,
                         tgnn_stream_t stream, tgnn_stream_t stream2);
+/* [r6] Optional, between the two: queued on `stream` BEHIND tgnn_graph_prep's launches and before the host has read the type count
+ * -- the edge weights and the edge-group NNConv's operand images of all layers (the first launch tgnn_forward_resume would queue),
+ * with the count read on the device from n_types_dev (= tgnn_graph_prep's `result`, word 0; more than 16 types: the launch writes
+ * nothing and tgnn_forward_resume, which knows the count, queues its own).  type_rep_edge: tgnn_graph_prep's output of that name.
+ * TGNN_ERR_UNSUPPORTED when there is no matching tgnn_forward_begin or the forward would not take this launch (nothing queued). */
+int tgnn_forward_begin_weights(const tgnn_model_dims *dims, const void *const *params_host, const float *adj_edge_attr,
+                               const int32_t *type_rep_edge, const int32_t *n_types_dev, int64_t n_nodes, void *ws, size_t ws_bytes,
+                               tgnn_stream_t stream);
 
 /* ---- the same forward for the TRAINING step (Trainer.train, solver/ml_solver/trainer.py:68-75: the network in train mode
  * with autograd recording): identical kernels and schedule, but what the backward reads is kept in the caller's buffers

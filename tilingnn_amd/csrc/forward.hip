@@ -197,7 +197,7 @@ extern "C" int32_t tgnn_set_nnconv_eg(int32_t on) {
     return g_nnconv_eg.exchange(on);
 }
 extern "C" int32_t tgnn_set_lean_head(int32_t bits) {
-    if (bits < 0 || bits > 15) return g_lean_head.load();
+    if (bits < 0 || bits > 31) return g_lean_head.load();
     return g_lean_head.exchange(bits);
 }
 extern "C" const char *tgnn_last_error(void) { return g_err; }
@@ -245,6 +245,7 @@ struct HeadEvent {
     hipEvent_t ev = nullptr;
     const void *ws = nullptr;        // what the last tgnn_forward_begin of this thread and device filled
     int64_t n = 0;
+    bool weights = false;            // tgnn_forward_begin_weights has queued the edge weights (edge-group images, device-side type count)
 };
 static thread_local HeadEvent g_head[64];
 // words of w.bounds holding (max |W_l|, bound of |BN(input of l)|) of the final MLP's layer l = 1 .. 3 (3: lean head only)
@@ -361,12 +362,15 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         for (int l = 0; l < 4; ++l) w.stat_f[l] = keep->fin_stat[l];
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    bool weights_early = false;
     if (head_done) {
         int dev = 0;
         TGNN_CHECK_HIP(hipGetDevice(&dev));
         TGNN_CHECK_ARG(dev >= 0 && dev < 64 && g_head[dev].ev && g_head[dev].ws == ws && g_head[dev].n == n,
                        "tgnn_forward_resume without a matching tgnn_forward_begin (same thread, device, workspace, node count)");
         g_head[dev].ws = nullptr;
+        weights_early = g_head[dev].weights;
+        g_head[dev].weights = false;
         TGNN_CHECK_HIP(hipStreamWaitEvent(s, g_head[dev].ev, 0));   // middle[0], the bounds, the final MLP's images: done long ago (the preparation ran meanwhile)
     }
     // Two-chain schedule: the collision branch is a chain of its own -- CollConv_i reads only CollConv_{i-1}
@@ -541,7 +545,9 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         sw = s2;
     }
     // (first on the side stream: the layer loop waits for these, the final MLP's bounds and images have the whole loop's time)
-    if (T > 0 || tiled) {
+    // [r6] tgnn_forward_begin_weights has queued exactly this launch behind the preparation already (type count read on the device)
+    const bool weights_queued = weights_early && weights_on_main && eg && T <= kCarveTypes && !weights_done && edge_weight_table_device_count_ok(fe, c);
+    if ((T > 0 || tiled) && !weights_queued) {
         // edge MLP of every (layer, type) and, for the matrix-core NNConv, its operand images (root = pseudo-type T): one launch
         EdgeMlpLayers layers{};
         const float *roots[kMaxDepth];
@@ -716,7 +722,10 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
             w.stat2[i & 1] = keep->stat2 + (size_t)i * 4 * c;
         }
         const float *h1 = w.mid + (size_t)i * nr * c;
-        if (s2) {
+        // [r6] tgnn_forward_resume, layer 0: the NNConv's launch goes out BEFORE the collision chain's -- the host is what the first
+        // layer waits for behind a just-prepared layout, and the adjacency chain is the longer one
+        const bool nn_first = weights_on_main && i == 0;
+        if (s2 && !nn_first) {
             // ---- collision chain, layer i, on the side stream: a2[i & 1] / stat2[i & 1] were last read by merge_{i-2}
             // (sharded: the halo rows and the statistics GIN_i reads arrive with the exchange of layer i-1, so the chain cannot run
             //  ahead; only the HBM-bound neighbourhood sum goes beside the merge / NNConv -- the MLP, which finds no CU beside an
@@ -778,6 +787,15 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
                                       TGNN_ACT_LEAKY_RELU, w.a1, w.part1, &np1, s));
         }
         prof.end();
+        if (nn_first) {                                      // (single device, i == 0: see the branch above)
+            TGNN_TRY(gin_layer(i, s2));
+            if (!fold_fin2) {
+                BnJobs j2{};
+                j2.job[0] = bn_job(w.part2, np2, P.bn(b + 20), w.stat2[i & 1]);
+                launch_bn_finalize(j2, 1, fin_mode, c, n, eps, momentum, s2);
+            }
+            TGNN_CHECK_HIP(hipEventRecord(ev[1 + i], s2));
+        }
         if (split && i + 1 < D) {
             // ---- sharded, split exchange: this chain carries the adjacency branch only (rows of a1 + its BatchNorm sums); the
             //      collision branch's half arrived (or is arriving) on the side stream
@@ -986,6 +1004,42 @@ extern "C" int tgnn_forward_begin(const tgnn_model_dims *dims, const void *const
     TGNN_CHECK_HIP(hipEventRecord(he.ev, s2));
     he.ws = ws;
     he.n = n_nodes;
+    he.weights = false;
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}
+
+// [r6] Between tgnn_forward_begin and tgnn_forward_resume, BEHIND the preparation's launches on `stream` and before the host has the
+// type count: the edge weights and the edge-group NNConv's operand images of all layers, with the count read on the device
+// (result word 0 of tgnn_graph_prep) -- the launch tgnn_forward_resume would queue first, ~60 us of host round trip earlier.
+extern "C" int tgnn_forward_begin_weights(const tgnn_model_dims *dims, const void *const *params_host, const float *adj_edge_attr,
+                                          const int32_t *type_rep_edge, const int32_t *n_types_dev, int64_t n_nodes, void *ws,
+                                          size_t ws_bytes, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
+    TGNN_CHECK_ARG(dims_ok(dims) && params_host && adj_edge_attr && type_rep_edge && n_types_dev, "arguments");
+    int dev = 0;
+    TGNN_CHECK_HIP(hipGetDevice(&dev));
+    TGNN_CHECK_ARG(dev >= 0 && dev < 64, "device index");
+    HeadEvent &he = g_head[dev];
+    const int c = dims->network_width, D = dims->network_depth, fe = dims->adj_edge_features_dim;
+    if (!he.ev || he.ws != ws || he.n != n_nodes || c != 32 || !edge_weight_table_device_count_ok(fe, c) || !g_nnconv_eg.load() ||
+        !g_split_f16.load() || (g_lean_head.load(std::memory_order_relaxed) & 24))
+        return TGNN_ERR_UNSUPPORTED;                           // (no matching tgnn_forward_begin, or a forward that will not take this launch)
+    Workspace w = carve(*dims, n_nodes, n_nodes, 0, ws, ws_bytes);
+    if (!ws || w.bytes > ws_bytes) return TGNN_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Params P{params_host, D};
+    EdgeMlpLayers layers{};
+    const float *roots[kMaxDepth];
+    for (int i = 0; i < D; ++i) {
+        const int b = P.layer(i);
+        layers.l[i] = EdgeMlpLayer{P.f(b), P.f(b + 1), P.f(b + 2), P.f(b + 3), P.f(b + 4), P.f(b + 5)};
+        roots[i] = P.f(b + 6);
+    }
+    // (no wait for tgnn_forward_begin's stream: the kernel takes the roots' bounds itself when it reads the type count itself)
+    launch_edge_weight_table_batched(adj_edge_attr, type_rep_edge, 0, fe, layers, D, c, w.wtab, roots, w.wimg, s, nullptr, w.bounds + D + 1,
+                                     kEgImageScale, n_types_dev, kCarveTypes);
+    he.weights = true;
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
 }

@@ -425,9 +425,28 @@ constexpr int kEwTypes = 16, kEwMaxFe = 64;   // types per pass; attribute colum
 __global__ __launch_bounds__(256) void edge_weight_table_chunks_kernel(
     const float *__restrict__ edge_attr, const int *__restrict__ type_rep_edge, int fe, EdgeMlpLayers layers, int cc,
     float *__restrict__ wtab_all, int n_types, RootPtrs roots, float *__restrict__ wimg_all, unsigned *__restrict__ done_ctr,
-    const unsigned *__restrict__ root_max, float img_scale) {
+    const unsigned *__restrict__ root_max, float img_scale, const int *__restrict__ n_types_dev, int max_types_dev) {
+    // [r6] n_types_dev: the type count read on the device (tgnn_forward_begin_weights: queued before the host knows it); more types
+    // than the workspace was carved for: nothing is written (the caller finds that out from the count and runs the general call)
+    unsigned own_root_max = 0u;
+    if (n_types_dev) {
+        n_types = *n_types_dev;
+        if (n_types > max_types_dev || n_types < 0) return;
+        // (... and the root's bound taken here -- max |root| is exact, the same word forward_scales leaves in root_max -- so that the
+        //  launch depends on nothing but the preparation it is queued behind)
+        if (root_max) {
+            __shared__ float wm[4];
+            float m = 0.f;
+            m = absmax4(m, reinterpret_cast<const float4 *>(roots.p[blockIdx.y])[threadIdx.x]);   // 1024 floats
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+            if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+            __syncthreads();
+            own_root_max = __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
+        }
+    }
     const bool f16 = root_max != nullptr;
-    const float wscale = f16 ? nnconv_weight_scale(root_max[blockIdx.y]) * img_scale : 1.0f;
+    const float wscale = f16 ? nnconv_weight_scale(n_types_dev ? own_root_max : root_max[blockIdx.y]) * img_scale : 1.0f;
     const int chunks = cc / 256, tid = threadIdx.x;
     auto image_of = [&](int t) { return wimg_all + ((int64_t)blockIdx.y * (n_types + 1) + t) * (f16 ? kWtTypeF16 : kWtType); };
     if ((int)blockIdx.x == chunks) {                             // the root matrix's image (width 32 only)
@@ -501,6 +520,7 @@ __global__ __launch_bounds__(256) void edge_weight_table_chunks_kernel(
 constexpr size_t kMaxDynLds = 160 * 1024 - 256;
 
 static bool edge_table_by_chunks(int fe, int c) { return fe <= kEwMaxFe && (c * c) % 256 == 0; }
+bool edge_weight_table_device_count_ok(int fe, int c) { return edge_table_by_chunks(fe, c); }   // (the grid does not depend on the type count)
 // blocks of the launch below = what its done counter reaches
 unsigned edge_weight_table_blocks(int n_types, int fe, int depth, int c, bool image) {
     image = image && c == 32;
@@ -509,7 +529,8 @@ unsigned edge_weight_table_blocks(int n_types, int fe, int depth, int c, bool im
 
 void launch_edge_weight_table_batched(const float *edge_attr, const int *type_rep_edge, int n_types, int fe,
                                       const EdgeMlpLayers &layers, int depth, int c, float *wtab, const float *const *roots,
-                                      float *wimg_all, hipStream_t s, unsigned *done_ctr, const unsigned *root_max, float img_scale) {
+                                      float *wimg_all, hipStream_t s, unsigned *done_ctr, const unsigned *root_max, float img_scale,
+                                      const int *n_types_dev, int max_types_dev) {
     RootPtrs rp{};
     const bool image = wimg_all && roots && c == 32;
     if (image)
@@ -517,9 +538,10 @@ void launch_edge_weight_table_batched(const float *edge_attr, const int *type_re
     if (edge_table_by_chunks(fe, c)) {
         edge_weight_table_chunks_kernel<<<dim3(c * c / 256 + (image ? 1 : 0), depth), 256, 0, s>>>(
             edge_attr, type_rep_edge, fe, layers, c * c, wtab, n_types, rp, image ? wimg_all : nullptr, done_ctr, image ? root_max : nullptr,
-            img_scale);
+            img_scale, n_types_dev, max_types_dev);
         return;
     }
+    if (n_types_dev) return;                                  // (callers check edge_weight_table_device_count_ok first)
     edge_weight_table_kernel<<<dim3(n_types + (image ? 1 : 0), depth), 256, 0, s>>>(edge_attr, type_rep_edge, fe, layers, c * c, wtab,
                                                                                   n_types, rp, image ? wimg_all : nullptr, done_ctr,
                                                                                   image ? root_max : nullptr, img_scale);

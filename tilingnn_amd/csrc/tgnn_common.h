@@ -478,7 +478,11 @@ unsigned edge_weight_table_blocks(int n_types, int fe, int depth, int c, bool im
 void launch_edge_weight_table_batched(const float *edge_attr, const int *type_rep_edge, int n_types, int fe,
                                       const EdgeMlpLayers &layers, int depth, int c, float *wtab, const float *const *roots,
                                       float *wimg_all, hipStream_t s, unsigned *done_ctr = nullptr,
-                                      const unsigned *root_max = nullptr, float img_scale = 1.0f);
+                                      const unsigned *root_max = nullptr, float img_scale = 1.0f, const int *n_types_dev = nullptr,
+                                      int max_types_dev = 0);
+// [r6] n_types_dev (device): the kernel reads the type count itself (more than max_types_dev: it writes nothing) -- only where the
+// launch's grid does not depend on the count:
+bool edge_weight_table_device_count_ok(int fe, int c);
 // img_scale (a power of two): on top of nnconv_weight_scale in the fp16-pair images -- kEgImageScale for the edge-group kernel
 // root_max (device, [depth] words = max |root_i| as float bits, forward_scales below): the images are fp16-pair images
 // [(T+1)][kWtTypeF16] instead.

@@ -262,7 +262,7 @@ class TilinGNN(Tracked, nn.Module):
             # without the graph (bounds, init MLP, the final MLP's operand images) is queued on the side stream BEFORE the preparation
             # and runs beside it (tgnn_forward_begin / tgnn_forward_resume; the workspace's layout does not depend on the type count
             # up to 16).  _BEGIN_FIRST = 0: behind the preparation's launches, in front of its one synchronisation (after_enqueue).
-            def begin():
+            def begin(info=None):
                 state["bytes"] = lib.tgnn_forward_workspace_bytes(C.byref(dims), n, 0)
                 state["ws"] = torch.empty(state["bytes"], dtype=torch.uint8, device=dev)
                 state["rc"] = lib.tgnn_forward_begin(C.byref(dims), table, ptr(xf), n, int(update_running), ptr(state["ws"]), state["bytes"],
@@ -277,9 +277,19 @@ class TilinGNN(Tracked, nn.Module):
                     side.wait_stream(torch.cuda.current_stream(dev))          # x and the parameters are ready HERE: in front of the preparation
             if use_begin and _BEGIN_FIRST:
                 begin()
+
+            def weights(info=None):
+                # behind the preparation's launches, before its one synchronisation: the edge weights, with the type count read on
+                # the device (tgnn_forward_begin_weights) -- the launch tgnn_forward_resume would otherwise queue first
+                if not _BEGIN_FIRST:
+                    begin()
+                if info is not None and state.get("rc") == 0:
+                    rcw = lib.tgnn_forward_begin_weights(C.byref(dims), table, ptr(ea), ptr(info["type_rep_edge"]), ptr(info["result"]),
+                                                         n, ptr(state["ws"]), state["bytes"], _lib.current_stream(dev))
+                    if rcw not in (0, _lib.ERR_UNSUPPORTED):
+                        check(rcw)
             try:
-                return ops.prepare_graph(n, adj_e_index, adj_e_features, col_e_idx,
-                                         after_enqueue=begin if use_begin and not _BEGIN_FIRST else None)
+                return ops.prepare_graph(n, adj_e_index, adj_e_features, col_e_idx, after_enqueue=weights if use_begin else None)
             except Exception:
                 side = _lib.side_stream_torch(dev) if state.get("rc") == 0 else None
                 if side is not None:                                          # (begin's launches write the workspace freed below)

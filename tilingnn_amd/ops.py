@@ -369,7 +369,9 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
             ev.record(torch.cuda.current_stream(dev))
             late = (words, ev, res)
         if after_enqueue is not None:
-            after_enqueue()                                                      # (the caller's launches that need nothing of the graph)
+            # (the caller's launches that need nothing of the graph -- or, of it, only what is on the device already: the types'
+            #  representative edges and the result words, whose word 0 is the type count)
+            after_enqueue({"type_rep_edge": rep, "result": res})
             after_enqueue = None
         check(lib.tgnn_graph_prep_wait(_stream(adj)))                                        # the one sync: the copy of the words alone
         host = early.tolist()
@@ -402,16 +404,17 @@ def prepare_graph(n_nodes: int, adj_e_index: Tensor, adj_e_features: Tensor, col
     tgnn_graph_prep call) the NNConv edge groups in its place; `graph_columns` / `graph_groups` build the other structure
     for whoever needs it.
     Synchronises once (the type count and the self-loop-free collision edge count are read back).
-    after_enqueue: called once, with no arguments, behind the preparation's launches and in front of that synchronisation (or first
-    thing on the paths that synchronise more than once): launches of the caller's that need nothing of the graph go there."""
+    after_enqueue: called once behind the preparation's launches and in front of that synchronisation (or first thing on the paths
+    that synchronise more than once): launches of the caller's that need nothing of the graph go there.  Its one argument is None
+    or, from the one-call preparation, {"type_rep_edge", "result"}: device tensors that are filled by the launches just queued."""
     done = [False]
     if after_enqueue is not None:
         user_cb = after_enqueue
 
-        def after_enqueue():
+        def after_enqueue(info=None):
             if not done[0]:
                 done[0] = True
-                user_cb()
+                user_cb(info)
     adj = _check_edge_index(adj_e_index, "adj_e_index")
     col = _check_edge_index(col_e_idx, "col_e_idx")
     ea, ec = int(adj.shape[1]), int(col.shape[1])
