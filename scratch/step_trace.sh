@@ -20,6 +20,10 @@ net = TilinGNN(adj_edge_features_dim=15, network_depth=20, network_width=32, nod
 net.load_state_dict(make_state_dict(15, 20, 32, 1, 3, seed=0), strict=True)
 net = net.to(dev).train()
 net.cache_graph = False
+import os
+if os.environ.get("LEAN"):
+    from tilingnn_amd._lib import lib
+    lib.tgnn_set_lean_head(int(os.environ["LEAN"]))
 for _ in range(8):
     net(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)
 torch.cuda.synchronize()
