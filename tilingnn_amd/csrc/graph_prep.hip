@@ -2061,7 +2061,7 @@ extern "C" int tgnn_graph_prep(const int64_t *adj_edge_index, int64_t n_adj_edge
         if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && hipHostGetDevicePointer(&dptr, result_host, 0) == hipSuccess && dptr) {
             // (a preparation of this thread whose words were never waited for -- a caller that gave up in between -- may still have
             //  its store in flight: it must not land behind the reset below)
-            if (g_prep_poll[dev]) TGNN_CHECK_HIP(hipStreamSynchronize(s));
+            if (g_prep_poll[dev]) TGNN_CHECK_HIP(hipDeviceSynchronize());   // (rare; whatever stream it was on)
             host_words_dev = static_cast<int32_t *>(dptr);
             __atomic_store_n(result_host + 31, 0, __ATOMIC_RELEASE);   // (the last preparation's words were waited for: nothing in flight)
             g_prep_poll[dev] = result_host;
