@@ -45,6 +45,7 @@ extern "C" {
 #define TGNN_ERR_LAUNCH (-3)      /* HIP launch / runtime failure */
 #define TGNN_ERR_UNSUPPORTED (-4) /* shape outside what the kernels are built for */
 #define TGNN_ERR_BAD_GRAPH (-5)   /* edge index out of [0, N) */
+#define TGNN_ERR_UNVERIFIED (-7)   /* tgnn_graph.nn_mid_verdict given where the forward cannot honour it: nothing was queued */
 #define TGNN_ERR_STALE_RESULT (-6) /* an EARLIER forward's persistent kernel gave up and nobody collected it: see tgnn_spin_error_poll */
 
 /* activation codes (torch.nn.LeakyReLU() slope 0.01 / torch.nn.Sigmoid()) */
@@ -322,6 +323,13 @@ typedef struct tgnn_graph {
      * general schedule of the fp32 width-32 forward prefers it (tgnn_set_nnconv_eg; in-degrees up to 2048). */
     const int32_t *nn_tile_grp_ptr;
     const int32_t *nn_grp;
+    /* [r6] NULL, or: a device word that is non-zero when nn_mid_tile_nb / nn_mid_ent turned out not to be usable (tgnn_graph_prep's
+     * result word 9, final behind its last launch).  A forward queued BEHIND the preparation without waiting for that word passes
+     * it: the mid-size persistent kernels read it first and leave without touching anything -- no output, no running-statistics
+     * update -- when it is set; the caller, who reads the word later, then runs the forward again without the batches.  Where the
+     * mid-size forward is not those two kernels alone (its init MLP or final MLP as separate launches), a forward given this
+     * pointer returns TGNN_ERR_UNVERIFIED and queues nothing: wait for the word, pass NULL. */
+    const int32_t *nn_mid_verdict;
 } tgnn_graph;
 
 size_t tgnn_forward_workspace_bytes(const tgnn_model_dims *dims, int64_t n_nodes, int32_t n_types);

@@ -35,7 +35,7 @@ class Graph(C.Structure):
                 ("nn_tile_col_ptr", C.c_void_p), ("nn_col_meta", C.c_void_p), ("nn_col_src", C.c_void_p),
                 ("nn_max_in_degree", C.c_int32),
                 ("nn_mid_tile_nb", C.c_void_p), ("nn_mid_ent", C.c_void_p),
-                ("nn_tile_grp_ptr", C.c_void_p), ("nn_grp", C.c_void_p)]
+                ("nn_tile_grp_ptr", C.c_void_p), ("nn_grp", C.c_void_p), ("nn_mid_verdict", C.c_void_p)]
 
 
 class TrainSave(C.Structure):
@@ -400,6 +400,7 @@ def side_stream(device) -> C.c_void_p:
 
 ERR_UNSUPPORTED = -4          # TGNN_ERR_UNSUPPORTED (include/tgnn.h)
 ERR_STALE_RESULT = -6         # TGNN_ERR_STALE_RESULT
+ERR_UNVERIFIED = -7           # TGNN_ERR_UNVERIFIED
 
 
 def side_stream_torch(device):

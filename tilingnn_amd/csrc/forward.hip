@@ -509,6 +509,12 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     // a block on every CU it starts BEHIND it, a cross-queue event later, and the launches, which run beside it, win: measured at
     // 16 384 and 32 768 nodes, profiles/r05_mid_tail.txt)
     const bool mid_init = mid_counter && mid_init_in_kernel() && fx <= 8;
+    // [r6] tgnn_graph.nn_mid_verdict: a forward queued behind a preparation whose batches are not verified yet -- honoured where the
+    // mid-size forward is the two persistent kernels alone (they read the word and leave); anywhere else nothing is queued
+    if (mid_k && graph->nn_mid_verdict && !(mid_init && tail_k)) {
+        set_error("tgnn_forward: nn_mid_verdict given, but the mid-size forward of this layout is not the two persistent kernels alone");
+        return TGNN_ERR_UNVERIFIED;
+    }
     unsigned *weights_done = mid_counter ? w.bounds + 2 * D + 6 : (small_teams == 2 && s2 && weights_on_side) ? w.small_ctr + 16 : nullptr;
     if (weights_done && !mid_counter) TGNN_CHECK_HIP(hipMemsetAsync(weights_done, 0, 4, s));
     const unsigned weights_target = edge_weight_table_blocks(T, fe, D, c, tiled);
@@ -704,7 +710,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         if (sw != s && weights_done) TGNN_CHECK_HIP(hipStreamWaitEvent(s, ev[kEvWeights], 0));
         if (tail_k) {
             TGNN_TRY(launch_forward_tail(dims, P, w.mid, w.small_pack, probs, w.partf, w.small_part_wide, slot_max, dense_max, n, tail_k,
-                                         tail_blocks, update_running, eps, momentum, s));
+                                         tail_blocks, update_running, eps, momentum, s, graph->nn_mid_verdict));
             return TGNN_OK;
         }
     } else if (s2 && !weights_on_main) {

@@ -93,6 +93,7 @@ struct MidArgs {
     int64_t n;
     int n_types, depth, update_running, tiles_per_block, deg_log2, fault, nn_split;
     float eps, momentum;
+    const int *verdict;          // NULL, or: non-zero = the batches are not usable (tgnn_graph.nn_mid_verdict): every block leaves at once
 };
 
 // ---- one tagged double: the low two mantissa bits carry the generation
@@ -347,6 +348,7 @@ __device__ __forceinline__ void mid_dma(const float *src, float *dst_lds, int by
 __global__ __launch_bounds__(kMidThreads) void forward_layers_mid_kernel(MidArgs A, SmallRunTab R) {
     extern __shared__ __attribute__((aligned(1024))) float lds[];
     if (A.fault && blockIdx.x == gridDim.x - 1) return;         // (test hook: a block that never shows up)
+    if (A.verdict && *A.verdict != 0) return;                   // (uniform over the grid: nobody waits at a barrier)
     const int T = A.n_types, D = A.depth;
     const int64_t n = A.n;
     // LDS: NNConv image | GIN image | 8 wave tiles [16][32] (the all-reduce's fold array [16][128] doubles aliases them) | batches of
@@ -946,6 +948,7 @@ int launch_forward_mid(const tgnn_model_dims *d, const Params &P, float *mid, fl
     A.a2[1] = a2_1;
     A.wimg = wimg;
     A.pack = pack;
+    A.verdict = graph->nn_mid_verdict;
     A.adj_rowptr = graph->adj_rowptr;
     A.col_rowptr = graph->col_rowptr;
     A.col_nbr = graph->col_src;

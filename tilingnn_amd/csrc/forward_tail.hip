@@ -57,6 +57,7 @@ struct TailArgs {
     int64_t n;
     int depth, tiles_per_block, out_dim, update_running, fault;
     float eps, momentum;
+    const int *verdict;          // as MidArgs.verdict: the layer loop's kernel in front of this one left without filling `mid`
 };
 
 #ifdef TGNN_TAIL_TIMING
@@ -439,6 +440,7 @@ __device__ __forceinline__ void tail_body(const TailArgs &A, float *lds, SpinCtx
 __global__ __launch_bounds__(kTailThreads) void forward_tail_mid_kernel(TailArgs A) {
     extern __shared__ __attribute__((aligned(1024))) float lds[];
     if (A.fault && blockIdx.x == gridDim.x - 1) return;         // (test hook: a block that never shows up)
+    if (A.verdict && *A.verdict != 0) return;
     const int tid = threadIdx.x;
     SpinCtx spin{A.err, A.spin_budget, false, A.err_host};
     TGNN_TT(24)
@@ -485,8 +487,9 @@ size_t mid_tail_part_doubles() { return (size_t)kTailMaxBlocks * kTailRowDoubles
 
 int launch_forward_tail(const tgnn_model_dims *d, const Params &P, const float *mid, const float *pack, float *probs, double *part,
                         double *gpart, const unsigned *slot_max, const unsigned *w0_max, int64_t n, int tiles_per_block, int blocks,
-                        int update_running, float eps, float momentum, hipStream_t s) {
+                        int update_running, float eps, float momentum, hipStream_t s, const int *verdict) {
     TailArgs A{};
+    A.verdict = verdict;
     A.mid = mid;
     for (int l = 0; l < 4; ++l) {
         const int pi = P.fin(l);

@@ -611,7 +611,7 @@ size_t mid_tail_part_doubles();
 const float *small_dense_image(const float *pack, int depth, int k);
 int launch_forward_tail(const tgnn_model_dims *d, const Params &P, const float *mid, const float *pack, float *probs, double *part,
                         double *gpart, const unsigned *slot_max, const unsigned *w0_max, int64_t n, int tiles_per_block, int blocks,
-                        int update_running, float eps, float momentum, hipStream_t s);
+                        int update_running, float eps, float momentum, hipStream_t s, const int *verdict = nullptr);
 // MFMA weight image of the column NNConv, per type: [plane 3 (hi, mid, lo)][M block 2][g 4][i 16] x 8 bf16 --
 // the A fragment of lane 16 g + i for one (plane, M block) is one 16-byte read, a wavefront reads 1 KB in lane order
 // (conflict-free: SQ_LDS_BANK_CONFLICT 2.3e6 -> 2.3e5 per launch against the [i][g] order of round 1); 6144 B per type

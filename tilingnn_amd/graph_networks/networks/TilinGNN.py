@@ -318,10 +318,11 @@ class TilinGNN(Tracked, nn.Module):
             graph.ensure_columns()                                            # (no fp16-pair path: the column kernel, not the CSR one)
         probs = torch.empty(n, self.output_dim, dtype=torch.float32, device=dev)
         # One running-statistics update per forward() (the buffers are state: ml_solver.py:129-131 keeps the network in train mode):
-        # an optimistic launch on a just-prepared mid-size layout's unverified batches would, when it has to be repeated, have
-        # applied a momentum update from garbage already -- with the update on, the preparation's last words are waited for first
-        writes_stats = bool(bn_train and update_running)
-        g = graph.c_struct(defer_late_check=not writes_stats)
+        # a just-prepared mid-size layout's batches are verified by the preparation's LAST launch; the forward is queued behind it
+        # without waiting, with the DEVICE address of that verdict in the graph struct -- the persistent kernels read it first and
+        # leave without output or update when the batches do not fit (tgnn_graph.nn_mid_verdict); the host looks at the word behind
+        # its launches and then runs the general schedule, whose update is this forward's one
+        g = graph.c_struct(defer_late_check=True)
         if begun:
             check(lib.tgnn_forward_resume(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), int(update_running), ptr(probs), ptr(ws),
                                           ws_bytes, _lib.current_stream(dev), _lib.side_stream(dev)))
@@ -330,8 +331,13 @@ class TilinGNN(Tracked, nn.Module):
                 check(lib.tgnn_forward(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), 0, 0, ptr(probs), ptr(ws), ws_bytes,
                                        _lib.current_stream(dev), _lib.side_stream(dev)))
             return probs, adj_e_features
-        check(lib.tgnn_forward(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), int(bn_train and update_running) | init_done,
-                               int(not bn_train), ptr(probs), ptr(ws), ws_bytes, _lib.current_stream(dev), _lib.side_stream(dev)))
+        rc = lib.tgnn_forward(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), int(bn_train and update_running) | init_done,
+                              int(not bn_train), ptr(probs), ptr(ws), ws_bytes, _lib.current_stream(dev), _lib.side_stream(dev))
+        if rc == _lib.ERR_UNVERIFIED:                                         # (a mid-size forward that is not the two persistent
+            g = graph.c_struct()                                              #  kernels alone: nothing was queued; wait for the words)
+            rc = lib.tgnn_forward(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), int(bn_train and update_running) | init_done,
+                                  int(not bn_train), ptr(probs), ptr(ws), ws_bytes, _lib.current_stream(dev), _lib.side_stream(dev))
+        check(rc)
         if graph.late_words_failed():                                         # (a just-prepared mid-size layout whose batches did not fit)
             g = graph.c_struct()
             check(lib.tgnn_forward(C.byref(dims), table, ptr(xf), ptr(ea), C.byref(g), int(bn_train and update_running),
