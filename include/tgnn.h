@@ -564,7 +564,8 @@ int32_t tgnn_set_lean_head(int32_t bits);
  * `stream` (one call at a time per counter pair).  result [32] (device; 8 used): n_types,
  * adjacency index error, collision index error, collision CSR slots, largest adjacency in-degree, 1 = column structure
  * built (n_types <= tgnn_nnconv_cols_max_types()), 1 = fall back to the separate calls (more than 1024 distinct attribute
- * rows).  Asynchronous. */
+ * rows).  Asynchronous.  [r6] result_host (NULL, or 32 words of pinned host memory the device can address): the kernel stores the
+ * words there too, word 31 = 0x600D0001 last, and tgnn_graph_prep_wait(stream) polls it -- no copy, no stream synchronise. */
 int64_t tgnn_graph_prep_small_max_nodes(void);
 int64_t tgnn_graph_prep_small_max_edges(void);
 size_t tgnn_graph_prep_small_tmp_ints(int64_t n_nodes, int64_t n_adj_edges, int64_t n_col_edges);
@@ -572,7 +573,8 @@ int tgnn_graph_prep_small(const int64_t *adj_edge_index, int64_t n_adj_edges, co
                           const int64_t *col_edge_index, int64_t n_col_edges, int64_t n_nodes, int32_t *adj_rowptr,
                           int32_t *adj_src, int32_t *adj_eid, int32_t *adj_type, int32_t *edge_type, int32_t *type_rep_edge,
                           int32_t *col_rowptr, int32_t *col_src, int32_t *col_eid, int32_t *tile_col_ptr, int32_t *col_meta,
-                          int32_t *col_slot_src, int32_t *tmp, int32_t *result, uint32_t *counters, tgnn_stream_t stream);
+                          int32_t *col_slot_src, int32_t *tmp, int32_t *result, uint32_t *counters, int32_t *result_host,
+                          tgnn_stream_t stream);
 
 /* The same at any size: one call that queues every launch of the preparation itself (no host round trip in the middle:
  * the column structure reads the type count from the device).  result [32] as above; word 6 = 1: the layout has more than

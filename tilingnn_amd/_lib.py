@@ -140,7 +140,7 @@ def _load() -> C.CDLL:
         "tgnn_graph_prep_small_max_nodes": (i64, []),
         "tgnn_graph_prep_small_max_edges": (i64, []),
         "tgnn_graph_prep_small_tmp_ints": (sz, [i64, i64, i64]),
-        "tgnn_graph_prep_small": (C.c_int, [p, i64, p, i32, p, i64, i64] + [p] * 15 + [p]),
+        "tgnn_graph_prep_small": (C.c_int, [p, i64, p, i32, p, i64, i64] + [p] * 16 + [p]),
         "tgnn_graph_prep_workspace_bytes": (sz, [i64, i64, i64, i32]),
         "tgnn_graph_prep": (C.c_int, [p, i64, p, i32, p, i64, i64, i64] + [p] * 17 + [sz, p, p, p]),
         "tgnn_graph_prep_wait": (C.c_int, [p]),

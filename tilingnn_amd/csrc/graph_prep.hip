@@ -716,6 +716,7 @@ struct SmallPrepArgs {
     int *edge_type, *type_rep;                        // types in edge order; first edge of every type
     int *col_rowptr, *col_src, *col_eid;              // CSR of the collision set (self loops dropped)
     int *tile_col_ptr, *col_meta, *col_slot_src;      // NNConv column structure
+    int *result_host;                                 // NULL, or the caller's pinned words (device address): written behind `result`, word 31 last
     int *tmp;                                         // tgnn_graph_prep_small_tmp_ints()
     int *result;                                      // [8]: n_types, adj_err, col_err, n_col_edges, max_in_degree, cols_built, fallback
     unsigned *ctr;                                    // [2] barrier counter, exit counter: zero before the first use, zero on return
@@ -1103,6 +1104,14 @@ __global__ __launch_bounds__(kSmallPrepThreads) void graph_prep_small_kernel(Sma
         A.result[4] = maxdeg;
         A.result[5] = cols ? 1 : 0;
         A.result[6] = fallback ? 1 : 0;
+        if (A.result_host) {                               // [r6] no copy, no stream synchronise: the host polls word 31 (tgnn_graph_prep_wait)
+            const int w[7] = {n_types, g_flags[0], g_flags[1], ec_valid, maxdeg, cols ? 1 : 0, fallback ? 1 : 0};
+#pragma unroll
+            for (int k = 0; k < 7; ++k) __hip_atomic_store(A.result_host + k, w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            for (int k = 7; k < 31; ++k) __hip_atomic_store(A.result_host + k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+            __hip_atomic_store(A.result_host + 31, kPrepWordsMagic, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     // the last block out re-arms the counters for the next call
     __syncthreads();
@@ -1888,7 +1897,7 @@ extern "C" int tgnn_graph_prep_small(const int64_t *adj_edge_index, int64_t n_ad
                                      int32_t *adj_src, int32_t *adj_eid, int32_t *adj_type, int32_t *edge_type,
                                      int32_t *type_rep_edge, int32_t *col_rowptr, int32_t *col_src, int32_t *col_eid,
                                      int32_t *tile_col_ptr, int32_t *col_meta, int32_t *col_slot_src, int32_t *tmp,
-                                     int32_t *result, uint32_t *counters, tgnn_stream_t stream) {
+                                     int32_t *result, uint32_t *counters, int32_t *result_host, tgnn_stream_t stream) {
     DeviceGuard guard__(stream);
     TGNN_CHECK_ARG(n_nodes >= 1 && n_nodes <= kSmallPrepMaxNodes, "n_nodes");
     const int64_t emax_allowed = (int64_t)kSmallPrepMaxBlocks * kSmallPrepLocal;
@@ -1907,6 +1916,26 @@ extern "C" int tgnn_graph_prep_small(const int64_t *adj_edge_index, int64_t n_ad
     A.col_rowptr = col_rowptr; A.col_src = col_src; A.col_eid = col_eid;
     A.tile_col_ptr = tile_col_ptr; A.col_meta = col_meta; A.col_slot_src = col_slot_src;
     A.tmp = tmp; A.result = result; A.ctr = counters;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int poll_dev = -1;
+    if (result_host && g_prep_poll_on.load(std::memory_order_relaxed)) {   // (as in tgnn_graph_prep: the words stored by the kernel, polled by the host)
+        int dev = 0;
+        void *dptr = nullptr;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && hipHostGetDevicePointer(&dptr, result_host, 0) == hipSuccess && dptr) {
+            if (g_prep_poll[dev]) TGNN_CHECK_HIP(hipDeviceSynchronize());   // (an earlier preparation nobody waited for)
+            A.result_host = static_cast<int *>(dptr);
+            __atomic_store_n(result_host + 31, 0, __ATOMIC_RELEASE);
+            g_prep_poll[dev] = result_host;
+            poll_dev = dev;
+        } else {
+            (void)hipGetLastError();
+            set_error("tgnn_graph_prep_small: result_host is not host memory the device can address");
+            return TGNN_ERR_INVALID_ARG;
+        }
+    } else if (result_host) {
+        set_error("tgnn_graph_prep_small: result_host needs tgnn_set_prep_words_poll(1)");
+        return TGNN_ERR_INVALID_ARG;
+    }
     // blocks: ~2048 edges each, and enough of them that a block's share of the adjacency edges fits its LDS table
     const int64_t emax = n_adj_edges > n_col_edges ? n_adj_edges : n_col_edges;
     int64_t blocks = (emax + 2047) / 2048;
@@ -1920,14 +1949,16 @@ extern "C" int tgnn_graph_prep_small(const int64_t *adj_edge_index, int64_t n_ad
     // the counters are zero on entry whatever a previous call left behind (an aborted launch would otherwise make every
     // later preparation on this pair hang or pass its barriers early); on the per-device chain of spin-barrier kernels: beside
     // a persistent forward of another stream / thread neither could get all its blocks resident
-    hipStream_t s = static_cast<hipStream_t>(stream);
     TGNN_CHECK_HIP(hipMemsetAsync(counters, 0, 2 * sizeof(uint32_t), s));
     struct Ctx { SmallPrepArgs *A; unsigned blocks; size_t lds; } ctx{&A, (unsigned)blocks, lds};
     const int rc = spin_kernel_chain(s, [](void *c, hipStream_t st) {
         Ctx *x = static_cast<Ctx *>(c);
         graph_prep_small_kernel<<<x->blocks, kSmallPrepThreads, x->lds, st>>>(*x->A);
     }, &ctx, (int)blocks);
-    if (rc != TGNN_OK) return rc;
+    if (rc != TGNN_OK) {
+        if (poll_dev >= 0) g_prep_poll[poll_dev] = nullptr;   // (nothing was launched: nothing to wait for)
+        return rc;
+    }
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
 }

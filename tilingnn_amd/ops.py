@@ -359,8 +359,12 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
     head = (ptr(adj), ea, ptr(attr), fe, ptr(col), ec, n_nodes) + (() if small else (n_src_nodes or n_nodes,)) + (ptr(a_rowptr), ptr(a_src), ptr(a_eid), ptr(adj_type), ptr(edge_type),
             ptr(rep), ptr(c_rowptr), ptr(c_src), ptr(c_eid),
             *((ptr(tile_col_ptr), ptr(col_meta), ptr(col_slot_src)) if want_cols else (None,) * 3))
+    small_words = None
     if small:
-        check(lib.tgnn_graph_prep_small(*head, ptr(tmp), ptr(res), ptr(_small_prep_counters(dev)), _stream(adj)))
+        # [r6] the kernel stores its result words into this thread's pinned buffer, tgnn_graph_prep_wait polls word 31
+        small_words = _pinned_result_words(dev) if lib.tgnn_set_prep_words_poll(-1) else None
+        check(lib.tgnn_graph_prep_small(*head, ptr(tmp), ptr(res), ptr(_small_prep_counters(dev)),
+                                        C.c_void_p(small_words.data_ptr()) if small_words is not None else None, _stream(adj)))
     else:
         mid_args = (ptr(mid_nb), ptr(mid_ent)) if want_mid else (None,) * 2
         eg_args = (ptr(tile_grp_ptr), ptr(grp)) if want_eg else (None,) * 2
@@ -391,7 +395,11 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
     else:
         if after_enqueue is not None:
             after_enqueue()
-        host = _read_back(res)                                                   # the one sync
+        if small_words is not None:
+            check(lib.tgnn_graph_prep_wait(_stream(adj)))                        # the one sync: a poll of pinned memory
+            host = small_words.tolist()
+        else:
+            host = _read_back(res)                                               # the one sync
     if host[1] or host[2]:
         raise IndexError(f"edge index out of range [0, {n_nodes}) in {'adj_e_index' if host[1] else 'col_e_idx'}")
     if host[6]:
