@@ -366,6 +366,16 @@ int tgnn_forward_begin(const tgnn_model_dims *dims, const void *const *params_ho
 int tgnn_forward_resume(const tgnn_model_dims *dims, const void *const *params_host, const float *x, const float *adj_edge_attr,
                         const tgnn_graph *graph, int32_t update_running, float *probs, void *ws, size_t ws_bytes,
                         tgnn_stream_t stream, tgnn_stream_t stream2);
+/* [r6] Small layouts (<= tgnn_get_small_layout_limit() nodes: the forward is one persistent kernel behind a pre-pass): the pre-pass
+ * -- edge weights with their operand images, parameter pack -- queued on `stream` BEHIND tgnn_graph_prep_small and before the host
+ * has its result words; the type count is read on the device (n_types_dev = the preparation's `result`, word 0; type_rep_edge:
+ * its output of that name).  ws as for tgnn_forward with n_types = 0 (the layout does not depend on the count up to 16).  The
+ * next tgnn_forward of this thread with the same ws and node count uses it if it takes the small-layout path (otherwise it queues
+ * its own work: nothing is lost but the launches).  TGNN_ERR_UNSUPPORTED (nothing queued) where it does not apply. */
+int tgnn_forward_small_prepass(const tgnn_model_dims *dims, const void *const *params_host, const float *adj_edge_attr,
+                               const int32_t *type_rep_edge, const int32_t *n_types_dev, int64_t n_nodes, void *ws, size_t ws_bytes,
+                               tgnn_stream_t stream);
+
 /* [r6] Optional, between the two: queued on `stream` BEHIND tgnn_graph_prep's launches and before the host has read the type count
  * -- the edge weights and the edge-group NNConv's operand images of all layers (the first launch tgnn_forward_resume would queue),
  * with the count read on the device from n_types_dev (= tgnn_graph_prep's `result`, word 0; more than 16 types: the launch writes

@@ -248,6 +248,13 @@ struct HeadEvent {
     bool weights = false;            // tgnn_forward_begin_weights has queued the edge weights (edge-group images, device-side type count)
 };
 static thread_local HeadEvent g_head[64];
+// [r6] tgnn_forward_small_prepass: the workspace whose edge weights (bf16 x 3 images, type count read on the device) and parameter
+// pack are queued on the caller's stream already -- what a small layout's forward does in front of its one persistent kernel
+struct SmallPre {
+    const void *ws = nullptr;
+    int64_t n = 0;
+};
+static thread_local SmallPre g_small_pre[64];
 // words of w.bounds holding (max |W_l|, bound of |BN(input of l)|) of the final MLP's layer l = 1 .. 3 (3: lean head only)
 static inline unsigned *final_bound_word(const Workspace &w, int D, int l) { return w.bounds + (l <= 2 ? 2 * D + 2 + 2 * (l - 1) : 2 * D + 8); }
 static int forward_head_bounds_images(const tgnn_model_dims *dims, const Params &P, const Workspace &w, int64_t n, int64_t n_total,
@@ -363,6 +370,14 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     bool weights_early = false;
+    bool small_pre = false;
+    {
+        int devp = 0;
+        if (hipGetDevice(&devp) == hipSuccess && devp >= 0 && devp < 64 && g_small_pre[devp].ws) {
+            small_pre = g_small_pre[devp].ws == ws && g_small_pre[devp].n == n && !head_done && !sh && !keep;
+            g_small_pre[devp].ws = nullptr;
+        }
+    }
     if (head_done) {
         int dev = 0;
         TGNN_CHECK_HIP(hipGetDevice(&dev));
@@ -515,7 +530,9 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
         set_error("tgnn_forward: nn_mid_verdict given, but the mid-size forward of this layout is not the two persistent kernels alone");
         return TGNN_ERR_UNVERIFIED;
     }
-    unsigned *weights_done = mid_counter ? w.bounds + 2 * D + 6 : (small_teams == 2 && s2 && weights_on_side) ? w.small_ctr + 16 : nullptr;
+    // [r6] a small layout whose pre-pass is on `stream` already (tgnn_forward_small_prepass): nothing to wait for, nothing to queue
+    const bool small_pre_used = small_pre && small_teams && c == 32 && T <= kCarveTypes && cols_ok && edge_weight_table_device_count_ok(fe, c);
+    unsigned *weights_done = mid_counter ? w.bounds + 2 * D + 6 : (small_teams == 2 && s2 && weights_on_side && !small_pre_used) ? w.small_ctr + 16 : nullptr;
     if (weights_done && !mid_counter) TGNN_CHECK_HIP(hipMemsetAsync(weights_done, 0, 4, s));
     const unsigned weights_target = edge_weight_table_blocks(T, fe, D, c, tiled);
     // [r6] the general schedule's head: no memset anywhere (a hipMemsetAsync is two fill kernels and ~10 us in front of the first
@@ -542,7 +559,9 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     // them and none in front of the first NNConv: ~12 us each), and the collision chain is released first -- its first aggregate
     // runs beside them instead of behind them
     const bool weights_on_main = head_used && s2 && !sh && !keep && !mid_k && !small_teams && (g_lean_head.load(std::memory_order_relaxed) & 8) == 0;
-    if (weights_on_main) {
+    if (small_pre_used) {
+        // (everything in front of the persistent kernel is on `stream`)
+    } else if (weights_on_main) {
         TGNN_CHECK_HIP(hipEventRecord(ev[0], s));            // middle[0] (the head's event, waited for above) and the layout are complete
         TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[0], 0));
     } else if (s2 && weights_on_side) {
@@ -553,7 +572,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
     // (first on the side stream: the layer loop waits for these, the final MLP's bounds and images have the whole loop's time)
     // [r6] tgnn_forward_begin_weights has queued exactly this launch behind the preparation already (type count read on the device)
     const bool weights_queued = weights_early && weights_on_main && eg && T <= kCarveTypes && !weights_done && edge_weight_table_device_count_ok(fe, c);
-    if ((T > 0 || tiled) && !weights_queued) {
+    if ((T > 0 || tiled) && !weights_queued && !small_pre_used) {
         // edge MLP of every (layer, type) and, for the matrix-core NNConv, its operand images (root = pseudo-type T): one launch
         EdgeMlpLayers layers{};
         const float *roots[kMaxDepth];
@@ -604,7 +623,7 @@ static int forward_impl(const tgnn_model_dims *dims, const void *const *params_h
             dimg_ok[l] = c == 32 && n >= kDenseRowsKernelMin && dense_f16_image_build(P.f(P.fin(l)), fin_dims[l], fin_dims[l + 1], wm, w.dimg[l], sw) == TGNN_OK;
         }
     }
-    if (small_teams) launch_small_pack(P, D, w.small_pack, w.small_ctr, s);   // on the main stream: it has nothing else to do yet
+    if (small_teams && !small_pre_used) launch_small_pack(P, D, w.small_pack, w.small_ctr, s);   // on the main stream: it has nothing else to do yet
     // (parameter vectors + GIN images of the layers; the same launch clears the barrier counter and the tagged partial rows)
     if (mid_k) launch_small_pack(P, D, w.small_pack, w.small_ctr, s, tail_k > 0 || mid_init, w.mid_part, mid_part_doubles() * sizeof(double), tail_k > 0 ? dense_max : nullptr,
                                  sw != s ? sw : nullptr);   // (the final MLP's images: side stream, joined behind the layer loop)
@@ -1018,6 +1037,43 @@ extern "C" int tgnn_forward_begin(const tgnn_model_dims *dims, const void *const
 // [r6] Between tgnn_forward_begin and tgnn_forward_resume, BEHIND the preparation's launches on `stream` and before the host has the
 // type count: the edge weights and the edge-group NNConv's operand images of all layers, with the count read on the device
 // (result word 0 of tgnn_graph_prep) -- the launch tgnn_forward_resume would queue first, ~60 us of host round trip earlier.
+// [r6] Small layouts (the one persistent kernel, forward_small.hip): what their forward queues in front of that kernel -- the edge
+// weights with the column kernel's bf16 x 3 operand images and the parameter pack -- BEHIND the one-launch preparation on `stream`
+// and before the host has read its result words: the type count is read on the device (`n_types_dev` = the preparation's result
+// word 0).  The next tgnn_forward of this thread with the same workspace and node count picks it up if it takes the small-layout
+// path; any other forward queues its own.
+extern "C" int tgnn_forward_small_prepass(const tgnn_model_dims *dims, const void *const *params_host, const float *adj_edge_attr,
+                                          const int32_t *type_rep_edge, const int32_t *n_types_dev, int64_t n_nodes, void *ws,
+                                          size_t ws_bytes, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
+    TGNN_CHECK_ARG(dims_ok(dims) && params_host && adj_edge_attr && type_rep_edge && n_types_dev, "arguments");
+    int dev = 0;
+    TGNN_CHECK_HIP(hipGetDevice(&dev));
+    TGNN_CHECK_ARG(dev >= 0 && dev < 64, "device index");
+    const int c = dims->network_width, D = dims->network_depth, fe = dims->adj_edge_features_dim;
+    if (c != 32 || n_nodes < 2 || n_nodes > tgnn_get_small_layout_limit() || !edge_weight_table_device_count_ok(fe, c) ||
+        (g_lean_head.load(std::memory_order_relaxed) & 8))
+        return TGNN_ERR_UNSUPPORTED;
+    Workspace w = carve(*dims, n_nodes, n_nodes, 0, ws, ws_bytes);
+    if (!ws || w.bytes > ws_bytes) return TGNN_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Params P{params_host, D};
+    EdgeMlpLayers layers{};
+    const float *roots[kMaxDepth];
+    for (int i = 0; i < D; ++i) {
+        const int b = P.layer(i);
+        layers.l[i] = EdgeMlpLayer{P.f(b), P.f(b + 1), P.f(b + 2), P.f(b + 3), P.f(b + 4), P.f(b + 5)};
+        roots[i] = P.f(b + 6);
+    }
+    launch_edge_weight_table_batched(adj_edge_attr, type_rep_edge, 0, fe, layers, D, c, w.wtab, roots, w.wimg, s, nullptr, nullptr, 1.0f,
+                                     n_types_dev, kCarveTypes);
+    launch_small_pack(P, D, w.small_pack, w.small_ctr, s);
+    g_small_pre[dev].ws = ws;
+    g_small_pre[dev].n = n_nodes;
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}
+
 extern "C" int tgnn_forward_begin_weights(const tgnn_model_dims *dims, const void *const *params_host, const float *adj_edge_attr,
                                           const int32_t *type_rep_edge, const int32_t *n_types_dev, int64_t n_nodes, void *ws,
                                           size_t ws_bytes, tgnn_stream_t stream) {

@@ -288,8 +288,24 @@ class TilinGNN(Tracked, nn.Module):
                                                          n, ptr(state["ws"]), state["bytes"], _lib.current_stream(dev))
                     if rcw not in (0, _lib.ERR_UNSUPPORTED):
                         check(rcw)
+            # a small layout (one persistent kernel behind a pre-pass): the pre-pass -- edge weights, parameter pack -- behind the
+            # one-launch preparation, the type count read on the device (tgnn_forward_small_prepass)
+            use_small = (not use_begin and bn_train and fast and 2 <= n <= min(4096, int(lib.tgnn_get_small_layout_limit())))
+
+            def small_pre(info=None):
+                if info is None:
+                    return
+                nbytes = lib.tgnn_forward_workspace_bytes(C.byref(dims), n, 0)
+                wsp = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                rcs = lib.tgnn_forward_small_prepass(C.byref(dims), table, ptr(ea), ptr(info["type_rep_edge"]), ptr(info["result"]), n,
+                                                     ptr(wsp), nbytes, _lib.current_stream(dev))
+                if rcs == 0:
+                    state["small_ws"], state["small_bytes"] = wsp, nbytes
+                elif rcs != _lib.ERR_UNSUPPORTED:
+                    check(rcs)
             try:
-                return ops.prepare_graph(n, adj_e_index, adj_e_features, col_e_idx, after_enqueue=weights if use_begin else None)
+                return ops.prepare_graph(n, adj_e_index, adj_e_features, col_e_idx,
+                                         after_enqueue=weights if use_begin else small_pre if use_small else None)
             except Exception:
                 side = _lib.side_stream_torch(dev) if state.get("rc") == 0 else None
                 if side is not None:                                          # (begin's launches write the workspace freed below)
@@ -310,7 +326,9 @@ class TilinGNN(Tracked, nn.Module):
                     torch.cuda.current_stream(dev).wait_stream(side)          # (begin's launches still write the smaller workspace)
                 begun = False
                 init_done = 2 if update_running else 0                        # (... and have updated the init MLP's running statistics)
-        if not begun:
+        if not begun and "small_ws" in state and graph.n_types <= 16:
+            ws, ws_bytes = state["small_ws"], state["small_bytes"]            # (the pre-pass is in it)
+        elif not begun:
             ws_bytes = lib.tgnn_forward_workspace_bytes(C.byref(dims), n, graph.n_types)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         if graph.cols is None and graph.groups is not None and (not bn_train or lib.tgnn_set_split_precision(-1) == 0 or

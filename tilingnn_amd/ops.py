@@ -394,7 +394,7 @@ def _prepare_graph_fused(n_nodes: int, adj: Tensor, attr: Tensor, col: Tensor, s
         host[9] = 0                                                              # (optimistic: see `late`)
     else:
         if after_enqueue is not None:
-            after_enqueue()
+            after_enqueue({"type_rep_edge": rep, "result": res} if small else None)
         if small_words is not None:
             check(lib.tgnn_graph_prep_wait(_stream(adj)))                        # the one sync: a poll of pinned memory
             host = small_words.tolist()
