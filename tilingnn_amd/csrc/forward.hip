@@ -1046,7 +1046,8 @@ extern "C" int tgnn_forward_small_prepass(const tgnn_model_dims *dims, const voi
                                           const int32_t *type_rep_edge, const int32_t *n_types_dev, int64_t n_nodes, void *ws,
                                           size_t ws_bytes, tgnn_stream_t stream) {
     DeviceGuard guard__(stream);
-    TGNN_CHECK_ARG(dims_ok(dims) && params_host && adj_edge_attr && type_rep_edge && n_types_dev, "arguments");
+    TGNN_CHECK_ARG(dims_ok(dims) && params_host && n_types_dev, "arguments");
+    if (!adj_edge_attr || !type_rep_edge) return TGNN_ERR_UNSUPPORTED;   // (a layout without adjacency edges: nothing to queue early)
     int dev = 0;
     TGNN_CHECK_HIP(hipGetDevice(&dev));
     TGNN_CHECK_ARG(dev >= 0 && dev < 64, "device index");
@@ -1078,7 +1079,8 @@ extern "C" int tgnn_forward_begin_weights(const tgnn_model_dims *dims, const voi
                                           const int32_t *type_rep_edge, const int32_t *n_types_dev, int64_t n_nodes, void *ws,
                                           size_t ws_bytes, tgnn_stream_t stream) {
     DeviceGuard guard__(stream);
-    TGNN_CHECK_ARG(dims_ok(dims) && params_host && adj_edge_attr && type_rep_edge && n_types_dev, "arguments");
+    TGNN_CHECK_ARG(dims_ok(dims) && params_host && n_types_dev, "arguments");
+    if (!adj_edge_attr || !type_rep_edge) return TGNN_ERR_UNSUPPORTED;   // (a layout without adjacency edges: nothing to queue early)
     int dev = 0;
     TGNN_CHECK_HIP(hipGetDevice(&dev));
     TGNN_CHECK_ARG(dev >= 0 && dev < 64, "device index");
