@@ -879,6 +879,12 @@ size_t tgnn_forward_bf16_workspace_bytes(const tgnn_model_dims *dims, int64_t n_
 int tgnn_forward_bf16(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
                       const float *adj_edge_attr, const tgnn_graph *graph, int32_t update_running, float *probs,
                       void *ws, size_t ws_bytes, tgnn_stream_t stream, tgnn_stream_t stream2);
+/* [r6] A NEW layout: the init MLP (TilinGNN.py:54 -- it needs nothing of the graph) queued on stream2 BEFORE the layout's
+ * preparation, so that it runs beside it; the caller has ordered stream2 behind x and the parameters.  ws: as for
+ * tgnn_forward_bf16 (the workspace's size and layout do not depend on the type count).  The next tgnn_forward_bf16 of this thread
+ * with the same ws and node count waits for it and skips its own init MLP (the running-statistics update was applied here). */
+int tgnn_forward_bf16_begin(const tgnn_model_dims *dims, const void *const *params_host, const float *x, int64_t n_nodes,
+                            int32_t update_running, void *ws, size_t ws_bytes, tgnn_stream_t stream2);
 
 int tgnn_rows_gather(const float *src, int64_t ld_src, const int32_t *idx, int64_t n_idx, int32_t c,
                      float *out, int64_t ld_out, tgnn_stream_t stream);

@@ -220,6 +220,29 @@ def test_config3_forward_runs_and_is_reproducible(dev, big):
     assert p1.shape == (100_000, 1) and bool(torch.isfinite(p1).all()) and torch.equal(p1, p2)
 
 
+def test_config3_new_layout_takes_the_early_init_mlp(dev, big):
+    """[r6] A new layout (cache off): the init MLP is queued on the side stream in front of the preparation
+    (tgnn_forward_bf16_begin) -- the same bits as the cached layout's forward, and ONE running-statistics update."""
+    x, adj, attr, col, _ = big
+    ref, _ = make_net(dev)
+    ref.activation_dtype = torch.bfloat16
+    ref(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)                       # (fills the layout cache: no begin)
+    ref2, _ = make_net(dev)
+    ref2.activation_dtype = torch.bfloat16
+    want = ref2(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)[0].clone()    # cached layout: the plain forward
+    net, _ = make_net(dev)
+    net.activation_dtype = torch.bfloat16
+    net.cache_graph = False
+    got = net(x=x, adj_e_index=adj, adj_e_features=attr, col_e_idx=col)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    for k, v in ref2.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            assert int(net.state_dict()[k]) == 1 == int(v), k
+        elif k.endswith(("running_mean", "running_var")):
+            assert torch.equal(net.state_dict()[k], v), k
+
+
 def compose_forward(net, x, adj, attr, col):
     """TilinGNN.forward (TilinGNN.py:51-78) spelled out op by op with the per-op entry points validated above -- the checker
     of the fused library call `tgnn_forward_bf16` (same kernels, same order: bit-identical probabilities)."""

@@ -203,6 +203,7 @@ def _load() -> C.CDLL:
         "tgnn_dense_bf16_slots_fwd": (C.c_int, [p, i64, i32, p, p, i64, i32, i32, p, p, p, pi32, p]),
         "tgnn_forward_bf16_workspace_bytes": (sz, [C.POINTER(ModelDims), i64, i32]),
         "tgnn_forward_bf16": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), p, p, C.POINTER(Graph), i32, p, p, sz, p, p]),
+        "tgnn_forward_bf16_begin": (C.c_int, [C.POINTER(ModelDims), C.POINTER(C.c_void_p), p, i64, i32, p, sz, p]),
         "tgnn_rows_gather": (C.c_int, [p, i64, p, i64, i32, p, i64, p]),
         "tgnn_rows_scatter": (C.c_int, [p, p, i64, i32, p, i64, p]),
     }
@@ -238,7 +239,7 @@ EXPORTED_SYMBOLS = (
     "tgnn_spin_error_poll", "tgnn_set_spin_budget_us", "tgnn_persist_fallback", "tgnn_spin_error_peek", "tgnn_gin_fwd", "tgnn_dense_act_fwd", "tgnn_dense_act_slots_fwd", "tgnn_dense_act_slots_f16_fwd", "tgnn_bn_finalize", "tgnn_bn_apply",
     "tgnn_merge_fwd", "tgnn_param_count", "tgnn_param_name", "tgnn_forward_workspace_bytes", "tgnn_forward", "tgnn_forward_begin", "tgnn_forward_resume",
     "tgnn_forward_profiled", "tgnn_forward_profiled_two_stream", "tgnn_forward_stamped", "tgnn_forward_many", "tgnn_graph_prep_small_max_nodes", "tgnn_graph_prep_small_max_edges", "tgnn_graph_prep_small_tmp_ints",
-    "tgnn_graph_prep_small", "tgnn_graph_prep_workspace_bytes", "tgnn_graph_prep", "tgnn_graph_prep_wait", "tgnn_set_small_layout_limit", "tgnn_get_small_layout_limit", "tgnn_set_split_precision", "tgnn_set_gin_fused", "tgnn_set_gin_mlp_f16", "tgnn_set_mid_tail", "tgnn_set_nnconv_eg", "tgnn_set_dense_rows_mode", "tgnn_set_lean_head", "tgnn_set_prep_words_poll", "tgnn_forward_begin_weights", "tgnn_forward_small_prepass", "tgnn_rccl_available", "tgnn_rccl_unique_id_bytes", "tgnn_rccl_unique_id", "tgnn_rccl_comm_create", "tgnn_rccl_comm_destroy", "tgnn_rccl_counters", "tgnn_forward_train", "tgnn_backward_workspace_bytes", "tgnn_backward", "tgnn_forward_sharded_workspace_bytes", "tgnn_forward_sharded",
+    "tgnn_graph_prep_small", "tgnn_graph_prep_workspace_bytes", "tgnn_graph_prep", "tgnn_graph_prep_wait", "tgnn_set_small_layout_limit", "tgnn_get_small_layout_limit", "tgnn_set_split_precision", "tgnn_set_gin_fused", "tgnn_set_gin_mlp_f16", "tgnn_set_mid_tail", "tgnn_set_nnconv_eg", "tgnn_set_dense_rows_mode", "tgnn_set_lean_head", "tgnn_set_prep_words_poll", "tgnn_forward_begin_weights", "tgnn_forward_bf16_begin", "tgnn_forward_small_prepass", "tgnn_rccl_available", "tgnn_rccl_unique_id_bytes", "tgnn_rccl_unique_id", "tgnn_rccl_comm_create", "tgnn_rccl_comm_destroy", "tgnn_rccl_counters", "tgnn_forward_train", "tgnn_backward_workspace_bytes", "tgnn_backward", "tgnn_forward_sharded_workspace_bytes", "tgnn_forward_sharded",
     "tgnn_rows_gather", "tgnn_rows_scatter", "tgnn_unsupervised_loss_workspace_bytes", "tgnn_unsupervised_loss", "tgnn_solution_score_sums",
     "tgnn_sublayout_workspace_bytes", "tgnn_sublayout_compact", "tgnn_greedy_round_workspace_bytes", "tgnn_greedy_round", "tgnn_shard_alive_rows",
     "tgnn_transpose", "tgnn_swap_leading", "tgnn_gin_aggregate", "tgnn_sigmoid_bwd", "tgnn_add_into", "tgnn_reduce_workspace_bytes", "tgnn_colsum",

@@ -876,7 +876,10 @@ static Ws64 carve64(const tgnn_model_dims &d, int64_t n, int32_t n_types, void *
     w.a2[0] = cv.take<__bf16>((size_t)n * kC);
     w.a2[1] = cv.take<__bf16>((size_t)n * kC);
     w.z = cv.take<__bf16>((size_t)n * kC);
-    w.wimg = cv.take<__bf16>((size_t)D * (n_types + 1) * kC * kC);
+    // [r6] the two type-dependent pieces sized for at least 16 types (what the kernels take): the layout then does not depend on the
+    // type count, and tgnn_forward_bf16_begin can fill middle[0] before the layout is prepared
+    const int tc = n_types < 16 ? 16 : n_types;
+    w.wimg = cv.take<__bf16>((size_t)D * (tc + 1) * kC * kC);
     w.wfin = cv.take<__bf16>((size_t)256 * kC * (D + 1));
     w.pre32 = cv.take<float>((size_t)n * kC);
     w.ctr = cv.take<unsigned>(64);                           // ([32 .. 37]: the final MLP's bounds, dense_bounds_kernel)
@@ -890,7 +893,7 @@ static Ws64 carve64(const tgnn_model_dims &d, int64_t n, int32_t n_types, void *
     w.f2 = cv.take<float>((size_t)n * 128);
     w.f3 = cv.take<float>((size_t)n * 64);
     w.f4 = cv.take<float>((size_t)n * kC);
-    w.wtab = cv.take<float>((size_t)D * (n_types > 0 ? n_types : 1) * kC * kC);
+    w.wtab = cv.take<float>((size_t)D * tc * kC * kC);
     w.part1 = cv.take<double>((size_t)TGNN_BN_MAX_PARTIALS * 2 * kC);
     w.part2 = cv.take<double>((size_t)TGNN_BN_MAX_PARTIALS * 2 * kC);
     w.partf = cv.take<double>((size_t)TGNN_BN_MAX_PARTIALS * 2 * 256);
@@ -1416,6 +1419,62 @@ extern "C" size_t tgnn_forward_bf16_workspace_bytes(const tgnn_model_dims *dims,
     return carve64(*dims, n_nodes, n_types, nullptr, 0).bytes;
 }
 
+// ---- init MLP (TilinGNN.py:54; fp32 products on the existing dense kernels), middle[0] stored as bf16; everything on `stream`
+static int init_mlp64(const tgnn_model_dims *dims, const Params &P, const float *x, const Ws64 &w, int64_t n, int update_running,
+                      tgnn_stream_t stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int fx = dims->node_features_dim;
+    int32_t np1 = 0;
+    auto finalize1 = [&](const BnPtrs &b, float *stat) {
+        BnJobs jobs{};
+        jobs.job[0] = BnJob{w.partf, np1, nullptr, b.gamma, b.beta, update_running ? b.rm : nullptr, update_running ? b.rv : nullptr,
+                            update_running ? b.nbt : nullptr, stat};
+        launch_bn_finalize(jobs, 1, 0, kC, n, 1e-5f, 0.1f, s);
+    };
+    TGNN_TRY64(tgnn_dense_act_fwd(x, fx, 32, nullptr, P.f(P.init(0)), P.f(P.init(0) + 1), n, fx, kC, TGNN_ACT_LEAKY_RELU, w.t0, kC,
+                                  w.partf, &np1, stream));
+    finalize1(P.bn(P.init(0) + 2), w.stat_i[0]);
+    TGNN_TRY64(tgnn_dense_act_fwd(w.t0, kC, 32, w.stat_i[0], P.f(P.init(1)), P.f(P.init(1) + 1), n, kC, kC, TGNN_ACT_LEAKY_RELU,
+                                  w.ainit, kC, w.partf, &np1, stream));
+    finalize1(P.bn(P.init(1) + 2), w.stat_i[1]);
+    bn_apply_bf16_kernel<<<ew_grid64(n * kC), 256, 0, s>>>(w.ainit, w.stat_i[1], n, kC, w.mid);
+    return TGNN_OK;
+}
+
+// [r6] the init MLP of a NEW layout's forward on stream2, BEFORE / beside the layout's preparation (it needs nothing of the graph;
+// the workspace's layout does not depend on the type count): the next tgnn_forward_bf16 of this thread with the same workspace and
+// node count waits for the event and skips its own (its running-statistics update has been applied here)
+struct Head64 {
+    hipEvent_t ev = nullptr;
+    const void *ws = nullptr;
+    int64_t n = 0;
+};
+static thread_local Head64 g_head64[64];
+
+extern "C" int tgnn_forward_bf16_begin(const tgnn_model_dims *dims, const void *const *params_host, const float *x, int64_t n_nodes,
+                                       int32_t update_running, void *ws, size_t ws_bytes, tgnn_stream_t stream2) {
+    DeviceGuard guard__(stream2);
+    TGNN_CHECK_ARG(dims && dims->network_width == kC && dims->network_depth >= 1 && dims->network_depth <= kMaxDepth && params_host && x &&
+                   n_nodes >= 2 && stream2, "arguments");
+    Ws64 w = carve64(*dims, n_nodes, 0, ws, ws_bytes);
+    if (!ws || w.bytes > ws_bytes) {
+        set_error("tgnn_forward_bf16_begin: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
+        return TGNN_ERR_WORKSPACE;
+    }
+    int dev = 0;
+    TGNN_CHECK_HIP(hipGetDevice(&dev));
+    TGNN_CHECK_ARG(dev >= 0 && dev < 64, "device index");
+    Head64 &he = g_head64[dev];
+    if (!he.ev) TGNN_CHECK_HIP(hipEventCreateWithFlags(&he.ev, hipEventDisableTiming));
+    const Params P{params_host, dims->network_depth};
+    TGNN_TRY64(init_mlp64(dims, P, x, w, n_nodes, update_running, stream2));
+    TGNN_CHECK_HIP(hipEventRecord(he.ev, static_cast<hipStream_t>(stream2)));
+    he.ws = ws;
+    he.n = n_nodes;
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}
+
 /* TilinGNN.forward (TilinGNN.py:51-78) at network_width 64 with bf16 activation storage; same parameter table, graph
  * structure and BatchNorm semantics as tgnn_forward.  Train mode only (the mode the reference runs inference in). */
 extern "C" int tgnn_forward_bf16(const tgnn_model_dims *dims, const void *const *params_host, const float *x,
@@ -1432,7 +1491,7 @@ extern "C" int tgnn_forward_bf16(const tgnn_model_dims *dims, const void *const 
     TGNN_CHECK_ARG(graph->adj_rowptr && graph->col_rowptr && (have_cols || eg),
                    "graph pointers (the NNConv column structure or the edge groups are required)");
     TGNN_CHECK_ARG(n * 128 < (int64_t(1) << 31), "rows must lie within 2 GB");
-    const int T = graph->n_types, D = dims->network_depth, fx = dims->node_features_dim, fe = dims->adj_edge_features_dim;
+    const int T = graph->n_types, D = dims->network_depth, fe = dims->adj_edge_features_dim;
     TGNN_CHECK_ARG(T == 0 || (adj_edge_attr && graph->type_rep_edge), "adjacency pointers");
     if ((eg ? nnconv64_eg_lds_bytes(T, 16) : nnconv64_lds_bytes(T, 16)) > kMaxLds64) {
         set_error("tgnn_forward_bf16: %d edge types do not fit the LDS weight image", T);
@@ -1499,14 +1558,19 @@ extern "C" int tgnn_forward_bf16(const tgnn_model_dims *dims, const void *const 
         nnconv64_image_kernel<<<dim3(T + 1, D), 256, 0, sw>>>(w.wtab, rp, T, w.wimg);
     }
     if (sw != s) TGNN_CHECK_HIP(hipEventRecord(ev[kEvWeights64], s2));
-    // ---- init MLP (fp32 products on the existing dense kernels), middle[0] stored as bf16
-    TGNN_TRY64(tgnn_dense_act_fwd(x, fx, 32, nullptr, P.f(P.init(0)), P.f(P.init(0) + 1), n, fx, kC, TGNN_ACT_LEAKY_RELU, w.t0, kC,
-                                  w.partf, &np1, stream));
-    finalize1(w.partf, np1, kC, P.bn(P.init(0) + 2), w.stat_i[0]);
-    TGNN_TRY64(tgnn_dense_act_fwd(w.t0, kC, 32, w.stat_i[0], P.f(P.init(1)), P.f(P.init(1) + 1), n, kC, kC, TGNN_ACT_LEAKY_RELU,
-                                  w.ainit, kC, w.partf, &np1, stream));
-    finalize1(w.partf, np1, kC, P.bn(P.init(1) + 2), w.stat_i[1]);
-    bn_apply_bf16_kernel<<<ew_grid64(n * kC), 256, 0, s>>>(w.ainit, w.stat_i[1], n, kC, w.mid);
+    // ---- init MLP: tgnn_forward_bf16_begin's (this thread, this workspace and node count), or here
+    {
+        int devh = 0;
+        TGNN_CHECK_HIP(hipGetDevice(&devh));
+        Head64 *he = devh >= 0 && devh < 64 ? &g_head64[devh] : nullptr;
+        if (he && he->ws && he->ws == ws && he->n == n) {
+            he->ws = nullptr;
+            TGNN_CHECK_HIP(hipStreamWaitEvent(s, he->ev, 0));
+        } else {
+            if (he) he->ws = nullptr;
+            TGNN_TRY64(init_mlp64(dims, P, x, w, n, update_running, stream));
+        }
+    }
     // ---- main loop.  a2[i & 1] holds h2_i = the collision branch's BatchNorm OUTPUT (stored normalised, see the MLP kernel)
     TGNN_CHECK_HIP(hipMemsetAsync(w.ctr, 0, 64 * sizeof(unsigned), s));
     if (s2) {

@@ -7,6 +7,7 @@ to bf16 operand images inside the library; BatchNorm partial sums are fp64, stat
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -140,15 +141,33 @@ def forward(net, x: Tensor, adj_e_index: Tensor, adj_e_features: Tensor, col_e_i
                          "solver does, ml_solver.py:131)")
     table, dev = net._param_table()
     n = int(x.shape[0])
-    if graph is None:
-        graph = ops.prepare_graph(n, adj_e_index, adj_e_features, col_e_idx)
-    if (graph.cols is None and graph.groups is None) or graph.n_types > max_types():
-        raise ValueError(f"the bf16 path needs the NNConv type columns or edge groups and at most {max_types()} edge types")
     dims = net._dims()
-    ws_bytes = lib.tgnn_forward_bf16_workspace_bytes(C.byref(dims), n, graph.n_types)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    xf = ops._f32c(x, "x")
+    ws = None
+    if graph is None:
+        # [r6] a NEW layout: the init MLP needs nothing of the graph -- queued on the side stream in front of the preparation, it
+        # runs beside it (tgnn_forward_bf16_begin; the workspace does not depend on the type count)
+        side = _lib.side_stream_torch(dev) if n >= 2 and os.environ.get("TGNN_BF16_BEGIN", "1") == "1" else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(dev))
+            ws_bytes = lib.tgnn_forward_bf16_workspace_bytes(C.byref(dims), n, 0)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            check(lib.tgnn_forward_bf16_begin(C.byref(dims), table, ptr(xf), n, 1, ptr(ws), ws_bytes, _lib.side_stream(dev)))
+        try:
+            graph = ops.prepare_graph(n, adj_e_index, adj_e_features, col_e_idx)
+        except Exception:
+            if side is not None:                                   # (begin's launches write the workspace freed below)
+                torch.cuda.current_stream(dev).wait_stream(side)
+            raise
+    if (graph.cols is None and graph.groups is None) or graph.n_types > max_types():
+        if ws is not None:
+            torch.cuda.current_stream(dev).wait_stream(_lib.side_stream_torch(dev))
+        raise ValueError(f"the bf16 path needs the NNConv type columns or edge groups and at most {max_types()} edge types")
+    if ws is None:
+        ws_bytes = lib.tgnn_forward_bf16_workspace_bytes(C.byref(dims), n, graph.n_types)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     probs = torch.empty(n, net.output_dim, dtype=torch.float32, device=dev)
     g = graph.c_struct()
-    check(lib.tgnn_forward_bf16(C.byref(dims), table, ptr(ops._f32c(x, "x")), ptr(ops._f32c(adj_e_features, "adj_e_features")),
+    check(lib.tgnn_forward_bf16(C.byref(dims), table, ptr(xf), ptr(ops._f32c(adj_e_features, "adj_e_features")),
                                 C.byref(g), 1, ptr(probs), ptr(ws), ws_bytes, _lib.current_stream(dev), _lib.side_stream(dev)))
     return probs
