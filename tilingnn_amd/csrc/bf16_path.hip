@@ -1531,45 +1531,51 @@ extern "C" int tgnn_forward_bf16(const tgnn_model_dims *dims, const void *const 
         jobs.job[0] = bn_job(part, nparts, b, stat);
         launch_bn_finalize(jobs, 1, 0, f, n, eps, momentum, s);
     };
-    // ---- per-type NNConv matrices of all layers (fp32 table, then the bf16 operand images)
-    // [r6] on the side stream, beside the init MLP (the first NNConv waits for them; ~40 us of the head were serial)
-    hipStream_t sw = s;
-#ifndef TGNN_ABL_C3SERIALHEAD
-    if (s2)
-#else
-    if (false)
-#endif
-    {
-        TGNN_CHECK_HIP(hipEventRecord(ev[kEvFork64], s));    // what the caller queued on `stream` so far (x, the parameters, the layout)
-        TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[kEvFork64], 0));
-        sw = s2;
-    }
-    if (T > 0) {
-        EdgeMlpLayers layers{};
-        for (int i = 0; i < D; ++i) {
-            const int b = P.layer(i);
-            layers.l[i] = EdgeMlpLayer{P.f(b), P.f(b + 1), P.f(b + 2), P.f(b + 3), P.f(b + 4), P.f(b + 5)};
-        }
-        launch_edge_weight_table_batched(adj_edge_attr, graph->type_rep_edge, T, fe, layers, D, kC, w.wtab, nullptr, nullptr, sw);
-    }
-    {
-        RootPtrs64 rp{};
-        for (int i = 0; i < D; ++i) rp.p[i] = P.f(P.layer(i) + 6);
-        nnconv64_image_kernel<<<dim3(T + 1, D), 256, 0, sw>>>(w.wtab, rp, T, w.wimg);
-    }
-    if (sw != s) TGNN_CHECK_HIP(hipEventRecord(ev[kEvWeights64], s2));
-    // ---- init MLP: tgnn_forward_bf16_begin's (this thread, this workspace and node count), or here
+    // ---- init MLP: tgnn_forward_bf16_begin's (this thread, this workspace and node count), or queued below
+    bool head_picked = false;
     {
         int devh = 0;
         TGNN_CHECK_HIP(hipGetDevice(&devh));
         Head64 *he = devh >= 0 && devh < 64 ? &g_head64[devh] : nullptr;
         if (he && he->ws && he->ws == ws && he->n == n) {
-            he->ws = nullptr;
+            head_picked = true;
             TGNN_CHECK_HIP(hipStreamWaitEvent(s, he->ev, 0));
-        } else {
-            if (he) he->ws = nullptr;
-            TGNN_TRY64(init_mlp64(dims, P, x, w, n, update_running, stream));
         }
+        if (he) he->ws = nullptr;
+    }
+    // ---- per-type NNConv matrices of all layers (fp32 table, then the bf16 operand images)
+    // [r6] on the side stream, beside the init MLP (the first NNConv waits for them; ~40 us of the head were serial) -- or, with the
+    // init MLP done by tgnn_forward_bf16_begin, on `stream` itself, straight behind the layout's preparation and BEHIND the release
+    // of the collision chain: no cross-queue hand-over in front of them or in front of the first NNConv (as tgnn_forward_resume)
+    hipStream_t sw = s;
+    auto queue_weights = [&]() {
+        if (T > 0) {
+            EdgeMlpLayers layers{};
+            for (int i = 0; i < D; ++i) {
+                const int b = P.layer(i);
+                layers.l[i] = EdgeMlpLayer{P.f(b), P.f(b + 1), P.f(b + 2), P.f(b + 3), P.f(b + 4), P.f(b + 5)};
+            }
+            launch_edge_weight_table_batched(adj_edge_attr, graph->type_rep_edge, T, fe, layers, D, kC, w.wtab, nullptr, nullptr, sw);
+        }
+        RootPtrs64 rp{};
+        for (int i = 0; i < D; ++i) rp.p[i] = P.f(P.layer(i) + 6);
+        nnconv64_image_kernel<<<dim3(T + 1, D), 256, 0, sw>>>(w.wtab, rp, T, w.wimg);
+    };
+    const bool weights_on_main = head_picked && s2 != nullptr;
+    if (!weights_on_main) {
+#ifndef TGNN_ABL_C3SERIALHEAD
+        if (s2)
+#else
+        if (false)
+#endif
+        {
+            TGNN_CHECK_HIP(hipEventRecord(ev[kEvFork64], s));    // what the caller queued on `stream` so far (x, the parameters, the layout)
+            TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[kEvFork64], 0));
+            sw = s2;
+        }
+        queue_weights();
+        if (sw != s) TGNN_CHECK_HIP(hipEventRecord(ev[kEvWeights64], s2));
+        if (!head_picked) TGNN_TRY64(init_mlp64(dims, P, x, w, n, update_running, stream));
     }
     // ---- main loop.  a2[i & 1] holds h2_i = the collision branch's BatchNorm OUTPUT (stored normalised, see the MLP kernel)
     TGNN_CHECK_HIP(hipMemsetAsync(w.ctr, 0, 64 * sizeof(unsigned), s));
@@ -1577,6 +1583,7 @@ extern "C" int tgnn_forward_bf16(const tgnn_model_dims *dims, const void *const 
         TGNN_CHECK_HIP(hipEventRecord(ev[0], s));
         TGNN_CHECK_HIP(hipStreamWaitEvent(s2, ev[0], 0));
     }
+    if (weights_on_main) queue_weights();                    // (sw == s)
     hipStream_t sc = s2 ? s2 : s;
     // [r6] the final MLP's Linears 1 .. 3 (256 -> 128 -> 64 -> 64, BatchNorm on load) on the fp32 path's fp16-pair kernels with W
     // resident in LDS (dense.hip: dense_f16_resident_kernel; bf16 x 3 block-tile kernels before: 84 + 31 + 31 us at 100 000 rows):
