@@ -71,6 +71,7 @@ class SubLayoutBuilder:
         self.err = self._tail[3:].view(torch.int32)[:1]
         self.ws_bytes = lib.tgnn_sublayout_workspace_bytes(self.n, self.ea, self.ec)
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        self._host = torch.empty(4, dtype=torch.int64, pin_memory=True)    # (`.cpu()` stages through a pageable tensor: ~10 us more per round)
 
     def build(self, alive: torch.Tensor) -> DeviceLayout:
         """alive: int32 [N] on the device (!= 0 = unlabelled).  One host sync (the three counts)."""
@@ -82,7 +83,9 @@ class SubLayoutBuilder:
                                          ptr(self.x_out), ptr(self.inverse), ptr(self.adj_out), ptr(self.attr_out),
                                          ptr(self.col_out), ptr(self.counts), ptr(self.err), ptr(self.ws), self.ws_bytes,
                                          _lib.current_stream(alive.device)))
-        n2, ea2, ec2, err = self._tail.cpu().tolist()
+        self._host.copy_(self._tail, non_blocking=True)
+        torch.cuda.current_stream(alive.device).synchronize()
+        n2, ea2, ec2, err = self._host.tolist()
         if err:
             raise IndexError("edge index out of range in the layout")
         return DeviceLayout(self.x_out[:n2], self.adj_out[:2 * ea2].view(2, ea2), self.attr_out[:ea2 * self.fe].view(ea2, self.fe),
