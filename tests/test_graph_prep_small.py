@@ -50,6 +50,32 @@ def test_labyrinth_layout(dev, monkeypatch):
     _same(ref, got)
 
 
+def test_result_words_by_copy_when_the_kernel_cannot_store_them(dev, monkeypatch):
+    """[r6] tgnn_graph_prep_small(..., result_host): the kernel stores the words into the pinned buffer and tgnn_graph_prep_wait polls
+    it; where that is not possible (here: polling switched off in the library while the caller still hands the buffer over) the
+    library copies them and the wait goes through its event -- the same graph either way, and with no buffer at all."""
+    from tilingnn_amd import _lib, ops
+    x, adj, attr, col, _ = graph_tensors(load_labyrinth_graph(), torch.float32, dev)
+    lib = _lib.lib
+    want = ops.prepare_graph(1254, adj, attr, col)                              # (kernel store + poll)
+    prev = lib.tgnn_set_prep_words_poll(0)
+    try:
+        plain = ops.prepare_graph(1254, adj, attr, col)                         # (no host buffer: copy + stream synchronise)
+
+        class Proxy:
+            def __getattr__(self, k):
+                if k == "tgnn_set_prep_words_poll":
+                    return lambda v: 1 if v < 0 else lib.tgnn_set_prep_words_poll(v)
+                return getattr(lib, k)
+        monkeypatch.setattr(ops, "lib", Proxy())
+        copied = ops.prepare_graph(1254, adj, attr, col)                        # (host buffer handed over, library copies)
+    finally:
+        lib.tgnn_set_prep_words_poll(prev)
+    for got in (plain, copied):
+        assert (got.n_types, got.n_col_edges, got.max_in_degree) == (want.n_types, want.n_col_edges, want.max_in_degree)
+        assert torch.equal(got.adj_rowptr.cpu(), want.adj_rowptr.cpu()) and torch.equal(got.col_src.cpu(), want.col_src.cpu())
+
+
 @pytest.mark.parametrize("n,ea,ec,t,seed", [(17, 68, 50, 13, 1), (300, 3000, 3750, 13, 2), (1000, 6800, 8350, 5, 3),
                                             (2500, 25000, 31250, 13, 4), (4096, 40960, 51200, 30, 5), (640, 6400, 8000, 60, 6)])
 def test_synthetic_layouts(dev, monkeypatch, n, ea, ec, t, seed):

@@ -1928,13 +1928,8 @@ extern "C" int tgnn_graph_prep_small(const int64_t *adj_edge_index, int64_t n_ad
             g_prep_poll[dev] = result_host;
             poll_dev = dev;
         } else {
-            (void)hipGetLastError();
-            set_error("tgnn_graph_prep_small: result_host is not host memory the device can address");
-            return TGNN_ERR_INVALID_ARG;
+            (void)hipGetLastError();                           // (not addressable by this device: the copy + event below instead)
         }
-    } else if (result_host) {
-        set_error("tgnn_graph_prep_small: result_host needs tgnn_set_prep_words_poll(1)");
-        return TGNN_ERR_INVALID_ARG;
     }
     // blocks: ~2048 edges each, and enough of them that a block's share of the adjacency edges fits its LDS table
     const int64_t emax = n_adj_edges > n_col_edges ? n_adj_edges : n_col_edges;
@@ -1958,6 +1953,12 @@ extern "C" int tgnn_graph_prep_small(const int64_t *adj_edge_index, int64_t n_ad
     if (rc != TGNN_OK) {
         if (poll_dev >= 0) g_prep_poll[poll_dev] = nullptr;   // (nothing was launched: nothing to wait for)
         return rc;
+    }
+    if (result_host && !A.result_host) {                     // the words by copy, tgnn_graph_prep_wait by event (as tgnn_graph_prep without polling)
+        hipEvent_t ev_words = nullptr;
+        TGNN_CHECK_HIP(prep_words_event(&ev_words));
+        TGNN_CHECK_HIP(hipMemcpyAsync(result_host, result, 32 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        TGNN_CHECK_HIP(hipEventRecord(ev_words, s));
     }
     TGNN_CHECK_LAUNCH();
     return TGNN_OK;
