@@ -721,6 +721,16 @@ int tgnn_greedy_round(const float *prob, int64_t ld_prob, const int64_t *inverse
                       int64_t n_col_edges, int32_t round, uint64_t seed, double *prob_saved, int32_t *alive,
                       int32_t *selected_round, int64_t *n_selected, int32_t *err_flag, void *ws, size_t ws_bytes,
                       tgnn_stream_t stream);
+/* [r6] The END of a greedy solve as one launch: on a sub-layout without adjacency edges (or without collision edges) every node
+ * gets probability 1 from ML_Solver.predict without the network (ml_solver.py:31-32), and so on every sub-layout of it -- the
+ * remaining rounds are tgnn_greedy_round with prob = 1 on ever smaller sub-layouts.  One block runs them all on the given
+ * sub-layout (n_sub <= tgnn_greedy_finish_max_nodes()): the same means, visiting order, draws and round numbers (first_round,
+ * first_round + 1, ...), hence the same selection as round by round.  out [2] (device): rounds run, nodes still unlabelled
+ * (0 unless max_rounds ran out). */
+int64_t tgnn_greedy_finish_max_nodes(void);
+int tgnn_greedy_finish(const int64_t *inverse, int64_t n_sub, const int64_t *col_edge_index, int64_t n_col_edges,
+                       int32_t first_round, int32_t max_rounds, uint64_t seed, double *prob_saved, int32_t *alive,
+                       int32_t *selected_round, int64_t *n_selected, int32_t *err_flag, int32_t *out, tgnn_stream_t stream);
 
 /* ---- the loss on the predict path -------------------------------------------------
  * Losses.calculate_unsupervised_loss (solver/ml_solver/losses.py:48-116), evaluated by ML_Solver.predict through

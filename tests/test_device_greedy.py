@@ -59,6 +59,58 @@ def test_device_greedy_selection_is_collision_free_maximal_and_seeded(dev, n):
     assert rounds <= 40 + 4 * int(np.log2(n))                   # O(log N) rounds, not O(sqrt N)
 
 
+@pytest.mark.parametrize("n,seed", [(300, 1), (3000, 7), (20000, 5)])
+def test_finishing_in_one_launch_is_the_round_by_round_solve(dev, n, seed):
+    """[r6] tgnn_greedy_finish: once the sub-layout has no adjacency (or no collision) edge left, the remaining rounds as one launch
+    on that sub-layout -- the same selection, order and round count as building every sub-layout and running tgnn_greedy_round."""
+    from tilingnn_amd.util import algorithms as alg
+    layout, col = _layout(n, dev, seed=3)
+    net, _ = make_net(dev)
+    ms = _solver(dev, net)
+    sel_a, _, order_a = alg.solve_by_device_greedy(ms, layout, seed=seed, finish=False)
+    rounds_a = alg.solve_by_device_greedy.last_rounds
+    net2, _ = make_net(dev)                                     # (the same running statistics at the start: train-mode forwards)
+    seen = []
+    orig = alg.lib.tgnn_greedy_finish
+
+    class Proxy:
+        def __getattr__(self, k):
+            if k == "tgnn_greedy_finish":
+                return lambda *a: (seen.append(int(a[1])), orig(*a))[1]
+            return getattr(_real, k)
+    _real = alg.lib
+    alg.lib = Proxy()
+    try:
+        sel_b, _, order_b = alg.solve_by_device_greedy(_solver(dev, net2), layout, seed=seed, finish=True)
+    finally:
+        alg.lib = _real
+    assert seen and seen[0] >= 1, "the solve never reached a sub-layout without adjacency edges"
+    assert np.array_equal(sel_a, sel_b) and order_a == order_b and alg.solve_by_device_greedy.last_rounds == rounds_a
+    _check_selection(sel_b, col, n)
+    print(f"n {n}: finished in one launch from {seen[0]} nodes, {rounds_a} rounds in all")
+
+
+@pytest.mark.parametrize("n,drop", [(3000, "adj"), (4096, "adj"), (2000, "col")])
+def test_a_layout_without_adjacency_or_collision_edges_is_one_launch(dev, n, drop):
+    """The whole solve inside tgnn_greedy_finish (thousands of nodes, many rounds, real collisions) against the round-by-round path."""
+    from tilingnn_amd.util import algorithms as alg
+    layout, col = _layout(n, dev, seed=4)
+    if drop == "adj":
+        layout = alg.DeviceLayout(layout.node_feature, layout.align_edge_index[:, :0], layout.align_edge_features[:0], layout.collide_edge_index)
+    else:
+        layout = alg.DeviceLayout(layout.node_feature, layout.align_edge_index, layout.align_edge_features, layout.collide_edge_index[:, :0])
+        col = col[:, :0]
+    net, _ = make_net(dev)
+    ms = _solver(dev, net)
+    sel_a, _, order_a = alg.solve_by_device_greedy(ms, layout, seed=11, finish=False)
+    rounds_a = alg.solve_by_device_greedy.last_rounds
+    sel_b, _, order_b = alg.solve_by_device_greedy(ms, layout, seed=11, finish=True)
+    assert np.array_equal(sel_a, sel_b) and order_a == order_b and alg.solve_by_device_greedy.last_rounds == rounds_a
+    assert rounds_a >= (2 if drop == "adj" else 1)      # (no collision edge: p = 1 in round 1, everything is accepted at once)
+    _check_selection(sel_b, col, n)
+    print(f"n {n} without {drop} edges: {int(np.sum(sel_b))} tiles in {rounds_a} rounds")
+
+
 def test_device_greedy_round_against_a_numpy_restatement(dev):
     """One round of tgnn_greedy_round on its own against the same rule in numpy (same running mean, same precedence, the same
     counter-based uniforms): exact agreement of the accepted set, the alive mask and the saved means."""

@@ -135,6 +135,8 @@ def _load() -> C.CDLL:
         "tgnn_shard_alive_rows": (C.c_int, [p, p, i64, i64, p, i64, p, i64, p, p, p]),
         "tgnn_greedy_round_workspace_bytes": (sz, [i64]),
         "tgnn_greedy_round": (C.c_int, [p, i64, p, i64, p, i64, i32, C.c_uint64, p, p, p, p, p, p, sz, p]),
+        "tgnn_greedy_finish_max_nodes": (i64, []),
+        "tgnn_greedy_finish": (C.c_int, [p, i64, p, i64, i32, i32, C.c_uint64, p, p, p, p, p, p, p]),
         "tgnn_unsupervised_loss_workspace_bytes": (sz, [i32]),
         "tgnn_unsupervised_loss": (C.c_int, [p, i64, i32, p, i64, i64, p, i64, p, i64, p, i64, f32, f32, f32, p, p, p, sz, p]),
         "tgnn_solution_score_sums": (C.c_int, [p, p, i64, p, i64, p, i64, p, i64, p, p, sz, p]),
@@ -241,7 +243,7 @@ EXPORTED_SYMBOLS = (
     "tgnn_forward_profiled", "tgnn_forward_profiled_two_stream", "tgnn_forward_stamped", "tgnn_forward_many", "tgnn_graph_prep_small_max_nodes", "tgnn_graph_prep_small_max_edges", "tgnn_graph_prep_small_tmp_ints",
     "tgnn_graph_prep_small", "tgnn_graph_prep_workspace_bytes", "tgnn_graph_prep", "tgnn_graph_prep_wait", "tgnn_set_small_layout_limit", "tgnn_get_small_layout_limit", "tgnn_set_split_precision", "tgnn_set_gin_fused", "tgnn_set_gin_mlp_f16", "tgnn_set_mid_tail", "tgnn_set_nnconv_eg", "tgnn_set_dense_rows_mode", "tgnn_set_lean_head", "tgnn_set_prep_words_poll", "tgnn_forward_begin_weights", "tgnn_forward_bf16_begin", "tgnn_forward_small_prepass", "tgnn_rccl_available", "tgnn_rccl_unique_id_bytes", "tgnn_rccl_unique_id", "tgnn_rccl_comm_create", "tgnn_rccl_comm_destroy", "tgnn_rccl_counters", "tgnn_forward_train", "tgnn_backward_workspace_bytes", "tgnn_backward", "tgnn_forward_sharded_workspace_bytes", "tgnn_forward_sharded",
     "tgnn_rows_gather", "tgnn_rows_scatter", "tgnn_unsupervised_loss_workspace_bytes", "tgnn_unsupervised_loss", "tgnn_solution_score_sums",
-    "tgnn_sublayout_workspace_bytes", "tgnn_sublayout_compact", "tgnn_greedy_round_workspace_bytes", "tgnn_greedy_round", "tgnn_shard_alive_rows",
+    "tgnn_sublayout_workspace_bytes", "tgnn_sublayout_compact", "tgnn_greedy_round_workspace_bytes", "tgnn_greedy_round", "tgnn_greedy_finish_max_nodes", "tgnn_greedy_finish", "tgnn_shard_alive_rows",
     "tgnn_transpose", "tgnn_swap_leading", "tgnn_gin_aggregate", "tgnn_sigmoid_bwd", "tgnn_add_into", "tgnn_reduce_workspace_bytes", "tgnn_colsum",
     "tgnn_bn_bwd_reduce", "tgnn_bn_bwd_apply", "tgnn_merge_bwd_reduce", "tgnn_wgrad_workspace_bytes", "tgnn_wgrad",
     "tgnn_sigmoid_mlp_bwd_workspace_bytes", "tgnn_sigmoid_mlp_bwd",

@@ -85,9 +85,108 @@ __global__ void greedy_label_kernel(const int64_t *__restrict__ col, int64_t ec,
     }
 }
 
+// [r6] The END of a solve as ONE launch: a sub-layout without adjacency edges (or without collision edges) gets probability 1 for
+// every node from ML_Solver.predict without the network (ml_solver.py:31-32), and so does every sub-layout of it -- the remaining
+// rounds are the four kernels above with prob = 1 on ever smaller sub-layouts.  One block runs them all on the sub-layout it is
+// given: nodes that have left (alive == 0) and the edges at them are skipped instead of compacted away; the geometric mean, the
+// visiting order (ties by node number: compaction keeps the order), the draws (keyed by seed, round and ORIGINAL node number) and
+// the round numbers are those of the round-by-round path, hence the same selection, order and round count.
+constexpr int kFinThreads = 1024;
+constexpr int kFinMaxNodes = 4096;
+__global__ __launch_bounds__(kFinThreads) void greedy_finish_kernel(const int64_t *__restrict__ inverse, int n_sub,
+                                                                    const int64_t *__restrict__ col, int64_t ec, int first_round,
+                                                                    int max_rounds, unsigned long long seed, double *__restrict__ saved,
+                                                                    int *__restrict__ alive, int *__restrict__ selected,
+                                                                    long long *__restrict__ count, int *__restrict__ err,
+                                                                    int *__restrict__ out) {   // out[0] rounds run, out[1] nodes left
+    __shared__ double p[kFinMaxNodes];
+    __shared__ __attribute__((aligned(16))) unsigned char flags[kFinMaxNodes];   // bit 0 beaten, bit 1 accepted, bit 2 gone, bit 3 leaving
+    __shared__ int left, accepted;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n_sub; i += kFinThreads) flags[i] = alive[inverse ? inverse[i] : i] ? 0 : 4;
+    __syncthreads();
+    int round = first_round, rounds_run = 0;
+    for (;; ++round) {
+        if (tid == 0) { left = 0; accepted = 0; }
+        __syncthreads();
+        int mine = 0;
+        for (int i = tid; i < n_sub; i += kFinThreads) {
+            if (flags[i] & 4) continue;
+            ++mine;
+            const int64_t o = inverse ? inverse[i] : i;
+            const double v = pow(pow(saved[o], (double)(round - 1)) * 1.0, 1.0 / (double)round);     // (greedy_mean_kernel, prob = 1)
+            saved[o] = v;
+            p[i] = v;
+            flags[i] = 0;
+        }
+        if (mine) atomicAdd(&left, mine);
+        __syncthreads();
+        if (left == 0 || rounds_run >= max_rounds) break;    // (uniform)
+        ++rounds_run;
+        for (int64_t e = tid; e < ec; e += kFinThreads) {      // greedy_beaten_kernel
+            const int64_t u = col[e], v = col[ec + e];
+            if (u < 0 || u >= n_sub || v < 0 || v >= n_sub) { *err = 1; continue; }
+            if (u == v || ((flags[u] | flags[v]) & 4)) continue;
+            const double pu = p[u], pv = p[v];
+            if (pv > pu || (pv == pu && v < u)) atomicOr(reinterpret_cast<unsigned *>(flags) + (u >> 2), 1u << (8 * (u & 3)));
+            else atomicOr(reinterpret_cast<unsigned *>(flags) + (v >> 2), 1u << (8 * (v & 3)));
+        }
+        __syncthreads();
+        int acc = 0;
+        for (int i = tid; i < n_sub; i += kFinThreads) {       // greedy_accept_kernel
+            if (flags[i] & 5) continue;
+            const int64_t o = inverse ? inverse[i] : i;
+            if (exp((p[i] - 1.0) * 1.0) > greedy_uniform(seed, (unsigned)round, (unsigned long long)o)) {
+                flags[i] |= 2;
+                alive[o] = 0;
+                selected[o] = round;
+                ++acc;
+            }
+        }
+        if (acc) atomicAdd(&accepted, acc);
+        __syncthreads();
+        for (int64_t e = tid; e < ec; e += kFinThreads) {      // greedy_label_kernel
+            const int64_t u = col[e], v = col[ec + e];
+            if (u < 0 || u >= n_sub || v < 0 || v >= n_sub) continue;
+            if ((flags[u] & 2) && !(flags[v] & 4)) {
+                alive[inverse ? inverse[v] : v] = 0;
+                atomicOr(reinterpret_cast<unsigned *>(flags) + (v >> 2), 8u << (8 * (v & 3)));   // bit 3: leaves behind this round
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < n_sub; i += kFinThreads)
+            if (flags[i] & (2 | 8)) flags[i] = 4;
+        if (tid == 0 && accepted) atomicAdd(reinterpret_cast<unsigned long long *>(count), (unsigned long long)accepted);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out[0] = rounds_run;
+        out[1] = left;
+    }
+}
+
 }  // namespace tgnn
 
 using namespace tgnn;
+
+extern "C" int64_t tgnn_greedy_finish_max_nodes(void) { return kFinMaxNodes; }
+
+/* The remaining rounds of a greedy solve on a sub-layout whose nodes all get probability 1 (no adjacency edge or no collision edge
+ * left: ml_solver.py:31-32) as one launch; see greedy_finish_kernel.  n_sub <= tgnn_greedy_finish_max_nodes().  out [2] (device):
+ * rounds run (first_round, first_round + 1, ...), nodes still unlabelled (0 unless max_rounds ran out). */
+extern "C" int tgnn_greedy_finish(const int64_t *inverse, int64_t n_sub, const int64_t *col_edge_index, int64_t n_col_edges,
+                                  int32_t first_round, int32_t max_rounds, uint64_t seed, double *prob_saved, int32_t *alive,
+                                  int32_t *selected_round, int64_t *n_selected, int32_t *err_flag, int32_t *out, tgnn_stream_t stream) {
+    DeviceGuard guard__(stream);
+    TGNN_CHECK_ARG(n_sub >= 1 && n_sub <= kFinMaxNodes && n_col_edges >= 0 && first_round >= 1 && max_rounds >= 1, "shape");
+    TGNN_CHECK_ARG(prob_saved && alive && selected_round && n_selected && err_flag && out, "null pointer");
+    TGNN_CHECK_ARG(n_col_edges == 0 || col_edge_index, "null edge index");
+    greedy_finish_kernel<<<1, kFinThreads, 0, static_cast<hipStream_t>(stream)>>>(
+        inverse, (int)n_sub, col_edge_index, n_col_edges, first_round, max_rounds, (unsigned long long)seed, prob_saved, alive,
+        selected_round, reinterpret_cast<long long *>(n_selected), err_flag, out);
+    TGNN_CHECK_LAUNCH();
+    return TGNN_OK;
+}
 
 extern "C" size_t tgnn_greedy_round_workspace_bytes(int64_t n_sub) {
     return align_up((size_t)(n_sub > 0 ? n_sub : 1) * sizeof(double), 256) + align_up((size_t)(n_sub > 0 ? n_sub : 1) * sizeof(int), 256) + 256;

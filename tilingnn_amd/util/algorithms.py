@@ -163,7 +163,7 @@ def solve_by_probablistic_greedy(ml_solver, origin_layout, score_fn=None, on_rou
     return sweep.selection, score, sweep.order
 
 
-def solve_by_device_greedy(ml_solver, origin_layout, seed=0, score_fn=None, on_round=None, max_rounds=100000):
+def solve_by_device_greedy(ml_solver, origin_layout, seed=0, score_fn=None, on_round=None, max_rounds=100000, finish=True):
     """The assembly loop with the acceptance BATCHED on the device (csrc/greedy.hip: tgnn_greedy_round) -- the documented
     substitute of the reference's sequential sweep (algorithms.py:41-54) for large layouts (BASELINE config 5: "batched greedy
     selection"): per round every node that precedes all its unlabelled collision neighbours in the reference's visiting order
@@ -171,7 +171,10 @@ def solve_by_device_greedy(ml_solver, origin_layout, seed=0, score_fn=None, on_r
     node).  NOT the reference's RNG stream -- `solve_by_probablistic_greedy` stays the default where seeded parity matters --
     but the same invariants: a collision-free selection, maximal when the loop ends, the same running geometric mean of the
     probabilities (:33-34).  O(log N) rounds of {compaction, forward, four small launches}; nothing but one count per round
-    travels to the host.  Same return values: (selection, score, predict_order); the order = by round, then by node number."""
+    travels to the host.  Same return values: (selection, score, predict_order); the order = by round, then by node number.
+    finish (no `on_round` given): once a sub-layout has no adjacency edge or no collision edge left -- from there on ML_Solver.predict
+    answers 1 for every node without the network (ml_solver.py:31-32) -- the remaining rounds run as ONE launch on that sub-layout
+    (tgnn_greedy_finish: the same means, order, draws and round numbers, hence the same selection and round count)."""
     device = ml_solver.device
     origin = origin_layout if isinstance(origin_layout, DeviceLayout) else DeviceLayout.upload(origin_layout, device)
     dev = origin.node_feature.device
@@ -194,6 +197,17 @@ def solve_by_device_greedy(ml_solver, origin_layout, seed=0, score_fn=None, on_r
             raise RuntimeError(f"solve_by_device_greedy: {n2} nodes still unlabelled after {max_rounds} rounds")
         if on_round is not None:
             on_round(sub)
+        ea2, ec2 = int(sub.align_edge_index.shape[1]), int(sub.collide_edge_index.shape[1])
+        if finish and on_round is None and (ea2 == 0 or ec2 == 0) and n2 <= int(lib.tgnn_greedy_finish_max_nodes()):
+            out = torch.zeros(2, dtype=torch.int32, device=dev)
+            check(lib.tgnn_greedy_finish(ptr(sub.inverse_index), n2, ptr(sub.collide_edge_index) if ec2 else None, ec2, rounds,
+                                         max_rounds - rounds + 1, int(seed) & (2 ** 64 - 1), ptr(saved), ptr(alive), ptr(selected),
+                                         ptr(tail[:1]), ptr(tail[1:].view(torch.int32)[:1]), ptr(out), _lib.current_stream(dev)))
+            ran, left = out.cpu().tolist()
+            rounds += ran - 1
+            if left:
+                raise RuntimeError(f"solve_by_device_greedy: {left} nodes still unlabelled after {max_rounds} rounds")
+            break
         probs = ml_solver.predict_on_device(sub)                # [n2] float32 on the device
         ec2 = int(sub.collide_edge_index.shape[1])
         check(lib.tgnn_greedy_round(ptr(probs), 1, ptr(sub.inverse_index), n2, ptr(sub.collide_edge_index) if ec2 else None, ec2,
